@@ -1,0 +1,134 @@
+/* roreg_hip.h -- C-ABI of libroreg_hip.so: the MI355X (gfx950) kernels behind RoReg's per-pair
+ * registration hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; buffers are owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); nothing synchronises;
+ *   - every entry point returns 0 on success, non-zero on failure (roreg_last_error() has the text);
+ *   - tensors are C-contiguous; "f32 [B,C,60]" means float32 with 60 fastest;
+ *   - group tables (P 60x60, Nei 60x13) are uploaded once with roreg_set_group_tables().
+ *
+ * Each entry cites the reference code it replaces (paths relative to the RoReg checkout).
+ */
+#ifndef ROREG_HIP_H
+#define ROREG_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int roreg_abi_version(void);
+const char *roreg_last_error(void);
+
+/* Upload the icosahedral tables: P[a*60+g] = index(R_g R_a) ("60_60.npy"), Nei[g*13+k]
+ * ("Nei_Index_in_SO3_ordered_13.npy"), R[60*9] float64 ("Rotation.npy").  Host pointers.
+ * Replaces the per-module np.load(...).cuda() at network/group_feat.py:12-14, rot_detect.py:39-40,
+ * eqv_trans.py:83-86, rot_coh_match.py:127, test/estimator.py:78,374-375. */
+int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_host, const double *R_host);
+
+/* ---- icosahedral group convolution (the MFMA kernel) --------------------------------------------
+ * out[b,o,j] = bias[o] + sum_c sum_k W[o,c,k] * act(x)[b,c,gather[j*KS+k]]  (+ residual[b,o,j])
+ *   act(x) = relu(x*bn_scale[c] + bn_shift[c]) when bn_scale != NULL, else x.
+ * x is [B,Cin,Lin], out/residual are [B,Cout,Lout]; gather is int32 [Lout*KS] with values in [0,Lin).
+ * For the full conv Lin=Lout=60, KS=13, gather=Nei.  Pruned layers (ET: only the group columns that can
+ * reach g=0 are live) use Lout<60 and a composed gather; KS=1 gives the 1x1 convs of the ET head.
+ * wpack is the weight tensor re-laid out by roreg_group_conv_pack_weights().
+ * Replaces: data_process gather + BatchNorm2d(eval)+ReLU+Conv2d(C,O,(1,13)) at network/group_feat.py:16-33,
+ * network/ops.py:11-64, network/eqv_trans.py:88-117,130-136, network/rot_detect.py:41,46. */
+size_t roreg_group_conv_packed_size(int Cin, int Cout, int KS);            /* in floats */
+int roreg_group_conv_pack_weights(const float *W_host /* [Cout,Cin,KS] */, int Cin, int Cout, int KS,
+                                  float *wpack_host /* roreg_group_conv_packed_size floats */);
+int roreg_group_conv(const float *x, const float *wpack, const float *bias,
+                     const float *bn_scale, const float *bn_shift, const float *residual,
+                     float *out, const int32_t *gather,
+                     int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
+
+/* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
+ * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
+int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream);
+
+/* ---- detector ------------------------------------------------------------------------------------
+ * enc [B,16,60] -> scores[b] = std_a( sum_f sum_g fn[f,P[a,g]] fn[f,g] ), fn = enc/||enc||_2 over 16 ch,
+ * unbiased std over the 60 a's.  network/rot_detect.py:47-52. */
+int roreg_det_score(const float *enc, float *scores, int B, void *stream);
+
+/* ---- descriptors / nearest neighbours ------------------------------------------------------------
+ * eqv [N,32,60] -> inv [N,32] = mean_g / (||.||_2 + 1e-5).  test/matcher.py:69-72. */
+int roreg_inv_descriptor(const float *eqv, float *inv, int N, void *stream);
+
+/* For every source row the nearest target row: d = sqrt(sum_f (s_f-t_f)^2 + 1e-7) accumulated in f order
+ * (fp32, no FMA), first minimum wins.  src [m,F], tgt [n,F] row-major; optional row index lists
+ * (src_rows/tgt_rows, int64, NULL = identity) select sampled keypoints without a gather copy.
+ * idx_out int64 [m] (position within the target list), dist_out f32 [m] (may be NULL); scratch is m
+ * uint64 of caller-owned workspace (packed (distance,index) keys merged across target slices by atomicMin).
+ * Replaces knn_module.KNN(1).__call__ -> find_nn_gpu  (utils/knn_search.py:17-66,138-156). */
+int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
+                    const float *tgt, const int64_t *tgt_rows, int n, int F,
+                    int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream);
+
+/* k nearest (k<=8) targets per source in increasing distance, first index on ties; idx_out int64 [m,k].
+ * Replaces KNN(k>=2) -> find_knn_gpu (utils/knn_search.py:68-103), used by NMS_sample with F=3, k=5
+ * (test/matcher.py:21-23). */
+int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k,
+                     int64_t *idx_out, void *stream);
+
+/* Mutual check + ordered compaction: for i in 0..m-1 (increasing) keep (i, nn01[i]) iff nn10[nn01[i]]==i;
+ * pairs are mapped through sample0/sample1 (int64, NULL = identity) and written to match_out int64 [*,2];
+ * *count_out (device int32) receives the number kept.  test/matcher.py:98-107. */
+int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m,
+                         const int64_t *sample0, const int64_t *sample1,
+                         int64_t *match_out, int32_t *count_out, void *stream);
+
+/* ---- estimator -----------------------------------------------------------------------------------
+ * Per correspondence b: cor[a] = sum_f ( sum_g d1[f,P[a,g]] d2[f,g] ), argmax_a (first max).
+ * d1 = feats1[rows1[b]], d2 = feats0[rows0[b]] with feats* f32 [N,32,60]; rows* int64 (NULL = b itself).
+ * idx_out int64 [M]; cor_out f32 [M,60] optional.
+ * Replaces extractor_dr_index.Batch_Des2R_torch (test/estimator.py:85-89) and the gathers at :108-110. */
+int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, const int64_t *rows0,
+                int M, int64_t *idx_out, float *cor_out, void *stream);
+
+/* Build the ET network input x [M,128,60] = cat(before1[r1][:, :, P[a]], before0[r0], after1[r1][:, :, P[a]],
+ * after0[r0]) for correspondence rows (r0,r1) and anchor a=pre_idx[b].
+ * Replaces batch_create + the per-row permutation loop (test/estimator.py:293-306; network/eqv_trans.py:126-129). */
+int roreg_et_gather(const float *before0, const float *before1, const float *after0, const float *after1,
+                    const int64_t *rows0, const int64_t *rows1, const int64_t *pre_idx, int M,
+                    float *x_out, void *stream);
+
+/* q [M,4] f32 (un-normalised head output) -> q/||q||; R = R(q) (fp32 arithmetic as utils/r_eval.py:90-106
+ * on float32 inputs) promoted to f64, times Rgroup[a] (the float32-rounded table, as test/estimator.py:279);
+ * t = key0 - key1 R^T (f64).  Trans_out f64 [M,3,4]; quat_out f32 [M,4] optional (normalised).
+ * Replaces eqv_trans.py:137 and test/estimator.py:350-366. */
+int roreg_quat_to_trans(const float *q, const int64_t *anchor, const double *keys0, const int64_t *rows0,
+                        const double *keys1, const int64_t *rows1, int M,
+                        double *Trans_out, float *quat_out, void *stream);
+
+/* One-shot RANSAC scoring (fp64, no FMA).  For hypothesis h (3x4 row-major in Trans[hyp_rows[h]], hyp_rows
+ * int64, NULL = identity): overlap[h] = sum_{i: ||k0_i - (R k1_i + t)||^2 < ird^2} w_i / M, accumulated in
+ * increasing i.  k0,k1 f64 [M,3] (already gathered by match), w f64 [M].  best_out (device int32[1]) gets
+ * the first h with the strictly greatest overlap (estimator.py:430-436; -1 if every overlap is 0);
+ * mask_out (uint8 [H,M], optional) the inlier masks.
+ * Replaces yohoo_ransac.overlap_cal and the hypothesis loop (test/estimator.py:377-382,426-436). */
+int roreg_ransac_score(const double *k0, const double *k1, const double *w, int M,
+                       const double *Trans, const int64_t *hyp_rows, int H, double ird,
+                       double *overlap_out, int32_t *best_out, uint8_t *mask_out, void *stream);
+
+/* Refinement step: inliers of T_in (3x4 taken from T_in, or from Trans[hyp_rows[*best]] when best!=NULL)
+ * at threshold `dist`; weights w/sum(w); weighted centroids; H = (k0-c0)^T diag(w) (k1-c1); R = U V^T of
+ * the 3x3 SVD (no reflection guard); t = c0 - c1 R^T.  T_out f64 [4,4].
+ * Replaces refiner.Refine_trans (test/estimator.py:28-72). */
+int roreg_refine(const double *k0, const double *k1, const double *w, int M,
+                 const double *T_in, int t_in_stride /* 4 for 3x4/4x4 rows */,
+                 const double *Trans, const int64_t *hyp_rows, const int32_t *best,
+                 double dist, double *T_out, void *stream);
+
+/* Gather rows: out[i] = src[rows[i]] for f64 [.,3] keypoints (estimator.py:407-408). */
+int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROREG_HIP_H */

@@ -1,0 +1,47 @@
+// Shared helpers for libroreg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "roreg_hip.h"
+
+#define ROREG_G 60
+#define ROREG_K 13
+#define ROREG_F 32
+
+namespace roreg {
+
+void set_error(const char *fmt, ...);
+
+// device-resident group tables (uploaded once by roreg_set_group_tables)
+struct GroupTablesDev {
+    int32_t *P;      // [60*60]  P[a*60+g]
+    int32_t *Nei;    // [60*13]
+    uint8_t *P8;     // [60*60]  same as P, one byte per entry (LDS friendly)
+    double *R;       // [60*9]   float64 rotations
+    float *Rf;       // [60*9]   float32-rounded rotations (test/estimator.py:279 .astype(np.float32))
+    bool ready;
+};
+const GroupTablesDev &group_tables();
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define ROREG_CHECK_LAUNCH(name)                                                     \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            roreg::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+#define ROREG_REQUIRE(cond, ...)         \
+    do {                                 \
+        if (!(cond)) {                   \
+            roreg::set_error(__VA_ARGS__); \
+            return 2;                    \
+        }                                \
+    } while (0)
+
+}  // namespace roreg

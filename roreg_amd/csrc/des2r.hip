@@ -1,0 +1,82 @@
+// Per-correspondence 60x60 local-rotation cross-correlation and its argmax (coarse rotation index).
+//
+//   cor[a] = sum_f ( sum_g d1[f, P[a,g]] * d2[f, g] ),   a* = first argmax_a cor[a]
+//
+// One wavefront per correspondence: lane a (< 60) owns cor[a].  d1 (the side that is permuted) is staged in
+// LDS because each lane walks it through its own row of the permutation table; d2 is read by every lane at
+// the same address, so it stays in registers (lane g holds column g) and is broadcast with v_readlane.
+// The accumulation order is the contract (s_f over g in order, then over f in order; fp32, no FMA
+// contraction) so the index is bit-identical to the oracle's on the same input.
+// Reference: extractor_dr_index.Batch_Des2R_torch, test/estimator.py:85-89 (gathers at :108-110).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,
+                                                    const float *__restrict__ feats0, const int64_t *__restrict__ rows0,
+                                                    const uint8_t *__restrict__ P8, int M, int64_t *__restrict__ idx_out,
+                                                    float *__restrict__ cor_out) {
+    __shared__ float d1s[4][ROREG_F * ROREG_G];
+    __shared__ uint8_t Pl[ROREG_G * ROREG_G];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < ROREG_G * ROREG_G; i += 256) Pl[i] = P8[i];
+    const int b = blockIdx.x * 4 + w;
+    const bool live = b < M;
+    const size_t r1 = live ? (rows1 ? (size_t)rows1[b] : (size_t)b) : 0;
+    const size_t r0 = live ? (rows0 ? (size_t)rows0[b] : (size_t)b) : 0;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(feats1 + r1 * (ROREG_F * ROREG_G));
+        float4 *dst = reinterpret_cast<float4 *>(d1s[w]);
+        for (int i = lane; i < ROREG_F * ROREG_G / 4; i += 64) dst[i] = src[i];
+    }
+    const bool act = lane < ROREG_G;
+    float d2[ROREG_F];
+    {
+        const float *src = feats0 + r0 * (ROREG_F * ROREG_G);
+#pragma unroll
+        for (int f = 0; f < ROREG_F; ++f) d2[f] = act ? src[f * ROREG_G + lane] : 0.f;
+    }
+    __syncthreads();
+    if (!live) return;
+
+    float s[ROREG_F];
+#pragma unroll
+    for (int f = 0; f < ROREG_F; ++f) s[f] = 0.f;
+    const uint8_t *prow = Pl + (act ? lane : 0) * ROREG_G;
+    for (int g = 0; g < ROREG_G; ++g) {
+        const int pg = prow[g];
+#pragma unroll
+        for (int f = 0; f < ROREG_F; ++f) {
+            const float bcast = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d2[f]), g));
+            s[f] = __fadd_rn(s[f], __fmul_rn(d1s[w][f * ROREG_G + pg], bcast));
+        }
+    }
+    float cor = 0.f;
+#pragma unroll
+    for (int f = 0; f < ROREG_F; ++f) cor = __fadd_rn(cor, s[f]);
+    if (cor_out && act) cor_out[(size_t)b * ROREG_G + lane] = cor;
+    // first argmax over lanes 0..59: order by (value desc, lane asc)
+    float bv = act ? cor : -__builtin_inff();
+    int bi = act ? lane : 0x7fffffff;
+    if (bv != bv) bv = -__builtin_inff();      // NaN never wins (torch.argmax would pick it; inputs are finite)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) idx_out[b] = bi;
+}
+
+}  // namespace
+
+extern "C" int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, const int64_t *rows0, int M,
+                           int64_t *idx_out, float *cor_out, void *stream) {
+    ROREG_REQUIRE(feats1 && feats0 && idx_out && M >= 0, "roreg_des2r: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_des2r: group tables not set");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(des2r_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), feats1, rows1, feats0, rows0,
+                       roreg::group_tables().P8, M, idx_out, cor_out);
+    ROREG_CHECK_LAUNCH("roreg_des2r");
+    return 0;
+}

@@ -1,0 +1,262 @@
+// Icosahedral group convolution on the gfx950 matrix cores (exact-f32 MFMA, v_mfma_f32_32x32x2_f32).
+//
+//   out[b,o,j] = bias[o] + sum_{k<KS} sum_{c<Cin} W[o,c,k] * act(x[b,c,gather[j,k]])   (+ residual[b,o,j])
+//
+// GEMM view: rows = output channels o (MFMA A operand = weights), columns = flattened (keypoint b, live group
+// column j) pairs (MFMA B operand = activations), reduction = (k, c) with c innermost.  The 13-stencil gather
+// is never materialised: each workgroup stages the [keypoints][CT channels][Lin] activation slab of its
+// columns in LDS once per channel chunk (BatchNorm(eval)+ReLU applied while staging, because ReLU sits
+// between BN and the conv so BN cannot be folded into W), and every lane reads its B value at
+// slab[row(b)][c][gather[j,k]] with one ds_read_b32 -- the stencil is an LDS address, not a tensor.
+//
+// Weights are pre-packed (roreg_group_conv_pack_weights) so that the A fragment of four consecutive MFMA
+// k-steps is ONE 16-byte load per lane, fully coalesced (1 KiB per wave instruction):
+//   wpack float4 index ((k*(Cin/8) + c/8)*CoutPad + o)*2 + h  holds  W[o, 8*(c/8) + 2r + h, k], r = 0..3
+// (h = lane>>5 is the MFMA k-half, so step r of the block multiplies channel pair (8*(c/8)+2r, +1)).
+//
+// Workgroup = 4 waves; wave tile = (OTW*32 output channels) x (4 column tiles of 32); the WO x WB wave grid
+// gives a workgroup tile of (WO*OTW*32) x (WB*128).  Accumulators: OTW*4 tiles x 16 VGPRs.
+//
+// Reference semantics: network/group_feat.py:16-33, network/ops.py:11-64, network/eqv_trans.py:88-117,130-136.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct GCParams {
+    const float *x;
+    const float4 *wp;
+    const float *bias;
+    const float *bn_scale;
+    const float *bn_shift;
+    const float *residual;
+    float *out;
+    const int32_t *gather;
+    int B, Cin, Cout, CoutPad, Lout, ncols, gt_bytes;
+};
+
+template <int KS, int LIN, int CT, int WO, int WB, int OTW>
+__global__ __launch_bounds__(256, 2) void group_conv_kernel(GCParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *gt = reinterpret_cast<int *>(smem);
+    float *xs = reinterpret_cast<float *>(smem + p.gt_bytes);
+
+    constexpr int OT = WO * OTW * 32;
+    constexpr int NCOL = WB * 128;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n_ot = p.CoutPad / OT;
+    const int ot_idx = blockIdx.x % n_ot, ct_idx = blockIdx.x / n_ot;
+    const int wo = w % WO, wb = w / WO;
+    const int o_wave = ot_idx * OT + wo * (OTW * 32);
+    const int col0 = ct_idx * NCOL;
+    const int b_first = col0 / p.Lout;
+    const int col_last = min(col0 + NCOL, p.ncols) - 1;
+    const int nkp = col_last / p.Lout - b_first + 1;
+
+    for (int i = tid; i < p.Lout * KS; i += 256) gt[i] = p.gather[i];
+
+    int rowbase[4], gi[4], bcol[4];
+    bool valid[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = col0 + wb * 128 + t * 32 + j;
+        valid[t] = n < p.ncols;
+        const int nn = valid[t] ? n : col0;
+        const int b = nn / p.Lout;
+        gi[t] = nn - b * p.Lout;
+        bcol[t] = b;
+        rowbase[t] = (b - b_first) * (CT * LIN) + h * LIN;
+    }
+
+    f32x16 acc[OTW][4];
+#pragma unroll
+    for (int a = 0; a < OTW; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    const bool has_bn = p.bn_scale != nullptr;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CT) {
+        __syncthreads();   // previous chunk fully consumed (also orders the gather-table fill)
+        // ---- stage act(x[b_first .. b_first+nkp) [c0 .. c0+CT) [0 .. LIN)) into LDS -----------------
+        if constexpr (LIN % 4 == 0) {
+            constexpr int PER_KP4 = CT * LIN / 4;
+            const int total4 = nkp * PER_KP4;
+            const float4 *x4 = reinterpret_cast<const float4 *>(p.x);
+            float4 *xs4 = reinterpret_cast<float4 *>(xs);
+            for (int i = tid; i < total4; i += 256) {
+                const int kp = i / PER_KP4, e4 = i - kp * PER_KP4;
+                const int c = (e4 * 4) / LIN;
+                float4 v = x4[((size_t)(b_first + kp) * p.Cin + c0) * (LIN / 4) + e4];
+                if (has_bn) {
+                    const float s = p.bn_scale[c0 + c], sh = p.bn_shift[c0 + c];
+                    v.x = fmaxf(fmaf(v.x, s, sh), 0.f);
+                    v.y = fmaxf(fmaf(v.y, s, sh), 0.f);
+                    v.z = fmaxf(fmaf(v.z, s, sh), 0.f);
+                    v.w = fmaxf(fmaf(v.w, s, sh), 0.f);
+                }
+                xs4[i] = v;
+            }
+        } else {
+            constexpr int PER_KP = CT * LIN;
+            const int total = nkp * PER_KP;
+            for (int i = tid; i < total; i += 256) {
+                const int kp = i / PER_KP, e = i - kp * PER_KP;
+                const int c = e / LIN;
+                float v = p.x[((size_t)(b_first + kp) * p.Cin + c0) * LIN + e];
+                if (has_bn) v = fmaxf(fmaf(v, p.bn_scale[c0 + c], p.bn_shift[c0 + c]), 0.f);
+                xs[i] = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA over (k, c in chunk) ----------------------------------------------------------------
+#pragma unroll 1
+        for (int k = 0; k < KS; ++k) {
+            int off[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) off[t] = rowbase[t] + gt[gi[t] * KS + k];
+            const float4 *wk = p.wp + ((size_t)(k * (p.Cin / 8) + c0 / 8) * p.CoutPad + o_wave + j) * 2 + h;
+#pragma unroll
+            for (int q = 0; q < CT / 8; ++q) {
+                float4 a[OTW];
+#pragma unroll
+                for (int ot = 0; ot < OTW; ++ot) a[ot] = wk[((size_t)q * p.CoutPad + ot * 32) * 2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float bv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bv[t] = xs[off[t] + (q * 8 + r * 2) * LIN];
+#pragma unroll
+                    for (int ot = 0; ot < OTW; ++ot) {
+                        const float av = r == 0 ? a[ot].x : r == 1 ? a[ot].y : r == 2 ? a[ot].z : a[ot].w;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[ot][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias (+ residual), masked store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int ot = 0; ot < OTW; ++ot) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (!valid[t]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < p.Cout) {
+                    const size_t idx = ((size_t)bcol[t] * p.Cout + o) * p.Lout + gi[t];
+                    float v = acc[ot][t][r] + p.bias[o];
+                    if (p.residual) v += p.residual[idx];
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <int KS, int LIN, int CT, int WO, int WB, int OTW>
+int launch(GCParams p, hipStream_t stream) {
+    constexpr int OT = WO * OTW * 32;
+    constexpr int NCOL = WB * 128;
+    if (p.CoutPad % OT != 0) {
+        roreg::set_error("roreg_group_conv: Cout pad %d not a multiple of the %d-row tile", p.CoutPad, OT);
+        return 2;
+    }
+    if (p.Cin % CT != 0) {
+        roreg::set_error("roreg_group_conv: Cin %d not a multiple of the %d-channel chunk", p.Cin, CT);
+        return 2;
+    }
+    p.gt_bytes = round_up(p.Lout * KS * 4, 16);
+    int nkp_max = (NCOL - 1) / p.Lout + 2;
+    if (nkp_max > p.B) nkp_max = p.B;
+    const size_t lds = (size_t)p.gt_bytes + (size_t)nkp_max * CT * LIN * 4;
+    if (lds > 160 * 1024) {
+        roreg::set_error("roreg_group_conv: tile needs %zu B of LDS", lds);
+        return 2;
+    }
+    auto kern = group_conv_kernel<KS, LIN, CT, WO, WB, OTW>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            roreg::set_error("roreg_group_conv: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return 1;
+        }
+    }
+    const int n_ct = (p.ncols + NCOL - 1) / NCOL;
+    const int grid = n_ct * (p.CoutPad / OT);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    ROREG_CHECK_LAUNCH("roreg_group_conv");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t roreg_group_conv_packed_size(int Cin, int Cout, int KS) {
+    return (size_t)KS * Cin * round_up(Cout, 32);
+}
+
+extern "C" int roreg_group_conv_pack_weights(const float *W, int Cin, int Cout, int KS, float *wp) {
+    ROREG_REQUIRE(W && wp, "roreg_group_conv_pack_weights: null pointer");
+    ROREG_REQUIRE(Cin % 8 == 0 && Cin > 0 && Cout > 0 && (KS == 13 || KS == 1),
+                  "roreg_group_conv_pack_weights: unsupported shape Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
+    const int CoutPad = round_up(Cout, 32);
+    memset(wp, 0, sizeof(float) * roreg_group_conv_packed_size(Cin, Cout, KS));
+    for (int k = 0; k < KS; ++k)
+        for (int cb = 0; cb < Cin / 8; ++cb)
+            for (int o = 0; o < Cout; ++o)
+                for (int h = 0; h < 2; ++h)
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = cb * 8 + 2 * r + h;
+                        wp[((((size_t)k * (Cin / 8) + cb) * CoutPad + o) * 2 + h) * 4 + r] =
+                            W[((size_t)o * Cin + c) * KS + k];
+                    }
+    return 0;
+}
+
+extern "C" int roreg_group_conv(const float *x, const float *wpack, const float *bias, const float *bn_scale,
+                                const float *bn_shift, const float *residual, float *out, const int32_t *gather,
+                                int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+    ROREG_REQUIRE(x && wpack && bias && out && gather, "roreg_group_conv: null pointer");
+    ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv: bn_scale/bn_shift must come together");
+    ROREG_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Lout > 0 && Lin > 0, "roreg_group_conv: bad sizes");
+    if (B == 0) return 0;
+    ROREG_REQUIRE((long long)B * Lout < (1ll << 31), "roreg_group_conv: too many columns");
+    GCParams p;
+    p.x = x; p.wp = reinterpret_cast<const float4 *>(wpack); p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+    p.residual = residual; p.out = out; p.gather = gather;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = round_up(Cout, 32); p.Lout = Lout; p.ncols = B * Lout; p.gt_bytes = 0;
+    hipStream_t s = roreg::as_stream(stream);
+    const int cp = p.CoutPad;
+    if (KS == 13 && Lin == 60) {
+        if (cp % 128 == 0) return launch<13, 60, 32, 2, 2, 2>(p, s);
+        if (cp % 64 == 0) return launch<13, 60, 16, 1, 4, 2>(p, s);
+        return launch<13, 60, 16, 1, 4, 1>(p, s);
+    }
+    if (KS == 13 && Lin == 45) {
+        if (cp % 128 == 0) return launch<13, 45, 16, 2, 2, 2>(p, s);
+        return launch<13, 45, 16, 1, 4, 1>(p, s);
+    }
+    if (KS == 13 && Lin == 13) {
+        if (cp % 256 == 0) return launch<13, 13, 8, 4, 1, 2>(p, s);
+        return launch<13, 13, 8, 1, 4, 1>(p, s);
+    }
+    if (KS == 1 && Lin == 1) {
+        if (cp % 128 == 0) return launch<1, 1, 32, 2, 2, 2>(p, s);
+        return launch<1, 1, 32, 1, 4, 1>(p, s);
+    }
+    roreg::set_error("roreg_group_conv: unsupported (KS=%d, Lin=%d)", KS, Lin);
+    return 2;
+}

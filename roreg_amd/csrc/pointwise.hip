@@ -1,0 +1,287 @@
+// Streaming (HBM-bound) kernels of the path: descriptor normalisation, invariant descriptors, the detector's
+// 60x60 self-correlation, ET input assembly and the quaternion -> local-transform assembly.
+#include "common.h"
+
+namespace {
+
+// numpy's pairwise float32 sum for a contiguous run of n (8 <= n <= 128) elements, reproduced exactly
+// (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum): eight strided partial sums, a fixed
+// combine tree, then the tail.  Used so that the matcher's invariant descriptor (np.mean / np.sum,
+// test/matcher.py:69-72) is bit-identical to the reference's on the same input.
+__device__ __forceinline__ float np_pairwise_sum(const float *a, int n) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+    }
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+    return res;
+}
+
+// ---- gf_finalize: one wave per keypoint ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void gf_finalize_kernel(const float *__restrict__ raw, float *__restrict__ eqv,
+                                                          float *__restrict__ inv, int B) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= B) return;
+    const float *src = raw + (size_t)b * (ROREG_F * ROREG_G);
+    float *dst = eqv + (size_t)b * (ROREG_F * ROREG_G);
+    const bool act = lane < ROREG_G;
+    float v[ROREG_F];
+    float n2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < ROREG_F; ++f) {
+        v[f] = act ? src[f * ROREG_G + lane] : 0.f;
+        n2 += v[f] * v[f];
+    }
+    const float nrm = fmaxf(sqrtf(n2), 1e-4f);
+    if (act) {
+#pragma unroll
+        for (int f = 0; f < ROREG_F; ++f) dst[f * ROREG_G + lane] = v[f] / nrm;
+    }
+    if (inv) {
+        // mean over g of the un-normalised features, then normalise over the 32 channels
+        float mine = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int f = 0; f < ROREG_F; ++f) {
+            float s = v[f];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s *= (1.0f / ROREG_G);
+            m2 += s * s;
+            if (lane == f) mine = s;
+        }
+        const float mn = fmaxf(sqrtf(m2), 1e-4f);
+        if (lane < ROREG_F) inv[(size_t)b * ROREG_F + lane] = mine / mn;
+    }
+}
+
+// ---- inv_descriptor: one wave per keypoint; lanes 0..31 own one channel row each ---------------------
+__global__ __launch_bounds__(256) void inv_descriptor_kernel(const float *__restrict__ eqv, float *__restrict__ inv, int N) {
+    __shared__ float tile[4][ROREG_F * ROREG_G + 32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + w;
+    const bool live = n < N;
+    if (live) {
+        const float4 *src = reinterpret_cast<const float4 *>(eqv + (size_t)n * (ROREG_F * ROREG_G));
+        float4 *t4 = reinterpret_cast<float4 *>(tile[w]);
+        for (int i = lane; i < ROREG_F * ROREG_G / 4; i += 64) t4[i] = src[i];
+    }
+    __syncthreads();
+    if (!live) return;
+    float m = 0.f;
+    if (lane < ROREG_F) {
+        float row[ROREG_G];
+#pragma unroll
+        for (int g = 0; g < ROREG_G; ++g) row[g] = tile[w][lane * ROREG_G + g];
+        // np.mean(axis=-1) on float32: float32 pairwise sum, then true_divide by the np.intp count, which
+        // numpy >= 2 evaluates in float64 and casts back (numpy/_core/_methods.py:_mean)
+        m = (float)((double)np_pairwise_sum(row, ROREG_G) / 60.0);
+    }
+    // sum of squares over the 32 channels in numpy's pairwise order (n=32: 8 partials, 4 rounds)
+    float sq[ROREG_F];
+#pragma unroll
+    for (int f = 0; f < ROREG_F; ++f) {
+        const float mf = __shfl(m, f);
+        sq[f] = __fmul_rn(mf, mf);
+    }
+    const float nrm = __fadd_rn(__fsqrt_rn(np_pairwise_sum(sq, ROREG_F)), 1e-5f);
+    if (lane < ROREG_F) inv[(size_t)n * ROREG_F + lane] = __fdiv_rn(m, nrm);
+}
+
+// ---- det_score: one wave per keypoint ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void det_score_kernel(const float *__restrict__ enc, const uint8_t *__restrict__ P8,
+                                                        float *__restrict__ scores, int B) {
+    __shared__ float fn[4][16 * ROREG_G];
+    __shared__ uint8_t Pl[ROREG_G * ROREG_G];
+    for (int i = threadIdx.x; i < ROREG_G * ROREG_G; i += 256) Pl[i] = P8[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    const bool live = b < B;
+    const float *src = enc + (size_t)(live ? b : 0) * (16 * ROREG_G);
+    const bool act = lane < ROREG_G;
+    float v[16];
+    float n2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        v[f] = act ? src[f * ROREG_G + lane] : 0.f;
+        n2 += v[f] * v[f];
+    }
+    const float rn = sqrtf(n2);
+    if (act) {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) fn[w][f * ROREG_G + lane] = v[f] / rn;
+    }
+    __syncthreads();
+    if (!live) return;
+    float c = 0.f;
+    if (act) {
+        float s[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) s[f] = 0.f;
+        for (int g = 0; g < ROREG_G; ++g) {
+            const int pg = Pl[lane * ROREG_G + g];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) s[f] += fn[w][f * ROREG_G + pg] * fn[w][f * ROREG_G + g];
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) c += s[f];
+    }
+    // unbiased std over the 60 lanes
+    float sum = act ? c : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / ROREG_G);
+    float d = act ? (c - mean) : 0.f;
+    float ss = d * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) scores[b] = sqrtf(ss / (ROREG_G - 1));
+}
+
+// ---- et_gather: one block per correspondence ------------------------------------------------------------
+__global__ __launch_bounds__(256) void et_gather_kernel(const float *__restrict__ before0, const float *__restrict__ before1,
+                                                        const float *__restrict__ after0, const float *__restrict__ after1,
+                                                        const int64_t *__restrict__ rows0, const int64_t *__restrict__ rows1,
+                                                        const int64_t *__restrict__ pre_idx, const int32_t *__restrict__ P,
+                                                        float *__restrict__ x, int M) {
+    const int b = blockIdx.x;
+    if (b >= M) return;
+    __shared__ int perm[ROREG_G];
+    const int a = (int)pre_idx[b];
+    if (threadIdx.x < ROREG_G) perm[threadIdx.x] = P[a * ROREG_G + threadIdx.x];
+    __syncthreads();
+    const size_t r0 = rows0 ? (size_t)rows0[b] : (size_t)b, r1 = rows1 ? (size_t)rows1[b] : (size_t)b;
+    const float *s_b1 = before1 + r1 * (ROREG_F * ROREG_G), *s_b0 = before0 + r0 * (ROREG_F * ROREG_G);
+    const float *s_a1 = after1 + r1 * (ROREG_F * ROREG_G), *s_a0 = after0 + r0 * (ROREG_F * ROREG_G);
+    float *dst = x + (size_t)b * (4 * ROREG_F * ROREG_G);
+    for (int i = threadIdx.x; i < ROREG_F * ROREG_G; i += 256) {
+        const int c = i / ROREG_G, g = i - c * ROREG_G;
+        const int pg = c * ROREG_G + perm[g];
+        dst[i] = s_b1[pg];
+        dst[ROREG_F * ROREG_G + i] = s_b0[i];
+        dst[2 * ROREG_F * ROREG_G + i] = s_a1[pg];
+        dst[3 * ROREG_F * ROREG_G + i] = s_a0[i];
+    }
+}
+
+// ---- quat_to_trans: one thread per correspondence --------------------------------------------------------
+__global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restrict__ q, const int64_t *__restrict__ anchor,
+                                                            const double *__restrict__ keys0, const int64_t *__restrict__ rows0,
+                                                            const double *__restrict__ keys1, const int64_t *__restrict__ rows1,
+                                                            const float *__restrict__ Rf, int M, double *__restrict__ T,
+                                                            float *__restrict__ quat_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float w = q[i * 4 + 0], x = q[i * 4 + 1], y = q[i * 4 + 2], z = q[i * 4 + 3];
+    // torch.norm(dim=1) then divide (network/eqv_trans.py:137)
+    const float n = __fsqrt_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w, w), __fmul_rn(x, x)), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    w = __fdiv_rn(w, n); x = __fdiv_rn(x, n); y = __fdiv_rn(y, n); z = __fdiv_rn(z, n);
+    if (quat_out) { quat_out[i * 4] = w; quat_out[i * 4 + 1] = x; quat_out[i * 4 + 2] = y; quat_out[i * 4 + 3] = z; }
+    // utils/r_eval.py:90-106 evaluated in float32 (the quaternion is a float32 array), left to right, no FMA
+    auto two = [](float a, float b) { return __fmul_rn(__fmul_rn(2.0f, a), b); };
+    float m[9];
+    m[0] = __fsub_rn(__fsub_rn(1.0f, two(y, y)), two(z, z));
+    m[1] = __fsub_rn(two(x, y), two(z, w));
+    m[2] = __fadd_rn(two(x, z), two(y, w));
+    m[3] = __fadd_rn(two(x, y), two(z, w));
+    m[4] = __fsub_rn(__fsub_rn(1.0f, two(x, x)), two(z, z));
+    m[5] = __fsub_rn(two(y, z), two(x, w));
+    m[6] = __fsub_rn(two(x, z), two(y, w));
+    m[7] = __fadd_rn(two(y, z), two(x, w));
+    m[8] = __fsub_rn(__fsub_rn(1.0f, two(x, x)), two(y, y));
+    const float *A = Rf + (int)anchor[i] * 9;
+    double R[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            R[r * 3 + c] = __dadd_rn(__dadd_rn(__dmul_rn((double)m[r * 3], (double)A[c]), __dmul_rn((double)m[r * 3 + 1], (double)A[3 + c])),
+                                     __dmul_rn((double)m[r * 3 + 2], (double)A[6 + c]));
+    const size_t r0 = rows0 ? (size_t)rows0[i] : (size_t)i, r1 = rows1 ? (size_t)rows1[i] : (size_t)i;
+    const double k0x = keys0[r0 * 3], k0y = keys0[r0 * 3 + 1], k0z = keys0[r0 * 3 + 2];
+    const double k1x = keys1[r1 * 3], k1y = keys1[r1 * 3 + 1], k1z = keys1[r1 * 3 + 2];
+    double *o = T + (size_t)i * 12;
+    const double k0[3] = {k0x, k0y, k0z};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[r * 4 + 0] = R[r * 3 + 0]; o[r * 4 + 1] = R[r * 3 + 1]; o[r * 4 + 2] = R[r * 3 + 2];
+        const double rot = __dadd_rn(__dadd_rn(__dmul_rn(k1x, R[r * 3]), __dmul_rn(k1y, R[r * 3 + 1])), __dmul_rn(k1z, R[r * 3 + 2]));
+        o[r * 4 + 3] = __dsub_rn(k0[r], rot);
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double *__restrict__ src, const int64_t *__restrict__ rows,
+                                                              int M, int width, double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * width) return;
+    const int r = i / width, c = i - r * width;
+    out[i] = src[(size_t)rows[r] * width + c];
+}
+
+}  // namespace
+
+extern "C" int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream) {
+    ROREG_REQUIRE(eqv_raw && eqv && B >= 0, "roreg_gf_finalize: bad arguments");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(gf_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv_raw, eqv, inv, B);
+    ROREG_CHECK_LAUNCH("roreg_gf_finalize");
+    return 0;
+}
+
+extern "C" int roreg_inv_descriptor(const float *eqv, float *inv, int N, void *stream) {
+    ROREG_REQUIRE(eqv && inv && N >= 0, "roreg_inv_descriptor: bad arguments");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(inv_descriptor_kernel, dim3((N + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv, inv, N);
+    ROREG_CHECK_LAUNCH("roreg_inv_descriptor");
+    return 0;
+}
+
+extern "C" int roreg_det_score(const float *enc, float *scores, int B, void *stream) {
+    ROREG_REQUIRE(enc && scores && B >= 0, "roreg_det_score: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_det_score: group tables not set");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(det_score_kernel, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), enc,
+                       roreg::group_tables().P8, scores, B);
+    ROREG_CHECK_LAUNCH("roreg_det_score");
+    return 0;
+}
+
+extern "C" int roreg_et_gather(const float *before0, const float *before1, const float *after0, const float *after1,
+                               const int64_t *rows0, const int64_t *rows1, const int64_t *pre_idx, int M, float *x_out,
+                               void *stream) {
+    ROREG_REQUIRE(before0 && before1 && after0 && after1 && pre_idx && x_out && M >= 0, "roreg_et_gather: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_et_gather: group tables not set");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(et_gather_kernel, dim3(M), dim3(256), 0, roreg::as_stream(stream), before0, before1, after0, after1,
+                       rows0, rows1, pre_idx, roreg::group_tables().P, x_out, M);
+    ROREG_CHECK_LAUNCH("roreg_et_gather");
+    return 0;
+}
+
+extern "C" int roreg_quat_to_trans(const float *q, const int64_t *anchor, const double *keys0, const int64_t *rows0,
+                                   const double *keys1, const int64_t *rows1, int M, double *Trans_out, float *quat_out,
+                                   void *stream) {
+    ROREG_REQUIRE(q && anchor && keys0 && keys1 && Trans_out && M >= 0, "roreg_quat_to_trans: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_quat_to_trans: group tables not set");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(quat_to_trans_kernel, dim3((M + 255) / 256), dim3(256), 0, roreg::as_stream(stream), q, anchor, keys0,
+                       rows0, keys1, rows1, roreg::group_tables().Rf, M, Trans_out, quat_out);
+    ROREG_CHECK_LAUNCH("roreg_quat_to_trans");
+    return 0;
+}
+
+extern "C" int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream) {
+    ROREG_REQUIRE(src && rows && out && M >= 0 && width > 0, "roreg_gather_rows_f64: bad arguments");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(gather_rows_f64_kernel, dim3((M * width + 255) / 256), dim3(256), 0, roreg::as_stream(stream), src, rows,
+                       M, width, out);
+    ROREG_CHECK_LAUNCH("roreg_gather_rows_f64");
+    return 0;
+}

@@ -1,0 +1,273 @@
+"""ctypes binding of libroreg_hip.so (C-ABI: include/roreg_hip.h).
+
+PyTorch is plumbing only here: it owns device memory and the HIP stream; every call below hands raw device
+pointers + the current stream handle to the C-ABI.  There is NO fallback: if the library is missing or a call
+fails, an exception is raised (the product path must never silently run on the CPU).
+"""
+import ctypes
+import os
+from ctypes import c_int, c_void_p, c_size_t, c_double, c_char_p
+
+import numpy as np
+import torch
+
+from .group import tables
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libroreg_hip.so')
+_lib = None
+_tables_uploaded = False
+
+# name -> (restype, argtypes); mirrors include/roreg_hip.h declaration by declaration
+_P = c_void_p
+PROTOTYPES = {
+    'roreg_abi_version': (c_int, []),
+    'roreg_last_error': (c_char_p, []),
+    'roreg_set_group_tables': (c_int, [_P, _P, _P]),
+    'roreg_group_conv_packed_size': (c_size_t, [c_int, c_int, c_int]),
+    'roreg_group_conv_pack_weights': (c_int, [_P, c_int, c_int, c_int, _P]),
+    'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_gf_finalize': (c_int, [_P, _P, _P, c_int, _P]),
+    'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
+    'roreg_inv_descriptor': (c_int, [_P, _P, c_int, _P]),
+    'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    'roreg_mutual_matches': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P]),
+    'roreg_des2r': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
+    'roreg_et_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
+    'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P]),
+    'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libroreg_hip.so (once).  Raises if it has not been built: run `python -c "import __graft_entry__ as g; g.build()"`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipError(f'{_LIB_PATH} is missing -- build it with `make -C roreg_amd/csrc` '
+                           f'(or __graft_entry__.build()); there is no CPU fallback')
+        L = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipError(f'{what} failed ({rc}): {lib().roreg_last_error().decode()}')
+
+
+def ensure_tables():
+    """Upload the icosahedral tables to the device (once per process)."""
+    global _tables_uploaded
+    if not _tables_uploaded:
+        T = tables()
+        P = np.ascontiguousarray(T.P, np.int32)
+        Nei = np.ascontiguousarray(T.Nei, np.int32)
+        R = np.ascontiguousarray(T.R, np.float64)
+        _check(lib().roreg_set_group_tables(P.ctypes.data, Nei.ctypes.data, R.ctypes.data), 'roreg_set_group_tables')
+        _tables_uploaded = True
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError('expected a device tensor (the HIP path has no host fallback)')
+    if not t.is_contiguous():
+        raise HipError('expected a contiguous tensor')
+    if dtype is not None and t.dtype != dtype:
+        raise HipError(f'expected dtype {dtype}, got {t.dtype}')
+    return c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------------------
+# group convolution
+# ----------------------------------------------------------------------------------------------------
+def pack_conv_weights(W):
+    """W: float32 [Cout,Cin,1,KS] or [Cout,Cin,KS] (host or device) -> packed float32 device tensor."""
+    Wn = W.detach().to('cpu', torch.float32).contiguous().numpy()
+    Cout, Cin = Wn.shape[0], Wn.shape[1]
+    KS = int(np.prod(Wn.shape[2:]))
+    Wn = np.ascontiguousarray(Wn.reshape(Cout, Cin, KS))
+    n = lib().roreg_group_conv_packed_size(Cin, Cout, KS)
+    out = np.empty(n, np.float32)
+    _check(lib().roreg_group_conv_pack_weights(Wn.ctypes.data, Cin, Cout, KS, out.ctypes.data), 'roreg_group_conv_pack_weights')
+    return torch.from_numpy(out).cuda()
+
+
+class ConvLayer:
+    """One BN(eval)+ReLU+group-conv layer in kernel-ready form (weights packed, BN folded to scale/shift)."""
+
+    def __init__(self, weight, bias, bn=None, eps=1e-5, device='cuda'):
+        self.Cout, self.Cin = int(weight.shape[0]), int(weight.shape[1])
+        self.KS = int(np.prod(weight.shape[2:]))
+        self.wpack = pack_conv_weights(weight)
+        self.bias = bias.detach().to(device, torch.float32).contiguous()
+        if bn is not None:
+            g, b, m, v = [t.detach().to('cpu', torch.float32) for t in bn]
+            scale = g / torch.sqrt(v + eps)
+            shift = b - m * scale
+            self.scale = scale.to(device).contiguous()
+            self.shift = shift.to(device).contiguous()
+        else:
+            self.scale = self.shift = None
+
+
+_gather_cache = {}
+
+
+def gather_table(key, array):
+    """int32 device copy of a [Lout,KS] gather table, cached by key."""
+    t = _gather_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(np.ascontiguousarray(array, np.int32)).cuda()
+        _gather_cache[key] = t
+    return t
+
+
+def full_gather():
+    return gather_table('nei60', tables().Nei)
+
+
+def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None):
+    """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32."""
+    ensure_tables()
+    B, Cin, Lin = x.shape
+    assert Cin == layer.Cin, (Cin, layer.Cin)
+    if gather is None:
+        gather = full_gather() if layer.KS == 13 else gather_table(('id', Lin), np.arange(Lin)[:, None])
+    Lout = int(gather.shape[0]) if Lout is None else Lout
+    if out is None:
+        out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
+    _check(lib().roreg_group_conv(_ptr(x, torch.float32), _ptr(layer.wpack), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
+                                  _ptr(residual, torch.float32), _ptr(out, torch.float32), _ptr(gather, torch.int32),
+                                  B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv')
+    return out
+
+
+def gf_finalize(eqv_raw, want_inv=True):
+    B = eqv_raw.shape[0]
+    eqv = torch.empty_like(eqv_raw)
+    inv = torch.empty((B, 32), dtype=torch.float32, device=eqv_raw.device) if want_inv else None
+    _check(lib().roreg_gf_finalize(_ptr(eqv_raw, torch.float32), _ptr(eqv), _ptr(inv), B, _stream()), 'roreg_gf_finalize')
+    return eqv, inv
+
+
+def det_score(enc):
+    ensure_tables()
+    B = enc.shape[0]
+    assert enc.shape[1:] == (16, 60)
+    out = torch.empty(B, dtype=torch.float32, device=enc.device)
+    _check(lib().roreg_det_score(_ptr(enc, torch.float32), _ptr(out), B, _stream()), 'roreg_det_score')
+    return out
+
+
+def inv_descriptor(eqv):
+    N = eqv.shape[0]
+    assert eqv.shape[1:] == (32, 60)
+    out = torch.empty((N, 32), dtype=torch.float32, device=eqv.device)
+    _check(lib().roreg_inv_descriptor(_ptr(eqv, torch.float32), _ptr(out), N, _stream()), 'roreg_inv_descriptor')
+    return out
+
+
+def nn_search(src, tgt, src_rows=None, tgt_rows=None, want_dist=False):
+    """nearest target for every source.  src [*,F], tgt [*,F] f32; optional int64 row lists."""
+    F = src.shape[1]
+    m = int(src_rows.shape[0]) if src_rows is not None else int(src.shape[0])
+    n = int(tgt_rows.shape[0]) if tgt_rows is not None else int(tgt.shape[0])
+    idx = torch.empty(m, dtype=torch.int64, device=src.device)
+    dist = torch.empty(m, dtype=torch.float32, device=src.device) if want_dist else None
+    scratch = torch.empty(max(m, 1), dtype=torch.int64, device=src.device)
+    _check(lib().roreg_nn_search(_ptr(src, torch.float32), _ptr(src_rows, torch.int64), m, _ptr(tgt, torch.float32),
+                                 _ptr(tgt_rows, torch.int64), n, F, _ptr(idx), _ptr(dist), _ptr(scratch), _stream()), 'roreg_nn_search')
+    return (idx, dist) if want_dist else idx
+
+
+def knn_search(src, tgt, k):
+    m, F = src.shape
+    n = tgt.shape[0]
+    idx = torch.empty((m, k), dtype=torch.int64, device=src.device)
+    _check(lib().roreg_knn_search(_ptr(src, torch.float32), m, _ptr(tgt, torch.float32), n, F, k, _ptr(idx), _stream()), 'roreg_knn_search')
+    return idx
+
+
+def mutual_matches(nn01, nn10, sample0=None, sample1=None):
+    """-> (matches int64 [m,2] buffer, count int32[1]); rows [0,count) are valid, in increasing source order."""
+    m = nn01.shape[0]
+    out = torch.empty((max(m, 1), 2), dtype=torch.int64, device=nn01.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=nn01.device)
+    _check(lib().roreg_mutual_matches(_ptr(nn01, torch.int64), _ptr(nn10, torch.int64), m, _ptr(sample0, torch.int64),
+                                      _ptr(sample1, torch.int64), _ptr(out), _ptr(cnt), _stream()), 'roreg_mutual_matches')
+    return out, cnt
+
+
+def des2r(feats1, feats0, rows1=None, rows0=None, want_cor=False):
+    ensure_tables()
+    M = int(rows1.shape[0]) if rows1 is not None else int(feats1.shape[0])
+    idx = torch.empty(M, dtype=torch.int64, device=feats1.device)
+    cor = torch.empty((M, 60), dtype=torch.float32, device=feats1.device) if want_cor else None
+    _check(lib().roreg_des2r(_ptr(feats1, torch.float32), _ptr(rows1, torch.int64), _ptr(feats0, torch.float32), _ptr(rows0, torch.int64),
+                             M, _ptr(idx), _ptr(cor), _stream()), 'roreg_des2r')
+    return (idx, cor) if want_cor else idx
+
+
+def et_gather(before0, before1, after0, after1, pre_idx, rows0=None, rows1=None):
+    ensure_tables()
+    M = pre_idx.shape[0]
+    x = torch.empty((M, 128, 60), dtype=torch.float32, device=before0.device)
+    _check(lib().roreg_et_gather(_ptr(before0, torch.float32), _ptr(before1, torch.float32), _ptr(after0, torch.float32),
+                                 _ptr(after1, torch.float32), _ptr(rows0, torch.int64), _ptr(rows1, torch.int64),
+                                 _ptr(pre_idx, torch.int64), M, _ptr(x), _stream()), 'roreg_et_gather')
+    return x
+
+
+def quat_to_trans(q, anchor, keys0, keys1, rows0=None, rows1=None, want_quat=False):
+    ensure_tables()
+    M = q.shape[0]
+    T = torch.empty((M, 3, 4), dtype=torch.float64, device=q.device)
+    qn = torch.empty((M, 4), dtype=torch.float32, device=q.device) if want_quat else None
+    _check(lib().roreg_quat_to_trans(_ptr(q, torch.float32), _ptr(anchor, torch.int64), _ptr(keys0, torch.float64), _ptr(rows0, torch.int64),
+                                     _ptr(keys1, torch.float64), _ptr(rows1, torch.int64), M, _ptr(T), _ptr(qn), _stream()), 'roreg_quat_to_trans')
+    return (T, qn) if want_quat else T
+
+
+def ransac_score(k0, k1, w, Trans, ird, hyp_rows=None, want_mask=False):
+    M = k0.shape[0]
+    H = int(hyp_rows.shape[0]) if hyp_rows is not None else int(Trans.shape[0])
+    ov = torch.empty(max(H, 1), dtype=torch.float64, device=k0.device)
+    best = torch.empty(1, dtype=torch.int32, device=k0.device)
+    mask = torch.empty((H, M), dtype=torch.uint8, device=k0.device) if want_mask else None
+    _check(lib().roreg_ransac_score(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), M, _ptr(Trans, torch.float64),
+                                    _ptr(hyp_rows, torch.int64), H, float(ird), _ptr(ov), _ptr(best), _ptr(mask), _stream()), 'roreg_ransac_score')
+    return ov[:H], best, mask
+
+
+def refine(k0, k1, w, dist, T_in=None, Trans=None, hyp_rows=None, best=None):
+    M = k0.shape[0]
+    out = torch.empty((4, 4), dtype=torch.float64, device=k0.device)
+    stride = 4
+    _check(lib().roreg_refine(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), M, _ptr(T_in, torch.float64), stride,
+                              _ptr(Trans, torch.float64), _ptr(hyp_rows, torch.int64), _ptr(best, torch.int32), float(dist), _ptr(out),
+                              _stream()), 'roreg_refine')
+    return out
+
+
+def gather_rows_f64(src, rows):
+    M, width = rows.shape[0], src.shape[1]
+    out = torch.empty((M, width), dtype=torch.float64, device=src.device)
+    _check(lib().roreg_gather_rows_f64(_ptr(src, torch.float64), _ptr(rows, torch.int64), M, width, _ptr(out), _stream()), 'roreg_gather_rows_f64')
+    return out

@@ -1,0 +1,90 @@
+"""ET_test: local-rotation regressor (mirror of network/eqv_trans.py:78-138).
+
+forward({'before_eqv0','before_eqv1','after_eqv0','after_eqv1': [B,32,60], 'pre_idx': [B]})
+  -> {'quaternion_pre': [B,4], 'pre_idxs': [B]}
+
+The reference evaluates its 1x1 head at all 60 group columns and keeps column g=0 (eqv_trans.py:133-136), so
+only the group columns that can reach g=0 through the 13-stencil are live: 45 columns of Conv_init's output,
+13 of comb_layer_in's, 1 of comb_layer_out's.  The pruned path computes exactly those (5.6x fewer MACs, same
+values); `pruned=False` evaluates every column like the reference, for the equality test."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..group import tables
+from .ops import Comb_Conv, Residual_Comb_Conv, _Branch, _version_key
+
+
+class ET_test(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.Conv_init = Comb_Conv(32 * 4, 256)
+        self.PartII_SO3_Conv_layers = nn.ModuleList([Residual_Comb_Conv(256, 512, 256)])
+        d = [256, 512, 128, 4]
+        self.PartII_To_R_dims = d
+        self.PartII_To_R_FC = nn.Sequential(
+            nn.Conv2d(d[0], d[1], 1, 1), nn.BatchNorm2d(d[1]), nn.ReLU(),
+            nn.Conv2d(d[1], d[2], 1, 1), nn.BatchNorm2d(d[2]), nn.ReLU(),
+            nn.Conv2d(d[2], d[3], 1, 1))
+        self.pruned = True
+
+    # ---- kernel plans -------------------------------------------------------------------------------------
+    def _head_plans(self):
+        fc = self.PartII_To_R_FC
+        key = _version_key(fc)
+        if getattr(self, '_head_key', None) != key:
+            def bn(m):
+                return (m.weight, m.bias, m.running_mean, m.running_var)
+            self._head = [hip.ConvLayer(fc[0].weight, fc[0].bias, None),
+                          hip.ConvLayer(fc[3].weight, fc[3].bias, bn(fc[1]), eps=fc[1].eps),
+                          hip.ConvLayer(fc[6].weight, fc[6].bias, bn(fc[4]), eps=fc[4].eps)]
+            self._head_key = key
+        return self._head
+
+    @staticmethod
+    def _pruned_gathers():
+        T = tables()
+        live = T.live_sets(2)                         # [ [0], 13, 45 ]
+        l0, l1, l2 = live[0], live[1], live[2]
+        pos2 = {g: i for i, g in enumerate(l2)}
+        pos1 = {g: i for i, g in enumerate(l1)}
+        ga = T.Nei[l2]                                                    # [45,13] into the full 60 columns
+        gb = np.array([[pos2[int(v)] for v in T.Nei[g]] for g in l1])     # [13,13] into the 45 live columns
+        gc = np.array([[pos1[int(v)] for v in T.Nei[g]] for g in l0])     # [1,13]  into the 13 live columns
+        return (hip.gather_table('et_a', ga), hip.gather_table('et_b', gb), hip.gather_table('et_c', gc), pos2[0])
+
+    def assemble(self, data):
+        """x [B,128,60] = cat(before0[P[pre]], before1, after0[P[pre]], after1)  (eqv_trans.py:126-129)."""
+        dev = 'cuda'
+        b0 = data['before_eqv0'].to(dev, torch.float32).contiguous(); b1 = data['before_eqv1'].to(dev, torch.float32).contiguous()
+        a0 = data['after_eqv0'].to(dev, torch.float32).contiguous(); a1 = data['after_eqv1'].to(dev, torch.float32).contiguous()
+        pre = data['pre_idx'].to(dev, torch.int64).contiguous()
+        # et_gather(before0, before1, after0, after1): channels = [before1-side permuted, before0-side, ...] with
+        # "1" = the permuted side; in the reference's batch the permuted side is before_eqv0/after_eqv0.
+        return hip.et_gather(b1, b0, a1, a0, pre), pre
+
+    def trunk_and_head(self, x):
+        """x [B,128,60] -> un-normalised quaternion [B,4]."""
+        res = self.PartII_SO3_Conv_layers[0]
+        h0p, h1p, h2p = self._head_plans()
+        if self.pruned:
+            ga, gb, gc, p0 = self._pruned_gathers()
+            h = self.Conv_init(x, gather=ga)                                   # [B,256,45]
+            m = res._b_in(h, gather=gb)                                        # [B,512,13]
+            sc = h[:, :, p0:p0 + 1].contiguous()                               # identity short cut at g=0
+            t = res._b_out(m, gather=gc, residual=sc)                          # [B,256,1]
+        else:
+            h = self.Conv_init(x)
+            t = res(h)[:, :, 0:1].contiguous()                                 # [B,256,1] (column g=0)
+        z = hip.group_conv(t, h0p)
+        z = hip.group_conv(z, h1p)
+        z = hip.group_conv(z, h2p)                                             # [B,4,1]
+        return z[:, :, 0].contiguous()
+
+    def forward(self, data):
+        x, pre = self.assemble(data)
+        q = self.trunk_and_head(x)
+        q = q / torch.norm(q, dim=1)[:, None]
+        return {'quaternion_pre': q, 'pre_idxs': pre}

@@ -1,0 +1,222 @@
+"""The oracle (oracle/ref_numpy.py) pinned against vectors produced by the real reference
+(tools/gen_golden.py -> tests/golden).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+from roreg_amd import synth
+
+
+def seeded_sd(kind, seed):
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+    net = name2network[kind](default_config())
+    sd = synth.seeded_state_dict(net, seed)
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+def test_group_tables_identities(group):
+    T = group
+    assert T.P.shape == (60, 60) and T.Nei.shape == (60, 13)
+    assert (T.Nei[:, 0] == np.arange(60)).all()
+    assert T.H.tolist() == [0, 1, 4, 7, 8, 11, 12, 15, 19, 20, 21, 25, 29]
+    # P[a,g] = index(R_g R_a)
+    for a, g in [(3, 5), (17, 0), (59, 58)]:
+        assert np.abs(T.R[T.P[a, g]] - T.R[g] @ T.R[a]).max() < 1e-3
+    hops = T.live_sets(3)
+    assert [len(h) for h in hops] == [1, 13, 45, 60]
+
+
+def test_gf_forward_matches_reference(group):
+    z = load_golden('gf_forward')
+    sd = seeded_sd('GF_test', int(z['seed']))
+    out = O.gf_forward(z['x'], sd, group.Nei, taps=True)
+    assert np.abs(out['conv_in'] - z['conv_in']).max() < 2e-5
+    assert np.abs(out['res'] - z['res']).max() < 2e-4 * max(1.0, np.abs(z['res']).max())
+    assert np.abs(out['eqv'] - z['eqv']).max() < 1e-5
+    assert np.abs(out['inv'] - z['inv']).max() < 1e-5
+
+
+def test_gf_equivariance(group):
+    z = load_golden('gf_forward')
+    sd = seeded_sd('GF_test', int(z['seed']))
+    x = z['x'][:4]
+    a = 23
+    y0 = O.gf_forward(x, sd, group.Nei)['eqv']
+    y1 = O.gf_forward(np.ascontiguousarray(x[:, :, group.P[a]]), sd, group.Nei)['eqv']
+    assert np.abs(y1 - y0[:, :, group.P[a]]).max() < 1e-5
+
+
+def test_rd_forward_matches_reference(group):
+    z = load_golden('rd_forward')
+    sd = dict(load_golden('weights_RD'))
+    enc = O.rd_encoder(z['x'], sd, group.Nei)
+    assert np.abs(enc - z['enc']).max() < 1e-4 * max(1.0, np.abs(z['enc']).max())
+    # the score is the std (~3e-3) of 60 correlations of magnitude ~60: fp32 cancellation leaves ~1e-5 of
+    # summation-order noise in the reference itself, so that is the tolerance
+    s = O.rd_scores_from_encoding(z['enc'], group.P)
+    assert np.abs(s - z['scores']).max() < 5e-5
+    s2 = O.rd_forward(z['x'], sd, group.Nei, group.P)
+    assert np.abs(s2 - z['scores']).max() < 1e-4
+
+
+def test_knn_matches_reference():
+    z = load_golden('knn')
+    for tag in ['a', 'b', 'c', 'tie']:
+        d, idx = O.knn(z[f'{tag}_target'], z[f'{tag}_source'], 1)
+        assert np.array_equal(idx, z[f'{tag}_idx'].reshape(-1)), tag
+        assert np.abs(d - z[f'{tag}_d'].reshape(-1)).max() < 1e-6
+    _, idx5 = O.knn(z['k5_keys'], z['k5_keys'], 5)
+    assert np.array_equal(idx5, z['k5_idx'][0].T)
+
+
+def test_nms_matches_reference():
+    z = load_golden('nms')
+    for num in [700, 600, 400, 150, 20]:
+        got = O.nms_sample(z['keys'], z['scores'], num)
+        assert np.array_equal(got, z[f'idx_{num}']), num
+
+
+def test_des2r_matches_reference(group):
+    z = load_golden('des2r')
+    cor = O.des2r_cor(z['d1'], z['d2'], group.P)
+    assert np.abs(cor - z['cor']).max() < 1e-4
+    assert np.array_equal(cor.argmax(1), z['idx'])
+    assert (z['idx'] == z['planted']).mean() > 0.95
+
+
+def test_et_forward_matches_reference(group):
+    z = load_golden('et_forward')
+    sd = seeded_sd('ET_test', int(z['seed']))
+    batch = {k: z[k] for k in ['before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx']}
+    q = O.et_forward(batch, sd, group.Nei, group.P)
+    assert np.abs(q - z['quaternion']).max() < 1e-4
+    for i in range(5):
+        assert np.abs(O.matrix_from_quaternion(z['quaternion'][i]) - z['R_from_q'][i]).max() == 0
+
+
+def test_ransac_pieces_match_reference():
+    z = load_golden('ransac')
+    for tag in ['ones', 'f32']:
+        k0, k1, sc, Tr = z[f'{tag}_k0'], z[f'{tag}_k1'], z[f'{tag}_scores'], z[f'{tag}_Trans']
+        masks = np.stack([O.inlier_mask(k0, k1, Tr[i], 0.1) for i in range(Tr.shape[0])])
+        assert np.array_equal(masks, z[f'{tag}_masks'])
+        ov = np.array([O.overlap_cal(k0, k1, Tr[i], sc, 0.1) for i in range(Tr.shape[0])])
+        assert np.array_equal(ov, z[f'{tag}_overlap'])
+        assert int(np.argmax(ov)) == int(z[f'{tag}_best'])
+        r1 = O.refine_trans(k0, k1, Tr[int(z[f'{tag}_best'])], sc, 0.2)
+        r2 = O.refine_trans(k0, k1, r1, sc, 0.1)
+        assert np.abs(r1 - z[f'{tag}_refine1']).max() < 1e-9
+        assert np.abs(r2 - z[f'{tag}_refine2']).max() < 1e-9
+    r = O.refine_trans(z['single_k0'], z['single_k1'], z['single_T'], np.ones(5), 0.1)
+    assert np.allclose(r, z['single_refined'], atol=1e-12)
+
+
+def test_quat_and_rdiff_match_reference():
+    z = load_golden('quat')
+    for i in range(50):
+        assert np.abs(O.matrix_from_quaternion(z['q'][i]) - z['R'][i]).max() == 0
+        assert abs(O.compute_R_diff(z['A'][i], z['Rn'][i]) - z['rdiff'][i]) < 1e-9
+        assert np.abs(O.quaternion_from_matrix(z['Rn'][i]) - z['qfrommat'][i]).max() < 1e-12
+
+
+def _scene(z):
+    return synth.make_scene(int(z['scene_seed']), n_clouds=int(z['n_clouds']), n_kpts=int(z['n_kpts']), overlap=0.6,
+                            name='synth/scene0')
+
+
+def test_pipeline_mutual_yohoo_stagewise(group):
+    """Every stage of the oracle, fed the reference's output of the previous stage, reproduces the reference's
+    output of this stage (parity is per stage on identical inputs)."""
+    z = load_golden('pipeline_mutual_yohoo')
+    ds = _scene(z)
+    keynum = int(z['keynum'])
+    gf_sd = seeded_sd('GF_test', 101)
+    et_sd = seeded_sd('ET_test', 202)
+    # stage 1: extractor
+    for pc in ds.pc_ids:
+        eqv = O.gf_forward(ds.feats[int(pc)], gf_sd, group.Nei)['eqv']
+        assert np.abs(eqv - z[f'yoho_{pc}']).max() < 1e-5
+    # stage 3: mutual matcher -- consumes the global RNG exactly like matcher.py:83-88
+    np.random.seed(1234)
+    for a, b in ds.pair_ids:
+        f0, f1 = z[f'yoho_{a}'], z[f'yoho_{b}']
+        s0 = np.arange(f0.shape[0]); s1 = np.arange(f1.shape[0])
+        np.random.shuffle(s0); np.random.shuffle(s1)
+        m = O.mutual_match(f0, f1, s0[:keynum], s1[:keynum])
+        assert np.array_equal(m, z[f'match_{a}_{b}']), (a, b)
+    # stage 4: Des2R, ET + Rt_pre, RANSAC
+    np.random.seed(4321)
+    Rg32 = group.R.astype(np.float32)
+    for a, b in ds.pair_ids:
+        pps = z[f'match_{a}_{b}']
+        y0, y1 = z[f'yoho_{a}'], z[f'yoho_{b}']
+        dr = O.des2r(y1[pps[:, 1]], y0[pps[:, 0]], group.P)
+        assert np.array_equal(dr, z[f'dr_{a}_{b}'])
+        batch = {'before_eqv0': ds.feats[int(b)][pps[:, 1]], 'before_eqv1': ds.feats[int(a)][pps[:, 0]],
+                 'after_eqv0': y1[pps[:, 1]], 'after_eqv1': y0[pps[:, 0]], 'pre_idx': dr}
+        q = O.et_forward(batch, et_sd, group.Nei, group.P)
+        k0 = ds.get_kps(a)[pps[:, 0]]; k1 = ds.get_kps(b)[pps[:, 1]]
+        Tr = O.rt_pre(q, dr, Rg32, k0, k1)
+        assert np.abs(Tr - z[f'transpre_{a}_{b}']).max() < 2e-4
+    for a, b in ds.pair_ids:
+        pps = z[f'match_{a}_{b}']
+        k0 = ds.get_kps(a)[pps[:, 0]]; k1 = ds.get_kps(b)[pps[:, 1]]
+        T, rec, _ = O.yohoo_ransac(k0, k1, z[f'mscore_{a}_{b}'], z[f'transpre_{a}_{b}'], 0.1, 1000, False, 0.5,
+                                   np.random.shuffle)
+        assert rec == int(z[f'recall_{a}_{b}'])
+        assert np.abs(T - z[f'trans_{a}_{b}']).max() < 1e-9
+    txt = O.pre_log_text(ds.pair_ids, len(ds.pc_ids), [z[f'trans_{a}_{b}'] for a, b in ds.pair_ids])
+    assert txt.encode() == z['pre_log'].tobytes()
+
+
+def test_pipeline_rd_mutual_yohoc_stagewise(group):
+    z = load_golden('pipeline_rd_mutual_yohoc')
+    y = load_golden('pipeline_mutual_yohoo')
+    ds = _scene(z)
+    keynum = int(z['keynum'])
+    rd_sd = dict(load_golden('weights_RD'))
+    for pc in ds.pc_ids:
+        raw = O.rd_forward(y[f'yoho_{pc}'], rd_sd, group.Nei, group.P)
+        got = O.det_rank_scores(raw)
+        # the raw score carries ~1e-5 of fp32 summation-order noise (see test_rd_forward), so neighbouring
+        # ranks may swap; a rank may move by a few places, never far
+        n = got.shape[0]
+        assert np.abs(got - z[f'det_{pc}']).max() <= 4.0 / n
+        assert (got == z[f'det_{pc}']).mean() > 0.6
+    for a, b in ds.pair_ids:
+        s0 = O.nms_sample(ds.get_kps(a), z[f'det_{a}'], keynum)
+        s1 = O.nms_sample(ds.get_kps(b), z[f'det_{b}'], keynum)
+        m = O.mutual_match(y[f'yoho_{a}'], y[f'yoho_{b}'], s0, s1)
+        assert np.array_equal(m, z[f'match_{a}_{b}'])
+    np.random.seed(4321)
+    for a, b in ds.pair_ids:
+        pps = z[f'match_{a}_{b}']
+        dr = O.des2r(y[f'yoho_{b}'][pps[:, 1]], y[f'yoho_{a}'][pps[:, 0]], group.P)
+        assert np.array_equal(dr, z[f'dr_{a}_{b}'])
+    for a, b in ds.pair_ids:
+        pps = z[f'match_{a}_{b}']
+        k0 = ds.get_kps(a)[pps[:, 0]]; k1 = ds.get_kps(b)[pps[:, 1]]
+        T, rec = O.yohoc_ransac(k0, k1, z[f'mscore_{a}_{b}'], z[f'dr_{a}_{b}'], 0.1, 1000, False, 0.5)
+        assert rec == int(z[f'recall_{a}_{b}'])
+        assert np.abs(T - z[f'trans_{a}_{b}']).max() < 1e-9
+
+
+def test_metrics_match_reference():
+    z = load_golden('pipeline_mutual_yohoo')
+    ds = _scene(z)
+    irs, rr, rre, rte = [], [], [], []
+    for a, b in ds.pair_ids:
+        gt = ds.get_transform(a, b)
+        irs.append(O.pair_inlier_ratio(ds.get_kps(a), ds.get_kps(b), z[f'match_{a}_{b}'], gt, 0.1))
+        T = z[f'trans_{a}_{b}']
+        rd = O.compute_R_diff(T[:3, :3], gt[:3, :3]); td = np.sqrt(np.sum(np.square(T[:3, 3] - gt[:3, 3])))
+        ok = rd < 15 and td < 0.3
+        rr.append(1 if ok else 0)
+        if ok:
+            rre.append(rd); rte.append(td)
+    assert abs(np.mean(irs) - float(z['ir'])) < 1e-12
+    assert abs(np.mean([1 if i > 0.05 else 0 for i in irs]) - float(z['fmr'])) < 1e-12
+    assert abs(np.mean(rr) - float(z['rr'])) < 1e-12
+    assert abs(np.mean(rre) - float(z['rre'])) < 1e-9 and abs(np.mean(rte) - float(z['rte'])) < 1e-9
