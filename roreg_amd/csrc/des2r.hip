@@ -10,6 +10,11 @@
 // Reference: extractor_dr_index.Batch_Des2R_torch, test/estimator.py:85-89 (gathers at :108-110).
 #include "common.h"
 
+// Bit-exactness contract: no fused multiply-add may be formed from separate * and + in this file (hipcc's
+// default is -ffp-contract=fast, and the __f*_rn helpers are plain operators); sqrtf and / are correctly
+// rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+#pragma clang fp contract(off)
+
 namespace {
 
 __global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,

@@ -13,6 +13,11 @@
 // which is precisely "first minimum wins".
 #include "common.h"
 
+// Bit-exactness contract: no fused multiply-add may be formed from separate * and + in this file (hipcc's
+// default is -ffp-contract=fast, and the __f*_rn helpers are plain operators); sqrtf and / are correctly
+// rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+#pragma clang fp contract(off)
+
 namespace {
 
 __global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *p, unsigned long long v, int n) {
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float *__restrict_
         }
         const float x = __fadd_rn(acc, 1e-7f);
         if (x < best_x) {                      // sqrt is monotone: only a smaller radicand can give a smaller d
-            const float d = __fsqrt_rn(x);
+            const float d = sqrtf(x);
             if (d < best_d) { best_d = d; best_j = j; }
             best_x = x;
         }
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
             const float d = __fsub_rn(s[f], t[f]);
             acc = __fadd_rn(acc, __fmul_rn(d, d));
         }
-        float d = __fsqrt_rn(__fadd_rn(acc, 1e-7f));
+        float d = sqrtf(__fadd_rn(acc, 1e-7f));
         int dj = j;
         // insertion into the sorted list; strict '<' keeps the earlier index ahead on ties
 #pragma unroll

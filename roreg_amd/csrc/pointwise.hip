@@ -2,6 +2,11 @@
 // 60x60 self-correlation, ET input assembly and the quaternion -> local-transform assembly.
 #include "common.h"
 
+// Bit-exactness contract: no fused multiply-add may be formed from separate * and + in this file (hipcc's
+// default is -ffp-contract=fast, and the __f*_rn helpers are plain operators); sqrtf and / are correctly
+// rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+#pragma clang fp contract(off)
+
 namespace {
 
 // numpy's pairwise float32 sum for a contiguous run of n (8 <= n <= 128) elements, reproduced exactly
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void inv_descriptor_kernel(const float *__rest
         const float mf = __shfl(m, f);
         sq[f] = __fmul_rn(mf, mf);
     }
-    const float nrm = __fadd_rn(__fsqrt_rn(np_pairwise_sum(sq, ROREG_F)), 1e-5f);
+    const float nrm = __fadd_rn(sqrtf(np_pairwise_sum(sq, ROREG_F)), 1e-5f);
     if (lane < ROREG_F) inv[(size_t)n * ROREG_F + lane] = __fdiv_rn(m, nrm);
 }
 
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restr
     if (i >= M) return;
     float w = q[i * 4 + 0], x = q[i * 4 + 1], y = q[i * 4 + 2], z = q[i * 4 + 3];
     // torch.norm(dim=1) then divide (network/eqv_trans.py:137)
-    const float n = __fsqrt_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w, w), __fmul_rn(x, x)), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    const float n = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w, w), __fmul_rn(x, x)), __fmul_rn(y, y)), __fmul_rn(z, z)));
     w = __fdiv_rn(w, n); x = __fdiv_rn(x, n); y = __fdiv_rn(y, n); z = __fdiv_rn(z, n);
     if (quat_out) { quat_out[i * 4] = w; quat_out[i * 4 + 1] = x; quat_out[i * 4 + 2] = y; quat_out[i * 4 + 3] = z; }
     // utils/r_eval.py:90-106 evaluated in float32 (the quaternion is a float32 array), left to right, no FMA

@@ -8,6 +8,11 @@
 // transform_points (utils/utils.py:38-46).
 #include "common.h"
 
+// Bit-exactness contract: no fused multiply-add may be formed from separate * and + in this file (hipcc's
+// default is -ffp-contract=fast, and the __f*_rn helpers are plain operators); sqrtf and / are correctly
+// rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {

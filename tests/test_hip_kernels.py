@@ -1,0 +1,266 @@
+"""HIP kernels (through the C-ABI) against the oracle on identical inputs.  GPU only (-m gpu).
+Bar: bit-exact for indices / masks; stated tolerance for floating-point network outputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+from roreg_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def seeded_net(kind, seed):
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+    net = name2network[kind](default_config())
+    sd = synth.seeded_state_dict(net, seed)
+    return net, {k: v.numpy() for k, v in sd.items()}
+
+
+# ---- group convolution ------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,Cin,Cout,bn,res', [(7, 32, 256, False, False), (9, 256, 512, True, False), (5, 512, 256, True, True),
+                                                (11, 256, 32, True, True), (13, 32, 64, True, False), (6, 64, 16, True, True),
+                                                (1, 128, 256, True, False), (70, 32, 16, True, False)])
+def test_group_conv_full(group, B, Cin, Cout, bn, res):
+    from roreg_amd import hip
+    rng = np.random.default_rng(B * 1000 + Cin + Cout)
+    x = rng.standard_normal((B, Cin, 60)).astype(np.float32)
+    W = (rng.standard_normal((Cout, Cin, 1, 13)) / np.sqrt(Cin * 13)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    sd = {'c.2.weight': W, 'c.2.bias': b}
+    bnp = None
+    if bn:
+        sd.update({'c.0.weight': rng.uniform(0.5, 1.5, Cin).astype(np.float32), 'c.0.bias': rng.normal(0, .1, Cin).astype(np.float32),
+                   'c.0.running_mean': rng.normal(0, .1, Cin).astype(np.float32), 'c.0.running_var': rng.uniform(.5, 1.5, Cin).astype(np.float32)})
+        want = O.comb_conv(x, sd, 'c', group.Nei)
+        bnp = tuple(torch.from_numpy(sd[f'c.0.{k}']) for k in ['weight', 'bias', 'running_mean', 'running_var'])
+    else:
+        want = O.group_conv(x, W, b, group.Nei)
+    r = rng.standard_normal((B, Cout, 60)).astype(np.float32) if res else None
+    if res:
+        want = want + r
+    layer = hip.ConvLayer(torch.from_numpy(W), torch.from_numpy(b), bnp)
+    got = hip.group_conv(cu(x), layer, residual=cu(r) if res else None).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_group_conv_transpose_detecting(group):
+    """A = identity-like weights with an asymmetric activation pattern: catches a swapped C/D mapping."""
+    from roreg_amd import hip
+    Cin = Cout = 32
+    W = np.zeros((Cout, Cin, 1, 13), np.float32)
+    for o in range(Cout):
+        W[o, (o * 7 + 3) % Cin, 0, o % 13] = 1.0 + o
+    x = np.arange(3 * Cin * 60, dtype=np.float32).reshape(3, Cin, 60) / 100.0
+    want = O.group_conv(x, W, np.zeros(Cout, np.float32), group.Nei)
+    layer = hip.ConvLayer(torch.from_numpy(W), torch.zeros(Cout), None)
+    got = hip.group_conv(cu(x), layer).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_gf_forward_vs_oracle_and_golden(group):
+    z = load_golden('gf_forward')
+    net, sd = seeded_net('GF_test', int(z['seed']))
+    out = net(torch.from_numpy(z['x']))
+    eqv = out['eqv'].cpu().numpy(); inv = out['inv'].cpu().numpy()
+    want = O.gf_forward(z['x'], sd, group.Nei)
+    assert np.abs(eqv - want['eqv']).max() < 1e-5 and np.abs(inv - want['inv']).max() < 1e-5
+    assert np.abs(eqv - z['eqv']).max() < 1e-5 and np.abs(inv - z['inv']).max() < 1e-5
+
+
+def test_gf_equivariance_on_device(group):
+    net, _ = seeded_net('GF_test', 5)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((130, 32, 60)).astype(np.float32)
+    a = 41
+    y0 = net(torch.from_numpy(x))['eqv'].cpu().numpy()
+    y1 = net(torch.from_numpy(np.ascontiguousarray(x[:, :, group.P[a]])))['eqv'].cpu().numpy()
+    assert np.abs(y1 - y0[:, :, group.P[a]]).max() < 1e-5
+
+
+def test_rd_forward_vs_golden(group):
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+    z = load_golden('rd_forward')
+    net = name2network['RD_test'](default_config())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()}, strict=True)
+    enc = net.encode(torch.from_numpy(z['x'])).cpu().numpy()
+    assert np.abs(enc - z['enc']).max() < 1e-4 * max(1.0, np.abs(z['enc']).max())
+    s = net({'feats': torch.from_numpy(z['x'])})['scores'].cpu().numpy()
+    assert np.abs(s - z['scores']).max() < 1e-4
+    from roreg_amd import hip
+    s2 = hip.det_score(cu(z['enc'])).cpu().numpy()
+    assert np.abs(s2 - z['scores']).max() < 5e-5
+
+
+def test_et_forward_pruned_equals_full_equals_golden(group):
+    z = load_golden('et_forward')
+    net, sd = seeded_net('ET_test', int(z['seed']))
+    batch = {k: torch.from_numpy(z[k].copy()) for k in ['before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx']}
+    net.pruned = True
+    qp = net(batch)['quaternion_pre'].cpu().numpy()
+    net.pruned = False
+    qf = net(batch)['quaternion_pre'].cpu().numpy()
+    assert np.abs(qp - qf).max() < 2e-5
+    assert np.abs(qp - z['quaternion']).max() < 1e-4
+    want = O.et_forward({k: z[k] for k in ['before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx']}, sd, group.Nei, group.P)
+    assert np.abs(qp - want).max() < 1e-4
+
+
+# ---- bit-exact kernels --------------------------------------------------------------------------------------
+def test_inv_descriptor_bit_exact():
+    from roreg_amd import hip
+    z = load_golden('pipeline_mutual_yohoo')
+    for pc in ['0', '1']:
+        want = O.inv_descriptor(z[f'yoho_{pc}'])
+        got = hip.inv_descriptor(cu(z[f'yoho_{pc}'])).cpu().numpy()
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'tie'])
+def test_nn_search_bit_exact_golden(tag):
+    from roreg_amd import hip
+    z = load_golden('knn')
+    idx, d = hip.nn_search(cu(z[f'{tag}_source']), cu(z[f'{tag}_target']), want_dist=True)
+    od, oi = O.knn(z[f'{tag}_target'], z[f'{tag}_source'], 1)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(d.cpu().numpy(), od)
+    assert np.array_equal(idx.cpu().numpy(), z[f'{tag}_idx'].reshape(-1))
+
+
+def test_nn_search_5000_with_row_lists():
+    from roreg_amd import hip
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((5000, 32)).astype(np.float32); A /= np.linalg.norm(A, axis=1, keepdims=True)
+    B = (A[rng.permutation(5000)] + 0.05 * rng.standard_normal((5000, 32))).astype(np.float32)
+    ra = rng.permutation(5000)[:4000]; rb = rng.permutation(5000)[:3777]
+    idx = hip.nn_search(cu(B), cu(A), src_rows=cu(rb), tgt_rows=cu(ra)).cpu().numpy()
+    _, oi = O.knn(A[ra], B[rb], 1)
+    assert np.array_equal(idx, oi)
+
+
+def test_knn5_golden():
+    from roreg_amd import hip
+    z = load_golden('knn')
+    idx = hip.knn_search(cu(z['k5_keys']), cu(z['k5_keys']), 5).cpu().numpy()
+    assert np.array_equal(idx, z['k5_idx'][0].T)
+
+
+def test_mutual_matches_bit_exact():
+    from roreg_amd import hip
+    rng = np.random.default_rng(4)
+    for m, n in [(5000, 4800), (37, 50), (1, 1), (2500, 2500)]:
+        nn01 = rng.integers(0, n, m); nn10 = rng.integers(0, m, n)
+        good = rng.random(m) < 0.5
+        for i in np.where(good)[0]:
+            nn10[nn01[i]] = i
+        s0 = rng.permutation(m + 10)[:m]; s1 = rng.permutation(n + 10)[:n]
+        want = O.mutual_check(nn01, nn10)
+        want = np.stack([s0[want[:, 0]], s1[want[:, 1]]], 1)
+        out, cnt = hip.mutual_matches(cu(nn01), cu(nn10), cu(s0), cu(s1))
+        c = int(cnt.item())
+        assert c == want.shape[0]
+        assert np.array_equal(out[:c].cpu().numpy(), want)
+
+
+def test_des2r_bit_exact(group):
+    from roreg_amd import hip
+    z = load_golden('des2r')
+    idx, cor = hip.des2r(cu(z['d1']), cu(z['d2']), want_cor=True)
+    want = O.des2r_cor(z['d1'], z['d2'], group.P)
+    assert np.array_equal(cor.cpu().numpy(), want)
+    assert np.array_equal(idx.cpu().numpy(), want.argmax(1))
+    assert np.array_equal(idx.cpu().numpy(), z['idx'])
+    # with row lists
+    rng = np.random.default_rng(1)
+    r1 = rng.integers(0, z['d1'].shape[0], 50); r0 = rng.integers(0, z['d1'].shape[0], 50)
+    idx2 = hip.des2r(cu(z['d1']), cu(z['d2']), rows1=cu(r1), rows0=cu(r0)).cpu().numpy()
+    assert np.array_equal(idx2, O.des2r(z['d1'][r1], z['d2'][r0], group.P))
+
+
+def test_des2r_recovers_planted_rotation(group):
+    from roreg_amd import hip
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2000, 32, 60)).astype(np.float32)
+    a = rng.integers(0, 60, 2000)
+    xr = np.empty_like(x)
+    for i in range(2000):
+        xr[i][:, group.P[a[i]]] = x[i]            # d1[:, P[a,g]] = d2[:, g]  ->  cor[a] is the full autocorrelation
+    assert np.array_equal(hip.des2r(cu(xr), cu(x)).cpu().numpy(), a)
+
+
+def test_quat_to_trans_vs_oracle(group):
+    from roreg_amd import hip
+    z = load_golden('et_forward')
+    rng = np.random.default_rng(6)
+    M = z['quaternion'].shape[0]
+    q = (z['quaternion'] * rng.uniform(0.5, 2.0, (M, 1))).astype(np.float32)      # un-normalised head output
+    k0 = rng.uniform(0, 3, (M, 3)); k1 = rng.uniform(0, 3, (M, 3))
+    anchor = z['pre_idx']
+    T, qn = hip.quat_to_trans(cu(q), cu(anchor), cu(k0), cu(k1), want_quat=True)
+    qn_ref = (q / np.sqrt((q * q).sum(1))[:, None]).astype(np.float32)
+    want = O.rt_pre(qn.cpu().numpy(), anchor, group.R.astype(np.float32), k0, k1)
+    assert np.abs(qn.cpu().numpy() - qn_ref).max() < 1e-6
+    assert np.abs(T.cpu().numpy() - want).max() < 1e-12
+
+
+@pytest.mark.parametrize('tag', ['ones', 'f32'])
+def test_ransac_score_masks_bit_exact(tag):
+    from roreg_amd import hip
+    z = load_golden('ransac')
+    k0, k1, sc, Tr = z[f'{tag}_k0'], z[f'{tag}_k1'], z[f'{tag}_scores'], z[f'{tag}_Trans']
+    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), cu(sc.astype(np.float64)), cu(Tr), 0.1, want_mask=True)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), z[f'{tag}_masks'])
+    ovh = ov.cpu().numpy()
+    if tag == 'ones':
+        assert np.array_equal(ovh, z[f'{tag}_overlap'])          # integer sums: exact
+    else:
+        assert np.abs(ovh - z[f'{tag}_overlap']).max() < 1e-6    # reference sums these in float32
+    assert int(best.item()) == int(z[f'{tag}_best'])
+    T1 = hip.refine(cu(k0), cu(k1), cu(sc.astype(np.float64)), 0.2, Trans=cu(Tr), best=best)
+    T2 = hip.refine(cu(k0), cu(k1), cu(sc.astype(np.float64)), 0.1, T_in=T1)
+    tol = 1e-9 if tag == 'ones' else 1e-6
+    assert np.abs(T1.cpu().numpy() - z[f'{tag}_refine1']).max() < tol
+    assert np.abs(T2.cpu().numpy() - z[f'{tag}_refine2']).max() < tol
+
+
+def test_refine_single_inlier_edge():
+    from roreg_amd import hip
+    z = load_golden('ransac')
+    T = hip.refine(cu(z['single_k0']), cu(z['single_k1']), cu(np.ones(5)), 0.1, T_in=cu(z['single_T'])).cpu().numpy()
+    assert np.allclose(T, z['single_refined'], atol=1e-12)
+
+
+def test_ransac_hypothesis_subset_and_full_size_properties():
+    """BASELINE-size run (M=5000, H=1000) checked through properties: overlap in [0,1], the planted
+    transform wins, masks agree with the oracle on a sampled hypothesis."""
+    from roreg_amd import hip
+    from roreg_amd.group import tables
+    rng = np.random.default_rng(9)
+    M = 5000
+    R = tables().R[33]; t = np.array([0.4, 0.1, -0.3])
+    k1 = rng.uniform(0, 3, (M, 3)); k0 = k1 @ R.T + t + 0.01 * rng.standard_normal((M, 3))
+    bad = rng.random(M) < 0.4; k0[bad] = rng.uniform(0, 3, (bad.sum(), 3))
+    Tr = np.zeros((M, 3, 4))
+    for i in range(M):
+        Rg = tables().R[int(rng.integers(0, 60))] if i % 7 else R
+        Tr[i, :, :3] = Rg; Tr[i, :, 3] = k0[i] - k1[i] @ Rg.T
+    rows = rng.permutation(M)[:1000]
+    w = np.ones(M)
+    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), cu(w), cu(Tr), 0.1, hyp_rows=cu(rows), want_mask=True)
+    ovh = ov.cpu().numpy()
+    assert ovh.min() >= 0 and ovh.max() <= 1
+    b = int(best.item())
+    assert ovh[b] == ovh.max() and b == int(np.argmax(ovh))
+    assert np.array_equal(mask[b].cpu().numpy().astype(bool), O.inlier_mask(k0, k1, Tr[rows[b]], 0.1))
+    assert abs(ovh[b] - (~bad).mean()) < 0.05
