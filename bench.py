@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- pair-registrations/sec of the RoReg hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path (GF extractor on every cloud, mutual matcher, Des2R + ET local
+transforms, one-shot RANSAC + 2 refinements on every pair) over one resident scene chunk of 5000-keypoint clouds
+(BASELINE.json configs[1]: one 3DMatch-'kitchen'-like scene, 60-rotation group features, random-init GF/ET
+weights of the reference's architecture; data synthetic).  The chunk has the 3DMatch clouds:pairs ratio
+(8 clouds, 28 pairs = 0.286 >= 433/1623), so `value` already includes the amortised per-cloud work.
+With N ranks every rank registers its own chunk (pairs shard with no data-path collective; weak scaling)
+and the per-pair result table is all-gathered once per step over RCCL.
+
+The JSON line also carries the roofline of the dominant kernel (the exact-f32 MFMA group convolution, timed
+with HIP events inside the timed region) and a CPU baseline (the numpy oracle, rank 0, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input MFMA peak
+N_KPTS = 5000
+N_CLOUDS = 8
+OVERLAP = 0.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--kpts', type=int, default=N_KPTS)
+    ap.add_argument('--clouds', type=int, default=N_CLOUDS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
+    """Oracle (numpy port of the reference's algorithm) timed on a bounded sample, scaled to the step's workload."""
+    from oracle import ref_numpy as O
+    from roreg_amd.group import tables
+    T = tables()
+    gf_sd, et_sd = cfg_nets
+    threads = torch.get_num_threads()
+    t = {}
+    nb = 48
+    x = scene.feats[0][:nb]
+    t0 = time.perf_counter(); eq = O.gf_forward(x, gf_sd, T.Nei)['eqv']; t['gf_per_kpt'] = (time.perf_counter() - t0) / nb
+    n = 1000
+    e0 = scene.feats[0][:n]; e1 = scene.feats[1][:n]
+    s = np.arange(n)
+    t0 = time.perf_counter(); m = O.mutual_match(e0, e1, s, s); dt = time.perf_counter() - t0
+    t['mutual_per_pair'] = dt * (scene.feats[0].shape[0] / n) ** 2          # O(N^2)
+    nm = 64
+    d1 = scene.feats[1][:nm]; d0 = scene.feats[0][:nm]
+    t0 = time.perf_counter(); dr = O.des2r(d1, d0, T.P); t['des2r_per_corr'] = (time.perf_counter() - t0) / nm
+    nb = 24
+    batch = {'before_eqv0': scene.feats[1][:nb], 'before_eqv1': scene.feats[0][:nb], 'after_eqv0': scene.feats[1][:nb],
+             'after_eqv1': scene.feats[0][:nb], 'pre_idx': dr[:nb]}
+    t0 = time.perf_counter(); q = O.et_forward(batch, et_sd, T.Nei, T.P); t['et_per_corr'] = (time.perf_counter() - t0) / nb
+    M, H = 3000, 40
+    rng = np.random.default_rng(0)
+    k0 = rng.uniform(0, 3, (M, 3)); k1 = rng.uniform(0, 3, (M, 3)); Tr = rng.standard_normal((H, 3, 4))
+    t0 = time.perf_counter()
+    for h in range(H):
+        O.overlap_cal(k0, k1, Tr[h], np.ones(M), 0.1)
+    t['ransac_per_hyp'] = (time.perf_counter() - t0) / H
+    return t, threads
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from roreg_amd import hip, synth
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+
+    cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
+    gf = name2network['GF_test'](cfg); gf_sd = synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); et_sd = synth.seeded_state_dict(et, 202)
+    eng = RegistrationEngine(cfg, gf, et)
+
+    scene = synth.make_scene(1000 + rank, n_clouds=args.clouds, n_kpts=args.kpts, overlap=OVERLAP, coord_noise=0.005)
+    pair_ids = scene.pair_ids
+    feats = [torch.from_numpy(f).cuda() for f in scene.feats]            # inputs resident in HBM before timing
+    keys = [torch.from_numpy(k).cuda() for k in scene._kps]
+    n_pairs = len(pair_ids)
+
+    def step():
+        np.random.seed(7)
+        res = eng.run_scene(feats, keys, pair_ids)
+        table = torch.tensor([[float(r.id0), float(r.id1), r.n_match, r.recalltime] + r.trans.reshape(-1).tolist() for r in res],
+                             dtype=torch.float64, device='cuda')
+        if dist is not None:
+            out = [torch.empty_like(table) for _ in range(world)]
+            dist.all_gather(out, table)                                     # the single result-table collective (RCCL/xGMI)
+        return res
+
+    for _ in range(args.warmup):
+        step()
+
+    hip.PROFILE = []                                                         # per-launch HIP events of the group conv
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = hip.PROFILE; hip.PROFILE = None
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: the two big GF layers (256->512, 512->256; identical MAC counts) ----
+    flops = 0.0; ms = 0.0; n_launch = 0
+    for (tag, e0, e1) in prof:
+        B, Cin, Cout, Lout, KS = tag
+        if Cin * Cout == 256 * 512 and KS == 13 and Lout == 60:
+            flops += 2.0 * B * Lout * Cout * Cin * KS
+            ms += e0.elapsed_time(e1); n_launch += 1
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    # ---- accuracy on the synthetic chunk (outside the timed region) ----
+    from oracle import ref_numpy as O
+    rr = []
+    for r in res:
+        gt = scene.get_transform(r.id0, r.id1)
+        if np.isfinite(r.trans).all():
+            rd = O.compute_R_diff(r.trans[:3, :3], gt[:3, :3]); td = float(np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))))
+            rr.append(1 if (rd < 15 and td < 0.3) else 0)
+        else:
+            rr.append(0)
+
+    if rank == 0:
+        value = world * n_pairs * args.steps / dt
+        out = {
+            'metric': 'pair-registrations/sec', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f"3DMatch-kitchen-like scene chunk per GPU: {args.clouds} clouds x {args.kpts} kpts, {n_pairs} pairs "
+                                   f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats)",
+                       'pairs_per_step_per_gpu': n_pairs, 'clouds_per_step_per_gpu': args.clouds, 'parallelism': f'pairs-sharded x{world}',
+                       'mean_matches': float(np.mean([r.n_match for r in res])), 'registration_recall_synthetic': float(np.mean(rr))},
+            'roofline': {'bound': 'mfma', 'kernel': 'group_conv_kernel<13,60,32,2,2,2> (GF 256->512 / 512->256)', 'achieved': achieved,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            gf_np = {k: v.numpy() for k, v in gf_sd.items()}; et_np = {k: v.numpy() for k, v in et_sd.items()}
+            t, threads = cpu_baseline((gf_np, et_np), scene, n_pairs, args.clouds)
+            M = float(np.mean([r.n_match for r in res])); H = min(M, 1000)
+            per_cloud = t['gf_per_kpt'] * args.kpts
+            per_pair = t['mutual_per_pair'] + M * (t['des2r_per_corr'] + t['et_per_corr']) + H * t['ransac_per_hyp'] * (M / 3000.0)
+            sec = args.clouds * per_cloud + n_pairs * per_pair
+            out['cpu_baseline'] = {'value': n_pairs / sec, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+                                   'sample': 'oracle/ref_numpy.py on this host: GF on 48 kpts, mutual on 1000x1000 (scaled N^2), Des2R on 64, '
+                                             'ET on 24 correspondences, RANSAC scoring on 40 hypotheses x 3000; scaled to the step workload',
+                                   'components_s': {'gf_per_cloud': per_cloud, 'per_pair': per_pair}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

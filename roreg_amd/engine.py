@@ -1,0 +1,148 @@
+"""Device-resident scene pipeline: extractor -> [detector] -> matcher -> estimator with every
+per-cloud tensor kept in HBM for the whole scene, so stage boundaries are views instead of .npy round trips
+(the reference re-loads 8 x 38.4 MB per pair).
+
+Stage order and host-RNG consumption are the reference's (test/evaluator.py:39-48): all clouds are extracted,
+then ALL pairs are matched (np.random.shuffle x2 per pair when the detector is off, matcher.py:83-88), then
+ALL pairs are estimated (one np.random.shuffle of the hypothesis order per pair, estimator.py:423-425).  The
+only device->host syncs are one per scene for the match counts (the hypothesis shuffle needs M) and one for
+the result table.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import hip
+from .group import tables
+
+
+@dataclass
+class CloudState:
+    before: torch.Tensor            # FCGF-like input group features [N,32,60] f32 (device)
+    eqv: torch.Tensor = None        # GF output [N,32,60]
+    inv: torch.Tensor = None        # matcher invariant descriptor [N,32]
+    keys: torch.Tensor = None       # keypoints [N,3] f64 (device)
+    det: np.ndarray = None          # detector rank scores (host, as det_score/*.npy)
+
+
+@dataclass
+class PairResult:
+    id0: str
+    id1: str
+    n_match: int
+    trans: np.ndarray               # [4,4] f64
+    recalltime: int
+    matches: torch.Tensor = None    # [M,2] int64 (device)
+    scores: np.ndarray = None
+
+
+class RegistrationEngine:
+    def __init__(self, cfg, gf_net, et_net, rd_net=None, sampler=None):
+        self.cfg = cfg
+        self.gf = gf_net
+        self.et = et_net
+        self.rd = rd_net
+        self.sampler = sampler
+        hip.ensure_tables()
+
+    # ---- per cloud ---------------------------------------------------------------------------------------
+    def extract(self, feats, keys):
+        """feats: [N,32,60] f32 (host ndarray or device tensor); keys [N,3] f64."""
+        x = feats if torch.is_tensor(feats) else torch.from_numpy(np.ascontiguousarray(feats, np.float32))
+        x = x.to('cuda', torch.float32).contiguous()
+        with torch.no_grad():
+            eqv = self.gf.PartI_net(x, want_inv=False)['eqv']
+        k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
+        return CloudState(before=x, eqv=eqv, inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
+
+    def detect(self, cloud):
+        """raw std scores -> rank/N on the host exactly as test/detector.py:45-46."""
+        with torch.no_grad():
+            s = self.rd({'feats': cloud.eqv})['scores'].cpu().numpy()
+        a = np.argsort(s)
+        s[a] = np.arange(s.shape[0]) / s.shape[0]
+        cloud.det = s
+        return s
+
+    # ---- per pair ------------------------------------------------------------------------------------------
+    def sample(self, c0, c1, keynum):
+        """Keypoint sampling; consumes the global numpy RNG exactly like test/matcher.py:75-88."""
+        n0, n1 = c0.before.shape[0], c1.before.shape[0]
+        if self.cfg.RD:
+            s0 = self.sampler(c0, keynum)
+            s1 = self.sampler(c1, keynum)
+        else:
+            s0 = np.arange(n0); s1 = np.arange(n1)
+            np.random.shuffle(s0); np.random.shuffle(s1)
+            s0 = s0[0:keynum]; s1 = s1[0:keynum]
+        return s0, s1
+
+    def match_mutual(self, c0, c1, s0, s1):
+        """-> (match buffer [m,2] int64 device, count int32[1] device); test/matcher.py:90-107."""
+        d0 = torch.from_numpy(np.ascontiguousarray(s0, np.int64)).cuda()
+        d1 = torch.from_numpy(np.ascontiguousarray(s1, np.int64)).cuda()
+        nn01 = hip.nn_search(c0.inv, c1.inv, src_rows=d0, tgt_rows=d1)     # for each sampled kp of cloud 0: nearest in cloud 1
+        nn10 = hip.nn_search(c1.inv, c0.inv, src_rows=d1, tgt_rows=d0)
+        return hip.mutual_matches(nn01, nn10, d0, d1)
+
+    def local_transforms(self, c0, c1, matches):
+        """Des2R + ET + assembly: matches [M,2] int64 device -> (dr_index [M], Trans [M,3,4] f64)."""
+        rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
+        dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0)
+        x = hip.et_gather(c0.before, c1.before, c0.eqv, c1.eqv, dr, rows0=rows0, rows1=rows1)
+        with torch.no_grad():
+            q = self.et.trunk_and_head(x)
+        Trans = hip.quat_to_trans(q, dr, c0.keys, c1.keys, rows0=rows0, rows1=rows1)
+        return dr, Trans, rows0, rows1
+
+    def ransac(self, c0, c1, rows0, rows1, Trans, scores, hyp_rows):
+        """One-shot RANSAC + two refinements; everything stays on the device.  -> (T [4,4], best int32[1])."""
+        k0 = hip.gather_rows_f64(c0.keys, rows0); k1 = hip.gather_rows_f64(c1.keys, rows1)
+        ird = float(self.cfg.ransac_ird)
+        _, best, _ = hip.ransac_score(k0, k1, scores, Trans, ird, hyp_rows=hyp_rows)
+        T1 = hip.refine(k0, k1, scores, ird * 2.0, Trans=Trans, hyp_rows=hyp_rows, best=best)
+        T2 = hip.refine(k0, k1, scores, ird, T_in=T1)
+        return T2, best
+
+    # ---- whole scene -----------------------------------------------------------------------------------------
+    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False):
+        """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
+        Returns [PairResult]."""
+        keynum = self.cfg.keynum if keynum is None else keynum
+        max_iter = self.cfg.max_iter if max_iter is None else max_iter
+        used = sorted({int(i) for p in pair_ids for i in p})
+        clouds = {i: self.extract(feats[i], keys[i]) for i in used}
+        if self.cfg.RD:
+            for i in used:
+                self.detect(clouds[i])
+        # stage 3: all pairs
+        pend = []
+        for a, b in pair_ids:
+            c0, c1 = clouds[int(a)], clouds[int(b)]
+            s0, s1 = self.sample(c0, c1, keynum)
+            pend.append(self.match_mutual(c0, c1, s0, s1))
+        counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
+        # stage 4: all pairs
+        T_all, best_all = [], []
+        local = []
+        for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts):
+            c0, c1 = clouds[int(a)], clouds[int(b)]
+            M = int(M)
+            matches = mbuf[:M]
+            local.append((c0, c1, matches) + self.local_transforms(c0, c1, matches))
+        for (c0, c1, matches, dr, Trans, rows0, rows1) in local:
+            M = matches.shape[0]
+            index = np.arange(M)
+            np.random.shuffle(index)                                        # estimator.py:423-424
+            hyp = torch.from_numpy(index[0:max_iter].astype(np.int64)).cuda()
+            w = torch.ones(M, dtype=torch.float64, device='cuda')          # matcher.py:109: scores = ones(M)
+            T2, best = self.ransac(c0, c1, rows0, rows1, Trans, w, hyp)
+            T_all.append(T2); best_all.append(best)
+        T_host = torch.stack(T_all).cpu().numpy()                           # the one sync of the estimator stage
+        best_host = torch.cat(best_all).cpu().numpy()
+        out = []
+        for i, (a, b) in enumerate(pair_ids):
+            out.append(PairResult(a, b, int(counts[i]), T_host[i], int(best_host[i]),
+                                  matches=local[i][2] if keep_matches else None))
+        return out

@@ -129,6 +129,10 @@ class ConvLayer:
 
 _gather_cache = {}
 
+# bench.py sets this to a list to collect (shape tag, start event, end event) per group-conv launch; the
+# events are recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+
 
 def gather_table(key, array):
     """int32 device copy of a [Lout,KS] gather table, cached by key."""
@@ -153,9 +157,15 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None):
     Lout = int(gather.shape[0]) if Lout is None else Lout
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
+    if PROFILE is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().roreg_group_conv(_ptr(x, torch.float32), _ptr(layer.wpack), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
                                   _ptr(residual, torch.float32), _ptr(out, torch.float32), _ptr(gather, torch.int32),
                                   B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv')
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(((B, Cin, layer.Cout, Lout, layer.KS), e0, e1))
     return out
 
 
