@@ -42,10 +42,15 @@ int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_host, const
 size_t roreg_group_conv_packed_size(int Cin, int Cout, int KS);            /* in floats */
 int roreg_group_conv_pack_weights(const float *W_host /* [Cout,Cin,KS] */, int Cin, int Cout, int KS,
                                   float *wpack_host /* roreg_group_conv_packed_size floats */);
+/* Small problems (few output tiles, long reduction) are split along the channel axis; the partial sums
+ * go through a caller-owned workspace and are reduced in a fixed order (deterministic).  Size in floats,
+ * 0 when the launch needs none. */
+size_t roreg_group_conv_workspace_size(int B, int Cin, int Cout, int Lin, int Lout, int KS);
 int roreg_group_conv(const float *x, const float *wpack, const float *bias,
                      const float *bn_scale, const float *bn_shift, const float *residual,
                      float *out, const int32_t *gather,
-                     int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
+                     int B, int Cin, int Cout, int Lin, int Lout, int KS,
+                     float *workspace, size_t workspace_floats, void *stream);
 
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */

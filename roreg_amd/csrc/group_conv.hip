@@ -33,7 +33,9 @@ struct GCParams {
     const float *residual;
     float *out;
     const int32_t *gather;
+    float *partial;        // split-K workspace [ksplit][B*Cout*Lout] (nullptr when ksplit == 1)
     int B, Cin, Cout, CoutPad, Lout, ncols, gt_bytes;
+    int ksplit, cin_per_slice;
 };
 
 template <int KS, int LIN, int CT, int WO, int WB, int OTW>
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256, 2) void group_conv_kernel(GCParams p) {
 
     const bool has_bn = p.bn_scale != nullptr;
 
-    for (int c0 = 0; c0 < p.Cin; c0 += CT) {
+    const int c_begin = blockIdx.y * p.cin_per_slice, c_end = c_begin + p.cin_per_slice;
+    for (int c0 = c_begin; c0 < c_end; c0 += CT) {
         __syncthreads();   // previous chunk fully consumed (also orders the gather-table fill)
         // ---- stage act(x[b_first .. b_first+nkp) [c0 .. c0+CT) [0 .. LIN)) into LDS -----------------
         if constexpr (LIN % 4 == 0) {
@@ -145,6 +148,22 @@ __global__ __launch_bounds__(256, 2) void group_conv_kernel(GCParams p) {
     }
 
     // ---- epilogue: bias (+ residual), masked store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    if (p.ksplit > 1) {     // split-K: raw partial sums; bias/residual are applied by the reduce kernel
+        float *part = p.partial + (size_t)blockIdx.y * ((size_t)p.B * p.Cout * p.Lout);
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!valid[t]) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (o < p.Cout) part[((size_t)bcol[t] * p.Cout + o) * p.Lout + gi[t]] = acc[ot][t][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ot = 0; ot < OTW; ++ot) {
 #pragma unroll
@@ -164,10 +183,34 @@ __global__ __launch_bounds__(256, 2) void group_conv_kernel(GCParams p) {
     }
 }
 
+// split-K reduction in a fixed slice order (deterministic): out = bias + sum_s partial[s] (+ residual)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
+                                                            const float *__restrict__ residual, float *__restrict__ out,
+                                                            size_t n, int Cout, int Lout, int ksplit) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int o = (int)((i / Lout) % Cout);
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += partial[(size_t)s * n + i];
+    v += bias[o];
+    if (residual) v += residual[i];
+    out[i] = v;
+}
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// number of K slices for an under-filled grid: aim at >= 512 workgroups, slices are whole channel chunks
+inline int choose_ksplit(int n_wg, int n_chunks) {
+    if (n_wg >= 256) return 1;
+    int want = (512 + n_wg - 1) / n_wg;
+    int s = 1;
+    for (int d = 1; d <= n_chunks; ++d)
+        if (n_chunks % d == 0 && d <= want) s = d;
+    return s;
+}
+
 template <int KS, int LIN, int CT, int WO, int WB, int OTW>
-int launch(GCParams p, hipStream_t stream) {
+int launch(GCParams p, hipStream_t stream, float *ws, size_t ws_floats, size_t *query_ws) {
     constexpr int OT = WO * OTW * 32;
     constexpr int NCOL = WB * 128;
     if (p.CoutPad % OT != 0) {
@@ -186,6 +229,11 @@ int launch(GCParams p, hipStream_t stream) {
         roreg::set_error("roreg_group_conv: tile needs %zu B of LDS", lds);
         return 2;
     }
+    const int n_ct = (p.ncols + NCOL - 1) / NCOL;
+    const int grid = n_ct * (p.CoutPad / OT);
+    const int ksplit = choose_ksplit(grid, p.Cin / CT);
+    const size_t n_out = (size_t)p.B * p.Cout * p.Lout;
+    if (query_ws) { *query_ws = ksplit > 1 ? (size_t)ksplit * n_out : 0; return 0; }
     auto kern = group_conv_kernel<KS, LIN, CT, WO, WB, OTW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -195,9 +243,18 @@ int launch(GCParams p, hipStream_t stream) {
             return 1;
         }
     }
-    const int n_ct = (p.ncols + NCOL - 1) / NCOL;
-    const int grid = n_ct * (p.CoutPad / OT);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    p.ksplit = ksplit; p.cin_per_slice = p.Cin / ksplit;
+    if (ksplit > 1) {
+        if (!ws || ws_floats < (size_t)ksplit * n_out) {
+            roreg::set_error("roreg_group_conv: split-K needs a workspace of %zu floats (got %zu)", (size_t)ksplit * n_out, ws_floats);
+            return 2;
+        }
+        p.partial = ws;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, ksplit), dim3(256), lds, stream, p);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, ws, p.bias, p.residual,
+                           p.out, n_out, p.Cout, p.Lout, ksplit);
     ROREG_CHECK_LAUNCH("roreg_group_conv");
     return 0;
 }
@@ -226,9 +283,21 @@ extern "C" int roreg_group_conv_pack_weights(const float *W, int Cin, int Cout, 
     return 0;
 }
 
+static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_t wsf, size_t *q);
+
+extern "C" size_t roreg_group_conv_workspace_size(int B, int Cin, int Cout, int Lin, int Lout, int KS) {
+    GCParams p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = round_up(Cout, 32); p.Lout = Lout; p.ncols = B * Lout;
+    size_t q = 0;
+    if (B <= 0 || dispatch(p, Lin, KS, nullptr, nullptr, 0, &q) != 0) return 0;
+    return q;
+}
+
 extern "C" int roreg_group_conv(const float *x, const float *wpack, const float *bias, const float *bn_scale,
                                 const float *bn_shift, const float *residual, float *out, const int32_t *gather,
-                                int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+                                int B, int Cin, int Cout, int Lin, int Lout, int KS, float *workspace, size_t workspace_floats,
+                                void *stream) {
     ROREG_REQUIRE(x && wpack && bias && out && gather, "roreg_group_conv: null pointer");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv: bn_scale/bn_shift must come together");
     ROREG_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Lout > 0 && Lin > 0, "roreg_group_conv: bad sizes");
@@ -238,24 +307,28 @@ extern "C" int roreg_group_conv(const float *x, const float *wpack, const float 
     p.x = x; p.wp = reinterpret_cast<const float4 *>(wpack); p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
     p.residual = residual; p.out = out; p.gather = gather;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = round_up(Cout, 32); p.Lout = Lout; p.ncols = B * Lout; p.gt_bytes = 0;
-    hipStream_t s = roreg::as_stream(stream);
+    p.partial = nullptr; p.ksplit = 1; p.cin_per_slice = Cin;
+    return dispatch(p, Lin, KS, roreg::as_stream(stream), workspace, workspace_floats, nullptr);
+}
+
+static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_t wsf, size_t *q) {
     const int cp = p.CoutPad;
     if (KS == 13 && Lin == 60) {
-        if (cp % 128 == 0) return launch<13, 60, 32, 2, 2, 2>(p, s);
-        if (cp % 64 == 0) return launch<13, 60, 16, 1, 4, 2>(p, s);
-        return launch<13, 60, 16, 1, 4, 1>(p, s);
+        if (cp % 128 == 0) return launch<13, 60, 32, 2, 2, 2>(p, s, ws, wsf, q);
+        if (cp % 64 == 0) return launch<13, 60, 16, 1, 4, 2>(p, s, ws, wsf, q);
+        return launch<13, 60, 16, 1, 4, 1>(p, s, ws, wsf, q);
     }
     if (KS == 13 && Lin == 45) {
-        if (cp % 128 == 0) return launch<13, 45, 16, 2, 2, 2>(p, s);
-        return launch<13, 45, 16, 1, 4, 1>(p, s);
+        if (cp % 128 == 0) return launch<13, 45, 16, 2, 2, 2>(p, s, ws, wsf, q);
+        return launch<13, 45, 16, 1, 4, 1>(p, s, ws, wsf, q);
     }
     if (KS == 13 && Lin == 13) {
-        if (cp % 256 == 0) return launch<13, 13, 8, 4, 1, 2>(p, s);
-        return launch<13, 13, 8, 1, 4, 1>(p, s);
+        if (cp % 256 == 0) return launch<13, 13, 8, 4, 1, 2>(p, s, ws, wsf, q);
+        return launch<13, 13, 8, 1, 4, 1>(p, s, ws, wsf, q);
     }
     if (KS == 1 && Lin == 1) {
-        if (cp % 128 == 0) return launch<1, 1, 32, 2, 2, 2>(p, s);
-        return launch<1, 1, 32, 1, 4, 1>(p, s);
+        if (cp % 128 == 0) return launch<1, 1, 32, 2, 2, 2>(p, s, ws, wsf, q);
+        return launch<1, 1, 32, 1, 4, 1>(p, s, ws, wsf, q);
     }
     roreg::set_error("roreg_group_conv: unsupported (KS=%d, Lin=%d)", KS, Lin);
     return 2;

@@ -25,7 +25,8 @@ PROTOTYPES = {
     'roreg_set_group_tables': (c_int, [_P, _P, _P]),
     'roreg_group_conv_packed_size': (c_size_t, [c_int, c_int, c_int]),
     'roreg_group_conv_pack_weights': (c_int, [_P, c_int, c_int, c_int, _P]),
-    'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_group_conv_workspace_size': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, _P, c_int, _P]),
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
     'roreg_inv_descriptor': (c_int, [_P, _P, c_int, _P]),
@@ -157,12 +158,14 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None):
     Lout = int(gather.shape[0]) if Lout is None else Lout
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
+    ws_n = lib().roreg_group_conv_workspace_size(B, Cin, layer.Cout, Lin, Lout, layer.KS)
+    ws = torch.empty(ws_n, dtype=torch.float32, device=x.device) if ws_n else None
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _check(lib().roreg_group_conv(_ptr(x, torch.float32), _ptr(layer.wpack), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
                                   _ptr(residual, torch.float32), _ptr(out, torch.float32), _ptr(gather, torch.int32),
-                                  B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv')
+                                  B, Cin, layer.Cout, Lin, Lout, layer.KS, _ptr(ws), ws_n, _stream()), 'roreg_group_conv')
     if PROFILE is not None:
         e1.record()
         PROFILE.append(((B, Cin, layer.Cout, Lout, layer.KS), e0, e1))
