@@ -123,12 +123,16 @@ int roreg_ransac_score(const double *k0, const double *k1, const double *w, int 
 
 /* Refinement step: inliers of T_in (3x4 taken from T_in, or from Trans[hyp_rows[*best]] when best!=NULL)
  * at threshold `dist`; weights w/sum(w); weighted centroids; H = (k0-c0)^T diag(w) (k1-c1); R = U V^T of
- * the 3x3 SVD (no reflection guard); t = c0 - c1 R^T.  T_out f64 [4,4].
+ * the 3x3 SVD (no reflection guard); t = c0 - c1 R^T.  T_out f64 [4,4].  The SVD runs on the device
+ * (one-sided Jacobi); when H is rank-deficient (<= 2 inliers, collinear inliers) U V^T is not unique and the
+ * reference's value is whatever LAPACK's null-space basis gives, so stats_out exposes H, the centroids and
+ * the weight sum for a host LAPACK evaluation of exactly that case.
  * Replaces refiner.Refine_trans (test/estimator.py:28-72). */
 int roreg_refine(const double *k0, const double *k1, const double *w, int M,
                  const double *T_in, int t_in_stride /* 4 for 3x4/4x4 rows */,
                  const double *Trans, const int64_t *hyp_rows, const int32_t *best,
-                 double dist, double *T_out, void *stream);
+                 double dist, double *T_out, double *stats_out /* optional f64[16]: H(9), c0(3), c1(3), sum w */,
+                 void *stream);
 
 /* Gather rows: out[i] = src[rows[i]] for f64 [.,3] keypoints (estimator.py:407-408). */
 int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                                                      const double *__restrict__ w, int M, const double *__restrict__ T_in,
                                                      int t_stride, const double *__restrict__ Trans,
                                                      const int64_t *__restrict__ hyp_rows, const int32_t *__restrict__ best,
-                                                     double thr2, double *__restrict__ T_out) {
+                                                     double thr2, double *__restrict__ T_out, double *__restrict__ stats) {
     __shared__ double red[4];
     __shared__ double Ts[12];
     const int tid = threadIdx.x;
@@ -187,9 +187,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             b0 += wi * k1[3 * i]; b1 += wi * k1[3 * i + 1]; b2 += wi * k1[3 * i + 2];
         }
     }
+    double cnt = 0;
+    for (int i = tid; i < M; i += 256)
+        if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) cnt += 1.0;
+    const int n_inl = (int)block_sum(cnt, red, tid);
     sw = block_sum(sw, red, tid);
-    const double c0x = block_sum(a0, red, tid) / sw, c0y = block_sum(a1, red, tid) / sw, c0z = block_sum(a2, red, tid) / sw;
-    const double c1x = block_sum(b0, red, tid) / sw, c1y = block_sum(b1, red, tid) / sw, c1z = block_sum(b2, red, tid) / sw;
+    double c0x = block_sum(a0, red, tid) / sw, c0y = block_sum(a1, red, tid) / sw, c0z = block_sum(a2, red, tid) / sw;
+    double c1x = block_sum(b0, red, tid) / sw, c1y = block_sum(b1, red, tid) / sw, c1z = block_sum(b2, red, tid) / sw;
     // pass 2: H = sum w' (k0-c0)(k1-c1)^T
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < M; i += 256) {
@@ -205,6 +209,32 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     double Hm[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Hm[q] = block_sum(h[q], red, tid);
+    if (tid == 0 && n_inl >= 1 && n_inl <= 7) {
+        // Few inliers (a failed registration): the cross-covariance is (nearly) rank-deficient and the reference's
+        // U V^T is decided by rounding noise, so reproduce its statistics bit for bit -- numpy's sequential sums for
+        // n < 8 and the k-ordered FMA chain of its dgemm (refiner.center_cal / SVDR_w, test/estimator.py:32-43).
+        int id[7];
+        int n = 0;
+        for (int i = 0; i < M && n < 7; ++i)
+            if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) id[n++] = i;
+        double ssum = 0.0;
+        for (int q = 0; q < n; ++q) ssum = ssum + w[id[q]];
+        double sk[7], c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+        for (int q = 0; q < n; ++q) sk[q] = w[id[q]] / ssum;
+        for (int q = 0; q < n; ++q)
+            for (int d = 0; d < 3; ++d) {
+                const double pa = k0[3 * id[q] + d] * sk[q], pb = k1[3 * id[q] + d] * sk[q];
+                c0[d] = q == 0 ? pa : c0[d] + pa;
+                c1[d] = q == 0 ? pb : c1[d] + pb;
+            }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0.0;
+                for (int q = 0; q < n; ++q) acc = fma((k0[3 * id[q] + r] - c0[r]) * sk[q], k1[3 * id[q] + c] - c1[c], acc);
+                Hm[r * 3 + c] = acc;
+            }
+        sw = ssum; c0x = c0[0]; c0y = c0[1]; c0z = c0[2]; c1x = c1[0]; c1y = c1[1]; c1z = c1[2];
+    }
     if (tid == 0) {
         double R[9];
         polar_uvt(Hm, R);
@@ -218,6 +248,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         T_out[7] = c0y - (c1x * R[3] + c1y * R[4] + c1z * R[5]);
         T_out[11] = c0z - (c1x * R[6] + c1y * R[7] + c1z * R[8]);
         T_out[12] = 0; T_out[13] = 0; T_out[14] = 0; T_out[15] = 1;
+        if (stats) {      // [H (9), c0 (3), c1 (3), sum of weights]: lets the host redo the 3x3 SVD with LAPACK when H is rank-deficient
+            for (int q = 0; q < 9; ++q) stats[q] = Hm[q];
+            stats[9] = c0x; stats[10] = c0y; stats[11] = c0z; stats[12] = c1x; stats[13] = c1y; stats[14] = c1z; stats[15] = sw;
+        }
     }
 }
 
@@ -238,11 +272,11 @@ extern "C" int roreg_ransac_score(const double *k0, const double *k1, const doub
 
 extern "C" int roreg_refine(const double *k0, const double *k1, const double *w, int M, const double *T_in, int t_in_stride,
                             const double *Trans, const int64_t *hyp_rows, const int32_t *best, double dist, double *T_out,
-                            void *stream) {
+                            double *stats_out, void *stream) {
     ROREG_REQUIRE(k0 && k1 && w && T_out && M > 0, "roreg_refine: bad arguments");
     ROREG_REQUIRE((best && Trans) || T_in, "roreg_refine: need T_in or (Trans, best)");
     hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(256), 0, roreg::as_stream(stream), k0, k1, w, M, T_in, t_in_stride, Trans,
-                       hyp_rows, best, dist * dist, T_out);
+                       hyp_rows, best, dist * dist, T_out, stats_out);
     ROREG_CHECK_LAUNCH("roreg_refine");
     return 0;
 }

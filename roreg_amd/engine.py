@@ -101,9 +101,9 @@ class RegistrationEngine:
         k0 = hip.gather_rows_f64(c0.keys, rows0); k1 = hip.gather_rows_f64(c1.keys, rows1)
         ird = float(self.cfg.ransac_ird)
         _, best, _ = hip.ransac_score(k0, k1, scores, Trans, ird, hyp_rows=hyp_rows)
-        T1 = hip.refine(k0, k1, scores, ird * 2.0, Trans=Trans, hyp_rows=hyp_rows, best=best)
-        T2 = hip.refine(k0, k1, scores, ird, T_in=T1)
-        return T2, best
+        T1, st1 = hip.refine(k0, k1, scores, ird * 2.0, Trans=Trans, hyp_rows=hyp_rows, best=best, want_stats=True)
+        T2, st2 = hip.refine(k0, k1, scores, ird, T_in=T1, want_stats=True)
+        return T2, best, (k0, k1, st1, st2)
 
     # ---- whole scene -----------------------------------------------------------------------------------------
     def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False):
@@ -124,7 +124,7 @@ class RegistrationEngine:
             pend.append(self.match_mutual(c0, c1, s0, s1))
         counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
         # stage 4: all pairs
-        T_all, best_all = [], []
+        T_all, best_all, aux_all = [], [], []
         local = []
         for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts):
             c0, c1 = clouds[int(a)], clouds[int(b)]
@@ -137,10 +137,21 @@ class RegistrationEngine:
             np.random.shuffle(index)                                        # estimator.py:423-424
             hyp = torch.from_numpy(index[0:max_iter].astype(np.int64)).cuda()
             w = torch.ones(M, dtype=torch.float64, device='cuda')          # matcher.py:109: scores = ones(M)
-            T2, best = self.ransac(c0, c1, rows0, rows1, Trans, w, hyp)
-            T_all.append(T2); best_all.append(best)
+            T2, best, aux = self.ransac(c0, c1, rows0, rows1, Trans, w, hyp)
+            T_all.append(T2); best_all.append(best); aux_all.append((w,) + aux)
         T_host = torch.stack(T_all).cpu().numpy()                           # the one sync of the estimator stage
         best_host = torch.cat(best_all).cpu().numpy()
+        st_host = torch.stack([torch.stack([a[3], a[4]]) for a in aux_all]).cpu().numpy()
+        # The device closes each refinement with its own 3x3 SVD.  When a cross-covariance is rank-deficient
+        # (<= 2 inliers: a failed registration) U V^T is not unique and the reference's value is LAPACK's; redo
+        # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.
+        from .test.estimator import _kabsch_host, _dev64
+        ird = float(self.cfg.ransac_ird)
+        for i, (w, k0, k1, _, _) in enumerate(aux_all):
+            if hip.stats_rank_deficient(st_host[i, 0]) or hip.stats_rank_deficient(st_host[i, 1]):
+                T1 = _kabsch_host(st_host[i, 0])
+                _, st = hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)
+                T_host[i] = _kabsch_host(st)
         out = []
         for i, (a, b) in enumerate(pair_ids):
             out.append(PairResult(a, b, int(counts[i]), T_host[i], int(best_host[i]),

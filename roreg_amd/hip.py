@@ -37,7 +37,7 @@ PROTOTYPES = {
     'roreg_et_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
     'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
-    'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P]),
+    'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
 }
 
@@ -269,14 +269,37 @@ def ransac_score(k0, k1, w, Trans, ird, hyp_rows=None, want_mask=False):
     return ov[:H], best, mask
 
 
-def refine(k0, k1, w, dist, T_in=None, Trans=None, hyp_rows=None, best=None):
+def refine(k0, k1, w, dist, T_in=None, Trans=None, hyp_rows=None, best=None, want_stats=False):
+    """-> T [4,4] f64 (device)  [, stats f64[16] = H(9), c0(3), c1(3), sum w]."""
     M = k0.shape[0]
     out = torch.empty((4, 4), dtype=torch.float64, device=k0.device)
-    stride = 4
-    _check(lib().roreg_refine(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), M, _ptr(T_in, torch.float64), stride,
+    stats = torch.empty(16, dtype=torch.float64, device=k0.device) if want_stats else None
+    _check(lib().roreg_refine(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), M, _ptr(T_in, torch.float64), 4,
                               _ptr(Trans, torch.float64), _ptr(hyp_rows, torch.int64), _ptr(best, torch.int32), float(dist), _ptr(out),
-                              _stream()), 'roreg_refine')
-    return out
+                              _ptr(stats), _stream()), 'roreg_refine')
+    return (out, stats) if want_stats else out
+
+
+def kabsch_from_stats(stats):
+    """Host evaluation of the refinement's closing step from the device-reduced statistics, with the same
+    LAPACK call as the reference (np.linalg.svd; test/estimator.py:39-43,48-51) -> [4,4] float64."""
+    s = stats if isinstance(stats, np.ndarray) else stats.cpu().numpy()
+    H = s[0:9].reshape(3, 3); c0 = s[9:12]; c1 = s[12:15]
+    U, _, VT = np.linalg.svd(H)
+    R = U @ VT
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = c0 - c1 @ R.T
+    return T
+
+
+def stats_rank_deficient(stats, tol=1e-10):
+    s = stats if isinstance(stats, np.ndarray) else stats.cpu().numpy()
+    H = s[0:9].reshape(3, 3)
+    if not np.isfinite(H).all():
+        return False
+    sv = np.linalg.svd(H, compute_uv=False)
+    return bool(sv[1] <= tol * max(sv[0], 1e-300))
 
 
 def gather_rows_f64(src, rows):

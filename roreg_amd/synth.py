@@ -31,6 +31,12 @@ def seeded_tensor(seed, name, shape):
     rng = _rng_for(seed, name)
     shape = tuple(int(s) for s in shape)
     leaf = name.split('.')[-1]
+    # ET head: keep the residual rotation small (q ~ (1, eps)) so that, as with a trained network, the local
+    # transforms of correct correspondences agree with each other and one-shot RANSAC has real inliers
+    if name == 'PartII_To_R_FC.6.weight':
+        return rng.normal(0.0, 0.02 / np.sqrt(shape[1]), shape).astype(np.float32)
+    if name == 'PartII_To_R_FC.6.bias':
+        return np.array([1.0, 0.0, 0.0, 0.0], np.float32) + rng.normal(0.0, 0.005, shape).astype(np.float32)
     if leaf == 'num_batches_tracked':
         return np.zeros(shape, np.int64)
     if leaf == 'running_mean':

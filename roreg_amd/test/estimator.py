@@ -1,0 +1,313 @@
+"""Stage 4: transformation estimation (mirror of test/estimator.py:14-454).
+
+  extractor_dr_index   -- coarse rotation index per correspondence (Des2R 60x60 cross-correlation argmax)
+  extractor_localtrans -- ET network + assembly of one local rigid transform per correspondence
+  yohoo_ransac / yohoo -- one-shot RANSAC over those transforms + 2 weighted-Kabsch refinements
+  yohoc_ransac / yohoc -- rotation-bin-restricted 3-point RANSAC
+  refiner, R_pre_log
+
+Files: match_{k}/DR_index/{a}-{b}.npy [M] int64, match_{k}/Trans_pre/{a}-{b}.npy [M,3,4] f64,
+match_{k}/{yohoo|yohoc}/{it}iters/{a}-{b}.npz {trans [4,4] f64, recalltime}, .../pre.log."""
+import os
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from .. import hip
+from ..group import tables
+from ..network import name2network
+from ..utils.r_eval import compute_R_diff
+from ..utils.utils import make_non_exists_dir, load_checkpoint
+from . import _cache
+from .extractor import scene_feature_name
+
+
+def R_pre_log(dataset, save_dir):
+    writer = open(f'{save_dir}/pre.log', 'w')
+    pair_num = int(len(dataset.pc_ids))
+    for pair in dataset.pair_ids:
+        pc0, pc1 = pair
+        ransac_result = np.load(f'{save_dir}/{pc0}-{pc1}.npz', allow_pickle=True)
+        transform_pr = ransac_result['trans']
+        writer.write(f'{int(pc0)}\t{int(pc1)}\t{pair_num}\n')
+        writer.write(f'{transform_pr[0][0]}\t{transform_pr[0][1]}\t{transform_pr[0][2]}\t{transform_pr[0][3]}\n')
+        writer.write(f'{transform_pr[1][0]}\t{transform_pr[1][1]}\t{transform_pr[1][2]}\t{transform_pr[1][3]}\n')
+        writer.write(f'{transform_pr[2][0]}\t{transform_pr[2][1]}\t{transform_pr[2][2]}\t{transform_pr[2][3]}\n')
+        writer.write(f'{0.0}\t{0.0}\t{0.0}\t{1.0}\n')
+    writer.close()
+
+
+def _dev64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()
+
+
+def _select_top(scores, match_n):
+    """estimator.py:415-421: the top-`match_n` share (or count) of correspondences by score."""
+    num = max(scores.shape[0] * match_n, 10) if match_n < 0.999 else match_n
+    return np.argsort(scores)[-int(num):]
+
+
+def _kabsch_host(stats):
+    try:
+        return hip.kabsch_from_stats(stats)
+    except np.linalg.LinAlgError:                   # zero inliers: NaN statistics
+        T = np.full((4, 4), np.nan); T[3] = [0, 0, 0, 1]
+        return T
+
+
+def refine_twice(k0, k1, w, ird, T_in=None, Trans=None, hyp_rows=None, best=None):
+    """The two refinements of estimator.py:438-439.  The M-sized reductions (inlier test, weighted centroids,
+    3x3 cross-covariance) run on the device; the closing 3x3 SVD is the reference's own LAPACK call on the host,
+    so that rank-deficient cases (<= 2 inliers) give the reference's value too."""
+    _, st = hip.refine(k0, k1, w, ird * 2.0, T_in=T_in, Trans=Trans, hyp_rows=hyp_rows, best=best, want_stats=True)
+    T1 = _kabsch_host(st)
+    _, st = hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)
+    return _kabsch_host(st)
+
+
+class refiner:
+    def Refine_trans(self, key_m0, key_m1, T, scores, inlinerdist=None):
+        """Weighted Kabsch on the inliers of T at `inlinerdist` (estimator.py:53-72) -> [4,4] float64."""
+        T = np.asarray(T, np.float64)
+        T4 = np.zeros((4, 4)); T4[:T.shape[0], :] = T
+        _, st = hip.refine(_dev64(key_m0), _dev64(key_m1), _dev64(scores), inlinerdist, T_in=_dev64(T4), want_stats=True)
+        return _kabsch_host(st)
+
+
+class extractor_dr_index:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        tables(self.cfg.SO3_related_files)           # validates the files when the directory exists
+
+    def Batch_Des2R_torch(self, des1_eqv, des2_eqv):  # beforerot afterrot
+        return hip.des2r(des1_eqv.to('cuda', torch.float32).contiguous(), des2_eqv.to('cuda', torch.float32).contiguous())
+
+    def Des2R_torch(self, des1_eqv, des2_eqv):
+        return self.Batch_Des2R_torch(des1_eqv[None], des2_eqv[None])[0]
+
+    def Rindex(self, dataset, keynum):
+        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        Save_dir = f'{match_dir}/DR_index'
+        make_non_exists_dir(Save_dir)
+        datasetname = scene_feature_name(dataset)
+        Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        print(f'extract the drindex of the matches on {dataset.name}')
+        for pair in tqdm(dataset.pair_ids):
+            id0, id1 = pair
+            match_pps = torch.from_numpy(np.load(f'{match_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
+            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')
+            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy')
+            pre_idxs = hip.des2r(feats1, feats0, rows1=match_pps[:, 1].contiguous(), rows0=match_pps[:, 0].contiguous())
+            np.save(f'{Save_dir}/{id0}-{id1}.npy', pre_idxs.cpu().numpy())
+
+
+class yohoc_ransac:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.inliner_dist = cfg.ransac_ird
+        self.refiner = refiner()
+
+    def DR_statictic(self, DR_indexs):
+        stat = {i: [] for i in range(60)}
+        for t in range(DR_indexs.shape[0]):
+            stat[int(DR_indexs[t])].append(t)
+        prob = []
+        for i in range(60):
+            if len(stat[i]) < 2:
+                prob.append(0)
+            else:
+                num = float(len(stat[i])) / 100.0
+                prob.append(num * (num - 0.01) * (num - 0.02))
+        prob = np.array(prob)
+        if np.sum(prob) == 0:
+            return None, np.zeros(60)
+        return stat, prob / np.sum(prob)
+
+    def Threepps2Tran(self, kps0_init, kps1_init):
+        center0 = np.mean(kps0_init, 0, keepdims=True)
+        center1 = np.mean(kps1_init, 0, keepdims=True)
+        m = (kps1_init - center1).T @ (kps0_init - center0)
+        U, S, VT = np.linalg.svd(m)
+        rotation = VT.T @ U.T
+        offset = center0 - (center1 @ rotation.T)
+        return np.concatenate([rotation, offset.T], 1)          # 3*4
+
+    def overlap_cal(self, key_m0, key_m1, T, scores):
+        ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist)
+        return float(ov[0].item())
+
+    def transdiff(self, gt, pre):
+        Rdiff = compute_R_diff(gt[0:3:, 0:3], pre[0:3:, 0:3])
+        tdiff = np.sqrt(np.sum(np.square(gt[0:3, 3] - pre[0:3, 3])))
+        return Rdiff, tdiff
+
+    def ransac_once(self, dataset, keynum, max_iter, pair):
+        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        Index_dir = f'{match_dir}/DR_index'
+        Save_dir = f'{match_dir}/yohoc/{max_iter}iters'
+        id0, id1 = pair
+        Keys0 = dataset.get_kps(id0)
+        Keys1 = dataset.get_kps(id1)
+        scores = np.load(f'{match_dir}/scores/{id0}-{id1}.npy')
+        pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
+        Keys_m0_init = Keys0[pps[:, 0]]
+        Keys_m1_init = Keys1[pps[:, 1]]
+        sample_index = np.arange(pps.shape[0])
+        if self.cfg.RM:
+            sample_index = _select_top(scores, self.cfg.match_n)
+        Keys_m0 = Keys_m0_init[sample_index]
+        Keys_m1 = Keys_m1_init[sample_index]
+        Index = np.load(f'{Index_dir}/{id0}-{id1}.npy')[sample_index]
+        stat, prob = self.DR_statictic(Index)
+        if np.sum(prob) < 1e-5:
+            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=np.random.rand(4, 4), center=np.ones([6, 3]), recalltime=50000)
+            return 0
+        # Hypothesis generation consumes the global RNG exactly like the reference's loop (estimator.py:220-241):
+        # its control flow depends only on the RNG and the bin statistics, never on the overlaps, so all
+        # hypotheses can be drawn first and scored in ONE device launch.
+        hyps = []
+        exec_time = 0
+        while len(hyps) < max_iter:
+            if exec_time > 50000:
+                break
+            exec_time += 1
+            R_index = np.random.choice(range(60), p=prob)
+            if len(stat[R_index]) < 2:
+                continue
+            idxs_init = np.random.choice(np.array(stat[R_index]), 3)
+            hyps.append(self.Threepps2Tran(Keys_m0[idxs_init], Keys_m1[idxs_init]))
+        k0 = _dev64(Keys_m0_init); k1 = _dev64(Keys_m1_init); w = _dev64(scores)
+        Trans = _dev64(np.stack(hyps))
+        _, best, _ = hip.ransac_score(k0, k1, w, Trans, self.inliner_dist)
+        T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=Trans, best=best)
+        recall_time = int(best.item()) + 1                      # iter_ransac is 1-based when recorded
+        np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T2, recalltime=recall_time)
+
+    def ransac(self, dataset, keynum, max_iter=1000):
+        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        Save_dir = f'{match_dir}/yohoc/{max_iter}iters'
+        make_non_exists_dir(Save_dir)
+        print(f'Ransac with YOHO-C on {dataset.name}:')
+        # the reference forks one process per pair (Pool(len(pair_ids)), estimator.py:258-262); hypothesis scoring is a
+        # single kernel launch per pair here, so the pairs simply run in order on the device
+        for pair in tqdm(dataset.pair_ids):
+            self.ransac_once(dataset, keynum, max_iter, pair)
+        R_pre_log(dataset, Save_dir)
+        print('Done')
+
+
+class yohoc:
+    def __init__(self, cfg):
+        self.rind_extractor = extractor_dr_index(cfg)
+        self.ransacer = yohoc_ransac(cfg)
+
+    def run(self, dataset, keynum, max_iter):
+        self.rind_extractor.Rindex(dataset, keynum)
+        self.ransacer.ransac(dataset, keynum, max_iter)
+
+
+class extractor_localtrans():
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.network = name2network['ET_test'](self.cfg)
+        self.best_model_fn = f'{self.cfg.model_fn}/ET/model_best.pth'
+        self.Rgroup = tables(self.cfg.SO3_related_files).R.astype(np.float32)
+        self.test_batch_size = self.cfg.bs_ET
+
+    def _load_model(self):
+        if os.path.exists(self.best_model_fn):
+            checkpoint = load_checkpoint(self.best_model_fn)
+            self.network.load_state_dict(checkpoint['network_state_dict'], strict=False)
+        else:
+            raise ValueError("No model exists")
+
+    def Rt_pre(self, dataset, keynum):
+        self._load_model()
+        self.network.eval()
+        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        DRindex_dir = f'{match_dir}/DR_index'
+        Save_dir = f'{match_dir}/Trans_pre'
+        make_non_exists_dir(Save_dir)
+        datasetname = scene_feature_name(dataset)
+        FCGF_dir = f'{self.cfg.output_cache_fn}/{datasetname}/{self.cfg.backbone}_Input_Group_feature'
+        YOMO_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        print(f'Extracting the local transformation on each correspondence of {dataset.name}')
+        for pair in tqdm(dataset.pair_ids):
+            id0, id1 = pair
+            pps = torch.from_numpy(np.load(f'{match_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
+            rows0 = pps[:, 0].contiguous(); rows1 = pps[:, 1].contiguous()
+            f0_in = _cache.load_device(f'{FCGF_dir}/{id0}.npy'); f1_in = _cache.load_device(f'{FCGF_dir}/{id1}.npy')
+            f0_out = _cache.load_device(f'{YOMO_dir}/{id0}.npy'); f1_out = _cache.load_device(f'{YOMO_dir}/{id1}.npy')
+            Index_pre = torch.from_numpy(np.load(f'{DRindex_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
+            keys0 = _dev64(dataset.get_kps(id0)); keys1 = _dev64(dataset.get_kps(id1))
+            outs = []
+            for start in range(0, pps.shape[0], self.test_batch_size):
+                sl = slice(start, start + self.test_batch_size)
+                # feats1 is the "before rotation" side: it is the one permuted by the anchor (estimator.py:293-306)
+                x = hip.et_gather(f0_in, f1_in, f0_out, f1_out, Index_pre[sl].contiguous(), rows0=rows0[sl].contiguous(), rows1=rows1[sl].contiguous())
+                with torch.no_grad():
+                    q = self.network.trunk_and_head(x)
+                outs.append(hip.quat_to_trans(q, Index_pre[sl].contiguous(), keys0, keys1, rows0=rows0[sl].contiguous(), rows1=rows1[sl].contiguous()))
+            Trans = torch.cat(outs, 0).cpu().numpy() if outs else np.zeros((0, 3, 4))
+            np.save(f'{Save_dir}/{id0}-{id1}.npy', Trans)
+
+
+class yohoo_ransac:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.inliner_dist = cfg.ransac_ird
+        T = tables(self.cfg.SO3_related_files)
+        self.Nei_in_SO3 = T.P.astype(np.float64)
+        self.Rgroup = T.R
+        self.refiner = refiner()
+
+    def overlap_cal(self, key_m0, key_m1, T, scores):
+        ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist)
+        return float(ov[0].item())
+
+    def transdiff(self, gt, pre):
+        Rdiff = compute_R_diff(gt[0:3:, 0:3], pre[0:3:, 0:3])
+        tdiff = np.sqrt(np.sum(np.square(gt[0:3, 3] - pre[0:3, 3])))
+        return Rdiff, tdiff
+
+    def ransac(self, dataset, keynum, max_iter=1000):
+        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        Trans_dir = f'{match_dir}/Trans_pre'
+        Save_dir = f'{match_dir}/yohoo/{max_iter}iters'
+        make_non_exists_dir(Save_dir)
+        print(f'Ransac with YOHO-O on {dataset.name}:')
+        for pair in tqdm(dataset.pair_ids):
+            id0, id1 = pair
+            Keys0 = dataset.get_kps(id0)
+            Keys1 = dataset.get_kps(id1)
+            scores = np.load(f'{match_dir}/scores/{id0}-{id1}.npy')
+            pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
+            k0 = _dev64(Keys0[pps[:, 0]]); k1 = _dev64(Keys1[pps[:, 1]])
+            Trans = np.load(f'{Trans_dir}/{id0}-{id1}.npy')
+            rows = np.arange(Trans.shape[0])
+            if self.cfg.RM:
+                rows = _select_top(scores, self.cfg.match_n)           # hypotheses only from the best-scored matches
+            index = np.arange(rows.shape[0])
+            np.random.shuffle(index)                                    # estimator.py:423-425
+            hyp = torch.from_numpy(np.ascontiguousarray(rows[index[0:max_iter]], np.int64)).cuda()
+            w = _dev64(scores)
+            TransD = _dev64(Trans)
+            _, best, _ = hip.ransac_score(k0, k1, w, TransD, self.inliner_dist, hyp_rows=hyp)
+            T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=TransD, hyp_rows=hyp, best=best)
+            recall_time = max(int(best.item()), 0)
+            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T2, recalltime=recall_time)
+        R_pre_log(dataset, Save_dir)
+
+
+class yohoo:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.rind_extractor = extractor_dr_index(cfg)
+        self.localT_extractor = extractor_localtrans(cfg)
+        self.ransacer = yohoo_ransac(cfg)
+
+    def run(self, dataset, keynum, max_iter):
+        self.rind_extractor.Rindex(dataset, keynum)
+        self.localT_extractor.Rt_pre(dataset, keynum)
+        self.ransacer.ransac(dataset, keynum, max_iter)

@@ -1,0 +1,162 @@
+"""Stage 3: matching (mirror of test/matcher.py:11-210).
+
+  NMS_sample(num,k).sample(keys,scores)  -- non-maximum suppression sampling on detector scores
+  mutual(cfg).run(dataset,keynum)        -- mutual nearest neighbours of the invariant descriptors
+  yoho_mat(cfg).run(dataset,keynum)      -- rotation-coherence matcher (Match_ot)
+
+Outputs: match_{keynum}/{id0}-{id1}.npy [M,2] int64 (col0 -> pc0, col1 -> pc1) and scores/{id0}-{id1}.npy."""
+import os
+
+import numpy as np
+import torch
+import tqdm
+
+from .. import hip
+from ..network import name2network
+from ..utils.knn_search import knn_module
+from ..utils.utils import make_non_exists_dir, to_cuda, load_checkpoint
+from . import _cache
+from .extractor import scene_feature_name
+
+
+class NMS_sample():
+    def __init__(self, num, k):
+        '''Non-maximum suppression'''
+        self.k = k
+        self.num = num
+        self.KNN = knn_module.KNN(self.k)
+
+    def sample(self, keys, scores):
+        if keys.shape[0] < self.num:                     # NB '<': equal sizes still go through NMS (matcher.py:19)
+            return np.arange(keys.shape[0])
+        keys = torch.from_numpy(keys.astype(np.float32)[None, :, :]).permute(0, 2, 1)
+        d, argmin = self.KNN(keys, keys)
+        argmin = argmin[0].permute(1, 0).cpu().numpy()   # N*k
+        scores_nei = scores[argmin.reshape(-1)].reshape(-1, self.k)
+        nei_max = np.max(scores_nei, axis=-1)
+        sam_indexs = np.where(scores >= nei_max)[0]
+        if sam_indexs.shape[0] > self.num:
+            sam_scores = scores[sam_indexs]
+            sam_scores = sam_scores / np.sum(sam_scores)
+            resam_indexs = np.argsort(sam_scores)[-self.num:]
+            sam_indexs = sam_indexs[resam_indexs]
+        if sam_indexs.shape[0] < self.num:
+            left = self.num - sam_indexs.shape[0]
+            index_left = np.where(scores < nei_max)[0]
+            scores_left = scores[index_left]
+            left_index = np.argsort(scores_left)[-left:]
+            left_index = index_left[left_index]
+            sam_indexs = np.concatenate([sam_indexs, left_index], axis=0)
+        return sam_indexs
+
+
+def _sample_pair(cfg, sampler, dataset, datasetname, id0, id1, n0, n1, keynum):
+    """Keypoint sampling of one pair; identical global-RNG consumption to matcher.py:75-88."""
+    if cfg.RD:
+        det_scores0 = np.load(f'{cfg.output_cache_fn}/{datasetname}/det_score/{id0}.npy')
+        det_scores1 = np.load(f'{cfg.output_cache_fn}/{datasetname}/det_score/{id1}.npy')
+        sample0 = sampler.sample(dataset.get_kps(id0), det_scores0)
+        sample1 = sampler.sample(dataset.get_kps(id1), det_scores1)
+    else:
+        sample0 = np.arange(n0)
+        sample1 = np.arange(n1)
+        np.random.shuffle(sample0)
+        np.random.shuffle(sample1)
+        sample0 = sample0[0:keynum]
+        sample1 = sample1[0:keynum]
+    return sample0, sample1
+
+
+class mutual():
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.KNN = knn_module.KNN(1)
+
+    def run(self, dataset, keynum=5000):
+        self.sampler = NMS_sample(keynum, 5)
+        print(f'Matching the keypoints with mutual on {dataset.name}')
+        Save_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        make_non_exists_dir(Save_dir)
+        Save_score_dir = f'{Save_dir}/scores'
+        make_non_exists_dir(Save_score_dir)
+        datasetname = scene_feature_name(dataset)
+        Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        for pair in tqdm.tqdm(dataset.pair_ids):
+            id0, id1 = pair
+            eqv0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')       # N*32*60, HBM-resident across pairs
+            eqv1 = _cache.load_device(f'{Feature_dir}/{id1}.npy')
+            inv0 = hip.inv_descriptor(eqv0)                               # mean over g, / (norm + 1e-5)  (matcher.py:69-72)
+            inv1 = hip.inv_descriptor(eqv1)
+            sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, eqv0.shape[0], eqv1.shape[0], keynum)
+            s0 = torch.from_numpy(np.ascontiguousarray(sample0, np.int64)).cuda()
+            s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
+            nn01 = hip.nn_search(inv0, inv1, src_rows=s0, tgt_rows=s1)
+            nn10 = hip.nn_search(inv1, inv0, src_rows=s1, tgt_rows=s0)
+            buf, cnt = hip.mutual_matches(nn01, nn10, s0, s1)
+            match_pps = buf[:int(cnt.item())].cpu().numpy()
+            np.save(f'{Save_dir}/{id0}-{id1}.npy', match_pps)
+            np.save(f'{Save_score_dir}/{id0}-{id1}.npy', np.ones(match_pps.shape[0]))
+
+
+class yoho_mat():
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.network = name2network['RM_test'](self.cfg)
+        self.best_model_fn = f'{self.cfg.model_fn}/RM/model_best.pth'
+        self.KNN = knn_module.KNN(1)
+        self._load_model()
+
+    def _load_model(self):
+        if os.path.exists(self.best_model_fn):
+            checkpoint = load_checkpoint(self.best_model_fn)
+            self.network.load_state_dict(checkpoint['network_state_dict'], strict=True)
+        else:
+            raise ValueError("No model exists")
+
+    def get_ot_match(self, batch):
+        self.network.eval()
+        with torch.no_grad():
+            result = self.network(to_cuda(batch))
+        matches0 = result['matches0'][0].cpu().numpy()
+        scores = result['matching_scores0'][0].cpu().numpy()
+        scores0 = scores
+        scores1 = result['matching_scores1'][0].cpu().numpy()
+        valid = np.where(matches0 != -1)[0]
+        score_ms = scores[valid]
+        if valid.shape[0] < 3:
+            pairs = None
+        else:
+            pairs = np.stack([valid, matches0[valid]], 1)
+        return pairs, np.array(score_ms), scores0, scores1
+
+    def run(self, dataset, keynum=2500):
+        self.sampler = NMS_sample(keynum, 5)
+        Save_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
+        make_non_exists_dir(Save_dir)
+        Save_score_dir = f'{Save_dir}/scores'
+        make_non_exists_dir(Save_score_dir)
+        datasetname = scene_feature_name(dataset)
+        Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        print(f'Matching the keypoints with rotation coherence matcher on {dataset.name}')
+        for pair in tqdm.tqdm(dataset.pair_ids):
+            id0, id1 = pair
+            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')
+            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy')
+            sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, feats0.shape[0], feats1.shape[0], keynum)
+            s0 = torch.from_numpy(np.ascontiguousarray(sample0, np.int64)).cuda()
+            s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
+            keys0 = dataset.get_kps(id0)[sample0]
+            keys1 = dataset.get_kps(id1)[sample1]
+            # NB the batch carries pc1 as 'feats0/keys0' and pc0 as 'feats1/keys1' (matcher.py:192-197)
+            batch = {'feats0': feats1[s1][None], 'feats1': feats0[s0][None],
+                     'keys0': torch.from_numpy(keys1[None, :, :].astype(np.float32)),
+                     'keys1': torch.from_numpy(keys0[None, :, :].astype(np.float32))}
+            matches, scores, scores1, scores0 = self.get_ot_match(batch)
+            if matches is None:
+                # the reference crashes here (np.ones(1,2) is a TypeError, matcher.py:200-202); documented
+                # divergence: emit the single dummy correspondence it evidently intended
+                matches = np.ones((1, 2), np.int64)
+                scores = np.ones(1, np.float32)
+            matches_in_former = np.concatenate([sample0[matches[:, 1]][:, None], sample1[matches[:, 0]][:, None]], axis=1)
+            np.save(f'{Save_dir}/{id0}-{id1}.npy', matches_in_former)
+            np.save(f'{Save_score_dir}/{id0}-{id1}.npy', scores)

@@ -234,6 +234,14 @@ def test_ransac_score_masks_bit_exact(tag):
     assert np.abs(T2.cpu().numpy() - z[f'{tag}_refine2']).max() < tol
 
 
+def test_refine_rank1_edge_via_host_lapack():
+    """Two inliers: H has rank 1 and U V^T is LAPACK's arbitrary completion; the stats path reproduces it."""
+    from roreg_amd.test.estimator import refiner
+    z = load_golden('ransac')
+    T = refiner().Refine_trans(z['rank1_k0'], z['rank1_k1'], z['rank1_T'], np.ones(6), inlinerdist=0.1)
+    assert np.abs(T - z['rank1_refined']).max() < 1e-9
+
+
 def test_refine_single_inlier_edge():
     from roreg_amd import hip
     z = load_golden('ransac')

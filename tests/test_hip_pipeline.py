@@ -1,0 +1,179 @@
+"""File-coupled stage classes (the reference's API) and the device-resident engine on the golden scene.  GPU only.
+Stage-wise parity: each stage is fed the REFERENCE's output of the previous stage."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from roreg_amd import synth
+from roreg_amd.parses.parses_test import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, z, **cfg_kw):
+    from roreg_amd.network import name2network
+    root = str(tmp_path)
+    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None,
+                         keynum=int(z['keynum']), bs_GF=50, bs_ET=40, **cfg_kw)
+    for kind, d, seed in [('GF_test', 'GF', 101), ('ET_test', 'ET', 202)]:
+        net = name2network[kind](cfg)
+        synth.seeded_state_dict(net, seed)
+        os.makedirs(f'{root}/ckpt/{d}', exist_ok=True)
+        torch.save({'best_para': 0, 'network_state_dict': net.state_dict()}, f'{root}/ckpt/{d}/model_best.pth')
+    for d in ['RD', 'RM']:
+        os.makedirs(f'{root}/ckpt/{d}', exist_ok=True)
+        sd = {k: torch.from_numpy(v) for k, v in load_golden(f'weights_{d}').items()}
+        torch.save({'best_para': 0, 'network_state_dict': sd}, f'{root}/ckpt/{d}/model_best.pth')
+    ds = synth.make_scene(int(z['scene_seed']), n_clouds=int(z['n_clouds']), n_kpts=int(z['n_kpts']), overlap=0.6, name='synth/scene0')
+    ds.write_inputs(cfg.output_cache_fn)
+    return cfg, ds
+
+
+def _put_yoho(cfg, ds, y):
+    d = f'{cfg.output_cache_fn}/{ds.name}/YOHO_Output_Group_feature'
+    os.makedirs(d, exist_ok=True)
+    for pc in ds.pc_ids:
+        np.save(f'{d}/{pc}.npy', y[f'yoho_{pc}'])
+
+
+def test_stages_mutual_yohoo_stagewise(tmp_path):
+    from roreg_amd.test import name2extractor, name2matcher, name2estimator
+    from roreg_amd.test import _cache
+    z = load_golden('pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, ET='yohoo')
+    keynum = int(z['keynum'])
+    base = f'{cfg.output_cache_fn}/{ds.name}'
+    # stage 1
+    name2extractor['yoho_des'](cfg).run(ds)
+    for pc in ds.pc_ids:
+        got = np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')
+        assert got.dtype == np.float32 and np.abs(got - z[f'yoho_{pc}']).max() < 1e-5
+    _put_yoho(cfg, ds, z); _cache.clear()
+    # stage 3
+    np.random.seed(1234)
+    name2matcher['matmul'](cfg).run(ds, keynum)
+    md = f'{base}/match_{keynum}'
+    for a, b in ds.pair_ids:
+        m = np.load(f'{md}/{a}-{b}.npy'); s = np.load(f'{md}/scores/{a}-{b}.npy')
+        assert m.dtype == np.int64 and np.array_equal(m, z[f'match_{a}_{b}'])
+        assert s.dtype == np.float64 and np.array_equal(s, z[f'mscore_{a}_{b}'])
+    # stage 4
+    est = name2estimator['yohoo'](cfg)
+    est.rind_extractor.Rindex(ds, keynum)
+    for a, b in ds.pair_ids:
+        dr = np.load(f'{md}/DR_index/{a}-{b}.npy')
+        assert dr.dtype == np.int64 and np.array_equal(dr, z[f'dr_{a}_{b}'])
+    est.localT_extractor.Rt_pre(ds, keynum)
+    for a, b in ds.pair_ids:
+        T = np.load(f'{md}/Trans_pre/{a}-{b}.npy')
+        assert T.dtype == np.float64 and T.shape == z[f'transpre_{a}_{b}'].shape
+        assert np.abs(T - z[f'transpre_{a}_{b}']).max() < 2e-4
+        np.save(f'{md}/Trans_pre/{a}-{b}.npy', z[f'transpre_{a}_{b}'])      # identical inputs for the RANSAC stage
+    np.random.seed(4321)
+    est.ransacer.ransac(ds, keynum, 1000)
+    for a, b in ds.pair_ids:
+        r = np.load(f'{md}/yohoo/1000iters/{a}-{b}.npz')
+        assert int(r['recalltime']) == int(z[f'recall_{a}_{b}'])
+        assert np.abs(r['trans'] - z[f'trans_{a}_{b}']).max() < 1e-8
+    got = np.array(open(f'{md}/yohoo/1000iters/pre.log').read().split(), float)
+    want = np.array(z['pre_log'].tobytes().decode().split(), float)
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-8
+
+
+def test_stages_rd_mutual_yohoc_stagewise(tmp_path):
+    from roreg_amd.test import name2detector, name2matcher, name2estimator
+    z = load_golden('pipeline_rd_mutual_yohoc')
+    y = load_golden('pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, RD=True, ET='yohoc')
+    keynum = int(z['keynum'])
+    base = f'{cfg.output_cache_fn}/{ds.name}'
+    _put_yoho(cfg, ds, y)
+    name2detector['yoho_det'](cfg).run(ds)
+    n = int(z['n_kpts'])
+    for pc in ds.pc_ids:
+        got = np.load(f'{base}/det_score/{pc}.npy')
+        assert got.dtype == np.float32
+        assert np.abs(got - z[f'det_{pc}']).max() <= 4.0 / n          # rank noise of the ill-conditioned std (see oracle test)
+        np.save(f'{base}/det_score/{pc}.npy', z[f'det_{pc}'])
+    name2matcher['matmul'](cfg).run(ds, keynum)
+    md = f'{base}/match_{keynum}'
+    for a, b in ds.pair_ids:
+        assert np.array_equal(np.load(f'{md}/{a}-{b}.npy'), z[f'match_{a}_{b}'])
+    est = name2estimator['yohoc'](cfg)
+    est.rind_extractor.Rindex(ds, keynum)
+    for a, b in ds.pair_ids:
+        assert np.array_equal(np.load(f'{md}/DR_index/{a}-{b}.npy'), z[f'dr_{a}_{b}'])
+    np.random.seed(4321)
+    est.ransacer.ransac(ds, keynum, 1000)
+    for a, b in ds.pair_ids:
+        r = np.load(f'{md}/yohoc/1000iters/{a}-{b}.npz')
+        assert int(r['recalltime']) == int(z[f'recall_{a}_{b}'])
+        assert np.abs(r['trans'] - z[f'trans_{a}_{b}']).max() < 1e-8
+
+
+def test_evaluator_metrics_on_reference_files(tmp_path):
+    """fmr / ir / rr computed by the evaluator mirror from the reference's own match + result files."""
+    from roreg_amd.test.evaluator import yoho_evaluator
+    z = load_golden('pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, ET='yohoo')
+    keynum = int(z['keynum'])
+    md = f'{cfg.output_cache_fn}/{ds.name}/match_{keynum}'
+    os.makedirs(f'{md}/scores'); os.makedirs(f'{md}/yohoo/1000iters')
+    for a, b in ds.pair_ids:
+        np.save(f'{md}/{a}-{b}.npy', z[f'match_{a}_{b}']); np.save(f'{md}/scores/{a}-{b}.npy', z[f'mscore_{a}_{b}'])
+        np.savez(f'{md}/yohoo/1000iters/{a}-{b}.npz', trans=z[f'trans_{a}_{b}'], recalltime=z[f'recall_{a}_{b}'])
+    ev = yoho_evaluator(cfg)
+    fmr, ir = ev.fmr_ir_scene(ds)
+    rr, rre, rte = ev.rr_scene(ds)
+    assert abs(fmr - float(z['fmr'])) < 1e-12 and abs(ir - float(z['ir'])) < 1e-12
+    assert abs(rr - float(z['rr'])) < 1e-12 and abs(rre - float(z['rre'])) < 1e-9 and abs(rte - float(z['rte'])) < 1e-9
+
+
+def test_engine_equals_file_coupled_stages(tmp_path):
+    """The device-resident engine and the file-coupled stages run the same kernels in the same order on the same
+    RNG stream: matches and the selected hypothesis are identical; the transform differs only by the closing 3x3
+    SVD (device Jacobi vs host LAPACK), i.e. at 1e-15."""
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    from roreg_amd.test import name2extractor, name2matcher, name2estimator
+    z = load_golden('pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, ET='yohoo')
+    keynum = int(z['keynum'])
+    np.random.seed(99)
+    name2extractor['yoho_des'](cfg).run(ds)
+    name2matcher['matmul'](cfg).run(ds, keynum)
+    name2estimator['yohoo'](cfg).run(ds, keynum, 1000)
+    md = f'{cfg.output_cache_fn}/{ds.name}/match_{keynum}'
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    eng = RegistrationEngine(cfg, gf, et)
+    np.random.seed(99)
+    res = eng.run_scene(ds.feats, [ds.get_kps(i) for i in ds.pc_ids], ds.pair_ids, keynum=keynum, max_iter=1000, keep_matches=True)
+    for r in res:
+        want = np.load(f'{md}/yohoo/1000iters/{r.id0}-{r.id1}.npz')
+        assert np.array_equal(r.matches.cpu().numpy(), np.load(f'{md}/{r.id0}-{r.id1}.npy'))
+        assert r.recalltime == int(want['recalltime'])
+        assert np.abs(r.trans - want['trans']).max() < 1e-10
+
+
+def test_knn_module_api_shapes():
+    from roreg_amd.utils.knn_search import knn_module
+    z = load_golden('knn')
+    d, idx = knn_module.KNN(1)(torch.from_numpy(z['a_target'].T[None].copy()), torch.from_numpy(z['a_source'].T[None].copy()))
+    assert tuple(d.shape) == tuple(z['a_d'].shape) and tuple(idx.shape) == tuple(z['a_idx'].shape)
+    assert not d.is_cuda and idx.dtype == torch.int64
+    assert np.array_equal(idx.numpy(), z['a_idx'])
+    K = torch.from_numpy(z['k5_keys'].T[None].copy())
+    d5, idx5 = knn_module.KNN(5)(K, K)
+    assert tuple(idx5.shape) == tuple(z['k5_idx'].shape) and np.array_equal(idx5.numpy(), z['k5_idx'])
+    assert tuple(d5.shape) == (1, 5, 1, 777)
+
+
+def test_nms_sample_matches_reference():
+    from roreg_amd.test.matcher import NMS_sample
+    z = load_golden('nms')
+    for num in [700, 600, 400, 150, 20]:
+        assert np.array_equal(NMS_sample(num, 5).sample(z['keys'], z['scores']), z[f'idx_{num}'])

@@ -235,6 +235,10 @@ def gen_ransac(cfg):
     Tn = np.concatenate([np.eye(3), np.zeros((3, 1))], 1)
     r = ref_est.refiner().Refine_trans(k0, k1, Tn, np.ones(5), inlinerdist=0.1)
     out.update({'single_k0': k0, 'single_k1': k1, 'single_T': Tn, 'single_refined': r})
+    # two-inlier edge: H has rank 1, U V^T is whatever LAPACK's null-space basis gives
+    k1 = rng.uniform(0, 3, (6, 3)); k0 = rng.uniform(5, 8, (6, 3)); k0[1] = k1[1] + 0.01; k0[4] = k1[4] - 0.02
+    r = ref_est.refiner().Refine_trans(k0, k1, Tn, np.ones(6), inlinerdist=0.1)
+    out.update({'rank1_k0': k0, 'rank1_k1': k1, 'rank1_T': Tn, 'rank1_refined': r})
     save('ransac', **out)
 
 
