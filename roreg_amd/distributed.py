@@ -1,0 +1,94 @@
+"""Multi-GPU: one process per GPU; scan pairs shard with no data-path collective; one gather of the result table.
+
+Pairs only connect clouds of the same scene, so the unit of sharding is the scene (each rank extracts only the clouds it
+needs and keeps them HBM-resident): scenes are assigned by longest-processing-time bin packing on their pair counts,
+and a scene larger than the ideal share is split into contiguous pair ranges (its clouds are then extracted on every
+rank that holds a slice -- 38 MB per cloud, cheap next to the pair work).  The only collective is an all_gather of the
+fixed-width float64 result table [pairs, 20] (= backend 'nccl', i.e. RCCL over xGMI, on GPUs; 'gloo' in CPU tests)."""
+import numpy as np
+import torch
+
+ROW = 20     # scene, id0, id1, n_match, recalltime, trans[16] (row-major -> 15 used + 1 pad)
+
+
+def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=4.0, tolerance=1.10):
+    """pair_counts: {scene: n_pairs}; cloud_counts: {scene: n_clouds} (per-cloud extraction costs about `cloud_cost`
+    pair-units and is paid again by every rank that holds a slice of the scene).
+    -> list (per rank) of [(scene, start, stop)] pair ranges; every pair appears exactly once."""
+    cloud_counts = cloud_counts or {s: 0 for s in pair_counts}
+
+    def cost(p):
+        return (p[2] - p[1]) + cloud_cost * cloud_counts.get(p[0], 0)
+
+    pieces = [(s, 0, n) for s, n in pair_counts.items() if n > 0]
+    ideal = sum(cost(p) for p in pieces) / float(max(world_size, 1))
+
+    def assign(ps):
+        loads = [0.0] * world_size
+        out = [[] for _ in range(world_size)]
+        for p in sorted(ps, key=lambda q: (-cost(q), q[0], q[1])):
+            r = int(np.argmin(loads))
+            out[r].append(p)
+            loads[r] += cost(p)
+        return out, loads
+
+    out, loads = assign(pieces)
+    while world_size > 1 and max(loads) > tolerance * ideal and len(pieces) < 6 * world_size:
+        big = max((p for p in pieces if p[2] - p[1] >= 2), key=cost, default=None)
+        if big is None:
+            break
+        mid = (big[1] + big[2]) // 2
+        cand = [p for p in pieces if p != big] + [(big[0], big[1], mid), (big[0], mid, big[2])]
+        c_out, c_loads = assign(cand)
+        pieces = cand
+        if max(c_loads) < max(loads):
+            out, loads = c_out, c_loads
+    # contiguous ranges of one scene that landed on the same rank are merged
+    for r in range(world_size):
+        out[r].sort()
+        merged = []
+        for p in out[r]:
+            if merged and merged[-1][0] == p[0] and merged[-1][2] == p[1]:
+                merged[-1] = (p[0], merged[-1][1], p[2])
+            else:
+                merged.append(p)
+        out[r] = merged
+    return out
+
+
+def pack_rows(scene_index, results):
+    """[PairResult] -> float64 [n, ROW]."""
+    t = np.zeros((len(results), ROW))
+    for i, r in enumerate(results):
+        t[i, 0] = scene_index; t[i, 1] = float(r.id0); t[i, 2] = float(r.id1); t[i, 3] = r.n_match; t[i, 4] = r.recalltime
+        t[i, 5:20] = np.asarray(r.trans, np.float64).reshape(-1)[:15]
+    return t
+
+
+def unpack_rows(table):
+    out = []
+    for row in table:
+        T = np.eye(4); T.reshape(-1)[:15] = row[5:20]
+        out.append({'scene': int(row[0]), 'id0': str(int(row[1])), 'id1': str(int(row[2])), 'n_match': int(row[3]),
+                    'recalltime': int(row[4]), 'trans': T})
+    return out
+
+
+def gather_table(local, device=None):
+    """all_gather of ragged [n_r, ROW] float64 tables -> [sum n_r, ROW] on every rank (rank order)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(local, np.float64).reshape(-1, ROW)
+    world = dist.get_world_size()
+    dev = device if device is not None else ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    buf = torch.zeros((mx, ROW), dtype=torch.float64, device=dev)
+    if len(local):
+        buf[:len(local)] = torch.as_tensor(np.asarray(local, np.float64), device=dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return np.concatenate([o[:c].cpu().numpy() for o, c in zip(outs, counts)], 0).reshape(-1, ROW)

@@ -1,0 +1,194 @@
+"""Host-side logic that needs no GPU: the C-ABI surface, config defaults, dataset parsing, sharding + gloo gather."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+
+def test_cabi_exports_every_declared_symbol():
+    """libroreg_hip.so loads on a CPU-only box and exports exactly what include/roreg_hip.h declares."""
+    from roreg_amd import hip
+    header = open(os.path.join(ROOT, 'include', 'roreg_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(roreg_\w+)\s*\(', header)))
+    assert len(declared) >= 18
+    L = hip.lib()
+    for name in declared:
+        assert hasattr(L, name), f'{name} declared in roreg_hip.h but not exported'
+        assert name in hip.PROTOTYPES, f'{name} has no ctypes prototype'
+    assert sorted(hip.PROTOTYPES) == declared
+    assert L.roreg_abi_version() == 1
+    # pure host entry points work without a GPU
+    assert L.roreg_group_conv_packed_size(256, 512, 13) == 13 * 256 * 512
+    assert L.roreg_group_conv_packed_size(64, 16, 13) == 13 * 64 * 32          # Cout padded to 32
+
+
+def test_weight_packing_layout():
+    from roreg_amd import hip
+    rng = np.random.default_rng(0)
+    Cout, Cin, KS = 48, 16, 13
+    W = rng.standard_normal((Cout, Cin, KS)).astype(np.float32)
+    n = hip.lib().roreg_group_conv_packed_size(Cin, Cout, KS)
+    out = np.full(n, np.nan, np.float32)
+    assert hip.lib().roreg_group_conv_pack_weights(W.ctypes.data, Cin, Cout, KS, out.ctypes.data) == 0
+    P = out.reshape(KS, Cin // 8, 64, 2, 4)                     # [k][c/8][o (padded)][h][r]
+    for (k, cb, o, h, r) in [(0, 0, 0, 0, 0), (12, 1, 47, 1, 3), (5, 0, 17, 1, 2)]:
+        assert P[k, cb, o, h, r] == W[o, cb * 8 + 2 * r + h, k]
+    assert (P[:, :, 48:] == 0).all()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from roreg_amd import hip
+    monkeypatch.setattr(hip, '_lib', None)
+    monkeypatch.setattr(hip, '_LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(hip.HipError):
+        hip.lib()
+
+
+def test_host_tensor_is_rejected_not_computed_on_cpu():
+    import torch
+    from roreg_amd import hip
+    with pytest.raises(hip.HipError):
+        hip._ptr(torch.zeros(4))
+
+
+def test_parses_defaults_match_reference():
+    from roreg_amd.parses.parses_test import default_config
+    c = default_config()
+    assert (c.GF, c.RD, c.RM, c.ET, c.testset, c.keynum, c.max_iter) == ('yoho_des', False, False, 'yohoc', '3dmatch', 5000, 1000)
+    assert (c.ransac_ird, c.tau_1, c.tau_2, c.tau_3, c.match_n, c.bs_GF, c.bs_ET) == (0.1, 0.05, 0.1, 0.2, 0.5, 1250, 1000)
+    assert c.output_cache_fn == './data/YOHO_FCGF/Testset' and c.model_fn == './checkpoints/FCGF' and c.backbone == 'FCGF'
+    assert c.SO3_related_files == './utils/group_related'
+
+
+def test_state_dict_keys_match_shipped_checkpoints():
+    """RD / RM mirrors load the reference's shipped weights strict=True (key names and shapes)."""
+    import torch
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+    for kind, f in [('RD_test', 'weights_RD'), ('RM_test', 'weights_RM')]:
+        net = name2network[kind](default_config())
+        sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, f + '.npz')).items()}
+        net.load_state_dict(sd, strict=True)
+    gf = name2network['GF_test'](default_config()).state_dict()
+    assert tuple(gf['PartI_net.Conv_in.0.weight'].shape) == (256, 32, 1, 13)
+    assert tuple(gf['PartI_net.SO3_Conv_layers.0.comb_layer_in.2.weight'].shape) == (512, 256, 1, 13)
+    et = name2network['ET_test'](default_config()).state_dict()
+    assert tuple(et['PartII_To_R_FC.6.weight'].shape) == (4, 128, 1, 1) and 'Conv_init.comb_layer.0.running_mean' in et
+
+
+def test_gt_log_parser_on_reference_demo_file(tmp_path):
+    from roreg_amd.dataops.dataset import ThrDMatchPartDataset
+    root = tmp_path / 'kitchen'
+    (root / 'PointCloud').mkdir(parents=True)
+    (root / 'PointCloud' / 'gt.log').write_bytes(open(os.path.join(GOLDEN, 'demo_gt.log'), 'rb').read())
+    ds = ThrDMatchPartDataset(str(root), 2)
+    assert ds.pair_ids == [('0', '1')] and ds.pc_ids == ['0', '1']
+    T = ds.get_transform('0', '1')
+    assert T.dtype == np.float32 and T.shape == (3, 4)
+    assert np.allclose(T, [[0.141, 0.989, 0.034, -2.247], [-0.903, 0.114, 0.414, -1.131], [0.405, -0.089, 0.910, 0.673]])
+
+
+def test_ply_reader_and_keypoints(tmp_path):
+    from roreg_amd.dataops.dataset import ThrDMatchPartDataset, read_ply_points
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-2, 2, (50, 3)).astype(np.float32)
+    root = tmp_path / 's'
+    (root / 'PointCloud').mkdir(parents=True); (root / 'Keypoints').mkdir()
+    hdr = 'ply\nformat binary_little_endian 1.0\nelement vertex 50\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nend_header\n'
+    rec = np.zeros(50, dtype=[('x', '<f4'), ('y', '<f4'), ('z', '<f4'), ('red', 'u1')])
+    rec['x'], rec['y'], rec['z'] = pts[:, 0], pts[:, 1], pts[:, 2]
+    (root / 'PointCloud' / 'cloud_bin_0.ply').write_bytes(hdr.encode() + rec.tobytes())
+    asc = 'ply\nformat ascii 1.0\nelement vertex 50\nproperty double x\nproperty double y\nproperty double z\nend_header\n' + \
+          '\n'.join(' '.join(repr(float(v)) for v in p) for p in pts) + '\n'
+    (root / 'PointCloud' / 'cloud_bin_1.ply').write_text(asc)
+    (root / 'PointCloud' / 'gt.log').write_text('0\t1\t2\n1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n')
+    assert np.array_equal(read_ply_points(str(root / 'PointCloud' / 'cloud_bin_0.ply')), pts.astype(np.float64))
+    assert np.array_equal(read_ply_points(str(root / 'PointCloud' / 'cloud_bin_1.ply')), pts.astype(np.float64))
+    idx = np.array([3, 7, 49, 0])
+    np.savetxt(root / 'Keypoints' / 'cloud_bin_0Keypoints.txt', idx)
+    ds = ThrDMatchPartDataset(str(root), 2)
+    k = ds.get_kps('0')
+    assert k.dtype == np.float64 and np.array_equal(k, pts[idx].astype(np.float64))
+    assert np.array_equal(np.load(root / 'Keypoints_PC' / 'cloud_bin_0Keypoints.npy'), k)
+    assert np.array_equal(ds.get_kps('0'), k)           # served from the cache
+
+
+def test_dropin_aliases():
+    import importlib
+    from roreg_amd import dropin
+    saved = {k: sys.modules.get(k) for k in dropin._ALIASES}
+    try:
+        dropin.install()
+        import network, test, utils.knn_search, parses.parses_test     # noqa: F401
+        assert set(test.name2estimator) == {'yohoc', 'yohoo'} and set(test.name2matcher) == {'matmul', 'yoho_mat'}
+        assert set(network.name2network) >= {'GF_test', 'RD_test', 'RM_test', 'ET_test'}
+        assert utils.knn_search.knn_module.KNN(5).k == 5
+        from test.evaluator import yoho_evaluator                       # noqa: F401
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_shard_scenes_balanced_and_complete():
+    from roreg_amd.distributed import shard_scenes
+    counts = dict(zip('abcdefgh', [449, 217, 159, 207, 104, 54, 292, 138]))       # 3DMatch-like pair counts
+    for world in [1, 2, 4, 8]:
+        sh = shard_scenes(counts, world)
+        assert len(sh) == world
+        seen = {}
+        for r in sh:
+            for scene, a, b in r:
+                assert 0 <= a < b <= counts[scene]
+                seen.setdefault(scene, []).append((a, b))
+        for scene, n in counts.items():
+            rs = sorted(seen[scene])
+            assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(len(rs) - 1))
+        loads = [sum(b - a for _, a, b in r) for r in sh]
+        assert max(loads) <= 1.25 * sum(counts.values()) / world + 1
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from roreg_amd.distributed import shard_scenes, gather_table, ROW
+rank, world, port = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = port
+dist.init_process_group('gloo', rank=rank, world_size=world)
+counts = {'s0': 7, 's1': 3, 's2': 5}
+mine = shard_scenes(counts, world)[rank]
+rows = []
+for scene, a, b in mine:
+    for i in range(a, b):
+        r = np.zeros(ROW); r[0] = int(scene[1:]); r[1] = i; r[2] = i + 1; r[3] = 100 + i; r[5:20] = np.arange(15) + rank
+        rows.append(r)
+table = gather_table(np.array(rows).reshape(-1, ROW))
+assert table.shape == (15, ROW), table.shape
+keys = sorted((int(r[0]), int(r[1])) for r in table)
+assert keys == sorted((s, i) for s, n in [(0, 7), (1, 3), (2, 5)] for i in range(n)), keys
+dist.barrier(); dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_gather_table_world_size_2_gloo(tmp_path):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = str(s.getsockname()[1]); s.close()
+    w = tmp_path / 'worker.py'
+    w.write_text(_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(w), ROOT, str(r), '2', port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'ok' in o
