@@ -96,6 +96,13 @@ int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m,
 int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, const int64_t *rows0,
                 int M, int64_t *idx_out, float *cor_out, void *stream);
 
+/* Generalised 60x60 group cross-correlation: cor[b,a] = sum_f sum_g A[f, T[a,g]] * B[f,g] with A = perm_feats[perm_rows[b]],
+ * B = bcast_feats[bcast_rows[b]] and T = P (transpose_table=0) or P^T (transpose_table=1: T[a,g] = P[g,a]).
+ * idx_out (first argmax) and cor_out (all 60 values) are each optional.  roreg_des2r is the transpose_table=0 case; the
+ * matcher's R_indicator (network/rot_coh_match.py:154-163) is the transpose_table=1 case in both orientations. */
+int roreg_group_corr(const float *perm_feats, const int64_t *perm_rows, const float *bcast_feats, const int64_t *bcast_rows,
+                     int M, int transpose_table, int64_t *idx_out, float *cor_out, void *stream);
+
 /* Build the ET network input x [M,128,60] = cat(before1[r1][:, :, P[a]], before0[r0], after1[r1][:, :, P[a]],
  * after0[r0]) for correspondence rows (r0,r1) and anchor a=pre_idx[b].
  * Replaces batch_create + the per-row permutation loop (test/estimator.py:293-306; network/eqv_trans.py:126-129). */
@@ -136,6 +143,45 @@ int roreg_refine(const double *k0, const double *k1, const double *w, int M,
 
 /* Gather rows: out[i] = src[rows[i]] for f64 [.,3] keypoints (estimator.py:407-408). */
 int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream);
+
+/* ---- rotation-coherence matcher (Match_ot, network/rot_coh_match.py) ---------------------------------
+ * Per-point tensors are position-major: [points, channels] or [points, k, channels] float32.
+ *
+ * roreg_topk_dot: for every row of A [m,32] the k (16, 8 or 1) rows of B [n,32] with the largest dot product, descending,
+ * lower index first on ties; replaces score_mat + the full descending argsort of Knn_index_extract
+ * (rot_coh_match.py:8-12,34-45) without materialising the m x n matrix.  ws: roreg_topk_dot_workspace_size floats. */
+size_t roreg_topk_dot_workspace_size(int m, int n, int k);
+int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t *idx_out, float *val_out /* optional [m,k] */,
+                   float *ws, size_t ws_floats, void *stream);
+
+/* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
+ * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119). */
+int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
+
+/* InstanceNorm2d(affine=False) statistics of h [L,C] over all L positions -> mean_rstd [2C] = mean, 1/sqrt(var_biased+eps).
+ * ws: 2*C*256 doubles.  (rot_coh_match.py:19,68) */
+int roreg_instnorm_stats(const float *h, int L, int C, float eps, float *mean_rstd, double *ws, void *stream);
+
+/* y [L,32] += W2 relu((h - mean) * rstd) + b2  (closing conv of mlp_2layer / Contextnorm; y already holds the residual conv). */
+int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2 /* [32,Cmid] */, const float *b2,
+                   float *y, void *stream);
+
+/* Core of MultiHeadedAttention(4 heads, d_model 32) on k-NN neighbourhoods (rot_coh_match.py:84-119): qp [m,32] projected
+ * queries; kp / vp projected keys / values, either dense [m,k,32] or a per-point table [n,32] addressed through idx [m,k].
+ * x_out [m,32] (input of the merge conv).  Channel c belongs to head c%4, dim c/4 (the reference's .view(b,8,4,-1)). */
+int roreg_knn_attention(const float *qp, const float *kp, const float *vp, const int64_t *idx, int k_is_table, int v_is_table,
+                        int m, int k, float *x_out, void *stream);
+
+/* Small data-movement / normalisation steps of the matcher graph (see csrc/rm.hip for the op list). */
+int roreg_rm_elementwise(int op, const float *a, const float *b, const float *c, const int64_t *idx, int L, int k, int C,
+                         float *out, float *ws, void *stream);
+
+/* Log-domain Sinkhorn with dustbins + mutual-argmax read-out (rot_coh_match.py:285-314,363,369-379).  The coupling scores
+ * <src_final[i], tgt_final[j]> ([m,32] x [n,32]) are formed on the fly; Z_out [(m+1),(n+1)]; matches0 [m], matches1 [n] (-1 = unmatched), mscores0/1 (exp of the row maximum for mutual matches).
+ * ws: roreg_sinkhorn_workspace_size floats (the coupling matrix and its transpose stay resident across the 2*iters passes). */
+size_t roreg_sinkhorn_workspace_size(int m, int n);
+int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n, float alpha, int iters, float *Z_out,
+                   int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats, void *stream);
 
 #ifdef __cplusplus
 }

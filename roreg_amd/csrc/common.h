@@ -19,6 +19,7 @@ struct GroupTablesDev {
     int32_t *P;      // [60*60]  P[a*60+g]
     int32_t *Nei;    // [60*13]
     uint8_t *P8;     // [60*60]  same as P, one byte per entry (LDS friendly)
+    uint8_t *P8t;    // [60*60]  transposed: P8t[h*60+g] = P[g*60+h]
     double *R;       // [60*9]   float64 rotations
     float *Rf;       // [60*9]   float32-rounded rotations (test/estimator.py:279 .astype(np.float32))
     bool ready;

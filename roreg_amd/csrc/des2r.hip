@@ -70,18 +70,23 @@ __global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ fe
         const int oi = __shfl_xor(bi, o);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (lane == 0) idx_out[b] = bi;
+    if (lane == 0 && idx_out) idx_out[b] = bi;
 }
 
 }  // namespace
 
 extern "C" int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, const int64_t *rows0, int M,
                            int64_t *idx_out, float *cor_out, void *stream) {
-    ROREG_REQUIRE(feats1 && feats0 && idx_out && M >= 0, "roreg_des2r: bad arguments");
-    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_des2r: group tables not set");
+    return roreg_group_corr(feats1, rows1, feats0, rows0, M, 0, idx_out, cor_out, stream);
+}
+
+extern "C" int roreg_group_corr(const float *perm_feats, const int64_t *perm_rows, const float *bcast_feats, const int64_t *bcast_rows,
+                                int M, int transpose_table, int64_t *idx_out, float *cor_out, void *stream) {
+    ROREG_REQUIRE(perm_feats && bcast_feats && (idx_out || cor_out) && M >= 0, "roreg_group_corr: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_group_corr: group tables not set");
     if (M == 0) return 0;
-    hipLaunchKernelGGL(des2r_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), feats1, rows1, feats0, rows0,
-                       roreg::group_tables().P8, M, idx_out, cor_out);
-    ROREG_CHECK_LAUNCH("roreg_des2r");
+    hipLaunchKernelGGL(des2r_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,
+                       bcast_rows, transpose_table ? roreg::group_tables().P8t : roreg::group_tables().P8, M, idx_out, cor_out);
+    ROREG_CHECK_LAUNCH("roreg_group_corr");
     return 0;
 }

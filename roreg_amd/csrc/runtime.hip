@@ -14,7 +14,7 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-static GroupTablesDev g_tables = {nullptr, nullptr, nullptr, nullptr, nullptr, false};
+static GroupTablesDev g_tables = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
 static std::mutex g_tables_mu;
 
 const GroupTablesDev &group_tables() { return g_tables; }
@@ -44,16 +44,20 @@ extern "C" int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_
         RT_CK(hipMalloc(&t.P, 3600 * sizeof(int32_t)));
         RT_CK(hipMalloc(&t.Nei, 780 * sizeof(int32_t)));
         RT_CK(hipMalloc(&t.P8, 3600));
+        RT_CK(hipMalloc(&t.P8t, 3600));
         RT_CK(hipMalloc(&t.R, 540 * sizeof(double)));
         RT_CK(hipMalloc(&t.Rf, 540 * sizeof(float)));
     }
-    uint8_t p8[3600];
+    uint8_t p8[3600], p8t[3600];
     float rf[540];
     for (int i = 0; i < 3600; ++i) p8[i] = (uint8_t)P_host[i];
+    for (int a = 0; a < 60; ++a)
+        for (int g = 0; g < 60; ++g) p8t[g * 60 + a] = (uint8_t)P_host[a * 60 + g];
     for (int i = 0; i < 540; ++i) rf[i] = (float)R_host[i];
     RT_CK(hipMemcpy(t.P, P_host, 3600 * sizeof(int32_t), hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.Nei, Nei_host, 780 * sizeof(int32_t), hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.P8, p8, 3600, hipMemcpyHostToDevice));
+    RT_CK(hipMemcpy(t.P8t, p8t, 3600, hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.R, R_host, 540 * sizeof(double), hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.Rf, rf, 540 * sizeof(float), hipMemcpyHostToDevice));
 #undef RT_CK

@@ -6,7 +6,7 @@ fails, an exception is raised (the product path must never silently run on the C
 """
 import ctypes
 import os
-from ctypes import c_int, c_void_p, c_size_t, c_double, c_char_p
+from ctypes import c_int, c_void_p, c_size_t, c_double, c_float, c_char_p
 
 import numpy as np
 import torch
@@ -39,6 +39,16 @@ PROTOTYPES = {
     'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
     'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    'roreg_topk_dot_workspace_size': (c_size_t, [c_int, c_int, c_int]),
+    'roreg_topk_dot': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    'roreg_linear': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
+    'roreg_instnorm_stats': (c_int, [_P, c_int, c_int, c_float, _P, _P, _P]),
+    'roreg_mlp_tail': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P]),
+    'roreg_knn_attention': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    'roreg_rm_elementwise': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    'roreg_sinkhorn_workspace_size': (c_size_t, [c_int, c_int]),
+    'roreg_sinkhorn': (c_int, [_P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 
@@ -307,3 +317,110 @@ def gather_rows_f64(src, rows):
     out = torch.empty((M, width), dtype=torch.float64, device=src.device)
     _check(lib().roreg_gather_rows_f64(_ptr(src, torch.float64), _ptr(rows, torch.int64), M, width, _ptr(out), _stream()), 'roreg_gather_rows_f64')
     return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# rotation-coherence matcher
+# ----------------------------------------------------------------------------------------------------
+def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpose=False, want_idx=False):
+    """cor [M,60] (and optionally the first argmax) of the generalised 60x60 group cross-correlation."""
+    ensure_tables()
+    M = int(perm_rows.shape[0]) if perm_rows is not None else (int(bcast_rows.shape[0]) if bcast_rows is not None else int(perm_feats.shape[0]))
+    cor = torch.empty((M, 60), dtype=torch.float32, device=perm_feats.device)
+    idx = torch.empty(M, dtype=torch.int64, device=perm_feats.device) if want_idx else None
+    _check(lib().roreg_group_corr(_ptr(perm_feats, torch.float32), _ptr(perm_rows, torch.int64), _ptr(bcast_feats, torch.float32),
+                                  _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(idx), _ptr(cor), _stream()), 'roreg_group_corr')
+    return (cor, idx) if want_idx else cor
+
+
+def topk_dot(A, B, k, want_val=False):
+    m, n = A.shape[0], B.shape[0]
+    idx = torch.empty((m, k), dtype=torch.int64, device=A.device)
+    val = torch.empty((m, k), dtype=torch.float32, device=A.device) if want_val else None
+    wsn = lib().roreg_topk_dot_workspace_size(m, n, k)
+    ws = torch.empty(wsn, dtype=torch.float32, device=A.device)
+    _check(lib().roreg_topk_dot(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, _stream()), 'roreg_topk_dot')
+    return (idx, val) if want_val else idx
+
+
+def linear(x, W, b):
+    """x [L,Cin] -> [L,Cout]; W [Cout,Cin], b [Cout] device float32."""
+    L, Cin = x.shape
+    Cout = W.shape[0]
+    y = torch.empty((L, Cout), dtype=torch.float32, device=x.device)
+    _check(lib().roreg_linear(_ptr(x, torch.float32), L, Cin, _ptr(W, torch.float32), _ptr(b, torch.float32), Cout, _ptr(y), _stream()), 'roreg_linear')
+    return y
+
+
+def mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=1e-5):
+    """mlp_2layer / Contextnorm: conv -> InstanceNorm -> ReLU -> conv, plus the residual conv.  x [L,Cin] -> [L,32]."""
+    L = x.shape[0]
+    h = linear(x, W1, b1)
+    C = h.shape[1]
+    stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * C * 256, dtype=torch.float64, device=x.device)
+    _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), _stream()), 'roreg_instnorm_stats')
+    y = linear(x, Wr, br)
+    _check(lib().roreg_mlp_tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), _stream()), 'roreg_mlp_tail')
+    return y
+
+
+def knn_attention(qp, kp, vp, idx, k, k_is_table, v_is_table):
+    m = qp.shape[0]
+    x = torch.empty((m, 32), dtype=torch.float32, device=qp.device)
+    _check(lib().roreg_knn_attention(_ptr(qp, torch.float32), _ptr(kp, torch.float32), _ptr(vp, torch.float32), _ptr(idx, torch.int64),
+                                     1 if k_is_table else 0, 1 if v_is_table else 0, m, k, _ptr(x), _stream()), 'roreg_knn_attention')
+    return x
+
+
+def _rm_op(op, a, out, b=None, c=None, idx=None, L=0, k=0, C=0, ws=None):
+    _check(lib().roreg_rm_elementwise(op, _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(c, torch.float32), _ptr(idx, torch.int64),
+                                      L, k, C, _ptr(out, torch.float32), _ptr(ws, torch.float32), _stream()), 'roreg_rm_elementwise')
+    return out
+
+
+def l2_normalize_rows(x):
+    L, C = x.shape
+    return _rm_op(0, x, torch.empty_like(x), L=L, C=C)
+
+
+def context_with_colmax(R):
+    """[R | max over points of R, broadcast]  (rot_coh_match.py:201)  [m,60] -> [m,120]."""
+    m = R.shape[0]
+    ws = torch.empty(256 * 60, dtype=torch.float32, device=R.device)
+    cmax = _rm_op(1, R, torch.empty(60, dtype=torch.float32, device=R.device), L=m, C=60, ws=ws)
+    return _rm_op(2, R, torch.empty((m, 120), dtype=torch.float32, device=R.device), b=cmax, L=m)
+
+
+def knn_coor(coor, idx):
+    m, k = idx.shape
+    return _rm_op(3, coor, torch.empty((m * k, 3), dtype=torch.float32, device=coor.device), idx=idx, L=m, k=k)
+
+
+def value_input(pos_n, fea_n_table, conf_n, idx):
+    m, k = idx.shape
+    return _rm_op(5, pos_n, torch.empty((m * k, 96), dtype=torch.float32, device=pos_n.device), b=fea_n_table, c=conf_n, idx=idx, L=m, k=k)
+
+
+def concat_rows(a, b, c=None):
+    L, C = a.shape
+    Cc = 0 if c is None else c.shape[1]
+    return _rm_op(6, a, torch.empty((L, 2 * C + Cc), dtype=torch.float32, device=a.device), b=b, c=c, L=L, k=Cc, C=C)
+
+
+def mean_over_group(eqv):
+    m = eqv.shape[0]
+    return _rm_op(7, eqv, torch.empty((m, 32), dtype=torch.float32, device=eqv.device), L=m)
+
+
+def sinkhorn(src_final, tgt_final, alpha, iters):
+    m, n = src_final.shape[0], tgt_final.shape[0]
+    dev = src_final.device
+    Z = torch.empty((m + 1, n + 1), dtype=torch.float32, device=dev)
+    m0 = torch.empty(m, dtype=torch.int64, device=dev); m1 = torch.empty(n, dtype=torch.int64, device=dev)
+    s0 = torch.empty(m, dtype=torch.float32, device=dev); s1 = torch.empty(n, dtype=torch.float32, device=dev)
+    wsn = lib().roreg_sinkhorn_workspace_size(m, n)
+    ws = torch.empty(wsn, dtype=torch.float32, device=dev)
+    _check(lib().roreg_sinkhorn(_ptr(src_final, torch.float32), m, _ptr(tgt_final, torch.float32), n, float(alpha), int(iters), _ptr(Z),
+                                _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, _stream()), 'roreg_sinkhorn')
+    return Z, m0, m1, s0, s1

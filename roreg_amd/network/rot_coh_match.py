@@ -1,9 +1,38 @@
-"""Match_ot: rotation-coherence matcher (network/rot_coh_match.py:323-390).  Parameter layout mirrors the
-reference so RM checkpoints load; the HIP forward lands in a later milestone of this round."""
+"""Match_ot: rotation-coherence matcher (mirror of network/rot_coh_match.py:8-390).
+
+Same module tree and state_dict keys as the reference (the shipped RM checkpoint loads strict=True); the torch sub-modules
+are parameter containers only.  forward() runs the HIP kernels of csrc/rm.hip on position-major tensors
+([points, channels]): on-the-fly top-k instead of the reference's twelve full N x N argsorts, the generalised 60x60 group
+cross-correlation for R_indicator, fused k-NN attention, two-pass InstanceNorm MLPs and a resident-matrix log-Sinkhorn.
+
+forward(batch) with feats0 [1,m,32,60], feats1 [1,n,32,60], keys0 [1,m,3], keys1 [1,n,3] returns the reference's dict:
+scores [1,m+1,n+1], matches0 [1,m], matches1 [1,n] (int64, -1 = unmatched), matching_scores0/1, source_final /
+target_final [1,32,m,1]; 'scores_other' (training-only supervision, never read at test time, rot_coh_match.py:355-358)
+is computed on demand."""
 from copy import deepcopy
 
 import torch
 import torch.nn as nn
+
+from .. import hip
+from .ops import _version_key
+
+
+def _wb(conv):
+    """[Cout,Cin] weight and bias of a 1x1 Conv2d as contiguous device float32 (cached per parameter version)."""
+    key = (conv.weight.data_ptr(), conv.weight._version, conv.bias.data_ptr(), conv.bias._version)
+    c = getattr(conv, '_roreg_wb', None)
+    if c is None or c[0] != key:
+        W = conv.weight.detach().to('cuda', torch.float32).reshape(conv.weight.shape[0], conv.weight.shape[1]).contiguous()
+        b = conv.bias.detach().to('cuda', torch.float32).contiguous()
+        conv._roreg_wb = (key, W, b)
+        c = conv._roreg_wb
+    return c[1], c[2]
+
+
+def _lin(conv, x):
+    W, b = _wb(conv)
+    return hip.linear(x, W, b)
 
 
 class mlp_2layer(nn.Module):
@@ -14,6 +43,13 @@ class mlp_2layer(nn.Module):
         self.res_sign = in_dim != out_dim
         if self.res_sign:
             self.res = nn.Conv2d(in_dim, out_dim, 1, 1)
+
+    def forward(self, x):
+        """x [L,Cin] (every row is one spatial position of the reference's [1,Cin,w,h] map) -> [L,out]."""
+        if not self.res_sign:
+            raise NotImplementedError('mlp_2layer without a residual conv is not used by Match_ot')
+        W1, b1 = _wb(self.net[0]); W2, b2 = _wb(self.net[3]); Wr, br = _wb(self.res)
+        return hip.mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=self.net[1].eps)
 
 
 class Contextnorm(mlp_2layer):
@@ -28,6 +64,15 @@ class MultiHeadedAttention(nn.Module):
         self.merge = nn.Conv2d(d_model, d_model, kernel_size=1, stride=1)
         self.proj = nn.ModuleList([deepcopy(self.merge) for _ in range(3)])
 
+    def forward(self, query, key, value, idx, k, key_is_table, value_is_table):
+        """query [m,32]; key/value: per-point tables [*,32] addressed through idx [m,k], or dense [m*k,32].
+        The 1x1 projections commute with the gather, so table operands are projected once per point."""
+        qp = _lin(self.proj[0], query)
+        kp = _lin(self.proj[1], key)
+        vp = _lin(self.proj[2], value)
+        x = hip.knn_attention(qp, kp, vp, idx, k, key_is_table, value_is_table)
+        return _lin(self.merge, x)
+
 
 class Cross_attention_block(nn.Module):
     def __init__(self, cross_k, s2t):
@@ -36,6 +81,18 @@ class Cross_attention_block(nn.Module):
         self.s2t = s2t
         self.cross_attn = MultiHeadedAttention(4, 32)
         self.merge = mlp_2layer(32 * 3, 64, 32)
+
+    def forward(self, source, target, source_eqv, target_eqv, featinv):
+        """source [m,32], target [n,32], *_eqv [.,32,60], featinv [m,32] -> (feat [m,32], R_indicator [m,60])."""
+        knn = hip.topk_dot(source, target, self.k)                         # k best targets per source point
+        nn_ind = knn[:, 0].contiguous()
+        att = self.cross_attn(source, target, target, knn, self.k, True, True)
+        feat = self.merge(hip.concat_rows(featinv, source, att))
+        if self.s2t:    # R[h] = sum_f sum_g src[f,P[g,h]] * tgt_nn[f,g]
+            R = hip.group_corr(source_eqv, target_eqv, perm_rows=None, bcast_rows=nn_ind, transpose=True)
+        else:           # R[h] = sum_f sum_g tgt_nn[f,P[g,h]] * src[f,g]
+            R = hip.group_corr(target_eqv, source_eqv, perm_rows=nn_ind, bcast_rows=None, transpose=True)
+        return feat, R
 
 
 class Self_attention_block(nn.Module):
@@ -49,6 +106,18 @@ class Self_attention_block(nn.Module):
         self.val_en = mlp_2layer(32 * 3, 64, 32)
         self.merge = mlp_2layer(32 * 3, 64, 32)
 
+    def forward(self, feat, coor, R_indicator, featinv):
+        """feat [m,32], coor [m,3] (already / coor_norm_step), R_indicator [m,60], featinv [m,32] -> [m,32]."""
+        knn = hip.topk_dot(feat, feat, self.k)
+        pos = self.pos_en(hip.knn_coor(coor, knn))                          # [m*k,32]
+        conf = self.ambiguity(hip.context_with_colmax(R_indicator))         # [m,32]
+        pos = hip.l2_normalize_rows(pos)
+        feat_n = hip.l2_normalize_rows(feat)                                # knn_fea / ||knn_fea|| == gather of normalised rows
+        conf = hip.l2_normalize_rows(conf)
+        value = self.val_en(hip.value_input(pos, feat_n, conf, knn))        # [m*k,32]
+        att = self.self_attn(feat, feat_n, value, knn, self.k, True, False)
+        return self.merge(hip.concat_rows(featinv, feat, att))
+
 
 class Merge_info_block(nn.Module):
     def __init__(self, self_k, cross_k):
@@ -58,11 +127,26 @@ class Merge_info_block(nn.Module):
         self.cross_graph_t2s = Cross_attention_block(cross_k, s2t=False)
         self.self_graph_t = Self_attention_block(self_k, source=False)
 
+    def forward(self, source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv):
+        source_s2t, R_ind_s2t = self.cross_graph_s2t(source, target, source_eqv, target_eqv, source_inv)
+        eh_source = self.self_graph_s(source_s2t, source_coor, R_ind_s2t, source_inv)
+        target_t2s, R_ind_t2s = self.cross_graph_t2s(target, source, target_eqv, source_eqv, target_inv)
+        eh_target = self.self_graph_t(target_t2s, target_coor, R_ind_t2s, target_inv)
+        return eh_source, eh_target
+
 
 class Graph_enhance_net(nn.Module):
     def __init__(self):
         super().__init__()
         self.merge_blocks = nn.ModuleList([Merge_info_block(16, 16), Merge_info_block(8, 8)])
+
+    def forward(self, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv):
+        sources, targets = [], []
+        source, target = source_inv, target_inv                             # mean over g (rot_coh_match.py:266-267)
+        for layer in self.merge_blocks:
+            source, target = layer(source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv)
+            sources.append(source); targets.append(target)
+        return sources, targets
 
 
 class sinkhorn_ot(nn.Module):
@@ -82,4 +166,33 @@ class Match_ot(nn.Module):
         self.ot_layer = sinkhorn_ot(0.2, 100)
 
     def forward(self, batch):
-        raise NotImplementedError('Match_ot HIP forward: not built yet in this round (DESIGN.md, scope row A6)')
+        dev = 'cuda'
+        source_eqv = batch['feats0'][0].to(dev, torch.float32).contiguous()            # [m,32,60]
+        target_eqv = batch['feats1'][0].to(dev, torch.float32).contiguous()
+        source_coor = (batch['keys0'][0].to(dev, torch.float32) / self.coor_norm_step).contiguous()
+        target_coor = (batch['keys1'][0].to(dev, torch.float32) / self.coor_norm_step).contiguous()
+        source_inv = hip.mean_over_group(source_eqv)
+        target_inv = hip.mean_over_group(target_eqv)
+        sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv)
+        source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]))
+        target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]))
+        alpha = float(self.ot_layer.bin_score.detach().cpu())
+        Z, m0, m1, s0, s1 = hip.sinkhorn(source_final, target_final, alpha, self.ot_layer.iters)
+        out = _MatchResult({
+            'scores': Z[None], 'matches0': m0[None], 'matches1': m1[None], 'matching_scores0': s0[None], 'matching_scores1': s1[None],
+            'source_final': source_final.t().contiguous()[None, :, :, None], 'target_final': target_final.t().contiguous()[None, :, :, None]})
+        out._lazy = (sources, targets)
+        return out
+
+
+class _MatchResult(dict):
+    """The result dict; 'scores_other' (two softmaxes over two m x n score maps, training-loss input only) is built on first access."""
+
+    def __missing__(self, key):
+        if key != 'scores_other':
+            raise KeyError(key)
+        sources, targets = self._lazy
+        so = torch.stack([s @ t.t() for s, t in zip(sources, targets)], -1)[None]       # evaluation-only convenience, off the hot path
+        val = torch.softmax(so, dim=-3) * torch.softmax(so, dim=-2)
+        self[key] = val
+        return val

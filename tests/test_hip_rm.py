@@ -1,0 +1,152 @@
+"""Rotation-coherence matcher (Match_ot) on HIP against the oracle and the reference's golden run.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import match_ot_numpy as MO
+from roreg_amd.parses.parses_test import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope='module')
+def rm():
+    from roreg_amd.network import name2network
+    net = name2network['RM_test'](default_config())
+    sd = dict(load_golden('weights_RM'))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net.eval()
+    return net, sd
+
+
+@pytest.mark.parametrize('m,n,k', [(300, 257, 16), (5000, 5000, 8), (40, 17, 16), (129, 700, 1)])
+def test_topk_dot(m, n, k):
+    from roreg_amd import hip
+    rng = np.random.default_rng(m + n + k)
+    A = rng.standard_normal((m, 32)).astype(np.float32); B = rng.standard_normal((n, 32)).astype(np.float32)
+    B[n // 2] = B[1]                                     # an exact tie: lower index first
+    idx, val = hip.topk_dot(cu(A), cu(B), k, want_val=True)
+    idx = idx.cpu().numpy(); val = val.cpu().numpy()
+    S = (A.astype(np.float64) @ B.T.astype(np.float64))
+    want = MO.topk_rows(S.astype(np.float32), k)
+    got_vals = np.take_along_axis(S, idx, 1)
+    assert np.abs(val - got_vals).max() < 1e-4
+    assert (np.diff(val, axis=1) <= 0).all()
+    # sets agree except where fp32 vs fp64 dot products reorder near-ties at the boundary
+    agree = np.mean([len(set(a) & set(b)) == k for a, b in zip(idx, want)])
+    assert agree > 0.995
+    rows_with_tie = [i for i in range(m) if 1 in idx[i] and n // 2 in idx[i]]
+    for i in rows_with_tie:
+        assert list(idx[i]).index(1) < list(idx[i]).index(n // 2)
+
+
+def test_group_corr_transposed_is_r_indicator(group):
+    from roreg_amd import hip
+    rng = np.random.default_rng(5)
+    own = rng.standard_normal((70, 32, 60)).astype(np.float32); other = rng.standard_normal((90, 32, 60)).astype(np.float32)
+    nn = rng.integers(0, 90, 70)
+    for s2t in [True, False]:
+        want = MO.r_indicator(own, other[nn], group.P, s2t)
+        if s2t:
+            got = hip.group_corr(cu(own), cu(other), perm_rows=None, bcast_rows=cu(nn), transpose=True)
+        else:
+            got = hip.group_corr(cu(other), cu(own), perm_rows=cu(nn), bcast_rows=None, transpose=True)
+        assert np.abs(got.cpu().numpy() - want).max() < 2e-4
+
+
+def test_mlp_instnorm_and_attention(rm):
+    from roreg_amd import hip
+    net, sd = rm
+    rng = np.random.default_rng(6)
+    blk = net.Graph.merge_blocks[0].self_graph_s
+    name = 'Graph.merge_blocks.0.self_graph_s'
+    x = rng.standard_normal((513, 96)).astype(np.float32)
+    assert np.abs(blk.val_en(cu(x)).cpu().numpy() - MO.mlp_2layer(x, sd, name + '.val_en')).max() < 1e-4
+    x3 = rng.standard_normal((700, 3)).astype(np.float32) * 10
+    assert np.abs(blk.pos_en(cu(x3)).cpu().numpy() - MO.mlp_2layer(x3, sd, name + '.pos_en')).max() < 1e-4
+    xc = rng.standard_normal((333, 120)).astype(np.float32)
+    assert np.abs(blk.ambiguity(cu(xc)).cpu().numpy() - MO.mlp_2layer(xc, sd, name + '.ambiguity')).max() < 1e-4
+    m, k = 200, 16
+    q = rng.standard_normal((m, 32)).astype(np.float32); table = rng.standard_normal((m, 32)).astype(np.float32)
+    val = rng.standard_normal((m, k, 32)).astype(np.float32); idx = rng.integers(0, m, (m, k))
+    want = MO.mha(q, table[idx], val, sd, name + '.self_attn')
+    got = blk.self_attn(cu(q), cu(table), cu(val.reshape(m * k, 32)), cu(idx), k, True, False).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
+
+
+def test_sinkhorn_and_readout():
+    from roreg_amd import hip
+    rng = np.random.default_rng(7)
+    for m, n in [(200, 173), (64, 300)]:
+        s = rng.standard_normal((m, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((n, 32)).astype(np.float32) * 0.5
+        t[:min(m, n) // 2] = s[:min(m, n) // 2] * 3           # planted strong matches
+        Z, m0, m1, s0, s1 = hip.sinkhorn(cu(s), cu(t), 1.5, 100)
+        want = MO.log_sinkhorn((s @ t.T).astype(np.float32), np.float32(1.5), 100)
+        assert np.abs(Z.cpu().numpy() - want).max() < 2e-3
+        w0, w1, ws0, ws1 = MO.readout(Z.cpu().numpy())
+        assert np.array_equal(m0.cpu().numpy(), w0) and np.array_equal(m1.cpu().numpy(), w1)
+        assert np.abs(s0.cpu().numpy() - ws0).max() < 1e-5 and np.abs(s1.cpu().numpy() - ws1).max() < 1e-5
+        assert (w0 >= 0).sum() >= min(m, n) // 2 - 2
+
+
+def test_match_ot_forward_vs_reference_golden(rm):
+    net, sd = rm
+    z = load_golden('match_ot')
+    batch = {k: torch.from_numpy(z[k]) for k in ['feats0', 'feats1', 'keys0', 'keys1']}
+    with torch.no_grad():
+        out = net(batch)
+    assert np.abs(out['source_final'].cpu().numpy() - z['out_source_final']).max() < 5e-4
+    assert np.abs(out['target_final'].cpu().numpy() - z['out_target_final']).max() < 5e-4
+    assert np.abs(out['scores'].cpu().numpy() - z['out_scores']).max() < 2e-3
+    assert np.array_equal(out['matches0'].cpu().numpy(), z['out_matches0'])
+    assert np.array_equal(out['matches1'].cpu().numpy(), z['out_matches1'])
+    assert np.abs(out['matching_scores0'].cpu().numpy() - z['out_matching_scores0']).max() < 1e-4
+    assert np.abs(out['matching_scores1'].cpu().numpy() - z['out_matching_scores1']).max() < 1e-4
+    assert out['scores'].shape == z['out_scores'].shape and out['matches0'].dtype == torch.int64
+    assert np.abs(out['scores_other'].cpu().numpy() - z['out_scores_other']).max() < 1e-4
+
+
+def test_stage_yoho_mat_and_yohoo_with_rm_scores(tmp_path):
+    """--RD --RM --ET yohoo pipeline golden: matcher output (matches + float32 scores) and the RM branch of yohoo_ransac."""
+    from test_hip_pipeline import _setup, _put_yoho
+    from roreg_amd.test import name2matcher, name2estimator
+    z = load_golden('pipeline_rd_rm_yohoo')
+    y = load_golden('pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, RD=True, RM=True, ET='yohoo')
+    keynum = int(z['keynum'])
+    base = f'{cfg.output_cache_fn}/{ds.name}'
+    _put_yoho(cfg, ds, y)
+    os.makedirs(f'{base}/det_score')
+    for pc in ds.pc_ids:
+        np.save(f'{base}/det_score/{pc}.npy', z[f'det_{pc}'])
+    np.random.seed(1234)
+    name2matcher['yoho_mat'](cfg).run(ds, keynum)
+    md = f'{base}/match_{keynum}'
+    for a, b in ds.pair_ids:
+        m = np.load(f'{md}/{a}-{b}.npy'); s = np.load(f'{md}/scores/{a}-{b}.npy')
+        assert m.dtype == np.int64 and np.array_equal(m, z[f'match_{a}_{b}'])
+        assert s.dtype == np.float32 and np.abs(s - z[f'mscore_{a}_{b}']).max() < 1e-4
+        np.save(f'{md}/scores/{a}-{b}.npy', z[f'mscore_{a}_{b}'])
+    est = name2estimator['yohoo'](cfg)
+    est.rind_extractor.Rindex(ds, keynum)
+    for a, b in ds.pair_ids:
+        assert np.array_equal(np.load(f'{md}/DR_index/{a}-{b}.npy'), z[f'dr_{a}_{b}'])
+    os.makedirs(f'{md}/Trans_pre', exist_ok=True)
+    for a, b in ds.pair_ids:
+        np.save(f'{md}/Trans_pre/{a}-{b}.npy', z[f'transpre_{a}_{b}'])
+    np.random.seed(4321)
+    # the golden run seeded before the whole estimator stage; Rindex / Rt_pre draw nothing, so the stream is the same here
+    est.ransacer.ransac(ds, keynum, 1000)
+    for a, b in ds.pair_ids:
+        r = np.load(f'{md}/yohoo/1000iters/{a}-{b}.npz')
+        assert int(r['recalltime']) == int(z[f'recall_{a}_{b}'])
+        want = z[f'trans_{a}_{b}']
+        if np.isfinite(want).all():
+            assert np.abs(r['trans'] - want).max() < 1e-5

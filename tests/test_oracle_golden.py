@@ -220,3 +220,17 @@ def test_metrics_match_reference():
     assert abs(np.mean([1 if i > 0.05 else 0 for i in irs]) - float(z['fmr'])) < 1e-12
     assert abs(np.mean(rr) - float(z['rr'])) < 1e-12
     assert abs(np.mean(rre) - float(z['rre'])) < 1e-9 and abs(np.mean(rte) - float(z['rte'])) < 1e-9
+
+
+def test_match_ot_matches_reference(group):
+    from oracle import match_ot_numpy as MO
+    z = load_golden('match_ot')
+    sd = dict(load_golden('weights_RM'))
+    out = MO.match_ot_forward({k: z[k] for k in ['feats0', 'feats1', 'keys0', 'keys1']}, sd, group.P)
+    assert np.abs(out['source_final'] - z['out_source_final']).max() < 2e-4
+    assert np.abs(out['target_final'] - z['out_target_final']).max() < 2e-4
+    assert np.abs(out['scores'] - z['out_scores']).max() < 1e-3
+    assert np.array_equal(out['matches0'], z['out_matches0']) and np.array_equal(out['matches1'], z['out_matches1'])
+    assert np.abs(out['matching_scores0'] - z['out_matching_scores0']).max() < 1e-4
+    assert np.abs(out['matching_scores1'] - z['out_matching_scores1']).max() < 1e-4
+    assert np.abs(out['scores_other'] - z['out_scores_other']).max() < 1e-4
