@@ -126,16 +126,25 @@ __global__ __launch_bounds__(256) void in_stats_partial_kernel(const float *__re
     }
 }
 
-__global__ void in_stats_final_kernel(const double *__restrict__ part, int nblk, int L, int C, float eps, float *__restrict__ mean_rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void in_stats_final_kernel(const double *__restrict__ part, int nblk, int L, int C, float eps,
+                                                             float *__restrict__ mean_rstd) {
+    __shared__ double sa[256], sb[256];
+    const int c = blockIdx.x;                       // one block per channel; fixed-order tree => deterministic
     double a = 0, a2 = 0;
-    for (int b = 0; b < nblk; ++b) { a += part[((size_t)b * C + c) * 2]; a2 += part[((size_t)b * C + c) * 2 + 1]; }
-    const double mu = a / L;
-    double var = a2 / L - mu * mu;
-    if (var < 0) var = 0;
-    mean_rstd[c] = (float)mu;
-    mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if ((int)threadIdx.x < nblk) { a = part[((size_t)threadIdx.x * C + c) * 2]; a2 = part[((size_t)threadIdx.x * C + c) * 2 + 1]; }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = a2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mu = sa[0] / L;
+        double var = sb[0] / L - mu * mu;
+        if (var < 0) var = 0;
+        mean_rstd[c] = (float)mu;
+        mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // =====================================================================================================
@@ -212,12 +221,16 @@ __global__ __launch_bounds__(256) void colmax_partial_kernel(const float *__rest
     part[(size_t)blockIdx.x * C + c] = mx;
 }
 
-__global__ void colmax_final_kernel(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float mx = -__builtin_inff();
-    for (int b = 0; b < nblk; ++b) mx = fmaxf(mx, part[(size_t)b * C + c]);
-    out[c] = mx;
+__global__ __launch_bounds__(256) void colmax_final_kernel(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
+    __shared__ float sm[256];
+    const int c = blockIdx.x;
+    sm[threadIdx.x] = (int)threadIdx.x < nblk ? part[(size_t)threadIdx.x * C + c] : -__builtin_inff();
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sm[0];
 }
 
 // ctx[p] = [R[p,0..59], colmax[0..59]]
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restri
 // -----------------------------------------------------------------------------------------------------------
 extern "C" size_t roreg_topk_dot_workspace_size(int m, int n, int k) {
     const int gx = (m + 255) / 256;
-    int slices = (1024 + gx - 1) / gx;
+    int slices = (320 + gx - 1) / gx;
     if (slices > (n + 63) / 64) slices = (n + 63) / 64;
     if (slices < 1) slices = 1;
     return (size_t)slices * m * k * 2;       // floats (values) + ints (indices), 4 bytes each
@@ -420,7 +433,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     ROREG_REQUIRE(k == 16 || k == 8 || k == 1, "roreg_topk_dot: k must be 16, 8 or 1 (got %d)", k);
     ROREG_REQUIRE(k <= n, "roreg_topk_dot: k > n");
     const int gx = (m + 255) / 256;
-    int slices = (1024 + gx - 1) / gx;
+    int slices = (320 + gx - 1) / gx;
     if (slices > (n + 63) / 64) slices = (n + 63) / 64;
     if (slices < 1) slices = 1;
     const int slice = (n + slices - 1) / slices;
@@ -463,7 +476,7 @@ extern "C" int roreg_instnorm_stats(const float *h, int L, int C, float eps, flo
     int nblk = (L + lanes - 1) / lanes;
     if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(in_stats_partial_kernel, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, h, L, C, ws);
-    hipLaunchKernelGGL(in_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nblk, L, C, eps, mean_rstd);
+    hipLaunchKernelGGL(in_stats_final_kernel, dim3(C), dim3(256), 0, s, ws, nblk, L, C, eps, mean_rstd);
     ROREG_CHECK_LAUNCH("roreg_instnorm_stats");
     return 0;
 }
@@ -506,7 +519,7 @@ extern "C" int roreg_rm_elementwise(int op, const float *a, const float *b, cons
         ROREG_REQUIRE(ws && C <= 256, "roreg_rm_elementwise: colmax needs a workspace");
         int nblk = L < 256 ? L : 256;
         hipLaunchKernelGGL(colmax_partial_kernel, dim3(nblk), dim3(256), 0, s, a, L, C, ws);
-        hipLaunchKernelGGL(colmax_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nblk, C, out);
+        hipLaunchKernelGGL(colmax_final_kernel, dim3(C), dim3(256), 0, s, ws, nblk, C, out);
         break;
     }
     case 2: hipLaunchKernelGGL(context_kernel, dim3((L * 120 + 255) / 256), dim3(256), 0, s, a, b, L, out); break;

@@ -56,6 +56,30 @@ class RegistrationEngine:
         k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
         return CloudState(before=x, eqv=eqv, inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
 
+    def extract_many(self, feats_list, keys_list, max_rows=65536):
+        """Several clouds per group-conv launch: a 5000-keypoint cloud is 9.2 waves of workgroups on the 512 resident slots,
+        so a lone cloud wastes ~8 % in the partial last wave; batching clouds makes that tail negligible."""
+        xs = [(f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32) for f in feats_list]
+        out = []
+        i = 0
+        while i < len(xs):
+            j, rows = i, 0
+            while j < len(xs) and (j == i or rows + xs[j].shape[0] <= max_rows):
+                rows += xs[j].shape[0]; j += 1
+            xcat = torch.cat(xs[i:j], 0) if j - i > 1 else xs[i].contiguous()
+            with torch.no_grad():
+                eqv = self.gf.PartI_net(xcat, want_inv=False)['eqv']
+            inv = hip.inv_descriptor(eqv)
+            o = 0
+            for q in range(i, j):
+                n = xs[q].shape[0]
+                k = keys_list[q]
+                k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
+                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], inv=inv[o:o + n], keys=k.to('cuda', torch.float64).contiguous()))
+                o += n
+            i = j
+        return out
+
     def detect(self, cloud):
         """raw std scores -> rank/N on the host exactly as test/detector.py:45-46."""
         with torch.no_grad():
@@ -86,6 +110,36 @@ class RegistrationEngine:
         nn10 = hip.nn_search(c1.inv, c0.inv, src_rows=d1, tgt_rows=d0)
         return hip.mutual_matches(nn01, nn10, d0, d1)
 
+    def local_transforms_many(self, items, max_rows=32768):
+        """Des2R + ET + assembly for several pairs with ONE pass of the ET network per group of pairs (the pruned trunk's
+        tail layers are small grids: per-pair launches leave most of the chip idle).  items: [(c0, c1, matches)]."""
+        out = [None] * len(items)
+        i = 0
+        while i < len(items):
+            j, rows = i, 0
+            while j < len(items) and (j == i or rows + items[j][2].shape[0] <= max_rows):
+                rows += items[j][2].shape[0]; j += 1
+            x_all = torch.empty((rows, 128, 60), dtype=torch.float32, device='cuda')
+            parts = []
+            o = 0
+            for q in range(i, j):
+                c0, c1, matches = items[q]
+                M = matches.shape[0]
+                rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
+                dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0)
+                if M:
+                    hip.et_gather(c0.before, c1.before, c0.eqv, c1.eqv, dr, rows0=rows0, rows1=rows1, out=x_all[o:o + M])
+                parts.append((dr, rows0, rows1, o, M))
+                o += M
+            with torch.no_grad():
+                q_all = self.et.trunk_and_head(x_all) if rows else torch.empty((0, 4), dtype=torch.float32, device='cuda')
+            for q, (dr, rows0, rows1, o, M) in zip(range(i, j), parts):
+                c0, c1, _ = items[q]
+                Trans = hip.quat_to_trans(q_all[o:o + M].contiguous(), dr, c0.keys, c1.keys, rows0=rows0, rows1=rows1)
+                out[q] = (dr, Trans, rows0, rows1)
+            i = j
+        return out
+
     def local_transforms(self, c0, c1, matches):
         """Des2R + ET + assembly: matches [M,2] int64 device -> (dr_index [M], Trans [M,3,4] f64)."""
         rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
@@ -112,7 +166,7 @@ class RegistrationEngine:
         keynum = self.cfg.keynum if keynum is None else keynum
         max_iter = self.cfg.max_iter if max_iter is None else max_iter
         used = sorted({int(i) for p in pair_ids for i in p})
-        clouds = {i: self.extract(feats[i], keys[i]) for i in used}
+        clouds = dict(zip(used, self.extract_many([feats[i] for i in used], [keys[i] for i in used])))
         if self.cfg.RD:
             for i in used:
                 self.detect(clouds[i])
@@ -125,12 +179,8 @@ class RegistrationEngine:
         counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
         # stage 4: all pairs
         T_all, best_all, aux_all = [], [], []
-        local = []
-        for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts):
-            c0, c1 = clouds[int(a)], clouds[int(b)]
-            M = int(M)
-            matches = mbuf[:M]
-            local.append((c0, c1, matches) + self.local_transforms(c0, c1, matches))
+        items = [(clouds[int(a)], clouds[int(b)], mbuf[:int(M)]) for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts)]
+        local = [it + lt for it, lt in zip(items, self.local_transforms_many(items))]
         for (c0, c1, matches, dr, Trans, rows0, rows1) in local:
             M = matches.shape[0]
             index = np.arange(M)

@@ -248,10 +248,11 @@ def des2r(feats1, feats0, rows1=None, rows0=None, want_cor=False):
     return (idx, cor) if want_cor else idx
 
 
-def et_gather(before0, before1, after0, after1, pre_idx, rows0=None, rows1=None):
+def et_gather(before0, before1, after0, after1, pre_idx, rows0=None, rows1=None, out=None):
     ensure_tables()
     M = pre_idx.shape[0]
-    x = torch.empty((M, 128, 60), dtype=torch.float32, device=before0.device)
+    x = out if out is not None else torch.empty((M, 128, 60), dtype=torch.float32, device=before0.device)
+    assert x.shape == (M, 128, 60)
     _check(lib().roreg_et_gather(_ptr(before0, torch.float32), _ptr(before1, torch.float32), _ptr(after0, torch.float32),
                                  _ptr(after1, torch.float32), _ptr(rows0, torch.int64), _ptr(rows1, torch.int64),
                                  _ptr(pre_idx, torch.int64), M, _ptr(x), _stream()), 'roreg_et_gather')
