@@ -12,8 +12,9 @@ weights of the reference's architecture; data synthetic).  The chunk has the 3DM
 With N ranks every rank registers its own chunk (pairs shard with no data-path collective; weak scaling)
 and the per-pair result table is all-gathered once per step over RCCL.
 
-The JSON line also carries the roofline of the dominant kernel (the exact-f32 MFMA group convolution, timed
-with HIP events inside the timed region) and a CPU baseline (the numpy oracle, rank 0, bounded sample).
+The JSON line also carries the roofline of the dominant kernel (the exact-f32 MFMA GEMMs of the group convolution in
+the irrep domain, timed with HIP events inside the timed region) and a CPU baseline (the numpy oracle, rank 0,
+bounded sample).
 """
 import argparse
 import json
@@ -134,14 +135,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- roofline of the dominant kernel: the two big GF layers (256->512, 512->256; identical MAC counts) ----
+    # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
+    # algorithmic work per launch = sum over the five irreps of 2*(d*O)*(d*C)*(d*B) = 2*O*C*B*244 flop
     flops = 0.0; ms = 0.0; n_launch = 0
     for (tag, e0, e1) in prof:
-        B, Cin, Cout, Lout, KS = tag
-        if Cin * Cout == 256 * 512 and KS == 13 and Lout == 60:
-            flops += 2.0 * B * Lout * Cout * Cin * KS
+        if tag[0] == 'irrep_gemm' and tag[2] * tag[3] == 256 * 512:
+            _, B_, C_, O_ = tag
+            flops += 2.0 * O_ * C_ * B_ * 244
             ms += e0.elapsed_time(e1); n_launch += 1
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_irrep_gemm_pmc.json')
+    if os.path.exists(pmc):                      # HBM bytes per launch from the rocprofv3 --pmc passes of this same command
+        traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
 
     # ---- accuracy on the synthetic chunk (outside the timed region) ----
     from oracle import ref_numpy as O
@@ -164,9 +170,9 @@ def main():
                                    f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats)",
                        'pairs_per_step_per_gpu': n_pairs, 'clouds_per_step_per_gpu': args.clouds, 'parallelism': f'pairs-sharded x{world}',
                        'mean_matches': float(np.mean([r.n_match for r in res])), 'registration_recall_synthetic': float(np.mean(rr))},
-            'roofline': {'bound': 'mfma', 'kernel': 'group_conv_kernel<13,60,32,2,2,2> (GF 256->512 / 512->256)', 'achieved': achieved,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                         'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': None},
+            'roofline': {'bound': 'mfma', 'kernel': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, exact f32 MFMA)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic},
         }
         if not args.no_cpu_baseline and world == 1:
             gf_np = {k: v.numpy() for k, v in gf_sd.items()}; et_np = {k: v.numpy() for k, v in et_sd.items()}

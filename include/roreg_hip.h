@@ -183,6 +183,29 @@ size_t roreg_sinkhorn_workspace_size(int m, int n);
 int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n, float alpha, int iters, float *Z_out,
                    int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats, void *stream);
 
+/* ---- group-Fourier evaluation of the group convolution (csrc/fourier.hip, roreg_amd/fourier.py) ---------------
+ * In the basis of the five real irreps (d = 1,3,3,4,5) the 13-stencil group conv is one dense GEMM per irrep,
+ *   Out_rho [d*O][d*B] = W_rho [d*O][d*C] . X_rho [d*C][d*B]      (row-major, keypoints fastest),
+ * 244 instead of 780 multiply-adds per (o,c) pair; same network function as roreg_group_conv (network/group_feat.py:16-33).
+ * roreg_set_fourier_tables: F [60 (q = (rho,i,l))][60 (g)], the orthonormal transform (host pointer).
+ * roreg_irrep_gemm_tiles:   fills / counts the (irrep, m-tile, n-tile) work list of one layer.
+ * roreg_irrep_gemm:         the five GEMMs in one launch; X/Out/Wpack are host arrays of 5 device pointers; Wpack[rho] is
+ *                           roreg_group_conv_pack_weights(KS=1) of the [round_up(d*O,128)][d*C] matrix.
+ * roreg_ft_nonlin:          per (keypoint, channel): inverse transform (or group-domain input) -> + bias (+ bias2)
+ *                           (+ group-domain residual) -> BatchNorm(eval)+ReLU (optional) -> forward transform (or group-domain
+ *                           output [B,C,60], or only the Lout columns selected by g_map -- the ET trunk keeps 45 live columns).
+ *                           Coefficients are one flat buffer: irrep rho occupies [off_rho*C*B, off_{rho+1}*C*B) as the row-major
+ *                           matrix [d*C][d*B].  Xadd: optional second coefficient set summed with Xin. */
+int roreg_set_fourier_tables(const float *F_host);
+size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host);
+int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Wpack, int C, int O, int B,
+                     const int32_t *tiles_dev, int n_tiles, void *stream);
+int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *Xadd, const float *x_spatial, const float *bias,
+                    const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
+                    float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
+                    const int32_t *g_map /* optional [60]: group column -> compact output column or -1 */, int Lout,
+                    int B, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,380 @@
+// Group-Fourier (irrep-domain) evaluation of the icosahedral group convolution.
+//
+// The 13-stencil group conv is a correlation on the 60-element group, so in the basis of the real irreps
+// (d = 1,3,3,4,5) it is, per irrep, ONE dense row-major GEMM
+//     Out_rho [M = d*O][N = d*B]  =  W_rho [M][K = d*C]  .  X_rho [K][N]
+// with sum_d d^3 = 244 multiply-adds per (o,c) pair instead of 60*13 = 780 (roreg_amd/fourier.py has the algebra).
+// Coefficient tensors are channel-major: X_rho[(l,c)][(i,b)] holds x~_{b,c}(rho)[i][l]; keypoints b are the fastest
+// axis, so both kernels below stream fully coalesced rows.
+//
+//   irrep_gemm_kernel : the five GEMMs of a layer in one launch (tile table), exact-f32 MFMA, double-buffered LDS
+//                       tiles of X, weights packed in fragment order exactly like group_conv.hip.
+//   ft_nonlin_kernel  : per (keypoint, channel): inverse transform -> +bias (+residual) -> BatchNorm -> ReLU ->
+//                       forward transform, as two chained 60x60 MFMA products whose intermediate never leaves the
+//                       accumulator registers (the K order of the second product is chosen to be the C/D register
+//                       layout of the first, so no transpose is needed).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int NIRR = 5;
+__constant__ int c_dims[NIRR] = {1, 3, 3, 4, 5};
+// q (row of F) -> irrep, row i, col l   (q = offset[rho] + i*d + l)
+__constant__ signed char c_q_irr[64], c_q_i[64], c_q_l[64];
+
+struct GemmDescs {
+    const float *X[NIRR];
+    float *Out[NIRR];
+    const float4 *W[NIRR];
+    int K[NIRR], M[NIRR], Mpad[NIRR], N[NIRR];
+};
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const int *__restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);                 // [2][CT][256]
+    constexpr int NCOL = 256, OT = 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
+    const float *__restrict__ X = p.X[irr];
+    const float4 *__restrict__ W = p.W[irr];
+    const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const int wo = w & 1, wb = w >> 1;
+    const int m_wave = mt * OT + wo * 64;
+    const int n0 = nt * NCOL;
+    const int ncol_wave = wb * 128;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    // staging: tile [CT][256] floats = CT*64 float4; thread loads CT/4 float4 (row = i*4 + tid/64 ... ) coalesced rows of 1 KiB
+    constexpr int PER_T = CT * 64 / 256;
+    float4 pre[PER_T];
+    const bool full = (n0 + NCOL <= N) && ((N & 3) == 0);
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int e = i * 256 + tid;               // float4 index in tile
+            const int c = e >> 6, n4 = (e & 63) * 4;
+            const float *src = X + (size_t)(k0 + c) * N + n0 + n4;
+            if (full) pre[i] = *reinterpret_cast<const float4 *>(src);
+            else {
+                float4 v;
+                v.x = (n0 + n4 + 0 < N) ? src[0] : 0.f; v.y = (n0 + n4 + 1 < N) ? src[1] : 0.f;
+                v.z = (n0 + n4 + 2 < N) ? src[2] : 0.f; v.w = (n0 + n4 + 3 < N) ? src[3] : 0.f;
+                pre[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(xs + buf * (CT * NCOL));
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) dst[i * 256 + tid] = pre[i];
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += CT) {
+        const bool more = k0 + CT < K;
+        if (more) load_tile(k0 + CT);                     // global loads in flight during the MFMA block
+        const float *xt = xs + buf * (CT * NCOL) + ncol_wave + j;
+        const float4 *wk = W + ((size_t)(k0 / 8) * Mpad + m_wave + j) * 2 + h;
+#pragma unroll
+        for (int q = 0; q < CT / 8; ++q) {
+            float4 a[2];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) a[ot] = wk[((size_t)q * Mpad + ot * 32) * 2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = xt[(q * 8 + r * 2 + h) * NCOL + t * 32];
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const float av = r == 0 ? a[ot].x : r == 1 ? a[ot].y : r == 2 ? a[ot].z : a[ot].w;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[ot][t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float *__restrict__ Out = p.Out[irr];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + ncol_wave + t * 32 + j;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < M) Out[(size_t)m * N + n] = acc[ot][t][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct NonlinParams {
+    const float *Xin;            // flat coefficient buffer [60*C*B] (nullptr when the input is spatial)
+    const float *Xadd;           // optional second coefficient buffer added to Xin (residual in the Fourier domain)
+    float *Xout;                 // flat coefficient buffer out (nullptr when the output is spatial)
+    const float *x_spatial;      // [B,C,60] input in the group domain
+    const float *r_spatial;      // [B,C,60] residual added in the group domain (before BN/ReLU; only with spatial output)
+    float *out_spatial;          // [B,C,Lout]
+    const int *g_map;            // optional [60] -> compact output column (or -1 = not written); Lout columns are written
+    const float *bias, *bias2, *bn_scale, *bn_shift;      // per channel; any may be null
+    const float *A1, *A2;        // fragment-ordered transform tables (roreg_set_fourier_tables)
+    int B, C, tiles_per_c, Lout;
+};
+
+// coefficient q = (rho, i, l) of (b, c) lives at flat offset  (alpha_q*C + c*d_q + i_q) * B + b   with alpha_q = offset_rho + l*d
+__constant__ int c_q_alpha[64], c_q_d[64], c_q_ii[64];
+
+template <bool IN_SPATIAL, bool OUT_SPATIAL>
+__global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
+    __shared__ int2 qtab[64];                      // per q: { alpha_q*C + i_q , d_q }
+    if (threadIdx.x < 64) qtab[threadIdx.x] = make_int2(c_q_alpha[threadIdx.x] * p.C + c_q_ii[threadIdx.x], c_q_d[threadIdx.x]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int jn = lane & 31, h = lane >> 5;
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * 256) >> 6;
+    const int B = p.B, C = p.C;
+    const int n_tiles = C * p.tiles_per_c;
+
+    // transform fragments: A1[s][tile][lane] (inverse), A2[step][tile][lane] (forward, K order = C/D register order)
+    float a1[IN_SPATIAL ? 1 : 30][2];
+    float a2[OUT_SPATIAL ? 1 : 32][2];
+    if (!IN_SPATIAL) {
+#pragma unroll
+        for (int s = 0; s < 30; ++s) { a1[s][0] = p.A1[(s * 2 + 0) * 64 + lane]; a1[s][1] = p.A1[(s * 2 + 1) * 64 + lane]; }
+    }
+    if (!OUT_SPATIAL) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) { a2[s][0] = p.A2[(s * 2 + 0) * 64 + lane]; a2[s][1] = p.A2[(s * 2 + 1) * 64 + lane]; }
+    }
+    const bool has_add = p.Xadd != nullptr;
+
+    for (int tile = wave_global; tile < n_tiles; tile += n_waves) {
+        const int c = tile / p.tiles_per_c;
+        const int b = (tile - c * p.tiles_per_c) * 32 + jn;
+        const bool valid = b < B;
+        const int bb = valid ? b : B - 1;
+        f32x16 v[2];
+        if (IN_SPATIAL) {
+            const float *src = p.x_spatial + ((size_t)bb * C + c) * ROREG_G;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    v[t][r] = g < ROREG_G ? src[g] : 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[t][r] = 0.f;
+            float cv[30];
+#pragma unroll
+            for (int s = 0; s < 30; ++s) {               // all loads first: 30 independent coalesced 128-B rows in flight
+                const int2 qt = qtab[2 * s + h];
+                const size_t off = (size_t)(qt.x + c * qt.y) * B + bb;
+                cv[s] = p.Xin[off];
+                if (has_add) cv[s] += p.Xadd[off];
+            }
+#pragma unroll
+            for (int s = 0; s < 30; ++s) {
+                v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][0], cv[s], v[0], 0, 0, 0);
+                v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][1], cv[s], v[1], 0, 0, 0);
+            }
+        }
+        // ---- group-domain epilogue --------------------------------------------------------------------------------
+        float bsum = 0.f;
+        if (p.bias) bsum += p.bias[c];
+        if (p.bias2) bsum += p.bias2[c];
+        const bool bn = p.bn_scale != nullptr;
+        const float sc = bn ? p.bn_scale[c] : 1.f, sh = bn ? p.bn_shift[c] : 0.f;
+        const float *rs = (OUT_SPATIAL && p.r_spatial) ? p.r_spatial + ((size_t)bb * C + c) * ROREG_G : nullptr;
+        float *os = OUT_SPATIAL ? p.out_spatial + ((size_t)bb * C + c) * p.Lout : nullptr;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float x = v[t][r] + bsum;
+                if (OUT_SPATIAL && rs && g < ROREG_G) x += rs[g];
+                if (bn) x = fmaxf(fmaf(x, sc, sh), 0.f);
+                if (g >= ROREG_G) x = 0.f;
+                v[t][r] = x;
+                if (OUT_SPATIAL && valid && g < ROREG_G) {
+                    const int go = p.g_map ? p.g_map[g] : g;
+                    if (go >= 0) os[go] = x;
+                }
+            }
+        if (!OUT_SPATIAL) {
+            f32x16 o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int s = t * 16 + r;
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s][0], v[t][r], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s][1], v[t][r], o[1], 0, 0, 0);
+                }
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int q = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (q < ROREG_G) {
+                            const int2 qt = qtab[q];
+                            p.Xout[(size_t)(qt.x + c * qt.y) * B + b] = o[t][r];
+                        }
+                    }
+            }
+        }
+    }
+}
+
+float *g_A1 = nullptr, *g_A2 = nullptr;
+
+}  // namespace
+
+extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)], orthonormal */) {
+    ROREG_REQUIRE(F_host, "roreg_set_fourier_tables: null table");
+    static const int dims[5] = {1, 3, 3, 4, 5};
+    signed char qi[64], ql[64], qr[64];
+    memset(qi, 0, 64); memset(ql, 0, 64); memset(qr, 0, 64);
+    int q = 0;
+    for (int r = 0; r < 5; ++r)
+        for (int i = 0; i < dims[r]; ++i)
+            for (int l = 0; l < dims[r]; ++l, ++q) { qr[q] = (signed char)r; qi[q] = (signed char)i; ql[q] = (signed char)l; }
+    int qa[64], qd[64], qii[64];
+    memset(qa, 0, sizeof(qa)); memset(qd, 0, sizeof(qd)); memset(qii, 0, sizeof(qii));
+    {
+        int off = 0, qq = 0;
+        for (int r = 0; r < 5; ++r) {
+            for (int i = 0; i < dims[r]; ++i)
+                for (int l = 0; l < dims[r]; ++l, ++qq) { qa[qq] = off + l * dims[r]; qd[qq] = dims[r]; qii[qq] = i; }
+            off += dims[r] * dims[r];
+        }
+        for (; qq < 64; ++qq) qd[qq] = 1;
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_q_irr), qr, 64) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_q_i), qi, 64) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(c_q_l), ql, 64) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_q_alpha), qa, sizeof(qa)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(c_q_d), qd, sizeof(qd)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_q_ii), qii, sizeof(qii)) != hipSuccess) {
+        roreg::set_error("roreg_set_fourier_tables: hipMemcpyToSymbol failed");
+        return 1;
+    }
+    // A1[s][tile][lane] = F[q = 2s + (lane>>5)][g = tile*32 + (lane&31)]   (inverse transform: x(g) = sum_q F[q][g] coef[q])
+    // A2[(t,r)][tile][lane] = F[q' = tile*32 + (lane&31)][g = t*32 + (r&3) + 8(r>>2) + 4(lane>>5)]
+    static float A1[30 * 2 * 64], A2[32 * 2 * 64];
+    for (int s = 0; s < 30; ++s)
+        for (int tile = 0; tile < 2; ++tile)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int qq = 2 * s + (lane >> 5), g = tile * 32 + (lane & 31);
+                A1[(s * 2 + tile) * 64 + lane] = g < 60 ? F_host[qq * 60 + g] : 0.f;
+            }
+    for (int t = 0; t < 2; ++t)
+        for (int r = 0; r < 16; ++r)
+            for (int tile = 0; tile < 2; ++tile)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int qq = tile * 32 + (lane & 31), g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    A2[((t * 16 + r) * 2 + tile) * 64 + lane] = (qq < 60 && g < 60) ? F_host[qq * 60 + g] : 0.f;
+                }
+    if (!g_A1) {
+        if (hipMalloc(&g_A1, sizeof(A1)) != hipSuccess || hipMalloc(&g_A2, sizeof(A2)) != hipSuccess) {
+            roreg::set_error("roreg_set_fourier_tables: hipMalloc failed");
+            return 1;
+        }
+    }
+    if (hipMemcpy(g_A1, A1, sizeof(A1), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(g_A2, A2, sizeof(A2), hipMemcpyHostToDevice) != hipSuccess) {
+        roreg::set_error("roreg_set_fourier_tables: hipMemcpy failed");
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host /* nullable; [n][3] */) {
+    static const int dims[5] = {1, 3, 3, 4, 5};
+    size_t n = 0;
+    // larger irreps first: the long tiles are scheduled before the short ones
+    for (int r = 4; r >= 0; --r) {
+        const int d = dims[r];
+        const int mts = round_up(d * O, 128) / 128, nts = (d * B + 255) / 256;
+        for (int nt = 0; nt < nts; ++nt)
+            for (int mt = 0; mt < mts; ++mt, ++n)
+                if (tiles_host) { tiles_host[n * 3] = r; tiles_host[n * 3 + 1] = mt; tiles_host[n * 3 + 2] = nt; }
+    }
+    return n;
+}
+
+extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Wpack, int C, int O, int B,
+                                const int32_t *tiles_dev, int n_tiles, void *stream) {
+    ROREG_REQUIRE(X && Out && Wpack && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm: bad arguments");
+    ROREG_REQUIRE(C % 32 == 0, "roreg_irrep_gemm: C must be a multiple of 32 (got %d)", C);
+    static const int dims[5] = {1, 3, 3, 4, 5};
+    GemmDescs p;
+    for (int r = 0; r < 5; ++r) {
+        p.X[r] = X[r]; p.Out[r] = Out[r]; p.W[r] = reinterpret_cast<const float4 *>(Wpack[r]);
+        p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
+    }
+    constexpr int CT = 32;
+    const size_t lds = 2 * CT * 256 * sizeof(float);
+    auto kern = irrep_gemm_kernel<CT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { roreg::set_error("roreg_irrep_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), lds, roreg::as_stream(stream), p, tiles_dev);
+    ROREG_CHECK_LAUNCH("roreg_irrep_gemm");
+    return 0;
+}
+
+extern "C" int roreg_ft_nonlin(const float *Xin, const float *Xadd, const float *x_spatial, const float *bias, const float *bias2,
+                               const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
+                               const int32_t *g_map, int Lout, int B, int C, void *stream) {
+    ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
+    ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
+    ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
+    ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr) && B > 0 && C > 0, "roreg_ft_nonlin: bad arguments");
+    ROREG_REQUIRE((long long)60 * C * B < (1ll << 40), "roreg_ft_nonlin: tensor too large");
+    NonlinParams p;
+    memset(&p, 0, sizeof(p));
+    p.Xin = Xin; p.Xadd = Xadd; p.Xout = Xout;
+    p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
+    p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G;
+    p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
+    p.B = B; p.C = C; p.tiles_per_c = (B + 31) / 32;
+    const long long n_tiles = (long long)C * p.tiles_per_c;
+    long long blocks = (n_tiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = roreg::as_stream(stream);
+    const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
+    if (in_sp && !out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (!in_sp && !out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (!in_sp && out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
+    ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
+    return 0;
+}

@@ -49,6 +49,10 @@ PROTOTYPES = {
     'roreg_rm_elementwise': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'roreg_sinkhorn_workspace_size': (c_size_t, [c_int, c_int]),
     'roreg_sinkhorn': (c_int, [_P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'roreg_set_fourier_tables': (c_int, [_P]),
+    'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
+    'roreg_irrep_gemm': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
 }
 
 
@@ -425,3 +429,69 @@ def sinkhorn(src_final, tgt_final, alpha, iters):
     _check(lib().roreg_sinkhorn(_ptr(src_final, torch.float32), m, _ptr(tgt_final, torch.float32), n, float(alpha), int(iters), _ptr(Z),
                                 _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, _stream()), 'roreg_sinkhorn')
     return Z, m0, m1, s0, s1
+
+
+# ----------------------------------------------------------------------------------------------------
+# group-Fourier path of the group convolution
+# ----------------------------------------------------------------------------------------------------
+_fourier_ready = False
+IRREP_DIMS = (1, 3, 3, 4, 5)
+IRREP_OFFSETS = (0, 1, 10, 19, 35, 60)
+
+
+def ensure_fourier():
+    global _fourier_ready
+    if not _fourier_ready:
+        from .fourier import group_fourier
+        F = np.ascontiguousarray(group_fourier().F, np.float32)
+        _check(lib().roreg_set_fourier_tables(F.ctypes.data), 'roreg_set_fourier_tables')
+        _fourier_ready = True
+
+
+def _ptr_array(views):
+    arr = (c_void_p * 5)(*[c_void_p(v.data_ptr()) for v in views])
+    return arr
+
+
+def coef_views(buf, C, B):
+    """Five per-irrep views [d*C, d*B] of a flat coefficient buffer of 60*C*B floats."""
+    return [buf[IRREP_OFFSETS[r] * C * B:IRREP_OFFSETS[r + 1] * C * B].view(IRREP_DIMS[r] * C, IRREP_DIMS[r] * B) for r in range(5)]
+
+
+_tile_cache = {}
+
+
+def irrep_gemm(X_buf, Wpacks, C, O, B):
+    """coefficients [60*C*B] -> [60*O*B] through the five per-irrep GEMMs."""
+    out = torch.empty(60 * O * B, dtype=torch.float32, device=X_buf.device)
+    key = (O, B)
+    t = _tile_cache.get(key)
+    if t is None:
+        n = lib().roreg_irrep_gemm_tiles(O, B, None)
+        host = np.empty((n, 3), np.int32)
+        lib().roreg_irrep_gemm_tiles(O, B, host.ctypes.data)
+        t = torch.from_numpy(host).cuda()
+        _tile_cache[key] = t
+    xv = coef_views(X_buf, C, B); ov = coef_views(out, O, B)
+    if PROFILE is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), _ptr_array(Wpacks), C, O, B, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
+           'roreg_irrep_gemm')
+    if PROFILE is not None:
+        e1.record(); PROFILE.append((('irrep_gemm', B, C, O), e0, e1))
+    return out
+
+
+def ft_nonlin(B, C, coef_in=None, coef_add=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
+              g_map=None, Lout=60):
+    ensure_fourier()
+    dev = (coef_in if coef_in is not None else x_spatial).device
+    if spatial_out:
+        out = torch.empty((B, C, Lout if g_map is not None else 60), dtype=torch.float32, device=dev); xout = None; osp = _ptr(out)
+    else:
+        out = torch.empty(60 * C * B, dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
+    scale, shift = bn if bn is not None else (None, None)
+    _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(coef_add, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
+                                 _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
+                                 _ptr(g_map, torch.int32), int(Lout), B, C, _stream()), 'roreg_ft_nonlin')
+    return out

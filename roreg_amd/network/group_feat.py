@@ -18,15 +18,24 @@ class Group_feat_network(nn.Module):
         self.SO3_Conv_layers = nn.ModuleList([Residual_Comb_Conv(256, 512, 256)])
         self.Conv_out = Comb_Conv(256, 32)
         object.__setattr__(self, '_b_in', _Branch(self.Conv_in))
+        # 'fourier': irrep-domain evaluation (3.2x fewer MACs, same function); 'direct': the 13-stencil MFMA group conv
+        object.__setattr__(self, 'mode', 'fourier')
+        object.__setattr__(self, '_fourier', None)
 
     def forward(self, feats, want_inv=True):
         if feats.dim() != 3 or feats.shape[1:] != (32, 60):
             raise ValueError(f'GF expects [B,32,60], got {tuple(feats.shape)}')
         x = feats.to('cuda', torch.float32).contiguous()
-        h = self._b_in(x)
-        for layer in self.SO3_Conv_layers:
-            h = layer(h)
-        raw = self.Conv_out(h, residual=x)              # feats_eqv + feats  (group_feat.py:37)
+        if self.mode == 'fourier':
+            if self._fourier is None:
+                from .gf_fourier import FourierGF
+                object.__setattr__(self, '_fourier', FourierGF(self))
+            raw = self._fourier.forward_raw(x)
+        else:
+            h = self._b_in(x)
+            for layer in self.SO3_Conv_layers:
+                h = layer(h)
+            raw = self.Conv_out(h, residual=x)          # feats_eqv + feats  (group_feat.py:37)
         eqv, inv = hip.gf_finalize(raw, want_inv=want_inv)
         return {'inv': inv, 'eqv': eqv}
 

@@ -1,0 +1,69 @@
+"""Irrep-domain (group-Fourier) evaluation of the group conv against the direct MFMA group conv, the oracle and the golden.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+from roreg_amd import synth
+from roreg_amd.parses.parses_test import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def test_transform_roundtrip_and_orthogonality():
+    from roreg_amd import hip
+    from roreg_amd.fourier import group_fourier
+    gf = group_fourier()
+    rng = np.random.default_rng(0)
+    for B, C in [(37, 32), (200, 64)]:
+        x = rng.standard_normal((B, C, 60)).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        coef = hip.ft_nonlin(B, C, x_spatial=xd)
+        # coefficient (rho,i,l) of (b,c) sits at X_rho[(l*C + c), (i*B + b)]
+        want = x @ gf.F.T.astype(np.float32)                                   # [B,C,60(q)]
+        views = hip.coef_views(coef, C, B)
+        for q, (ri, i, l) in enumerate(gf.index):
+            got = views[ri].view(hip.IRREP_DIMS[ri], C, hip.IRREP_DIMS[ri], B)[l, :, i, :].t().cpu().numpy()
+            assert np.abs(got - want[:, :, q]).max() < 1e-5
+        back = hip.ft_nonlin(B, C, coef_in=coef, spatial_out=True).cpu().numpy()
+        assert np.abs(back - x).max() < 1e-5
+
+
+def test_fourier_layer_equals_direct_group_conv(group):
+    """FT -> per-irrep GEMMs -> IFT reproduces the 13-stencil group conv (incl. bias)."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(1)
+    B, C, Oc = 70, 64, 160
+    conv = torch.nn.Conv2d(C, Oc, (1, 13))
+    x = rng.standard_normal((B, C, 60)).astype(np.float32)
+    want = O.group_conv(x, conv.weight.detach().numpy(), conv.bias.detach().numpy(), group.Nei)
+    L = _Layer(conv)
+    xd = torch.from_numpy(x).cuda()
+    X = hip.ft_nonlin(B, C, x_spatial=xd)
+    T = hip.irrep_gemm(X, L.wpack, C, Oc, B)
+    got = hip.ft_nonlin(B, Oc, coef_in=T, bias=L.bias, spatial_out=True).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_gf_fourier_vs_direct_vs_golden(group):
+    from roreg_amd.network import name2network
+    z = load_golden('gf_forward')
+    net = name2network['GF_test'](default_config())
+    sd = synth.seeded_state_dict(net, int(z['seed']))
+    x = torch.from_numpy(z['x'])
+    net.PartI_net.mode = 'fourier'
+    f = net(x)
+    net.PartI_net.mode = 'direct'
+    d = net(x)
+    assert np.abs(f['eqv'].cpu().numpy() - d['eqv'].cpu().numpy()).max() < 1e-5
+    assert np.abs(f['eqv'].cpu().numpy() - z['eqv']).max() < 1e-5
+    assert np.abs(f['inv'].cpu().numpy() - z['inv']).max() < 1e-5
+    # ragged batch sizes (not multiples of 4 / 32 / 256)
+    rng = np.random.default_rng(2)
+    for B in [1, 5, 257, 1250]:
+        xb = torch.from_numpy(rng.standard_normal((B, 32, 60)).astype(np.float32))
+        net.PartI_net.mode = 'fourier'; a = net(xb)['eqv'].cpu().numpy()
+        net.PartI_net.mode = 'direct'; b = net(xb)['eqv'].cpu().numpy()
+        assert np.abs(a - b).max() < 1e-5, B
