@@ -34,14 +34,18 @@ struct GemmDescs {
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---------------------------------------------------------------------------------------------------------------
+// X tiles go global -> LDS with the LDS-DMA path (global_load_lds_dwordx4: one wave instruction moves one 1-KiB tile row, no
+// VGPR staging), which frees the registers to double-buffer the weight fragments of the next K chunk as well: during the
+// 128 MFMAs of a chunk both operands of the next chunk are in flight.
 template <int CT>
 __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const int *__restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs = reinterpret_cast<float *>(smem);                 // [2][CT][256]
-    constexpr int NCOL = 256, OT = 128;
+    constexpr int NCOL = 256, OT = 128, NQ = CT / 8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
+    if (irr < 0) return;
     const float *__restrict__ X = p.X[irr];
     const float4 *__restrict__ W = p.W[irr];
     const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
@@ -58,45 +62,41 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
-    // staging: tile [CT][256] floats = CT*64 float4; thread loads CT/4 float4 (row = i*4 + tid/64 ... ) coalesced rows of 1 KiB
-    constexpr int PER_T = CT * 64 / 256;
-    float4 pre[PER_T];
-    const bool full = (n0 + NCOL <= N) && ((N & 3) == 0);
-    auto load_tile = [&](int k0) {
+    // this lane's 16-byte column group of a tile row (clamped inside the matrix: out-of-range columns are never stored)
+    int ncol = n0 + lane * 4;
+    if (ncol > N - 4) ncol = N - 4;
+    const float *xrow = X + ncol;
+    auto issue_tile = [&](int k0, int buf) {
 #pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int e = i * 256 + tid;               // float4 index in tile
-            const int c = e >> 6, n4 = (e & 63) * 4;
-            const float *src = X + (size_t)(k0 + c) * N + n0 + n4;
-            if (full) pre[i] = *reinterpret_cast<const float4 *>(src);
-            else {
-                float4 v;
-                v.x = (n0 + n4 + 0 < N) ? src[0] : 0.f; v.y = (n0 + n4 + 1 < N) ? src[1] : 0.f;
-                v.z = (n0 + n4 + 2 < N) ? src[2] : 0.f; v.w = (n0 + n4 + 3 < N) ? src[3] : 0.f;
-                pre[i] = v;
-            }
+        for (int i = 0; i < CT / 4; ++i) {
+            const int c = w * (CT / 4) + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xrow + (size_t)(k0 + c) * N),
+                                             (__attribute__((address_space(3))) void *)(xs + (buf * CT + c) * NCOL), 16, 0, 0);
         }
     };
-    auto store_tile = [&](int buf) {
-        float4 *dst = reinterpret_cast<float4 *>(xs + buf * (CT * NCOL));
+    float4 a_cur[NQ][2], a_nxt[NQ][2];
+    auto load_a = [&](int k0, float4 (&a)[NQ][2]) {
+        const float4 *wk = W + ((size_t)(k0 / 8) * Mpad + m_wave + j) * 2 + h;
 #pragma unroll
-        for (int i = 0; i < PER_T; ++i) dst[i * 256 + tid] = pre[i];
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) a[q][ot] = wk[((size_t)q * Mpad + ot * 32) * 2];
     };
 
-    load_tile(0);
-    store_tile(0);
+    issue_tile(0, 0);
+    load_a(0, a_cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += CT) {
         const bool more = k0 + CT < K;
-        if (more) load_tile(k0 + CT);                     // global loads in flight during the MFMA block
+        if (more) {
+            issue_tile(k0 + CT, buf ^ 1);
+            load_a(k0 + CT, a_nxt);
+        }
         const float *xt = xs + buf * (CT * NCOL) + ncol_wave + j;
-        const float4 *wk = W + ((size_t)(k0 / 8) * Mpad + m_wave + j) * 2 + h;
 #pragma unroll
-        for (int q = 0; q < CT / 8; ++q) {
-            float4 a[2];
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) a[ot] = wk[((size_t)q * Mpad + ot * 32) * 2];
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float bv[4];
@@ -104,13 +104,17 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
                 for (int t = 0; t < 4; ++t) bv[t] = xt[(q * 8 + r * 2 + h) * NCOL + t * 32];
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
-                    const float av = r == 0 ? a[ot].x : r == 1 ? a[ot].y : r == 2 ? a[ot].z : a[ot].w;
+                    const float av = r == 0 ? a_cur[q][ot].x : r == 1 ? a_cur[q][ot].y : r == 2 ? a_cur[q][ot].z : a_cur[q][ot].w;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[ot][t], 0, 0, 0);
                 }
             }
         }
-        if (more) store_tile(buf ^ 1);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's tile rows have landed in LDS
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { a_cur[q][0] = a_nxt[q][0]; a_cur[q][1] = a_nxt[q][1]; }
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -335,6 +339,7 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
                                 const int32_t *tiles_dev, int n_tiles, void *stream) {
     ROREG_REQUIRE(X && Out && Wpack && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm: bad arguments");
     ROREG_REQUIRE(C % 32 == 0, "roreg_irrep_gemm: C must be a multiple of 32 (got %d)", C);
+    ROREG_REQUIRE(B % 4 == 0, "roreg_irrep_gemm: B must be a multiple of 4 (got %d); pad the keypoint batch", B);
     static const int dims[5] = {1, 3, 3, 4, 5};
     GemmDescs p;
     for (int r = 0; r < 5; ++r) {

@@ -60,6 +60,9 @@ class FourierGF:
         """x [B,32,60] device float32 -> eqv_raw = conv stack(x) + x  [B,32,60]."""
         self._plan()
         hip.ensure_fourier()
+        B0 = x.shape[0]
+        if B0 % 4:                                    # the GEMM streams 16-byte column groups: pad the batch, drop the rows at the end
+            x = torch.cat([x, x.new_zeros((4 - B0 % 4,) + tuple(x.shape[1:]))], 0)
         B = x.shape[0]
         X0 = hip.ft_nonlin(B, 32, x_spatial=x)
         T0 = hip.irrep_gemm(X0, self.l_in.wpack, 32, 256, B)
@@ -73,4 +76,5 @@ class FourierGF:
         X3 = hip.ft_nonlin(B, 256, coef_in=T2, coef_add=T0, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3)
         del T2, T0
         T3 = hip.irrep_gemm(X3, self.l_out.wpack, 256, 32, B)
-        return hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True)
+        out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True)
+        return out[:B0] if B0 != B else out

@@ -35,7 +35,7 @@ def test_fourier_layer_equals_direct_group_conv(group):
     from roreg_amd import hip
     from roreg_amd.network.gf_fourier import _Layer
     rng = np.random.default_rng(1)
-    B, C, Oc = 70, 64, 160
+    B, C, Oc = 72, 64, 160
     conv = torch.nn.Conv2d(C, Oc, (1, 13))
     x = rng.standard_normal((B, C, 60)).astype(np.float32)
     want = O.group_conv(x, conv.weight.detach().numpy(), conv.bias.detach().numpy(), group.Nei)
