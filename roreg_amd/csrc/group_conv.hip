@@ -118,18 +118,25 @@ __global__ __launch_bounds__(256, 2) void group_conv_kernel(GCParams p) {
         }
         __syncthreads();
 
-        // ---- MFMA over (k, c in chunk) ----------------------------------------------------------------
+        // ---- MFMA over (k, c in chunk); the weight fragments of stencil position k+1 are in flight during position k -----
+        constexpr int NQ = CT / 8;
+        float4 a_cur[NQ][OTW], a_nxt[NQ][OTW];
+        auto load_a = [&](int k, float4 (&a)[NQ][OTW]) {
+            const float4 *wk = p.wp + ((size_t)(k * (p.Cin / 8) + c0 / 8) * p.CoutPad + o_wave + j) * 2 + h;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int ot = 0; ot < OTW; ++ot) a[q][ot] = wk[((size_t)q * p.CoutPad + ot * 32) * 2];
+        };
+        load_a(0, a_cur);
 #pragma unroll 1
         for (int k = 0; k < KS; ++k) {
+            if (k + 1 < KS) load_a(k + 1, a_nxt);
             int off[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) off[t] = rowbase[t] + gt[gi[t] * KS + k];
-            const float4 *wk = p.wp + ((size_t)(k * (p.Cin / 8) + c0 / 8) * p.CoutPad + o_wave + j) * 2 + h;
 #pragma unroll
-            for (int q = 0; q < CT / 8; ++q) {
-                float4 a[OTW];
-#pragma unroll
-                for (int ot = 0; ot < OTW; ++ot) a[ot] = wk[((size_t)q * p.CoutPad + ot * 32) * 2];
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float bv[4];
@@ -137,12 +144,18 @@ __global__ __launch_bounds__(256, 2) void group_conv_kernel(GCParams p) {
                     for (int t = 0; t < 4; ++t) bv[t] = xs[off[t] + (q * 8 + r * 2) * LIN];
 #pragma unroll
                     for (int ot = 0; ot < OTW; ++ot) {
-                        const float av = r == 0 ? a[ot].x : r == 1 ? a[ot].y : r == 2 ? a[ot].z : a[ot].w;
+                        const float av = r == 0 ? a_cur[q][ot].x : r == 1 ? a_cur[q][ot].y : r == 2 ? a_cur[q][ot].z : a_cur[q][ot].w;
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
                             acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[ot][t], 0, 0, 0);
                     }
                 }
+            }
+            if (k + 1 < KS) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int ot = 0; ot < OTW; ++ot) a_cur[q][ot] = a_nxt[q][ot];
             }
         }
     }
@@ -317,6 +330,10 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
         if (cp % 128 == 0) return launch<13, 60, 32, 2, 2, 2>(p, s, ws, wsf, q);
         if (cp % 64 == 0) return launch<13, 60, 16, 1, 4, 2>(p, s, ws, wsf, q);
         return launch<13, 60, 16, 1, 4, 1>(p, s, ws, wsf, q);
+    }
+    if (KS == 13 && Lin == 48) {
+        if (cp % 128 == 0) return launch<13, 48, 16, 2, 2, 2>(p, s, ws, wsf, q);
+        return launch<13, 48, 16, 1, 4, 1>(p, s, ws, wsf, q);
     }
     if (KS == 13 && Lin == 45) {
         if (cp % 128 == 0) return launch<13, 45, 16, 2, 2, 2>(p, s, ws, wsf, q);

@@ -119,7 +119,9 @@ class RegistrationEngine:
             j, rows = i, 0
             while j < len(items) and (j == i or rows + items[j][2].shape[0] <= max_rows):
                 rows += items[j][2].shape[0]; j += 1
-            x_all = torch.empty((rows, 128, 60), dtype=torch.float32, device='cuda')
+            rows_pad = (rows + 3) // 4 * 4                # the irrep-domain GEMM streams 16-byte column groups
+            x_all = torch.zeros((rows_pad, 128, 60), dtype=torch.float32, device='cuda') if rows_pad != rows else \
+                torch.empty((rows, 128, 60), dtype=torch.float32, device='cuda')
             parts = []
             o = 0
             for q in range(i, j):

@@ -29,6 +29,7 @@ class ET_test(nn.Module):
             nn.Conv2d(d[1], d[2], 1, 1), nn.BatchNorm2d(d[2]), nn.ReLU(),
             nn.Conv2d(d[2], d[3], 1, 1))
         self.pruned = True
+        self.fourier_init = True
 
     # ---- kernel plans -------------------------------------------------------------------------------------
     def _head_plans(self):
@@ -43,6 +44,8 @@ class ET_test(nn.Module):
             self._head_key = key
         return self._head
 
+    LIVE_PAD = 48          # the 45 live columns of Conv_init's output are stored with a 16-byte-friendly stride
+
     @staticmethod
     def _pruned_gathers():
         T = tables()
@@ -53,7 +56,21 @@ class ET_test(nn.Module):
         ga = T.Nei[l2]                                                    # [45,13] into the full 60 columns
         gb = np.array([[pos2[int(v)] for v in T.Nei[g]] for g in l1])     # [13,13] into the 45 live columns
         gc = np.array([[pos1[int(v)] for v in T.Nei[g]] for g in l0])     # [1,13]  into the 13 live columns
-        return (hip.gather_table('et_a', ga), hip.gather_table('et_b', gb), hip.gather_table('et_c', gc), pos2[0])
+        gmap = np.full(60, -1, np.int32)
+        for g, i in pos2.items():
+            gmap[g] = i
+        return (hip.gather_table('et_a', ga), hip.gather_table('et_b', gb), hip.gather_table('et_c', gc), pos2[0],
+                hip.gather_table('et_gmap', gmap))
+
+    def _fourier_init(self):
+        """Conv_init (BN -> ReLU -> group conv 128 -> 256) in the irrep domain; only its 45 live output columns are
+        transformed back (244 instead of 45*13 = 585 multiply-adds per channel pair)."""
+        from .gf_fourier import _Layer, _fold_bn
+        key = _version_key(self.Conv_init)
+        if getattr(self, '_finit_key', None) != key:
+            self._finit = (_Layer(self.Conv_init.comb_layer[2]), _fold_bn(self.Conv_init.comb_layer[0]))
+            self._finit_key = key
+        return self._finit
 
     def assemble(self, data):
         """x [B,128,60] = cat(before0[P[pre]], before1, after0[P[pre]], after1)  (eqv_trans.py:126-129)."""
@@ -70,8 +87,18 @@ class ET_test(nn.Module):
         res = self.PartII_SO3_Conv_layers[0]
         h0p, h1p, h2p = self._head_plans()
         if self.pruned:
-            ga, gb, gc, p0 = self._pruned_gathers()
-            h = self.Conv_init(x, gather=ga)                                   # [B,256,45]
+            ga, gb, gc, p0, gmap = self._pruned_gathers()
+            B = x.shape[0]
+            if self.fourier_init and B % 4 == 0:
+                layer, bn = self._fourier_init()
+                hip.ensure_fourier()
+                X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn)
+                T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B)
+                del X0
+                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD)   # [B,256,48]
+                del T0
+            else:
+                h = self.Conv_init(x, gather=ga)                               # [B,256,45]
             m = res._b_in(h, gather=gb)                                        # [B,512,13]
             sc = h[:, :, p0:p0 + 1].contiguous()                               # identity short cut at g=0
             t = res._b_out(m, gather=gc, residual=sc)                          # [B,256,1]
