@@ -175,6 +175,22 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     }
     const bool has_add = p.Xadd != nullptr;
 
+    // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
+    float cv[IN_SPATIAL ? 1 : 30], cn[IN_SPATIAL ? 1 : 30];
+    auto load_coefs = [&](int tile, float (&dst)[IN_SPATIAL ? 1 : 30]) {
+        const int c = tile / p.tiles_per_c;
+        int b = (tile - c * p.tiles_per_c) * 32 + jn;
+        if (b >= B) b = B - 1;
+#pragma unroll
+        for (int s = 0; s < 30; ++s) {
+            const int2 qt = qtab[2 * s + h];
+            const size_t off = (size_t)(qt.x + c * qt.y) * B + b;
+            dst[s] = p.Xin[off];
+            if (has_add) dst[s] += p.Xadd[off];
+        }
+    };
+    if (!IN_SPATIAL && wave_global < n_tiles) load_coefs(wave_global, cv);
+
     for (int tile = wave_global; tile < n_tiles; tile += n_waves) {
         const int c = tile / p.tiles_per_c;
         const int b = (tile - c * p.tiles_per_c) * 32 + jn;
@@ -191,18 +207,11 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                     v[t][r] = g < ROREG_G ? src[g] : 0.f;
                 }
         } else {
+            if (tile + n_waves < n_tiles) load_coefs(tile + n_waves, cn);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[t][r] = 0.f;
-            float cv[30];
-#pragma unroll
-            for (int s = 0; s < 30; ++s) {               // all loads first: 30 independent coalesced 128-B rows in flight
-                const int2 qt = qtab[2 * s + h];
-                const size_t off = (size_t)(qt.x + c * qt.y) * B + bb;
-                cv[s] = p.Xin[off];
-                if (has_add) cv[s] += p.Xadd[off];
-            }
 #pragma unroll
             for (int s = 0; s < 30; ++s) {
                 v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][0], cv[s], v[0], 0, 0, 0);
@@ -258,6 +267,10 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                         }
                     }
             }
+        }
+        if (!IN_SPATIAL) {
+#pragma unroll
+            for (int s = 0; s < 30; ++s) cv[s] = cn[s];
         }
     }
 }

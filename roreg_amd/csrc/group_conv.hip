@@ -332,6 +332,9 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
         return launch<13, 60, 16, 1, 4, 1>(p, s, ws, wsf, q);
     }
     if (KS == 13 && Lin == 48) {
+        // 256 output channels x 128 columns per workgroup: the 48-column slabs of the ~11 keypoints a tile touches are small enough
+        // for 32-channel chunks (half the barriers, twice the MFMA work per staged byte of the 2x2 layout)
+        if (cp % 256 == 0) return launch<13, 48, 32, 4, 1, 2>(p, s, ws, wsf, q);
         if (cp % 128 == 0) return launch<13, 48, 16, 2, 2, 2>(p, s, ws, wsf, q);
         return launch<13, 48, 16, 1, 4, 1>(p, s, ws, wsf, q);
     }

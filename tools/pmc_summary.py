@@ -8,7 +8,8 @@ import sys
 
 
 def short(name):
-    n = name.split('(anonymous namespace)::')[-1]
+    parts = name.split('(anonymous namespace)::')
+    n = parts[1] if len(parts) > 1 else parts[0]
     return n.split('(')[0][:48]
 
 
