@@ -37,8 +37,8 @@ OVERLAP = 0.6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--kpts', type=int, default=N_KPTS)
     ap.add_argument('--clouds', type=int, default=N_CLOUDS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -53,22 +53,22 @@ def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
     gf_sd, et_sd = cfg_nets
     threads = torch.get_num_threads()
     t = {}
-    nb = 48
+    nb = 1024
     x = scene.feats[0][:nb]
     t0 = time.perf_counter(); eq = O.gf_forward(x, gf_sd, T.Nei)['eqv']; t['gf_per_kpt'] = (time.perf_counter() - t0) / nb
-    n = 1000
+    n = 3500
     e0 = scene.feats[0][:n]; e1 = scene.feats[1][:n]
     s = np.arange(n)
     t0 = time.perf_counter(); m = O.mutual_match(e0, e1, s, s); dt = time.perf_counter() - t0
     t['mutual_per_pair'] = dt * (scene.feats[0].shape[0] / n) ** 2          # O(N^2)
-    nm = 64
+    nm = 1024
     d1 = scene.feats[1][:nm]; d0 = scene.feats[0][:nm]
     t0 = time.perf_counter(); dr = O.des2r(d1, d0, T.P); t['des2r_per_corr'] = (time.perf_counter() - t0) / nm
-    nb = 24
+    nb = 768
     batch = {'before_eqv0': scene.feats[1][:nb], 'before_eqv1': scene.feats[0][:nb], 'after_eqv0': scene.feats[1][:nb],
              'after_eqv1': scene.feats[0][:nb], 'pre_idx': dr[:nb]}
     t0 = time.perf_counter(); q = O.et_forward(batch, et_sd, T.Nei, T.P); t['et_per_corr'] = (time.perf_counter() - t0) / nb
-    M, H = 3000, 40
+    M, H = 3000, 200
     rng = np.random.default_rng(0)
     k0 = rng.uniform(0, 3, (M, 3)); k1 = rng.uniform(0, 3, (M, 3)); Tr = rng.standard_normal((H, 3, 4))
     t0 = time.perf_counter()
@@ -182,8 +182,8 @@ def main():
             per_pair = t['mutual_per_pair'] + M * (t['des2r_per_corr'] + t['et_per_corr']) + H * t['ransac_per_hyp'] * (M / 3000.0)
             sec = args.clouds * per_cloud + n_pairs * per_pair
             out['cpu_baseline'] = {'value': n_pairs / sec, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-                                   'sample': 'oracle/ref_numpy.py on this host: GF on 48 kpts, mutual on 1000x1000 (scaled N^2), Des2R on 64, '
-                                             'ET on 24 correspondences, RANSAC scoring on 40 hypotheses x 3000; scaled to the step workload',
+                                   'sample': 'oracle/ref_numpy.py on this host: GF on 1024 kpts, mutual on 3500x3500 (scaled N^2), Des2R on 1024, '
+                                             'ET on 768 correspondences, RANSAC scoring on 200 hypotheses x 3000; scaled to the step workload',
                                    'components_s': {'gf_per_cloud': per_cloud, 'per_pair': per_pair}}
         print(json.dumps(out))
     if dist is not None:
