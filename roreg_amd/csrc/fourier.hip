@@ -14,6 +14,8 @@
 //                       accumulator registers (the K order of the second product is chosen to be the C/D register
 //                       layout of the first, so no transpose is needed).
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -334,17 +336,48 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
     return 0;
 }
 
+// Work list of one layer.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness), and each XCD has a private
+// 4 MB L2: the list is built as eight per-XCD streams, each a sequence of 8 x 8 (m-tile x n-tile) blocks, interleaved so that entry
+// 8*i + k belongs to stream k.  The ~64 workgroups resident on an XCD then share 8 weight slices and 8 X tiles (minimum of
+// |X|*mts/a + |W|*nts/b under a*b = 64), instead of every XCD streaming every X tile.  Streams are balanced by (tiles x irrep dim).
 extern "C" size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host /* nullable; [n][3] */) {
     static const int dims[5] = {1, 3, 3, 4, 5};
-    size_t n = 0;
-    // larger irreps first: the long tiles are scheduled before the short ones
+    struct Block { int r, mg, ng, cost; };
+    std::vector<Block> blocks;
     for (int r = 4; r >= 0; --r) {
         const int d = dims[r];
         const int mts = round_up(d * O, 128) / 128, nts = (d * B + 255) / 256;
-        for (int nt = 0; nt < nts; ++nt)
-            for (int mt = 0; mt < mts; ++mt, ++n)
-                if (tiles_host) { tiles_host[n * 3] = r; tiles_host[n * 3 + 1] = mt; tiles_host[n * 3 + 2] = nt; }
+        for (int ng = 0; ng * 8 < nts; ++ng)
+            for (int mg = 0; mg * 8 < mts; ++mg) {
+                const int a = std::min(8, mts - mg * 8), b = std::min(8, nts - ng * 8);
+                blocks.push_back({r, mg, ng, a * b * d});
+            }
     }
+    std::stable_sort(blocks.begin(), blocks.end(), [](const Block &x, const Block &y) { return x.cost > y.cost; });
+    std::vector<std::vector<int>> stream(8);
+    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Block &bk : blocks) {
+        int k = 0;
+        for (int q = 1; q < 8; ++q)
+            if (load[q] < load[k]) k = q;
+        load[k] += bk.cost;
+        const int d = dims[bk.r];
+        const int mts = round_up(d * O, 128) / 128, nts = (d * B + 255) / 256;
+        for (int nt = bk.ng * 8; nt < std::min(nts, bk.ng * 8 + 8); ++nt)
+            for (int mt = bk.mg * 8; mt < std::min(mts, bk.mg * 8 + 8); ++mt) {
+                stream[k].push_back(bk.r); stream[k].push_back(mt); stream[k].push_back(nt);
+            }
+    }
+    size_t longest = 0;
+    for (int k = 0; k < 8; ++k) longest = std::max(longest, stream[k].size() / 3);
+    const size_t n = longest * 8;
+    if (tiles_host)
+        for (size_t i = 0; i < longest; ++i)
+            for (int k = 0; k < 8; ++k) {
+                int32_t *t = tiles_host + (i * 8 + k) * 3;
+                if (i * 3 < stream[k].size()) { t[0] = stream[k][i * 3]; t[1] = stream[k][i * 3 + 1]; t[2] = stream[k][i * 3 + 2]; }
+                else { t[0] = -1; t[1] = 0; t[2] = 0; }          // padding entry: the workgroup exits immediately
+            }
     return n;
 }
 
