@@ -162,7 +162,7 @@ class RegistrationEngine:
         return T2, best, (k0, k1, st1, st2)
 
     # ---- whole scene -----------------------------------------------------------------------------------------
-    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False):
+    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False):
         """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
         Returns [PairResult]."""
         keynum = self.cfg.keynum if keynum is None else keynum
@@ -179,18 +179,32 @@ class RegistrationEngine:
             s0, s1 = self.sample(c0, c1, keynum)
             pend.append(self.match_mutual(c0, c1, s0, s1))
         counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
-        # stage 4: all pairs
+        # stage 4: all pairs.  One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
+        # (estimator.py:423-425), and that draw depends on M alone, so the hypothesis order is drawn first (same global-RNG calls
+        # in the same order as the reference) and Des2R + ET run on the selected correspondences only.  The registration result
+        # is identical; the reference computes all M local transforms because its stages are coupled through Trans_pre files.
+        # all_local_transforms=True evaluates every correspondence like the reference does.
         T_all, best_all, aux_all = [], [], []
-        items = [(clouds[int(a)], clouds[int(b)], mbuf[:int(M)]) for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts)]
-        local = [it + lt for it, lt in zip(items, self.local_transforms_many(items))]
-        for (c0, c1, matches, dr, Trans, rows0, rows1) in local:
-            M = matches.shape[0]
-            index = np.arange(M)
+        full = [(clouds[int(a)], clouds[int(b)], mbuf[:int(M)]) for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts)]
+        hyps = []
+        for (c0, c1, matches) in full:
+            index = np.arange(matches.shape[0])
             np.random.shuffle(index)                                        # estimator.py:423-424
-            hyp = torch.from_numpy(index[0:max_iter].astype(np.int64)).cuda()
+            hyps.append(np.ascontiguousarray(index[0:max_iter], np.int64))
+        if all_local_transforms:
+            items = full
+        else:
+            items = [(c0, c1, m[torch.from_numpy(h).cuda()]) for (c0, c1, m), h in zip(full, hyps)]
+        lts = self.local_transforms_many(items)
+        local = []
+        for (c0, c1, matches), hsel, (dr, Trans, _, _) in zip(full, hyps, lts):
+            M = matches.shape[0]
+            rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
+            hyp = torch.from_numpy(hsel).cuda() if all_local_transforms else None          # Trans already in hypothesis order
             w = torch.ones(M, dtype=torch.float64, device='cuda')          # matcher.py:109: scores = ones(M)
             T2, best, aux = self.ransac(c0, c1, rows0, rows1, Trans, w, hyp)
             T_all.append(T2); best_all.append(best); aux_all.append((w,) + aux)
+            local.append((c0, c1, matches))
         T_host = torch.stack(T_all).cpu().numpy()                           # the one sync of the estimator stage
         best_host = torch.cat(best_all).cpu().numpy()
         st_host = torch.stack([torch.stack([a[3], a[4]]) for a in aux_all]).cpu().numpy()
