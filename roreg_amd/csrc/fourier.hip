@@ -164,17 +164,16 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     const int B = p.B, C = p.C;
     const int n_tiles = C * p.tiles_per_c;
 
-    // transform fragments: A1[s][tile][lane] (inverse), A2[step][tile][lane] (forward, K order = C/D register order)
-    float a1[IN_SPATIAL ? 1 : 30][2];
-    float a2[OUT_SPATIAL ? 1 : 32][2];
-    if (!IN_SPATIAL) {
-#pragma unroll
-        for (int s = 0; s < 30; ++s) { a1[s][0] = p.A1[(s * 2 + 0) * 64 + lane]; a1[s][1] = p.A1[(s * 2 + 1) * 64 + lane]; }
-    }
-    if (!OUT_SPATIAL) {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) { a2[s][0] = p.A2[(s * 2 + 0) * 64 + lane]; a2[s][1] = p.A2[(s * 2 + 1) * 64 + lane]; }
-    }
+    // transform fragments A1[s][tile][lane] (inverse) and A2[step][tile][lane] (forward, K order = C/D register order) live in LDS
+    // (31 KB per workgroup, conflict-free lane-contiguous reads): keeping them out of the register file leaves room for 4+ waves
+    // per SIMD, which this streaming kernel needs to cover its 30 scattered 128-byte row reads per tile.
+    __shared__ float sA1[IN_SPATIAL ? 64 : 30 * 2 * 64];
+    __shared__ float sA2[OUT_SPATIAL ? 64 : 32 * 2 * 64];
+    if (!IN_SPATIAL)
+        for (int i = threadIdx.x; i < 30 * 2 * 64; i += 256) sA1[i] = p.A1[i];
+    if (!OUT_SPATIAL)
+        for (int i = threadIdx.x; i < 32 * 2 * 64; i += 256) sA2[i] = p.A2[i];
+    __syncthreads();
     const bool has_add = p.Xadd != nullptr;
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
@@ -194,6 +193,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     if (!IN_SPATIAL && wave_global < n_tiles) load_coefs(wave_global, cv);
 
     for (int tile = wave_global; tile < n_tiles; tile += n_waves) {
+        asm volatile("" ::: "memory");      // keep the transform fragments in LDS: without this the compiler hoists all 62 of them into VGPRs
         const int c = tile / p.tiles_per_c;
         const int b = (tile - c * p.tiles_per_c) * 32 + jn;
         const bool valid = b < B;
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                 for (int r = 0; r < 16; ++r) v[t][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 30; ++s) {
-                v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][0], cv[s], v[0], 0, 0, 0);
-                v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][1], cv[s], v[1], 0, 0, 0);
+                v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA1[(s * 2 + 0) * 64 + lane], cv[s], v[0], 0, 0, 0);
+                v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA1[(s * 2 + 1) * 64 + lane], cv[s], v[1], 0, 0, 0);
             }
         }
         // ---- group-domain epilogue --------------------------------------------------------------------------------
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int s = t * 16 + r;
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s][0], v[t][r], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s][1], v[t][r], o[1], 0, 0, 0);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 0) * 64 + lane], v[t][r], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 1) * 64 + lane], v[t][r], o[1], 0, 0, 0);
                 }
             if (valid) {
 #pragma unroll
