@@ -177,3 +177,23 @@ def test_nms_sample_matches_reference():
     z = load_golden('nms')
     for num in [700, 600, 400, 150, 20]:
         assert np.array_equal(NMS_sample(num, 5).sample(z['keys'], z['scores']), z[f'idx_{num}'])
+
+
+def test_group_feature_assembly_with_plugin_backbone(group):
+    """N3: rotated-cloud backbone + nearest-point lookup assembles the [N,32,60] input of the path (toy backbone)."""
+    from oracle import ref_numpy as O
+    from roreg_amd.testset import assemble_group_features
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1, 1, (900, 3)); kps = pts[rng.permutation(900)[:70]] + 0.01 * rng.standard_normal((70, 3))
+    Wp = rng.standard_normal((3, 32)).astype(np.float32)
+
+    def backbone(xyz):                      # deterministic stand-in: every 3rd point, features = tanh(xyz @ W)
+        d = xyz[::3]
+        return d, np.tanh(d @ Wp).astype(np.float32)
+    got = assemble_group_features(backbone, pts, kps)
+    assert got.shape == (70, 32, 60) and got.dtype == np.float32
+    for g in [0, 7, 59]:
+        xg = (pts @ group.R[g].T).astype(np.float32); kg = (kps @ group.R[g].T).astype(np.float32)
+        d, f = backbone(xg)
+        _, idx = O.knn(d, kg, 1)
+        assert np.array_equal(got[:, :, g], f[idx])

@@ -192,3 +192,24 @@ def test_gather_table_world_size_2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o
+
+
+def test_rr_cal_benchmark_matches_reference(tmp_path):
+    """Redwood-protocol registration recall (utils/RR_cal.py) on the reference's own inputs/outputs."""
+    from types import SimpleNamespace as NS
+    from roreg_amd.utils import RR_cal
+    z = np.load(os.path.join(GOLDEN, 'rr_cal.npz'))
+    scene_dir = tmp_path / 'origin' / 'synth' / 'scene0' / 'PointCloud'
+    scene_dir.mkdir(parents=True)
+    (scene_dir / 'gt.log').write_bytes(z['gt_log'].tobytes()); (scene_dir / 'gt.info').write_bytes(z['gt_info'].tobytes())
+    cfg = NS(output_cache_fn=str(tmp_path / 'cache'), tau_3=0.2)
+    pre_dir = tmp_path / 'cache' / 'synth' / 'scene0' / 'match_128' / 'yohoo' / '1000iters'
+    pre_dir.mkdir(parents=True)
+    (pre_dir / 'pre.log').write_bytes(z['pre_log'].tobytes())
+    datasets = {'wholesetname': 'synth', 'scene0': NS(name='synth/scene0', gt_dir=str(scene_dir / 'gt.log'))}
+    rr, flags, errors = RR_cal.benchmark(cfg, datasets, 128, 1000, yoho_sign='yohoo')
+    assert abs(rr - float(z['rr'])) < 1e-12
+    assert np.array_equal(np.array(flags['synth/scene0']), z['flags'])
+    assert np.abs(np.array(errors['synth/scene0']) - z['errors']).max() < 1e-9
+    got = (tmp_path / 'cache' / 'synth' / 'Eval_results' / 'yohoo_RR' / '1000iters' / 'result.txt').read_text()
+    assert got == z['result_txt'].tobytes().decode()

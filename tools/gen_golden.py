@@ -22,7 +22,7 @@ OUT = os.path.join(REPO, 'tests', 'golden')
 sys.path.insert(0, REPO)
 
 # ---- shims (Appendix B) ---------------------------------------------------------------------------
-np.int = int; np.float = float; np.bool = bool
+np.int = int; np.float = float        # (np.bool still exists in numpy 2; overriding it breaks numpy.ma)
 for _n in ['open3d', 'nibabel', 'nibabel.quaternions', 'tensorboardX']:
     sys.modules[_n] = types.ModuleType(_n)
 sys.modules['nibabel'].quaternions = sys.modules['nibabel.quaternions']
@@ -337,6 +337,50 @@ def gen_match_ot(cfg):
     save('match_ot', **out)
 
 
+def gen_rr_cal():
+    """utils/RR_cal.benchmark on a fabricated Redwood-format scene (gt.log, gt.info, pre.log).  nibabel is not installed, so
+    nibabel.quaternions.mat2quat is served by the reference's own utils.r_eval.quaternion_from_matrix (same K-matrix method)."""
+    import utils.RR_cal as ref_rr
+    sys.modules['nibabel.quaternions'].mat2quat = lambda r: ref_reval.quaternion_from_matrix(r)
+    ref_rr.nq = sys.modules['nibabel.quaternions']
+    rng = np.random.default_rng(15)
+    root = tempfile.mkdtemp(prefix='golden_rr_')
+    try:
+        n_frag = 7
+        pairs = [(i, j) for i in range(n_frag) for j in range(i + 1, n_frag) if rng.random() < 0.7]
+        scene_dir = f'{root}/origin/synth/scene0/PointCloud'
+        os.makedirs(scene_dir)
+        T = tables()
+        gt_lines, info_lines, pre_lines = [], [], []
+        for (i, j) in pairs:
+            Rg = T.R[int(rng.integers(0, 60))]; tg = rng.uniform(-1, 1, 3)
+            G = np.eye(4); G[:3, :3] = Rg; G[:3, 3] = tg
+            gt_lines.append(f'{i}\t {j}\t {n_frag}\t\n' + ''.join('\t'.join(f'{v:.8f}' for v in G[r]) + '\n' for r in range(4)))
+            A = rng.standard_normal((6, 6)); info = A @ A.T * 50 + np.eye(6) * 200
+            info_lines.append(f'{i}\t{j}\t{n_frag}\n' + ''.join('\t'.join(f'{v:.6f}' for v in info[r]) + '\n' for r in range(6)))
+            # estimate: GT perturbed (small for most pairs, large for some)
+            big = rng.random() < 0.3
+            ax = rng.standard_normal(3); ax /= np.linalg.norm(ax); ang = (0.5 if big else 0.01) * rng.standard_normal()
+            Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            dR = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+            E = np.eye(4); E[:3, :3] = dR @ Rg; E[:3, 3] = tg + (0.5 if big else 0.01) * rng.standard_normal(3)
+            pre_lines.append(f'{i}\t{j}\t{n_frag}\n' + ''.join(f'{E[r][0]}\t{E[r][1]}\t{E[r][2]}\t{E[r][3]}\n' for r in range(3)) + '0.0\t0.0\t0.0\t1.0\n')
+        gt_txt = ''.join(gt_lines); info_txt = ''.join(info_lines); pre_txt = ''.join(pre_lines)
+        open(f'{scene_dir}/gt.log', 'w').write(gt_txt); open(f'{scene_dir}/gt.info', 'w').write(info_txt)
+        cfg = NS(output_cache_fn=f'{root}/cache', tau_3=0.2)
+        pre_dir = f'{cfg.output_cache_fn}/synth/scene0/match_128/yohoo/1000iters'
+        os.makedirs(pre_dir); open(f'{pre_dir}/pre.log', 'w').write(pre_txt)
+        ds = NS(name='synth/scene0', gt_dir=f'{scene_dir}/gt.log')
+        datasets = {'wholesetname': 'synth', 'scene0': ds}
+        rr, flags, errors = ref_rr.benchmark(cfg, datasets, 128, 1000, yoho_sign='yohoo')
+        result_txt = open(f'{cfg.output_cache_fn}/synth/Eval_results/yohoo_RR/1000iters/result.txt').read()
+        save('rr_cal', gt_log=np.frombuffer(gt_txt.encode(), np.uint8), gt_info=np.frombuffer(info_txt.encode(), np.uint8),
+             pre_log=np.frombuffer(pre_txt.encode(), np.uint8), rr=np.float64(rr), flags=np.array(flags['synth/scene0']),
+             errors=np.array(errors['synth/scene0']), result_txt=np.frombuffer(result_txt.encode(), np.uint8))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     root = tempfile.mkdtemp(prefix='golden_cfg_')
     try:
@@ -351,6 +395,7 @@ def main():
         print('ransac'); gen_ransac(cfg)
         print('quat'); gen_quat()
         print('match_ot'); gen_match_ot(cfg)
+        print('rr_cal'); gen_rr_cal()
     finally:
         shutil.rmtree(root, ignore_errors=True)
     print('pipelines')
