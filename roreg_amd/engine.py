@@ -24,6 +24,7 @@ class CloudState:
     inv: torch.Tensor = None        # matcher invariant descriptor [N,32]
     keys: torch.Tensor = None       # keypoints [N,3] f64 (device)
     det: np.ndarray = None          # detector rank scores (host, as det_score/*.npy)
+    keys_host: np.ndarray = None    # keypoints on the host (NMS sampling runs numpy selections like the reference)
 
 
 @dataclass
@@ -38,12 +39,12 @@ class PairResult:
 
 
 class RegistrationEngine:
-    def __init__(self, cfg, gf_net, et_net, rd_net=None, sampler=None):
+    def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None):
         self.cfg = cfg
         self.gf = gf_net
         self.et = et_net
-        self.rd = rd_net
-        self.sampler = sampler
+        self.rd = rd_net            # detector_eqv_test (needed when cfg.RD)
+        self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
 
     # ---- per cloud ---------------------------------------------------------------------------------------
@@ -75,7 +76,8 @@ class RegistrationEngine:
                 n = xs[q].shape[0]
                 k = keys_list[q]
                 k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
-                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], inv=inv[o:o + n], keys=k.to('cuda', torch.float64).contiguous()))
+                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], inv=inv[o:o + n], keys=k.to('cuda', torch.float64).contiguous(),
+                                      keys_host=k.cpu().numpy() if self.cfg.RD else None))
                 o += n
             i = j
         return out
@@ -94,13 +96,31 @@ class RegistrationEngine:
         """Keypoint sampling; consumes the global numpy RNG exactly like test/matcher.py:75-88."""
         n0, n1 = c0.before.shape[0], c1.before.shape[0]
         if self.cfg.RD:
-            s0 = self.sampler(c0, keynum)
-            s1 = self.sampler(c1, keynum)
+            from .test.matcher import NMS_sample
+            sampler = NMS_sample(keynum, 5)
+            s0 = sampler.sample(c0.keys_host, c0.det)
+            s1 = sampler.sample(c1.keys_host, c1.det)
         else:
             s0 = np.arange(n0); s1 = np.arange(n1)
             np.random.shuffle(s0); np.random.shuffle(s1)
             s0 = s0[0:keynum]; s1 = s1[0:keynum]
         return s0, s1
+
+    def match_rm(self, c0, c1, s0, s1):
+        """Rotation-coherence matcher on the sampled keypoints (test/matcher.py:187-206) -> (matches [M,2] int64 device in cloud
+        coordinates, scores float32 host).  The batch carries cloud 1 as feats0/keys0 and cloud 0 as feats1/keys1."""
+        d0 = torch.from_numpy(np.ascontiguousarray(s0, np.int64)).cuda()
+        d1 = torch.from_numpy(np.ascontiguousarray(s1, np.int64)).cuda()
+        batch = {'feats0': c1.eqv[d1][None], 'feats1': c0.eqv[d0][None],
+                 'keys0': c1.keys[d1].float()[None], 'keys1': c0.keys[d0].float()[None]}
+        with torch.no_grad():
+            r = self.rm(batch)
+        m0 = r['matches0'][0]
+        valid = torch.nonzero(m0 >= 0)[:, 0]
+        if valid.shape[0] < 3:                       # the reference crashes here; same documented divergence as test/matcher.py
+            return torch.ones((1, 2), dtype=torch.int64, device='cuda'), np.ones(1, np.float32)
+        matches = torch.stack([d0[m0[valid]], d1[valid]], 1).contiguous()
+        return matches, r['matching_scores0'][0][valid].cpu().numpy()
 
     def match_mutual(self, c0, c1, s0, s1):
         """-> (match buffer [m,2] int64 device, count int32[1] device); test/matcher.py:90-107."""
@@ -173,35 +193,52 @@ class RegistrationEngine:
             for i in used:
                 self.detect(clouds[i])
         # stage 3: all pairs
-        pend = []
-        for a, b in pair_ids:
-            c0, c1 = clouds[int(a)], clouds[int(b)]
-            s0, s1 = self.sample(c0, c1, keynum)
-            pend.append(self.match_mutual(c0, c1, s0, s1))
-        counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
+        full, all_scores = [], []
+        if self.cfg.RM:
+            for a, b in pair_ids:
+                c0, c1 = clouds[int(a)], clouds[int(b)]
+                s0, s1 = self.sample(c0, c1, keynum)
+                m, sc = self.match_rm(c0, c1, s0, s1)
+                full.append((c0, c1, m)); all_scores.append(sc)
+            counts = np.array([m.shape[0] for _, _, m in full])
+        else:
+            pend = []
+            for a, b in pair_ids:
+                c0, c1 = clouds[int(a)], clouds[int(b)]
+                s0, s1 = self.sample(c0, c1, keynum)
+                pend.append(self.match_mutual(c0, c1, s0, s1))
+            counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
+            full = [(clouds[int(a)], clouds[int(b)], mbuf[:int(M)]) for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts)]
+            all_scores = [None] * len(full)
         # stage 4: all pairs.  One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
-        # (estimator.py:423-425), and that draw depends on M alone, so the hypothesis order is drawn first (same global-RNG calls
-        # in the same order as the reference) and Des2R + ET run on the selected correspondences only.  The registration result
-        # is identical; the reference computes all M local transforms because its stages are coupled through Trans_pre files.
-        # all_local_transforms=True evaluates every correspondence like the reference does.
+        # (estimator.py:423-425), and that draw depends on M (and, with --RM, on the scores) alone, so the hypothesis order is drawn
+        # first (same global-RNG calls in the same order as the reference) and Des2R + ET run on the selected correspondences only.
+        # The registration result is identical; the reference computes all M local transforms because its stages are coupled through
+        # Trans_pre files.  all_local_transforms=True evaluates every correspondence like the reference does.
         T_all, best_all, aux_all = [], [], []
-        full = [(clouds[int(a)], clouds[int(b)], mbuf[:int(M)]) for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts)]
         hyps = []
-        for (c0, c1, matches) in full:
-            index = np.arange(matches.shape[0])
+        for (c0, c1, matches), sc in zip(full, all_scores):
+            rows = np.arange(matches.shape[0])
+            if self.cfg.RM:                                                 # hypotheses only from the best-scored matches (:415-421)
+                num = max(sc.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
+                rows = np.argsort(sc)[-int(num):]
+            index = np.arange(rows.shape[0])
             np.random.shuffle(index)                                        # estimator.py:423-424
-            hyps.append(np.ascontiguousarray(index[0:max_iter], np.int64))
+            hyps.append(np.ascontiguousarray(rows[index[0:max_iter]], np.int64))
         if all_local_transforms:
             items = full
         else:
             items = [(c0, c1, m[torch.from_numpy(h).cuda()]) for (c0, c1, m), h in zip(full, hyps)]
         lts = self.local_transforms_many(items)
         local = []
-        for (c0, c1, matches), hsel, (dr, Trans, _, _) in zip(full, hyps, lts):
+        for (c0, c1, matches), hsel, sc, (dr, Trans, _, _) in zip(full, hyps, all_scores, lts):
             M = matches.shape[0]
             rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
             hyp = torch.from_numpy(hsel).cuda() if all_local_transforms else None          # Trans already in hypothesis order
-            w = torch.ones(M, dtype=torch.float64, device='cuda')          # matcher.py:109: scores = ones(M)
+            if sc is None:
+                w = torch.ones(M, dtype=torch.float64, device='cuda')      # matcher.py:109: scores = ones(M)
+            else:
+                w = torch.from_numpy(sc.astype(np.float64)).cuda()
             T2, best, aux = self.ransac(c0, c1, rows0, rows1, Trans, w, hyp)
             T_all.append(T2); best_all.append(best); aux_all.append((w,) + aux)
             local.append((c0, c1, matches))
@@ -220,6 +257,6 @@ class RegistrationEngine:
                 T_host[i] = _kabsch_host(st)
         out = []
         for i, (a, b) in enumerate(pair_ids):
-            out.append(PairResult(a, b, int(counts[i]), T_host[i], int(best_host[i]),
-                                  matches=local[i][2] if keep_matches else None))
+            out.append(PairResult(a, b, int(counts[i]), T_host[i], max(int(best_host[i]), 0),
+                                  matches=local[i][2] if keep_matches else None, scores=all_scores[i]))
         return out

@@ -197,3 +197,33 @@ def test_group_feature_assembly_with_plugin_backbone(group):
         d, f = backbone(xg)
         _, idx = O.knn(d, kg, 1)
         assert np.array_equal(got[:, :, g], f[idx])
+
+
+def test_engine_rd_rm_equals_file_coupled_stages(tmp_path):
+    """--RD --RM --ET yohoo: the device-resident engine against the file-coupled stage classes on one RNG stream."""
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    from roreg_amd.test import name2extractor, name2detector, name2matcher, name2estimator
+    z = load_golden('pipeline_rd_rm_yohoo')
+    cfg, ds = _setup(tmp_path, z, RD=True, RM=True, ET='yohoo')
+    keynum = int(z['keynum'])
+    np.random.seed(5)
+    name2extractor['yoho_des'](cfg).run(ds)
+    name2detector['yoho_det'](cfg).run(ds)
+    name2matcher['yoho_mat'](cfg).run(ds, keynum)
+    name2estimator['yohoo'](cfg).run(ds, keynum, 1000)
+    md = f'{cfg.output_cache_fn}/{ds.name}/match_{keynum}'
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    rd = name2network['RD_test'](cfg); rd.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()})
+    rm = name2network['RM_test'](cfg); rm.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RM').items()})
+    eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
+    np.random.seed(5)
+    res = eng.run_scene(ds.feats, [ds.get_kps(i) for i in ds.pc_ids], ds.pair_ids, keynum=keynum, max_iter=1000, keep_matches=True)
+    for r in res:
+        want = np.load(f'{md}/yohoo/1000iters/{r.id0}-{r.id1}.npz')
+        assert np.array_equal(r.matches.cpu().numpy(), np.load(f'{md}/{r.id0}-{r.id1}.npy'))
+        assert np.array_equal(r.scores, np.load(f'{md}/scores/{r.id0}-{r.id1}.npy'))
+        assert r.recalltime == int(want['recalltime'])
+        if np.isfinite(want['trans']).all():
+            assert np.abs(r.trans - want['trans']).max() < 1e-10
