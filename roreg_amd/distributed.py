@@ -8,7 +8,7 @@ fixed-width float64 result table [pairs, 20] (= backend 'nccl', i.e. RCCL over x
 import numpy as np
 import torch
 
-ROW = 20     # scene, id0, id1, n_match, recalltime, trans[16] (row-major -> 15 used + 1 pad)
+ROW = 21     # scene, id0, id1, n_match, recalltime, trans[0:15] (row-major 4x4 without the final 1), inlier ratio
 
 
 def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=4.0, tolerance=1.10):
@@ -62,6 +62,7 @@ def pack_rows(scene_index, results):
     for i, r in enumerate(results):
         t[i, 0] = scene_index; t[i, 1] = float(r.id0); t[i, 2] = float(r.id1); t[i, 3] = r.n_match; t[i, 4] = r.recalltime
         t[i, 5:20] = np.asarray(r.trans, np.float64).reshape(-1)[:15]
+        t[i, 20] = getattr(r, 'ir', np.nan)
     return t
 
 
@@ -70,7 +71,7 @@ def unpack_rows(table):
     for row in table:
         T = np.eye(4); T.reshape(-1)[:15] = row[5:20]
         out.append({'scene': int(row[0]), 'id0': str(int(row[1])), 'id1': str(int(row[2])), 'n_match': int(row[3]),
-                    'recalltime': int(row[4]), 'trans': T})
+                    'recalltime': int(row[4]), 'trans': T, 'ir': float(row[20])})
     return out
 
 

@@ -1,0 +1,142 @@
+"""Multi-GPU evaluation driver: one process per GPU, scan pairs sharded by scene, ONE gather of the result table.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m roreg_amd.run_distributed \
+           --testset 3dmatch --ET yohoo --keynum 5000 [--RD] [--RM] [--seed 0]
+
+Every rank builds the same shard plan (roreg_amd.distributed.shard_scenes), extracts only the clouds its pair ranges touch,
+registers its pairs with the device-resident engine, computes the per-pair inlier ratio locally, and contributes fixed-width
+float64 rows to one all_gather (backend nccl = RCCL over xGMI).  Rank 0 then writes the reference's result files
+({ET}/{iters}iters/*.npz, pre.log) and computes FMR / IR / RR(pointdsc) / RR(predator) like test/evaluator.py:103-145.
+With --seed the global numpy RNG is re-seeded per pair range, so results do not depend on the number of ranks."""
+import os
+import zlib
+
+import numpy as np
+import torch
+
+from . import distributed as D
+from .utils import RR_cal
+from .utils.r_eval import compute_R_diff
+from .utils.utils import make_non_exists_dir, transform_points, load_checkpoint
+
+
+def build_engine(cfg):
+    from .engine import RegistrationEngine
+    from .network import name2network
+
+    def load(kind, sub, strict=True):
+        net = name2network[kind](cfg)
+        fn = f'{cfg.model_fn}/{sub}/model_best.pth'
+        if not os.path.exists(fn):
+            raise ValueError("No model exists")
+        net.load_state_dict(load_checkpoint(fn)['network_state_dict'], strict=strict)
+        return net.eval()
+    gf = load('GF_test', 'GF'); et = load('ET_test', 'ET', strict=False)
+    rd = load('RD_test', 'RD') if cfg.RD else None
+    rm = load('RM_test', 'RM') if cfg.RM else None
+    return RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
+
+
+def _feature_dir(cfg, dataset):
+    name = f'3d{dataset.name[4:]}' if dataset.name[0:4] == '3dLo' else dataset.name
+    return f'{cfg.output_cache_fn}/{name}/{cfg.backbone}_Input_Group_feature'
+
+
+def evaluate(cfg, datasets, engine, rank=0, world=1, seed=None):
+    scenes = [s for s in datasets if s not in ('wholesetname', 'valscenes')]
+    pair_counts = {s: len(datasets[s].pair_ids) for s in scenes}
+    cloud_counts = {s: len(datasets[s].pc_ids) for s in scenes}
+    plan = D.shard_scenes(pair_counts, world, cloud_counts)
+    rows = []
+    for scene, a, b in plan[rank]:
+        ds = datasets[scene]
+        pairs = ds.pair_ids[a:b]
+        if seed is not None:
+            np.random.seed((int(seed) + zlib.crc32(f'{scene}:{a}'.encode())) % (2 ** 32))
+        used = sorted({int(i) for p in pairs for i in p})
+        fdir = _feature_dir(cfg, ds)
+        feats = {i: np.load(f'{fdir}/{i}.npy') for i in used}
+        keys = {i: ds.get_kps(str(i)) for i in used}
+        res = engine.run_scene(feats, keys, pairs, keynum=cfg.keynum, max_iter=cfg.max_iter, keep_matches=True)
+        for r in res:                                    # inlier ratio of the (top-scored) correspondences, evaluator.py:50-81
+            corr = r.matches.cpu().numpy()
+            if cfg.RM:
+                num = max(r.scores.shape[0] * cfg.match_n, 10) if cfg.match_n < 0.999 else cfg.match_n
+                corr = corr[np.argsort(r.scores)[-int(num):]]
+            gt = ds.get_transform(r.id0, r.id1)
+            k0 = keys[int(r.id0)][corr[:, 0]]; k1 = transform_points(keys[int(r.id1)][corr[:, 1]], gt)
+            r.ir = float(np.mean(np.sqrt(np.sum(np.square(k0 - k1), axis=-1)) < cfg.tau_2))
+        rows.append(D.pack_rows(scenes.index(scene), res))
+    table = D.gather_table(np.concatenate(rows, 0) if rows else np.zeros((0, D.ROW)))
+    if rank != 0:
+        return None
+    by_scene = {s: {} for s in scenes}
+    for row in D.unpack_rows(table):
+        by_scene[scenes[row['scene']]][(row['id0'], row['id1'])] = row
+    fmrs, irs, rrs, rres, rtes = [], [], [], [], []
+    for s in scenes:
+        ds = datasets[s]
+        save_dir = f'{cfg.output_cache_fn}/{ds.name}/match_{cfg.keynum}/{cfg.ET}/{cfg.max_iter}iters'
+        make_non_exists_dir(save_dir)
+        ir_s, ok_s, re_s, te_s = [], [], [], []
+        with open(f'{save_dir}/pre.log', 'w') as w:
+            for (a, b) in ds.pair_ids:
+                row = by_scene[s][(a, b)]
+                T = row['trans']
+                np.savez(f'{save_dir}/{a}-{b}.npz', trans=T, recalltime=row['recalltime'])
+                w.write(f'{int(a)}\t{int(b)}\t{len(ds.pc_ids)}\n')
+                for r in range(3):
+                    w.write(f'{T[r][0]}\t{T[r][1]}\t{T[r][2]}\t{T[r][3]}\n')
+                w.write(f'{0.0}\t{0.0}\t{0.0}\t{1.0}\n')
+                gt = ds.get_transform(a, b)
+                ir_s.append(row['ir'])
+                rd = compute_R_diff(T[0:3, 0:3], gt[0:3, 0:3]); td = np.sqrt(np.sum(np.square(T[0:3, -1] - gt[0:3, -1])))
+                good = bool(rd < 15 and td < 0.3)
+                ok_s.append(1 if good else 0)
+                if good:
+                    re_s.append(rd); te_s.append(td)
+        fmrs.append(np.mean([1 if i > cfg.tau_1 else 0 for i in ir_s])); irs.append(np.mean(ir_s))
+        rrs.append(np.mean(ok_s)); rres.append(np.mean(re_s) if re_s else np.nan); rtes.append(np.mean(te_s) if te_s else np.nan)
+    out = {'fmr': float(np.mean(fmrs)), 'ir': float(np.mean(irs)), 'rr': float(np.mean(rrs)), 'rre': float(np.mean(rres)),
+           'rte': float(np.mean(rtes)), 'pairs': int(table.shape[0])}
+    if datasets['wholesetname'] == 'demo' or not all(os.path.exists(datasets[s].gt_dir[:datasets[s].gt_dir.rfind('.')] + '.info') for s in scenes):
+        out['rr_predator'] = 1.0 if datasets['wholesetname'] == 'demo' else float('nan')
+    else:
+        out['rr_predator'] = float(RR_cal.benchmark(cfg, datasets, cfg.keynum, cfg.max_iter, yoho_sign=cfg.ET)[0])
+    msg = f"{datasets['wholesetname']}-{cfg.GF}-{'yoho_det' if cfg.RD else 'nodet'}-{'yoho_mat' if cfg.RM else 'matmul'}-{cfg.ET}-{cfg.keynum}keys-{cfg.max_iter}iters\n"
+    msg += f"feature matching recall          : {out['fmr']:.5f}\n" \
+           f"inlier ratio                     : {out['ir']:.5f}\n" \
+           f"registration recall(predator)    : {out['rr_predator']:.5f}\n" \
+           f"rotation error(pointdsc)         : {out['rre']:.5f}\n" \
+           f"translation error(pointdsc)      : {out['rte']:.5f}\n" \
+           f"registration recall(pointdsc)    : {out['rr']:.5f}"
+    make_non_exists_dir(cfg.base_dir)
+    with open(f'{cfg.base_dir}/results.log', 'a') as f:
+        f.write(msg + '\n')
+    print(msg)
+    return out
+
+
+def main():
+    from .parses.parses_test import build_parser
+    from .dataops.dataset import get_dataset_name
+    parser = build_parser()
+    parser.add_argument('--seed', type=int, default=None, help='re-seed the global RNG per pair range (rank-count independent results)')
+    cfg, _ = parser.parse_known_args()
+    if cfg.ET != 'yohoo':
+        raise SystemExit('the device-resident engine implements the yohoo estimator; use the stage classes (Test.py) for yohoc')
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    datasets = get_dataset_name(cfg.testset, cfg.origin_data_dir)
+    evaluate(cfg, datasets, build_engine(cfg), rank, world, cfg.seed)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

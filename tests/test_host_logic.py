@@ -170,7 +170,7 @@ mine = shard_scenes(counts, world)[rank]
 rows = []
 for scene, a, b in mine:
     for i in range(a, b):
-        r = np.zeros(ROW); r[0] = int(scene[1:]); r[1] = i; r[2] = i + 1; r[3] = 100 + i; r[5:20] = np.arange(15) + rank
+        r = np.zeros(ROW); r[0] = int(scene[1:]); r[1] = i; r[2] = i + 1; r[3] = 100 + i; r[5:20] = np.arange(15) + rank; r[20] = 0.5
         rows.append(r)
 table = gather_table(np.array(rows).reshape(-1, ROW))
 assert table.shape == (15, ROW), table.shape
