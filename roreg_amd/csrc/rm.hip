@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 template <int CIN, int COUT, bool NORM, bool ACCUM>
 __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int L, const float *__restrict__ W,
                                                      const float *__restrict__ b, const float *__restrict__ mean_rstd,
-                                                     float *__restrict__ y) {
+                                                     float *__restrict__ y, int ochunk) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int pp = p < L ? p : L - 1;
     float xi[CIN];
@@ -95,13 +95,22 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
     }
     if (p >= L) return;
     float *yo = y + (size_t)p * COUT;
+    // blockIdx.y selects a chunk of output channels: with few positions (m = 5000 points) the output channels supply the
+    // parallelism that positions alone cannot (78 waves would leave 90 % of the chip idle)
+    const int o0 = blockIdx.y * ochunk, o1 = min(o0 + ochunk, COUT);
 #pragma unroll 2
-    for (int o = 0; o < COUT; ++o) {
+    for (int o = o0; o < o1; ++o) {
         float acc = b[o];
 #pragma unroll
         for (int c = 0; c < CIN; ++c) acc = fmaf(xi[c], W[o * CIN + c], acc);
         yo[o] = ACCUM ? yo[o] + acc : acc;
     }
+}
+
+inline int linear_ochunk(int L, int Cout) {
+    int chunk = Cout;
+    while (chunk > 4 && (long long)L * (Cout / chunk) < 65536) chunk /= 2;
+    return chunk;
 }
 
 // InstanceNorm statistics: per channel over all L positions (biased variance), accumulated in fp64, two stages,
@@ -454,10 +463,11 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
-    const dim3 g((L + 255) / 256), t(256);
-#define RM_LIN(CI, CO)                                                                                  \
-    if (Cin == CI && Cout == CO) {                                                                       \
-        hipLaunchKernelGGL((linear_kernel<CI, CO, false, false>), g, t, 0, s, x, L, W, b, nullptr, y);  \
+    const int oc = linear_ochunk(L, Cout);
+    const dim3 g((L + 255) / 256, (Cout + oc - 1) / oc), t(256);
+#define RM_LIN(CI, CO)                                                                                      \
+    if (Cin == CI && Cout == CO) {                                                                           \
+        hipLaunchKernelGGL((linear_kernel<CI, CO, false, false>), g, t, 0, s, x, L, W, b, nullptr, y, oc);  \
         ROREG_CHECK_LAUNCH("roreg_linear");                                                              \
         return 0;                                                                                        \
     }
@@ -485,9 +495,10 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
                               void *stream) {
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
-    const dim3 g((L + 255) / 256), t(256);
-    if (Cmid == 64) hipLaunchKernelGGL((linear_kernel<64, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y);
-    else if (Cmid == 128) hipLaunchKernelGGL((linear_kernel<128, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y);
+    const int oc = linear_ochunk(L, 32);
+    const dim3 g((L + 255) / 256, (32 + oc - 1) / oc), t(256);
+    if (Cmid == 64) hipLaunchKernelGGL((linear_kernel<64, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc);
+    else if (Cmid == 128) hipLaunchKernelGGL((linear_kernel<128, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc);
     else { roreg::set_error("roreg_mlp_tail: unsupported width %d", Cmid); return 2; }
     ROREG_CHECK_LAUNCH("roreg_mlp_tail");
     return 0;
