@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void mean_g_kernel(const float *__restrict__ e
 // dustbin row/column = alpha.  One thread per column (its descriptor in registers), rows arrive through the scalar path, so
 // every store is coalesced; called twice (Z0 and its transpose) instead of transposing through memory.
 __global__ __launch_bounds__(256) void ot_build_kernel(const float *__restrict__ rowvec, int R, const float *__restrict__ colvec, int C,
-                                                       float alpha, int rows_per_block, float *__restrict__ M) {
+                                                       float alpha, int rows_per_block, float *__restrict__ M, int ld) {
     const int c = blockIdx.x * 256 + threadIdx.x;          // column in [0, C]  (C = dustbin)
     const int cc = c < C ? c : C - 1;
     float t[RM_F];
@@ -335,22 +335,28 @@ __global__ __launch_bounds__(256) void ot_build_kernel(const float *__restrict__
             for (int f = 0; f < RM_F; ++f) acc = fmaf(a[f], t[f], acc);
             v = acc;
         }
-        M[(size_t)r * (C + 1) + c] = v;
+        M[(size_t)r * ld + c] = v;
     }
 }
 
 // out[i] = log_a(i) - LSE_j(Z[i,j] + vec[j]);  log_a = normc for i < R-1, last_extra + normc for the dustbin row
-__global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ Z, int R, int C, const float *__restrict__ vec, float normc,
-                                                      float last_extra, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ Z, int R, int C, int ld, const float *__restrict__ vec,
+                                                      float normc, float last_extra, float *__restrict__ out) {
     __shared__ float smx[4], ssum[4];
     const int i = blockIdx.x;
-    const float *row = Z + (size_t)i * C;
+    const float *row = Z + (size_t)i * ld;          // ld is a multiple of 4: rows are 16-byte aligned
     float mx = -__builtin_inff(), s = 0.f;
-    for (int j = threadIdx.x; j < C; j += 256) {
-        const float x = row[j] + vec[j];
+    auto upd = [&](float x) {
         if (x > mx) { s = s * __expf(mx - x) + 1.0f; mx = x; }
         else s += __expf(x - mx);
+    };
+    const int C4 = C & ~3;
+    for (int j = threadIdx.x * 4; j < C4; j += 1024) {
+        const float4 z = *reinterpret_cast<const float4 *>(row + j);
+        const float4 v = *reinterpret_cast<const float4 *>(vec + j);
+        upd(z.x + v.x); upd(z.y + v.y); upd(z.z + v.z); upd(z.w + v.w);
     }
+    if ((int)threadIdx.x < C - C4) upd(row[C4 + threadIdx.x] + vec[C4 + threadIdx.x]);
     // combine (mx, s) pairs: wave butterfly then across the 4 waves
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -370,24 +376,24 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void ot_final_kernel(const float *__restrict__ Z0, int m, int n, const float *__restrict__ u,
+__global__ __launch_bounds__(256) void ot_final_kernel(const float *__restrict__ Z0, int ld, int m, int n, const float *__restrict__ u,
                                                        const float *__restrict__ v, float normc, float *__restrict__ Z) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tot = (size_t)(m + 1) * (n + 1);
     if (i >= tot) return;
     const int r = (int)(i / (n + 1)), c = (int)(i - (size_t)r * (n + 1));
-    Z[i] = Z0[i] + u[r] + v[c] - normc;
+    Z[i] = Z0[(size_t)r * ld + c] + u[r] + v[c] - normc;
 }
 
 // arg-max over the first C-1 columns of rows 0..R-2 of (Z0[i,j] + vec[j]) (+ rowc[i] - normc for the value)
 template <bool ROWC_FIRST>
-__global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ Z, int R, int C, const float *__restrict__ vec,
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ Z, int R, int C, int ld, const float *__restrict__ vec,
                                                          const float *__restrict__ rowc, float normc, int64_t *__restrict__ idx,
                                                          float *__restrict__ val) {
     __shared__ float sv[256];
     __shared__ int si[256];
     const int i = blockIdx.x;            // < R-1
-    const float *row = Z + (size_t)i * C;
+    const float *row = Z + (size_t)i * ld;
     float bv = -__builtin_inff();
     int bi = 0x7fffffff;
     for (int j = threadIdx.x; j < C - 1; j += 256) {
@@ -550,11 +556,14 @@ extern "C" int roreg_sinkhorn(const float *src_final, int m, const float *tgt_fi
                               void *stream) {
     ROREG_REQUIRE(src_final && tgt_final && Z_out && ws && m > 0 && n > 0 && iters >= 0, "roreg_sinkhorn: bad arguments");
     const size_t tot = (size_t)(m + 1) * (n + 1);
-    const size_t need = 2 * tot + 4 * (size_t)(m + n + 2);      // Z0, Z0^T, u, v, row/col max values + indices
+    const int ldz = (n + 1 + 3) & ~3, ldt = (m + 1 + 3) & ~3;             // padded row pitches: 16-byte aligned rows for float4 streaming
+    const size_t sz0 = (size_t)(m + 1) * ldz, szt = (size_t)(n + 1) * ldt;
+    const int up = (m + 1 + 3) & ~3, vp = (n + 1 + 3) & ~3;
+    const size_t need = sz0 + szt + up + vp + (size_t)(m + n) + 2 * (size_t)(m + n) + 8;      // Z0, Z0^T, u, v, row/col max values + indices
     ROREG_REQUIRE(ws_floats >= need, "roreg_sinkhorn: workspace of %zu floats needed (got %zu)", need, ws_floats);
     hipStream_t s = roreg::as_stream(stream);
-    float *Z0 = ws, *Z0T = ws + tot, *u = Z0T + tot, *v = u + (m + 1);
-    float *val0 = v + (n + 1), *val1 = val0 + m;
+    float *Z0 = ws, *Z0T = ws + sz0, *u = Z0T + szt, *v = u + up;
+    float *val0 = v + vp, *val1 = val0 + m;
     const size_t off = ((reinterpret_cast<uintptr_t>(val1 + n) + 7) & ~(uintptr_t)7) - reinterpret_cast<uintptr_t>(ws);
     int64_t *i0 = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + off);
     int64_t *i1 = i0 + m;
@@ -564,22 +573,22 @@ extern "C" int roreg_sinkhorn(const float *src_final, int m, const float *tgt_fi
     {
         const int rpb = 32;
         hipLaunchKernelGGL(ot_build_kernel, dim3((n + 1 + 255) / 256, (m + 1 + rpb - 1) / rpb), dim3(256), 0, s, src_final, m, tgt_final, n,
-                           alpha, rpb, Z0);
+                           alpha, rpb, Z0, ldz);
         hipLaunchKernelGGL(ot_build_kernel, dim3((m + 1 + 255) / 256, (n + 1 + rpb - 1) / rpb), dim3(256), 0, s, tgt_final, n, src_final, m,
-                           alpha, rpb, Z0T);
+                           alpha, rpb, Z0T, ldt);
     }
-    (void)hipMemsetAsync(u, 0, sizeof(float) * (m + 1), s);
-    (void)hipMemsetAsync(v, 0, sizeof(float) * (n + 1), s);
+    (void)hipMemsetAsync(u, 0, sizeof(float) * up, s);
+    (void)hipMemsetAsync(v, 0, sizeof(float) * vp, s);
     const float ln_n = logf((float)n), ln_m = logf((float)m);
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(row_lse_kernel, dim3(m + 1), dim3(256), 0, s, Z0, m + 1, n + 1, v, normc, ln_n, u);
-        hipLaunchKernelGGL(row_lse_kernel, dim3(n + 1), dim3(256), 0, s, Z0T, n + 1, m + 1, u, normc, ln_m, v);
+        hipLaunchKernelGGL(row_lse_kernel, dim3(m + 1), dim3(256), 0, s, Z0, m + 1, n + 1, ldz, v, normc, ln_n, u);
+        hipLaunchKernelGGL(row_lse_kernel, dim3(n + 1), dim3(256), 0, s, Z0T, n + 1, m + 1, ldt, u, normc, ln_m, v);
     }
-    hipLaunchKernelGGL(ot_final_kernel, dim3(gb), dim3(256), 0, s, Z0, m, n, u, v, normc, Z_out);
+    hipLaunchKernelGGL(ot_final_kernel, dim3(gb), dim3(256), 0, s, Z0, ldz, m, n, u, v, normc, Z_out);
     if (matches0) {
         ROREG_REQUIRE(matches1 && mscores0 && mscores1, "roreg_sinkhorn: all four readout outputs are needed");
-        hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(m), dim3(256), 0, s, Z0, m + 1, n + 1, v, u, normc, i0, val0);
-        hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(n), dim3(256), 0, s, Z0T, n + 1, m + 1, u, v, normc, i1, val1);
+        hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(m), dim3(256), 0, s, Z0, m + 1, n + 1, ldz, v, u, normc, i0, val0);
+        hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(n), dim3(256), 0, s, Z0T, n + 1, m + 1, ldt, u, v, normc, i1, val1);
         const int mx = m > n ? m : n;
         hipLaunchKernelGGL(ot_readout_kernel, dim3((mx + 255) / 256), dim3(256), 0, s, i0, val0, m, i1, n, matches0, matches1, mscores0, mscores1);
     }
@@ -588,5 +597,5 @@ extern "C" int roreg_sinkhorn(const float *src_final, int m, const float *tgt_fi
 }
 
 extern "C" size_t roreg_sinkhorn_workspace_size(int m, int n) {
-    return 2 * (size_t)(m + 1) * (n + 1) + 4 * (size_t)(m + n + 2) + 2 * (size_t)(m + n) + 16;
+    return (size_t)(m + 1) * ((n + 4) & ~3) + (size_t)(n + 1) * ((m + 4) & ~3) + 5 * (size_t)(m + n + 8) + 32;
 }
