@@ -263,3 +263,59 @@ def test_distributed_driver_equals_evaluator(tmp_path):
     for (s, a, b), T in got_files.items():
         want = np.load(f'{cfg.output_cache_fn}/{datasets[s].name}/match_{cfg.keynum}/yohoo/1000iters/{a}-{b}.npz')['trans']
         assert np.abs(T - want).max() < 1e-10
+
+
+def test_dropin_end_to_end_on_a_demo_layout(tmp_path, monkeypatch):
+    """The reference's entry point flow (parse flags -> yoho_evaluator(cfg).run()) through the drop-in aliases, on a dataset laid out
+    like data/origin_data/demo/kitchen (binary PLY clouds, keypoint index files, gt.log) with checkpoints under --model_fn."""
+    import sys
+    from roreg_amd import dropin
+    from roreg_amd.network import name2network
+    z = load_golden('pipeline_mutual_yohoo')
+    root = str(tmp_path)
+    scene = synth.make_scene(31, n_clouds=2, n_kpts=160, overlap=0.7, name='demo/kitchen')
+    base = f'{root}/data/origin_data/demo/kitchen'
+    os.makedirs(f'{base}/PointCloud'); os.makedirs(f'{base}/Keypoints')
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        kps = scene.get_kps(str(i)).astype(np.float32)
+        extra = rng.uniform(0, 3, (300, 3)).astype(np.float32)
+        pts = np.concatenate([extra, kps], 0)                       # keypoints are indices into the cloud
+        rec = np.zeros(pts.shape[0], dtype=[('x', '<f4'), ('y', '<f4'), ('z', '<f4')])
+        rec['x'], rec['y'], rec['z'] = pts[:, 0], pts[:, 1], pts[:, 2]
+        hdr = f'ply\nformat binary_little_endian 1.0\nelement vertex {pts.shape[0]}\nproperty float x\nproperty float y\nproperty float z\nend_header\n'
+        open(f'{base}/PointCloud/cloud_bin_{i}.ply', 'wb').write(hdr.encode() + rec.tobytes())
+        np.savetxt(f'{base}/Keypoints/cloud_bin_{i}Keypoints.txt', np.arange(300, 300 + kps.shape[0]))
+    gt = scene.get_transform('0', '1')
+    with open(f'{base}/PointCloud/gt.log', 'w') as f:
+        f.write('0\t 1\t 2\t\n' + ''.join('\t'.join(repr(float(v)) for v in gt[r]) + '\n' for r in range(3)) + '0.0\t0.0\t0.0\t1.0\n')
+    cache = f'{root}/data/YOHO_FCGF/Testset'
+    scene.write_inputs(cache)
+    cfg0 = default_config()
+    for kind, d, seed in [('GF_test', 'GF', 101), ('ET_test', 'ET', 202)]:
+        net = name2network[kind](cfg0); synth.seeded_state_dict(net, seed)
+        os.makedirs(f'{root}/ckpt/{d}')
+        torch.save({'best_para': 0, 'network_state_dict': net.state_dict()}, f'{root}/ckpt/{d}/model_best.pth')
+    saved = {k: sys.modules.get(k) for k in dropin._ALIASES}
+    monkeypatch.setattr(sys, 'argv', ['Test.py', '--testset', 'demo', '--ET', 'yohoo', '--keynum', '160', '--max_iter', '1000',
+                                      '--base_dir', f'{root}/data', '--origin_data_dir', f'{root}/data/origin_data', '--output_cache_fn', cache,
+                                      '--model_fn', f'{root}/ckpt', '--SO3_related_files', f'{root}/no_such_dir'])
+    try:
+        dropin.install()
+        import parses.parses_test as parses_test                     # what Test.py does (Test.py:3-4,21-23)
+        from test.evaluator import yoho_evaluator
+        config, _ = parses_test.get_config()
+        np.random.seed(3)
+        out = yoho_evaluator(config).run()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    log = open(f'{root}/data/results.log').read()
+    assert log.startswith('demo-yoho_des-nodet-matmul-yohoo-160keys-1000iters\n') and 'registration recall(predator)    : 1.00000' in log
+    assert out['fmr'] == 1.0 and out['ir'] > 0.8 and out['rr'] == 1.0
+    T = np.load(f'{cache}/demo/kitchen/match_160/yohoo/1000iters/0-1.npz')['trans']
+    assert np.abs(T[:3] - gt).max() < 1e-3
+    assert os.path.exists(f'{base}/Keypoints_PC/cloud_bin_0Keypoints.npy')
