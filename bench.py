@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--kpts', type=int, default=N_KPTS)
     ap.add_argument('--clouds', type=int, default=N_CLOUDS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the all-local-transforms figure (profiling runs)')
     return ap.parse_args()
 
 
@@ -137,13 +138,16 @@ def main():
 
     # ---- secondary figure: the same steps with the local transform of EVERY correspondence evaluated, as the reference's
     # file-coupled estimator does (the default evaluates only the <= max_iter hypotheses one-shot RANSAC draws; same results) ----
-    for _ in range(1):
+    n_all = max(1, args.steps // 2)
+    if args.no_secondary:
+        n_all = 0
+    for _ in range(1 if n_all else 0):
         step(all_lt=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    n_all = max(1, args.steps // 2)
+    res_all = res
     for _ in range(n_all):
         res_all = step(all_lt=True)
     torch.cuda.synchronize()
@@ -192,7 +196,7 @@ def main():
                        'pairs_per_step_per_gpu': n_pairs, 'clouds_per_step_per_gpu': args.clouds, 'parallelism': f'pairs-sharded x{world}',
                        'mean_matches': float(np.mean([r.n_match for r in res])), 'registration_recall_synthetic': float(np.mean(rr)),
                        'local_transforms': 'only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M)',
-                       'value_all_local_transforms': world * n_pairs * n_all / dt_all, 'results_identical_to_all_local_transforms': bool(same)},
+                       'value_all_local_transforms': (world * n_pairs * n_all / dt_all) if n_all else None, 'results_identical_to_all_local_transforms': bool(same)},
             'roofline': {'bound': 'mfma', 'kernel': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, exact f32 MFMA)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
                          'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic},

@@ -203,7 +203,8 @@ int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *cons
 int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *Xadd, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
-                    const int32_t *g_map /* optional [60]: group column -> compact output column or -1 */, int Lout,
+                    const int32_t *g_map /* optional [60]: group column -> compact output column (< Lvalid) or -1 */,
+                    int Lout /* row pitch of the compact output, >= Lvalid; pad columns are zero */, int Lvalid,
                     int B, int C, void *stream);
 
 #ifdef __cplusplus

@@ -146,7 +146,7 @@ struct NonlinParams {
     const int *g_map;            // optional [60] -> compact output column (or -1 = not written); Lout columns are written
     const float *bias, *bias2, *bn_scale, *bn_shift;      // per channel; any may be null
     const float *A1, *A2;        // fragment-ordered transform tables (roreg_set_fourier_tables)
-    int B, C, tiles_per_c, Lout;
+    int B, C, tiles_per_c, Lout, Lvalid;
 };
 
 // coefficient q = (rho, i, l) of (b, c) lives at flat offset  (alpha_q*C + c*d_q + i_q) * B + b   with alpha_q = offset_rho + l*d
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     // per SIMD, which this streaming kernel needs to cover its 30 scattered 128-byte row reads per tile.
     __shared__ float sA1[IN_SPATIAL ? 64 : 30 * 2 * 64];
     __shared__ float sA2[OUT_SPATIAL ? 64 : 32 * 2 * 64];
+    __shared__ float sT[OUT_SPATIAL ? 4 * 32 * 65 : 64];
     if (!IN_SPATIAL)
         for (int i = threadIdx.x; i < 30 * 2 * 64; i += 256) sA1[i] = p.A1[i];
     if (!OUT_SPATIAL)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
         const bool bn = p.bn_scale != nullptr;
         const float sc = bn ? p.bn_scale[c] : 1.f, sh = bn ? p.bn_shift[c] : 0.f;
         const float *rs = (OUT_SPATIAL && p.r_spatial) ? p.r_spatial + ((size_t)bb * C + c) * ROREG_G : nullptr;
-        float *os = OUT_SPATIAL ? p.out_spatial + ((size_t)bb * C + c) * p.Lout : nullptr;
+        float *tb = OUT_SPATIAL ? sT + (threadIdx.x >> 6) * (32 * 65) : nullptr;      // this wave's [32 keypoints][65] transpose buffer
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -238,11 +239,20 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                 if (bn) x = fmaxf(fmaf(x, sc, sh), 0.f);
                 if (g >= ROREG_G) x = 0.f;
                 v[t][r] = x;
-                if (OUT_SPATIAL && valid && g < ROREG_G) {
+                if (OUT_SPATIAL && g < ROREG_G) {
                     const int go = p.g_map ? p.g_map[g] : g;
-                    if (go >= 0) os[go] = x;
+                    if (go >= 0) tb[jn * 65 + go] = x;
                 }
             }
+        if (OUT_SPATIAL) {
+            // lanes own keypoints, but the output is [b][c][column]: go through LDS so that every store instruction writes one
+            // keypoint's contiguous row of Lout floats instead of 64 scattered dwords
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int b0 = (tile - c * p.tiles_per_c) * 32;
+            for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
+                if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if (!OUT_SPATIAL) {
             f32x16 o[2];
 #pragma unroll
@@ -404,17 +414,18 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
 
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *Xadd, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
-                               const int32_t *g_map, int Lout, int B, int C, void *stream) {
+                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr) && B > 0 && C > 0, "roreg_ft_nonlin: bad arguments");
     ROREG_REQUIRE((long long)60 * C * B < (1ll << 40), "roreg_ft_nonlin: tensor too large");
+    ROREG_REQUIRE(!g_map || (Lout >= Lvalid && Lvalid > 0 && Lout <= 64), "roreg_ft_nonlin: bad Lout/Lvalid");
     NonlinParams p;
     memset(&p, 0, sizeof(p));
     p.Xin = Xin; p.Xadd = Xadd; p.Xout = Xout;
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
-    p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G;
+    p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
     p.B = B; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;

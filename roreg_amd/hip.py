@@ -52,7 +52,7 @@ PROTOTYPES = {
     'roreg_set_fourier_tables': (c_int, [_P]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
 }
 
 
@@ -483,7 +483,7 @@ def irrep_gemm(X_buf, Wpacks, C, O, B):
 
 
 def ft_nonlin(B, C, coef_in=None, coef_add=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
-              g_map=None, Lout=60):
+              g_map=None, Lout=60, Lvalid=60):
     ensure_fourier()
     dev = (coef_in if coef_in is not None else x_spatial).device
     if spatial_out:
@@ -493,5 +493,5 @@ def ft_nonlin(B, C, coef_in=None, coef_add=None, x_spatial=None, bias=None, bias
     scale, shift = bn if bn is not None else (None, None)
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(coef_add, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
-                                 _ptr(g_map, torch.int32), int(Lout), B, C, _stream()), 'roreg_ft_nonlin')
+                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, _stream()), 'roreg_ft_nonlin')
     return out

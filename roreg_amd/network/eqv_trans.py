@@ -95,7 +95,7 @@ class ET_test(nn.Module):
                 X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn)
                 T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B)
                 del X0
-                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD)   # [B,256,48]
+                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45)   # [B,256,48]
                 del T0
             else:
                 h = self.Conv_init(x, gather=ga)                               # [B,256,45]
