@@ -82,7 +82,8 @@ extern "C" int roreg_des2r(const float *feats1, const int64_t *rows1, const floa
 
 extern "C" int roreg_group_corr(const float *perm_feats, const int64_t *perm_rows, const float *bcast_feats, const int64_t *bcast_rows,
                                 int M, int transpose_table, int64_t *idx_out, float *cor_out, void *stream) {
-    ROREG_REQUIRE(perm_feats && bcast_feats && (idx_out || cor_out) && M >= 0, "roreg_group_corr: bad arguments");
+    if (M == 0) return 0;
+    ROREG_REQUIRE(perm_feats && bcast_feats && (idx_out || cor_out) && M > 0, "roreg_group_corr: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_group_corr: group tables not set");
     if (M == 0) return 0;
     hipLaunchKernelGGL(des2r_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,

@@ -311,6 +311,7 @@ extern "C" int roreg_group_conv(const float *x, const float *wpack, const float 
                                 const float *bn_shift, const float *residual, float *out, const int32_t *gather,
                                 int B, int Cin, int Cout, int Lin, int Lout, int KS, float *workspace, size_t workspace_floats,
                                 void *stream) {
+    if (B == 0) return 0;
     ROREG_REQUIRE(x && wpack && bias && out && gather, "roreg_group_conv: null pointer");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv: bn_scale/bn_shift must come together");
     ROREG_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Lout > 0 && Lin > 0, "roreg_group_conv: bad sizes");

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict_
 
 extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m, const float *tgt, const int64_t *tgt_rows,
                                int n, int F, int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream) {
-    ROREG_REQUIRE(src && tgt && idx_out && scratch && m >= 0 && n > 0, "roreg_nn_search: bad arguments");
+    if (m == 0) return 0;
+    ROREG_REQUIRE(src && tgt && idx_out && scratch && m > 0 && n > 0, "roreg_nn_search: bad arguments");
     ROREG_REQUIRE(F == 32 || F == 3, "roreg_nn_search: F must be 32 or 3 (got %d)", F);
     if (m == 0) return 0;
     hipStream_t s = roreg::as_stream(stream);
@@ -172,7 +173,8 @@ extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
 }
 
 extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k, int64_t *idx_out, void *stream) {
-    ROREG_REQUIRE(src && tgt && idx_out && m >= 0 && n > 0, "roreg_knn_search: bad arguments");
+    if (m == 0) return 0;
+    ROREG_REQUIRE(src && tgt && idx_out && m > 0 && n > 0, "roreg_knn_search: bad arguments");
     ROREG_REQUIRE(k >= 1 && k <= 8 && k <= n, "roreg_knn_search: k must be in 1..min(8,n) (got %d)", k);
     ROREG_REQUIRE(F == 3 || F == 32, "roreg_knn_search: F must be 3 or 32 (got %d)", F);
     if (m == 0) return 0;
@@ -187,7 +189,7 @@ extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n
 
 extern "C" int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m, const int64_t *sample0,
                                     const int64_t *sample1, int64_t *match_out, int32_t *count_out, void *stream) {
-    ROREG_REQUIRE(nn01 && nn10 && match_out && count_out && m >= 0, "roreg_mutual_matches: bad arguments");
+    ROREG_REQUIRE(count_out && m >= 0 && (m == 0 || (nn01 && nn10 && match_out)), "roreg_mutual_matches: bad arguments");
     hipLaunchKernelGGL(mutual_kernel, dim3(1), dim3(1024), 0, roreg::as_stream(stream), nn01, nn10, m, sample0, sample1,
                        match_out, count_out);
     ROREG_CHECK_LAUNCH("roreg_mutual_matches");

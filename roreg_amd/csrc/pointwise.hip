@@ -233,23 +233,24 @@ __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double *__re
 }  // namespace
 
 extern "C" int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream) {
-    ROREG_REQUIRE(eqv_raw && eqv && B >= 0, "roreg_gf_finalize: bad arguments");
     if (B == 0) return 0;
+    ROREG_REQUIRE(eqv_raw && eqv && B > 0, "roreg_gf_finalize: bad arguments");
     hipLaunchKernelGGL(gf_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv_raw, eqv, inv, B);
     ROREG_CHECK_LAUNCH("roreg_gf_finalize");
     return 0;
 }
 
 extern "C" int roreg_inv_descriptor(const float *eqv, float *inv, int N, void *stream) {
-    ROREG_REQUIRE(eqv && inv && N >= 0, "roreg_inv_descriptor: bad arguments");
     if (N == 0) return 0;
+    ROREG_REQUIRE(eqv && inv && N > 0, "roreg_inv_descriptor: bad arguments");
     hipLaunchKernelGGL(inv_descriptor_kernel, dim3((N + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv, inv, N);
     ROREG_CHECK_LAUNCH("roreg_inv_descriptor");
     return 0;
 }
 
 extern "C" int roreg_det_score(const float *enc, float *scores, int B, void *stream) {
-    ROREG_REQUIRE(enc && scores && B >= 0, "roreg_det_score: bad arguments");
+    if (B == 0) return 0;
+    ROREG_REQUIRE(enc && scores && B > 0, "roreg_det_score: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_det_score: group tables not set");
     if (B == 0) return 0;
     hipLaunchKernelGGL(det_score_kernel, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), enc,
@@ -261,7 +262,8 @@ extern "C" int roreg_det_score(const float *enc, float *scores, int B, void *str
 extern "C" int roreg_et_gather(const float *before0, const float *before1, const float *after0, const float *after1,
                                const int64_t *rows0, const int64_t *rows1, const int64_t *pre_idx, int M, float *x_out,
                                void *stream) {
-    ROREG_REQUIRE(before0 && before1 && after0 && after1 && pre_idx && x_out && M >= 0, "roreg_et_gather: bad arguments");
+    if (M == 0) return 0;
+    ROREG_REQUIRE(before0 && before1 && after0 && after1 && pre_idx && x_out && M > 0, "roreg_et_gather: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_et_gather: group tables not set");
     if (M == 0) return 0;
     hipLaunchKernelGGL(et_gather_kernel, dim3(M), dim3(256), 0, roreg::as_stream(stream), before0, before1, after0, after1,
@@ -273,7 +275,8 @@ extern "C" int roreg_et_gather(const float *before0, const float *before1, const
 extern "C" int roreg_quat_to_trans(const float *q, const int64_t *anchor, const double *keys0, const int64_t *rows0,
                                    const double *keys1, const int64_t *rows1, int M, double *Trans_out, float *quat_out,
                                    void *stream) {
-    ROREG_REQUIRE(q && anchor && keys0 && keys1 && Trans_out && M >= 0, "roreg_quat_to_trans: bad arguments");
+    if (M == 0) return 0;
+    ROREG_REQUIRE(q && anchor && keys0 && keys1 && Trans_out && M > 0, "roreg_quat_to_trans: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_quat_to_trans: group tables not set");
     if (M == 0) return 0;
     hipLaunchKernelGGL(quat_to_trans_kernel, dim3((M + 255) / 256), dim3(256), 0, roreg::as_stream(stream), q, anchor, keys0,
@@ -283,7 +286,8 @@ extern "C" int roreg_quat_to_trans(const float *q, const int64_t *anchor, const 
 }
 
 extern "C" int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream) {
-    ROREG_REQUIRE(src && rows && out && M >= 0 && width > 0, "roreg_gather_rows_f64: bad arguments");
+    if (M == 0) return 0;
+    ROREG_REQUIRE(src && rows && out && M > 0 && width > 0, "roreg_gather_rows_f64: bad arguments");
     if (M == 0) return 0;
     hipLaunchKernelGGL(gather_rows_f64_kernel, dim3((M * width + 255) / 256), dim3(256), 0, roreg::as_stream(stream), src, rows,
                        M, width, out);

@@ -1,0 +1,134 @@
+"""Edge cases and full-size (BASELINE.json configs[1]: 5000 keypoints) property tests of the HIP path.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+from roreg_amd import synth
+from roreg_amd.parses.parses_test import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_empty_inputs_are_no_ops():
+    from roreg_amd import hip
+    e32 = torch.empty((0, 32, 60), dtype=torch.float32, device='cuda')
+    assert hip.inv_descriptor(e32).shape == (0, 32)
+    assert hip.des2r(e32, e32).shape == (0,)
+    idx = hip.nn_search(torch.empty((0, 32), device='cuda'), torch.randn(5, 32, device='cuda'))
+    assert idx.shape == (0,)
+    out, cnt = hip.mutual_matches(torch.empty(0, dtype=torch.int64, device='cuda'), torch.empty(0, dtype=torch.int64, device='cuda'))
+    assert int(cnt.item()) == 0
+    layer = hip.ConvLayer(torch.randn(64, 32, 1, 13), torch.zeros(64), None)
+    assert hip.group_conv(torch.empty((0, 32, 60), device='cuda'), layer).shape == (0, 64, 60)
+    T = hip.quat_to_trans(torch.empty((0, 4), device='cuda'), torch.empty(0, dtype=torch.int64, device='cuda'),
+                          torch.zeros((3, 3), dtype=torch.float64, device='cuda'), torch.zeros((3, 3), dtype=torch.float64, device='cuda'))
+    assert T.shape == (0, 3, 4)
+
+
+def test_bad_arguments_raise_not_crash():
+    from roreg_amd import hip
+    with pytest.raises(hip.HipError):
+        hip.nn_search(torch.randn(4, 7, device='cuda'), torch.randn(4, 7, device='cuda'))          # unsupported F
+    with pytest.raises(hip.HipError):
+        hip.knn_search(torch.randn(4, 3, device='cuda'), torch.randn(4, 3, device='cuda'), 9)      # k > 8
+    with pytest.raises(hip.HipError):
+        hip.group_conv(torch.randn(2, 32, 60), hip.ConvLayer(torch.randn(64, 32, 1, 13), torch.zeros(64), None))   # host tensor
+    with pytest.raises(hip.HipError):
+        hip.topk_dot(torch.randn(10, 32, device='cuda'), torch.randn(4, 32, device='cuda'), 16)    # k > n
+
+
+def test_single_keypoint_and_single_pair_batches(group):
+    """B=1 (the reference's torch.squeeze hazard, group_feat.py:21) and a 1x1 nearest-neighbour problem."""
+    from roreg_amd import hip
+    from roreg_amd.network import name2network
+    net = name2network['GF_test'](default_config()); sd = synth.seeded_state_dict(net, 3)
+    x = np.random.default_rng(0).standard_normal((1, 32, 60)).astype(np.float32)
+    got = net(torch.from_numpy(x))['eqv'].cpu().numpy()
+    want = O.gf_forward(x, {k: v.numpy() for k, v in sd.items()}, group.Nei)['eqv']
+    assert np.abs(got - want).max() < 1e-5
+    a = torch.randn(1, 32, device='cuda')
+    assert hip.nn_search(a, a).cpu().numpy().tolist() == [0]
+
+
+def test_ragged_sample_sizes_in_mutual(group):
+    """keynum larger than one cloud and smaller than the other: samples of different length (matcher.py:83-88)."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(1)
+    e0 = rng.standard_normal((300, 32, 60)).astype(np.float32); e1 = rng.standard_normal((170, 32, 60)).astype(np.float32)
+    e1[:120] = e0[50:170] + 0.01 * rng.standard_normal((120, 32, 60)).astype(np.float32)
+    s0 = rng.permutation(300)[:250]; s1 = rng.permutation(170)
+    i0 = hip.inv_descriptor(cu(e0)); i1 = hip.inv_descriptor(cu(e1))
+    d0, d1 = cu(s0), cu(s1)
+    buf, cnt = hip.mutual_matches(hip.nn_search(i0, i1, src_rows=d0, tgt_rows=d1), hip.nn_search(i1, i0, src_rows=d1, tgt_rows=d0), d0, d1)
+    got = buf[:int(cnt.item())].cpu().numpy()
+    assert np.array_equal(got, O.mutual_match(e0, e1, s0, s1))
+    assert len(got) > 60
+
+
+def test_full_size_equivariance_and_planted_rotation(group):
+    """N = 5000: GF(x[..., P[a]]) == GF(x)[..., P[a]], Des2R recovers the planted group element, and the mutual matcher
+    returns a partial permutation that contains the planted correspondences."""
+    from roreg_amd import hip
+    from roreg_amd.network import name2network
+    net = name2network['GF_test'](default_config()); synth.seeded_state_dict(net, 101)
+    ds = synth.make_scene(9, n_clouds=2, n_kpts=5000, overlap=0.6, feat_noise=0.02)
+    a = 37
+    x = torch.from_numpy(ds.feats[0]).cuda()
+    y0 = net(x)['eqv']
+    y1 = net(x[:, :, torch.from_numpy(group.P[a]).cuda()].contiguous())['eqv']
+    assert float((y1 - y0[:, :, torch.from_numpy(group.P[a]).cuda()]).abs().max()) < 1e-5
+    # Des2R between the descriptor and its rotated copy: d1[:, P[a,g]] = d2[:, g]
+    d1 = torch.empty_like(y0); d1[:, :, torch.from_numpy(group.P[a]).cuda()] = y0
+    assert bool((hip.des2r(d1, y0) == a).all())
+    # mutual matching of the two clouds of the scene
+    e1 = net(torch.from_numpy(ds.feats[1]).cuda())['eqv']
+    i0, i1 = hip.inv_descriptor(y0), hip.inv_descriptor(e1)
+    buf, cnt = hip.mutual_matches(hip.nn_search(i0, i1), hip.nn_search(i1, i0))
+    m = buf[:int(cnt.item())].cpu().numpy()
+    assert len(np.unique(m[:, 0])) == len(m) and len(np.unique(m[:, 1])) == len(m)          # partial permutation
+    assert (np.diff(m[:, 0]) > 0).all()                                                      # increasing source order
+    gt = ds.get_transform('0', '1')
+    k0 = ds.get_kps('0')[m[:, 0]]; k1 = ds.get_kps('1')[m[:, 1]] @ gt[:, :3].T + gt[:, 3]
+    assert (np.linalg.norm(k0 - k1, axis=1) < 1e-4).mean() > 0.9 and len(m) > 2500
+
+
+def test_full_size_registration_recovers_ground_truth(group):
+    """One 5000-keypoint pair end to end through the engine: refined transform equals the ground truth, is orthonormal, overlap in [0,1]."""
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    cfg = default_config(keynum=5000, max_iter=1000, ET='yohoo')
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    ds = synth.make_scene(12, n_clouds=2, n_kpts=5000, overlap=0.6)
+    np.random.seed(0)
+    r = RegistrationEngine(cfg, gf, et).run_scene(ds.feats, [ds.get_kps(i) for i in ds.pc_ids], ds.pair_ids)[0]
+    gt = ds.get_transform('0', '1')
+    assert np.abs(r.trans[:3] - gt).max() < 1e-4
+    R = r.trans[:3, :3]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
+    assert 2500 < r.n_match <= 5000 and 0 <= r.recalltime < 1000
+
+
+def test_sinkhorn_marginals_at_full_size():
+    """5000 x 5000: exp(Z) has the prescribed marginals (mass 1 per real row/column, n resp. m for the dustbins) up to the
+    residual of the last half-iteration; matches0/1 are mutually consistent."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(5)
+    m = n = 5000
+    s = (rng.standard_normal((m, 32)) * 0.4).astype(np.float32); t = (rng.standard_normal((n, 32)) * 0.4).astype(np.float32)
+    t[:2000] = s[1000:3000] * 2.5
+    Z, m0, m1, s0, s1 = hip.sinkhorn(cu(s), cu(t), 1.0, 100)
+    P = torch.exp(Z.double() - np.log(m + n))            # Z = log coupling + log(m+n)
+    col = P.sum(0).cpu().numpy(); row = P.sum(1).cpu().numpy()
+    assert np.abs(col[:-1] - 1.0 / (m + n)).max() < 1e-6 and abs(col[-1] - m / (m + n)) < 1e-4          # v-update was the last one
+    assert np.abs(row[:-1] * (m + n) - 1).max() < 0.05
+    m0 = m0.cpu().numpy(); m1 = m1.cpu().numpy()
+    v = np.where(m0 >= 0)[0]
+    assert np.array_equal(m1[m0[v]], v) and len(v) >= 1900
+    assert np.array_equal(m0[1000:3000][m0[1000:3000] >= 0], np.arange(2000)[m0[1000:3000] >= 0])
