@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--pairs', type=int, default=N_PAIRS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the all-local-transforms figure (profiling runs)')
+    ap.add_argument('--gemm', choices=['f32', 'split'], default='f32', help="irrep GEMMs: exact f32-input MFMA, or 3 x bf16 split (f32-accurate)")
     return ap.parse_args()
 
 
@@ -81,6 +82,19 @@ def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
     return t, threads
 
 
+def roofline_obj(mode, achieved, ms, n_launch, traffic):
+    """MFMA roofline of the dominant kernel.  'f32': v_mfma_f32_32x32x2_f32 (exact f32 inputs), priced against the f32 MFMA
+    peak.  'split': every product is six bf16 MFMAs (operands split 3 x bf16), priced against the dense bf16 peak with 6x
+    the algorithmic flops counted as executed work; `achieved` stays the ALGORITHMIC f32-equivalent rate."""
+    if mode == 'f32':
+        return {'bound': 'mfma', 'kernel': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, exact f32 MFMA)',
+                'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic}
+    return {'bound': 'mfma', 'kernel': 'irrep_gemm_split_kernel<32> (same GEMMs, 3 x bf16 split operands, 6 bf16 MFMAs per product)',
+            'achieved': achieved, 'executed_bf16': 6 * achieved, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': 6 * achieved / PEAK_BF16_MFMA_TFLOPS, 'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
@@ -101,6 +115,7 @@ def main():
     gf = name2network['GF_test'](cfg); gf_sd = synth.seeded_state_dict(gf, 101)
     et = name2network['ET_test'](cfg); et_sd = synth.seeded_state_dict(et, 202)
     eng = RegistrationEngine(cfg, gf, et)
+    eng.set_gemm_mode(args.gemm)
 
     scene = synth.make_scene(1000 + rank, n_clouds=args.clouds, n_kpts=args.kpts, overlap=OVERLAP, coord_noise=0.005)
     # a fixed pseudo-random subset of the cloud pairs that touches every cloud (like a scene's gt.log lists the overlapping pairs)
@@ -140,39 +155,56 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- secondary figure: the same steps with the local transform of EVERY correspondence evaluated, as the reference's
+    def timed(n, **kw):
+        """n timed steps (after one untimed one) with the same barrier + synchronise bracket; MAX over ranks."""
+        if n == 0:
+            return 0.0, res
+        step(**kw)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            r = step(**kw)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        d = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([d], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d, r
+
+    # ---- secondary figure 1: the same steps with the local transform of EVERY correspondence evaluated, as the reference's
     # file-coupled estimator does (the default evaluates only the <= max_iter hypotheses one-shot RANSAC draws; same results) ----
-    n_all = max(1, args.steps // 2)
-    if args.no_secondary:
-        n_all = 0
-    for _ in range(1 if n_all else 0):
-        step(all_lt=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    res_all = res
-    for _ in range(n_all):
-        res_all = step(all_lt=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt_all = time.perf_counter() - t1
-    if dist is not None:
-        tt = torch.tensor([dt_all], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_all = float(tt.item())
+    n_all = 0 if args.no_secondary else max(1, args.steps // 2)
+    dt_all, res_all = timed(n_all, all_lt=True)
     same = all(np.array_equal(a.trans, b.trans) and a.recalltime == b.recalltime for a, b in zip(res, res_all))
+
+    # ---- secondary figure 2: the other GEMM mode (3 x bf16 split operands, f32 accumulate: f32-accurate, not bit-equal) ----
+    other = 'split' if args.gemm == 'f32' else 'f32'
+    eng.set_gemm_mode(other)
+    hip.PROFILE = []
+    dt_other, res_other = timed(n_all)
+    prof_other = hip.PROFILE; hip.PROFILE = None
+    eng.set_gemm_mode(args.gemm)
+    max_dT = max([float(np.abs(a.trans - b.trans).max()) for a, b in zip(res, res_other) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()] or [0.0])
 
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
     # algorithmic work per launch = sum over the five irreps of 2*(d*O)*(d*C)*(d*B) = 2*O*C*B*244 flop (DESIGN.md section 4)
-    flops = 0.0; ms = 0.0; n_launch = 0
-    for (tag, e0, e1) in prof:
-        if tag[0] == 'irrep_gemm' and tag[2] * tag[3] == 256 * 512:
-            _, B_, C_, O_ = tag
-            flops += 2.0 * O_ * C_ * B_ * 244
-            ms += e0.elapsed_time(e1); n_launch += 1
-    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    def gemm_roofline(events, tagname):
+        flops = 0.0; ms = 0.0; n_launch = 0
+        for (tag, e0, e1) in events:
+            if tag[0] == tagname and tag[2] * tag[3] == 256 * 512:
+                _, B_, C_, O_ = tag
+                flops += 2.0 * O_ * C_ * B_ * 244
+                ms += e0.elapsed_time(e1); n_launch += 1
+        return (flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), ms, n_launch
+
+    tag_of = {'f32': 'irrep_gemm', 'split': 'irrep_gemm_split'}
+    achieved, ms, n_launch = gemm_roofline(prof, tag_of[args.gemm])
+    achieved_other, ms_other, n_other = gemm_roofline(prof_other or [], tag_of[other])
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'r01_irrep_gemm_pmc.json')
     if os.path.exists(pmc):                      # HBM bytes per launch from the rocprofv3 --pmc passes of this same command
@@ -201,10 +233,13 @@ def main():
                        'mean_matches': float(np.mean([r.n_match for r in res])), 'registration_recall_synthetic': float(np.mean(rr)),
                        'local_transforms': 'only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M)',
                        'value_all_local_transforms': (world * n_pairs * n_all / dt_all) if n_all else None, 'results_identical_to_all_local_transforms': bool(same)},
-            'roofline': {'bound': 'mfma', 'kernel': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, exact f32 MFMA)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                         'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic},
+            'roofline': roofline_obj(args.gemm, achieved, ms, n_launch, traffic),
         }
+        if n_all:
+            out['config']['other_gemm_mode'] = {
+                'mode': other, 'value': world * n_pairs * n_all / dt_other, 'ms_per_step': 1e3 * dt_other / n_all,
+                'max_abs_diff_of_transforms_vs_default': max_dT,
+                'roofline': roofline_obj(other, achieved_other, ms_other, n_other, None)}
         if not args.no_cpu_baseline and world == 1:
             gf_np = {k: v.numpy() for k, v in gf_sd.items()}; et_np = {k: v.numpy() for k, v in et_sd.items()}
             t, threads = cpu_baseline((gf_np, et_np), scene, n_pairs, args.clouds)

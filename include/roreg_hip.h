@@ -200,6 +200,11 @@ int roreg_set_fourier_tables(const float *F_host);
 size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host);
 int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Wpack, int C, int O, int B,
                      const int32_t *tiles_dev, int n_tiles, void *stream);
+/* Same GEMMs on the bf16 matrix cores with f32 accuracy: every operand is split into three bf16 pieces and the six cross products
+ * of order <= 4 are accumulated in f32 (error at the f32 rounding level; 2.67x fewer matrix-core cycles than the f32-input MFMA).
+ * Wsplit[rho]: uint16 bf16 bits, layout [3 splits][d*C/16][round_up(d*O,128)][2 k-halves][8]. */
+int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const void *const *Wsplit, int C, int O, int B,
+                           const int32_t *tiles_dev, int n_tiles, void *stream);
 int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *Xadd, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,

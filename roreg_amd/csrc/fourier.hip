@@ -136,6 +136,174 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// f32-accurate GEMM on the bf16 matrix cores ("3 x bf16 split"): every f32 operand is the exact sum of three bf16 pieces
+// (8 + 8 + 8 significant bits); the six cross products of order <= 4, (1,1) (1,2) (2,1) (1,3) (2,2) (3,1), are accumulated in f32.
+// The dropped products are below 2^-24 relative, i.e. at the f32 rounding level (measured error equals a plain f32 GEMM's, see
+// tests), while six bf16 MFMAs (32 cycles, K=16 each) replace eight f32 MFMAs (64 cycles, K=2 each): 2.67x fewer matrix-core cycles.
+// Weights are split and packed once on the host ([split][k/16][m][k-half][8] bf16 = one 16-byte load per fragment); activations are
+// split on the fly from the f32 LDS tile (v_cvt_pk_bf16_f32, round-to-nearest-even), which the VALU does under the MFMAs' shadow.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmSplitDescs {
+    const float *X[NIRR];
+    float *Out[NIRR];
+    const bf16x8 *W[NIRR];        // [3][K/16][2][Mpad]
+    int K[NIRR], M[NIRR], Mpad[NIRR], N[NIRR];
+};
+
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h1 = (__bf16)v[e];
+        const float r1 = v[e] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        b1[e] = h1; b2[e] = h2; b3[e] = (__bf16)r2;
+    }
+}
+
+// Data flow of one K16 step: the packed weight fragments of the NEXT step (3 planes x 2 k-octets x 128 rows = 12 KiB) go
+// global -> LDS with LDS-DMA (no VGPR staging); every thread owns an 8(k) x 2(n) patch of the f32 activations, loaded two steps
+// ahead into registers, split ONCE (v_cvt_pk_bf16_f32) and written as three 16-byte k-octets into LDS in B-fragment order, so the
+// MFMA phase reads every bf16 fragment with one conflict-free ds_read_b128.  The ~110 VALU instructions of the conversion are
+// interleaved with the 48 MFMAs of the step (sched_group_barrier), i.e. they issue in the matrix pipe's shadow.  Both LDS areas
+// are double-buffered: one barrier per step.
+template <int CT>
+__global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCOL = 256, OT = 128;
+    constexpr int XBUF = 3 * 2 * NCOL, ABUF = 3 * 2 * OT;         // fragments (16 B) per buffer
+    bf16x8 *xs = reinterpret_cast<bf16x8 *>(smem);               // [2 buf][3 split][2 k-octet][256 n (swizzled)]
+    bf16x8 *as = xs + 2 * XBUF;                                  // [2 buf][3 split][2 k-octet][128 m]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
+    if (irr < 0) return;
+    const float *__restrict__ X = p.X[irr];
+    const bf16x8 *__restrict__ W = p.W[irr];
+    const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
+    const int wo = w & 1, wb = w >> 1;
+    const int m_wave = mt * OT + wo * 64;
+    const int n0 = nt * NCOL;
+    const int ncol_wave = wb * 128;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    // staging patch of this thread: columns n0 + 2*pp, +1 (clamped inside the matrix: out-of-range columns are never stored),
+    // k-octet po of the step.  Column n lives in fragment slot n ^ ((n >> 3) & 1): conflict-free for the 8-lane groups of
+    // ds_write_b128 (even columns of 8 neighbouring threads) and for the 16-lane groups of ds_read_b128.
+    const int pp = tid & 127, po = tid >> 7;
+    int ncol = n0 + 2 * pp;
+    if (ncol > N - 2) ncol = N - 2;
+    const float *xcol = X + ncol + (size_t)(8 * po) * N;
+    const int nsteps = K / 16;                                   // even (C % 32 == 0)
+    auto load_x = [&](int kstep, float2 (&xr)[8]) {
+        const float *q = xcol + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 16 * N;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[e] = *reinterpret_cast<const float2 *>(q + (size_t)e * N);
+    };
+    const int sw = (pp >> 2) & 1;                                // ((2*pp) >> 3) & 1
+    const int slot0 = po * NCOL + ((2 * pp) ^ sw), slot1 = po * NCOL + ((2 * pp + 1) ^ sw);
+    auto convert_store = [&](int buf, const float2 (&xr)[8]) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v0[e] = xr[e].x; v1[e] = xr[e].y; }
+        bf16x8 b1, b2, b3;
+        bf16x8 *dst = xs + buf * XBUF;
+        split3(v0, b1, b2, b3);
+        dst[slot0] = b1; dst[2 * NCOL + slot0] = b2; dst[4 * NCOL + slot0] = b3;
+        split3(v1, b1, b2, b3);
+        dst[slot1] = b1; dst[2 * NCOL + slot1] = b2; dst[4 * NCOL + slot1] = b3;
+    };
+    // weight fragments of a step: per split plane [2 k-octets][128 rows] = 256 fragments, one per thread, 64 consecutive per wave
+    const bf16x8 *wsrc = W + (size_t)(w >> 1) * Mpad + mt * OT + (w & 1) * 64 + lane;
+    auto issue_a = [&](int kstep, int buf) {
+        const bf16x8 *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * split_stride),
+                                             (__attribute__((address_space(3))) void *)(as + buf * ABUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+    };
+    // fragment slots this lane reads in the MFMA phase
+    int xslot[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int n = ncol_wave + t * 32 + j; xslot[t] = h * NCOL + (n ^ ((n >> 3) & 1)); }
+    const int aslot = h * OT + wo * 64 + j;
+
+    auto step = [&](int ks, int buf, float2 (&xr_load)[8], const float2 (&xr_use)[8]) {
+        issue_a(ks + 1, buf ^ 1);                                 // land under the MFMAs of this step
+        load_x(ks + 2, xr_load);                                  // consumed during the next step
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 *xt = xs + buf * XBUF;
+        const bf16x8 *at = as + buf * ABUF + aslot;
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) a[ot][sp] = at[sp * (2 * OT) + ot * 32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 b1 = xt[xslot[t]], b2 = xt[2 * NCOL + xslot[t]], b3 = xt[4 * NCOL + xslot[t]];
+            f32x16 c0 = acc[0][t], c1 = acc[1][t];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b2, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b3, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b3, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b2, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b1, c1, 0, 0, 0);
+            acc[0][t] = c0; acc[1][t] = c1;
+        }
+        convert_store(buf ^ 1, xr_use);                           // the next step's activations, split under the MFMAs' shadow
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // ... then up to three VALU instructions in its shadow
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next weights (LDS-DMA) and the staged patch have landed
+        __syncthreads();
+    };
+
+    float2 xr0[8], xr1[8];
+    load_x(0, xr0);
+    issue_a(0, 0);
+    load_x(1, xr1);
+    convert_store(0, xr0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks = 0; ks < nsteps; ks += 2) {
+        step(ks, 0, xr0, xr1);
+        step(ks + 1, 1, xr1, xr0);
+    }
+    float *__restrict__ Out = p.Out[irr];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + ncol_wave + t * 32 + j;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < M) Out[(size_t)m * N + n] = acc[ot][t][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct NonlinParams {
     const float *Xin;            // flat coefficient buffer [60*C*B] (nullptr when the input is spatial)
     const float *Xadd;           // optional second coefficient buffer added to Xin (residual in the Fourier domain)
@@ -409,6 +577,26 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
     if (e != hipSuccess) { roreg::set_error("roreg_irrep_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), lds, roreg::as_stream(stream), p, tiles_dev);
     ROREG_CHECK_LAUNCH("roreg_irrep_gemm");
+    return 0;
+}
+
+extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const void *const *Wsplit, int C, int O, int B,
+                                      const int32_t *tiles_dev, int n_tiles, void *stream) {
+    ROREG_REQUIRE(X && Out && Wsplit && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_split: bad arguments");
+    ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_split: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
+    static const int dims[5] = {1, 3, 3, 4, 5};
+    GemmSplitDescs p;
+    for (int r = 0; r < 5; ++r) {
+        p.X[r] = X[r]; p.Out[r] = Out[r]; p.W[r] = reinterpret_cast<const bf16x8 *>(Wsplit[r]);
+        p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
+    }
+    constexpr int CT = 32;
+    const size_t lds = 2 * (3 * 2 * 256 + 3 * 128 * 2) * 16;       // two buffers of (activation planes + weight fragments) of a K16 step
+    auto kern = irrep_gemm_split_kernel<CT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { roreg::set_error("roreg_irrep_gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), lds, roreg::as_stream(stream), p, tiles_dev);
+    ROREG_CHECK_LAUNCH("roreg_irrep_gemm_split");
     return 0;
 }
 

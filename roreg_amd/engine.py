@@ -47,6 +47,15 @@ class RegistrationEngine:
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
 
+    def set_gemm_mode(self, mode):
+        """'f32': exact f32-input MFMA GEMMs (bitwise an fmaf chain);  'split': 3 x bf16 split GEMMs (f32-accurate)."""
+        from .network.gf_fourier import FourierGF
+        net = self.gf.PartI_net
+        if net._fourier is None:
+            object.__setattr__(net, '_fourier', FourierGF(net))
+        net._fourier.split_bf16 = (mode == 'split')
+        self.et.split_bf16 = (mode == 'split')
+
     # ---- per cloud ---------------------------------------------------------------------------------------
     def extract(self, feats, keys):
         """feats: [N,32,60] f32 (host ndarray or device tensor); keys [N,3] f64."""

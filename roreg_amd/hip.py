@@ -52,6 +52,7 @@ PROTOTYPES = {
     'roreg_set_fourier_tables': (c_int, [_P]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
 }
 
@@ -461,8 +462,9 @@ def coef_views(buf, C, B):
 _tile_cache = {}
 
 
-def irrep_gemm(X_buf, Wpacks, C, O, B):
-    """coefficients [60*C*B] -> [60*O*B] through the five per-irrep GEMMs."""
+def irrep_gemm(X_buf, Wpacks, C, O, B, split=None):
+    """coefficients [60*C*B] -> [60*O*B] through the five per-irrep GEMMs.  split: the five 3xbf16-split weight tensors
+    (f32-accurate GEMM on the bf16 matrix cores) or None for the exact f32-input MFMA kernel."""
     out = torch.empty(60 * O * B, dtype=torch.float32, device=X_buf.device)
     key = (O, B)
     t = _tile_cache.get(key)
@@ -475,10 +477,14 @@ def irrep_gemm(X_buf, Wpacks, C, O, B):
     xv = coef_views(X_buf, C, B); ov = coef_views(out, O, B)
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), _ptr_array(Wpacks), C, O, B, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
-           'roreg_irrep_gemm')
+    if split is not None:
+        _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), _ptr_array(split), C, O, B, _ptr(t, torch.int32), int(t.shape[0]),
+                                            _stream()), 'roreg_irrep_gemm_split')
+    else:
+        _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), _ptr_array(Wpacks), C, O, B, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
+               'roreg_irrep_gemm')
     if PROFILE is not None:
-        e1.record(); PROFILE.append((('irrep_gemm', B, C, O), e0, e1))
+        e1.record(); PROFILE.append((('irrep_gemm_split' if split is not None else 'irrep_gemm', B, C, O), e0, e1))
     return out
 
 
@@ -495,3 +501,23 @@ def ft_nonlin(B, C, coef_in=None, coef_add=None, x_spatial=None, bias=None, bias
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
                                  _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, _stream()), 'roreg_ft_nonlin')
     return out
+
+
+def bf16_split3_pack(Wm):
+    """Wm float32 [Mpad, K] (K % 16 == 0) -> int16 device tensor [3][K/16][2][Mpad][8]: the three bf16 pieces (round-to-nearest-even,
+    each piece taken from the exact float32 remainder) in the fragment order of irrep_gemm_split_kernel."""
+    Wm = np.ascontiguousarray(Wm, np.float32)
+    Mpad, K = Wm.shape
+
+    def rne(x):
+        u = x.view(np.uint32)
+        r = ((u >> 16) & 1) + 0x7fff
+        hi = ((u + r) >> 16).astype(np.uint16)
+        return hi, (hi.astype(np.uint32) << 16).view(np.float32)
+    out = np.empty((3, K // 16, 2, Mpad, 8), np.uint16)
+    rem = Wm
+    for sp in range(3):
+        bits, val = rne(np.ascontiguousarray(rem))
+        out[sp] = bits.reshape(Mpad, K // 16, 2, 8).transpose(1, 2, 0, 3)
+        rem = rem - val
+    return torch.from_numpy(out.view(np.int16)).cuda()

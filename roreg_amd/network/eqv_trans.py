@@ -30,6 +30,7 @@ class ET_test(nn.Module):
             nn.Conv2d(d[2], d[3], 1, 1))
         self.pruned = True
         self.fourier_init = True
+        self.split_bf16 = False
 
     # ---- kernel plans -------------------------------------------------------------------------------------
     def _head_plans(self):
@@ -93,7 +94,7 @@ class ET_test(nn.Module):
                 layer, bn = self._fourier_init()
                 hip.ensure_fourier()
                 X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn)
-                T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B)
+                T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if self.split_bf16 else None)
                 del X0
                 h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45)   # [B,256,48]
                 del T0

@@ -67,3 +67,39 @@ def test_gf_fourier_vs_direct_vs_golden(group):
         net.PartI_net.mode = 'fourier'; a = net(xb)['eqv'].cpu().numpy()
         net.PartI_net.mode = 'direct'; b = net(xb)['eqv'].cpu().numpy()
         assert np.abs(a - b).max() < 1e-5, B
+
+
+def test_split_bf16_gemm_is_f32_accurate(group):
+    """3 x bf16 split GEMM (six cross products, f32 accumulate) against float64: error at the level of the exact-f32 MFMA kernel."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(4)
+    B, C, Oc = 64, 256, 512
+    conv = torch.nn.Conv2d(C, Oc, (1, 13))
+    L = _Layer(conv)
+    x = rng.standard_normal((B, C, 60)).astype(np.float32) * np.abs(rng.standard_normal((B, C, 1))).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    X = hip.ft_nonlin(B, C, x_spatial=xd)
+    T32 = hip.irrep_gemm(X, L.wpack, C, Oc, B)
+    Tsp = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=L.wsplit)
+    y32 = hip.ft_nonlin(B, Oc, coef_in=T32, bias=L.bias, spatial_out=True).double().cpu().numpy()
+    ysp = hip.ft_nonlin(B, Oc, coef_in=Tsp, bias=L.bias, spatial_out=True).double().cpu().numpy()
+    ref = np.einsum('ock,bcgk->bog', conv.weight.detach().double().numpy()[:, :, 0, :], x.astype(np.float64)[:, :, group.Nei]) + \
+        conv.bias.detach().double().numpy()[None, :, None]
+    scale = np.abs(ref).max()
+    e32 = np.abs(y32 - ref).max() / scale; esp = np.abs(ysp - ref).max() / scale
+    assert e32 < 2e-6 and esp < 2e-6, (e32, esp)
+    assert esp < 3 * e32 + 1e-7, (e32, esp)
+
+
+def test_gf_split_bf16_vs_golden(group):
+    from roreg_amd.network import name2network
+    z = load_golden('gf_forward')
+    net = name2network['GF_test'](default_config())
+    synth.seeded_state_dict(net, int(z['seed']))
+    x = torch.from_numpy(z['x'])
+    net.PartI_net.mode = 'fourier'
+    a = net(x)['eqv'].cpu().numpy()
+    net.PartI_net._fourier.split_bf16 = True
+    b = net(x)['eqv'].cpu().numpy()
+    assert np.abs(b - z['eqv']).max() < 1e-5 and np.abs(a - b).max() < 5e-6
