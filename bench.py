@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 N_KPTS = 5000
 N_CLOUDS = 16
 N_PAIRS = 60          # 16 clouds : 60 pairs = 0.267 = 3DMatch's 433 clouds : 1623 pairs

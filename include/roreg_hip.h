@@ -190,22 +190,24 @@ int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n,
  * roreg_set_fourier_tables: F [60 (q = (rho,i,l))][60 (g)], the orthonormal transform (host pointer).
  * roreg_irrep_gemm_tiles:   fills / counts the (irrep, m-tile, n-tile) work list of one layer.
  * roreg_irrep_gemm:         the five GEMMs in one launch; X/Out/Wpack are host arrays of 5 device pointers; Wpack[rho] is
- *                           roreg_group_conv_pack_weights(KS=1) of the [round_up(d*O,128)][d*C] matrix.
+ *                           roreg_group_conv_pack_weights(KS=1) of the [round_up(d*O,128)][d*C] matrix.  Add (nullable): 5 device
+ *                           pointers shaped like Out; Out = W.X + Add (the residual short cut of network/ops.py:46-64 taken in the
+ *                           irrep domain).
  * roreg_ft_nonlin:          per (keypoint, channel): inverse transform (or group-domain input) -> + bias (+ bias2)
  *                           (+ group-domain residual) -> BatchNorm(eval)+ReLU (optional) -> forward transform (or group-domain
  *                           output [B,C,60], or only the Lout columns selected by g_map -- the ET trunk keeps 45 live columns).
  *                           Coefficients are one flat buffer: irrep rho occupies [off_rho*C*B, off_{rho+1}*C*B) as the row-major
- *                           matrix [d*C][d*B].  Xadd: optional second coefficient set summed with Xin. */
+ *                           matrix [d*C][d*B]. */
 int roreg_set_fourier_tables(const float *F_host);
 size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host);
-int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Wpack, int C, int O, int B,
+int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Add, const float *const *Wpack, int C, int O, int B,
                      const int32_t *tiles_dev, int n_tiles, void *stream);
 /* Same GEMMs on the bf16 matrix cores with f32 accuracy: every operand is split into three bf16 pieces and the six cross products
  * of order <= 4 are accumulated in f32 (error at the f32 rounding level; 2.67x fewer matrix-core cycles than the f32-input MFMA).
- * Wsplit[rho]: uint16 bf16 bits, layout [3 splits][d*C/16][round_up(d*O,128)][2 k-halves][8]. */
-int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const void *const *Wsplit, int C, int O, int B,
+ * Wsplit[rho]: uint16 bf16 bits, layout [3 splits][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
+int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit, int C, int O, int B,
                            const int32_t *tiles_dev, int n_tiles, void *stream);
-int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *Xadd, const float *x_spatial, const float *bias,
+int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
                     const int32_t *g_map /* optional [60]: group column -> compact output column (< Lvalid) or -1 */,

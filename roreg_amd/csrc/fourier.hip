@@ -15,6 +15,7 @@
 //                       layout of the first, so no transpose is needed).
 #include "common.h"
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,13 +23,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int NIRR = 5;
-__constant__ int c_dims[NIRR] = {1, 3, 3, 4, 5};
-// q (row of F) -> irrep, row i, col l   (q = offset[rho] + i*d + l)
-__constant__ signed char c_q_irr[64], c_q_i[64], c_q_l[64];
 
 struct GemmDescs {
     const float *X[NIRR];
     float *Out[NIRR];
+    const float *Add[NIRR];       // optional: Out = W.X + Add (residual in the irrep domain), or all null
     const float4 *W[NIRR];
     int K[NIRR], M[NIRR], Mpad[NIRR], N[NIRR];
 };
@@ -121,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
         buf ^= 1;
     }
     float *__restrict__ Out = p.Out[irr];
+    const float *__restrict__ Add = p.Add[irr];
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -130,7 +130,11 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < M) Out[(size_t)m * N + n] = acc[ot][t][r];
+                if (m < M) {
+                    float o = acc[ot][t][r];
+                    if (Add) o += Add[(size_t)m * N + n];
+                    Out[(size_t)m * N + n] = o;
+                }
             }
         }
 }
@@ -147,6 +151,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct GemmSplitDescs {
     const float *X[NIRR];
     float *Out[NIRR];
+    const float *Add[NIRR];
     const bf16x8 *W[NIRR];        // [3][K/16][2][Mpad]
     int K[NIRR], M[NIRR], Mpad[NIRR], N[NIRR];
 };
@@ -289,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
         step(ks + 1, 1, xr1, xr0);
     }
     float *__restrict__ Out = p.Out[irr];
+    const float *__restrict__ Add = p.Add[irr];
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -298,7 +304,11 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < M) Out[(size_t)m * N + n] = acc[ot][t][r];
+                if (m < M) {
+                    float o = acc[ot][t][r];
+                    if (Add) o += Add[(size_t)m * N + n];
+                    Out[(size_t)m * N + n] = o;
+                }
             }
         }
 }
@@ -306,7 +316,6 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
 // ---------------------------------------------------------------------------------------------------------------
 struct NonlinParams {
     const float *Xin;            // flat coefficient buffer [60*C*B] (nullptr when the input is spatial)
-    const float *Xadd;           // optional second coefficient buffer added to Xin (residual in the Fourier domain)
     float *Xout;                 // flat coefficient buffer out (nullptr when the output is spatial)
     const float *x_spatial;      // [B,C,60] input in the group domain
     const float *r_spatial;      // [B,C,60] residual added in the group domain (before BN/ReLU; only with spatial output)
@@ -317,17 +326,35 @@ struct NonlinParams {
     int B, C, tiles_per_c, Lout, Lvalid;
 };
 
-// coefficient q = (rho, i, l) of (b, c) lives at flat offset  (alpha_q*C + c*d_q + i_q) * B + b   with alpha_q = offset_rho + l*d
-__constant__ int c_q_alpha[64], c_q_d[64], c_q_ii[64];
+// coefficient q = (rho, i, l) of (b, c) lives at flat offset  (alpha_q*C + c*d_q + i_q) * B + b   with alpha_q = offset_rho + l*d.
+// The table is a compile-time constant: with the transform loops unrolled every row index is (constant*C + constant + c*constant),
+// i.e. scalar-ALU work on the wave-uniform channel c, and a lane only selects between the two candidates of its half-wave.
+struct QRows { int alpha[64], d[64], i[64]; };
+constexpr QRows make_qrows() {
+    QRows t{};
+    const int dims[NIRR] = {1, 3, 3, 4, 5};
+    int off = 0, q = 0;
+    for (int r = 0; r < NIRR; ++r) {
+        for (int i = 0; i < dims[r]; ++i)
+            for (int l = 0; l < dims[r]; ++l, ++q) { t.alpha[q] = off + l * dims[r]; t.d[q] = dims[r]; t.i[q] = i; }
+        off += dims[r] * dims[r];
+    }
+    for (; q < 64; ++q) { t.alpha[q] = 0; t.d[q] = 1; t.i[q] = 0; }
+    return t;
+}
+constexpr QRows kQ = make_qrows();
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <bool IN_SPATIAL, bool OUT_SPATIAL>
 __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
-    __shared__ int2 qtab[64];                      // per q: { alpha_q*C + i_q , d_q }
-    if (threadIdx.x < 64) qtab[threadIdx.x] = make_int2(c_q_alpha[threadIdx.x] * p.C + c_q_ii[threadIdx.x], c_q_d[threadIdx.x]);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int jn = lane & 31, h = lane >> 5;
-    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);   // wave-uniform: tile, c are scalars
     const int n_waves = (gridDim.x * 256) >> 6;
     const int B = p.B, C = p.C;
     const int n_tiles = C * p.tiles_per_c;
@@ -343,7 +370,9 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     if (!OUT_SPATIAL)
         for (int i = threadIdx.x; i < 32 * 2 * 64; i += 256) sA2[i] = p.A2[i];
     __syncthreads();
-    const bool has_add = p.Xadd != nullptr;
+    // row (of the [60*C][B] coefficient matrix) of coefficient q0 (first half-wave) / q1 (second half-wave) of channel c
+    // (the table entries are compile-time constants, the two candidate rows scalar-ALU values; a lane only selects)
+#define ROW_OF(Q0, Q1, c) (h ? (kQ.alpha[Q1] * C + kQ.i[Q1] + (c) * kQ.d[Q1]) : (kQ.alpha[Q0] * C + kQ.i[Q0] + (c) * kQ.d[Q0]))
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
     float cv[IN_SPATIAL ? 1 : 30], cn[IN_SPATIAL ? 1 : 30];
@@ -351,13 +380,11 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
         const int c = tile / p.tiles_per_c;
         int b = (tile - c * p.tiles_per_c) * 32 + jn;
         if (b >= B) b = B - 1;
-#pragma unroll
-        for (int s = 0; s < 30; ++s) {
-            const int2 qt = qtab[2 * s + h];
-            const size_t off = (size_t)(qt.x + c * qt.y) * B + b;
-            dst[s] = p.Xin[off];
-            if (has_add) dst[s] += p.Xadd[off];
-        }
+        static_for<30>([&](auto ic) {
+            constexpr int s = decltype(ic)::value;
+            constexpr int q0 = 2 * s, q1 = 2 * s + 1;
+            dst[s] = p.Xin[(size_t)ROW_OF(q0, q1, c) * B + b];
+        });
     };
     if (!IN_SPATIAL && wave_global < n_tiles) load_coefs(wave_global, cv);
 
@@ -436,16 +463,13 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                     o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 1) * 64 + lane], v[t][r], o[1], 0, 0, 0);
                 }
             if (valid) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int q = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (q < ROREG_G) {
-                            const int2 qt = qtab[q];
-                            p.Xout[(size_t)(qt.x + c * qt.y) * B + b] = o[t][r];
-                        }
+                static_for<32>([&](auto ic) {
+                    constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
+                    constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
+                    if constexpr (q0 < ROREG_G) {
+                        if (q1 < ROREG_G || h == 0) p.Xout[(size_t)ROW_OF(q0, (q1 < 64 ? q1 : 63), c) * B + b] = o[t][r];
                     }
+                });
             }
         }
         if (!IN_SPATIAL) {
@@ -455,36 +479,14 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     }
 }
 
+#undef ROW_OF
+
 float *g_A1 = nullptr, *g_A2 = nullptr;
 
 }  // namespace
 
 extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)], orthonormal */) {
     ROREG_REQUIRE(F_host, "roreg_set_fourier_tables: null table");
-    static const int dims[5] = {1, 3, 3, 4, 5};
-    signed char qi[64], ql[64], qr[64];
-    memset(qi, 0, 64); memset(ql, 0, 64); memset(qr, 0, 64);
-    int q = 0;
-    for (int r = 0; r < 5; ++r)
-        for (int i = 0; i < dims[r]; ++i)
-            for (int l = 0; l < dims[r]; ++l, ++q) { qr[q] = (signed char)r; qi[q] = (signed char)i; ql[q] = (signed char)l; }
-    int qa[64], qd[64], qii[64];
-    memset(qa, 0, sizeof(qa)); memset(qd, 0, sizeof(qd)); memset(qii, 0, sizeof(qii));
-    {
-        int off = 0, qq = 0;
-        for (int r = 0; r < 5; ++r) {
-            for (int i = 0; i < dims[r]; ++i)
-                for (int l = 0; l < dims[r]; ++l, ++qq) { qa[qq] = off + l * dims[r]; qd[qq] = dims[r]; qii[qq] = i; }
-            off += dims[r] * dims[r];
-        }
-        for (; qq < 64; ++qq) qd[qq] = 1;
-    }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_q_irr), qr, 64) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_q_i), qi, 64) != hipSuccess ||
-        hipMemcpyToSymbol(HIP_SYMBOL(c_q_l), ql, 64) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_q_alpha), qa, sizeof(qa)) != hipSuccess ||
-        hipMemcpyToSymbol(HIP_SYMBOL(c_q_d), qd, sizeof(qd)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_q_ii), qii, sizeof(qii)) != hipSuccess) {
-        roreg::set_error("roreg_set_fourier_tables: hipMemcpyToSymbol failed");
-        return 1;
-    }
     // A1[s][tile][lane] = F[q = 2s + (lane>>5)][g = tile*32 + (lane&31)]   (inverse transform: x(g) = sum_q F[q][g] coef[q])
     // A2[(t,r)][tile][lane] = F[q' = tile*32 + (lane&31)][g = t*32 + (r&3) + 8(r>>2) + 4(lane>>5)]
     static float A1[30 * 2 * 64], A2[32 * 2 * 64];
@@ -559,7 +561,7 @@ extern "C" size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host /* nu
     return n;
 }
 
-extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Wpack, int C, int O, int B,
+extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Add, const float *const *Wpack, int C, int O, int B,
                                 const int32_t *tiles_dev, int n_tiles, void *stream) {
     ROREG_REQUIRE(X && Out && Wpack && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm: bad arguments");
     ROREG_REQUIRE(C % 32 == 0, "roreg_irrep_gemm: C must be a multiple of 32 (got %d)", C);
@@ -567,7 +569,7 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
     static const int dims[5] = {1, 3, 3, 4, 5};
     GemmDescs p;
     for (int r = 0; r < 5; ++r) {
-        p.X[r] = X[r]; p.Out[r] = Out[r]; p.W[r] = reinterpret_cast<const float4 *>(Wpack[r]);
+        p.X[r] = X[r]; p.Out[r] = Out[r]; p.Add[r] = Add ? Add[r] : nullptr; p.W[r] = reinterpret_cast<const float4 *>(Wpack[r]);
         p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
     }
     constexpr int CT = 32;
@@ -580,14 +582,14 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
     return 0;
 }
 
-extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const void *const *Wsplit, int C, int O, int B,
+extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit, int C, int O, int B,
                                       const int32_t *tiles_dev, int n_tiles, void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_split: bad arguments");
     ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_split: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
     static const int dims[5] = {1, 3, 3, 4, 5};
     GemmSplitDescs p;
     for (int r = 0; r < 5; ++r) {
-        p.X[r] = X[r]; p.Out[r] = Out[r]; p.W[r] = reinterpret_cast<const bf16x8 *>(Wsplit[r]);
+        p.X[r] = X[r]; p.Out[r] = Out[r]; p.Add[r] = Add ? Add[r] : nullptr; p.W[r] = reinterpret_cast<const bf16x8 *>(Wsplit[r]);
         p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
     }
     constexpr int CT = 32;
@@ -600,7 +602,7 @@ extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, 
     return 0;
 }
 
-extern "C" int roreg_ft_nonlin(const float *Xin, const float *Xadd, const float *x_spatial, const float *bias, const float *bias2,
+extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
                                const int32_t *g_map, int Lout, int Lvalid, int B, int C, void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
@@ -611,7 +613,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *Xadd, const float 
     ROREG_REQUIRE(!g_map || (Lout >= Lvalid && Lvalid > 0 && Lout <= 64), "roreg_ft_nonlin: bad Lout/Lvalid");
     NonlinParams p;
     memset(&p, 0, sizeof(p));
-    p.Xin = Xin; p.Xadd = Xadd; p.Xout = Xout;
+    p.Xin = Xin; p.Xout = Xout;
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;

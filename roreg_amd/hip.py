@@ -51,9 +51,9 @@ PROTOTYPES = {
     'roreg_sinkhorn': (c_int, [_P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_set_fourier_tables': (c_int, [_P]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
-    'roreg_irrep_gemm': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
 }
 
 
@@ -462,9 +462,10 @@ def coef_views(buf, C, B):
 _tile_cache = {}
 
 
-def irrep_gemm(X_buf, Wpacks, C, O, B, split=None):
+def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None):
     """coefficients [60*C*B] -> [60*O*B] through the five per-irrep GEMMs.  split: the five 3xbf16-split weight tensors
-    (f32-accurate GEMM on the bf16 matrix cores) or None for the exact f32-input MFMA kernel."""
+    (f32-accurate GEMM on the bf16 matrix cores) or None for the exact f32-input MFMA kernel.  add: optional coefficient
+    buffer [60*O*B] summed onto the result in the epilogue (residual short cut in the irrep domain)."""
     out = torch.empty(60 * O * B, dtype=torch.float32, device=X_buf.device)
     key = (O, B)
     t = _tile_cache.get(key)
@@ -475,20 +476,21 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None):
         t = torch.from_numpy(host).cuda()
         _tile_cache[key] = t
     xv = coef_views(X_buf, C, B); ov = coef_views(out, O, B)
+    av = _ptr_array(coef_views(add, O, B)) if add is not None else None
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
     if split is not None:
-        _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), _ptr_array(split), C, O, B, _ptr(t, torch.int32), int(t.shape[0]),
+        _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, B, _ptr(t, torch.int32), int(t.shape[0]),
                                             _stream()), 'roreg_irrep_gemm_split')
     else:
-        _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), _ptr_array(Wpacks), C, O, B, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
+        _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(Wpacks), C, O, B, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
                'roreg_irrep_gemm')
     if PROFILE is not None:
         e1.record(); PROFILE.append((('irrep_gemm_split' if split is not None else 'irrep_gemm', B, C, O), e0, e1))
     return out
 
 
-def ft_nonlin(B, C, coef_in=None, coef_add=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
+def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
               g_map=None, Lout=60, Lvalid=60):
     ensure_fourier()
     dev = (coef_in if coef_in is not None else x_spatial).device
@@ -497,7 +499,7 @@ def ft_nonlin(B, C, coef_in=None, coef_add=None, x_spatial=None, bias=None, bias
     else:
         out = torch.empty(60 * C * B, dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
     scale, shift = bn if bn is not None else (None, None)
-    _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(coef_add, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
+    _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
                                  _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, _stream()), 'roreg_ft_nonlin')
     return out

@@ -75,10 +75,10 @@ class FourierGF:
         del X1
         X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2)
         del T1
-        T2 = hip.irrep_gemm(X2, self.l_2.wpack, 512, 256, B, split=self.l_2.wsplit if sp else None)
-        del X2
-        X3 = hip.ft_nonlin(B, 256, coef_in=T2, coef_add=T0, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3)
-        del T2, T0
+        T2 = hip.irrep_gemm(X2, self.l_2.wpack, 512, 256, B, split=self.l_2.wsplit if sp else None, add=T0)   # + identity short cut
+        del X2, T0
+        X3 = hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3)
+        del T2
         T3 = hip.irrep_gemm(X3, self.l_out.wpack, 256, 32, B, split=self.l_out.wsplit if sp else None)
         out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True)
         return out[:B0] if B0 != B else out

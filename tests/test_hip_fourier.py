@@ -47,6 +47,21 @@ def test_fourier_layer_equals_direct_group_conv(group):
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+def test_gemm_epilogue_residual_is_exact(group):
+    """Out = W.X + Add in the GEMM epilogue is bitwise the separately computed sum (both GEMM kernels)."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(7)
+    B, C, Oc = 100, 64, 96
+    L = _Layer(torch.nn.Conv2d(C, Oc, (1, 13)))
+    X = torch.from_numpy(rng.standard_normal(60 * C * B).astype(np.float32)).cuda()
+    A = torch.from_numpy(rng.standard_normal(60 * Oc * B).astype(np.float32)).cuda()
+    for sp in (None, L.wsplit):
+        plain = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp)
+        fused = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp, add=A)
+        assert torch.equal(fused, plain + A)
+
+
 def test_gf_fourier_vs_direct_vs_golden(group):
     from roreg_amd.network import name2network
     z = load_golden('gf_forward')
