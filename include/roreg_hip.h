@@ -75,6 +75,20 @@ int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
                     const float *tgt, const int64_t *tgt_rows, int n, int F,
                     int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream);
 
+/* The mutual matcher for a batch of pairs in three launches (test/matcher.py:90-107 for every pair of a scene).  Task p:
+ * sampled descriptors desc0[rows0[i]] (m0 rows) and desc1[rows1[j]] (m1 rows), F = 32, rows NULL = identity; both directions are
+ * searched with the exact formula of roreg_nn_search and the mutual pairs (rows0 value, rows1 value) are written in increasing
+ * i to match_out + p*pitch*2 (pitch = max_m rounded up to even), their number to counts_out[p].  tasks_dev is a DEVICE array;
+ * max_m >= every m0, m1.  workspace: roreg_mutual_match_batch_workspace(n_tasks, max_m) bytes. */
+typedef struct {
+    const float *desc0, *desc1;
+    const int64_t *rows0, *rows1;
+    int32_t m0, m1;
+} roreg_match_task;
+size_t roreg_mutual_match_batch_workspace(int n_tasks, int max_m);
+int roreg_mutual_match_batch(const roreg_match_task *tasks_dev, int n_tasks, int max_m, int64_t *match_out, int32_t *counts_out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* k nearest (k<=8) targets per source in increasing distance, first index on ties; idx_out int64 [m,k].
  * Replaces KNN(k>=2) -> find_knn_gpu (utils/knn_search.py:68-103), used by NMS_sample with F=3, k=5
  * (test/matcher.py:21-23). */
@@ -140,6 +154,25 @@ int roreg_refine(const double *k0, const double *k1, const double *w, int M,
                  const double *Trans, const int64_t *hyp_rows, const int32_t *best,
                  double dist, double *T_out, double *stats_out /* optional f64[16]: H(9), c0(3), c1(3), sum w */,
                  void *stream);
+
+/* The estimator tail of every pair of a scene in five launches: gather the matched keypoints, score the <= max_iter hypotheses
+ * (one wavefront each), first strictly-greatest overlap, refine at 2*ird from the winning local transform, refine at ird from that
+ * (test/estimator.py:405-443 per pair; same arithmetic order as roreg_ransac_score / roreg_refine, so results are bit-identical).
+ * tasks_dev: DEVICE array; koff = prefix sum of M over the tasks; total_M = sum of M; max_M / max_H >= every M / H.
+ * Outputs per task: best_out[p] (hypothesis index or -1), T1/T2 [p][16] row-major 4x4, stats1/stats2 [p][16] as roreg_refine. */
+typedef struct {
+    const double *keys0, *keys1;   /* keypoints of the two clouds [*,3] f64 */
+    const int64_t *matches;        /* [M,2] interleaved rows (cloud 0, cloud 1) */
+    const double *w;               /* [M] match scores, NULL = ones (test/matcher.py:109) */
+    const double *Trans;           /* [*,3,4] f64 local transforms */
+    const int64_t *hyp_rows;       /* [H] rows of Trans in hypothesis order, NULL = identity */
+    int32_t M, H;
+    int64_t koff;
+} roreg_ransac_task;
+size_t roreg_ransac_batch_workspace(int n_tasks, long long total_M, int max_H);
+int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long long total_M, int max_M, int max_H, double ird,
+                       int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* Gather rows: out[i] = src[rows[i]] for f64 [.,3] keypoints (estimator.py:407-408). */
 int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream);

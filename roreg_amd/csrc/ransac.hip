@@ -31,12 +31,15 @@ __device__ __forceinline__ bool point_inlier(const double *__restrict__ T, doubl
     return d2 < thr2;
 }
 
-__global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restrict__ k0, const double *__restrict__ k1,
-                                                           const double *__restrict__ w, int M, const double *__restrict__ Trans,
-                                                           const int64_t *__restrict__ hyp_rows, int H, double thr2,
-                                                           double *__restrict__ overlap, uint8_t *__restrict__ mask) {
+// w == nullptr means "all weights are 1.0" (the mutual matcher's scores, test/matcher.py:109): adding the literal 1.0 is the same
+// floating-point operation as adding a loaded 1.0.
+__device__ __forceinline__ double weight_of(const double *__restrict__ w, int i) { return w ? w[i] : 1.0; }
+
+__device__ __forceinline__ void ransac_score_body(const double *__restrict__ k0, const double *__restrict__ k1,
+                                                  const double *__restrict__ w, int M, const double *__restrict__ Trans,
+                                                  const int64_t *__restrict__ hyp_rows, int H, double thr2, int h,
+                                                  double *__restrict__ overlap, uint8_t *__restrict__ mask) {
     const int lane = threadIdx.x & 63;
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= H) return;
     const size_t row = hyp_rows ? (size_t)hyp_rows[h] : (size_t)h;
     double T[12];
@@ -45,15 +48,22 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restr
     double acc = 0.0;
     for (int i = lane; i < M; i += 64) {
         const bool in = point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2);
-        if (in) acc += w[i];
+        if (in) acc += weight_of(w, i);
         if (mask) mask[(size_t)h * M + i] = in ? 1 : 0;
     }
     acc = wave_sum(acc);
     if (lane == 0) overlap[h] = acc / (double)M;
 }
 
+__global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restrict__ k0, const double *__restrict__ k1,
+                                                           const double *__restrict__ w, int M, const double *__restrict__ Trans,
+                                                           const int64_t *__restrict__ hyp_rows, int H, double thr2,
+                                                           double *__restrict__ overlap, uint8_t *__restrict__ mask) {
+    ransac_score_body(k0, k1, w, M, Trans, hyp_rows, H, thr2, blockIdx.x * 4 + (threadIdx.x >> 6), overlap, mask);
+}
+
 // first index of the strictly greatest overlap (> 0), as the reference's running '>' scan
-__global__ __launch_bounds__(256) void first_best_kernel(const double *__restrict__ overlap, int H, int32_t *__restrict__ best) {
+__device__ __forceinline__ void first_best_body(const double *__restrict__ overlap, int H, int32_t *__restrict__ best) {
     __shared__ double sv[256];
     __shared__ int si[256];
     double bv = 0.0;
@@ -73,6 +83,10 @@ __global__ __launch_bounds__(256) void first_best_kernel(const double *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) *best = (sv[0] > 0.0 && si[0] != 0x7fffffff) ? si[0] : -1;
+}
+
+__global__ __launch_bounds__(256) void first_best_kernel(const double *__restrict__ overlap, int H, int32_t *__restrict__ best) {
+    first_best_body(overlap, H, best);
 }
 
 // ---- 3x3 SVD polar factor R = U V^T by one-sided Jacobi (fp64) ----------------------------------------
@@ -151,11 +165,11 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ k0, const double *__restrict__ k1,
-                                                     const double *__restrict__ w, int M, const double *__restrict__ T_in,
-                                                     int t_stride, const double *__restrict__ Trans,
-                                                     const int64_t *__restrict__ hyp_rows, const int32_t *__restrict__ best,
-                                                     double thr2, double *__restrict__ T_out, double *__restrict__ stats) {
+__device__ __forceinline__ void refine_body(const double *__restrict__ k0, const double *__restrict__ k1,
+                                            const double *__restrict__ w, int M, const double *__restrict__ T_in,
+                                            int t_stride, const double *__restrict__ Trans,
+                                            const int64_t *__restrict__ hyp_rows, const int32_t *__restrict__ best,
+                                            double thr2, double *__restrict__ T_out, double *__restrict__ stats) {
     __shared__ double red[4];
     __shared__ double Ts[12];
     const int tid = threadIdx.x;
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     double sw = 0, a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
     for (int i = tid; i < M; i += 256) {
         if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) {
-            const double wi = w[i];
+            const double wi = weight_of(w, i);
             sw += wi;
             a0 += wi * k0[3 * i]; a1 += wi * k0[3 * i + 1]; a2 += wi * k0[3 * i + 2];
             b0 += wi * k1[3 * i]; b1 += wi * k1[3 * i + 1]; b2 += wi * k1[3 * i + 2];
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < M; i += 256) {
         if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) {
-            const double wi = w[i] / sw;
+            const double wi = weight_of(w, i) / sw;
             const double ax = k0[3 * i] - c0x, ay = k0[3 * i + 1] - c0y, az = k0[3 * i + 2] - c0z;
             const double bx = k1[3 * i] - c1x, by = k1[3 * i + 1] - c1y, bz = k1[3 * i + 2] - c1z;
             h[0] += wi * ax * bx; h[1] += wi * ax * by; h[2] += wi * ax * bz;
@@ -218,9 +232,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         for (int i = 0; i < M && n < 7; ++i)
             if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) id[n++] = i;
         double ssum = 0.0;
-        for (int q = 0; q < n; ++q) ssum = ssum + w[id[q]];
+        for (int q = 0; q < n; ++q) ssum = ssum + weight_of(w, id[q]);
         double sk[7], c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
-        for (int q = 0; q < n; ++q) sk[q] = w[id[q]] / ssum;
+        for (int q = 0; q < n; ++q) sk[q] = weight_of(w, id[q]) / ssum;
         for (int q = 0; q < n; ++q)
             for (int d = 0; d < 3; ++d) {
                 const double pa = k0[3 * id[q] + d] * sk[q], pb = k1[3 * id[q] + d] * sk[q];
@@ -255,6 +269,62 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ k0, const double *__restrict__ k1,
+                                                     const double *__restrict__ w, int M, const double *__restrict__ T_in,
+                                                     int t_stride, const double *__restrict__ Trans,
+                                                     const int64_t *__restrict__ hyp_rows, const int32_t *__restrict__ best,
+                                                     double thr2, double *__restrict__ T_out, double *__restrict__ stats) {
+    refine_body(k0, k1, w, M, T_in, t_stride, Trans, hyp_rows, best, thr2, T_out, stats);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched estimator tail: every pair of a scene in five launches (gather, score, first-best, refine x2).  A pair's kernels are
+// tiny (refine is ONE workgroup, the scoring ~250), so per-pair launches leave the chip idle; here blockIdx.y is the pair.
+struct RansacTask {                // mirrors roreg_ransac_task (include/roreg_hip.h)
+    const double *keys0, *keys1;   // the two clouds' keypoints [*,3]
+    const int64_t *matches;        // [M,2] interleaved (row in cloud 0, row in cloud 1)
+    const double *w;               // [M] or null (= ones)
+    const double *Trans;           // [*,3,4] local transforms
+    const int64_t *hyp_rows;       // [H] rows of Trans, or null (= identity)
+    int32_t M, H;
+    int64_t koff;                  // first row of this pair in the gathered keypoint workspace
+};
+
+__global__ __launch_bounds__(256) void ransac_gather_batch_kernel(const RansacTask *__restrict__ tasks, double *__restrict__ k0_all,
+                                                                  double *__restrict__ k1_all) {
+    const RansacTask t = tasks[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.M) return;
+    const int64_t r0 = t.matches[2 * i], r1 = t.matches[2 * i + 1];
+    double *a = k0_all + (t.koff + i) * 3, *b = k1_all + (t.koff + i) * 3;
+    a[0] = t.keys0[3 * r0]; a[1] = t.keys0[3 * r0 + 1]; a[2] = t.keys0[3 * r0 + 2];
+    b[0] = t.keys1[3 * r1]; b[1] = t.keys1[3 * r1 + 1]; b[2] = t.keys1[3 * r1 + 2];
+}
+
+__global__ __launch_bounds__(256) void ransac_score_batch_kernel(const RansacTask *__restrict__ tasks, const double *__restrict__ k0_all,
+                                                                 const double *__restrict__ k1_all, double thr2, int pitch_h,
+                                                                 double *__restrict__ overlap_all) {
+    const RansacTask t = tasks[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= t.H) return;
+    ransac_score_body(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, t.Trans, t.hyp_rows, t.H, thr2,
+                      blockIdx.x * 4 + (threadIdx.x >> 6), overlap_all + (size_t)blockIdx.y * pitch_h, nullptr);
+}
+
+__global__ __launch_bounds__(256) void first_best_batch_kernel(const RansacTask *__restrict__ tasks, int pitch_h,
+                                                               const double *__restrict__ overlap_all, int32_t *__restrict__ best_all) {
+    first_best_body(overlap_all + (size_t)blockIdx.x * pitch_h, tasks[blockIdx.x].H, best_all + blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void refine_batch_kernel(const RansacTask *__restrict__ tasks, const double *__restrict__ k0_all,
+                                                           const double *__restrict__ k1_all, const double *__restrict__ T_in_all,
+                                                           const int32_t *__restrict__ best_all, double thr2,
+                                                           double *__restrict__ T_out_all, double *__restrict__ stats_all) {
+    const RansacTask t = tasks[blockIdx.x];
+    refine_body(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, T_in_all ? T_in_all + (size_t)blockIdx.x * 16 : nullptr, 4, t.Trans,
+                t.hyp_rows, T_in_all ? nullptr : best_all + blockIdx.x, thr2, T_out_all + (size_t)blockIdx.x * 16,
+                stats_all + (size_t)blockIdx.x * 16);
+}
+
 }  // namespace
 
 extern "C" int roreg_ransac_score(const double *k0, const double *k1, const double *w, int M, const double *Trans,
@@ -278,5 +348,33 @@ extern "C" int roreg_refine(const double *k0, const double *k1, const double *w,
     hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(256), 0, roreg::as_stream(stream), k0, k1, w, M, T_in, t_in_stride, Trans,
                        hyp_rows, best, dist * dist, T_out, stats_out);
     ROREG_CHECK_LAUNCH("roreg_refine");
+    return 0;
+}
+
+extern "C" size_t roreg_ransac_batch_workspace(int n_tasks, long long total_M, int max_H) {
+    return ((size_t)total_M * 6 + (size_t)n_tasks * (size_t)(max_H > 0 ? max_H : 1)) * sizeof(double);
+}
+
+extern "C" int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long long total_M, int max_M, int max_H, double ird,
+                                  int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_tasks == 0) return 0;
+    ROREG_REQUIRE(tasks_dev && best_out && T1_out && stats1_out && T2_out && stats2_out && workspace && n_tasks > 0 && max_M > 0 && max_H >= 0,
+                  "roreg_ransac_batch: bad arguments");
+    ROREG_REQUIRE(workspace_bytes >= roreg_ransac_batch_workspace(n_tasks, total_M, max_H), "roreg_ransac_batch: workspace too small");
+    static_assert(sizeof(roreg_ransac_task) == sizeof(RansacTask), "roreg_ransac_task layout");
+    hipStream_t s = roreg::as_stream(stream);
+    const RansacTask *tasks = reinterpret_cast<const RansacTask *>(tasks_dev);
+    double *k0 = reinterpret_cast<double *>(workspace), *k1 = k0 + (size_t)total_M * 3, *overlap = k1 + (size_t)total_M * 3;
+    const int pitch_h = max_H > 0 ? max_H : 1;
+    hipLaunchKernelGGL(ransac_gather_batch_kernel, dim3((max_M + 255) / 256, n_tasks), dim3(256), 0, s, tasks, k0, k1);
+    if (max_H > 0)
+        hipLaunchKernelGGL(ransac_score_batch_kernel, dim3((max_H + 3) / 4, n_tasks), dim3(256), 0, s, tasks, k0, k1, ird * ird, pitch_h, overlap);
+    hipLaunchKernelGGL(first_best_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, pitch_h, overlap, best_out);
+    hipLaunchKernelGGL(refine_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
+                       (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);
+    hipLaunchKernelGGL(refine_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)T1_out, (const int32_t *)nullptr,
+                       ird * ird, T2_out, stats2_out);
+    ROREG_CHECK_LAUNCH("roreg_ransac_batch");
     return 0;
 }

@@ -38,14 +38,62 @@ class PairResult:
     scores: np.ndarray = None
 
 
+class _Lanes:
+    """Side HIP streams for the per-pair launches.  A pair's matcher / RANSAC kernels are small (refine is ONE workgroup, the
+    mutual check one, Des2R and the hypothesis scoring ~250 on 256 CUs), so pairs are issued round-robin on a few streams and
+    the hardware queues overlap them; the big batched launches (GF, ET trunk) stay on the caller's stream.  fork(): lanes wait
+    for everything issued so far; join(): the caller's stream waits for the lanes.  Tensors that cross streams are kept
+    referenced by the caller until its final host sync, so the caching allocator never recycles them early."""
+
+    def __init__(self, n=4):
+        self.streams = [torch.cuda.Stream() for _ in range(n)]
+
+    def fork(self):
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(main)
+
+    def lane(self, i):
+        return torch.cuda.stream(self.streams[i % len(self.streams)])
+
+    def join(self):
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            main.wait_stream(s)
+
+
 class RegistrationEngine:
-    def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None):
+    def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None, n_lanes=4):
         self.cfg = cfg
         self.gf = gf_net
         self.et = et_net
         self.rd = rd_net            # detector_eqv_test (needed when cfg.RD)
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
+        self.lanes = _Lanes(n_lanes) if n_lanes > 1 else None
+        self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
+
+    def _mark(self, name, t0):
+        """Diagnostics: with phase_ms set, synchronise and add the wall time since t0 to phase `name`; returns the new t0."""
+        if self.phase_ms is None:
+            return t0
+        import time
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.phase_ms[name] = self.phase_ms.get(name, 0.0) + 1e3 * (t1 - t0)
+        return t1
+
+    def _fork(self):
+        if self.lanes is not None:
+            self.lanes.fork()
+
+    def _join(self):
+        if self.lanes is not None:
+            self.lanes.join()
+
+    def _lane(self, i):
+        import contextlib
+        return self.lanes.lane(i) if self.lanes is not None else contextlib.nullcontext()
 
     def set_gemm_mode(self, mode):
         """'f32': exact f32-input MFMA GEMMs (bitwise an fmaf chain);  'split': 3 x bf16 split GEMMs (f32-accurate)."""
@@ -153,21 +201,27 @@ class RegistrationEngine:
                 torch.empty((rows, 128, 60), dtype=torch.float32, device='cuda')
             parts = []
             o = 0
+            self._fork()
             for q in range(i, j):
                 c0, c1, matches = items[q]
                 M = matches.shape[0]
-                rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
-                dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0)
-                if M:
-                    hip.et_gather(c0.before, c1.before, c0.eqv, c1.eqv, dr, rows0=rows0, rows1=rows1, out=x_all[o:o + M])
+                with self._lane(q):
+                    rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
+                    dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0)
+                    if M:
+                        hip.et_gather(c0.before, c1.before, c0.eqv, c1.eqv, dr, rows0=rows0, rows1=rows1, out=x_all[o:o + M])
                 parts.append((dr, rows0, rows1, o, M))
                 o += M
+            self._join()
             with torch.no_grad():
                 q_all = self.et.trunk_and_head(x_all) if rows else torch.empty((0, 4), dtype=torch.float32, device='cuda')
+            self._fork()
             for q, (dr, rows0, rows1, o, M) in zip(range(i, j), parts):
                 c0, c1, _ = items[q]
-                Trans = hip.quat_to_trans(q_all[o:o + M].contiguous(), dr, c0.keys, c1.keys, rows0=rows0, rows1=rows1)
+                with self._lane(q):
+                    Trans = hip.quat_to_trans(q_all[o:o + M].contiguous(), dr, c0.keys, c1.keys, rows0=rows0, rows1=rows1)
                 out[q] = (dr, Trans, rows0, rows1)
+            self._join()                                  # q_all / x_all may be recycled by the next group only after the lanes read them
             i = j
         return out
 
@@ -196,8 +250,13 @@ class RegistrationEngine:
         Returns [PairResult]."""
         keynum = self.cfg.keynum if keynum is None else keynum
         max_iter = self.cfg.max_iter if max_iter is None else max_iter
+        import time
+        if self.phase_ms is not None:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
         used = sorted({int(i) for p in pair_ids for i in p})
         clouds = dict(zip(used, self.extract_many([feats[i] for i in used], [keys[i] for i in used])))
+        t0 = self._mark('extract', t0)
         if self.cfg.RD:
             for i in used:
                 self.detect(clouds[i])
@@ -211,20 +270,27 @@ class RegistrationEngine:
                 full.append((c0, c1, m)); all_scores.append(sc)
             counts = np.array([m.shape[0] for _, _, m in full])
         else:
-            pend = []
-            for a, b in pair_ids:
+            # every pair's sampling first (host RNG in the reference's order), ONE upload of all row lists, then the whole
+            # matcher stage in three launches
+            samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum) for a, b in pair_ids]   # host; runs under the extractor's kernels
+            flat = np.concatenate([np.ascontiguousarray(x, np.int64) for s in samples for x in s]) if samples else np.zeros(0, np.int64)
+            flat_dev = torch.from_numpy(flat).cuda()
+            tasks, o = [], 0
+            for (a, b), (s0, s1) in zip(pair_ids, samples):
                 c0, c1 = clouds[int(a)], clouds[int(b)]
-                s0, s1 = self.sample(c0, c1, keynum)
-                pend.append(self.match_mutual(c0, c1, s0, s1))
-            counts = torch.cat([c for _, c in pend]).cpu().numpy()          # the one sync of the matcher stage
-            full = [(clouds[int(a)], clouds[int(b)], mbuf[:int(M)]) for (a, b), (mbuf, _), M in zip(pair_ids, pend, counts)]
+                d0 = flat_dev[o:o + len(s0)]; o += len(s0)
+                d1 = flat_dev[o:o + len(s1)]; o += len(s1)
+                tasks.append((c0.inv, c1.inv, d0, d1))
+            mbuf, cnt = hip.mutual_match_batch(tasks)
+            counts = cnt.cpu().numpy()                                       # the one sync of the matcher stage
+            full = [(clouds[int(a)], clouds[int(b)], mbuf[q, :int(M)]) for q, ((a, b), M) in enumerate(zip(pair_ids, counts))]
             all_scores = [None] * len(full)
+        t0 = self._mark('match', t0)
         # stage 4: all pairs.  One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
         # (estimator.py:423-425), and that draw depends on M (and, with --RM, on the scores) alone, so the hypothesis order is drawn
         # first (same global-RNG calls in the same order as the reference) and Des2R + ET run on the selected correspondences only.
         # The registration result is identical; the reference computes all M local transforms because its stages are coupled through
         # Trans_pre files.  all_local_transforms=True evaluates every correspondence like the reference does.
-        T_all, best_all, aux_all = [], [], []
         hyps = []
         for (c0, c1, matches), sc in zip(full, all_scores):
             rows = np.arange(matches.shape[0])
@@ -239,31 +305,32 @@ class RegistrationEngine:
         else:
             items = [(c0, c1, m[torch.from_numpy(h).cuda()]) for (c0, c1, m), h in zip(full, hyps)]
         lts = self.local_transforms_many(items)
-        local = []
+        t0 = self._mark('local_transforms', t0)
+        # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
+        rt, w_all, hyp_all = [], [], []
         for (c0, c1, matches), hsel, sc, (dr, Trans, _, _) in zip(full, hyps, all_scores, lts):
-            M = matches.shape[0]
-            rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
-            hyp = torch.from_numpy(hsel).cuda() if all_local_transforms else None          # Trans already in hypothesis order
-            if sc is None:
-                w = torch.ones(M, dtype=torch.float64, device='cuda')      # matcher.py:109: scores = ones(M)
-            else:
-                w = torch.from_numpy(sc.astype(np.float64)).cuda()
-            T2, best, aux = self.ransac(c0, c1, rows0, rows1, Trans, w, hyp)
-            T_all.append(T2); best_all.append(best); aux_all.append((w,) + aux)
-            local.append((c0, c1, matches))
-        T_host = torch.stack(T_all).cpu().numpy()                           # the one sync of the estimator stage
-        best_host = torch.cat(best_all).cpu().numpy()
-        st_host = torch.stack([torch.stack([a[3], a[4]]) for a in aux_all]).cpu().numpy()
+            hyp = torch.from_numpy(hsel).cuda() if all_local_transforms else None          # else Trans is already in hypothesis order
+            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()     # None = ones(M)  (matcher.py:109)
+            rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w); hyp_all.append(hyp)
+        ird = float(self.cfg.ransac_ird)
+        best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird)
+        t0 = self._mark('ransac_issue', t0)
+        T_host = T2_d.cpu().numpy()                                         # the one sync of the estimator stage
+        best_host = best_d.cpu().numpy()
+        st_host = torch.stack([st1_d, st2_d], 1).cpu().numpy()
         # The device closes each refinement with its own 3x3 SVD.  When a cross-covariance is rank-deficient
         # (<= 2 inliers: a failed registration) U V^T is not unique and the reference's value is LAPACK's; redo
         # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.
         from .test.estimator import _kabsch_host, _dev64
-        ird = float(self.cfg.ransac_ird)
-        for i, (w, k0, k1, _, _) in enumerate(aux_all):
+        for i, (c0, c1, matches) in enumerate(full):
             if hip.stats_rank_deficient(st_host[i, 0]) or hip.stats_rank_deficient(st_host[i, 1]):
+                k0 = hip.gather_rows_f64(c0.keys, matches[:, 0].contiguous()); k1 = hip.gather_rows_f64(c1.keys, matches[:, 1].contiguous())
+                w = w_all[i] if w_all[i] is not None else torch.ones(matches.shape[0], dtype=torch.float64, device='cuda')
                 T1 = _kabsch_host(st_host[i, 0])
                 _, st = hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)
                 T_host[i] = _kabsch_host(st)
+        local = full
+        t0 = self._mark('ransac_finish', t0)
         out = []
         for i, (a, b) in enumerate(pair_ids):
             out.append(PairResult(a, b, int(counts[i]), T_host[i], max(int(best_host[i]), 0),

@@ -33,11 +33,15 @@ PROTOTYPES = {
     'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
     'roreg_mutual_matches': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P]),
+    'roreg_mutual_match_batch_workspace': (c_size_t, [c_int, c_int]),
+    'roreg_mutual_match_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     'roreg_des2r': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_et_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
     'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
     'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
+    'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
+    'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'roreg_topk_dot_workspace_size': (c_size_t, [c_int, c_int, c_int]),
@@ -240,6 +244,76 @@ def mutual_matches(nn01, nn10, sample0=None, sample1=None):
     cnt = torch.zeros(1, dtype=torch.int32, device=nn01.device)
     _check(lib().roreg_mutual_matches(_ptr(nn01, torch.int64), _ptr(nn10, torch.int64), m, _ptr(sample0, torch.int64),
                                       _ptr(sample1, torch.int64), _ptr(out), _ptr(cnt), _stream()), 'roreg_mutual_matches')
+    return out, cnt
+
+
+_RANSAC_TASK = np.dtype([('keys0', np.uint64), ('keys1', np.uint64), ('matches', np.uint64), ('w', np.uint64), ('Trans', np.uint64),
+                         ('hyp_rows', np.uint64), ('M', np.int32), ('H', np.int32), ('koff', np.int64)])
+
+
+def ransac_batch(tasks, ird):
+    """tasks: [(keys0 [*,3] f64, keys1 [*,3] f64, matches [M,2] int64, w [M] f64 or None, Trans [*,3,4] f64, hyp_rows int64 [H] or None)]
+    (device tensors).  One-shot RANSAC + the two refinements of every task in five launches ->
+    (best int32 [n], T1 [n,4,4], stats1 [n,16], T2 [n,4,4], stats2 [n,16]) device tensors."""
+    n = len(tasks)
+    dev = tasks[0][0].device if n else torch.device('cuda')
+    best = torch.empty(n, dtype=torch.int32, device=dev)
+    T1 = torch.empty((n, 4, 4), dtype=torch.float64, device=dev); T2 = torch.empty_like(T1)
+    st1 = torch.empty((n, 16), dtype=torch.float64, device=dev); st2 = torch.empty_like(st1)
+    if n == 0:
+        return best, T1, st1, T2, st2
+    table = np.zeros(n, _RANSAC_TASK)
+    koff = 0
+    for i, (k0, k1, m, w, Tr, hr) in enumerate(tasks):
+        _ptr(k0, torch.float64); _ptr(k1, torch.float64); _ptr(m, torch.int64); _ptr(Tr, torch.float64)
+        if w is not None:
+            _ptr(w, torch.float64)
+        if hr is not None:
+            _ptr(hr, torch.int64)
+        M = int(m.shape[0]); H = int(hr.shape[0]) if hr is not None else int(Tr.shape[0])
+        table[i] = (k0.data_ptr(), k1.data_ptr(), m.data_ptr() if M else 0, w.data_ptr() if w is not None else 0, Tr.data_ptr() if H else 0,
+                    hr.data_ptr() if hr is not None else 0, M, H, koff)
+        koff += M
+    max_M = int(table['M'].max()); max_H = int(table['H'].max())
+    tdev = torch.from_numpy(table.view(np.uint8).reshape(n, _RANSAC_TASK.itemsize).copy()).to(dev)
+    ws_n = lib().roreg_ransac_batch_workspace(n, koff, max_H)
+    ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.float64, device=dev)
+    _check(lib().roreg_ransac_batch(_ptr(tdev), n, koff, max(max_M, 1), max_H, float(ird), _ptr(best), _ptr(T1), _ptr(st1), _ptr(T2), _ptr(st2),
+                                    _ptr(ws), ws_n, _stream()), 'roreg_ransac_batch')
+    return best, T1, st1, T2, st2
+
+
+_MATCH_TASK = np.dtype([('desc0', np.uint64), ('desc1', np.uint64), ('rows0', np.uint64), ('rows1', np.uint64), ('m0', np.int32), ('m1', np.int32)])
+
+
+def mutual_match_batch(tasks):
+    """tasks: [(desc0 [*,32] f32, desc1 [*,32] f32, rows0 int64 [m0] or None, rows1 int64 [m1] or None)] (device tensors).
+    The mutual matcher of every task in three launches -> (match buffer int64 [n_tasks, pitch, 2], counts int32 [n_tasks]);
+    rows [0,count) of task p are its mutual pairs (rows0 value, rows1 value) in increasing source order."""
+    n = len(tasks)
+    table = np.zeros(n, _MATCH_TASK)
+    keep = []
+    for i, (d0, d1, r0, r1) in enumerate(tasks):
+        if d0.shape[1] != 32 or d1.shape[1] != 32:
+            raise HipError('mutual_match_batch: descriptors must be [*,32] float32')
+        for t in (d0, d1):
+            _ptr(t, torch.float32)
+        table[i] = (d0.data_ptr(), d1.data_ptr(), r0.data_ptr() if r0 is not None else 0, r1.data_ptr() if r1 is not None else 0,
+                    r0.shape[0] if r0 is not None else d0.shape[0], r1.shape[0] if r1 is not None else d1.shape[0])
+        for t in (r0, r1):
+            if t is not None:
+                _ptr(t, torch.int64)
+    dev = tasks[0][0].device if n else torch.device('cuda')
+    max_m = int(max([0] + [max(int(t['m0']), int(t['m1'])) for t in table]))
+    pitch = (max_m + 1) & ~1
+    out = torch.empty((n, max(pitch, 1), 2), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    if n == 0:
+        return out, cnt
+    tdev = torch.from_numpy(table.view(np.uint8).reshape(n, _MATCH_TASK.itemsize).copy()).to(dev)
+    ws_n = lib().roreg_mutual_match_batch_workspace(n, max_m)
+    ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.int64, device=dev)
+    _check(lib().roreg_mutual_match_batch(_ptr(tdev), n, max_m, _ptr(out), _ptr(cnt), _ptr(ws), ws_n, _stream()), 'roreg_mutual_match_batch')
     return out, cnt
 
 

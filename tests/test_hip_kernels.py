@@ -173,6 +173,44 @@ def test_mutual_matches_bit_exact():
         assert np.array_equal(out[:c].cpu().numpy(), want)
 
 
+def test_mutual_match_batch_equals_oracle_and_per_pair_calls():
+    """The batched matcher (paired-target packed-f32 scan) is bit-identical to the oracle and to the per-pair entry points:
+    ragged task sizes, odd target counts, identity row lists, a one-row cloud, duplicate descriptors (first-minimum ties)."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(11)
+
+    def cloud(n):
+        a = rng.standard_normal((n, 32)).astype(np.float32)
+        return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    base = cloud(700)
+    clouds = [base, (base[rng.permutation(700)[:613]] + 0.05 * rng.standard_normal((613, 32))).astype(np.float32), cloud(1), cloud(255),
+              np.concatenate([base[:100], base[:100]])]                       # last: every descriptor twice -> distance ties
+    specs = [(0, 1, 'perm', 'perm'), (1, 0, None, 'perm'), (0, 4, 'perm', None), (2, 3, None, None), (3, 2, 'perm', None), (4, 4, None, None)]
+    tasks, host = [], []
+    for a, b, ra, rb in specs:
+        A, B = clouds[a], clouds[b]
+        r0 = rng.permutation(A.shape[0])[:max(1, A.shape[0] - 3)] if ra else None
+        r1 = rng.permutation(B.shape[0])[:max(1, B.shape[0] - 2)] if rb else None
+        tasks.append((cu(A), cu(B), cu(r0) if r0 is not None else None, cu(r1) if r1 is not None else None))
+        host.append((A, B, r0, r1))
+    mbuf, cnt = hip.mutual_match_batch(tasks)
+    cnt = cnt.cpu().numpy(); mbuf = mbuf.cpu().numpy()
+    for q, ((A, B, r0, r1), t) in enumerate(zip(host, tasks)):
+        sa = A if r0 is None else A[r0]; sb = B if r1 is None else B[r1]
+        _, nn01 = O.knn(sb, sa, 1); _, nn10 = O.knn(sa, sb, 1)
+        want = O.mutual_check(nn01, nn10)
+        i0 = np.arange(sa.shape[0]) if r0 is None else r0; i1 = np.arange(sb.shape[0]) if r1 is None else r1
+        want = np.stack([i0[want[:, 0]], i1[want[:, 1]]], 1)
+        assert cnt[q] == want.shape[0], q
+        assert np.array_equal(mbuf[q, :cnt[q]], want), q
+        # and the per-pair C-ABI entry points give the same
+        a01 = hip.nn_search(t[0], t[1], src_rows=t[2], tgt_rows=t[3]); a10 = hip.nn_search(t[1], t[0], src_rows=t[3], tgt_rows=t[2])
+        out, c = hip.mutual_matches(a01, a10, t[2], t[3])
+        assert int(c.item()) == cnt[q] and np.array_equal(out[:cnt[q]].cpu().numpy(), mbuf[q, :cnt[q]])
+    e_buf, e_cnt = hip.mutual_match_batch([])
+    assert e_cnt.numel() == 0
+
+
 def test_des2r_bit_exact(group):
     from roreg_amd import hip
     z = load_golden('des2r')
@@ -272,3 +310,46 @@ def test_ransac_hypothesis_subset_and_full_size_properties():
     assert ovh[b] == ovh.max() and b == int(np.argmax(ovh))
     assert np.array_equal(mask[b].cpu().numpy().astype(bool), O.inlier_mask(k0, k1, Tr[rows[b]], 0.1))
     assert abs(ovh[b] - (~bad).mean()) < 0.05
+
+
+def test_ransac_batch_equals_per_pair_calls():
+    """The batched estimator tail (five launches for all pairs) is bitwise the per-pair entry points: ragged M and H, weights
+    given / implied ones, hypothesis row lists given / identity, a failed pair (no consistent transform), a 3-match pair."""
+    from roreg_amd import hip
+    from roreg_amd.group import tables
+    rng = np.random.default_rng(21)
+    R60 = tables().R
+    keys = [rng.uniform(0, 3, (900, 3)) for _ in range(3)]
+    specs = [(0, 1, 700, 300, True, True, 0.3), (1, 2, 333, None, False, False, 0.5), (2, 0, 3, None, True, False, 0.0),
+             (0, 2, 512, 100, False, True, 1.0), (1, 0, 64, 64, True, True, 0.2)]
+    tasks, per_pair = [], []
+    for a, b, M, H, use_w, use_rows, bad_frac in specs:
+        g = int(rng.integers(0, 60)); t = rng.uniform(-0.5, 0.5, 3)
+        r1 = rng.permutation(900)[:M]; r0 = rng.permutation(900)[:M]
+        K0 = keys[a].copy(); K1 = keys[b].copy()
+        K0[r0] = K1[r1] @ R60[g].T + t + 0.01 * rng.standard_normal((M, 3))
+        bad = rng.random(M) < bad_frac
+        K0[r0[bad]] = rng.uniform(0, 3, (int(bad.sum()), 3))
+        matches = np.stack([r0, r1], 1).astype(np.int64)
+        nT = M if use_rows else (H or M)
+        Tr = np.zeros((nT, 3, 4))
+        for i in range(nT):
+            Rg = R60[g] if i % 3 == 0 else R60[int(rng.integers(0, 60))]
+            j = i % M
+            Tr[i, :, :3] = Rg; Tr[i, :, 3] = K0[r0[j]] - K1[r1[j]] @ Rg.T
+        rows = rng.permutation(nT)[:H] if (use_rows and H) else None
+        w = rng.uniform(0.1, 1.0, M) if use_w else None
+        d = dict(k0=cu(K0), k1=cu(K1), m=cu(matches), w=cu(w) if w is not None else None, Tr=cu(Tr), rows=cu(rows) if rows is not None else None)
+        tasks.append((d['k0'], d['k1'], d['m'], d['w'], d['Tr'], d['rows'])); per_pair.append((d, M))
+    ird = 0.1
+    best, T1, st1, T2, st2 = [x.cpu().numpy() for x in hip.ransac_batch(tasks, ird)]
+    for q, (d, M) in enumerate(per_pair):
+        k0 = hip.gather_rows_f64(d['k0'], d['m'][:, 0].contiguous()); k1 = hip.gather_rows_f64(d['k1'], d['m'][:, 1].contiguous())
+        w = d['w'] if d['w'] is not None else torch.ones(M, dtype=torch.float64, device='cuda')
+        _, b, _ = hip.ransac_score(k0, k1, w, d['Tr'], ird, hyp_rows=d['rows'])
+        a1, s1 = hip.refine(k0, k1, w, ird * 2.0, Trans=d['Tr'], hyp_rows=d['rows'], best=b, want_stats=True)
+        a2, s2 = hip.refine(k0, k1, w, ird, T_in=a1, want_stats=True)
+        assert int(b.item()) == best[q], q
+        for got, want in ((T1[q], a1), (st1[q], s1), (T2[q], a2), (st2[q], s2)):
+            assert np.array_equal(got.reshape(-1), want.cpu().numpy().reshape(-1), equal_nan=True), q
+    assert hip.ransac_batch([], ird)[0].numel() == 0
