@@ -155,6 +155,22 @@ int roreg_refine(const double *k0, const double *k1, const double *w, int M,
                  double dist, double *T_out, double *stats_out /* optional f64[16]: H(9), c0(3), c1(3), sum w */,
                  void *stream);
 
+/* The local-transform stage (Des2R + ET input assembly, then quaternion -> 3x4 transform) of every pair of a scene in 2 + 1 launches
+ * around the one batched ET trunk pass (test/estimator.py:85-111,293-366 per pair; same arithmetic as roreg_des2r / roreg_et_gather /
+ * roreg_quat_to_trans, bit-identical).  Task p evaluates its n correspondences matches[sel[i]] (sel NULL = the first n rows); output
+ * rows [off, off+n): dr_out int64, x_out [*,128,60] f32 (ET input), Trans_out [*,3,4] f64.  tasks_dev is a DEVICE array. */
+typedef struct {
+    const float *before0, *before1, *after0, *after1;
+    const double *keys0, *keys1;
+    const int64_t *matches;
+    const int64_t *sel;
+    int32_t n, pad_;
+    int64_t off;
+} roreg_lt_task;
+int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int64_t *dr_out, float *x_out, void *stream);
+int roreg_lt_finish_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, const float *q_all, const int64_t *dr_all,
+                          double *Trans_out, void *stream);
+
 /* The estimator tail of every pair of a scene in five launches: gather the matched keypoints, score the <= max_iter hypotheses
  * (one wavefront each), first strictly-greatest overlap, refine at 2*ird from the winning local transform, refine at ird from that
  * (test/estimator.py:405-443 per pair; same arithmetic order as roreg_ransac_score / roreg_refine, so results are bit-identical).

@@ -28,6 +28,21 @@ const GroupTablesDev &group_tables();
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// one pair of the batched local-transform stage (mirrors roreg_lt_task, include/roreg_hip.h)
+struct LtTask {
+    const float *before0, *before1, *after0, *after1;   // the two clouds' FCGF-in / YOHO-out group features [*,32,60]
+    const double *keys0, *keys1;                        // keypoints [*,3]
+    const int64_t *matches;                             // [M,2] interleaved rows (cloud 0, cloud 1)
+    const int64_t *sel;                                 // [n] rows of `matches` to evaluate, or null (= 0..n-1)
+    int32_t n, pad_;
+    int64_t off;                                        // first output row of this pair
+};
+__device__ __forceinline__ void lt_rows(const LtTask &t, int i, size_t &r0, size_t &r1) {
+    const int64_t m = t.sel ? t.sel[i] : (int64_t)i;
+    r0 = (size_t)t.matches[2 * m]; r1 = (size_t)t.matches[2 * m + 1];
+}
+void launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, hipStream_t s);
+
 #define ROREG_CHECK_LAUNCH(name)                                                     \
     do {                                                                             \
         hipError_t e__ = hipGetLastError();                                          \

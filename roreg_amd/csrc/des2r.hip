@@ -17,18 +17,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,
-                                                    const float *__restrict__ feats0, const int64_t *__restrict__ rows0,
-                                                    const uint8_t *__restrict__ P8, int M, int64_t *__restrict__ idx_out,
-                                                    float *__restrict__ cor_out) {
+// one wavefront = one correspondence: feats1 row r1 is the permuted side, feats0 row r0 the broadcast side; result row b
+__device__ __forceinline__ void des2r_body(const float *__restrict__ feats1, size_t r1, const float *__restrict__ feats0, size_t r0,
+                                           bool live, const uint8_t *__restrict__ P8, size_t b, int64_t *__restrict__ idx_out,
+                                           float *__restrict__ cor_out) {
     __shared__ float d1s[4][ROREG_F * ROREG_G];
     __shared__ uint8_t Pl[ROREG_G * ROREG_G];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < ROREG_G * ROREG_G; i += 256) Pl[i] = P8[i];
-    const int b = blockIdx.x * 4 + w;
-    const bool live = b < M;
-    const size_t r1 = live ? (rows1 ? (size_t)rows1[b] : (size_t)b) : 0;
-    const size_t r0 = live ? (rows0 ? (size_t)rows0[b] : (size_t)b) : 0;
     {
         const float4 *src = reinterpret_cast<const float4 *>(feats1 + r1 * (ROREG_F * ROREG_G));
         float4 *dst = reinterpret_cast<float4 *>(d1s[w]);
@@ -59,7 +55,7 @@ __global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ fe
     float cor = 0.f;
 #pragma unroll
     for (int f = 0; f < ROREG_F; ++f) cor = __fadd_rn(cor, s[f]);
-    if (cor_out && act) cor_out[(size_t)b * ROREG_G + lane] = cor;
+    if (cor_out && act) cor_out[b * ROREG_G + lane] = cor;
     // first argmax over lanes 0..59: order by (value desc, lane asc)
     float bv = act ? cor : -__builtin_inff();
     int bi = act ? lane : 0x7fffffff;
@@ -73,7 +69,34 @@ __global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ fe
     if (lane == 0 && idx_out) idx_out[b] = bi;
 }
 
+__global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,
+                                                    const float *__restrict__ feats0, const int64_t *__restrict__ rows0,
+                                                    const uint8_t *__restrict__ P8, int M, int64_t *__restrict__ idx_out,
+                                                    float *__restrict__ cor_out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = b < M;
+    const size_t r1 = live ? (rows1 ? (size_t)rows1[b] : (size_t)b) : 0;
+    const size_t r0 = live ? (rows0 ? (size_t)rows0[b] : (size_t)b) : 0;
+    des2r_body(feats1, r1, feats0, r0, live, P8, (size_t)b, idx_out, cor_out);
+}
+
+// all pairs of a scene in one launch: blockIdx.y = pair, cloud 1 is the permuted side (test/estimator.py:108-110)
+__global__ __launch_bounds__(256) void des2r_batch_kernel(const roreg::LtTask *__restrict__ tasks, const uint8_t *__restrict__ P8,
+                                                          int64_t *__restrict__ dr_all) {
+    const roreg::LtTask t = tasks[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= t.n) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = i < t.n;
+    size_t r0 = 0, r1 = 0;
+    if (live) roreg::lt_rows(t, i, r0, r1);
+    des2r_body(t.after1, r1, t.after0, r0, live, P8, (size_t)(t.off + i), dr_all, nullptr);
+}
+
 }  // namespace
+
+void roreg::launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, hipStream_t s) {
+    hipLaunchKernelGGL(des2r_batch_kernel, dim3((max_n + 3) / 4, n_tasks), dim3(256), 0, s, tasks, roreg::group_tables().P8, dr_all);
+}
 
 extern "C" int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, const int64_t *rows0, int M,
                            int64_t *idx_out, float *cor_out, void *stream) {

@@ -151,21 +151,14 @@ __global__ __launch_bounds__(256) void det_score_kernel(const float *__restrict_
 }
 
 // ---- et_gather: one block per correspondence ------------------------------------------------------------
-__global__ __launch_bounds__(256) void et_gather_kernel(const float *__restrict__ before0, const float *__restrict__ before1,
-                                                        const float *__restrict__ after0, const float *__restrict__ after1,
-                                                        const int64_t *__restrict__ rows0, const int64_t *__restrict__ rows1,
-                                                        const int64_t *__restrict__ pre_idx, const int32_t *__restrict__ P,
-                                                        float *__restrict__ x, int M) {
-    const int b = blockIdx.x;
-    if (b >= M) return;
+__device__ __forceinline__ void et_gather_body(const float *__restrict__ before0, const float *__restrict__ before1,
+                                               const float *__restrict__ after0, const float *__restrict__ after1, size_t r0, size_t r1,
+                                               int a, const int32_t *__restrict__ P, float *__restrict__ dst) {
     __shared__ int perm[ROREG_G];
-    const int a = (int)pre_idx[b];
     if (threadIdx.x < ROREG_G) perm[threadIdx.x] = P[a * ROREG_G + threadIdx.x];
     __syncthreads();
-    const size_t r0 = rows0 ? (size_t)rows0[b] : (size_t)b, r1 = rows1 ? (size_t)rows1[b] : (size_t)b;
     const float *s_b1 = before1 + r1 * (ROREG_F * ROREG_G), *s_b0 = before0 + r0 * (ROREG_F * ROREG_G);
     const float *s_a1 = after1 + r1 * (ROREG_F * ROREG_G), *s_a0 = after0 + r0 * (ROREG_F * ROREG_G);
-    float *dst = x + (size_t)b * (4 * ROREG_F * ROREG_G);
     for (int i = threadIdx.x; i < ROREG_F * ROREG_G; i += 256) {
         const int c = i / ROREG_G, g = i - c * ROREG_G;
         const int pg = c * ROREG_G + perm[g];
@@ -176,19 +169,36 @@ __global__ __launch_bounds__(256) void et_gather_kernel(const float *__restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void et_gather_kernel(const float *__restrict__ before0, const float *__restrict__ before1,
+                                                        const float *__restrict__ after0, const float *__restrict__ after1,
+                                                        const int64_t *__restrict__ rows0, const int64_t *__restrict__ rows1,
+                                                        const int64_t *__restrict__ pre_idx, const int32_t *__restrict__ P,
+                                                        float *__restrict__ x, int M) {
+    const int b = blockIdx.x;
+    if (b >= M) return;
+    const size_t r0 = rows0 ? (size_t)rows0[b] : (size_t)b, r1 = rows1 ? (size_t)rows1[b] : (size_t)b;
+    et_gather_body(before0, before1, after0, after1, r0, r1, (int)pre_idx[b], P, x + (size_t)b * (4 * ROREG_F * ROREG_G));
+}
+
+__global__ __launch_bounds__(256) void et_gather_batch_kernel(const roreg::LtTask *__restrict__ tasks, const int64_t *__restrict__ dr_all,
+                                                              const int32_t *__restrict__ P, float *__restrict__ x_all) {
+    const roreg::LtTask t = tasks[blockIdx.y];
+    const int i = blockIdx.x;
+    if (i >= t.n) return;
+    size_t r0, r1;
+    roreg::lt_rows(t, i, r0, r1);
+    et_gather_body(t.before0, t.before1, t.after0, t.after1, r0, r1, (int)dr_all[t.off + i], P, x_all + (size_t)(t.off + i) * (4 * ROREG_F * ROREG_G));
+}
+
 // ---- quat_to_trans: one thread per correspondence --------------------------------------------------------
-__global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restrict__ q, const int64_t *__restrict__ anchor,
-                                                            const double *__restrict__ keys0, const int64_t *__restrict__ rows0,
-                                                            const double *__restrict__ keys1, const int64_t *__restrict__ rows1,
-                                                            const float *__restrict__ Rf, int M, double *__restrict__ T,
-                                                            float *__restrict__ quat_out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    float w = q[i * 4 + 0], x = q[i * 4 + 1], y = q[i * 4 + 2], z = q[i * 4 + 3];
+__device__ __forceinline__ void quat_to_trans_body(const float *__restrict__ q4, int anchor, const double *__restrict__ keys0, size_t r0,
+                                                   const double *__restrict__ keys1, size_t r1, const float *__restrict__ Rf,
+                                                   double *__restrict__ o, float *__restrict__ quat_out4) {
+    float w = q4[0], x = q4[1], y = q4[2], z = q4[3];
     // torch.norm(dim=1) then divide (network/eqv_trans.py:137)
     const float n = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w, w), __fmul_rn(x, x)), __fmul_rn(y, y)), __fmul_rn(z, z)));
     w = __fdiv_rn(w, n); x = __fdiv_rn(x, n); y = __fdiv_rn(y, n); z = __fdiv_rn(z, n);
-    if (quat_out) { quat_out[i * 4] = w; quat_out[i * 4 + 1] = x; quat_out[i * 4 + 2] = y; quat_out[i * 4 + 3] = z; }
+    if (quat_out4) { quat_out4[0] = w; quat_out4[1] = x; quat_out4[2] = y; quat_out4[3] = z; }
     // utils/r_eval.py:90-106 evaluated in float32 (the quaternion is a float32 array), left to right, no FMA
     auto two = [](float a, float b) { return __fmul_rn(__fmul_rn(2.0f, a), b); };
     float m[9];
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restr
     m[6] = __fsub_rn(two(x, z), two(y, w));
     m[7] = __fadd_rn(two(y, z), two(x, w));
     m[8] = __fsub_rn(__fsub_rn(1.0f, two(x, x)), two(y, y));
-    const float *A = Rf + (int)anchor[i] * 9;
+    const float *A = Rf + anchor * 9;
     double R[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -209,10 +219,8 @@ __global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restr
         for (int c = 0; c < 3; ++c)
             R[r * 3 + c] = __dadd_rn(__dadd_rn(__dmul_rn((double)m[r * 3], (double)A[c]), __dmul_rn((double)m[r * 3 + 1], (double)A[3 + c])),
                                      __dmul_rn((double)m[r * 3 + 2], (double)A[6 + c]));
-    const size_t r0 = rows0 ? (size_t)rows0[i] : (size_t)i, r1 = rows1 ? (size_t)rows1[i] : (size_t)i;
     const double k0x = keys0[r0 * 3], k0y = keys0[r0 * 3 + 1], k0z = keys0[r0 * 3 + 2];
     const double k1x = keys1[r1 * 3], k1y = keys1[r1 * 3 + 1], k1z = keys1[r1 * 3 + 2];
-    double *o = T + (size_t)i * 12;
     const double k0[3] = {k0x, k0y, k0z};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -220,6 +228,29 @@ __global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restr
         const double rot = __dadd_rn(__dadd_rn(__dmul_rn(k1x, R[r * 3]), __dmul_rn(k1y, R[r * 3 + 1])), __dmul_rn(k1z, R[r * 3 + 2]));
         o[r * 4 + 3] = __dsub_rn(k0[r], rot);
     }
+}
+
+__global__ __launch_bounds__(256) void quat_to_trans_kernel(const float *__restrict__ q, const int64_t *__restrict__ anchor,
+                                                            const double *__restrict__ keys0, const int64_t *__restrict__ rows0,
+                                                            const double *__restrict__ keys1, const int64_t *__restrict__ rows1,
+                                                            const float *__restrict__ Rf, int M, double *__restrict__ T,
+                                                            float *__restrict__ quat_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const size_t r0 = rows0 ? (size_t)rows0[i] : (size_t)i, r1 = rows1 ? (size_t)rows1[i] : (size_t)i;
+    quat_to_trans_body(q + (size_t)i * 4, (int)anchor[i], keys0, r0, keys1, r1, Rf, T + (size_t)i * 12, quat_out ? quat_out + (size_t)i * 4 : nullptr);
+}
+
+__global__ __launch_bounds__(256) void quat_to_trans_batch_kernel(const roreg::LtTask *__restrict__ tasks, const float *__restrict__ q_all,
+                                                                  const int64_t *__restrict__ dr_all, const float *__restrict__ Rf,
+                                                                  double *__restrict__ T_all) {
+    const roreg::LtTask t = tasks[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n) return;
+    size_t r0, r1;
+    roreg::lt_rows(t, i, r0, r1);
+    const size_t row = (size_t)(t.off + i);
+    quat_to_trans_body(q_all + row * 4, (int)dr_all[row], t.keys0, r0, t.keys1, r1, Rf, T_all + row * 12, nullptr);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double *__restrict__ src, const int64_t *__restrict__ rows,
@@ -292,5 +323,29 @@ extern "C" int roreg_gather_rows_f64(const double *src, const int64_t *rows, int
     hipLaunchKernelGGL(gather_rows_f64_kernel, dim3((M * width + 255) / 256), dim3(256), 0, roreg::as_stream(stream), src, rows,
                        M, width, out);
     ROREG_CHECK_LAUNCH("roreg_gather_rows_f64");
+    return 0;
+}
+
+extern "C" int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int64_t *dr_out, float *x_out, void *stream) {
+    if (n_tasks == 0 || max_n == 0) return 0;
+    ROREG_REQUIRE(tasks_dev && dr_out && x_out && n_tasks > 0 && max_n > 0, "roreg_lt_prepare_batch: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_lt_prepare_batch: group tables not set");
+    static_assert(sizeof(roreg_lt_task) == sizeof(roreg::LtTask), "roreg_lt_task layout");
+    const roreg::LtTask *tasks = reinterpret_cast<const roreg::LtTask *>(tasks_dev);
+    hipStream_t s = roreg::as_stream(stream);
+    roreg::launch_des2r_batch(tasks, n_tasks, max_n, dr_out, s);
+    hipLaunchKernelGGL(et_gather_batch_kernel, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+    ROREG_CHECK_LAUNCH("roreg_lt_prepare_batch");
+    return 0;
+}
+
+extern "C" int roreg_lt_finish_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, const float *q_all, const int64_t *dr_all,
+                                     double *Trans_out, void *stream) {
+    if (n_tasks == 0 || max_n == 0) return 0;
+    ROREG_REQUIRE(tasks_dev && q_all && dr_all && Trans_out && n_tasks > 0 && max_n > 0, "roreg_lt_finish_batch: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready, "roreg_lt_finish_batch: group tables not set");
+    hipLaunchKernelGGL(quat_to_trans_batch_kernel, dim3((max_n + 255) / 256, n_tasks), dim3(256), 0, roreg::as_stream(stream),
+                       reinterpret_cast<const roreg::LtTask *>(tasks_dev), q_all, dr_all, roreg::group_tables().Rf, Trans_out);
+    ROREG_CHECK_LAUNCH("roreg_lt_finish_batch");
     return 0;
 }

@@ -38,39 +38,14 @@ class PairResult:
     scores: np.ndarray = None
 
 
-class _Lanes:
-    """Side HIP streams for the per-pair launches.  A pair's matcher / RANSAC kernels are small (refine is ONE workgroup, the
-    mutual check one, Des2R and the hypothesis scoring ~250 on 256 CUs), so pairs are issued round-robin on a few streams and
-    the hardware queues overlap them; the big batched launches (GF, ET trunk) stay on the caller's stream.  fork(): lanes wait
-    for everything issued so far; join(): the caller's stream waits for the lanes.  Tensors that cross streams are kept
-    referenced by the caller until its final host sync, so the caching allocator never recycles them early."""
-
-    def __init__(self, n=4):
-        self.streams = [torch.cuda.Stream() for _ in range(n)]
-
-    def fork(self):
-        main = torch.cuda.current_stream()
-        for s in self.streams:
-            s.wait_stream(main)
-
-    def lane(self, i):
-        return torch.cuda.stream(self.streams[i % len(self.streams)])
-
-    def join(self):
-        main = torch.cuda.current_stream()
-        for s in self.streams:
-            main.wait_stream(s)
-
-
 class RegistrationEngine:
-    def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None, n_lanes=4):
+    def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None):
         self.cfg = cfg
         self.gf = gf_net
         self.et = et_net
         self.rd = rd_net            # detector_eqv_test (needed when cfg.RD)
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
-        self.lanes = _Lanes(n_lanes) if n_lanes > 1 else None
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
 
     def _mark(self, name, t0):
@@ -82,18 +57,6 @@ class RegistrationEngine:
         t1 = time.perf_counter()
         self.phase_ms[name] = self.phase_ms.get(name, 0.0) + 1e3 * (t1 - t0)
         return t1
-
-    def _fork(self):
-        if self.lanes is not None:
-            self.lanes.fork()
-
-    def _join(self):
-        if self.lanes is not None:
-            self.lanes.join()
-
-    def _lane(self, i):
-        import contextlib
-        return self.lanes.lane(i) if self.lanes is not None else contextlib.nullcontext()
 
     def set_gemm_mode(self, mode):
         """'f32': exact f32-input MFMA GEMMs (bitwise an fmaf chain);  'split': 3 x bf16 split GEMMs (f32-accurate)."""
@@ -188,40 +151,25 @@ class RegistrationEngine:
         return hip.mutual_matches(nn01, nn10, d0, d1)
 
     def local_transforms_many(self, items, max_rows=32768):
-        """Des2R + ET + assembly for several pairs with ONE pass of the ET network per group of pairs (the pruned trunk's
-        tail layers are small grids: per-pair launches leave most of the chip idle).  items: [(c0, c1, matches)]."""
+        """Des2R + ET + assembly for several pairs: per group of pairs, 2 launches (Des2R, ET input assembly), ONE pass of the ET
+        network and 1 launch (quaternion -> transform).  items: [(c0, c1, matches [M,2], sel)] with sel = device int64 rows of
+        `matches` to evaluate or None (= all M).  -> [(dr [n], Trans [n,3,4])] per item."""
         out = [None] * len(items)
+        sizes = [int(it[3].shape[0]) if it[3] is not None else int(it[2].shape[0]) for it in items]
         i = 0
         while i < len(items):
             j, rows = i, 0
-            while j < len(items) and (j == i or rows + items[j][2].shape[0] <= max_rows):
-                rows += items[j][2].shape[0]; j += 1
+            while j < len(items) and (j == i or rows + sizes[j] <= max_rows):
+                rows += sizes[j]; j += 1
+            batch = hip.LtBatch([(c0.before, c1.before, c0.eqv, c1.eqv, c0.keys, c1.keys, m, sel) for c0, c1, m, sel in items[i:j]])
             rows_pad = (rows + 3) // 4 * 4                # the irrep-domain GEMM streams 16-byte column groups
-            x_all = torch.zeros((rows_pad, 128, 60), dtype=torch.float32, device='cuda') if rows_pad != rows else \
-                torch.empty((rows, 128, 60), dtype=torch.float32, device='cuda')
-            parts = []
-            o = 0
-            self._fork()
-            for q in range(i, j):
-                c0, c1, matches = items[q]
-                M = matches.shape[0]
-                with self._lane(q):
-                    rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
-                    dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0)
-                    if M:
-                        hip.et_gather(c0.before, c1.before, c0.eqv, c1.eqv, dr, rows0=rows0, rows1=rows1, out=x_all[o:o + M])
-                parts.append((dr, rows0, rows1, o, M))
-                o += M
-            self._join()
+            dr_all, x_all = batch.prepare(rows_pad)
             with torch.no_grad():
                 q_all = self.et.trunk_and_head(x_all) if rows else torch.empty((0, 4), dtype=torch.float32, device='cuda')
-            self._fork()
-            for q, (dr, rows0, rows1, o, M) in zip(range(i, j), parts):
-                c0, c1, _ = items[q]
-                with self._lane(q):
-                    Trans = hip.quat_to_trans(q_all[o:o + M].contiguous(), dr, c0.keys, c1.keys, rows0=rows0, rows1=rows1)
-                out[q] = (dr, Trans, rows0, rows1)
-            self._join()                                  # q_all / x_all may be recycled by the next group only after the lanes read them
+            del x_all
+            T_all = batch.finish(q_all, dr_all)
+            for q, (o, n) in zip(range(i, j), batch.offsets):
+                out[q] = (dr_all[o:o + n], T_all[o:o + n])
             i = j
         return out
 
@@ -300,18 +248,19 @@ class RegistrationEngine:
             index = np.arange(rows.shape[0])
             np.random.shuffle(index)                                        # estimator.py:423-424
             hyps.append(np.ascontiguousarray(rows[index[0:max_iter]], np.int64))
-        if all_local_transforms:
-            items = full
-        else:
-            items = [(c0, c1, m[torch.from_numpy(h).cuda()]) for (c0, c1, m), h in zip(full, hyps)]
+        hyp_flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros(0, np.int64)).cuda()   # ONE upload of all hypothesis lists
+        hyp_dev, o = [], 0
+        for h in hyps:
+            hyp_dev.append(hyp_flat[o:o + h.shape[0]]); o += h.shape[0]
+        items = [(c0, c1, m, None if all_local_transforms else h) for (c0, c1, m), h in zip(full, hyp_dev)]
         lts = self.local_transforms_many(items)
         t0 = self._mark('local_transforms', t0)
         # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
-        rt, w_all, hyp_all = [], [], []
-        for (c0, c1, matches), hsel, sc, (dr, Trans, _, _) in zip(full, hyps, all_scores, lts):
-            hyp = torch.from_numpy(hsel).cuda() if all_local_transforms else None          # else Trans is already in hypothesis order
+        rt, w_all = [], []
+        for (c0, c1, matches), h, sc, (dr, Trans) in zip(full, hyp_dev, all_scores, lts):
+            hyp = h if all_local_transforms else None                                      # else Trans is already in hypothesis order
             w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()     # None = ones(M)  (matcher.py:109)
-            rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w); hyp_all.append(hyp)
+            rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
         ird = float(self.cfg.ransac_ird)
         best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird)
         t0 = self._mark('ransac_issue', t0)

@@ -40,6 +40,8 @@ PROTOTYPES = {
     'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
     'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
+    'roreg_lt_prepare_batch': (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    'roreg_lt_finish_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
     'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
@@ -245,6 +247,56 @@ def mutual_matches(nn01, nn10, sample0=None, sample1=None):
     _check(lib().roreg_mutual_matches(_ptr(nn01, torch.int64), _ptr(nn10, torch.int64), m, _ptr(sample0, torch.int64),
                                       _ptr(sample1, torch.int64), _ptr(out), _ptr(cnt), _stream()), 'roreg_mutual_matches')
     return out, cnt
+
+
+_LT_TASK = np.dtype([('before0', np.uint64), ('before1', np.uint64), ('after0', np.uint64), ('after1', np.uint64), ('keys0', np.uint64),
+                     ('keys1', np.uint64), ('matches', np.uint64), ('sel', np.uint64), ('n', np.int32), ('pad', np.int32), ('off', np.int64)])
+
+
+class LtBatch:
+    """Task table of the batched local-transform stage.  tasks: [(before0, before1, after0, after1 [*,32,60] f32, keys0, keys1 [*,3] f64,
+    matches [M,2] int64, sel int64 [n] or None)] device tensors; task p owns output rows [off[p], off[p]+n[p])."""
+
+    def __init__(self, tasks):
+        self.n_tasks = len(tasks)
+        table = np.zeros(self.n_tasks, _LT_TASK)
+        off = 0
+        self.offsets = []
+        for i, (b0, b1, a0, a1, k0, k1, m, sel) in enumerate(tasks):
+            for t in (b0, b1, a0, a1):
+                _ptr(t, torch.float32)
+            _ptr(k0, torch.float64); _ptr(k1, torch.float64); _ptr(m, torch.int64)
+            if sel is not None:
+                _ptr(sel, torch.int64)
+            n = int(sel.shape[0]) if sel is not None else int(m.shape[0])
+            table[i] = (b0.data_ptr(), b1.data_ptr(), a0.data_ptr(), a1.data_ptr(), k0.data_ptr(), k1.data_ptr(), m.data_ptr() if n else 0,
+                        sel.data_ptr() if sel is not None else 0, n, 0, off)
+            self.offsets.append((off, n))
+            off += n
+        self.total = off
+        self.max_n = int(table['n'].max()) if self.n_tasks else 0
+        self.keep = tasks                              # the table holds raw pointers: keep the tensors alive
+        self.table = torch.from_numpy(table.view(np.uint8).reshape(self.n_tasks, _LT_TASK.itemsize).copy()).cuda() if self.n_tasks else None
+
+    def prepare(self, rows_alloc=None):
+        """Des2R + ET input assembly -> (dr int64 [total], x [rows_alloc,128,60] f32; rows beyond total are zero)."""
+        ensure_tables()
+        rows_alloc = self.total if rows_alloc is None else rows_alloc
+        dr = torch.empty(self.total, dtype=torch.int64, device='cuda')
+        x = torch.empty((rows_alloc, 128, 60), dtype=torch.float32, device='cuda')
+        if rows_alloc > self.total:
+            x[self.total:].zero_()
+        if self.total:
+            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(dr), _ptr(x), _stream()), 'roreg_lt_prepare_batch')
+        return dr, x
+
+    def finish(self, q_all, dr):
+        """un-normalised quaternions [>=total,4] f32 + dr -> Trans [total,3,4] f64."""
+        T = torch.empty((self.total, 3, 4), dtype=torch.float64, device='cuda')
+        if self.total:
+            _check(lib().roreg_lt_finish_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(q_all, torch.float32), _ptr(dr, torch.int64), _ptr(T),
+                                               _stream()), 'roreg_lt_finish_batch')
+        return T
 
 
 _RANSAC_TASK = np.dtype([('keys0', np.uint64), ('keys1', np.uint64), ('matches', np.uint64), ('w', np.uint64), ('Trans', np.uint64),

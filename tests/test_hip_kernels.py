@@ -353,3 +353,37 @@ def test_ransac_batch_equals_per_pair_calls():
         for got, want in ((T1[q], a1), (st1[q], s1), (T2[q], a2), (st2[q], s2)):
             assert np.array_equal(got.reshape(-1), want.cpu().numpy().reshape(-1), equal_nan=True), q
     assert hip.ransac_batch([], ird)[0].numel() == 0
+
+
+def test_lt_batch_equals_per_pair_calls(group):
+    """Batched Des2R + ET-input assembly + quaternion->transform against the per-pair entry points: ragged n, hypothesis
+    selections given / all matches, an empty task."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(31)
+    clouds = []
+    for n in (120, 77, 200):
+        clouds.append(dict(before=cu(rng.standard_normal((n, 32, 60)).astype(np.float32)), eqv=cu(rng.standard_normal((n, 32, 60)).astype(np.float32)),
+                           keys=cu(rng.uniform(0, 3, (n, 3)))))
+    specs = [(0, 1, 60, 25), (1, 2, 40, None), (2, 0, 90, 90), (0, 2, 5, 0)]
+    tasks, host = [], []
+    for a, b, M, nsel in specs:
+        c0, c1 = clouds[a], clouds[b]
+        m = np.stack([rng.integers(0, c0['keys'].shape[0], M), rng.integers(0, c1['keys'].shape[0], M)], 1).astype(np.int64)
+        sel = rng.permutation(M)[:nsel] if nsel is not None else None
+        md = cu(m); sd = cu(sel) if sel is not None else None
+        tasks.append((c0['before'], c1['before'], c0['eqv'], c1['eqv'], c0['keys'], c1['keys'], md, sd))
+        host.append((c0, c1, m if sel is None else m[sel]))
+    batch = hip.LtBatch(tasks)
+    dr, x = batch.prepare(batch.total + 3)
+    assert float(x[batch.total:].abs().max()) == 0.0
+    q = cu(rng.standard_normal((batch.total, 4)).astype(np.float32))
+    T = batch.finish(q, dr)
+    for (o, n), (c0, c1, m) in zip(batch.offsets, host):
+        assert n == m.shape[0]
+        if n == 0:
+            continue
+        r0 = cu(m[:, 0].copy()); r1 = cu(m[:, 1].copy())
+        dr1 = hip.des2r(c1['eqv'], c0['eqv'], rows1=r1, rows0=r0)
+        x1 = hip.et_gather(c0['before'], c1['before'], c0['eqv'], c1['eqv'], dr1, rows0=r0, rows1=r1)
+        T1 = hip.quat_to_trans(q[o:o + n].contiguous(), dr1, c0['keys'], c1['keys'], rows0=r0, rows1=r1)
+        assert torch.equal(dr[o:o + n], dr1) and torch.equal(x[o:o + n], x1) and torch.equal(T[o:o + n], T1)

@@ -13,13 +13,12 @@ eng = RegistrationEngine(cfg, gf, et)
 scene = synth.make_scene(1000, n_clouds=16, n_kpts=5000, overlap=0.6, coord_noise=0.005)
 feats = [torch.from_numpy(f).cuda() for f in scene.feats]; keys = [torch.from_numpy(k).cuda() for k in scene._kps]
 order = np.random.default_rng(4242).permutation(len(scene.pair_ids)); pair_ids = [scene.pair_ids[i] for i in sorted(order[:60])]
-for lanes in (1, 4):
-    eng2 = RegistrationEngine(cfg, gf, et, n_lanes=lanes)
-    for rep in range(3):
-        eng2.phase_ms = {} if rep == 2 else None
-        np.random.seed(7)
-        eng2.run_scene(feats, keys, pair_ids)
-    print('lanes', lanes, {k: round(v, 2) for k, v in eng2.phase_ms.items()})
+for rep in range(3):
+    eng.phase_ms = {} if rep == 2 else None
+    np.random.seed(7)
+    eng.run_scene(feats, keys, pair_ids)
+print('phases (synchronised, ms):', {k: round(v, 2) for k, v in eng.phase_ms.items()})
+eng.phase_ms = None
 for mode in ['f32', 'split']:
     eng.set_gemm_mode(mode)
     for rep in range(2):
