@@ -261,7 +261,7 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
                     const int32_t *g_map /* optional [60]: group column -> compact output column (< Lvalid) or -1 */,
                     int Lout /* row pitch of the compact output, >= Lvalid; pad columns are zero */, int Lvalid,
-                    int B, int C, void *stream);
+                    int B, int C, int split /* 1: transforms as 3 x bf16 split MFMAs (f32-accurate) */, void *stream);
 
 #ifdef __cplusplus
 }

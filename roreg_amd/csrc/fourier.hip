@@ -323,6 +323,7 @@ struct NonlinParams {
     const int *g_map;            // optional [60] -> compact output column (or -1 = not written); Lout columns are written
     const float *bias, *bias2, *bn_scale, *bn_shift;      // per channel; any may be null
     const float *A1, *A2;        // fragment-ordered transform tables (roreg_set_fourier_tables)
+    const bf16x8 *A1s, *A2s;     // the same tables as 3 x bf16 split fragments of the K=16 bf16 MFMA (SPLIT kernels)
     int B, C, tiles_per_c, Lout, Lvalid;
 };
 
@@ -350,7 +351,11 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <bool IN_SPATIAL, bool OUT_SPATIAL>
+// SPLIT: both 60x60 transforms run on the bf16 matrix cores with f32 accuracy (operands split 3 x bf16, six cross products, f32
+// accumulate -- see irrep_gemm_split_kernel): 96 K=16 MFMAs (3072 cycles) per 32-keypoint tile instead of 124 f32 MFMAs (7936), which
+// turns the kernel from matrix-core-bound into HBM-bound.  K orders: inverse step st feeds coefficients q = 16 st + 8 h + e; the forward
+// product's step st consumes this lane's accumulator registers v[st>>1][8 (st&1) + e], i.e. again no transpose between the products.
+template <bool IN_SPATIAL, bool OUT_SPATIAL, bool SPLIT>
 __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     const int lane = threadIdx.x & 63;
     const int jn = lane & 31, h = lane >> 5;
@@ -362,29 +367,55 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     // transform fragments A1[s][tile][lane] (inverse) and A2[step][tile][lane] (forward, K order = C/D register order) live in LDS
     // (31 KB per workgroup, conflict-free lane-contiguous reads): keeping them out of the register file leaves room for 4+ waves
     // per SIMD, which this streaming kernel needs to cover its 30 scattered 128-byte row reads per tile.
-    __shared__ float sA1[IN_SPATIAL ? 64 : 30 * 2 * 64];
-    __shared__ float sA2[OUT_SPATIAL ? 64 : 32 * 2 * 64];
+    constexpr int NA1 = SPLIT ? 4 * 2 * 3 * 64 * 4 : 30 * 2 * 64, NA2 = SPLIT ? 4 * 2 * 3 * 64 * 4 : 32 * 2 * 64;   // floats (a bf16x8 = 4 floats)
+    __shared__ __attribute__((aligned(16))) float sA1[IN_SPATIAL ? 64 : NA1];
+    __shared__ __attribute__((aligned(16))) float sA2[OUT_SPATIAL ? 64 : NA2];
     __shared__ float sT[OUT_SPATIAL ? 4 * 32 * 65 : 64];
-    if (!IN_SPATIAL)
-        for (int i = threadIdx.x; i < 30 * 2 * 64; i += 256) sA1[i] = p.A1[i];
-    if (!OUT_SPATIAL)
-        for (int i = threadIdx.x; i < 32 * 2 * 64; i += 256) sA2[i] = p.A2[i];
+    {
+        const float *g1 = SPLIT ? reinterpret_cast<const float *>(p.A1s) : p.A1, *g2 = SPLIT ? reinterpret_cast<const float *>(p.A2s) : p.A2;
+        if (!IN_SPATIAL)
+            for (int i = threadIdx.x; i < NA1; i += 256) sA1[i] = g1[i];
+        if (!OUT_SPATIAL)
+            for (int i = threadIdx.x; i < NA2; i += 256) sA2[i] = g2[i];
+    }
     __syncthreads();
+    const bf16x8 *sA1s = reinterpret_cast<const bf16x8 *>(sA1), *sA2s = reinterpret_cast<const bf16x8 *>(sA2);   // [st][tile][plane][lane]
     // row (of the [60*C][B] coefficient matrix) of coefficient q0 (first half-wave) / q1 (second half-wave) of channel c
     // (the table entries are compile-time constants, the two candidate rows scalar-ALU values; a lane only selects)
 #define ROW_OF(Q0, Q1, c) (h ? (kQ.alpha[Q1] * C + kQ.i[Q1] + (c) * kQ.d[Q1]) : (kQ.alpha[Q0] * C + kQ.i[Q0] + (c) * kQ.d[Q0]))
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
-    float cv[IN_SPATIAL ? 1 : 30], cn[IN_SPATIAL ? 1 : 30];
-    auto load_coefs = [&](int tile, float (&dst)[IN_SPATIAL ? 1 : 30]) {
+    constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT ? 32 : 30);
+    float cv[NCV], cn[NCV];
+    auto load_coefs = [&](int tile, float (&dst)[NCV]) {
         const int c = tile / p.tiles_per_c;
         int b = (tile - c * p.tiles_per_c) * 32 + jn;
         if (b >= B) b = B - 1;
-        static_for<30>([&](auto ic) {
-            constexpr int s = decltype(ic)::value;
-            constexpr int q0 = 2 * s, q1 = 2 * s + 1;
-            dst[s] = p.Xin[(size_t)ROW_OF(q0, q1, c) * B + b];
-        });
+        if constexpr (SPLIT) {
+            static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
+                constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
+                constexpr int q0 = 16 * st + e, q1 = 16 * st + 8 + e;
+                if constexpr (q1 < ROREG_G) dst[st * 8 + e] = p.Xin[(size_t)ROW_OF(q0, q1, c) * B + b];
+                else dst[st * 8 + e] = h ? 0.f : p.Xin[(size_t)(kQ.alpha[q0] * C + kQ.i[q0] + c * kQ.d[q0]) * B + b];
+            });
+        } else {
+            static_for<30>([&](auto ic) {
+                constexpr int s = decltype(ic)::value;
+                constexpr int q0 = 2 * s, q1 = 2 * s + 1;
+                dst[s] = p.Xin[(size_t)ROW_OF(q0, q1, c) * B + b];
+            });
+        }
+    };
+    // six bf16 MFMAs = one f32-accurate product of the split fragments (a1+a2+a3)(b1+b2+b3), terms of order <= 4
+    auto mfma6 = [&](const bf16x8 *a, const bf16x8 &b1, const bf16x8 &b2, const bf16x8 &b3, f32x16 c) {
+        const bf16x8 a1 = a[0], a2 = a[64], a3 = a[128];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+        return c;
     };
     if (!IN_SPATIAL && wave_global < n_tiles) load_coefs(wave_global, cv);
 
@@ -410,10 +441,23 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[t][r] = 0.f;
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int s = 0; s < 30; ++s) {
-                v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA1[(s * 2 + 0) * 64 + lane], cv[s], v[0], 0, 0, 0);
-                v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA1[(s * 2 + 1) * 64 + lane], cv[s], v[1], 0, 0, 0);
+                for (int st = 0; st < 4; ++st) {
+                    float x8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x8[e] = cv[st * 8 + e];
+                    bf16x8 b1, b2, b3;
+                    split3(x8, b1, b2, b3);
+                    v[0] = mfma6(sA1s + ((st * 2 + 0) * 3) * 64 + lane, b1, b2, b3, v[0]);
+                    v[1] = mfma6(sA1s + ((st * 2 + 1) * 3) * 64 + lane, b1, b2, b3, v[1]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 30; ++s) {
+                    v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA1[(s * 2 + 0) * 64 + lane], cv[s], v[0], 0, 0, 0);
+                    v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA1[(s * 2 + 1) * 64 + lane], cv[s], v[1], 0, 0, 0);
+                }
             }
         }
         // ---- group-domain epilogue --------------------------------------------------------------------------------
@@ -454,14 +498,27 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int st = 0; st < 4; ++st) {
+                    float x8[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int s = t * 16 + r;
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 0) * 64 + lane], v[t][r], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 1) * 64 + lane], v[t][r], o[1], 0, 0, 0);
+                    for (int e = 0; e < 8; ++e) x8[e] = v[st >> 1][8 * (st & 1) + e];
+                    bf16x8 b1, b2, b3;
+                    split3(x8, b1, b2, b3);
+                    o[0] = mfma6(sA2s + ((st * 2 + 0) * 3) * 64 + lane, b1, b2, b3, o[0]);
+                    o[1] = mfma6(sA2s + ((st * 2 + 1) * 3) * 64 + lane, b1, b2, b3, o[1]);
                 }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int s = t * 16 + r;
+                        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 0) * 64 + lane], v[t][r], o[0], 0, 0, 0);
+                        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 1) * 64 + lane], v[t][r], o[1], 0, 0, 0);
+                    }
+            }
             if (valid) {
                 static_for<32>([&](auto ic) {
                     constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
@@ -474,7 +531,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
         }
         if (!IN_SPATIAL) {
 #pragma unroll
-            for (int s = 0; s < 30; ++s) cv[s] = cn[s];
+            for (int s = 0; s < NCV; ++s) cv[s] = cn[s];
         }
     }
 }
@@ -482,6 +539,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
 #undef ROW_OF
 
 float *g_A1 = nullptr, *g_A2 = nullptr;
+uint16_t *g_A1s = nullptr, *g_A2s = nullptr;
 
 }  // namespace
 
@@ -510,6 +568,48 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
         }
     }
     if (hipMemcpy(g_A1, A1, sizeof(A1), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(g_A2, A2, sizeof(A2), hipMemcpyHostToDevice) != hipSuccess) {
+        roreg::set_error("roreg_set_fourier_tables: hipMemcpy failed");
+        return 1;
+    }
+    // the same tables as 3 x bf16 split fragments of the K=16 MFMA: [step st][tile][plane][lane][e]
+    //   A1s: F[q = 16 st + 8 h + e][g = tile*32 + j]                                  (inverse)
+    //   A2s: F[q' = tile*32 + j][g = 32 (st>>1) + (r&3) + 8 (r>>2) + 4 h], r = 8 (st&1) + e   (forward; K order = accumulator registers)
+    static uint16_t A1s[4 * 2 * 3 * 64 * 8], A2s[4 * 2 * 3 * 64 * 8];
+    auto split3_host = [](float x, uint16_t out[3]) {                  // round-to-nearest-even pieces of the exact remainders
+        float rem = x;
+        for (int sp = 0; sp < 3; ++sp) {
+            uint32_t u; memcpy(&u, &rem, 4);
+            const uint32_t r = ((u >> 16) & 1u) + 0x7fffu;
+            const uint16_t hi = (uint16_t)((u + r) >> 16);
+            out[sp] = hi;
+            const uint32_t back = (uint32_t)hi << 16;
+            float v; memcpy(&v, &back, 4);
+            rem = rem - v;
+        }
+    };
+    for (int st = 0; st < 4; ++st)
+        for (int tile = 0; tile < 2; ++tile)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int j = lane & 31, h = lane >> 5;
+                    const int q1 = 16 * st + 8 * h + e, g1 = tile * 32 + j;
+                    const float f1 = (q1 < 60 && g1 < 60) ? F_host[q1 * 60 + g1] : 0.f;
+                    const int r = 8 * (st & 1) + e, q2 = tile * 32 + j, g2 = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float f2 = (q2 < 60 && g2 < 60) ? F_host[q2 * 60 + g2] : 0.f;
+                    uint16_t p1[3], p2[3];
+                    split3_host(f1, p1); split3_host(f2, p2);
+                    for (int sp = 0; sp < 3; ++sp) {
+                        const size_t at = ((((size_t)st * 2 + tile) * 3 + sp) * 64 + lane) * 8 + e;
+                        A1s[at] = p1[sp]; A2s[at] = p2[sp];
+                    }
+                }
+    if (!g_A1s) {
+        if (hipMalloc(&g_A1s, sizeof(A1s)) != hipSuccess || hipMalloc(&g_A2s, sizeof(A2s)) != hipSuccess) {
+            roreg::set_error("roreg_set_fourier_tables: hipMalloc failed");
+            return 1;
+        }
+    }
+    if (hipMemcpy(g_A1s, A1s, sizeof(A1s), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(g_A2s, A2s, sizeof(A2s), hipMemcpyHostToDevice) != hipSuccess) {
         roreg::set_error("roreg_set_fourier_tables: hipMemcpy failed");
         return 1;
     }
@@ -604,7 +704,7 @@ extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, 
 
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
-                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, void *stream) {
+                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
@@ -617,16 +717,24 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s);
     p.B = B; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
     long long blocks = (n_tiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipStream_t s = roreg::as_stream(stream);
     const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
-    if (in_sp && !out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else if (!in_sp && !out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else if (!in_sp && out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (in_sp && out_sp) { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
+    if (split) {
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, true>), grid, blk, 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, true>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, true>), grid, blk, 0, s, p);
+    } else {
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, false>), grid, blk, 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, false>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, false>), grid, blk, 0, s, p);
+    }
     ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
     return 0;
 }

@@ -59,7 +59,7 @@ PROTOTYPES = {
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
 }
 
 
@@ -617,7 +617,7 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None):
 
 
 def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
-              g_map=None, Lout=60, Lvalid=60):
+              g_map=None, Lout=60, Lvalid=60, split=False):
     ensure_fourier()
     dev = (coef_in if coef_in is not None else x_spatial).device
     if spatial_out:
@@ -627,7 +627,7 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     scale, shift = bn if bn is not None else (None, None)
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
-                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, _stream()), 'roreg_ft_nonlin')
+                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 1 if split else 0, _stream()), 'roreg_ft_nonlin')
     return out
 
 

@@ -93,10 +93,10 @@ class ET_test(nn.Module):
             if self.fourier_init and B % 4 == 0:
                 layer, bn = self._fourier_init()
                 hip.ensure_fourier()
-                X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn)
+                X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=self.split_bf16)
                 T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if self.split_bf16 else None)
                 del X0
-                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45)   # [B,256,48]
+                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split=self.split_bf16)   # [B,256,48]
                 del T0
             else:
                 h = self.Conv_init(x, gather=ga)                               # [B,256,45]

@@ -67,18 +67,18 @@ class FourierGF:
         if B0 % 4:                                    # the GEMM streams 16-byte column groups: pad the batch, drop the rows at the end
             x = torch.cat([x, x.new_zeros((4 - B0 % 4,) + tuple(x.shape[1:]))], 0)
         B = x.shape[0]
-        X0 = hip.ft_nonlin(B, 32, x_spatial=x)
         sp = self.split_bf16
+        X0 = hip.ft_nonlin(B, 32, x_spatial=x, split=sp)
         T0 = hip.irrep_gemm(X0, self.l_in.wpack, 32, 256, B, split=self.l_in.wsplit if sp else None)
-        X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1)
+        X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=sp)
         T1 = hip.irrep_gemm(X1, self.l_1.wpack, 256, 512, B, split=self.l_1.wsplit if sp else None)
         del X1
-        X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2)
+        X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split=sp)
         del T1
         T2 = hip.irrep_gemm(X2, self.l_2.wpack, 512, 256, B, split=self.l_2.wsplit if sp else None, add=T0)   # + identity short cut
         del X2, T0
-        X3 = hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3)
+        X3 = hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3, split=sp)
         del T2
         T3 = hip.irrep_gemm(X3, self.l_out.wpack, 256, 32, B, split=self.l_out.wsplit if sp else None)
-        out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True)
+        out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True, split=sp)
         return out[:B0] if B0 != B else out

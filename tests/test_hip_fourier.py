@@ -47,6 +47,29 @@ def test_fourier_layer_equals_direct_group_conv(group):
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+def test_ft_nonlin_split_matches_f32_path(group):
+    """The 3 x bf16 split transforms agree with the exact-f32 MFMA transforms at the f32 rounding level, for all three kernel
+    variants (group -> irrep, irrep -> irrep with bias/BN/ReLU, irrep -> group with residual and a live-column map)."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(8)
+    B, C = 77, 48
+    x = torch.from_numpy((rng.standard_normal((B, C, 60)) * np.exp(rng.standard_normal((B, C, 1)))).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda()
+    bn = (torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda(), torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda())
+    X32 = hip.ft_nonlin(B, C, x_spatial=x); Xsp = hip.ft_nonlin(B, C, x_spatial=x, split=True)
+    scale = float(X32.abs().max())
+    assert float((X32 - Xsp).abs().max()) < 4e-7 * scale
+    Y32 = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, bn=bn); Ysp = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, bn=bn, split=True)
+    assert float((Y32 - Ysp).abs().max()) < 1e-6 * float(Y32.abs().max())
+    gmap = np.full(60, -1, np.int32); live = rng.permutation(60)[:45]; gmap[live] = np.arange(45)
+    gm = torch.from_numpy(gmap).cuda()
+    Z32 = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, spatial_out=True, g_map=gm, Lout=48, Lvalid=45)
+    Zsp = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, spatial_out=True, g_map=gm, Lout=48, Lvalid=45, split=True)
+    assert float((Z32 - Zsp).abs().max()) < 1e-6 * float(Z32.abs().max())
+    back = hip.ft_nonlin(B, C, coef_in=Xsp, resid_spatial=x, spatial_out=True, split=True)      # F^-1 F x + x = 2x
+    assert float((back - 2 * x).abs().max()) < 2e-6 * float(x.abs().max())
+
+
 def test_gemm_epilogue_residual_is_exact(group):
     """Out = W.X + Add in the GEMM epilogue is bitwise the separately computed sum (both GEMM kernels)."""
     from roreg_amd import hip
