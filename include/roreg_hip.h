@@ -52,6 +52,13 @@ int roreg_group_conv(const float *x, const float *wpack, const float *bias,
                      int B, int Cin, int Cout, int Lin, int Lout, int KS,
                      float *workspace, size_t workspace_floats, void *stream);
 
+/* The same convolution with f32 accuracy on the bf16 matrix cores: operands as three bf16 pieces, six cross products, f32 accumulate
+ * (2.67x fewer matrix-core cycles than the f32-input MFMA; measured error = the f32 kernel's).  KS = 13, Cin % 16 == 0,
+ * Cout % 256 == 0, no residual.  wsplit: bf16 bits, layout [3 planes][KS][Cin/16][2 k-octets][Cout][8 channels]
+ * (plane p of W[o, 16*(c/16) + 8*h + e, k]; the pieces are round-to-nearest-even of the exact remainders). */
+int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
+                           float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
+
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
 int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream);

@@ -210,6 +210,158 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     out[i] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same convolution on the bf16 matrix cores with f32 accuracy ("3 x bf16 split", see fourier.hip): activations and weights are
+// the exact sums of three bf16 pieces, the six cross products of order <= 4 are accumulated in f32.  Reduction step = one stencil
+// position k x 16 channels (the K of v_mfma_f32_32x32x16_bf16); the B operand of a lane is the 16-byte k-octet
+//   slab[plane][h][keypoint][gather[j,k]]   (8 channels of one input column),
+// i.e. the stencil is still an LDS address.  BatchNorm + ReLU + the three-way split are applied ONCE while staging a 16-channel
+// chunk.  Workgroup = 4 waves x (64 output channels x 128 columns) = 256 x 128; weights stream from L2 in fragment order
+//   wsplit[plane][k][c/16][h][CoutPad][8]  (one 16-byte load per fragment, next stencil position in flight).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct GCSplitParams {
+    const float *x;
+    const bf16x8 *ws;
+    const float *bias, *bn_scale, *bn_shift;
+    float *out;
+    const int32_t *gather;
+    int B, Cin, Cout, CoutPad, Lin, Lout, ncols, gt_bytes, nkp_max;
+};
+
+__device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h1 = (__bf16)v[e];
+        const float r1 = v[e] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        b1[e] = h1; b2[e] = h2; b3[e] = (__bf16)r2;
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *gt = reinterpret_cast<int *>(smem);
+    bf16x8 *slab = reinterpret_cast<bf16x8 *>(smem + p.gt_bytes);        // [3 planes][2 k-octets][nkp_max][Lin]
+    constexpr int OT = 256, NCOL = 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int Lin = p.Lin, Lout = p.Lout;
+    const int n_ot = p.CoutPad / OT;
+    const int ot_idx = blockIdx.x % n_ot, ct_idx = blockIdx.x / n_ot;
+    const int o_wave = ot_idx * OT + w * 64;
+    const int col0 = ct_idx * NCOL;
+    const int b_first = col0 / Lout;
+    const int col_last = min(col0 + NCOL, p.ncols) - 1;
+    const int nkp = col_last / Lout - b_first + 1;
+    const int plane_stride = 2 * p.nkp_max * Lin, h_stride = p.nkp_max * Lin;     // in 16-byte fragments
+
+    for (int i = tid; i < Lout * KS; i += 256) gt[i] = p.gather[i];
+
+    int rowbase[4], gi[4], bcol[4];
+    bool valid[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = col0 + t * 32 + j;
+        valid[t] = n < p.ncols;
+        const int nn = valid[t] ? n : col0;
+        const int b = nn / Lout;
+        gi[t] = nn - b * Lout;
+        bcol[t] = b;
+        rowbase[t] = h * h_stride + (b - b_first) * Lin;
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    const bool has_bn = p.bn_scale != nullptr;
+    const size_t ws_plane = (size_t)KS * (p.Cin / 16) * 2 * p.CoutPad;    // fragments per split plane
+
+    for (int c0 = 0; c0 < p.Cin; c0 += 16) {
+        __syncthreads();   // previous chunk fully consumed (also orders the gather-table fill)
+        // ---- stage act(x[b_first .. +nkp) [c0 .. c0+16) [0 .. Lin)) as three bf16 planes of k-octets ----------------
+        const int items = nkp * 2 * Lin;
+        for (int i = tid; i < items; i += 256) {
+            const int col = i % Lin, r = i / Lin;
+            const int ho = r & 1, kp = r >> 1;
+            const float *src = p.x + ((size_t)(b_first + kp) * p.Cin + c0 + 8 * ho) * Lin + col;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * Lin];
+            if (has_bn) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.bn_scale[c0 + 8 * ho + e], p.bn_shift[c0 + 8 * ho + e]), 0.f);
+            }
+            bf16x8 b1, b2, b3;
+            gc_split3(v, b1, b2, b3);
+            bf16x8 *dst = slab + ho * h_stride + kp * Lin + col;
+            dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
+        }
+        __syncthreads();
+
+        // ---- MFMA over the stencil; the weight fragments of position k+1 are in flight during position k ----------------
+        bf16x8 a_cur[2][3], a_nxt[2][3];
+        auto load_a = [&](int k, bf16x8 (&a)[2][3]) {
+            const bf16x8 *wk = p.ws + (((size_t)k * (p.Cin / 16) + c0 / 16) * 2 + h) * p.CoutPad + o_wave + j;
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) a[ot][sp] = wk[sp * ws_plane + ot * 32];
+        };
+        load_a(0, a_cur);
+#pragma unroll 1
+        for (int k = 0; k < KS; ++k) {
+            if (k + 1 < KS) load_a(k + 1, a_nxt);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 *bp = slab + rowbase[t] + gt[gi[t] * KS + k];
+                const bf16x8 b1 = bp[0], b2 = bp[plane_stride], b3 = bp[2 * plane_stride];
+                f32x16 c0v = acc[0][t], c1v = acc[1][t];
+                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][2], b1, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][2], b1, c1v, 0, 0, 0);
+                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b2, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][1], b2, c1v, 0, 0, 0);
+                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b3, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b3, c1v, 0, 0, 0);
+                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b1, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][1], b1, c1v, 0, 0, 0);
+                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b2, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b2, c1v, 0, 0, 0);
+                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b1, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b1, c1v, 0, 0, 0);
+                acc[0][t] = c0v; acc[1][t] = c1v;
+            }
+            if (k + 1 < KS) {
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) a_cur[ot][sp] = a_nxt[ot][sp];
+            }
+        }
+    }
+
+    // ---- epilogue: bias, masked store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (!valid[t]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < p.Cout) p.out[((size_t)bcol[t] * p.Cout + o) * Lout + gi[t]] = acc[ot][t][r] + p.bias[o];
+            }
+        }
+    }
+}
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // number of K slices for an under-filled grid: aim at >= 512 workgroups, slices are whole channel chunks
@@ -353,4 +505,29 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
     }
     roreg::set_error("roreg_group_conv: unsupported (KS=%d, Lin=%d)", KS, Lin);
     return 2;
+}
+
+extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
+                                      float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+    if (B == 0) return 0;
+    ROREG_REQUIRE(x && wsplit && bias && out && gather && B > 0, "roreg_group_conv_split: bad arguments");
+    ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv_split: bn_scale/bn_shift must come together");
+    ROREG_REQUIRE(KS == 13 && Cin % 16 == 0 && Cout % 256 == 0 && Lin > 0 && Lin <= 64 && Lout > 0 && Lout <= 64,
+                  "roreg_group_conv_split: unsupported shape (KS=%d Cin=%d Cout=%d Lin=%d Lout=%d)", KS, Cin, Cout, Lin, Lout);
+    ROREG_REQUIRE((long long)B * Lout < (1ll << 31), "roreg_group_conv_split: too many columns");
+    GCSplitParams p;
+    p.x = x; p.ws = reinterpret_cast<const bf16x8 *>(wsplit); p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.out = out;
+    p.gather = gather; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = Cout; p.Lin = Lin; p.Lout = Lout; p.ncols = B * Lout;
+    p.gt_bytes = round_up(Lout * KS * 4, 16);
+    p.nkp_max = (128 - 1) / Lout + 2;
+    if (p.nkp_max > B) p.nkp_max = B;
+    const size_t lds = (size_t)p.gt_bytes + (size_t)3 * 2 * p.nkp_max * Lin * 16;
+    ROREG_REQUIRE(lds <= 80 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
+    auto kern = group_conv_split_kernel<13>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
+    const int grid = ((p.ncols + 127) / 128) * (Cout / 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, roreg::as_stream(stream), p);
+    ROREG_CHECK_LAUNCH("roreg_group_conv_split");
+    return 0;
 }

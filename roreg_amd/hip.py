@@ -14,6 +14,15 @@ import torch
 from .group import tables
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libroreg_hip.so')
+
+# How the irrep-domain GEMMs and transforms feed the matrix cores:
+#   'split' (default): every f32 operand as three bf16 pieces, six cross products, f32 accumulate -- f32-accurate (measured error =
+#                      the f32 kernel's), 2.67x fewer matrix-core cycles;
+#   'f32'            : f32-input MFMA (bitwise an fmaf chain).
+# Environment override for drop-in runs of Test.py: ROREG_GEMM=f32.
+GEMM_MODE = os.environ.get('ROREG_GEMM', 'split')
+if GEMM_MODE not in ('split', 'f32'):
+    raise ValueError(f"ROREG_GEMM must be 'split' or 'f32', got {GEMM_MODE!r}")
 _lib = None
 _tables_uploaded = False
 
@@ -27,6 +36,7 @@ PROTOTYPES = {
     'roreg_group_conv_pack_weights': (c_int, [_P, c_int, c_int, c_int, _P]),
     'roreg_group_conv_workspace_size': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, _P, c_int, _P]),
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
     'roreg_inv_descriptor': (c_int, [_P, _P, c_int, _P]),
@@ -138,6 +148,8 @@ class ConvLayer:
         self.Cout, self.Cin = int(weight.shape[0]), int(weight.shape[1])
         self.KS = int(np.prod(weight.shape[2:]))
         self.wpack = pack_conv_weights(weight)
+        self._weight = weight.detach().to('cpu', torch.float32).clone()
+        self._wsplit = None
         self.bias = bias.detach().to(device, torch.float32).contiguous()
         if bn is not None:
             g, b, m, v = [t.detach().to('cpu', torch.float32) for t in bn]
@@ -150,6 +162,12 @@ class ConvLayer:
 
 
 _gather_cache = {}
+
+
+def _conv_wsplit(layer):
+    if layer._wsplit is None:
+        layer._wsplit = group_conv_split_pack(layer._weight)
+    return layer._wsplit
 
 # bench.py sets this to a list to collect (shape tag, start event, end event) per group-conv launch; the
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -169,8 +187,8 @@ def full_gather():
     return gather_table('nei60', tables().Nei)
 
 
-def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None):
-    """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32."""
+def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False):
+    """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32.  split: use the 3 x bf16 split kernel (f32-accurate) where its shape constraints hold."""
     ensure_tables()
     B, Cin, Lin = x.shape
     assert Cin == layer.Cin, (Cin, layer.Cin)
@@ -179,6 +197,11 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None):
     Lout = int(gather.shape[0]) if Lout is None else Lout
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
+    if split and residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0:
+        _check(lib().roreg_group_conv_split(_ptr(x, torch.float32), _ptr(_conv_wsplit(layer)), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
+                                            _ptr(out, torch.float32), _ptr(gather, torch.int32), B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()),
+               'roreg_group_conv_split')
+        return out
     ws_n = lib().roreg_group_conv_workspace_size(B, Cin, layer.Cout, Lin, Lout, layer.KS)
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device) if ws_n else None
     if PROFILE is not None:
@@ -631,21 +654,38 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     return out
 
 
-def bf16_split3_pack(Wm):
-    """Wm float32 [Mpad, K] (K % 16 == 0) -> int16 device tensor [3][K/16][2][Mpad][8]: the three bf16 pieces (round-to-nearest-even,
-    each piece taken from the exact float32 remainder) in the fragment order of irrep_gemm_split_kernel."""
-    Wm = np.ascontiguousarray(Wm, np.float32)
-    Mpad, K = Wm.shape
-
-    def rne(x):
-        u = x.view(np.uint32)
+def _bf16_split3(x):
+    """float32 array -> three uint16 arrays of bf16 bits: round-to-nearest-even pieces, each taken from the exact float32 remainder."""
+    out = []
+    rem = np.ascontiguousarray(x, np.float32)
+    for _ in range(3):
+        u = rem.view(np.uint32)
         r = ((u >> 16) & 1) + 0x7fff
         hi = ((u + r) >> 16).astype(np.uint16)
-        return hi, (hi.astype(np.uint32) << 16).view(np.float32)
+        out.append(hi)
+        rem = rem - (hi.astype(np.uint32) << 16).view(np.float32)
+    return out
+
+
+def bf16_split3_pack(Wm):
+    """Wm float32 [Mpad, K] (K % 16 == 0) -> int16 device tensor [3][K/16][2][Mpad][8]: the three bf16 pieces of every weight in the
+    fragment order of irrep_gemm_split_kernel."""
+    Wm = np.ascontiguousarray(Wm, np.float32)
+    Mpad, K = Wm.shape
     out = np.empty((3, K // 16, 2, Mpad, 8), np.uint16)
-    rem = Wm
-    for sp in range(3):
-        bits, val = rne(np.ascontiguousarray(rem))
+    for sp, bits in enumerate(_bf16_split3(Wm)):
         out[sp] = bits.reshape(Mpad, K // 16, 2, 8).transpose(1, 2, 0, 3)
-        rem = rem - val
+    return torch.from_numpy(out.view(np.int16)).cuda()
+
+
+def group_conv_split_pack(W):
+    """W [Cout,Cin,1,KS] / [Cout,Cin,KS] float32 -> int16 device tensor [3][KS][Cin/16][2][Cout][8] (group_conv_split_kernel's
+    fragment order: piece p of W[o, 16*(c/16) + 8*h + e, k])."""
+    Wn = W.detach().to('cpu', torch.float32).contiguous().numpy()
+    Cout, Cin = Wn.shape[0], Wn.shape[1]
+    KS = int(np.prod(Wn.shape[2:]))
+    Wn = Wn.reshape(Cout, Cin // 16, 2, 8, KS)
+    out = np.empty((3, KS, Cin // 16, 2, Cout, 8), np.uint16)
+    for sp, bits in enumerate(_bf16_split3(Wn)):
+        out[sp] = bits.transpose(4, 1, 2, 0, 3)
     return torch.from_numpy(out.view(np.int16)).cuda()

@@ -30,7 +30,7 @@ class ET_test(nn.Module):
             nn.Conv2d(d[2], d[3], 1, 1))
         self.pruned = True
         self.fourier_init = True
-        self.split_bf16 = False
+        self.split_bf16 = hip.GEMM_MODE == 'split'
 
     # ---- kernel plans -------------------------------------------------------------------------------------
     def _head_plans(self):
@@ -100,7 +100,7 @@ class ET_test(nn.Module):
                 del T0
             else:
                 h = self.Conv_init(x, gather=ga)                               # [B,256,45]
-            m = res._b_in(h, gather=gb)                                        # [B,512,13]
+            m = res._b_in(h, gather=gb, split=self.split_bf16)                 # [B,512,13]
             sc = h[:, :, p0:p0 + 1].contiguous()                               # identity short cut at g=0
             t = res._b_out(m, gather=gc, residual=sc)                          # [B,256,1]
         else:

@@ -47,7 +47,7 @@ class FourierGF:
         """net: Group_feat_network (parameter container)."""
         self.net = net
         self._key = None
-        self.split_bf16 = False       # True: GEMMs as 3 x bf16 split products (f32-accurate, 2.67x fewer matrix-core cycles)
+        self.split_bf16 = hip.GEMM_MODE == 'split'       # GEMMs / transforms as 3 x bf16 split products (f32-accurate), see hip.GEMM_MODE
 
     def _plan(self):
         key = _version_key(self.net)

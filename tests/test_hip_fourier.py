@@ -70,6 +70,30 @@ def test_ft_nonlin_split_matches_f32_path(group):
     assert float((back - 2 * x).abs().max()) < 2e-6 * float(x.abs().max())
 
 
+def test_group_conv_split_is_f32_accurate(group):
+    """Pruned 13-stencil conv (45 live columns -> 13) with BN+ReLU: the 3 x bf16 split kernel against float64 and the f32-MFMA kernel."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(12)
+    B, C, Oc, Lin, Lout = 37, 64, 256, 48, 13
+    conv = torch.nn.Conv2d(C, Oc, (1, 13))
+    bn = (torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.1, torch.rand(C) + 0.5)
+    layer = hip.ConvLayer(conv.weight, conv.bias, bn)
+    x = (rng.standard_normal((B, C, Lin)) * np.exp(rng.standard_normal((B, C, 1)))).astype(np.float32)
+    x[:, :, 45:] = 0
+    gather = np.stack([rng.permutation(45)[:13] for _ in range(Lout)]).astype(np.int32)
+    xd = torch.from_numpy(x).cuda(); gd = torch.from_numpy(gather).cuda()
+    y32 = hip.group_conv(xd, layer, gather=gd).double().cpu().numpy()
+    ysp = hip.group_conv(xd, layer, gather=gd, split=True).double().cpu().numpy()
+    g, b_, m, v = [t.double().numpy() for t in bn]
+    scale = g / np.sqrt(v + 1e-5); shift = b_ - m * scale
+    a = np.maximum(x.astype(np.float64) * scale[None, :, None] + shift[None, :, None], 0.0)
+    ref = np.einsum('ock,bcjk->boj', conv.weight.detach().double().numpy()[:, :, 0, :], a[:, :, gather]) + conv.bias.detach().double().numpy()[None, :, None]
+    s = np.abs(ref).max()
+    e32 = np.abs(y32 - ref).max() / s; esp = np.abs(ysp - ref).max() / s
+    assert e32 < 2e-6 and esp < 2e-6, (e32, esp)
+    assert esp < 3 * e32 + 2e-7, (e32, esp)
+
+
 def test_gemm_epilogue_residual_is_exact(group):
     """Out = W.X + Add in the GEMM epilogue is bitwise the separately computed sum (both GEMM kernels)."""
     from roreg_amd import hip
@@ -130,14 +154,32 @@ def test_split_bf16_gemm_is_f32_accurate(group):
     assert esp < 3 * e32 + 1e-7, (e32, esp)
 
 
-def test_gf_split_bf16_vs_golden(group):
+def test_gf_both_gemm_modes_vs_golden(group):
+    """The extractor in both matrix-core modes (3 x bf16 split = default, f32-input MFMA) against the reference's output."""
     from roreg_amd.network import name2network
     z = load_golden('gf_forward')
     net = name2network['GF_test'](default_config())
     synth.seeded_state_dict(net, int(z['seed']))
     x = torch.from_numpy(z['x'])
     net.PartI_net.mode = 'fourier'
-    a = net(x)['eqv'].cpu().numpy()
-    net.PartI_net._fourier.split_bf16 = True
-    b = net(x)['eqv'].cpu().numpy()
-    assert np.abs(b - z['eqv']).max() < 1e-5 and np.abs(a - b).max() < 5e-6
+    net(x)                                              # builds the plan
+    out = {}
+    for split in (False, True):
+        net.PartI_net._fourier.split_bf16 = split
+        out[split] = net(x)['eqv'].cpu().numpy()
+        assert np.abs(out[split] - z['eqv']).max() < 1e-5, split
+    assert np.abs(out[False] - out[True]).max() < 5e-6
+
+
+def test_et_both_gemm_modes_vs_golden(group):
+    from roreg_amd.network import name2network
+    z = load_golden('et_forward')
+    net = name2network['ET_test'](default_config())
+    synth.seeded_state_dict(net, int(z['seed']))
+    q = {}
+    for split in (False, True):
+        net.split_bf16 = split
+        batch = {k: torch.from_numpy(z[k].copy()) for k in ('before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx')}
+        q[split] = net(batch)['quaternion_pre'].cpu().numpy()
+        assert np.abs(q[split] - z['quaternion']).max() < 1e-4, split
+    assert np.abs(q[False] - q[True]).max() < 2e-5
