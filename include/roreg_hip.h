@@ -252,8 +252,10 @@ int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n,
  * roreg_ft_nonlin:          per (keypoint, channel): inverse transform (or group-domain input) -> + bias (+ bias2)
  *                           (+ group-domain residual) -> BatchNorm(eval)+ReLU (optional) -> forward transform (or group-domain
  *                           output [B,C,60], or only the Lout columns selected by g_map -- the ET trunk keeps 45 live columns).
- *                           Coefficients are one flat buffer: irrep rho occupies [off_rho*C*B, off_{rho+1}*C*B) as the row-major
- *                           matrix [d*C][d*B]. */
+ *                           Coefficients are one flat buffer of 60*C*Bp floats, Bp = B rounded up to 32: irrep rho occupies
+ *                           [off_rho*C*Bp, off_{rho+1}*C*Bp) as the row-major GEMM operand [d*C][d*Bp] (row (l,c); columns blocked by
+ *                           32 keypoints: column = (b/32)*(32*d) + i*32 + b%32; pad keypoints hold zeros).  roreg_irrep_gemm* is
+ *                           called with B := Bp. */
 int roreg_set_fourier_tables(const float *F_host);
 size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host);
 int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Add, const float *const *Wpack, int C, int O, int B,

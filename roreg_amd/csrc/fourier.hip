@@ -324,10 +324,15 @@ struct NonlinParams {
     const float *bias, *bias2, *bn_scale, *bn_shift;      // per channel; any may be null
     const float *A1, *A2;        // fragment-ordered transform tables (roreg_set_fourier_tables)
     const bf16x8 *A1s, *A2s;     // the same tables as 3 x bf16 split fragments of the K=16 bf16 MFMA (SPLIT kernels)
-    int B, C, tiles_per_c, Lout, Lvalid;
+    float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
+    int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
 
-// coefficient q = (rho, i, l) of (b, c) lives at flat offset  (alpha_q*C + c*d_q + i_q) * B + b   with alpha_q = offset_rho + l*d.
+// Coefficient layout: irrep rho occupies [off_rho*C*Bp, off_{rho+1}*C*Bp) as the row-major GEMM operand [d*C][d*Bp]; row (l, c), and
+// inside a row the columns are blocked by 32 keypoints: column = (b/32)*(32*d) + i*32 + (b%32).  The GEMMs never look inside a row,
+// and a 32-keypoint tile of this kernel reads, per (rho, l, c), ONE contiguous segment of d*128 bytes (16 segments of avg 480 B per
+// tile instead of 60 scattered 128-byte pieces).  coefficient q = (rho, i, l) of (b, c):
+//   offset = (alpha_q*C + c*d_q) * Bp + (b/32)*32*d_q + i_q*32 + b%32          with alpha_q = offset_rho + l*d.
 // The table is a compile-time constant: with the transform loops unrolled every row index is (constant*C + constant + c*constant),
 // i.e. scalar-ALU work on the wave-uniform channel c, and a lane only selects between the two candidates of its half-wave.
 struct QRows { int alpha[64], d[64], i[64]; };
@@ -378,31 +383,40 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
         if (!OUT_SPATIAL)
             for (int i = threadIdx.x; i < NA2; i += 256) sA2[i] = g2[i];
     }
+    // per-channel epilogue constants also live in LDS: as vector loads inside the tile loop they would force s_waitcnt vmcnt(0), i.e.
+    // drain the coefficient prefetch of the next tile (VMEM operations of a wave complete in order)
+    __shared__ float sBias[512], sScale[512], sShift[512];
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+        sBias[i] = (p.bias ? p.bias[i] : 0.f) + (p.bias2 ? p.bias2[i] : 0.f);
+        sScale[i] = p.bn_scale ? p.bn_scale[i] : 1.f;
+        sShift[i] = p.bn_shift ? p.bn_shift[i] : 0.f;
+    }
     __syncthreads();
     const bf16x8 *sA1s = reinterpret_cast<const bf16x8 *>(sA1), *sA2s = reinterpret_cast<const bf16x8 *>(sA2);   // [st][tile][plane][lane]
-    // row (of the [60*C][B] coefficient matrix) of coefficient q0 (first half-wave) / q1 (second half-wave) of channel c
-    // (the table entries are compile-time constants, the two candidate rows scalar-ALU values; a lane only selects)
-#define ROW_OF(Q0, Q1, c) (h ? (kQ.alpha[Q1] * C + kQ.i[Q1] + (c) * kQ.d[Q1]) : (kQ.alpha[Q0] * C + kQ.i[Q0] + (c) * kQ.d[Q0]))
+    // flat offset (without the lane's keypoint jn) of coefficient q of channel c in keypoint tile tb; the table entries are compile-time
+    // constants, so both half-wave candidates are scalar-ALU values and a lane only selects
+    const size_t Bp = (size_t)p.Bp;
+#define OFF_Q(Q, c, tb) ((size_t)(kQ.alpha[Q] * C + (c) * kQ.d[Q]) * Bp + (size_t)(tb) * (32 * kQ.d[Q]) + kQ.i[Q] * 32)
+#define OFF_OF(Q0, Q1, c, tb) (OFF_Q(Q0, c, tb) + (size_t)h * (OFF_Q(Q1, c, tb) - OFF_Q(Q0, c, tb)))   // arithmetic select: one load, no exec-masked pair
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
     constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT ? 32 : 30);
-    float cv[NCV], cn[NCV];
+    float cn[NCV];
     auto load_coefs = [&](int tile, float (&dst)[NCV]) {
         const int c = tile / p.tiles_per_c;
-        int b = (tile - c * p.tiles_per_c) * 32 + jn;
-        if (b >= B) b = B - 1;
+        const int tb = tile - c * p.tiles_per_c;
         if constexpr (SPLIT) {
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
                 constexpr int q0 = 16 * st + e, q1 = 16 * st + 8 + e;
-                if constexpr (q1 < ROREG_G) dst[st * 8 + e] = p.Xin[(size_t)ROW_OF(q0, q1, c) * B + b];
-                else dst[st * 8 + e] = h ? 0.f : p.Xin[(size_t)(kQ.alpha[q0] * C + kQ.i[q0] + c * kQ.d[q0]) * B + b];
+                if constexpr (q1 < ROREG_G) dst[st * 8 + e] = p.Xin[OFF_OF(q0, q1, c, tb) + jn];
+                else dst[st * 8 + e] = p.Xin[OFF_Q(q0, c, tb) + jn];      // q1 does not exist: the second half-wave's copy is zeroed at use
             });
         } else {
             static_for<30>([&](auto ic) {
                 constexpr int s = decltype(ic)::value;
                 constexpr int q0 = 2 * s, q1 = 2 * s + 1;
-                dst[s] = p.Xin[(size_t)ROW_OF(q0, q1, c) * B + b];
+                dst[s] = p.Xin[OFF_OF(q0, q1, c, tb) + jn];
             });
         }
     };
@@ -417,9 +431,12 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
         return c;
     };
-    if (!IN_SPATIAL && wave_global < n_tiles) load_coefs(wave_global, cv);
-
-    for (int tile = wave_global; tile < n_tiles; tile += n_waves) {
+    // Pipeline with two register sets (no copies): while a tile is computed from one set, the coefficients of the wave's next tile
+    // are in flight into the other one.  VMEM operations of a wave complete in order, so a tile only waits for loads that are a whole
+    // tile old (the stores and loads issued after them stay in flight).  The explicit wait after the first loads gives the loop ONE
+    // wait state on both entry paths -- otherwise the compiler merges "first loads just issued" with the steady state and drains the
+    // prefetch at every tile.  A wave with an odd number of tiles processes its last tile twice (idempotent stores): branch-free.
+    auto process = [&](int tile, int next_tile, float (&cv)[NCV], float (&cnext)[NCV]) {
         asm volatile("" ::: "memory");      // keep the transform fragments in LDS: without this the compiler hoists all 62 of them into VGPRs
         const int c = tile / p.tiles_per_c;
         const int b = (tile - c * p.tiles_per_c) * 32 + jn;
@@ -436,7 +453,8 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                     v[t][r] = g < ROREG_G ? src[g] : 0.f;
                 }
         } else {
-            if (tile + n_waves < n_tiles) load_coefs(tile + n_waves, cn);
+            load_coefs(next_tile, cnext);
+            __builtin_amdgcn_sched_barrier(0);          // the prefetch stays ahead of this tile's MFMAs (the scheduler would sink it to save registers)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -446,7 +464,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                 for (int st = 0; st < 4; ++st) {
                     float x8[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x8[e] = cv[st * 8 + e];
+                    for (int e = 0; e < 8; ++e) x8[e] = (16 * st + 8 + e < ROREG_G || h == 0) ? cv[st * 8 + e] : 0.f;
                     bf16x8 b1, b2, b3;
                     split3(x8, b1, b2, b3);
                     v[0] = mfma6(sA1s + ((st * 2 + 0) * 3) * 64 + lane, b1, b2, b3, v[0]);
@@ -461,11 +479,9 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
             }
         }
         // ---- group-domain epilogue --------------------------------------------------------------------------------
-        float bsum = 0.f;
-        if (p.bias) bsum += p.bias[c];
-        if (p.bias2) bsum += p.bias2[c];
+        const float bsum = sBias[c];
         const bool bn = p.bn_scale != nullptr;
-        const float sc = bn ? p.bn_scale[c] : 1.f, sh = bn ? p.bn_shift[c] : 0.f;
+        const float sc = sScale[c], sh = sShift[c];
         const float *rs = (OUT_SPATIAL && p.r_spatial) ? p.r_spatial + ((size_t)bb * C + c) * ROREG_G : nullptr;
         float *tb = OUT_SPATIAL ? sT + (threadIdx.x >> 6) * (32 * 65) : nullptr;      // this wave's [32 keypoints][65] transpose buffer
 #pragma unroll
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                 float x = v[t][r] + bsum;
                 if (OUT_SPATIAL && rs && g < ROREG_G) x += rs[g];
                 if (bn) x = fmaxf(fmaf(x, sc, sh), 0.f);
-                if (g >= ROREG_G) x = 0.f;
+                if (g >= ROREG_G || !valid) x = 0.f;          // pad keypoints carry zeros through the forward transform: their coefficients are exact 0
                 v[t][r] = x;
                 if (OUT_SPATIAL && g < ROREG_G) {
                     const int go = p.g_map ? p.g_map[g] : g;
@@ -519,27 +535,44 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
                         o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 1) * 64 + lane], v[t][r], o[1], 0, 0, 0);
                     }
             }
-            if (valid) {
+            {
+                const int tb = tile - c * p.tiles_per_c;      // pad keypoints (b >= B) get zeros: the buffers stay fully defined
                 static_for<32>([&](auto ic) {
                     constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
                     constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
                     if constexpr (q0 < ROREG_G) {
-                        if (q1 < ROREG_G || h == 0) p.Xout[(size_t)ROW_OF(q0, (q1 < 64 ? q1 : 63), c) * B + b] = o[t][r];
+                        if constexpr (q1 < ROREG_G) p.Xout[OFF_OF(q0, q1, c, tb) + jn] = o[t][r];
+                        else {      // q1 does not exist: the second half-wave stores into a dump row instead of branching around the store,
+                                    // so every tile issues the same 32 stores and the pipeline's vmcnt bookkeeping stays exact
+                            float *dst = h ? p.dump + lane : p.Xout + OFF_Q(q0, c, tb) + jn;
+                            *dst = o[t][r];
+                        }
                     }
                 });
             }
         }
+    };
+    if (wave_global < n_tiles) {
+        const int last = wave_global + ((n_tiles - 1 - wave_global) / n_waves) * n_waves;        // this wave's last tile
+        float cb[NCV];
         if (!IN_SPATIAL) {
-#pragma unroll
-            for (int s = 0; s < NCV; ++s) cv[s] = cn[s];
+            load_coefs(wave_global, cn);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+        }
+        for (int tile = wave_global; tile <= last; tile += 2 * n_waves) {
+            const int t1 = min(tile + n_waves, last), t2 = min(tile + 2 * n_waves, last);
+            process(tile, t1, cn, cb);
+            process(t1, t2, cb, cn);
         }
     }
 }
 
-#undef ROW_OF
+#undef OFF_OF
+#undef OFF_Q
 
 float *g_A1 = nullptr, *g_A2 = nullptr;
 uint16_t *g_A1s = nullptr, *g_A2s = nullptr;
+float *g_dump = nullptr;
 
 }  // namespace
 
@@ -604,7 +637,7 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
                     }
                 }
     if (!g_A1s) {
-        if (hipMalloc(&g_A1s, sizeof(A1s)) != hipSuccess || hipMalloc(&g_A2s, sizeof(A2s)) != hipSuccess) {
+        if (hipMalloc(&g_A1s, sizeof(A1s)) != hipSuccess || hipMalloc(&g_A2s, sizeof(A2s)) != hipSuccess || hipMalloc(&g_dump, 64 * sizeof(float)) != hipSuccess) {
             roreg::set_error("roreg_set_fourier_tables: hipMalloc failed");
             return 1;
         }
@@ -708,7 +741,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
-    ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr) && B > 0 && C > 0, "roreg_ft_nonlin: bad arguments");
+    ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr) && B > 0 && C > 0 && C <= 512, "roreg_ft_nonlin: bad arguments (C <= 512)");
     ROREG_REQUIRE((long long)60 * C * B < (1ll << 40), "roreg_ft_nonlin: tensor too large");
     ROREG_REQUIRE(!g_map || (Lout >= Lvalid && Lvalid > 0 && Lout <= 64), "roreg_ft_nonlin: bad Lout/Lvalid");
     NonlinParams p;
@@ -717,8 +750,8 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
-    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s);
-    p.B = B; p.C = C; p.tiles_per_c = (B + 31) / 32;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump;
+    p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
     long long blocks = (n_tiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;

@@ -162,8 +162,7 @@ class RegistrationEngine:
             while j < len(items) and (j == i or rows + sizes[j] <= max_rows):
                 rows += sizes[j]; j += 1
             batch = hip.LtBatch([(c0.before, c1.before, c0.eqv, c1.eqv, c0.keys, c1.keys, m, sel) for c0, c1, m, sel in items[i:j]])
-            rows_pad = (rows + 3) // 4 * 4                # the irrep-domain GEMM streams 16-byte column groups
-            dr_all, x_all = batch.prepare(rows_pad)
+            dr_all, x_all = batch.prepare()
             with torch.no_grad():
                 q_all = self.et.trunk_and_head(x_all) if rows else torch.empty((0, 4), dtype=torch.float32, device='cuda')
             del x_all

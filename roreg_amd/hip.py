@@ -603,25 +603,38 @@ def _ptr_array(views):
     return arr
 
 
+def coef_pitch(B):
+    """Keypoint pitch of the coefficient buffers: B rounded up to the 32-keypoint tile of ft_nonlin (pad keypoints hold zeros)."""
+    return (int(B) + 31) // 32 * 32
+
+
+def coef_size(C, B):
+    return 60 * C * coef_pitch(B)
+
+
 def coef_views(buf, C, B):
-    """Five per-irrep views [d*C, d*B] of a flat coefficient buffer of 60*C*B floats."""
-    return [buf[IRREP_OFFSETS[r] * C * B:IRREP_OFFSETS[r + 1] * C * B].view(IRREP_DIMS[r] * C, IRREP_DIMS[r] * B) for r in range(5)]
+    """Five per-irrep GEMM operands [d*C, d*Bp] of a flat coefficient buffer of 60*C*Bp floats (Bp = coef_pitch(B))."""
+    Bp = coef_pitch(B)
+    return [buf[IRREP_OFFSETS[r] * C * Bp:IRREP_OFFSETS[r + 1] * C * Bp].view(IRREP_DIMS[r] * C, IRREP_DIMS[r] * Bp) for r in range(5)]
 
 
 _tile_cache = {}
 
 
 def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None):
-    """coefficients [60*C*B] -> [60*O*B] through the five per-irrep GEMMs.  split: the five 3xbf16-split weight tensors
-    (f32-accurate GEMM on the bf16 matrix cores) or None for the exact f32-input MFMA kernel.  add: optional coefficient
-    buffer [60*O*B] summed onto the result in the epilogue (residual short cut in the irrep domain)."""
-    out = torch.empty(60 * O * B, dtype=torch.float32, device=X_buf.device)
-    key = (O, B)
+    """coefficients [60*C*Bp] -> [60*O*Bp] through the five per-irrep GEMMs (Bp = coef_pitch(B): the GEMMs run on the padded width).
+    split: the five 3xbf16-split weight tensors (f32-accurate GEMM on the bf16 matrix cores) or None for the f32-input MFMA kernel.
+    add: optional coefficient buffer [60*O*Bp] summed onto the result in the epilogue (residual short cut in the irrep domain)."""
+    Bp = coef_pitch(B)
+    if X_buf.numel() != 60 * C * Bp or (add is not None and add.numel() != 60 * O * Bp):
+        raise HipError(f'irrep_gemm: coefficient buffers must hold 60*C*{Bp} floats (B={B} padded to the 32-keypoint pitch)')
+    out = torch.empty(60 * O * Bp, dtype=torch.float32, device=X_buf.device)
+    key = (O, Bp)
     t = _tile_cache.get(key)
     if t is None:
-        n = lib().roreg_irrep_gemm_tiles(O, B, None)
+        n = lib().roreg_irrep_gemm_tiles(O, Bp, None)
         host = np.empty((n, 3), np.int32)
-        lib().roreg_irrep_gemm_tiles(O, B, host.ctypes.data)
+        lib().roreg_irrep_gemm_tiles(O, Bp, host.ctypes.data)
         t = torch.from_numpy(host).cuda()
         _tile_cache[key] = t
     xv = coef_views(X_buf, C, B); ov = coef_views(out, O, B)
@@ -629,13 +642,13 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None):
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
     if split is not None:
-        _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, B, _ptr(t, torch.int32), int(t.shape[0]),
+        _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]),
                                             _stream()), 'roreg_irrep_gemm_split')
     else:
-        _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(Wpacks), C, O, B, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
+        _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(Wpacks), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
                'roreg_irrep_gemm')
     if PROFILE is not None:
-        e1.record(); PROFILE.append((('irrep_gemm_split' if split is not None else 'irrep_gemm', B, C, O), e0, e1))
+        e1.record(); PROFILE.append((('irrep_gemm_split' if split is not None else 'irrep_gemm', Bp, C, O), e0, e1))
     return out
 
 
@@ -646,8 +659,10 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     if spatial_out:
         out = torch.empty((B, C, Lout if g_map is not None else 60), dtype=torch.float32, device=dev); xout = None; osp = _ptr(out)
     else:
-        out = torch.empty(60 * C * B, dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
+        out = torch.empty(coef_size(C, B), dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
     scale, shift = bn if bn is not None else (None, None)
+    if coef_in is not None and coef_in.numel() != coef_size(C, B):
+        raise HipError(f'ft_nonlin: coef_in must hold 60*C*{coef_pitch(B)} floats')
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
                                  _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 1 if split else 0, _stream()), 'roreg_ft_nonlin')

@@ -90,7 +90,7 @@ class ET_test(nn.Module):
         if self.pruned:
             ga, gb, gc, p0, gmap = self._pruned_gathers()
             B = x.shape[0]
-            if self.fourier_init and B % 4 == 0:
+            if self.fourier_init:
                 layer, bn = self._fourier_init()
                 hip.ensure_fourier()
                 X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=self.split_bf16)

@@ -63,9 +63,6 @@ class FourierGF:
         """x [B,32,60] device float32 -> eqv_raw = conv stack(x) + x  [B,32,60]."""
         self._plan()
         hip.ensure_fourier()
-        B0 = x.shape[0]
-        if B0 % 4:                                    # the GEMM streams 16-byte column groups: pad the batch, drop the rows at the end
-            x = torch.cat([x, x.new_zeros((4 - B0 % 4,) + tuple(x.shape[1:]))], 0)
         B = x.shape[0]
         sp = self.split_bf16
         X0 = hip.ft_nonlin(B, 32, x_spatial=x, split=sp)
@@ -81,4 +78,4 @@ class FourierGF:
         del T2
         T3 = hip.irrep_gemm(X3, self.l_out.wpack, 256, 32, B, split=self.l_out.wsplit if sp else None)
         out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True, split=sp)
-        return out[:B0] if B0 != B else out
+        return out

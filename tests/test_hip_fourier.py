@@ -20,12 +20,15 @@ def test_transform_roundtrip_and_orthogonality():
         x = rng.standard_normal((B, C, 60)).astype(np.float32)
         xd = torch.from_numpy(x).cuda()
         coef = hip.ft_nonlin(B, C, x_spatial=xd)
-        # coefficient (rho,i,l) of (b,c) sits at X_rho[(l*C + c), (i*B + b)]
+        # coefficient (rho,i,l) of (b,c) sits at X_rho[(l*C + c), (b/32)*32*d + i*32 + b%32]; pad keypoints are zero
         want = x @ gf.F.T.astype(np.float32)                                   # [B,C,60(q)]
         views = hip.coef_views(coef, C, B)
+        Bp = hip.coef_pitch(B)
         for q, (ri, i, l) in enumerate(gf.index):
-            got = views[ri].view(hip.IRREP_DIMS[ri], C, hip.IRREP_DIMS[ri], B)[l, :, i, :].t().cpu().numpy()
-            assert np.abs(got - want[:, :, q]).max() < 1e-5
+            d = hip.IRREP_DIMS[ri]
+            got = views[ri].view(d, C, Bp // 32, d, 32)[l, :, :, i, :].reshape(C, Bp).t().cpu().numpy()
+            assert np.abs(got[:B] - want[:, :, q]).max() < 1e-5
+            assert np.abs(got[B:]).max() == 0 if Bp > B else True
         back = hip.ft_nonlin(B, C, coef_in=coef, spatial_out=True).cpu().numpy()
         assert np.abs(back - x).max() < 1e-5
 
@@ -101,8 +104,8 @@ def test_gemm_epilogue_residual_is_exact(group):
     rng = np.random.default_rng(7)
     B, C, Oc = 100, 64, 96
     L = _Layer(torch.nn.Conv2d(C, Oc, (1, 13)))
-    X = torch.from_numpy(rng.standard_normal(60 * C * B).astype(np.float32)).cuda()
-    A = torch.from_numpy(rng.standard_normal(60 * Oc * B).astype(np.float32)).cuda()
+    X = torch.from_numpy(rng.standard_normal(hip.coef_size(C, B)).astype(np.float32)).cuda()
+    A = torch.from_numpy(rng.standard_normal(hip.coef_size(Oc, B)).astype(np.float32)).cuda()
     for sp in (None, L.wsplit):
         plain = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp)
         fused = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp, add=A)

@@ -6,7 +6,7 @@ from roreg_amd import hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65000
 hip.ensure_fourier()
 for C in (256, 512):
-    X = torch.randn(60 * C * B, device='cuda')
+    X = torch.randn(hip.coef_size(C, B), device='cuda')
     bias = torch.randn(C, device='cuda'); bn = (torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda'))
     for sp in (False, True):
         for _ in range(2):

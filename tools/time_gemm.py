@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 for (C, O) in [(256, 512), (512, 256)]:
     conv = torch.nn.Conv2d(C, O, (1, 13))
     L = _Layer(conv)
-    X = torch.randn(60 * C * B, device='cuda')
+    X = torch.randn(hip.coef_size(C, B), device='cuda')
     for name, sp in [('f32', None), ('split', L.wsplit)]:
         for _ in range(2):
             hip.irrep_gemm(X, L.wpack, C, O, B, split=sp)
