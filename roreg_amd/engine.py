@@ -25,6 +25,7 @@ class CloudState:
     keys: torch.Tensor = None       # keypoints [N,3] f64 (device)
     det: np.ndarray = None          # detector rank scores (host, as det_score/*.npy)
     keys_host: np.ndarray = None    # keypoints on the host (NMS sampling runs numpy selections like the reference)
+    nms: dict = field(default_factory=dict)   # keynum -> NMS sample of this cloud (a pure function of the cloud)
 
 
 @dataclass
@@ -116,10 +117,15 @@ class RegistrationEngine:
         """Keypoint sampling; consumes the global numpy RNG exactly like test/matcher.py:75-88."""
         n0, n1 = c0.before.shape[0], c1.before.shape[0]
         if self.cfg.RD:
+            # NMS sampling is a pure function of the cloud (keypoints, detector scores, keynum; no RNG): the reference recomputes
+            # it for both clouds of every pair (matcher.py:77-82), here it is computed once per cloud and reused
             from .test.matcher import NMS_sample
-            sampler = NMS_sample(keynum, 5)
-            s0 = sampler.sample(c0.keys_host, c0.det)
-            s1 = sampler.sample(c1.keys_host, c1.det)
+            out = []
+            for c in (c0, c1):
+                if keynum not in c.nms:
+                    c.nms[keynum] = NMS_sample(keynum, 5).sample(c.keys_host, c.det)
+                out.append(c.nms[keynum])
+            s0, s1 = out
         else:
             s0 = np.arange(n0); s1 = np.arange(n1)
             np.random.shuffle(s0); np.random.shuffle(s1)
