@@ -360,12 +360,13 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 // accumulate -- see irrep_gemm_split_kernel): 96 K=16 MFMAs (3072 cycles) per 32-keypoint tile instead of 124 f32 MFMAs (7936), which
 // turns the kernel from matrix-core-bound into HBM-bound.  K orders: inverse step st feeds coefficients q = 16 st + 8 h + e; the forward
 // product's step st consumes this lane's accumulator registers v[st>>1][8 (st&1) + e], i.e. again no transpose between the products.
-template <bool IN_SPATIAL, bool OUT_SPATIAL, bool SPLIT>
-__global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
+template <bool IN_SPATIAL, bool OUT_SPATIAL, bool SPLIT, int NW /* waves per workgroup */, int MINW /* waves per SIMD to fit */>
+__global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p) {
+    constexpr int NT = NW * 64;
     const int lane = threadIdx.x & 63;
     const int jn = lane & 31, h = lane >> 5;
-    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);   // wave-uniform: tile, c are scalars
-    const int n_waves = (gridDim.x * 256) >> 6;
+    const int wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x * NT + threadIdx.x) >> 6);   // wave-uniform: tile, c are scalars
+    const int n_waves = gridDim.x * NW;
     const int B = p.B, C = p.C;
     const int n_tiles = C * p.tiles_per_c;
 
@@ -375,18 +376,18 @@ __global__ __launch_bounds__(256) void ft_nonlin_kernel(NonlinParams p) {
     constexpr int NA1 = SPLIT ? 4 * 2 * 3 * 64 * 4 : 30 * 2 * 64, NA2 = SPLIT ? 4 * 2 * 3 * 64 * 4 : 32 * 2 * 64;   // floats (a bf16x8 = 4 floats)
     __shared__ __attribute__((aligned(16))) float sA1[IN_SPATIAL ? 64 : NA1];
     __shared__ __attribute__((aligned(16))) float sA2[OUT_SPATIAL ? 64 : NA2];
-    __shared__ float sT[OUT_SPATIAL ? 4 * 32 * 65 : 64];
+    __shared__ float sT[OUT_SPATIAL ? NW * 32 * 65 : 64];
     {
         const float *g1 = SPLIT ? reinterpret_cast<const float *>(p.A1s) : p.A1, *g2 = SPLIT ? reinterpret_cast<const float *>(p.A2s) : p.A2;
         if (!IN_SPATIAL)
-            for (int i = threadIdx.x; i < NA1; i += 256) sA1[i] = g1[i];
+            for (int i = threadIdx.x; i < NA1; i += NT) sA1[i] = g1[i];
         if (!OUT_SPATIAL)
-            for (int i = threadIdx.x; i < NA2; i += 256) sA2[i] = g2[i];
+            for (int i = threadIdx.x; i < NA2; i += NT) sA2[i] = g2[i];
     }
     // per-channel epilogue constants also live in LDS: as vector loads inside the tile loop they would force s_waitcnt vmcnt(0), i.e.
     // drain the coefficient prefetch of the next tile (VMEM operations of a wave complete in order)
     __shared__ float sBias[512], sScale[512], sShift[512];
-    for (int i = threadIdx.x; i < p.C; i += 256) {
+    for (int i = threadIdx.x; i < p.C; i += NT) {
         sBias[i] = (p.bias ? p.bias[i] : 0.f) + (p.bias2 ? p.bias2[i] : 0.f);
         sScale[i] = p.bn_scale ? p.bn_scale[i] : 1.f;
         sShift[i] = p.bn_shift ? p.bn_shift[i] : 0.f;
@@ -753,20 +754,19 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
-    long long blocks = (n_tiles + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
     hipStream_t s = roreg::as_stream(stream);
     const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
-    const dim3 grid((unsigned)blocks), blk(256);
     if (in_sp && out_sp) { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
+    auto grid_for = [&](int nw, long long cap) { long long b = (n_tiles + nw - 1) / nw; return dim3((unsigned)(b > cap ? cap : b)); };
     if (split) {
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, true>), grid, blk, 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, true>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, true>), grid, blk, 0, s, p);
+        // (6-wave workgroups at 3 waves per SIMD -- <.., 6, 3>, 384 threads, 139 VGPRs -- measured SLOWER: 4.6 vs 4.0 ms at C=512, B=65000)
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, true, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, true, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, true, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
     } else {
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, false>), grid, blk, 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, false>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, false>), grid, blk, 0, s, p);
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, false, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, false, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, false, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
     }
     ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
     return 0;
