@@ -82,11 +82,13 @@ int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
                     const float *tgt, const int64_t *tgt_rows, int n, int F,
                     int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream);
 
-/* The mutual matcher for a batch of pairs in three launches (test/matcher.py:90-107 for every pair of a scene).  Task p:
- * sampled descriptors desc0[rows0[i]] (m0 rows) and desc1[rows1[j]] (m1 rows), F = 32, rows NULL = identity; both directions are
- * searched with the exact formula of roreg_nn_search and the mutual pairs (rows0 value, rows1 value) are written in increasing
- * i to match_out + p*pitch*2 (pitch = max_m rounded up to even), their number to counts_out[p].  tasks_dev is a DEVICE array;
- * max_m >= every m0, m1.  workspace: roreg_mutual_match_batch_workspace(n_tasks, max_m) bytes. */
+/* The mutual matcher for a batch of pairs (test/matcher.py:90-107 for every pair of a scene), on the matrix cores and bit-exact:
+ * approximate squared distances |s|^2+|t|^2-2s.t as 3 x bf16 split MFMAs give row / column minima; every entry within a proven margin
+ * of its row (column) minimum is re-evaluated with the literal formula of roreg_nn_search and merged "first minimum wins"
+ * (csrc/mfma_match.hip).  Task p: sampled descriptors desc0[rows0[i]] (m0 rows) and desc1[rows1[j]] (m1 rows), F = 32, rows NULL =
+ * identity; the mutual pairs (rows0 value, rows1 value) are written in increasing i to match_out + p*pitch*2 (pitch = max_m rounded up
+ * to even), their number to counts_out[p].  tasks_dev is a DEVICE array; max_m >= every m0, m1.
+ * workspace: roreg_mutual_match_batch_workspace(n_tasks, max_m) bytes. */
 typedef struct {
     const float *desc0, *desc1;
     const int64_t *rows0, *rows1;

@@ -148,134 +148,6 @@ __global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict_
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Batched mutual matcher: all pairs of a scene in three launches.
-//   1. match_prepare_kernel: the sampled target rows of every (pair, direction) are copied into a PAIRED transposed layout
-//      tp[j/2][f][j&1] and the packed (distance, index) keys are reset;
-//   2. nn_search_batch_kernel: the exact-formula scan of nn_search_kernel with two targets per step -- the paired layout puts
-//      (t_j[f], t_{j+1}[f]) in one 64-bit scalar register pair, so subtract / multiply / accumulate are packed-f32 VALU
-//      instructions (v_pk_add_f32, v_pk_mul_f32: each component IEEE-rounded exactly like the scalar op), halving the VALU work;
-//   3. mutual_batch_kernel: the mutual check + ordered compaction straight from the packed keys.
-typedef float float2v __attribute__((ext_vector_type(2)));
-
-struct MatchTask {                 // mirrors roreg_match_task (include/roreg_hip.h)
-    const float *desc0, *desc1;
-    const int64_t *rows0, *rows1;
-    int32_t m0, m1;
-};
-
-__global__ __launch_bounds__(256) void match_prepare_kernel(const MatchTask *__restrict__ tasks, int pitch, float *__restrict__ tp_all,
-                                                            unsigned long long *__restrict__ packed_all) {
-    const int task = blockIdx.z >> 1, dir = blockIdx.z & 1;
-    const MatchTask t = tasks[task];
-    // direction 0 searches cloud 1 for every sampled keypoint of cloud 0: its targets are cloud 1's rows
-    const float *tgt = dir ? t.desc0 : t.desc1;
-    const int64_t *rows = dir ? t.rows0 : t.rows1;
-    const int n = dir ? t.m0 : t.m1, m = dir ? t.m1 : t.m0;
-    const int j = blockIdx.x * 8 + (threadIdx.x >> 5), f = threadIdx.x & 31;
-    const size_t region = (size_t)(task * 2 + dir) * pitch;
-    if (j < pitch) {
-        float v = 0.f;
-        if (j < n) v = tgt[(size_t)(rows ? rows[j] : (int64_t)j) * 32 + f];
-        tp_all[(region + (size_t)(j & ~1)) * 32 + f * 2 + (j & 1)] = v;
-        if (f == 0 && j < m) packed_all[region + j] = ~0ull;
-    }
-}
-
-__global__ __launch_bounds__(256) void nn_search_batch_kernel(const MatchTask *__restrict__ tasks, int pitch, int slice,
-                                                              const float *__restrict__ tp_all, unsigned long long *__restrict__ packed_all) {
-    constexpr int F = 32;
-    const int task = blockIdx.z >> 1, dir = blockIdx.z & 1;
-    const MatchTask t = tasks[task];
-    const float *src = dir ? t.desc1 : t.desc0;
-    const int64_t *src_rows = dir ? t.rows1 : t.rows0;
-    const int m = dir ? t.m1 : t.m0, n = dir ? t.m0 : t.m1;
-    if ((int)blockIdx.x * 256 >= m) return;
-    const size_t region = (size_t)(task * 2 + dir) * pitch;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int ii = i < m ? i : m - 1;
-    const size_t srow = src_rows ? (size_t)src_rows[ii] : (size_t)ii;
-    float s[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) s[f] = src[srow * F + f];
-    const int j0 = blockIdx.y * slice;                       // slice is even
-    const int j1 = min(j0 + slice, n);
-    float best_x = __builtin_inff(), best_d = __builtin_inff();
-    int best_j = 0x7fffffff;
-    const float2v *tp = reinterpret_cast<const float2v *>(tp_all + region * F);     // wave-uniform reads: scalar loads
-    for (int j = j0; j < j1; j += 2) {
-        const float2v *row = tp + (size_t)(j >> 1) * F;
-        float2v acc = {0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const float2v sf = {s[f], s[f]};
-            const float2v d = sf - row[f];
-            acc = acc + d * d;
-        }
-        const float x0 = __fadd_rn(acc.x, 1e-7f);
-        if (x0 < best_x) {                                   // sqrt is monotone: only a smaller radicand can give a smaller d
-            const float d = sqrtf(x0);
-            if (d < best_d) { best_d = d; best_j = j; }
-            best_x = x0;
-        }
-        const float x1 = __fadd_rn(acc.y, 1e-7f);
-        if (j + 1 < j1 && x1 < best_x) {
-            const float d = sqrtf(x1);
-            if (d < best_d) { best_d = d; best_j = j + 1; }
-            best_x = x1;
-        }
-    }
-    if (i < m && best_j != 0x7fffffff) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(best_d) << 32) | (unsigned)best_j;
-        atomicMin(&packed_all[region + i], key);
-    }
-}
-
-__global__ __launch_bounds__(1024) void mutual_batch_kernel(const MatchTask *__restrict__ tasks, int pitch,
-                                                            const unsigned long long *__restrict__ packed_all,
-                                                            int64_t *__restrict__ match_all, int32_t *__restrict__ counts) {
-    __shared__ int wave_cnt[16];
-    __shared__ int base;
-    const int task = blockIdx.x;
-    const MatchTask t = tasks[task];
-    const unsigned long long *p01 = packed_all + (size_t)(task * 2) * pitch, *p10 = p01 + pitch;
-    int64_t *match_out = match_all + (size_t)task * pitch * 2;
-    const int m = t.m0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int start = 0; start < m; start += 1024) {
-        const int i = start + tid;
-        bool keep = false;
-        int64_t j = 0;
-        if (i < m) {
-            j = (int64_t)(p01[i] & 0xffffffffu);
-            keep = (int64_t)(p10[j] & 0xffffffffu) == (int64_t)i;
-        }
-        const unsigned long long mask = __ballot(keep);
-        const int before = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[w] = __popcll(mask);
-        __syncthreads();
-        int woff = 0, total = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = wave_cnt[q];
-            if (q < w) woff += c;
-            total += c;
-        }
-        const int b0 = base;
-        if (keep) {
-            const int pos = b0 + woff + before;
-            match_out[2 * pos] = t.rows0 ? t.rows0[i] : (int64_t)i;
-            match_out[2 * pos + 1] = t.rows1 ? t.rows1[j] : j;
-        }
-        __syncthreads();
-        if (tid == 0) base = b0 + total;
-        __syncthreads();
-    }
-    if (tid == 0) counts[task] = base;
-}
-
 }  // namespace
 
 extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m, const float *tgt, const int64_t *tgt_rows,
@@ -322,37 +194,5 @@ extern "C" int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, in
     hipLaunchKernelGGL(mutual_kernel, dim3(1), dim3(1024), 0, roreg::as_stream(stream), nn01, nn10, m, sample0, sample1,
                        match_out, count_out);
     ROREG_CHECK_LAUNCH("roreg_mutual_matches");
-    return 0;
-}
-
-extern "C" size_t roreg_mutual_match_batch_workspace(int n_tasks, int max_m) {
-    const size_t pitch = (size_t)((max_m + 1) & ~1);
-    return (size_t)n_tasks * 2 * pitch * (sizeof(unsigned long long) + 32 * sizeof(float));
-}
-
-extern "C" int roreg_mutual_match_batch(const roreg_match_task *tasks_dev, int n_tasks, int max_m, int64_t *match_out, int32_t *counts_out,
-                                        void *workspace, size_t workspace_bytes, void *stream) {
-    if (n_tasks == 0) return 0;
-    ROREG_REQUIRE(tasks_dev && match_out && counts_out && workspace && n_tasks > 0 && max_m >= 0, "roreg_mutual_match_batch: bad arguments");
-    ROREG_REQUIRE(workspace_bytes >= roreg_mutual_match_batch_workspace(n_tasks, max_m), "roreg_mutual_match_batch: workspace too small");
-    static_assert(sizeof(roreg_match_task) == sizeof(MatchTask), "roreg_match_task layout");
-    hipStream_t s = roreg::as_stream(stream);
-    const MatchTask *tasks = reinterpret_cast<const MatchTask *>(tasks_dev);
-    const int pitch = (max_m + 1) & ~1;
-    unsigned long long *packed = reinterpret_cast<unsigned long long *>(workspace);
-    float *tp = reinterpret_cast<float *>(packed + (size_t)n_tasks * 2 * pitch);
-    if (pitch > 0) {
-        hipLaunchKernelGGL(match_prepare_kernel, dim3((pitch + 7) / 8, 1, 2 * n_tasks), dim3(256), 0, s, tasks, pitch, tp, packed);
-        const int gx = (max_m + 255) / 256;
-        int slices = (8192 + gx * 2 * n_tasks - 1) / (gx * 2 * n_tasks);        // aim at >= ~8192 workgroups: 32 per CU keeps the last round short
-        if (slices > (max_m + 1) / 2) slices = (max_m + 1) / 2;
-        if (slices < 1) slices = 1;
-        int slice = (max_m + slices - 1) / slices;
-        slice = (slice + 1) & ~1;
-        slices = (max_m + slice - 1) / slice;
-        hipLaunchKernelGGL(nn_search_batch_kernel, dim3(gx, slices, 2 * n_tasks), dim3(256), 0, s, tasks, pitch, slice, tp, packed);
-    }
-    hipLaunchKernelGGL(mutual_batch_kernel, dim3(n_tasks), dim3(1024), 0, s, tasks, pitch, packed, match_out, counts_out);
-    ROREG_CHECK_LAUNCH("roreg_mutual_match_batch");
     return 0;
 }

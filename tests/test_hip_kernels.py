@@ -387,3 +387,27 @@ def test_lt_batch_equals_per_pair_calls(group):
         x1 = hip.et_gather(c0['before'], c1['before'], c0['eqv'], c1['eqv'], dr1, rows0=r0, rows1=r1)
         T1 = hip.quat_to_trans(q[o:o + n].contiguous(), dr1, c0['keys'], c1['keys'], rows0=r0, rows1=r1)
         assert torch.equal(dr[o:o + n], dr1) and torch.equal(x[o:o + n], x1) and torch.equal(T[o:o + n], T1)
+
+
+@pytest.mark.parametrize('scale', [1.0, 37.5, 0.02])
+def test_mfma_matcher_is_exact_on_adversarial_descriptors(scale):
+    """The matrix-core matcher (approximate minima + exact check of the candidates) must reproduce the literal formula's first-minimum
+    indices where a plain dot-product expansion fails: clustered descriptors (thousands of near ties at the 1e-4..1e-7 level), exact
+    duplicates, descriptors of very different norms, any overall scale."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(5)
+    centers = rng.standard_normal((40, 32)).astype(np.float32)
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    A = (centers[rng.integers(0, 40, 1500)] + 1e-3 * rng.standard_normal((1500, 32))).astype(np.float32)
+    A[100:200] = A[0:100]                                                  # exact duplicates: ties resolved by the first index
+    A[300:400] += (1e-6 * rng.standard_normal((100, 32))).astype(np.float32)
+    B = (centers[rng.integers(0, 40, 1300)] + 1e-3 * rng.standard_normal((1300, 32))).astype(np.float32)
+    B[50:90] = A[500:540]                                                  # zero distances
+    B[200:260] *= np.float32(3.0)                                          # a few descriptors with 9x the squared norm
+    A = (A * np.float32(scale)).astype(np.float32); B = (B * np.float32(scale)).astype(np.float32)
+    mbuf, cnt = hip.mutual_match_batch([(cu(A), cu(B), None, None), (cu(B), cu(A), None, None)])
+    cnt = cnt.cpu().numpy(); mbuf = mbuf.cpu().numpy()
+    for q, (S, T) in enumerate(((A, B), (B, A))):
+        _, nn01 = O.knn(T, S, 1); _, nn10 = O.knn(S, T, 1)
+        want = O.mutual_check(nn01, nn10)
+        assert cnt[q] == want.shape[0] and np.array_equal(mbuf[q, :cnt[q]], want), (scale, q)
