@@ -152,9 +152,8 @@ class RegistrationEngine:
         """-> (match buffer [m,2] int64 device, count int32[1] device); test/matcher.py:90-107."""
         d0 = torch.from_numpy(np.ascontiguousarray(s0, np.int64)).cuda()
         d1 = torch.from_numpy(np.ascontiguousarray(s1, np.int64)).cuda()
-        nn01 = hip.nn_search(c0.inv, c1.inv, src_rows=d0, tgt_rows=d1)     # for each sampled kp of cloud 0: nearest in cloud 1
-        nn10 = hip.nn_search(c1.inv, c0.inv, src_rows=d1, tgt_rows=d0)
-        return hip.mutual_matches(nn01, nn10, d0, d1)
+        buf, cnt = hip.mutual_match_batch([(c0.inv, c1.inv, d0, d1)])
+        return buf[0], cnt
 
     def local_transforms_many(self, items, max_rows=32768):
         """Des2R + ET + assembly for several pairs: per group of pairs, 2 launches (Des2R, ET input assembly), ONE pass of the ET

@@ -90,10 +90,8 @@ class mutual():
             sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, eqv0.shape[0], eqv1.shape[0], keynum)
             s0 = torch.from_numpy(np.ascontiguousarray(sample0, np.int64)).cuda()
             s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
-            nn01 = hip.nn_search(inv0, inv1, src_rows=s0, tgt_rows=s1)
-            nn10 = hip.nn_search(inv1, inv0, src_rows=s1, tgt_rows=s0)
-            buf, cnt = hip.mutual_matches(nn01, nn10, s0, s1)
-            match_pps = buf[:int(cnt.item())].cpu().numpy()
+            buf, cnt = hip.mutual_match_batch([(inv0, inv1, s0, s1)])       # both NN directions + the mutual check (matcher.py:90-107)
+            match_pps = buf[0, :int(cnt.item())].cpu().numpy()
             np.save(f'{Save_dir}/{id0}-{id1}.npy', match_pps)
             np.save(f'{Save_score_dir}/{id0}-{id1}.npy', np.ones(match_pps.shape[0]))
 
