@@ -59,6 +59,14 @@ int roreg_group_conv(const float *x, const float *wpack, const float *bias,
 int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
                            float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
 
+/* Dense layer on row-major activations with the same f32-accurate 3 x bf16 split:
+ *   out[b][o] = bias[o] + sum_k W[o][k] * act_k(x[b][k]) (+ residual[b][o]),  act_k(v) = max(v*scale[k] + shift[k], 0) or identity (scale NULL).
+ * x [B][K] f32 (K % 16 == 0), out / residual [B][O].  wsplit: bf16 bits [3 planes][K/16][2 k-octets][round_up(O,256)][8] (zero rows beyond O).
+ * Used for the ET trunk's last layer (K = 512*13: the 13-column stencil of the single live output column, gather folded into the weight
+ * order; network/eqv_trans.py:101-117, network/ops.py:58-62) and the 1x1 head (network/eqv_trans.py:91-99,130-136). */
+int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
+                      const float *residual, float *out, int B, int K, int O, void *stream);
+
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
 int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream);

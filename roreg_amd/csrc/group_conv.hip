@@ -362,6 +362,147 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dense layer on row-major activations, 3 x bf16 split (f32-accurate):   out[b][o] = bias[o] + sum_k W[o][k] * act_k(x[b][k]) (+ res[b][o])
+// with act_k(v) = max(v * scale[k] + shift[k], 0) (BatchNorm(eval)+ReLU, per k) or the identity.  This is the ET trunk's last layer
+// (13 input columns -> the single column g = 0: K = 512*13 with the stencil's gather folded into the weight order) and the 1x1 head.
+// Activations are the MFMA A operand (rows b: a lane's fragment is 8 CONSECUTIVE floats of one row -- no transposition anywhere),
+// weights the B operand (columns o), so a lane's 16 accumulator rows are keypoints and its column is an output channel: stores are
+// coalesced along o.  Workgroup = 128 rows x 256 output channels, 4 waves as 2 x 2 (64 x 128 each, 8 accumulator tiles); per K16 step
+// the weight fragments of the next step (3 planes x 2 k-octets x 256 channels = 24 KiB) arrive by LDS-DMA, the activation k-octets of
+// the next step are converted (BN, ReLU, split) by one thread each and written in fragment order; both areas double-buffered.
+struct DenseParams {
+    const float *x;                // [B][K]
+    const bf16x8 *ws;              // [3][K/16][2][Opad][8], Opad = round_up(O, 256)
+    const float *bias;             // [O]
+    const float *scale, *shift;    // [K] or null
+    const float *res;              // [B][O] or null
+    float *out;                    // [B][O]
+    int B, K, O, Opad;
+};
+
+__global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 128, TO = 256;
+    constexpr int XBUF = 3 * 2 * TB, WBUF = 3 * 2 * TO;          // fragments per buffer
+    bf16x8 *xs = reinterpret_cast<bf16x8 *>(smem);               // [2 buf][3 planes][2 k-octets][128 rows]
+    bf16x8 *wsm = xs + 2 * XBUF;                                 // [2 buf][3 planes][2 k-octets][256 channels]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int wr = w & 1, wc = w >> 1;
+    const int n_ot = p.Opad / TO;
+    const int ot = blockIdx.x % n_ot, bt = blockIdx.x / n_ot;
+    const int b0 = bt * TB, o0 = ot * TO;
+    const int nsteps = p.K / 16;
+    const size_t wplane = (size_t)nsteps * 2 * p.Opad;            // fragments per split plane
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    // activation staging: thread -> (row, k-octet)
+    const int srow = tid >> 1, sho = tid & 1;
+    int brow = b0 + srow;
+    if (brow >= p.B) brow = p.B - 1;                              // clamped rows are never stored
+    const float *xrow = p.x + (size_t)brow * p.K + 8 * sho;
+    const bool has_act = p.scale != nullptr;
+    float4 xa, xb;
+    auto load_x = [&](int ks) {
+        const int kk = (ks < nsteps ? ks : nsteps - 1) * 16;
+        xa = *reinterpret_cast<const float4 *>(xrow + kk);
+        xb = *reinterpret_cast<const float4 *>(xrow + kk + 4);
+    };
+    auto convert_store = [&](int ks, int buf) {
+        float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        if (has_act) {
+            const int kk = (ks < nsteps ? ks : nsteps - 1) * 16 + 8 * sho;
+            const float4 s0 = *reinterpret_cast<const float4 *>(p.scale + kk), s1 = *reinterpret_cast<const float4 *>(p.scale + kk + 4);
+            const float4 t0 = *reinterpret_cast<const float4 *>(p.shift + kk), t1 = *reinterpret_cast<const float4 *>(p.shift + kk + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+        }
+        bf16x8 b1, b2, b3;
+        gc_split3(v, b1, b2, b3);
+        bf16x8 *dst = xs + buf * XBUF + sho * TB + srow;
+        dst[0] = b1; dst[2 * TB] = b2; dst[4 * TB] = b3;
+    };
+    // weight fragments of a step: per plane [2 k-octets][256 channels] = 512 fragments = two per thread
+    auto issue_w = [&](int ks, int buf) {
+        const bf16x8 *q = p.ws + (size_t)(ks < nsteps ? ks : nsteps - 1) * 2 * p.Opad + o0;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int ho = 0; ho < 2; ++ho)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * wplane + (size_t)ho * p.Opad + tid),
+                                                 (__attribute__((address_space(3))) void *)(wsm + buf * WBUF + sp * (2 * TO) + ho * TO + w * 64), 16, 0, 0);
+    };
+
+    load_x(0);
+    issue_w(0, 0);
+    convert_store(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int ks = 0; ks < nsteps; ++ks) {
+        issue_w(ks + 1, buf ^ 1);                                 // both land under the MFMAs of this step
+        load_x(ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 *xt = xs + buf * XBUF + h * TB + wr * 64 + j;
+        const bf16x8 *wt = wsm + buf * WBUF + h * TO + wc * 128 + j;
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) a[rt][sp] = xt[sp * (2 * TB) + rt * 32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 b1 = wt[t * 32], b2 = wt[2 * TO + t * 32], b3 = wt[4 * TO + t * 32];
+            f32x16 c0 = acc[0][t], c1 = acc[1][t];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b2, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b3, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b3, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b2, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b1, c1, 0, 0, 0);
+            acc[0][t] = c0; acc[1][t] = c1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next weights (LDS-DMA) and the staged activations have landed
+        convert_store(ks + 1, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- epilogue: C/D map: column (lane&31) = output channel, rows (r&3)+8*(r>>2)+4*h = keypoints --------------------------
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = o0 + wc * 128 + t * 32 + j;
+        if (o >= p.O) continue;
+        const float bo = p.bias[o];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = b0 + wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (b < p.B) {
+                    float v = acc[rt][t][r] + bo;
+                    if (p.res) v += p.res[(size_t)b * p.O + o];
+                    p.out[(size_t)b * p.O + o] = v;
+                }
+            }
+    }
+}
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // number of K slices for an under-filled grid: aim at >= 512 workgroups, slices are whole channel chunks
@@ -529,5 +670,24 @@ extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const 
     const int grid = ((p.ncols + 127) / 128) * (Cout / 256);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, roreg::as_stream(stream), p);
     ROREG_CHECK_LAUNCH("roreg_group_conv_split");
+    return 0;
+}
+
+extern "C" int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
+                                 const float *residual, float *out, int B, int K, int O, void *stream) {
+    if (B == 0) return 0;
+    ROREG_REQUIRE(x && wsplit && bias && out && B > 0 && K > 0 && O > 0, "roreg_dense_split: bad arguments");
+    ROREG_REQUIRE((scale == nullptr) == (shift == nullptr), "roreg_dense_split: scale/shift must come together");
+    ROREG_REQUIRE(K % 16 == 0, "roreg_dense_split: K must be a multiple of 16 (got %d)", K);
+    DenseParams p;
+    p.x = x; p.ws = reinterpret_cast<const bf16x8 *>(wsplit); p.bias = bias; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
+    p.B = B; p.K = K; p.O = O; p.Opad = round_up(O, 256);
+    const size_t lds = (size_t)2 * (3 * 2 * 128 + 3 * 2 * 256) * 16;
+    auto kern = dense_split_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { roreg::set_error("roreg_dense_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
+    const int grid = ((B + 127) / 128) * (p.Opad / 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, roreg::as_stream(stream), p);
+    ROREG_CHECK_LAUNCH("roreg_dense_split");
     return 0;
 }

@@ -37,6 +37,7 @@ PROTOTYPES = {
     'roreg_group_conv_workspace_size': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, _P, c_int, _P]),
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
     'roreg_inv_descriptor': (c_int, [_P, _P, c_int, _P]),
@@ -691,6 +692,35 @@ def bf16_split3_pack(Wm):
     for sp, bits in enumerate(_bf16_split3(Wm)):
         out[sp] = bits.reshape(Mpad, K // 16, 2, 8).transpose(1, 2, 0, 3)
     return torch.from_numpy(out.view(np.int16)).cuda()
+
+
+class DenseSplitLayer:
+    """out[b][o] = bias[o] + sum_k W[o][k] * act_k(x[b][k]) (+ residual) in kernel-ready form: W float32 [O,K] (K % 16 == 0) as the
+    three bf16 planes [3][K/16][2][round_up(O,256)][8]; act = BatchNorm(eval)+ReLU given as per-k scale/shift, or None."""
+
+    def __init__(self, W, bias, scale=None, shift=None):
+        Wn = np.ascontiguousarray(W, np.float32)
+        self.O, self.K = Wn.shape
+        Opad = (self.O + 255) // 256 * 256
+        Wp = np.zeros((Opad, self.K), np.float32); Wp[:self.O] = Wn
+        out = np.empty((3, self.K // 16, 2, Opad, 8), np.uint16)
+        for sp, bits in enumerate(_bf16_split3(Wp)):
+            out[sp] = bits.reshape(Opad, self.K // 16, 2, 8).transpose(1, 2, 0, 3)
+        self.ws = torch.from_numpy(out.view(np.int16)).cuda()
+        self.bias = torch.from_numpy(np.ascontiguousarray(bias, np.float32)).cuda()
+        self.scale = torch.from_numpy(np.ascontiguousarray(scale, np.float32)).cuda() if scale is not None else None
+        self.shift = torch.from_numpy(np.ascontiguousarray(shift, np.float32)).cuda() if shift is not None else None
+
+
+def dense_split(x, layer, residual=None):
+    """x [B, K] float32 (device, contiguous) -> [B, O]."""
+    B, K = x.shape
+    if K != layer.K:
+        raise HipError(f'dense_split: K mismatch ({K} vs {layer.K})')
+    out = torch.empty((B, layer.O), dtype=torch.float32, device=x.device)
+    _check(lib().roreg_dense_split(_ptr(x, torch.float32), _ptr(layer.ws), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
+                                   _ptr(residual, torch.float32), _ptr(out), B, K, layer.O, _stream()), 'roreg_dense_split')
+    return out
 
 
 def group_conv_split_pack(W):

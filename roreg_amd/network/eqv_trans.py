@@ -45,6 +45,36 @@ class ET_test(nn.Module):
             self._head_key = key
         return self._head
 
+    def _dense_plans(self):
+        """Split-mode tail of the network as dense layers on row-major activations (hip.dense_split): the trunk's last layer
+        (512 x 13 live columns -> the single column g = 0, the stencil's gather folded into the weight order) and the 1x1 head."""
+        res = self.PartII_SO3_Conv_layers[0]
+        fc = self.PartII_To_R_FC
+        key = _version_key(res.comb_layer_out, fc)
+        if getattr(self, '_dense_key', None) != key:
+            def fold(bn):
+                g, b, m, v = [t.detach().to('cpu', torch.float32).numpy() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+                sc = g / np.sqrt(v + bn.eps)
+                return sc, b - m * sc
+            T = tables()
+            l0, l1 = T.live_sets(2)[0], T.live_sets(2)[1]
+            pos1 = {g: i for i, g in enumerate(l1)}
+            cols = [pos1[int(v)] for v in T.Nei[l0[0]]]                       # stencil position k reads live column cols[k]
+            Wc = res.comb_layer_out[2].weight.detach().to('cpu', torch.float32).numpy()[:, :, 0, :]      # [256,512,13]
+            Wd = np.zeros((Wc.shape[0], Wc.shape[1], 13), np.float32)
+            for k, col in enumerate(cols):
+                Wd[:, :, col] += Wc[:, :, k]
+            sc, sh = fold(res.comb_layer_out[0])
+            out = hip.DenseSplitLayer(Wd.reshape(Wd.shape[0], -1), res.comb_layer_out[2].bias.detach().cpu().numpy(), np.repeat(sc, 13), np.repeat(sh, 13))
+            def w1(conv):
+                return conv.weight.detach().to('cpu', torch.float32).numpy()[:, :, 0, 0], conv.bias.detach().cpu().numpy()
+            h0 = hip.DenseSplitLayer(*w1(fc[0]))
+            h1 = hip.DenseSplitLayer(*w1(fc[3]), *fold(fc[1]))
+            h2 = hip.DenseSplitLayer(*w1(fc[6]), *fold(fc[4]))
+            self._dense = (out, h0, h1, h2)
+            self._dense_key = key
+        return self._dense
+
     LIVE_PAD = 48          # the 45 live columns of Conv_init's output are stored with a 16-byte-friendly stride
 
     @staticmethod
@@ -102,6 +132,10 @@ class ET_test(nn.Module):
                 h = self.Conv_init(x, gather=ga)                               # [B,256,45]
             m = res._b_in(h, gather=gb, split=self.split_bf16)                 # [B,512,13]
             sc = h[:, :, p0:p0 + 1].contiguous()                               # identity short cut at g=0
+            if self.split_bf16:                                                # trunk tail + head as dense split layers
+                d_out, d0, d1, d2 = self._dense_plans()
+                t = hip.dense_split(m.view(B, -1), d_out, residual=sc.view(B, -1))      # [B,256]
+                return hip.dense_split(hip.dense_split(hip.dense_split(t, d0), d1), d2)  # [B,4]
             t = res._b_out(m, gather=gc, residual=sc)                          # [B,256,1]
         else:
             h = self.Conv_init(x)

@@ -97,6 +97,24 @@ def test_group_conv_split_is_f32_accurate(group):
     assert esp < 3 * e32 + 2e-7, (e32, esp)
 
 
+def test_dense_split_is_f32_accurate():
+    """Dense layer on row-major activations (ET trunk tail / head): ragged B and O, with and without BN+ReLU / residual, against float64."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(13)
+    for B, K, Oc, act, res in [(300, 6656, 256, True, True), (77, 256, 512, False, False), (130, 128, 4, True, False), (1, 512, 128, True, True)]:
+        W = (rng.standard_normal((Oc, K)) / np.sqrt(K)).astype(np.float32); bias = rng.standard_normal(Oc).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, K).astype(np.float32) if act else None; sh = rng.standard_normal(K).astype(np.float32) if act else None
+        x = (rng.standard_normal((B, K)) * np.exp(rng.standard_normal((B, 1)))).astype(np.float32)
+        r = rng.standard_normal((B, Oc)).astype(np.float32) if res else None
+        layer = hip.DenseSplitLayer(W, bias, sc, sh)
+        got = hip.dense_split(torch.from_numpy(x).cuda(), layer, residual=torch.from_numpy(r).cuda() if res else None).double().cpu().numpy()
+        a = x.astype(np.float64)
+        if act:
+            a = np.maximum(a * sc.astype(np.float64) + sh.astype(np.float64), 0.0)
+        ref = a @ W.astype(np.float64).T + bias.astype(np.float64) + (r.astype(np.float64) if res else 0.0)
+        assert np.abs(got - ref).max() < 3e-6 * max(1.0, np.abs(ref).max()), (B, K, Oc)
+
+
 def test_gemm_epilogue_residual_is_exact(group):
     """Out = W.X + Add in the GEMM epilogue is bitwise the separately computed sum (both GEMM kernels)."""
     from roreg_amd import hip

@@ -17,3 +17,16 @@ for C in (256, 512):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
         gb = 2 * 60 * C * B * 4 / 1e9
         print(f'ft_nonlin coef->coef C={C} B={B} split={sp}: {dt*1e3:.2f} ms  {gb/dt/1e3:.2f} TB/s  {2*2*64*64*C*B/dt/1e12:.1f} TFLOP/s (padded 64x64 transforms)')
+# ET Conv_init output: irrep -> 45 live group columns (pitch 48), and the group -> irrep input transform
+B2 = 60000
+X = torch.randn(hip.coef_size(256, B2), device='cuda'); bias = torch.randn(256, device='cuda')
+gmap = torch.full((60,), -1, dtype=torch.int32); gmap[:45] = torch.arange(45, dtype=torch.int32); gmap = gmap.cuda()
+xs = torch.randn(B2, 128, 60, device='cuda'); bn = (torch.rand(128, device='cuda') + 0.5, torch.randn(128, device='cuda'))
+for sp in (False, True):
+    for name, fn, gb in (('irrep->group(45 of 60) C=256', lambda: hip.ft_nonlin(B2, 256, coef_in=X, bias=bias, spatial_out=True, g_map=gmap, Lout=48, Lvalid=45, split=sp), (60 + 48) * 256 * B2 * 4 / 1e9),
+                         ('group->irrep C=128', lambda: hip.ft_nonlin(B2, 128, x_spatial=xs, bn=bn, split=sp), 120 * 128 * B2 * 4 / 1e9)):
+        for _ in range(2): fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+        print(f'ft_nonlin {name} B={B2} split={sp}: {dt*1e3:.2f} ms  {gb/dt/1e3:.2f} TB/s')
