@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--pairs', type=int, default=N_PAIRS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the all-local-transforms figure (profiling runs)')
-    ap.add_argument('--gemm', choices=['f32', 'split'], default='split', help="irrep GEMMs / transforms: 3 x bf16 split operands with f32 accumulate (f32-accurate; default), or f32-input MFMA")
+    ap.add_argument('--gemm', choices=['f16x2', 'bf16x3', 'f32'], default='f16x2', help="matrix-core mode of the group-conv GEMMs: fp16 x 2 operands with power-of-two block scaling (default), bf16 x 3, or f32-input MFMA; all accumulate in f32")
     return ap.parse_args()
 
 
@@ -83,24 +83,29 @@ def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
     return t, threads
 
 
-DTYPE_OF = {'split': 'bf16x3 (every f32 operand as 3 bf16 pieces, 6 cross products, f32 accumulate: f32-accurate); fp64 estimator',
+DTYPE_OF = {'f16x2': 'fp16x2 (every f32 operand as hi+lo fp16 with power-of-two block scaling = 22 significant bits, 3 cross products, f32 accumulate; '
+                     'measured error <= the f32-input MFMA kernel\'s; transforms / ET convs bf16x3); fp64 estimator',
+            'bf16x3': 'bf16x3 (every f32 operand as 3 bf16 pieces, 6 cross products, f32 accumulate: f32-accurate); fp64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); fp64 estimator'}
+MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}
+KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2> (GF 256->512 / 512->256 in the irrep domain, fp16 x 2 block-scaled operands: 3 fp16 MFMAs per product)',
+             'bf16x3': 'irrep_gemm_split_kernel<32,3> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
+             'f32': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, f32-input MFMA)'}
 
 
 def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic):
     """MFMA roofline of the dominant kernel, in EXECUTED matrix-core flops: the kernel performs, per irrep, the GEMM
     [d*O x d*C] . [d*C x d*B], i.e. 2*O*C*B*244 flop per launch = `gemm_tflops` when divided by its time.
-    'f32': v_mfma_f32_32x32x2_f32, priced against the f32-input MFMA peak.  'split': every product is six bf16 MFMAs, so
-    6 x gemm_tflops are executed and priced against the dense bf16 peak; the f32-equivalent rate is reported beside it.
+    'f32': v_mfma_f32_32x32x2_f32, priced against the f32-input MFMA peak.  'bf16x3' / 'f16x2': every product is six bf16 / three fp16
+    MFMAs, so 6x / 3x gemm_tflops are executed and priced against the dense bf16 = fp16 peak; the f32-equivalent rate is reported too.
     (In the reference's own 13-stencil form the same layer is 780/244 = 3.2x more flops: SURVEY 8d's per-keypoint figure.)"""
     base = {'bound': 'mfma', 'unit': 'TFLOP/s', 'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic,
             'f32_equivalent_gemm_tflops': gemm_tflops, 'reference_stencil_form_equivalent_tflops': gemm_tflops * 780.0 / 244.0}
     if mode == 'f32':
-        base.update({'kernel': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, f32-input MFMA)',
-                     'achieved': gemm_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': gemm_tflops / PEAK_F32_MFMA_TFLOPS})
+        base.update({'kernel': KERNEL_OF[mode], 'achieved': gemm_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': gemm_tflops / PEAK_F32_MFMA_TFLOPS})
     else:
-        base.update({'kernel': 'irrep_gemm_split_kernel<32> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
-                     'achieved': 6 * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
+        k = MFMAS_PER_PRODUCT[mode]
+        base.update({'kernel': KERNEL_OF[mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
     return base
 
 
@@ -192,7 +197,7 @@ def main():
     same = all(np.array_equal(a.trans, b.trans) and a.recalltime == b.recalltime for a, b in zip(res, res_all))
 
     # ---- secondary figure 2: the other GEMM mode (3 x bf16 split operands, f32 accumulate: f32-accurate, not bit-equal) ----
-    other = 'split' if args.gemm == 'f32' else 'f32'
+    other = 'f32' if args.gemm != 'f32' else 'f16x2'
     eng.set_gemm_mode(other)
     hip.PROFILE = []
     dt_other, res_other = timed(n_all)
@@ -211,7 +216,7 @@ def main():
                 ms += e0.elapsed_time(e1); n_launch += 1
         return (flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), ms, n_launch
 
-    tag_of = {'f32': 'irrep_gemm', 'split': 'irrep_gemm_split'}
+    tag_of = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
     achieved, ms, n_launch = gemm_roofline(prof, tag_of[args.gemm])
     achieved_other, ms_other, n_other = gemm_roofline(prof_other or [], tag_of[other])
     traffic = None

@@ -275,12 +275,21 @@ int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *cons
  * Wsplit[rho]: uint16 bf16 bits, layout [3 splits][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
 int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit, int C, int O, int B,
                            const int32_t *tiles_dev, int n_tiles, void *stream);
+/* The same GEMMs with fp16 x 2 operands and power-of-two block scaling (half the matrix-core work of the bf16 x 3 split): activations
+ * are scaled by 2^e so that their absolute maximum (*x_absmax_dev, a device scalar maintained by the producer; NULL = 1) is <= 2^14, the
+ * weights were scaled by 2^w_exp when split; hi = fp16(x), lo = fp16(x - hi) keep 22 significant bits of every operand within 18 binades
+ * of the maximum (absolute error < 2^-39 of the maximum below that); products hi.hi + hi.lo + lo.hi, f32 accumulate, exact rescale.
+ * Wsplit2[rho]: fp16 bits, layout [2 (hi, lo)][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
+int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
+                           const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream);
 int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
                     const int32_t *g_map /* optional [60]: group column -> compact output column (< Lvalid) or -1 */,
                     int Lout /* row pitch of the compact output, >= Lvalid; pad columns are zero */, int Lvalid,
-                    int B, int C, int split /* 1: transforms as 3 x bf16 split MFMAs (f32-accurate) */, void *stream);
+                    int B, int C, int split /* 1: transforms as 3 x bf16 split MFMAs (f32-accurate) */,
+                    float *out_absmax /* optional device scalar, zeroed by the caller: receives max |coefficient written| (block scale of roreg_irrep_gemm_f16x2) */,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 //                       layout of the first, so no transpose is needed).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -148,11 +149,15 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
 // split on the fly from the f32 LDS tile (v_cvt_pk_bf16_f32, round-to-nearest-even), which the VALU does under the MFMAs' shadow.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 struct GemmSplitDescs {
     const float *X[NIRR];
     float *Out[NIRR];
     const float *Add[NIRR];
-    const bf16x8 *W[NIRR];        // [3][K/16][2][Mpad]
+    const float *xabsmax;         // NP = 2: device scalar, absolute maximum of the activation tensor (null = 1)
+    int w_exp;                    // NP = 2: the weights were scaled by 2^w_exp before the fp16 split
+    const void *W[NIRR];          // [NP][K/16][2][Mpad] 16-byte fragments
     int K[NIRR], M[NIRR], Mpad[NIRR], N[NIRR];
 };
 
@@ -167,25 +172,42 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8 &b1, bf16x8 &
     }
 }
 
+// fp16 x 2: hi = fp16(v * scale), lo = fp16(v * scale - hi)   (round-to-nearest-even conversions, the remainder is exact in f32)
+__device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * scale;
+        const _Float16 h1 = (_Float16)x;
+        hi[e] = h1; lo[e] = (_Float16)(x - (float)h1);
+    }
+}
+
 // Data flow of one K16 step: the packed weight fragments of the NEXT step (3 planes x 2 k-octets x 128 rows = 12 KiB) go
 // global -> LDS with LDS-DMA (no VGPR staging); every thread owns an 8(k) x 2(n) patch of the f32 activations, loaded two steps
 // ahead into registers, split ONCE (v_cvt_pk_bf16_f32) and written as three 16-byte k-octets into LDS in B-fragment order, so the
 // MFMA phase reads every bf16 fragment with one conflict-free ds_read_b128.  The ~110 VALU instructions of the conversion are
 // interleaved with the 48 MFMAs of the step (sched_group_barrier), i.e. they issue in the matrix pipe's shadow.  Both LDS areas
 // are double-buffered: one barrier per step.
-template <int CT>
+//
+// NP = 3: bf16 x 3 (24 significant bits per operand, six cross products).  NP = 2: fp16 x 2 with power-of-two block scaling -- the
+// activations are scaled by 2^e with e chosen from the tensor's absolute maximum (tracked by the producer kernel) so that |x| <= 2^14,
+// the weights by their own 2^w_exp; hi = fp16(x), lo = fp16(x - hi) keep 22 significant bits of every operand in the top 18 binades
+// below the maximum (smaller values keep an ABSOLUTE error below 2^-39 of the maximum), three cross products hi.hi, hi.lo, lo.hi, the
+// accumulator is rescaled by the exact 2^-(e + w_exp) in the epilogue.  Half the matrix-core work of NP = 3.
+template <int CT, int NP>
 __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+    using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NCOL = 256, OT = 128;
-    constexpr int XBUF = 3 * 2 * NCOL, ABUF = 3 * 2 * OT;         // fragments (16 B) per buffer
-    bf16x8 *xs = reinterpret_cast<bf16x8 *>(smem);               // [2 buf][3 split][2 k-octet][256 n (swizzled)]
-    bf16x8 *as = xs + 2 * XBUF;                                  // [2 buf][3 split][2 k-octet][128 m]
+    constexpr int XBUF = NP * 2 * NCOL, ABUF = NP * 2 * OT;       // fragments (16 B) per buffer
+    frag *xs = reinterpret_cast<frag *>(smem);                   // [2 buf][NP split][2 k-octet][256 n (swizzled)]
+    frag *as = xs + 2 * XBUF;                                    // [2 buf][NP split][2 k-octet][128 m]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
     if (irr < 0) return;
     const float *__restrict__ X = p.X[irr];
-    const bf16x8 *__restrict__ W = p.W[irr];
+    const frag *__restrict__ W = reinterpret_cast<const frag *>(p.W[irr]);
     const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
     const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
     const int wo = w & 1, wb = w >> 1;
@@ -193,6 +215,14 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
     const int n0 = nt * NCOL;
     const int ncol_wave = wb * 128;
 
+    // NP = 2: 2^e with |x| * 2^e <= 2^14 for the tensor's absolute maximum
+    float xscale = 1.f, oscale = 1.f;
+    if constexpr (NP == 2) {
+        const float mx = p.xabsmax ? *p.xabsmax : 1.f;
+        int e = 0;
+        if (mx > 0.f && mx < __builtin_inff()) { int ex; (void)frexpf(mx, &ex); e = 14 - ex; }       // mx = f * 2^ex, f in [0.5, 1)
+        xscale = ldexpf(1.f, e); oscale = ldexpf(1.f, -(e + p.w_exp));
+    }
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -220,19 +250,27 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
         float v0[8], v1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v0[e] = xr[e].x; v1[e] = xr[e].y; }
-        bf16x8 b1, b2, b3;
-        bf16x8 *dst = xs + buf * XBUF;
-        split3(v0, b1, b2, b3);
-        dst[slot0] = b1; dst[2 * NCOL + slot0] = b2; dst[4 * NCOL + slot0] = b3;
-        split3(v1, b1, b2, b3);
-        dst[slot1] = b1; dst[2 * NCOL + slot1] = b2; dst[4 * NCOL + slot1] = b3;
+        frag *dst = xs + buf * XBUF;
+        if constexpr (NP == 3) {
+            bf16x8 b1, b2, b3;
+            split3(v0, b1, b2, b3);
+            dst[slot0] = b1; dst[2 * NCOL + slot0] = b2; dst[4 * NCOL + slot0] = b3;
+            split3(v1, b1, b2, b3);
+            dst[slot1] = b1; dst[2 * NCOL + slot1] = b2; dst[4 * NCOL + slot1] = b3;
+        } else {
+            f16x8 hi, lo;
+            split2(v0, xscale, hi, lo);
+            dst[slot0] = hi; dst[2 * NCOL + slot0] = lo;
+            split2(v1, xscale, hi, lo);
+            dst[slot1] = hi; dst[2 * NCOL + slot1] = lo;
+        }
     };
     // weight fragments of a step: per split plane [2 k-octets][128 rows] = 256 fragments, one per thread, 64 consecutive per wave
-    const bf16x8 *wsrc = W + (size_t)(w >> 1) * Mpad + mt * OT + (w & 1) * 64 + lane;
+    const frag *wsrc = W + (size_t)(w >> 1) * Mpad + mt * OT + (w & 1) * 64 + lane;
     auto issue_a = [&](int kstep, int buf) {
-        const bf16x8 *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+        const frag *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
+        for (int sp = 0; sp < NP; ++sp)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * split_stride),
                                              (__attribute__((address_space(3))) void *)(as + buf * ABUF + sp * (2 * OT) + w * 64), 16, 0, 0);
     };
@@ -246,36 +284,46 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
         issue_a(ks + 1, buf ^ 1);                                 // land under the MFMAs of this step
         load_x(ks + 2, xr_load);                                  // consumed during the next step
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 *xt = xs + buf * XBUF;
-        const bf16x8 *at = as + buf * ABUF + aslot;
-        bf16x8 a[2][3];
+        const frag *xt = xs + buf * XBUF;
+        const frag *at = as + buf * ABUF + aslot;
+        frag a[2][NP];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) a[ot][sp] = at[sp * (2 * OT) + ot * 32];
+            for (int sp = 0; sp < NP; ++sp) a[ot][sp] = at[sp * (2 * OT) + ot * 32];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8 b1 = xt[xslot[t]], b2 = xt[2 * NCOL + xslot[t]], b3 = xt[4 * NCOL + xslot[t]];
             f32x16 c0 = acc[0][t], c1 = acc[1][t];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b1, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b1, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b2, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b2, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b3, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b3, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b1, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b1, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b2, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b2, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b1, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b1, c1, 0, 0, 0);
+            if constexpr (NP == 3) {
+                const bf16x8 b1 = xt[xslot[t]], b2 = xt[2 * NCOL + xslot[t]], b3 = xt[4 * NCOL + xslot[t]];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b1, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b2, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b2, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b3, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b3, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b1, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b2, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b2, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b1, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b1, c1, 0, 0, 0);
+            } else {
+                const f16x8 bh = xt[xslot[t]], bl = xt[2 * NCOL + xslot[t]];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], bh, c0, 0, 0, 0);       // lo.hi
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], bh, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], bl, c0, 0, 0, 0);       // hi.lo
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], bl, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], bh, c0, 0, 0, 0);       // hi.hi
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], bh, c1, 0, 0, 0);
+            }
             acc[0][t] = c0; acc[1][t] = c1;
         }
         convert_store(buf ^ 1, xr_use);                           // the next step's activations, split under the MFMAs' shadow
 #pragma unroll
-        for (int i = 0; i < 48; ++i) {
+        for (int i = 0; i < (NP == 3 ? 48 : 24); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA ...
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // ... then up to three VALU instructions in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 3 : 4, 0);    // ... then a few VALU instructions in its shadow
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next weights (LDS-DMA) and the staged patch have landed
@@ -306,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
                 const int m = m_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < M) {
                     float o = acc[ot][t][r];
+                    if constexpr (NP == 2) o *= oscale;
                     if (Add) o += Add[(size_t)m * N + n];
                     Out[(size_t)m * N + n] = o;
                 }
@@ -324,6 +373,7 @@ struct NonlinParams {
     const float *bias, *bias2, *bn_scale, *bn_shift;      // per channel; any may be null
     const float *A1, *A2;        // fragment-ordered transform tables (roreg_set_fourier_tables)
     const bf16x8 *A1s, *A2s;     // the same tables as 3 x bf16 split fragments of the K=16 bf16 MFMA (SPLIT kernels)
+    float *out_absmax;           // optional device scalar (zeroed by the caller): max |coefficient| written, for the fp16 x 2 GEMM's block scale
     float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
@@ -437,6 +487,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     // tile old (the stores and loads issued after them stay in flight).  The explicit wait after the first loads gives the loop ONE
     // wait state on both entry paths -- otherwise the compiler merges "first loads just issued" with the steady state and drains the
     // prefetch at every tile.  A wave with an odd number of tiles processes its last tile twice (idempotent stores): branch-free.
+    float wmax = 0.f;                                            // running max |coefficient| written by this lane
     auto process = [&](int tile, int next_tile, float (&cv)[NCV], float (&cnext)[NCV]) {
         asm volatile("" ::: "memory");      // keep the transform fragments in LDS: without this the compiler hoists all 62 of them into VGPRs
         const int c = tile / p.tiles_per_c;
@@ -538,6 +589,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             }
             {
                 const int tb = tile - c * p.tiles_per_c;      // pad keypoints (b >= B) get zeros: the buffers stay fully defined
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wmax = fmaxf(wmax, fabsf(o[t][r]));             // (rows q >= 60 and pad keypoints are exact zeros)
                 static_for<32>([&](auto ic) {
                     constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
                     constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
@@ -565,6 +620,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             process(tile, t1, cn, cb);
             process(t1, t2, cb, cn);
         }
+    }
+    if (!OUT_SPATIAL && p.out_absmax) {                              // one atomic per wave (non-negative floats order like their bit patterns)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(p.out_absmax), __float_as_uint(wmax));
     }
 }
 
@@ -716,29 +776,44 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
     return 0;
 }
 
+template <int NP>
+static int launch_gemm_split(const char *what, const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit,
+                             const float *xabsmax, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream) {
+    static const int dims[5] = {1, 3, 3, 4, 5};
+    GemmSplitDescs p;
+    for (int r = 0; r < 5; ++r) {
+        p.X[r] = X[r]; p.Out[r] = Out[r]; p.Add[r] = Add ? Add[r] : nullptr; p.W[r] = Wsplit[r];
+        p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
+    }
+    p.xabsmax = xabsmax; p.w_exp = w_exp;
+    constexpr int CT = 32;
+    const size_t lds = 2 * (NP * 2 * 256 + NP * 128 * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
+    auto kern = irrep_gemm_split_kernel<CT, NP>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), lds, roreg::as_stream(stream), p, tiles_dev);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
+    return 0;
+}
+
 extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit, int C, int O, int B,
                                       const int32_t *tiles_dev, int n_tiles, void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_split: bad arguments");
     ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_split: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
-    static const int dims[5] = {1, 3, 3, 4, 5};
-    GemmSplitDescs p;
-    for (int r = 0; r < 5; ++r) {
-        p.X[r] = X[r]; p.Out[r] = Out[r]; p.Add[r] = Add ? Add[r] : nullptr; p.W[r] = reinterpret_cast<const bf16x8 *>(Wsplit[r]);
-        p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
-    }
-    constexpr int CT = 32;
-    const size_t lds = 2 * (3 * 2 * 256 + 3 * 128 * 2) * 16;       // two buffers of (activation planes + weight fragments) of a K16 step
-    auto kern = irrep_gemm_split_kernel<CT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { roreg::set_error("roreg_irrep_gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), lds, roreg::as_stream(stream), p, tiles_dev);
-    ROREG_CHECK_LAUNCH("roreg_irrep_gemm_split");
-    return 0;
+    return launch_gemm_split<3>("roreg_irrep_gemm_split", X, Out, Add, Wsplit, nullptr, 0, C, O, B, tiles_dev, n_tiles, stream);
+}
+
+extern "C" int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
+                                      const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream) {
+    ROREG_REQUIRE(X && Out && Wsplit2 && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_f16x2: bad arguments");
+    ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_f16x2: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
+    return launch_gemm_split<2>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_absmax_dev, w_exp, C, O, B, tiles_dev, n_tiles, stream);
 }
 
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
-                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, void *stream) {
+                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, float *out_absmax, void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
@@ -751,7 +826,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
-    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_absmax = out_absmax;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
     hipStream_t s = roreg::as_stream(stream);

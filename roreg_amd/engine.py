@@ -60,13 +60,17 @@ class RegistrationEngine:
         return t1
 
     def set_gemm_mode(self, mode):
-        """'f32': exact f32-input MFMA GEMMs (bitwise an fmaf chain);  'split': 3 x bf16 split GEMMs (f32-accurate)."""
+        """'f16x2' | 'bf16x3' | 'f32': how the group-conv GEMMs / convolutions feed the matrix cores (hip.GEMM_MODE)."""
         from .network.gf_fourier import FourierGF
+        if mode == 'split':
+            mode = 'bf16x3'
+        if mode not in hip.GEMM_MODES:
+            raise ValueError(f'gemm mode must be one of {hip.GEMM_MODES}')
         net = self.gf.PartI_net
         if net._fourier is None:
             object.__setattr__(net, '_fourier', FourierGF(net))
-        net._fourier.split_bf16 = (mode == 'split')
-        self.et.split_bf16 = (mode == 'split')
+        net._fourier.gemm = mode
+        self.et.gemm = mode
 
     # ---- per cloud ---------------------------------------------------------------------------------------
     def extract(self, feats, keys):

@@ -16,13 +16,17 @@ from .group import tables
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libroreg_hip.so')
 
 # How the irrep-domain GEMMs and transforms feed the matrix cores:
-#   'split' (default): every f32 operand as three bf16 pieces, six cross products, f32 accumulate -- f32-accurate (measured error =
-#                      the f32 kernel's), 2.67x fewer matrix-core cycles;
+#   'f16x2' (default): every f32 operand as hi + lo fp16 with power-of-two block scaling (22 significant bits), products hi.hi + hi.lo +
+#                      lo.hi, f32 accumulate: measured error <= the f32-input kernel's, 5.3x fewer matrix-core cycles than 'f32';
+#   'bf16x3'         : every f32 operand as three bf16 pieces (24 bits), six cross products, f32 accumulate; 2.67x fewer cycles;
 #   'f32'            : f32-input MFMA (bitwise an fmaf chain).
-# Environment override for drop-in runs of Test.py: ROREG_GEMM=f32.
-GEMM_MODE = os.environ.get('ROREG_GEMM', 'split')
-if GEMM_MODE not in ('split', 'f32'):
-    raise ValueError(f"ROREG_GEMM must be 'split' or 'f32', got {GEMM_MODE!r}")
+# Environment override for drop-in runs of Test.py: ROREG_GEMM=f32 | bf16x3 | f16x2.
+GEMM_MODES = ('f16x2', 'bf16x3', 'f32')
+GEMM_MODE = os.environ.get('ROREG_GEMM', 'f16x2')
+if GEMM_MODE == 'split':
+    GEMM_MODE = 'bf16x3'
+if GEMM_MODE not in GEMM_MODES:
+    raise ValueError(f"ROREG_GEMM must be one of {GEMM_MODES}, got {GEMM_MODE!r}")
 _lib = None
 _tables_uploaded = False
 
@@ -70,7 +74,8 @@ PROTOTYPES = {
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
 }
 
 
@@ -622,7 +627,7 @@ def coef_views(buf, C, B):
 _tile_cache = {}
 
 
-def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None):
+def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_absmax=None):
     """coefficients [60*C*Bp] -> [60*O*Bp] through the five per-irrep GEMMs (Bp = coef_pitch(B): the GEMMs run on the padded width).
     split: the five 3xbf16-split weight tensors (f32-accurate GEMM on the bf16 matrix cores) or None for the f32-input MFMA kernel.
     add: optional coefficient buffer [60*O*Bp] summed onto the result in the epilogue (residual short cut in the irrep domain)."""
@@ -642,19 +647,23 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None):
     av = _ptr_array(coef_views(add, O, B)) if add is not None else None
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    if split is not None:
+    if f16x2 is not None:                               # (five fp16x2 weight tensors, w_exp); x_absmax: device scalar float32[1]
+        wl, w_exp = f16x2
+        _check(lib().roreg_irrep_gemm_f16x2(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(wl), _ptr(x_absmax, torch.float32), int(w_exp), C, O, Bp,
+                                            _ptr(t, torch.int32), int(t.shape[0]), _stream()), 'roreg_irrep_gemm_f16x2')
+    elif split is not None:
         _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]),
                                             _stream()), 'roreg_irrep_gemm_split')
     else:
         _check(lib().roreg_irrep_gemm(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(Wpacks), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]), _stream()),
                'roreg_irrep_gemm')
     if PROFILE is not None:
-        e1.record(); PROFILE.append((('irrep_gemm_split' if split is not None else 'irrep_gemm', Bp, C, O), e0, e1))
+        e1.record(); PROFILE.append((('irrep_gemm_f16x2' if f16x2 is not None else 'irrep_gemm_split' if split is not None else 'irrep_gemm', Bp, C, O), e0, e1))
     return out
 
 
 def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
-              g_map=None, Lout=60, Lvalid=60, split=False):
+              g_map=None, Lout=60, Lvalid=60, split=False, want_absmax=False):
     ensure_fourier()
     dev = (coef_in if coef_in is not None else x_spatial).device
     if spatial_out:
@@ -662,12 +671,13 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     else:
         out = torch.empty(coef_size(C, B), dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
     scale, shift = bn if bn is not None else (None, None)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev) if (want_absmax and not spatial_out) else None
     if coef_in is not None and coef_in.numel() != coef_size(C, B):
         raise HipError(f'ft_nonlin: coef_in must hold 60*C*{coef_pitch(B)} floats')
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
-                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 1 if split else 0, _stream()), 'roreg_ft_nonlin')
-    return out
+                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 1 if split else 0, _ptr(amax), _stream()), 'roreg_ft_nonlin')
+    return (out, amax) if want_absmax else out
 
 
 def _bf16_split3(x):
@@ -681,6 +691,24 @@ def _bf16_split3(x):
         out.append(hi)
         rem = rem - (hi.astype(np.uint32) << 16).view(np.float32)
     return out
+
+
+def f16_scale_exp(absmax):
+    """e with absmax * 2^e in [2^13, 2^14): the block-scaling exponent of the fp16 x 2 operand split."""
+    return 14 - int(np.frexp(float(absmax))[1]) if absmax > 0 else 0
+
+
+def f16_split2_pack(Wm, w_exp):
+    """Wm float32 [Mpad, K] (K % 16 == 0) -> int16 device tensor [2][K/16][2][Mpad][8] of fp16 bits: hi = fp16(w * 2^w_exp),
+    lo = fp16(w * 2^w_exp - hi), in the fragment order of irrep_gemm_split_kernel<NP=2>."""
+    Ws = np.ldexp(np.ascontiguousarray(Wm, np.float32), w_exp).astype(np.float32)
+    Mpad, K = Ws.shape
+    hi = Ws.astype(np.float16)
+    lo = (Ws - hi.astype(np.float32)).astype(np.float16)
+    out = np.empty((2, K // 16, 2, Mpad, 8), np.uint16)
+    for sp, part in enumerate((hi, lo)):
+        out[sp] = part.view(np.uint16).reshape(Mpad, K // 16, 2, 8).transpose(1, 2, 0, 3)
+    return torch.from_numpy(out.view(np.int16)).cuda()
 
 
 def bf16_split3_pack(Wm):

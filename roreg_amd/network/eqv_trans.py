@@ -30,7 +30,7 @@ class ET_test(nn.Module):
             nn.Conv2d(d[2], d[3], 1, 1))
         self.pruned = True
         self.fourier_init = True
-        self.split_bf16 = hip.GEMM_MODE == 'split'
+        self.gemm = hip.GEMM_MODE           # 'f16x2' | 'bf16x3' | 'f32' (hip.GEMM_MODE)
 
     # ---- kernel plans -------------------------------------------------------------------------------------
     def _head_plans(self):
@@ -123,16 +123,21 @@ class ET_test(nn.Module):
             if self.fourier_init:
                 layer, bn = self._fourier_init()
                 hip.ensure_fourier()
-                X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=self.split_bf16)
-                T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if self.split_bf16 else None)
+                sp = self.gemm != 'f32'
+                if self.gemm == 'f16x2':
+                    X0, amax = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=True, want_absmax=True)
+                    T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, f16x2=layer.wsplit2, x_absmax=amax)
+                else:
+                    X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=sp)
+                    T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if sp else None)
                 del X0
-                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split=self.split_bf16)   # [B,256,48]
+                h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split=sp)   # [B,256,48]
                 del T0
             else:
                 h = self.Conv_init(x, gather=ga)                               # [B,256,45]
-            m = res._b_in(h, gather=gb, split=self.split_bf16)                 # [B,512,13]
+            m = res._b_in(h, gather=gb, split=self.gemm != 'f32')              # [B,512,13]
             sc = h[:, :, p0:p0 + 1].contiguous()                               # identity short cut at g=0
-            if self.split_bf16:                                                # trunk tail + head as dense split layers
+            if self.gemm != 'f32':                                             # trunk tail + head as dense split layers
                 d_out, d0, d1, d2 = self._dense_plans()
                 t = hip.dense_split(m.view(B, -1), d_out, residual=sc.view(B, -1))      # [B,256]
                 return hip.dense_split(hip.dense_split(hip.dense_split(t, d0), d1), d2)  # [B,4]

@@ -32,14 +32,19 @@ class _Layer:
         self.bias = conv.bias.detach().float().cuda().contiguous()
         self.wpack = []
         self.wsplit = []          # 3 x bf16 pieces for the f32-accurate GEMM on the bf16 matrix cores
+        self.dense = []           # the five padded float32 matrices [round_up(d*O,128), d*C]
         for ri, Wh in enumerate(gf.transform_weights(W)):                 # [O,C,l,j]
             d = DIMS[ri]
             Wm = np.ascontiguousarray(Wh.transpose(3, 0, 2, 1)).reshape(d * O, d * C)     # rows (j,o), cols (l,c)
             Mpad = (d * O + 127) // 128 * 128
             Wp = np.zeros((Mpad, d * C), np.float32)
             Wp[:d * O] = Wm.astype(np.float32)
+            self.dense.append(Wp)
             self.wpack.append(hip.pack_conv_weights(torch.from_numpy(Wp).reshape(Mpad, d * C, 1)))
             self.wsplit.append(hip.bf16_split3_pack(Wp) if (d * C) % 16 == 0 else None)
+        # fp16 x 2 pieces with one power-of-two scale for the whole layer (the five GEMMs are one launch)
+        w_exp = hip.f16_scale_exp(max(float(np.abs(Wp).max()) for Wp in self.dense))
+        self.wsplit2 = ([hip.f16_split2_pack(Wp, w_exp) for Wp in self.dense], w_exp) if all(Wp.shape[1] % 16 == 0 for Wp in self.dense) else None
 
 
 class FourierGF:
@@ -47,7 +52,7 @@ class FourierGF:
         """net: Group_feat_network (parameter container)."""
         self.net = net
         self._key = None
-        self.split_bf16 = hip.GEMM_MODE == 'split'       # GEMMs / transforms as 3 x bf16 split products (f32-accurate), see hip.GEMM_MODE
+        self.gemm = hip.GEMM_MODE       # matrix-core mode of the GEMMs: 'f16x2' | 'bf16x3' | 'f32' (hip.GEMM_MODE); transforms: bf16x3 unless 'f32'
 
     def _plan(self):
         key = _version_key(self.net)
@@ -64,18 +69,30 @@ class FourierGF:
         self._plan()
         hip.ensure_fourier()
         B = x.shape[0]
-        sp = self.split_bf16
-        X0 = hip.ft_nonlin(B, 32, x_spatial=x, split=sp)
-        T0 = hip.irrep_gemm(X0, self.l_in.wpack, 32, 256, B, split=self.l_in.wsplit if sp else None)
-        X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=sp)
-        T1 = hip.irrep_gemm(X1, self.l_1.wpack, 256, 512, B, split=self.l_1.wsplit if sp else None)
+        sp = self.gemm != 'f32'                       # transforms as 3 x bf16 split products
+        f16 = self.gemm == 'f16x2'                    # GEMMs with fp16 x 2 operands: every transform also tracks max |coefficient|
+
+        def gemm(Xa, layer, C, O, add=None):
+            X, amax = Xa
+            if f16:
+                return hip.irrep_gemm(X, layer.wpack, C, O, B, f16x2=layer.wsplit2, x_absmax=amax, add=add)
+            return hip.irrep_gemm(X, layer.wpack, C, O, B, split=layer.wsplit if sp else None, add=add)
+
+        def ft(C, **kw):
+            r = hip.ft_nonlin(B, C, split=sp, want_absmax=f16, **kw)
+            return r if f16 else (r, None)
+        X0 = ft(32, x_spatial=x)
+        T0 = gemm(X0, self.l_in, 32, 256)
+        del X0
+        X1 = ft(256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1)
+        T1 = gemm(X1, self.l_1, 256, 512)
         del X1
-        X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split=sp)
+        X2 = ft(512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2)
         del T1
-        T2 = hip.irrep_gemm(X2, self.l_2.wpack, 512, 256, B, split=self.l_2.wsplit if sp else None, add=T0)   # + identity short cut
+        T2 = gemm(X2, self.l_2, 512, 256, add=T0)                            # + identity short cut
         del X2, T0
-        X3 = hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3, split=sp)
+        X3 = ft(256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3)
         del T2
-        T3 = hip.irrep_gemm(X3, self.l_out.wpack, 256, 32, B, split=self.l_out.wsplit if sp else None)
+        T3 = gemm(X3, self.l_out, 256, 32)
         out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True, split=sp)
         return out

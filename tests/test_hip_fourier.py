@@ -128,6 +128,9 @@ def test_gemm_epilogue_residual_is_exact(group):
         plain = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp)
         fused = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp, add=A)
         assert torch.equal(fused, plain + A)
+    amax = X.abs().max().reshape(1)
+    plain = hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=amax)
+    assert torch.equal(hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=amax, add=A), plain + A)
 
 
 def test_gf_fourier_vs_direct_vs_golden(group):
@@ -163,20 +166,24 @@ def test_split_bf16_gemm_is_f32_accurate(group):
     x = rng.standard_normal((B, C, 60)).astype(np.float32) * np.abs(rng.standard_normal((B, C, 1))).astype(np.float32)
     xd = torch.from_numpy(x).cuda()
     X = hip.ft_nonlin(B, C, x_spatial=xd)
+    X, amax = hip.ft_nonlin(B, C, x_spatial=xd, want_absmax=True)
+    assert float(amax) == float(X.abs().max())                                           # the tracked block scale is the tensor's exact maximum
     T32 = hip.irrep_gemm(X, L.wpack, C, Oc, B)
     Tsp = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=L.wsplit)
+    T16 = hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=amax)
     y32 = hip.ft_nonlin(B, Oc, coef_in=T32, bias=L.bias, spatial_out=True).double().cpu().numpy()
     ysp = hip.ft_nonlin(B, Oc, coef_in=Tsp, bias=L.bias, spatial_out=True).double().cpu().numpy()
+    y16 = hip.ft_nonlin(B, Oc, coef_in=T16, bias=L.bias, spatial_out=True).double().cpu().numpy()
     ref = np.einsum('ock,bcgk->bog', conv.weight.detach().double().numpy()[:, :, 0, :], x.astype(np.float64)[:, :, group.Nei]) + \
         conv.bias.detach().double().numpy()[None, :, None]
     scale = np.abs(ref).max()
-    e32 = np.abs(y32 - ref).max() / scale; esp = np.abs(ysp - ref).max() / scale
-    assert e32 < 2e-6 and esp < 2e-6, (e32, esp)
-    assert esp < 3 * e32 + 1e-7, (e32, esp)
+    e32 = np.abs(y32 - ref).max() / scale; esp = np.abs(ysp - ref).max() / scale; e16 = np.abs(y16 - ref).max() / scale
+    assert e32 < 2e-6 and esp < 2e-6 and e16 < 2e-6, (e32, esp, e16)
+    assert esp < 3 * e32 + 1e-7 and e16 < 3 * e32 + 1e-7, (e32, esp, e16)
 
 
 def test_gf_both_gemm_modes_vs_golden(group):
-    """The extractor in both matrix-core modes (3 x bf16 split = default, f32-input MFMA) against the reference's output."""
+    """The extractor in all three matrix-core modes (fp16 x 2 = default, bf16 x 3, f32-input MFMA) against the reference's output."""
     from roreg_amd.network import name2network
     z = load_golden('gf_forward')
     net = name2network['GF_test'](default_config())
@@ -185,11 +192,11 @@ def test_gf_both_gemm_modes_vs_golden(group):
     net.PartI_net.mode = 'fourier'
     net(x)                                              # builds the plan
     out = {}
-    for split in (False, True):
-        net.PartI_net._fourier.split_bf16 = split
-        out[split] = net(x)['eqv'].cpu().numpy()
-        assert np.abs(out[split] - z['eqv']).max() < 1e-5, split
-    assert np.abs(out[False] - out[True]).max() < 5e-6
+    for mode in ('f32', 'bf16x3', 'f16x2'):
+        net.PartI_net._fourier.gemm = mode
+        out[mode] = net(x)['eqv'].cpu().numpy()
+        assert np.abs(out[mode] - z['eqv']).max() < 1e-5, mode
+    assert np.abs(out['f32'] - out['bf16x3']).max() < 5e-6 and np.abs(out['f32'] - out['f16x2']).max() < 5e-6
 
 
 def test_et_both_gemm_modes_vs_golden(group):
@@ -198,9 +205,9 @@ def test_et_both_gemm_modes_vs_golden(group):
     net = name2network['ET_test'](default_config())
     synth.seeded_state_dict(net, int(z['seed']))
     q = {}
-    for split in (False, True):
-        net.split_bf16 = split
+    for split in ('f32', 'bf16x3', 'f16x2'):
+        net.gemm = split
         batch = {k: torch.from_numpy(z[k].copy()) for k in ('before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx')}
         q[split] = net(batch)['quaternion_pre'].cpu().numpy()
         assert np.abs(q[split] - z['quaternion']).max() < 1e-4, split
-    assert np.abs(q[False] - q[True]).max() < 2e-5
+    assert np.abs(q['f32'] - q['bf16x3']).max() < 2e-5 and np.abs(q['f32'] - q['f16x2']).max() < 2e-5

@@ -1,6 +1,6 @@
 """Summarise rocprofv3 --pmc CSVs (one pass per counter group) per kernel+grid into a text table and, for the dominant
 kernel of each matrix-core mode, the per-launch HBM traffic figure bench.py reports as roofline.traffic.
-usage: python tools/pmc_summary.py <out.txt> <out.json> <mode>=<dir> [<mode>=<dir> ...]     (mode: split | f32)
+usage: python tools/pmc_summary.py <out.txt> <out.json> <mode>=<dir> [<mode>=<dir> ...]     (mode: f16x2 | bf16x3 | f32)
 Each <dir> holds the counter_collection.csv files of the passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
 --no-secondary --gemm <mode>`."""
 import collections
@@ -57,7 +57,7 @@ def main():
                     cal = (rows, known, f)
         if cal:
             lines.append(f'calibration: gf_finalize on {cal[0]} keypoints reads {cal[1]:.0f} KiB; FETCH_SIZE reports {cal[2]:.0f} KiB -> factor {cal[1] / cal[2]:.3f}')
-        kern = 'irrep_gemm_split_kernel' if mode == 'split' else 'irrep_gemm_kernel'
+        kern = 'irrep_gemm_kernel' if mode == 'f32' else 'irrep_gemm_split_kernel'
         big = [k for k in agg if k[0].startswith(kern) and k[1] >= 4000000 and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]]
         if big:
             nf = sum(len(agg[k]['FETCH_SIZE']) for k in big); nw = sum(len(agg[k]['WRITE_SIZE']) for k in big)

@@ -1,4 +1,4 @@
-"""Time the irrep-domain GEMM kernels (exact f32 vs 3 x bf16 split) on GF's big layers."""
+"""Time and check the irrep-domain GEMM kernels (f32-input MFMA, bf16 x 3 split, fp16 x 2 with block scaling) on GF's big layers."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -8,12 +8,24 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 for (C, O) in [(256, 512), (512, 256)]:
     conv = torch.nn.Conv2d(C, O, (1, 13))
     L = _Layer(conv)
-    X = torch.randn(hip.coef_size(C, B), device='cuda')
-    for name, sp in [('f32', None), ('split', L.wsplit)]:
+    X = torch.randn(hip.coef_size(C, B), device='cuda') * torch.exp(torch.randn(hip.coef_size(C, B), device='cuda'))
+    amax = X.abs().max().reshape(1).float()
+    variants = [('f32', dict()), ('bf16x3', dict(split=L.wsplit)), ('fp16x2', dict(f16x2=L.wsplit2, x_absmax=amax))]
+    outs = {}
+    for name, kw in variants:
         for _ in range(2):
-            hip.irrep_gemm(X, L.wpack, C, O, B, split=sp)
+            hip.irrep_gemm(X, L.wpack, C, O, B, **kw)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(3):
-            hip.irrep_gemm(X, L.wpack, C, O, B, split=sp)
+            outs[name] = hip.irrep_gemm(X, L.wpack, C, O, B, **kw)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 3
         print(f'{C}->{O} B={B} {name}: {dt*1e3:.2f} ms  {2.0*O*C*B*244/dt/1e12:.1f} TFLOP/s (f32-equivalent)')
+    # accuracy on a slice against float64 (irrep 4, d = 5)
+    Bp = hip.coef_pitch(B)
+    xv = hip.coef_views(X, C, B)[4][:, :4096].double().cpu().numpy()
+    Wm = L.dense[4].astype(np.float64)
+    ref = Wm @ xv
+    s = np.abs(ref).max()
+    for name in outs:
+        got = hip.coef_views(outs[name], O, B)[4][:, :4096].double().cpu().numpy()
+        print(f'   {name}: max err / max|ref| = {np.abs(got - ref[:got.shape[0]]).max() / s:.3e}   rms err / rms ref = {np.sqrt(np.mean((got - ref[:got.shape[0]])**2)) / np.sqrt(np.mean(ref**2)):.3e}')
