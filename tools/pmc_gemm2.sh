@@ -1,11 +1,11 @@
-# usage (GPU box): bash tools/pmc_gemm.sh  -> per-kernel PMC averages of tools/time_gemm.py (both GEMM kernels)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcg
 i=0
-for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
+for grp in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmcg/g$i -- python3 tools/time_gemm.py 20000 > gpurun_out/pmcg_g$i.log 2>&1
+  tail -2 gpurun_out/pmcg_g$i.log | cut -c1-200
 done
 python3 - <<'PY'
 import glob, csv, collections
