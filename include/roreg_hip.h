@@ -67,6 +67,17 @@ int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias
 int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
                       const float *residual, float *out, int B, int K, int O, void *stream);
 
+/* fp16 x 2 variants of the two entries above (half the matrix-core work; operands as hi + lo fp16 under a power-of-two block scale, see
+ * roreg_irrep_gemm_f16x2).  The activation scale is derived on the device from the bound |act(x)| <= act_smax * (*in_absmax_dev) + act_tmax
+ * (act_smax = max |scale| or 1, act_tmax = max |shift| or 0); the weights were scaled by 2^w_exp when split (layouts as above with two
+ * planes hi, lo of fp16 bits).  out_absmax_dev (nullable, zeroed by the caller) receives max |out| for the next layer. */
+int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *bn_scale, const float *bn_shift,
+                           float act_smax, float act_tmax, const float *in_absmax_dev, float *out, float *out_absmax_dev,
+                           const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
+int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
+                      float act_smax, float act_tmax, const float *in_absmax_dev, const float *residual, float *out,
+                      float *out_absmax_dev, int B, int K, int O, void *stream);
+
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
 int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream);

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 v[t][r] = x;
                 if (OUT_SPATIAL && g < ROREG_G) {
                     const int go = p.g_map ? p.g_map[g] : g;
-                    if (go >= 0) tb[jn * 65 + go] = x;
+                    if (go >= 0) { tb[jn * 65 + go] = x; wmax = fmaxf(wmax, fabsf(x)); }      // (pad keypoints were zeroed above)
                 }
             }
         if (OUT_SPATIAL) {
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             process(t1, t2, cb, cn);
         }
     }
-    if (!OUT_SPATIAL && p.out_absmax) {                              // one atomic per wave (non-negative floats order like their bit patterns)
+    if (p.out_absmax) {                                              // one atomic per wave (non-negative floats order like their bit patterns)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
         if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(p.out_absmax), __float_as_uint(wmax));

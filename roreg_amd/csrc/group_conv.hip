@@ -19,6 +19,7 @@
 //
 // Reference semantics: network/group_feat.py:16-33, network/ops.py:11-64, network/eqv_trans.py:88-117,130-136.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -220,13 +221,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 //   wsplit[plane][k][c/16][h][CoutPad][8]  (one 16-byte load per fragment, next stencil position in flight).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// NP = 3: bf16 x 3 pieces.  NP = 2: fp16 hi/lo with power-of-two block scaling (fourier.hip, irrep_gemm_split_kernel): the activation
+// scale comes from a bound on |act(x)| <= act_smax * (*in_absmax) + act_tmax (act_smax = max |BN scale| or 1, act_tmax = max |BN shift|
+// or 0; *in_absmax is the device-tracked maximum of the input tensor), the weights carry 2^w_exp; the kernel tracks max |out| for the
+// next layer (one atomicMax per wave).
+struct SplitScale {
+    const float *in_absmax;        // device scalar (NP = 2)
+    float act_smax, act_tmax;
+    int w_exp;
+    float *out_absmax;             // device scalar or null
+};
+__device__ __forceinline__ void split_scales(const SplitScale &q, float &xscale, float &oscale) {
+    const float mx = q.act_smax * (q.in_absmax ? *q.in_absmax : 1.f) + q.act_tmax;
+    int e = 0;
+    if (mx > 0.f && mx < __builtin_inff()) { int ex; (void)frexpf(mx, &ex); e = 14 - ex; }
+    xscale = ldexpf(1.f, e); oscale = ldexpf(1.f, -(e + q.w_exp));
+}
+__device__ __forceinline__ void track_absmax(float *dst, float wmax) {
+    if (!dst) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(dst), __float_as_uint(wmax));
+}
+__device__ __forceinline__ void gc_split2(const float (&v)[8], float scale, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * scale;
+        const _Float16 h1 = (_Float16)x;
+        hi[e] = h1; lo[e] = (_Float16)(x - (float)h1);
+    }
+}
+
 struct GCSplitParams {
     const float *x;
-    const bf16x8 *ws;
+    const void *ws;
     const float *bias, *bn_scale, *bn_shift;
     float *out;
     const int32_t *gather;
     int B, Cin, Cout, CoutPad, Lin, Lout, ncols, gt_bytes, nkp_max;
+    SplitScale sc;
 };
 
 __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
@@ -240,11 +275,12 @@ __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x
     }
 }
 
-template <int KS>
+template <int KS, int NP>
 __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams p) {
+    using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *gt = reinterpret_cast<int *>(smem);
-    bf16x8 *slab = reinterpret_cast<bf16x8 *>(smem + p.gt_bytes);        // [3 planes][2 k-octets][nkp_max][Lin]
+    frag *slab = reinterpret_cast<frag *>(smem + p.gt_bytes);            // [NP planes][2 k-octets][nkp_max][Lin]
     constexpr int OT = 256, NCOL = 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -282,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
     const bool has_bn = p.bn_scale != nullptr;
+    float xscale = 1.f, oscale = 1.f;
+    if constexpr (NP == 2) split_scales(p.sc, xscale, oscale);
+    const frag *wsb = reinterpret_cast<const frag *>(p.ws);
     const size_t ws_plane = (size_t)KS * (p.Cin / 16) * 2 * p.CoutPad;    // fragments per split plane
 
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
@@ -299,21 +338,27 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.bn_scale[c0 + 8 * ho + e], p.bn_shift[c0 + 8 * ho + e]), 0.f);
             }
-            bf16x8 b1, b2, b3;
-            gc_split3(v, b1, b2, b3);
-            bf16x8 *dst = slab + ho * h_stride + kp * Lin + col;
-            dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
+            frag *dst = slab + ho * h_stride + kp * Lin + col;
+            if constexpr (NP == 3) {
+                bf16x8 b1, b2, b3;
+                gc_split3(v, b1, b2, b3);
+                dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
+            } else {
+                f16x8 hi, lo;
+                gc_split2(v, xscale, hi, lo);
+                dst[0] = hi; dst[plane_stride] = lo;
+            }
         }
         __syncthreads();
 
         // ---- MFMA over the stencil; the weight fragments of position k+1 are in flight during position k ----------------
-        bf16x8 a_cur[2][3], a_nxt[2][3];
-        auto load_a = [&](int k, bf16x8 (&a)[2][3]) {
-            const bf16x8 *wk = p.ws + (((size_t)k * (p.Cin / 16) + c0 / 16) * 2 + h) * p.CoutPad + o_wave + j;
+        frag a_cur[2][NP], a_nxt[2][NP];
+        auto load_a = [&](int k, frag (&a)[2][NP]) {
+            const frag *wk = wsb + (((size_t)k * (p.Cin / 16) + c0 / 16) * 2 + h) * p.CoutPad + o_wave + j;
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) a[ot][sp] = wk[sp * ws_plane + ot * 32];
+                for (int sp = 0; sp < NP; ++sp) a[ot][sp] = wk[sp * ws_plane + ot * 32];
         };
         load_a(0, a_cur);
 #pragma unroll 1
@@ -321,33 +366,44 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
             if (k + 1 < KS) load_a(k + 1, a_nxt);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const bf16x8 *bp = slab + rowbase[t] + gt[gi[t] * KS + k];
-                const bf16x8 b1 = bp[0], b2 = bp[plane_stride], b3 = bp[2 * plane_stride];
+                const frag *bp = slab + rowbase[t] + gt[gi[t] * KS + k];
                 f32x16 c0v = acc[0][t], c1v = acc[1][t];
-                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][2], b1, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][2], b1, c1v, 0, 0, 0);
-                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b2, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][1], b2, c1v, 0, 0, 0);
-                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b3, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b3, c1v, 0, 0, 0);
-                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b1, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][1], b1, c1v, 0, 0, 0);
-                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b2, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b2, c1v, 0, 0, 0);
-                c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b1, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b1, c1v, 0, 0, 0);
+                if constexpr (NP == 3) {
+                    const bf16x8 b1 = bp[0], b2 = bp[plane_stride], b3 = bp[2 * plane_stride];
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][2], b1, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][2], b1, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b2, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][1], b2, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b3, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b3, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b1, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][1], b1, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b2, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b2, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b1, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b1, c1v, 0, 0, 0);
+                } else {
+                    const f16x8 bh = bp[0], bl = bp[plane_stride];
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][1], bh, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], bh, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], bl, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], bl, c1v, 0, 0, 0);
+                    c0v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], bh, c0v, 0, 0, 0);
+                    c1v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], bh, c1v, 0, 0, 0);
+                }
                 acc[0][t] = c0v; acc[1][t] = c1v;
             }
             if (k + 1 < KS) {
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                    for (int sp = 0; sp < 3; ++sp) a_cur[ot][sp] = a_nxt[ot][sp];
+                    for (int sp = 0; sp < NP; ++sp) a_cur[ot][sp] = a_nxt[ot][sp];
             }
         }
     }
 
     // ---- epilogue: bias, masked store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    float wmax = 0.f;
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
 #pragma unroll
@@ -356,10 +412,15 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (o < p.Cout) p.out[((size_t)bcol[t] * p.Cout + o) * Lout + gi[t]] = acc[ot][t][r] + p.bias[o];
+                if (o < p.Cout) {
+                    const float v = (NP == 2 ? acc[ot][t][r] * oscale : acc[ot][t][r]) + p.bias[o];
+                    p.out[((size_t)bcol[t] * p.Cout + o) * Lout + gi[t]] = v;
+                    wmax = fmaxf(wmax, fabsf(v));
+                }
             }
         }
     }
+    track_absmax(p.sc.out_absmax, wmax);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -373,20 +434,23 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 // the next step are converted (BN, ReLU, split) by one thread each and written in fragment order; both areas double-buffered.
 struct DenseParams {
     const float *x;                // [B][K]
-    const bf16x8 *ws;              // [3][K/16][2][Opad][8], Opad = round_up(O, 256)
+    const void *ws;                // [NP][K/16][2][Opad][8], Opad = round_up(O, 256)
     const float *bias;             // [O]
     const float *scale, *shift;    // [K] or null
     const float *res;              // [B][O] or null
     float *out;                    // [B][O]
     int B, K, O, Opad;
+    SplitScale sc;
 };
 
+template <int NP>
 __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
+    using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 128, TO = 256;
-    constexpr int XBUF = 3 * 2 * TB, WBUF = 3 * 2 * TO;          // fragments per buffer
-    bf16x8 *xs = reinterpret_cast<bf16x8 *>(smem);               // [2 buf][3 planes][2 k-octets][128 rows]
-    bf16x8 *wsm = xs + 2 * XBUF;                                 // [2 buf][3 planes][2 k-octets][256 channels]
+    constexpr int XBUF = NP * 2 * TB, WBUF = NP * 2 * TO;        // fragments per buffer
+    frag *xs = reinterpret_cast<frag *>(smem);                   // [2 buf][NP planes][2 k-octets][128 rows]
+    frag *wsm = xs + 2 * XBUF;                                   // [2 buf][NP planes][2 k-octets][256 channels]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int wr = w & 1, wc = w >> 1;
@@ -395,6 +459,9 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
     const int b0 = bt * TB, o0 = ot * TO;
     const int nsteps = p.K / 16;
     const size_t wplane = (size_t)nsteps * 2 * p.Opad;            // fragments per split plane
+    const frag *wsb = reinterpret_cast<const frag *>(p.ws);
+    float xscale = 1.f, oscale = 1.f;
+    if constexpr (NP == 2) split_scales(p.sc, xscale, oscale);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -426,16 +493,22 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
         }
-        bf16x8 b1, b2, b3;
-        gc_split3(v, b1, b2, b3);
-        bf16x8 *dst = xs + buf * XBUF + sho * TB + srow;
-        dst[0] = b1; dst[2 * TB] = b2; dst[4 * TB] = b3;
+        frag *dst = xs + buf * XBUF + sho * TB + srow;
+        if constexpr (NP == 3) {
+            bf16x8 b1, b2, b3;
+            gc_split3(v, b1, b2, b3);
+            dst[0] = b1; dst[2 * TB] = b2; dst[4 * TB] = b3;
+        } else {
+            f16x8 hi, lo;
+            gc_split2(v, xscale, hi, lo);
+            dst[0] = hi; dst[2 * TB] = lo;
+        }
     };
     // weight fragments of a step: per plane [2 k-octets][256 channels] = 512 fragments = two per thread
     auto issue_w = [&](int ks, int buf) {
-        const bf16x8 *q = p.ws + (size_t)(ks < nsteps ? ks : nsteps - 1) * 2 * p.Opad + o0;
+        const frag *q = wsb + (size_t)(ks < nsteps ? ks : nsteps - 1) * 2 * p.Opad + o0;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
+        for (int sp = 0; sp < NP; ++sp)
 #pragma unroll
             for (int ho = 0; ho < 2; ++ho)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * wplane + (size_t)ho * p.Opad + tid),
@@ -452,29 +525,39 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
         issue_w(ks + 1, buf ^ 1);                                 // both land under the MFMAs of this step
         load_x(ks + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 *xt = xs + buf * XBUF + h * TB + wr * 64 + j;
-        const bf16x8 *wt = wsm + buf * WBUF + h * TO + wc * 128 + j;
-        bf16x8 a[2][3];
+        const frag *xt = xs + buf * XBUF + h * TB + wr * 64 + j;
+        const frag *wt = wsm + buf * WBUF + h * TO + wc * 128 + j;
+        frag a[2][NP];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) a[rt][sp] = xt[sp * (2 * TB) + rt * 32];
+            for (int sp = 0; sp < NP; ++sp) a[rt][sp] = xt[sp * (2 * TB) + rt * 32];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8 b1 = wt[t * 32], b2 = wt[2 * TO + t * 32], b3 = wt[4 * TO + t * 32];
             f32x16 c0 = acc[0][t], c1 = acc[1][t];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b1, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b1, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b2, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b2, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b3, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b3, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b1, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b1, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b2, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b2, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b1, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b1, c1, 0, 0, 0);
+            if constexpr (NP == 3) {
+                const bf16x8 b1 = wt[t * 32], b2 = wt[2 * TO + t * 32], b3 = wt[4 * TO + t * 32];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b1, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b2, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b2, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b3, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b3, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b1, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b2, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b2, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b1, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b1, c1, 0, 0, 0);
+            } else {
+                const f16x8 wh = wt[t * 32], wl = wt[2 * TO + t * 32];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], wh, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], wh, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], wl, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], wl, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], wh, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], wh, c1, 0, 0, 0);
+            }
             acc[0][t] = c0; acc[1][t] = c1;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -484,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
         buf ^= 1;
     }
     // ---- epilogue: C/D map: column (lane&31) = output channel, rows (r&3)+8*(r>>2)+4*h = keypoints --------------------------
+    float wmax = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int o = o0 + wc * 128 + t * 32 + j;
@@ -495,12 +579,14 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int b = b0 + wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (b < p.B) {
-                    float v = acc[rt][t][r] + bo;
+                    float v = (NP == 2 ? acc[rt][t][r] * oscale : acc[rt][t][r]) + bo;
                     if (p.res) v += p.res[(size_t)b * p.O + o];
                     p.out[(size_t)b * p.O + o] = v;
+                    wmax = fmaxf(wmax, fabsf(v));
                 }
             }
     }
+    track_absmax(p.sc.out_absmax, wmax);
 }
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -648,8 +734,21 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
     return 2;
 }
 
-extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
-                                      float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+template <int NP>
+static int launch_conv_split(GCSplitParams p, hipStream_t s) {
+    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.Lin * 16;
+    ROREG_REQUIRE(lds <= 80 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
+    auto kern = group_conv_split_kernel<13, NP>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
+    const int grid = ((p.ncols + 127) / 128) * (p.Cout / 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+    ROREG_CHECK_LAUNCH("roreg_group_conv_split");
+    return 0;
+}
+
+static int conv_split_common(int np, const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
+                             float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, SplitScale sc, void *stream) {
     if (B == 0) return 0;
     ROREG_REQUIRE(x && wsplit && bias && out && gather && B > 0, "roreg_group_conv_split: bad arguments");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv_split: bn_scale/bn_shift must come together");
@@ -657,37 +756,63 @@ extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const 
                   "roreg_group_conv_split: unsupported shape (KS=%d Cin=%d Cout=%d Lin=%d Lout=%d)", KS, Cin, Cout, Lin, Lout);
     ROREG_REQUIRE((long long)B * Lout < (1ll << 31), "roreg_group_conv_split: too many columns");
     GCSplitParams p;
-    p.x = x; p.ws = reinterpret_cast<const bf16x8 *>(wsplit); p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.out = out;
+    p.x = x; p.ws = wsplit; p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.out = out;
     p.gather = gather; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = Cout; p.Lin = Lin; p.Lout = Lout; p.ncols = B * Lout;
     p.gt_bytes = round_up(Lout * KS * 4, 16);
     p.nkp_max = (128 - 1) / Lout + 2;
     if (p.nkp_max > B) p.nkp_max = B;
-    const size_t lds = (size_t)p.gt_bytes + (size_t)3 * 2 * p.nkp_max * Lin * 16;
-    ROREG_REQUIRE(lds <= 80 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
-    auto kern = group_conv_split_kernel<13>;
+    p.sc = sc;
+    return np == 3 ? launch_conv_split<3>(p, roreg::as_stream(stream)) : launch_conv_split<2>(p, roreg::as_stream(stream));
+}
+
+extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
+                                      float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+    SplitScale sc = {nullptr, 1.f, 0.f, 0, nullptr};
+    return conv_split_common(3, x, wsplit, bias, bn_scale, bn_shift, out, gather, B, Cin, Cout, Lin, Lout, KS, sc, stream);
+}
+
+extern "C" int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *bn_scale, const float *bn_shift,
+                                      float act_smax, float act_tmax, const float *in_absmax_dev, float *out, float *out_absmax_dev,
+                                      const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+    ROREG_REQUIRE(in_absmax_dev, "roreg_group_conv_f16x2: in_absmax_dev is required");
+    SplitScale sc = {in_absmax_dev, act_smax, act_tmax, w_exp, out_absmax_dev};
+    return conv_split_common(2, x, wsplit2, bias, bn_scale, bn_shift, out, gather, B, Cin, Cout, Lin, Lout, KS, sc, stream);
+}
+
+template <int NP>
+static int launch_dense(DenseParams p, hipStream_t s) {
+    const size_t lds = (size_t)2 * (NP * 2 * 128 + NP * 2 * 256) * 16;
+    auto kern = dense_split_kernel<NP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
-    const int grid = ((p.ncols + 127) / 128) * (Cout / 256);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, roreg::as_stream(stream), p);
-    ROREG_CHECK_LAUNCH("roreg_group_conv_split");
+    if (e != hipSuccess) { roreg::set_error("roreg_dense_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
+    const int grid = ((p.B + 127) / 128) * (p.Opad / 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+    ROREG_CHECK_LAUNCH("roreg_dense_split");
     return 0;
 }
 
-extern "C" int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
-                                 const float *residual, float *out, int B, int K, int O, void *stream) {
+static int dense_common(int np, const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
+                        const float *residual, float *out, int B, int K, int O, SplitScale sc, void *stream) {
     if (B == 0) return 0;
     ROREG_REQUIRE(x && wsplit && bias && out && B > 0 && K > 0 && O > 0, "roreg_dense_split: bad arguments");
     ROREG_REQUIRE((scale == nullptr) == (shift == nullptr), "roreg_dense_split: scale/shift must come together");
     ROREG_REQUIRE(K % 16 == 0, "roreg_dense_split: K must be a multiple of 16 (got %d)", K);
     DenseParams p;
-    p.x = x; p.ws = reinterpret_cast<const bf16x8 *>(wsplit); p.bias = bias; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
-    p.B = B; p.K = K; p.O = O; p.Opad = round_up(O, 256);
-    const size_t lds = (size_t)2 * (3 * 2 * 128 + 3 * 2 * 256) * 16;
-    auto kern = dense_split_kernel;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { roreg::set_error("roreg_dense_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
-    const int grid = ((B + 127) / 128) * (p.Opad / 256);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, roreg::as_stream(stream), p);
-    ROREG_CHECK_LAUNCH("roreg_dense_split");
-    return 0;
+    p.x = x; p.ws = wsplit; p.bias = bias; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
+    p.B = B; p.K = K; p.O = O; p.Opad = round_up(O, 256); p.sc = sc;
+    return np == 3 ? launch_dense<3>(p, roreg::as_stream(stream)) : launch_dense<2>(p, roreg::as_stream(stream));
+}
+
+extern "C" int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
+                                 const float *residual, float *out, int B, int K, int O, void *stream) {
+    SplitScale sc = {nullptr, 1.f, 0.f, 0, nullptr};
+    return dense_common(3, x, wsplit, bias, scale, shift, residual, out, B, K, O, sc, stream);
+}
+
+extern "C" int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
+                                 float act_smax, float act_tmax, const float *in_absmax_dev, const float *residual, float *out,
+                                 float *out_absmax_dev, int B, int K, int O, void *stream) {
+    ROREG_REQUIRE(in_absmax_dev, "roreg_dense_f16x2: in_absmax_dev is required");
+    SplitScale sc = {in_absmax_dev, act_smax, act_tmax, w_exp, out_absmax_dev};
+    return dense_common(2, x, wsplit2, bias, scale, shift, residual, out, B, K, O, sc, stream);
 }

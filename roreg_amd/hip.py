@@ -41,6 +41,8 @@ PROTOTYPES = {
     'roreg_group_conv_workspace_size': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_group_conv_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_dense_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, _P, c_int, _P]),
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
@@ -175,6 +177,24 @@ def _conv_wsplit(layer):
         layer._wsplit = group_conv_split_pack(layer._weight)
     return layer._wsplit
 
+
+def _conv_wsplit2(layer):
+    """(fp16 x 2 planes [2][KS][Cin/16][2][Cout][8], w_exp, act_smax, act_tmax) of a ConvLayer, built on first use."""
+    if getattr(layer, '_wsplit2', None) is None:
+        Wn = layer._weight.numpy()
+        Cout, Cin = Wn.shape[0], Wn.shape[1]
+        KS = int(np.prod(Wn.shape[2:]))
+        w_exp = f16_scale_exp(float(np.abs(Wn).max()))
+        Ws = np.ldexp(Wn.reshape(Cout, Cin // 16, 2, 8, KS).astype(np.float32), w_exp).astype(np.float32)
+        hi = Ws.astype(np.float16); lo = (Ws - hi.astype(np.float32)).astype(np.float16)
+        out = np.empty((2, KS, Cin // 16, 2, Cout, 8), np.uint16)
+        for sp, part in enumerate((hi, lo)):
+            out[sp] = part.view(np.uint16).transpose(4, 1, 2, 0, 3)
+        smax = float(layer.scale.abs().max()) if layer.scale is not None else 1.0
+        tmax = float(layer.shift.abs().max()) if layer.shift is not None else 0.0
+        layer._wsplit2 = (torch.from_numpy(out.view(np.int16)).cuda(), w_exp, smax, tmax)
+    return layer._wsplit2
+
 # bench.py sets this to a list to collect (shape tag, start event, end event) per group-conv launch; the
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
@@ -193,8 +213,9 @@ def full_gather():
     return gather_table('nei60', tables().Nei)
 
 
-def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False):
-    """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32.  split: use the 3 x bf16 split kernel (f32-accurate) where its shape constraints hold."""
+def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False, in_absmax=None, want_absmax=False):
+    """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32.  split: use the 3 x bf16 split kernel (f32-accurate) where its shape constraints hold;
+    with in_absmax (device float32[1], tracked max |x|) the fp16 x 2 kernel, which can also return the tracked max |out| (want_absmax)."""
     ensure_tables()
     B, Cin, Lin = x.shape
     assert Cin == layer.Cin, (Cin, layer.Cin)
@@ -203,7 +224,17 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
     Lout = int(gather.shape[0]) if Lout is None else Lout
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
-    if split and residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0:
+    split_ok = residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0
+    if in_absmax is not None:
+        if not split_ok:
+            raise HipError('group_conv: the fp16 x 2 kernel does not support this shape')
+        w2, w_exp, smax, tmax = _conv_wsplit2(layer)
+        amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_absmax else None
+        _check(lib().roreg_group_conv_f16x2(_ptr(x, torch.float32), _ptr(w2), w_exp, _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift), smax, tmax,
+                                            _ptr(in_absmax, torch.float32), _ptr(out, torch.float32), _ptr(amax), _ptr(gather, torch.int32),
+                                            B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv_f16x2')
+        return (out, amax) if want_absmax else out
+    if split and split_ok:
         _check(lib().roreg_group_conv_split(_ptr(x, torch.float32), _ptr(_conv_wsplit(layer)), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
                                             _ptr(out, torch.float32), _ptr(gather, torch.int32), B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()),
                'roreg_group_conv_split')
@@ -671,7 +702,7 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     else:
         out = torch.empty(coef_size(C, B), dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
     scale, shift = bn if bn is not None else (None, None)
-    amax = torch.zeros(1, dtype=torch.float32, device=dev) if (want_absmax and not spatial_out) else None
+    amax = torch.zeros(1, dtype=torch.float32, device=dev) if want_absmax else None
     if coef_in is not None and coef_in.numel() != coef_size(C, B):
         raise HipError(f'ft_nonlin: coef_in must hold 60*C*{coef_pitch(B)} floats')
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
@@ -735,17 +766,34 @@ class DenseSplitLayer:
         for sp, bits in enumerate(_bf16_split3(Wp)):
             out[sp] = bits.reshape(Opad, self.K // 16, 2, 8).transpose(1, 2, 0, 3)
         self.ws = torch.from_numpy(out.view(np.int16)).cuda()
+        # fp16 x 2 planes (hi, lo) under the power-of-two scale 2^w_exp
+        self.w_exp = f16_scale_exp(float(np.abs(Wp).max()))
+        Ws = np.ldexp(Wp, self.w_exp).astype(np.float32)
+        hi = Ws.astype(np.float16); lo = (Ws - hi.astype(np.float32)).astype(np.float16)
+        out2 = np.empty((2, self.K // 16, 2, Opad, 8), np.uint16)
+        for sp, part in enumerate((hi, lo)):
+            out2[sp] = part.view(np.uint16).reshape(Opad, self.K // 16, 2, 8).transpose(1, 2, 0, 3)
+        self.ws2 = torch.from_numpy(out2.view(np.int16)).cuda()
+        self.act_smax = float(np.abs(scale).max()) if scale is not None else 1.0
+        self.act_tmax = float(np.abs(shift).max()) if shift is not None else 0.0
         self.bias = torch.from_numpy(np.ascontiguousarray(bias, np.float32)).cuda()
         self.scale = torch.from_numpy(np.ascontiguousarray(scale, np.float32)).cuda() if scale is not None else None
         self.shift = torch.from_numpy(np.ascontiguousarray(shift, np.float32)).cuda() if shift is not None else None
 
 
-def dense_split(x, layer, residual=None):
-    """x [B, K] float32 (device, contiguous) -> [B, O]."""
+def dense_split(x, layer, residual=None, in_absmax=None, want_absmax=False):
+    """x [B, K] float32 (device, contiguous) -> [B, O].  in_absmax (device float32[1], the tracked max |x|): use the fp16 x 2 kernel;
+    want_absmax: also return the tracked max |out| (device float32[1]) for the next layer."""
     B, K = x.shape
     if K != layer.K:
         raise HipError(f'dense_split: K mismatch ({K} vs {layer.K})')
     out = torch.empty((B, layer.O), dtype=torch.float32, device=x.device)
+    if in_absmax is not None:
+        amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_absmax else None
+        _check(lib().roreg_dense_f16x2(_ptr(x, torch.float32), _ptr(layer.ws2), layer.w_exp, _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
+                                       layer.act_smax, layer.act_tmax, _ptr(in_absmax, torch.float32), _ptr(residual, torch.float32), _ptr(out),
+                                       _ptr(amax), B, K, layer.O, _stream()), 'roreg_dense_f16x2')
+        return (out, amax) if want_absmax else out
     _check(lib().roreg_dense_split(_ptr(x, torch.float32), _ptr(layer.ws), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
                                    _ptr(residual, torch.float32), _ptr(out), B, K, layer.O, _stream()), 'roreg_dense_split')
     return out

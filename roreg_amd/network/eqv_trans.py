@@ -125,11 +125,22 @@ class ET_test(nn.Module):
                 hip.ensure_fourier()
                 sp = self.gemm != 'f32'
                 if self.gemm == 'f16x2':
-                    X0, amax = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=True, want_absmax=True)
-                    T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, f16x2=layer.wsplit2, x_absmax=amax)
-                else:
-                    X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=sp)
-                    T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if sp else None)
+                    # fp16 x 2 all the way: every kernel tracks max |output| on the device as the next kernel's block scale
+                    X0, a0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=True, want_absmax=True)
+                    T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, f16x2=layer.wsplit2, x_absmax=a0)
+                    del X0
+                    h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split=True,
+                                          want_absmax=True)                                                          # [B,256,48]
+                    del T0
+                    m, am = res._b_in(h, gather=gb, in_absmax=ah, want_absmax=True)                                  # [B,512,13]
+                    sc = h[:, :, p0:p0 + 1].contiguous()                                                             # identity short cut at g=0
+                    d_out, d0, d1, d2 = self._dense_plans()
+                    t, at = hip.dense_split(m.view(B, -1), d_out, residual=sc.view(B, -1), in_absmax=am, want_absmax=True)   # [B,256]
+                    z, az = hip.dense_split(t, d0, in_absmax=at, want_absmax=True)
+                    z, az = hip.dense_split(z, d1, in_absmax=az, want_absmax=True)
+                    return hip.dense_split(z, d2, in_absmax=az)                                                      # [B,4]
+                X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=sp)
+                T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if sp else None)
                 del X0
                 h = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split=sp)   # [B,256,48]
                 del T0

@@ -33,8 +33,8 @@ class _PlannedConv(nn.Module):
             self._plan_key = key
         return self._plan
 
-    def forward(self, x, gather=None, residual=None, split=False):
-        return hip.group_conv(x, self.plan(), gather=gather, residual=residual, split=split)
+    def forward(self, x, gather=None, residual=None, split=False, in_absmax=None, want_absmax=False):
+        return hip.group_conv(x, self.plan(), gather=gather, residual=residual, split=split, in_absmax=in_absmax, want_absmax=want_absmax)
 
 
 class Comb_Conv(_PlannedConv):

@@ -92,9 +92,13 @@ def test_group_conv_split_is_f32_accurate(group):
     a = np.maximum(x.astype(np.float64) * scale[None, :, None] + shift[None, :, None], 0.0)
     ref = np.einsum('ock,bcjk->boj', conv.weight.detach().double().numpy()[:, :, 0, :], a[:, :, gather]) + conv.bias.detach().double().numpy()[None, :, None]
     s = np.abs(ref).max()
-    e32 = np.abs(y32 - ref).max() / s; esp = np.abs(ysp - ref).max() / s
-    assert e32 < 2e-6 and esp < 2e-6, (e32, esp)
-    assert esp < 3 * e32 + 2e-7, (e32, esp)
+    amax = xd.abs().max().reshape(1)
+    y16t, omax = hip.group_conv(xd, layer, gather=gd, in_absmax=amax, want_absmax=True)
+    assert float(omax) == float(y16t.abs().max())                          # the kernel tracks the exact maximum of what it wrote
+    y16 = y16t.double().cpu().numpy()
+    e32 = np.abs(y32 - ref).max() / s; esp = np.abs(ysp - ref).max() / s; e16 = np.abs(y16 - ref).max() / s
+    assert e32 < 2e-6 and esp < 2e-6 and e16 < 2e-6, (e32, esp, e16)
+    assert esp < 3 * e32 + 2e-7 and e16 < 3 * e32 + 2e-7, (e32, esp, e16)
 
 
 def test_dense_split_is_f32_accurate():
@@ -107,12 +111,16 @@ def test_dense_split_is_f32_accurate():
         x = (rng.standard_normal((B, K)) * np.exp(rng.standard_normal((B, 1)))).astype(np.float32)
         r = rng.standard_normal((B, Oc)).astype(np.float32) if res else None
         layer = hip.DenseSplitLayer(W, bias, sc, sh)
-        got = hip.dense_split(torch.from_numpy(x).cuda(), layer, residual=torch.from_numpy(r).cuda() if res else None).double().cpu().numpy()
+        xd = torch.from_numpy(x).cuda(); rd = torch.from_numpy(r).cuda() if res else None
+        got = hip.dense_split(xd, layer, residual=rd).double().cpu().numpy()
+        g16, omax = hip.dense_split(xd, layer, residual=rd, in_absmax=xd.abs().max().reshape(1), want_absmax=True)
+        assert float(omax) == float(g16.abs().max())
         a = x.astype(np.float64)
         if act:
             a = np.maximum(a * sc.astype(np.float64) + sh.astype(np.float64), 0.0)
         ref = a @ W.astype(np.float64).T + bias.astype(np.float64) + (r.astype(np.float64) if res else 0.0)
-        assert np.abs(got - ref).max() < 3e-6 * max(1.0, np.abs(ref).max()), (B, K, Oc)
+        tol = 3e-6 * max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() < tol and np.abs(g16.double().cpu().numpy() - ref).max() < tol, (B, K, Oc)
 
 
 def test_gemm_epilogue_residual_is_exact(group):
