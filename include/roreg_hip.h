@@ -278,7 +278,8 @@ int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n,
  *                           32 keypoints: column = (b/32)*(32*d) + i*32 + b%32; pad keypoints hold zeros).  roreg_irrep_gemm* is
  *                           called with B := Bp. */
 int roreg_set_fourier_tables(const float *F_host);
-size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host);
+size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host);            /* 128-row m-tiles */
+size_t roreg_irrep_gemm_tiles_m(int O, int B, int tile_m /* 128 | 256 */, int32_t *tiles_host);
 int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *const *Add, const float *const *Wpack, int C, int O, int B,
                      const int32_t *tiles_dev, int n_tiles, void *stream);
 /* Same GEMMs on the bf16 matrix cores with f32 accuracy: every operand is split into three bf16 pieces and the six cross products
@@ -292,7 +293,8 @@ int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float
  * of the maximum (absolute error < 2^-39 of the maximum below that); products hi.hi + hi.lo + lo.hi, f32 accumulate, exact rescale.
  * Wsplit2[rho]: fp16 bits, layout [2 (hi, lo)][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
 int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
-                           const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream);
+                           const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles,
+                           int tile_m /* 128 | 256 (O % 256 == 0): the m-tile the list was built with; 256 = 8-wave workgroups */, void *stream);
 int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,

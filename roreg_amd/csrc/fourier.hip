@@ -194,11 +194,14 @@ __device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &
 // the weights by their own 2^w_exp; hi = fp16(x), lo = fp16(x - hi) keep 22 significant bits of every operand in the top 18 binades
 // below the maximum (smaller values keep an ABSOLUTE error below 2^-39 of the maximum), three cross products hi.hi, hi.lo, lo.hi, the
 // accumulator is rescaled by the exact 2^-(e + w_exp) in the epilogue.  Half the matrix-core work of NP = 3.
-template <int CT, int NP>
-__global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+// WO = number of 64-row wave groups: WO = 2 -> 128 x 256 workgroup tile, 4 waves (two workgroups per CU); WO = 4 -> 256 x 256 tile, 8 waves
+// (one workgroup per CU, the same 2 waves per SIMD): a third less L2 -> CU traffic per MFMA and half the conversion work per MFMA,
+// because one converted activation tile now feeds 256 output rows.
+template <int CT, int NP, int WO>
+__global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NCOL = 256, OT = 128;
+    constexpr int NCOL = 256, OT = WO * 64, NT = WO * 128, CPT = 512 / NT;      // CPT: activation columns converted per thread
     constexpr int XBUF = NP * 2 * NCOL, ABUF = NP * 2 * OT;       // fragments (16 B) per buffer
     frag *xs = reinterpret_cast<frag *>(smem);                   // [2 buf][NP split][2 k-octet][256 n (swizzled)]
     frag *as = xs + 2 * XBUF;                                    // [2 buf][NP split][2 k-octet][128 m]
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
     const frag *__restrict__ W = reinterpret_cast<const frag *>(p.W[irr]);
     const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
     const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
-    const int wo = w & 1, wb = w >> 1;
+    const int wo = w % WO, wb = w / WO;
     const int m_wave = mt * OT + wo * 64;
     const int n0 = nt * NCOL;
     const int ncol_wave = wb * 128;
@@ -234,39 +237,40 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
     // staging patch of this thread: columns n0 + 2*pp, +1 (clamped inside the matrix: out-of-range columns are never stored),
     // k-octet po of the step.  Column n lives in fragment slot n ^ ((n >> 3) & 1): conflict-free for the 8-lane groups of
     // ds_write_b128 (even columns of 8 neighbouring threads) and for the 16-lane groups of ds_read_b128.
-    const int pp = tid & 127, po = tid >> 7;
-    int ncol = n0 + 2 * pp;
-    if (ncol > N - 2) ncol = N - 2;
+    const int pp = tid % (NCOL / CPT), po = tid / (NCOL / CPT);
+    int ncol = n0 + CPT * pp;
+    if (ncol > N - CPT) ncol = N - CPT;
     const float *xcol = X + ncol + (size_t)(8 * po) * N;
     const int nsteps = K / 16;                                   // even (C % 32 == 0)
-    auto load_x = [&](int kstep, float2 (&xr)[8]) {
+    typedef float xpatch __attribute__((ext_vector_type(CPT)));
+    auto load_x = [&](int kstep, xpatch (&xr)[8]) {
         const float *q = xcol + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 16 * N;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xr[e] = *reinterpret_cast<const float2 *>(q + (size_t)e * N);
+        for (int e = 0; e < 8; ++e) xr[e] = *reinterpret_cast<const xpatch *>(q + (size_t)e * N);
     };
-    const int sw = (pp >> 2) & 1;                                // ((2*pp) >> 3) & 1
-    const int slot0 = po * NCOL + ((2 * pp) ^ sw), slot1 = po * NCOL + ((2 * pp + 1) ^ sw);
-    auto convert_store = [&](int buf, const float2 (&xr)[8]) {
-        float v0[8], v1[8];
+    int slot[CPT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v0[e] = xr[e].x; v1[e] = xr[e].y; }
+    for (int c = 0; c < CPT; ++c) { const int n = CPT * pp + c; slot[c] = po * NCOL + (n ^ ((n >> 3) & 1)); }
+    auto convert_store = [&](int buf, const xpatch (&xr)[8]) {
         frag *dst = xs + buf * XBUF;
-        if constexpr (NP == 3) {
-            bf16x8 b1, b2, b3;
-            split3(v0, b1, b2, b3);
-            dst[slot0] = b1; dst[2 * NCOL + slot0] = b2; dst[4 * NCOL + slot0] = b3;
-            split3(v1, b1, b2, b3);
-            dst[slot1] = b1; dst[2 * NCOL + slot1] = b2; dst[4 * NCOL + slot1] = b3;
-        } else {
-            f16x8 hi, lo;
-            split2(v0, xscale, hi, lo);
-            dst[slot0] = hi; dst[2 * NCOL + slot0] = lo;
-            split2(v1, xscale, hi, lo);
-            dst[slot1] = hi; dst[2 * NCOL + slot1] = lo;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xr[e][c];
+            if constexpr (NP == 3) {
+                bf16x8 b1, b2, b3;
+                split3(v, b1, b2, b3);
+                dst[slot[c]] = b1; dst[2 * NCOL + slot[c]] = b2; dst[4 * NCOL + slot[c]] = b3;
+            } else {
+                f16x8 hi, lo;
+                split2(v, xscale, hi, lo);
+                dst[slot[c]] = hi; dst[2 * NCOL + slot[c]] = lo;
+            }
         }
     };
-    // weight fragments of a step: per split plane [2 k-octets][128 rows] = 256 fragments, one per thread, 64 consecutive per wave
-    const frag *wsrc = W + (size_t)(w >> 1) * Mpad + mt * OT + (w & 1) * 64 + lane;
+    // weight fragments of a step: per split plane [2 k-octets][OT rows] = NT fragments, one per thread, 64 consecutive per wave
+    const frag *wsrc = W + (size_t)(tid / OT) * Mpad + mt * OT + (tid % OT);
     auto issue_a = [&](int kstep, int buf) {
         const frag *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
     for (int t = 0; t < 4; ++t) { const int n = ncol_wave + t * 32 + j; xslot[t] = h * NCOL + (n ^ ((n >> 3) & 1)); }
     const int aslot = h * OT + wo * 64 + j;
 
-    auto step = [&](int ks, int buf, float2 (&xr_load)[8], const float2 (&xr_use)[8]) {
+    auto step = [&](int ks, int buf, xpatch (&xr_load)[8], const xpatch (&xr_use)[8]) {
         issue_a(ks + 1, buf ^ 1);                                 // land under the MFMAs of this step
         load_x(ks + 2, xr_load);                                  // consumed during the next step
         __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_split_kernel(GemmSplitDescs
         __syncthreads();
     };
 
-    float2 xr0[8], xr1[8];
+    xpatch xr0[8], xr1[8];
     load_x(0, xr0);
     issue_a(0, 0);
     load_x(1, xr1);
@@ -714,13 +718,16 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
 // 4 MB L2: the list is built as eight per-XCD streams, each a sequence of 8 x 8 (m-tile x n-tile) blocks, interleaved so that entry
 // 8*i + k belongs to stream k.  The ~64 workgroups resident on an XCD then share 8 weight slices and 8 X tiles (minimum of
 // |X|*mts/a + |W|*nts/b under a*b = 64), instead of every XCD streaming every X tile.  Streams are balanced by (tiles x irrep dim).
-extern "C" size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host /* nullable; [n][3] */) {
+extern "C" size_t roreg_irrep_gemm_tiles_m(int O, int B, int tile_m, int32_t *tiles_host);
+extern "C" size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host /* nullable; [n][3] */) { return roreg_irrep_gemm_tiles_m(O, B, 128, tiles_host); }
+
+extern "C" size_t roreg_irrep_gemm_tiles_m(int O, int B, int tile_m /* 128 | 256 */, int32_t *tiles_host) {
     static const int dims[5] = {1, 3, 3, 4, 5};
     struct Block { int r, mg, ng, cost; };
     std::vector<Block> blocks;
     for (int r = 4; r >= 0; --r) {
         const int d = dims[r];
-        const int mts = round_up(d * O, 128) / 128, nts = (d * B + 255) / 256;
+        const int mts = round_up(d * O, tile_m) / tile_m, nts = (d * B + 255) / 256;
         for (int ng = 0; ng * 8 < nts; ++ng)
             for (int mg = 0; mg * 8 < mts; ++mg) {
                 const int a = std::min(8, mts - mg * 8), b = std::min(8, nts - ng * 8);
@@ -736,7 +743,7 @@ extern "C" size_t roreg_irrep_gemm_tiles(int O, int B, int32_t *tiles_host /* nu
             if (load[q] < load[k]) k = q;
         load[k] += bk.cost;
         const int d = dims[bk.r];
-        const int mts = round_up(d * O, 128) / 128, nts = (d * B + 255) / 256;
+        const int mts = round_up(d * O, tile_m) / tile_m, nts = (d * B + 255) / 256;
         for (int nt = bk.ng * 8; nt < std::min(nts, bk.ng * 8 + 8); ++nt)
             for (int mt = bk.mg * 8; mt < std::min(mts, bk.mg * 8 + 8); ++mt) {
                 stream[k].push_back(bk.r); stream[k].push_back(mt); stream[k].push_back(nt);
@@ -776,7 +783,7 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
     return 0;
 }
 
-template <int NP>
+template <int NP, int WO>
 static int launch_gemm_split(const char *what, const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit,
                              const float *xabsmax, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream) {
     static const int dims[5] = {1, 3, 3, 4, 5};
@@ -784,14 +791,15 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
     for (int r = 0; r < 5; ++r) {
         p.X[r] = X[r]; p.Out[r] = Out[r]; p.Add[r] = Add ? Add[r] : nullptr; p.W[r] = Wsplit[r];
         p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
+        if (WO == 4 && p.Mpad[r] % 256 != 0) { roreg::set_error("%s: tile_m = 256 needs O %% 256 == 0 (got %d)", what, O); return 2; }
     }
     p.xabsmax = xabsmax; p.w_exp = w_exp;
     constexpr int CT = 32;
-    const size_t lds = 2 * (NP * 2 * 256 + NP * 128 * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
-    auto kern = irrep_gemm_split_kernel<CT, NP>;
+    const size_t lds = 2 * (NP * 2 * 256 + NP * (WO * 64) * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
+    auto kern = irrep_gemm_split_kernel<CT, NP, WO>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), lds, roreg::as_stream(stream), p, tiles_dev);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(WO * 128), lds, roreg::as_stream(stream), p, tiles_dev);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
     return 0;
@@ -801,14 +809,18 @@ extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, 
                                       const int32_t *tiles_dev, int n_tiles, void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_split: bad arguments");
     ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_split: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
-    return launch_gemm_split<3>("roreg_irrep_gemm_split", X, Out, Add, Wsplit, nullptr, 0, C, O, B, tiles_dev, n_tiles, stream);
+    return launch_gemm_split<3, 2>("roreg_irrep_gemm_split", X, Out, Add, Wsplit, nullptr, 0, C, O, B, tiles_dev, n_tiles, stream);
 }
 
 extern "C" int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
-                                      const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream) {
+                                      const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, int tile_m,
+                                      void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit2 && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_f16x2: bad arguments");
     ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_f16x2: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
-    return launch_gemm_split<2>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_absmax_dev, w_exp, C, O, B, tiles_dev, n_tiles, stream);
+    ROREG_REQUIRE(tile_m == 128 || tile_m == 256, "roreg_irrep_gemm_f16x2: tile_m must be 128 or 256 (the value the tile list was built with)");
+    if (tile_m == 256)
+        return launch_gemm_split<2, 4>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_absmax_dev, w_exp, C, O, B, tiles_dev, n_tiles, stream);
+    return launch_gemm_split<2, 2>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_absmax_dev, w_exp, C, O, B, tiles_dev, n_tiles, stream);
 }
 
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,

@@ -74,9 +74,10 @@ PROTOTYPES = {
     'roreg_sinkhorn': (c_int, [_P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_set_fourier_tables': (c_int, [_P]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
+    'roreg_irrep_gemm_tiles_m': (c_size_t, [c_int, c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
 }
 
@@ -666,12 +667,13 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_absma
     if X_buf.numel() != 60 * C * Bp or (add is not None and add.numel() != 60 * O * Bp):
         raise HipError(f'irrep_gemm: coefficient buffers must hold 60*C*{Bp} floats (B={B} padded to the 32-keypoint pitch)')
     out = torch.empty(60 * O * Bp, dtype=torch.float32, device=X_buf.device)
-    key = (O, Bp)
+    tile_m = 256 if (f16x2 is not None and O % 256 == 0) else 128          # 256-row tiles = 8-wave workgroups (fp16 x 2 kernel)
+    key = (O, Bp, tile_m)
     t = _tile_cache.get(key)
     if t is None:
-        n = lib().roreg_irrep_gemm_tiles(O, Bp, None)
+        n = lib().roreg_irrep_gemm_tiles_m(O, Bp, tile_m, None)
         host = np.empty((n, 3), np.int32)
-        lib().roreg_irrep_gemm_tiles(O, Bp, host.ctypes.data)
+        lib().roreg_irrep_gemm_tiles_m(O, Bp, tile_m, host.ctypes.data)
         t = torch.from_numpy(host).cuda()
         _tile_cache[key] = t
     xv = coef_views(X_buf, C, B); ov = coef_views(out, O, B)
@@ -681,7 +683,7 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_absma
     if f16x2 is not None:                               # (five fp16x2 weight tensors, w_exp); x_absmax: device scalar float32[1]
         wl, w_exp = f16x2
         _check(lib().roreg_irrep_gemm_f16x2(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(wl), _ptr(x_absmax, torch.float32), int(w_exp), C, O, Bp,
-                                            _ptr(t, torch.int32), int(t.shape[0]), _stream()), 'roreg_irrep_gemm_f16x2')
+                                            _ptr(t, torch.int32), int(t.shape[0]), tile_m, _stream()), 'roreg_irrep_gemm_f16x2')
     elif split is not None:
         _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]),
                                             _stream()), 'roreg_irrep_gemm_split')
