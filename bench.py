@@ -84,7 +84,7 @@ def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
 
 
 DTYPE_OF = {'f16x2': 'fp16x2 (every f32 operand as hi+lo fp16 with power-of-two block scaling = 22 significant bits, 3 cross products, f32 accumulate; '
-                     'measured error <= the f32-input MFMA kernel\'s; transforms / ET convs bf16x3); fp64 estimator',
+                     'measured error <= the f32-input MFMA kernel\'s; every MFMA kernel of the path); fp64 estimator',
             'bf16x3': 'bf16x3 (every f32 operand as 3 bf16 pieces, 6 cross products, f32 accumulate: f32-accurate); fp64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); fp64 estimator'}
 MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}

@@ -300,7 +300,7 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
                     const int32_t *g_map /* optional [60]: group column -> compact output column (< Lvalid) or -1 */,
                     int Lout /* row pitch of the compact output, >= Lvalid; pad columns are zero */, int Lvalid,
-                    int B, int C, int split /* 1: transforms as 3 x bf16 split MFMAs (f32-accurate) */,
+                    int B, int C, int split /* 0: f32-input MFMA; 1: 3 x bf16 split MFMAs; 2: fp16 x 2 with per-column (per-keypoint) power-of-two scales */,
                     float *out_absmax /* optional device scalar, zeroed by the caller: receives max |coefficient written| (block scale of roreg_irrep_gemm_f16x2) */,
                     void *stream);
 

@@ -15,6 +15,7 @@
 //                       layout of the first, so no transpose is needed).
 #include "common.h"
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -376,7 +377,9 @@ struct NonlinParams {
     const int *g_map;            // optional [60] -> compact output column (or -1 = not written); Lout columns are written
     const float *bias, *bias2, *bn_scale, *bn_shift;      // per channel; any may be null
     const float *A1, *A2;        // fragment-ordered transform tables (roreg_set_fourier_tables)
-    const bf16x8 *A1s, *A2s;     // the same tables as 3 x bf16 split fragments of the K=16 bf16 MFMA (SPLIT kernels)
+    const bf16x8 *A1s, *A2s;     // the same tables as 3 x bf16 split fragments of the K=16 bf16 MFMA (SPLIT = 3 kernels)
+    const f16x8 *A1h, *A2h;      // ... and as fp16 hi/lo fragments scaled by 2^f_exp (SPLIT = 2 kernels)
+    int f_exp;
     float *out_absmax;           // optional device scalar (zeroed by the caller): max |coefficient| written, for the fp16 x 2 GEMM's block scale
     float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
@@ -414,7 +417,7 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 // accumulate -- see irrep_gemm_split_kernel): 96 K=16 MFMAs (3072 cycles) per 32-keypoint tile instead of 124 f32 MFMAs (7936), which
 // turns the kernel from matrix-core-bound into HBM-bound.  K orders: inverse step st feeds coefficients q = 16 st + 8 h + e; the forward
 // product's step st consumes this lane's accumulator registers v[st>>1][8 (st&1) + e], i.e. again no transpose between the products.
-template <bool IN_SPATIAL, bool OUT_SPATIAL, bool SPLIT, int NW /* waves per workgroup */, int MINW /* waves per SIMD to fit */>
+template <bool IN_SPATIAL, bool OUT_SPATIAL, int SPLIT /* 0: f32 MFMA, 3: bf16 x 3, 2: fp16 x 2 with per-column scales */, int NW /* waves per workgroup */, int MINW /* waves per SIMD to fit */>
 __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p) {
     constexpr int NT = NW * 64;
     const int lane = threadIdx.x & 63;
@@ -427,12 +430,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     // transform fragments A1[s][tile][lane] (inverse) and A2[step][tile][lane] (forward, K order = C/D register order) live in LDS
     // (31 KB per workgroup, conflict-free lane-contiguous reads): keeping them out of the register file leaves room for 4+ waves
     // per SIMD, which this streaming kernel needs to cover its 30 scattered 128-byte row reads per tile.
-    constexpr int NA1 = SPLIT ? 4 * 2 * 3 * 64 * 4 : 30 * 2 * 64, NA2 = SPLIT ? 4 * 2 * 3 * 64 * 4 : 32 * 2 * 64;   // floats (a bf16x8 = 4 floats)
+    constexpr int NPL = SPLIT == 2 ? 2 : 3;                      // planes of the split tables
+    constexpr int NA1 = SPLIT ? 4 * 2 * NPL * 64 * 4 : 30 * 2 * 64, NA2 = SPLIT ? 4 * 2 * NPL * 64 * 4 : 32 * 2 * 64;   // floats (a fragment = 4 floats)
     __shared__ __attribute__((aligned(16))) float sA1[IN_SPATIAL ? 64 : NA1];
     __shared__ __attribute__((aligned(16))) float sA2[OUT_SPATIAL ? 64 : NA2];
     __shared__ float sT[OUT_SPATIAL ? NW * 32 * 65 : 64];
     {
-        const float *g1 = SPLIT ? reinterpret_cast<const float *>(p.A1s) : p.A1, *g2 = SPLIT ? reinterpret_cast<const float *>(p.A2s) : p.A2;
+        const float *g1 = SPLIT == 3 ? reinterpret_cast<const float *>(p.A1s) : SPLIT == 2 ? reinterpret_cast<const float *>(p.A1h) : p.A1;
+        const float *g2 = SPLIT == 3 ? reinterpret_cast<const float *>(p.A2s) : SPLIT == 2 ? reinterpret_cast<const float *>(p.A2h) : p.A2;
         if (!IN_SPATIAL)
             for (int i = threadIdx.x; i < NA1; i += NT) sA1[i] = g1[i];
         if (!OUT_SPATIAL)
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     }
     __syncthreads();
     const bf16x8 *sA1s = reinterpret_cast<const bf16x8 *>(sA1), *sA2s = reinterpret_cast<const bf16x8 *>(sA2);   // [st][tile][plane][lane]
+    const f16x8 *sA1h = reinterpret_cast<const f16x8 *>(sA1), *sA2h = reinterpret_cast<const f16x8 *>(sA2);
     // flat offset (without the lane's keypoint jn) of coefficient q of channel c in keypoint tile tb; the table entries are compile-time
     // constants, so both half-wave candidates are scalar-ALU values and a lane only selects
     const size_t Bp = (size_t)p.Bp;
@@ -455,12 +461,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
 #define OFF_OF(Q0, Q1, c, tb) (OFF_Q(Q0, c, tb) + (size_t)h * (OFF_Q(Q1, c, tb) - OFF_Q(Q0, c, tb)))   // arithmetic select: one load, no exec-masked pair
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
-    constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT ? 32 : 30);
+    constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT != 0 ? 32 : 30);
     float cn[NCV];
     auto load_coefs = [&](int tile, float (&dst)[NCV]) {
         const int c = tile / p.tiles_per_c;
         const int tb = tile - c * p.tiles_per_c;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT != 0) {
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
                 constexpr int q0 = 16 * st + e, q1 = 16 * st + 8 + e;
@@ -485,6 +491,21 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
         return c;
+    };
+    // fp16 x 2: three MFMAs per product, and because every column (keypoint) of these transforms is independent, the block scale is
+    // PER COLUMN: 2^e from the column's own maximum (this lane's 32 values and its partner half-wave's), undone on this lane's accumulators
+    auto mfma3 = [&](const f16x8 *a, const f16x8 &bh, const f16x8 &bl, f32x16 c) {
+        const f16x8 ah = a[0], al = a[64];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+        return c;
+    };
+    auto column_scale = [&](float mx, float &xscale, float &oscale) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (mx > 0.f && mx < __builtin_inff()) { int ex; (void)frexpf(mx, &ex); e = 14 - ex; }
+        xscale = ldexpf(1.f, e); oscale = ldexpf(1.f, -(e + p.f_exp));
     };
     // Pipeline with two register sets (no copies): while a tile is computed from one set, the coefficients of the wave's next tile
     // are in flight into the other one.  VMEM operations of a wave complete in order, so a tile only waits for loads that are a whole
@@ -515,7 +536,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[t][r] = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 3) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     float x8[8];
@@ -526,6 +547,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     v[0] = mfma6(sA1s + ((st * 2 + 0) * 3) * 64 + lane, b1, b2, b3, v[0]);
                     v[1] = mfma6(sA1s + ((st * 2 + 1) * 3) * 64 + lane, b1, b2, b3, v[1]);
                 }
+            } else if constexpr (SPLIT == 2) {
+                float mx = 0.f;
+#pragma unroll
+                for (int s = 0; s < 32; ++s) mx = fmaxf(mx, ((16 * (s >> 3) + 8 + (s & 7) < ROREG_G || h == 0) ? fabsf(cv[s]) : 0.f));
+                float xsc, osc;
+                column_scale(mx, xsc, osc);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    float x8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x8[e] = (16 * st + 8 + e < ROREG_G || h == 0) ? cv[st * 8 + e] : 0.f;
+                    f16x8 bh, bl;
+                    split2(x8, xsc, bh, bl);
+                    v[0] = mfma3(sA1h + ((st * 2 + 0) * 2) * 64 + lane, bh, bl, v[0]);
+                    v[1] = mfma3(sA1h + ((st * 2 + 1) * 2) * 64 + lane, bh, bl, v[1]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[t][r] *= osc;
             } else {
 #pragma unroll
                 for (int s = 0; s < 30; ++s) {
@@ -570,7 +611,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 3) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     float x8[8];
@@ -581,6 +622,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     o[0] = mfma6(sA2s + ((st * 2 + 0) * 3) * 64 + lane, b1, b2, b3, o[0]);
                     o[1] = mfma6(sA2s + ((st * 2 + 1) * 3) * 64 + lane, b1, b2, b3, o[1]);
                 }
+            } else if constexpr (SPLIT == 2) {
+                float mx = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(v[t][r]));
+                float xsc, osc;
+                column_scale(mx, xsc, osc);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    float x8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x8[e] = v[st >> 1][8 * (st & 1) + e];
+                    f16x8 bh, bl;
+                    split2(x8, xsc, bh, bl);
+                    o[0] = mfma3(sA2h + ((st * 2 + 0) * 2) * 64 + lane, bh, bl, o[0]);
+                    o[1] = mfma3(sA2h + ((st * 2 + 1) * 2) * 64 + lane, bh, bl, o[1]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= osc;
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -636,7 +699,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
 #undef OFF_Q
 
 float *g_A1 = nullptr, *g_A2 = nullptr;
-uint16_t *g_A1s = nullptr, *g_A2s = nullptr;
+uint16_t *g_A1s = nullptr, *g_A2s = nullptr, *g_A1h = nullptr, *g_A2h = nullptr;
+int g_f_exp = 0;
 float *g_dump = nullptr;
 
 }  // namespace
@@ -708,6 +772,43 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
         }
     }
     if (hipMemcpy(g_A1s, A1s, sizeof(A1s), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(g_A2s, A2s, sizeof(A2s), hipMemcpyHostToDevice) != hipSuccess) {
+        roreg::set_error("roreg_set_fourier_tables: hipMemcpy failed");
+        return 1;
+    }
+    // ... and as fp16 hi/lo fragments under the power-of-two scale 2^f_exp (|F| * 2^f_exp <= 2^14): [st][tile][2 planes][lane][e]
+    static uint16_t A1h[4 * 2 * 2 * 64 * 8], A2h[4 * 2 * 2 * 64 * 8];
+    float fmx = 0.f;
+    for (int i = 0; i < 3600; ++i) fmx = std::max(fmx, std::fabs(F_host[i]));
+    int fex = 0;
+    (void)std::frexp(fmx, &fex);
+    g_f_exp = fmx > 0.f ? 14 - fex : 0;
+    auto f2h = [](float x) -> uint16_t {                                  // float -> fp16 bits, round-to-nearest-even (values are normal or zero here)
+        _Float16 hv = (_Float16)x;
+        uint16_t b; memcpy(&b, &hv, 2);
+        return b;
+    };
+    auto h2f = [](uint16_t b) -> float { _Float16 hv; memcpy(&hv, &b, 2); return (float)hv; };
+    for (int st = 0; st < 4; ++st)
+        for (int tile = 0; tile < 2; ++tile)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int j = lane & 31, h = lane >> 5;
+                    const int q1 = 16 * st + 8 * h + e, g1 = tile * 32 + j;
+                    const float f1 = (q1 < 60 && g1 < 60) ? std::ldexp(F_host[q1 * 60 + g1], g_f_exp) : 0.f;
+                    const int r = 8 * (st & 1) + e, q2 = tile * 32 + j, g2 = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float f2 = (q2 < 60 && g2 < 60) ? std::ldexp(F_host[q2 * 60 + g2], g_f_exp) : 0.f;
+                    const uint16_t h1 = f2h(f1), h2 = f2h(f2);
+                    const size_t hi_at = ((((size_t)st * 2 + tile) * 2 + 0) * 64 + lane) * 8 + e, lo_at = hi_at + 64 * 8;
+                    A1h[hi_at] = h1; A1h[lo_at] = f2h(f1 - h2f(h1));
+                    A2h[hi_at] = h2; A2h[lo_at] = f2h(f2 - h2f(h2));
+                }
+    if (!g_A1h) {
+        if (hipMalloc(&g_A1h, sizeof(A1h)) != hipSuccess || hipMalloc(&g_A2h, sizeof(A2h)) != hipSuccess) {
+            roreg::set_error("roreg_set_fourier_tables: hipMalloc failed");
+            return 1;
+        }
+    }
+    if (hipMemcpy(g_A1h, A1h, sizeof(A1h), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(g_A2h, A2h, sizeof(A2h), hipMemcpyHostToDevice) != hipSuccess) {
         roreg::set_error("roreg_set_fourier_tables: hipMemcpy failed");
         return 1;
     }
@@ -839,21 +940,27 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
     p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_absmax = out_absmax;
+    p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
     hipStream_t s = roreg::as_stream(stream);
     const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
     if (in_sp && out_sp) { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
     auto grid_for = [&](int nw, long long cap) { long long b = (n_tiles + nw - 1) / nw; return dim3((unsigned)(b > cap ? cap : b)); };
-    if (split) {
+    ROREG_REQUIRE(split >= 0 && split <= 2, "roreg_ft_nonlin: split must be 0 (f32 MFMA), 1 (bf16 x 3) or 2 (fp16 x 2)");
+    if (split == 2) {
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 2, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, 2, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 2, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+    } else if (split == 1) {
         // (6-wave workgroups at 3 waves per SIMD -- <.., 6, 3>, 384 threads, 139 VGPRs -- measured SLOWER: 4.6 vs 4.0 ms at C=512, B=65000)
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, true, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, true, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, true, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 3, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, 3, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 3, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
     } else {
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, false, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, false, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, false, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
     }
     ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
     return 0;

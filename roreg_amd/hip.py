@@ -709,7 +709,7 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
         raise HipError(f'ft_nonlin: coef_in must hold 60*C*{coef_pitch(B)} floats')
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
-                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 1 if split else 0, _ptr(amax), _stream()), 'roreg_ft_nonlin')
+                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 2 if split == 'f16x2' else (1 if split else 0), _ptr(amax), _stream()), 'roreg_ft_nonlin')
     return (out, amax) if want_absmax else out
 
 

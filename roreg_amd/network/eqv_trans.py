@@ -126,10 +126,10 @@ class ET_test(nn.Module):
                 sp = self.gemm != 'f32'
                 if self.gemm == 'f16x2':
                     # fp16 x 2 all the way: every kernel tracks max |output| on the device as the next kernel's block scale
-                    X0, a0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=True, want_absmax=True)
+                    X0, a0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', want_absmax=True)
                     T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, f16x2=layer.wsplit2, x_absmax=a0)
                     del X0
-                    h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split=True,
+                    h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split='f16x2',
                                           want_absmax=True)                                                          # [B,256,48]
                     del T0
                     m, am = res._b_in(h, gather=gb, in_absmax=ah, want_absmax=True)                                  # [B,512,13]

@@ -69,14 +69,14 @@ class FourierGF:
         self._plan()
         hip.ensure_fourier()
         B = x.shape[0]
-        sp = self.gemm != 'f32'                       # transforms as 3 x bf16 split products
+        sp = {'f32': False, 'bf16x3': True, 'f16x2': 'f16x2'}[self.gemm]      # matrix-core mode of the transforms
         f16 = self.gemm == 'f16x2'                    # GEMMs with fp16 x 2 operands: every transform also tracks max |coefficient|
 
         def gemm(Xa, layer, C, O, add=None):
             X, amax = Xa
             if f16:
                 return hip.irrep_gemm(X, layer.wpack, C, O, B, f16x2=layer.wsplit2, x_absmax=amax, add=add)
-            return hip.irrep_gemm(X, layer.wpack, C, O, B, split=layer.wsplit if sp else None, add=add)
+            return hip.irrep_gemm(X, layer.wpack, C, O, B, split=layer.wsplit if self.gemm == 'bf16x3' else None, add=add)
 
         def ft(C, **kw):
             r = hip.ft_nonlin(B, C, split=sp, want_absmax=f16, **kw)

@@ -71,6 +71,13 @@ def test_ft_nonlin_split_matches_f32_path(group):
     assert float((Z32 - Zsp).abs().max()) < 1e-6 * float(Z32.abs().max())
     back = hip.ft_nonlin(B, C, coef_in=Xsp, resid_spatial=x, spatial_out=True, split=True)      # F^-1 F x + x = 2x
     assert float((back - 2 * x).abs().max()) < 2e-6 * float(x.abs().max())
+    # fp16 x 2 with per-keypoint-column scales
+    X16 = hip.ft_nonlin(B, C, x_spatial=x, split='f16x2')
+    assert float((X32 - X16).abs().max()) < 6e-7 * scale
+    Y16 = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, bn=bn, split='f16x2')
+    assert float((Y32 - Y16).abs().max()) < 1.5e-6 * float(Y32.abs().max())
+    Z16 = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, spatial_out=True, g_map=gm, Lout=48, Lvalid=45, split='f16x2')
+    assert float((Z32 - Z16).abs().max()) < 1.5e-6 * float(Z32.abs().max())
 
 
 def test_group_conv_split_is_f32_accurate(group):
