@@ -197,6 +197,29 @@ def test_split_bf16_gemm_is_f32_accurate(group):
     assert esp < 3 * e32 + 1e-7 and e16 < 3 * e32 + 1e-7, (e32, esp, e16)
 
 
+def test_f16x2_block_scale_survives_outliers(group):
+    """One activation column 10^4 times larger than the rest sets the tensor-wide block scale of the fp16 x 2 GEMM; the OTHER columns must keep
+    their accuracy (the hi/lo split keeps 22 bits within 18 binades of the maximum)."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(3)
+    B, C, Oc = 256, 256, 512
+    L = _Layer(torch.nn.Conv2d(C, Oc, (1, 13)))
+    X = torch.from_numpy(rng.standard_normal(hip.coef_size(C, B)).astype(np.float32)).cuda()
+    v = hip.coef_views(X, C, B)
+    v[4][:, 7] *= 1e4
+    T16 = hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=X.abs().max().reshape(1))
+    T32 = hip.irrep_gemm(X, L.wpack, C, Oc, B)
+    ref = L.dense[4].astype(np.float64) @ v[4].double().cpu().numpy()
+    cols = [c for c in range(600) if c != 7]
+    scale = np.abs(ref[:, cols]).max(0)
+    err = {}
+    for name, T in (('f16', T16), ('f32', T32)):
+        g = hip.coef_views(T, Oc, B)[4].double().cpu().numpy()[:ref.shape[0]]
+        err[name] = float((np.abs(g[:, cols] - ref[:, cols]).max(0) / scale).max())
+    assert err['f16'] < 3 * err['f32'] + 1e-7 and err['f16'] < 4e-6, err
+
+
 def test_gf_both_gemm_modes_vs_golden(group):
     """The extractor in all three matrix-core modes (fp16 x 2 = default, bf16 x 3, f32-input MFMA) against the reference's output."""
     from roreg_amd.network import name2network
