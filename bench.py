@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--clouds', type=int, default=N_CLOUDS)
     ap.add_argument('--pairs', type=int, default=N_PAIRS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="torch.distributed backend: 'nccl' (= RCCL, one GPU per rank); "
+                    "'gloo' with ROREG_BENCH_SHARED_GPU=1 runs all ranks on GPU 0 -- a control-flow check of the multi-rank path on a 1-GPU box")
     ap.add_argument('--no-secondary', action='store_true', help='skip the all-local-transforms figure (profiling runs)')
     ap.add_argument('--gemm', choices=['f16x2', 'bf16x3', 'f32'], default='f16x2', help="matrix-core mode of the group-conv GEMMs: fp16 x 2 operands with power-of-two block scaling (default), bf16 x 3, or f32-input MFMA; all accumulate in f32")
     return ap.parse_args()
@@ -113,12 +115,13 @@ def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(0 if os.environ.get('ROREG_BENCH_SHARED_GPU') else local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    coll_dev = 'cuda' if args.backend == 'nccl' else 'cpu'                 # device of the (tiny) collective payloads
 
     from roreg_amd import hip, synth
     from roreg_amd.engine import RegistrationEngine
@@ -143,7 +146,7 @@ def main():
         np.random.seed(7)
         res = eng.run_scene(feats, keys, pair_ids, all_local_transforms=all_lt)
         table = torch.tensor([[float(r.id0), float(r.id1), r.n_match, r.recalltime] + r.trans.reshape(-1).tolist() for r in res],
-                             dtype=torch.float64, device='cuda')
+                             dtype=torch.float64, device=coll_dev)
         if dist is not None:
             out = [torch.empty_like(table) for _ in range(world)]
             dist.all_gather(out, table)                                     # the single result-table collective (RCCL/xGMI)
@@ -165,7 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = hip.PROFILE; hip.PROFILE = None
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -185,7 +188,7 @@ def main():
             dist.barrier()
         d = time.perf_counter() - t1
         if dist is not None:
-            tt = torch.tensor([d], dtype=torch.float64, device='cuda')
+            tt = torch.tensor([d], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
         return d, r
