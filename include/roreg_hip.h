@@ -120,8 +120,10 @@ int roreg_mutual_match_batch(const roreg_match_task *tasks_dev, int n_tasks, int
 /* k nearest (k<=8) targets per source in increasing distance, first index on ties; idx_out int64 [m,k].
  * Replaces KNN(k>=2) -> find_knn_gpu (utils/knn_search.py:68-103), used by NMS_sample with F=3, k=5
  * (test/matcher.py:21-23). */
+size_t roreg_knn_search_workspace(int m, int n);
 int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k,
-                     int64_t *idx_out, void *stream);
+                     int64_t *idx_out, void *workspace /* roreg_knn_search_workspace bytes: targets are scanned in slices that fill the chip;
+                     NULL = one thread per source scans everything */, size_t workspace_bytes, void *stream);
 
 /* Mutual check + ordered compaction: for i in 0..m-1 (increasing) keep (i, nn01[i]) iff nn10[nn01[i]]==i;
  * pairs are mapped through sample0/sample1 (int64, NULL = identity) and written to match_out int64 [*,2];

@@ -106,6 +106,74 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
         for (int q = 0; q < k; ++q) idx_out[(size_t)i * k + q] = bj[q];
 }
 
+// the same scan over one slice of the targets (grid.y slices fill the chip: one thread per source alone is 20 workgroups at m = 5000);
+// per-slice sorted lists go to a workspace and are merged in slice order = index order, so ties still resolve to the first index
+template <int F>
+__global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict__ src, int m, const float *__restrict__ tgt, int n, int k, int slice,
+                                                        float *__restrict__ pd, int *__restrict__ pj) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ii = i < m ? i : m - 1;
+    float s[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) s[f] = src[(size_t)ii * F + f];
+    float bd[8];
+    int bj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bd[q] = __builtin_inff(); bj[q] = -1; }
+    const int j0 = blockIdx.y * slice, j1 = min(j0 + slice, n);
+    for (int j = j0; j < j1; ++j) {
+        const float *t = tgt + (size_t)j * F;
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float d = __fsub_rn(s[f], t[f]);
+            acc = __fadd_rn(acc, __fmul_rn(d, d));
+        }
+        float d = sqrtf(__fadd_rn(acc, 1e-7f));
+        int dj = j;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < k && d < bd[q]) {
+                const float td = bd[q]; const int tj = bj[q];
+                bd[q] = d; bj[q] = dj; d = td; dj = tj;
+            }
+        }
+    }
+    if (i < m) {
+        float *od = pd + ((size_t)blockIdx.y * m + i) * 8;
+        int *oj = pj + ((size_t)blockIdx.y * m + i) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { od[q] = bd[q]; oj[q] = bj[q]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_merge_kernel(const float *__restrict__ pd, const int *__restrict__ pj, int m, int slices, int k,
+                                                        int64_t *__restrict__ idx_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    float bd[8];
+    int bj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bd[q] = __builtin_inff(); bj[q] = -1; }
+    for (int sidx = 0; sidx < slices; ++sidx) {
+        const float *vd = pd + ((size_t)sidx * m + i) * 8;
+        const int *vj = pj + ((size_t)sidx * m + i) * 8;
+        for (int c = 0; c < 8; ++c) {
+            float d = vd[c];
+            int dj = vj[c];
+            if (dj < 0) break;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q < k && d < bd[q]) {
+                    const float td = bd[q]; const int tj = bj[q];
+                    bd[q] = d; bj[q] = dj; d = td; dj = tj;
+                }
+            }
+        }
+    }
+    for (int q = 0; q < k; ++q) idx_out[(size_t)i * k + q] = bj[q];
+}
+
 // mutual check + ordered compaction by a single workgroup (m <= a few thousand)
 __global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict__ nn01, const int64_t *__restrict__ nn10, int m,
                                                       const int64_t *__restrict__ sample0, const int64_t *__restrict__ sample1,
@@ -173,21 +241,42 @@ extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
     return 0;
 }
 
-extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k, int64_t *idx_out, void *stream) {
+static int knn_slices(int m, int n) {
+    const int gx = (m + 255) / 256;
+    int slices = (1024 + gx - 1) / gx;                 // aim at ~1024 workgroups
+    if (slices > (n + 31) / 32) slices = (n + 31) / 32;
+    return slices < 1 ? 1 : slices;
+}
+
+extern "C" size_t roreg_knn_search_workspace(int m, int n) {
+    const int slices = knn_slices(m, n);
+    return slices > 1 ? (size_t)slices * m * 8 * (sizeof(float) + sizeof(int)) : 0;
+}
+
+extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k, int64_t *idx_out, void *workspace,
+                                size_t workspace_bytes, void *stream) {
     if (m == 0) return 0;
     ROREG_REQUIRE(src && tgt && idx_out && m > 0 && n > 0, "roreg_knn_search: bad arguments");
     ROREG_REQUIRE(k >= 1 && k <= 8 && k <= n, "roreg_knn_search: k must be in 1..min(8,n) (got %d)", k);
     ROREG_REQUIRE(F == 3 || F == 32, "roreg_knn_search: F must be 3 or 32 (got %d)", F);
-    if (m == 0) return 0;
     hipStream_t s = roreg::as_stream(stream);
-    if (F == 3)
-        hipLaunchKernelGGL(knn_search_kernel<3>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
-    else
-        hipLaunchKernelGGL(knn_search_kernel<32>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
+    const int slices = knn_slices(m, n);
+    const size_t need = roreg_knn_search_workspace(m, n);
+    if (slices > 1 && workspace && workspace_bytes >= need) {
+        float *pd = reinterpret_cast<float *>(workspace);
+        int *pj = reinterpret_cast<int *>(pd + (size_t)slices * m * 8);
+        const int slice = (n + slices - 1) / slices;
+        const dim3 grid((m + 255) / 256, (n + slice - 1) / slice);
+        if (F == 3) hipLaunchKernelGGL(knn_slice_kernel<3>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj);
+        else hipLaunchKernelGGL(knn_slice_kernel<32>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj);
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((m + 255) / 256), dim3(256), 0, s, pd, pj, m, (int)grid.y, k, idx_out);
+    } else {                                           // no workspace: the single-pass scan (one thread per source)
+        if (F == 3) hipLaunchKernelGGL(knn_search_kernel<3>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
+        else hipLaunchKernelGGL(knn_search_kernel<32>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
+    }
     ROREG_CHECK_LAUNCH("roreg_knn_search");
     return 0;
 }
-
 extern "C" int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m, const int64_t *sample0,
                                     const int64_t *sample1, int64_t *match_out, int32_t *count_out, void *stream) {
     ROREG_REQUIRE(count_out && m >= 0 && (m == 0 || (nn01 && nn10 && match_out)), "roreg_mutual_matches: bad arguments");

@@ -48,7 +48,8 @@ PROTOTYPES = {
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
     'roreg_inv_descriptor': (c_int, [_P, _P, c_int, _P]),
     'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
-    'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    'roreg_knn_search_workspace': (c_size_t, [c_int, c_int]),
+    'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     'roreg_mutual_matches': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P]),
     'roreg_mutual_match_batch_workspace': (c_size_t, [c_int, c_int]),
     'roreg_mutual_match_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
@@ -296,7 +297,9 @@ def knn_search(src, tgt, k):
     m, F = src.shape
     n = tgt.shape[0]
     idx = torch.empty((m, k), dtype=torch.int64, device=src.device)
-    _check(lib().roreg_knn_search(_ptr(src, torch.float32), m, _ptr(tgt, torch.float32), n, F, k, _ptr(idx), _stream()), 'roreg_knn_search')
+    ws_n = lib().roreg_knn_search_workspace(m, n)
+    ws = torch.empty(ws_n // 4, dtype=torch.int32, device=src.device) if ws_n else None
+    _check(lib().roreg_knn_search(_ptr(src, torch.float32), m, _ptr(tgt, torch.float32), n, F, k, _ptr(idx), _ptr(ws), ws_n, _stream()), 'roreg_knn_search')
     return idx
 
 

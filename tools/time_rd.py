@@ -1,0 +1,30 @@
+"""Where the RD (detector + NMS sampling) configuration spends its time: 16 clouds / 60 pairs."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+from conftest import load_golden
+from roreg_amd import synth
+from roreg_amd.engine import RegistrationEngine
+from roreg_amd.network import name2network
+from roreg_amd.parses.parses_test import default_config
+cfg = default_config(keynum=5000, max_iter=1000, ET='yohoo', RD=True)
+gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+rd = name2network['RD_test'](cfg); rd.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()})
+eng = RegistrationEngine(cfg, gf, et, rd_net=rd)
+scene = synth.make_scene(1000, n_clouds=16, n_kpts=5000, overlap=0.6, coord_noise=0.005)
+order = np.random.default_rng(4242).permutation(len(scene.pair_ids)); pair_ids = [scene.pair_ids[i] for i in sorted(order[:60])]
+feats = [torch.from_numpy(f).cuda() for f in scene.feats]; keys = [torch.from_numpy(k).cuda() for k in scene._kps]
+for rep in range(3):
+    np.random.seed(7); torch.cuda.synchronize(); t = time.perf_counter()
+    eng.run_scene(feats, keys, pair_ids)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+print(f'RD + mutual + yohoo: {60 / dt:.1f} pairs/s ({dt * 1e3:.1f} ms per 16-cloud / 60-pair step)')
+clouds = eng.extract_many(feats, keys)
+torch.cuda.synchronize(); t = time.perf_counter()
+for c in clouds: eng.detect(c)
+torch.cuda.synchronize(); t1 = time.perf_counter()
+from roreg_amd.test.matcher import NMS_sample
+for c in clouds: NMS_sample(5000, 5).sample(c.keys_host, c.det)
+t2 = time.perf_counter()
+print(f'detect: {(t1 - t) * 1e3 / 16:.2f} ms per cloud;  NMS sample: {(t2 - t1) * 1e3 / 16:.2f} ms per cloud')
