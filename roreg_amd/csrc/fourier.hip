@@ -464,8 +464,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT != 0 ? 32 : 30);
     float cn[NCV];
     auto load_coefs = [&](int tile, float (&dst)[NCV]) {
-        const int c = tile / p.tiles_per_c;
-        const int tb = tile - c * p.tiles_per_c;
+        const int c = (IN_SPATIAL || OUT_SPATIAL) ? tile % C : tile / p.tiles_per_c;      // group-domain tensors are [b][c][.]: channel-fastest tiles
+        const int tb = (IN_SPATIAL || OUT_SPATIAL) ? tile / C : tile - c * p.tiles_per_c;         // make the waves of a workgroup touch adjacent rows
         if constexpr (SPLIT != 0) {
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
@@ -515,8 +515,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     float wmax = 0.f;                                            // running max |coefficient| written by this lane
     auto process = [&](int tile, int next_tile, float (&cv)[NCV], float (&cnext)[NCV]) {
         asm volatile("" ::: "memory");      // keep the transform fragments in LDS: without this the compiler hoists all 62 of them into VGPRs
-        const int c = tile / p.tiles_per_c;
-        const int b = (tile - c * p.tiles_per_c) * 32 + jn;
+        const int c = (IN_SPATIAL || OUT_SPATIAL) ? tile % C : tile / p.tiles_per_c;
+        const int tbi = (IN_SPATIAL || OUT_SPATIAL) ? tile / C : tile - c * p.tiles_per_c;
+        const int b = tbi * 32 + jn;
         const bool valid = b < B;
         const int bb = valid ? b : B - 1;
         f32x16 v[2];
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             // lanes own keypoints, but the output is [b][c][column]: go through LDS so that every store instruction writes one
             // keypoint's contiguous row of Lout floats instead of 64 scattered dwords
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int b0 = (tile - c * p.tiles_per_c) * 32;
+            const int b0 = tbi * 32;
             for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
                 if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     }
             }
             {
-                const int tb = tile - c * p.tiles_per_c;      // pad keypoints (b >= B) get zeros: the buffers stay fully defined
+                const int tb = tbi;                           // pad keypoints (b >= B) get zeros: the buffers stay fully defined
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
