@@ -188,7 +188,8 @@ int roreg_refine(const double *k0, const double *k1, const double *w, int M,
 /* The local-transform stage (Des2R + ET input assembly, then quaternion -> 3x4 transform) of every pair of a scene in 2 + 1 launches
  * around the one batched ET trunk pass (test/estimator.py:85-111,293-366 per pair; same arithmetic as roreg_des2r / roreg_et_gather /
  * roreg_quat_to_trans, bit-identical).  Task p evaluates its n correspondences matches[sel[i]] (sel NULL = the first n rows); output
- * rows [off, off+n): dr_out int64, x_out [*,128,60] f32 (ET input), Trans_out [*,3,4] f64.  tasks_dev is a DEVICE array. */
+ * rows [off, off+n): dr_out int64, x_out [*,128,60] f32 (ET input; NULL = Des2R only, the YOHO-C estimator's DR_index),
+ * Trans_out [*,3,4] f64.  tasks_dev is a DEVICE array. */
 typedef struct {
     const float *before0, *before1, *after0, *after1;
     const double *keys0, *keys1;
@@ -219,6 +220,14 @@ size_t roreg_ransac_batch_workspace(int n_tasks, long long total_M, int max_H);
 int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long long total_M, int max_M, int max_H, double ird,
                        int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* YOHO-C hypothesis draws, HOST function (no device work): replays the generator calls of the reference's sampling loop
+ * (test/estimator.py:220-230: np.random.choice(range(60), p=prob), then np.random.choice(bin_members, 3)) over a block of raw MT19937
+ * words drawn by the caller from the global generator.  cdf f64 [60] = prob.cumsum()/prob.sum(); bin_size int32 [60] = members per
+ * rotation bin; at most max_iter hypotheses and max_tries + 1 tries.  bin_out int32 [max_iter], pick_out int64 [max_iter,3] (positions
+ * inside the bin's member list).  Returns 3 when the block is too short (retry with more words); *words_used = words consumed. */
+int roreg_yohoc_draw(const uint32_t *words, long long n_words, const double *cdf, const int32_t *bin_size, int max_iter, int max_tries,
+                     int32_t *bin_out, int64_t *pick_out, int32_t *n_hyp_out, long long *words_used);
 
 /* Gather rows: out[i] = src[rows[i]] for f64 [.,3] keypoints (estimator.py:407-408). */
 int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream);

@@ -328,13 +328,13 @@ extern "C" int roreg_gather_rows_f64(const double *src, const int64_t *rows, int
 
 extern "C" int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int64_t *dr_out, float *x_out, void *stream) {
     if (n_tasks == 0 || max_n == 0) return 0;
-    ROREG_REQUIRE(tasks_dev && dr_out && x_out && n_tasks > 0 && max_n > 0, "roreg_lt_prepare_batch: bad arguments");
+    ROREG_REQUIRE(tasks_dev && dr_out && n_tasks > 0 && max_n > 0, "roreg_lt_prepare_batch: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_lt_prepare_batch: group tables not set");
     static_assert(sizeof(roreg_lt_task) == sizeof(roreg::LtTask), "roreg_lt_task layout");
     const roreg::LtTask *tasks = reinterpret_cast<const roreg::LtTask *>(tasks_dev);
     hipStream_t s = roreg::as_stream(stream);
     roreg::launch_des2r_batch(tasks, n_tasks, max_n, dr_out, s);
-    hipLaunchKernelGGL(et_gather_batch_kernel, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+    if (x_out) hipLaunchKernelGGL(et_gather_batch_kernel, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
     ROREG_CHECK_LAUNCH("roreg_lt_prepare_batch");
     return 0;
 }

@@ -64,3 +64,48 @@ extern "C" int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_
     t.ready = true;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// YOHO-C hypothesis draws (host code; test/estimator.py:220-230).  The reference's loop calls, per try,
+//   np.random.choice(range(60), p=prob)      -> one legacy double (two MT19937 words: (a>>5, b>>6)), cdf.searchsorted(u, 'right')
+//   np.random.choice(bin_members, 3)         -> randint(0, n, 3): three masked-rejection draws, one 32-bit word per attempt
+// and its control flow depends on nothing but the generator, so the whole loop is replayed here over a block of raw generator words
+// (the caller draws them from the same global generator and afterwards advances it by exactly *words_used).
+extern "C" int roreg_yohoc_draw(const uint32_t *words, long long n_words, const double *cdf, const int32_t *bin_size, int max_iter,
+                                int max_tries, int32_t *bin_out, int64_t *pick_out, int32_t *n_hyp_out, long long *words_used) {
+    ROREG_REQUIRE(words && cdf && bin_size && bin_out && pick_out && n_hyp_out && words_used && max_iter >= 0 && n_words >= 0,
+                  "roreg_yohoc_draw: bad arguments");
+    long long pos = 0;
+    int n_hyp = 0, tries = 0;
+    while (n_hyp < max_iter) {
+        if (tries > max_tries) break;                             // `if exec_time > max_time: break` before the increment
+        ++tries;
+        if (pos + 2 > n_words) return 3;                          // block exhausted: the caller retries with a larger one
+        const uint32_t a = words[pos] >> 5, b = words[pos + 1] >> 6;
+        pos += 2;
+        const double u = (a * 67108864.0 + b) / 9007199254740992.0;
+        int lo = 0, hi = 60;                                      // first index with cdf[i] > u   (searchsorted side='right')
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        ROREG_REQUIRE(lo < 60, "roreg_yohoc_draw: cdf does not end at 1");
+        const int n = bin_size[lo];
+        if (n < 2) continue;
+        const uint32_t rng = (uint32_t)(n - 1);
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        for (int t = 0; t < 3; ++t) {
+            uint32_t v;
+            do {
+                if (pos >= n_words) return 3;
+                v = words[pos++] & mask;
+            } while (v > rng);
+            pick_out[(size_t)n_hyp * 3 + t] = v;
+        }
+        bin_out[n_hyp++] = lo;
+    }
+    *n_hyp_out = n_hyp;
+    *words_used = pos;
+    return 0;
+}

@@ -28,6 +28,18 @@ class CloudState:
     nms: dict = field(default_factory=dict)   # keynum -> NMS sample of this cloud (a pure function of the cloud)
 
 
+_POOL = None
+
+
+def _host_pool():
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
 @dataclass
 class PairResult:
     id0: str
@@ -43,7 +55,7 @@ class RegistrationEngine:
     def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None):
         self.cfg = cfg
         self.gf = gf_net
-        self.et = et_net
+        self.et = et_net            # ET_test (None is fine for the yohoc estimator, which never evaluates it)
         self.rd = rd_net            # detector_eqv_test (needed when cfg.RD)
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
@@ -70,7 +82,8 @@ class RegistrationEngine:
         if net._fourier is None:
             object.__setattr__(net, '_fourier', FourierGF(net))
         net._fourier.gemm = mode
-        self.et.gemm = mode
+        if self.et is not None:
+            self.et.gemm = mode
 
     # ---- per cloud ---------------------------------------------------------------------------------------
     def extract(self, feats, keys):
@@ -200,6 +213,71 @@ class RegistrationEngine:
         T2, st2 = hip.refine(k0, k1, scores, ird, T_in=T1, want_stats=True)
         return T2, best, (k0, k1, st1, st2)
 
+    def _yohoo_tasks(self, full, all_scores, max_iter, all_local_transforms):
+        """Estimator-tail tasks of the one-shot estimator (test/estimator.py:405-436)."""
+        # One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
+        # (estimator.py:423-425), and that draw depends on M (and, with --RM, on the scores) alone, so the hypothesis order is drawn
+        # first (same global-RNG calls in the same order as the reference) and Des2R + ET run on the selected correspondences only.
+        # The registration result is identical; the reference computes all M local transforms because its stages are coupled through
+        # Trans_pre files.  all_local_transforms=True evaluates every correspondence like the reference does.
+        hyps = []
+        for (c0, c1, matches), sc in zip(full, all_scores):
+            rows = np.arange(matches.shape[0])
+            if self.cfg.RM:                                                 # hypotheses only from the best-scored matches (:415-421)
+                num = max(sc.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
+                rows = np.argsort(sc)[-int(num):]
+            index = np.arange(rows.shape[0])
+            np.random.shuffle(index)                                        # estimator.py:423-424
+            hyps.append(np.ascontiguousarray(rows[index[0:max_iter]], np.int64))
+        hyp_flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros(0, np.int64)).cuda()   # ONE upload of all hypothesis lists
+        hyp_dev, o = [], 0
+        for h in hyps:
+            hyp_dev.append(hyp_flat[o:o + h.shape[0]]); o += h.shape[0]
+        items = [(c0, c1, m, None if all_local_transforms else h) for (c0, c1, m), h in zip(full, hyp_dev)]
+        lts = self.local_transforms_many(items)
+        # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
+        rt, w_all = [], []
+        for (c0, c1, matches), h, sc, (dr, Trans) in zip(full, hyp_dev, all_scores, lts):
+            hyp = h if all_local_transforms else None                                      # else Trans is already in hypothesis order
+            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()     # None = ones(M)  (matcher.py:109)
+            rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
+        return rt, w_all
+
+    def _yohoc_tasks(self, full, all_scores, max_iter):
+        """Estimator-tail tasks of the rotation-bin RANSAC (test/estimator.py:173-241): coarse rotation of every correspondence of every
+        pair in one launch (Des2R), one download, then per pair (host, the reference's order of generator calls) the bin statistics,
+        the hypothesis draws and the 3-point Kabsch stack; ONE upload of all hypotheses.  -> (tasks, weights, {pair: (T, recalltime)}
+        for the pairs the reference gives up on)."""
+        from .test.estimator import yohoc_draws, three_point_transforms, _select_top
+        batch = hip.LtBatch([(c0.eqv, c1.eqv, c0.eqv, c1.eqv, c0.keys, c1.keys, m, None) for c0, c1, m in full])
+        dr_all = batch.des2r().cpu().numpy()
+        sizes = [int(m.shape[0]) for _, _, m in full]
+        m_host = torch.cat([m.reshape(-1) for _, _, m in full]).cpu().numpy().reshape(-1, 2) if full else np.zeros((0, 2), np.int64)
+        jobs, skipped, o = [], {}, 0
+        for i, ((c0, c1, _), sc, (off, n)) in enumerate(zip(full, all_scores, batch.offsets)):     # sequential: the global generator
+            pps = m_host[o:o + sizes[i]]; o += sizes[i]
+            if c0.keys_host is None:
+                c0.keys_host = c0.keys.cpu().numpy()
+            if c1.keys_host is None:
+                c1.keys_host = c1.keys.cpu().numpy()
+            sel = _select_top(sc, self.cfg.match_n) if self.cfg.RM else np.arange(n)
+            idxs = yohoc_draws(dr_all[off:off + n][sel], max_iter)
+            if idxs is None:                                               # no rotation bin with two correspondences (:214-216)
+                skipped[i] = (np.random.rand(4, 4), 50000)
+                jobs.append(None)
+            else:
+                jobs.append((c0.keys_host, c1.keys_host, pps[sel, 0][idxs], pps[sel, 1][idxs]))
+        # the 3-point Kabsch stacks are pure functions of the draws: LAPACK releases the GIL, so the pairs run on a few host threads
+        kabsch = lambda j: np.zeros((0, 3, 4)) if j is None else three_point_transforms(j[0][j[2]], j[1][j[3]])
+        hyps = list(_host_pool().map(kabsch, jobs))
+        flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros((0, 3, 4))).cuda()
+        rt, w_all, o = [], [], 0
+        for (c0, c1, matches), sc, T in zip(full, all_scores, hyps):
+            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()
+            rt.append((c0.keys, c1.keys, matches, w, flat[o:o + T.shape[0]], None)); w_all.append(w)
+            o += T.shape[0]
+        return rt, w_all, skipped
+
     # ---- whole scene -----------------------------------------------------------------------------------------
     def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False):
         """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
@@ -242,33 +320,13 @@ class RegistrationEngine:
             full = [(clouds[int(a)], clouds[int(b)], mbuf[q, :int(M)]) for q, ((a, b), M) in enumerate(zip(pair_ids, counts))]
             all_scores = [None] * len(full)
         t0 = self._mark('match', t0)
-        # stage 4: all pairs.  One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
-        # (estimator.py:423-425), and that draw depends on M (and, with --RM, on the scores) alone, so the hypothesis order is drawn
-        # first (same global-RNG calls in the same order as the reference) and Des2R + ET run on the selected correspondences only.
-        # The registration result is identical; the reference computes all M local transforms because its stages are coupled through
-        # Trans_pre files.  all_local_transforms=True evaluates every correspondence like the reference does.
-        hyps = []
-        for (c0, c1, matches), sc in zip(full, all_scores):
-            rows = np.arange(matches.shape[0])
-            if self.cfg.RM:                                                 # hypotheses only from the best-scored matches (:415-421)
-                num = max(sc.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
-                rows = np.argsort(sc)[-int(num):]
-            index = np.arange(rows.shape[0])
-            np.random.shuffle(index)                                        # estimator.py:423-424
-            hyps.append(np.ascontiguousarray(rows[index[0:max_iter]], np.int64))
-        hyp_flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros(0, np.int64)).cuda()   # ONE upload of all hypothesis lists
-        hyp_dev, o = [], 0
-        for h in hyps:
-            hyp_dev.append(hyp_flat[o:o + h.shape[0]]); o += h.shape[0]
-        items = [(c0, c1, m, None if all_local_transforms else h) for (c0, c1, m), h in zip(full, hyp_dev)]
-        lts = self.local_transforms_many(items)
+        # stage 4: all pairs
+        yohoc = getattr(self.cfg, 'ET', 'yohoo') == 'yohoc'
+        if yohoc:
+            rt, w_all, skipped = self._yohoc_tasks(full, all_scores, max_iter)
+        else:
+            (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms), {}
         t0 = self._mark('local_transforms', t0)
-        # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
-        rt, w_all = [], []
-        for (c0, c1, matches), h, sc, (dr, Trans) in zip(full, hyp_dev, all_scores, lts):
-            hyp = h if all_local_transforms else None                                      # else Trans is already in hypothesis order
-            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()     # None = ones(M)  (matcher.py:109)
-            rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
         ird = float(self.cfg.ransac_ird)
         best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird)
         t0 = self._mark('ransac_issue', t0)
@@ -280,6 +338,8 @@ class RegistrationEngine:
         # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.
         from .test.estimator import _kabsch_host, _dev64
         for i, (c0, c1, matches) in enumerate(full):
+            if i in skipped:
+                continue
             if hip.stats_rank_deficient(st_host[i, 0]) or hip.stats_rank_deficient(st_host[i, 1]):
                 k0 = hip.gather_rows_f64(c0.keys, matches[:, 0].contiguous()); k1 = hip.gather_rows_f64(c1.keys, matches[:, 1].contiguous())
                 w = w_all[i] if w_all[i] is not None else torch.ones(matches.shape[0], dtype=torch.float64, device='cuda')
@@ -290,6 +350,7 @@ class RegistrationEngine:
         t0 = self._mark('ransac_finish', t0)
         out = []
         for i, (a, b) in enumerate(pair_ids):
-            out.append(PairResult(a, b, int(counts[i]), T_host[i], max(int(best_host[i]), 0),
-                                  matches=local[i][2] if keep_matches else None, scores=all_scores[i]))
+            # recalltime: index of the winning hypothesis (yohoo, estimator.py:436) / its 1-based try count (yohoc, :241)
+            T, rec = skipped[i] if i in skipped else (T_host[i], int(best_host[i]) + 1 if yohoc else max(int(best_host[i]), 0))
+            out.append(PairResult(a, b, int(counts[i]), T, rec, matches=local[i][2] if keep_matches else None, scores=all_scores[i]))
         return out

@@ -62,6 +62,7 @@ PROTOTYPES = {
     'roreg_lt_finish_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
     'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'roreg_yohoc_draw': (c_int, [_P, ctypes.c_longlong, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'roreg_topk_dot_workspace_size': (c_size_t, [c_int, c_int, c_int]),
@@ -354,6 +355,14 @@ class LtBatch:
             _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(dr), _ptr(x), _stream()), 'roreg_lt_prepare_batch')
         return dr, x
 
+    def des2r(self):
+        """Des2R alone -> dr int64 [total] (the YOHO-C estimator's DR_index, test/estimator.py:85-111)."""
+        ensure_tables()
+        dr = torch.empty(self.total, dtype=torch.int64, device='cuda')
+        if self.total:
+            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(dr), None, _stream()), 'roreg_lt_prepare_batch')
+        return dr
+
     def finish(self, q_all, dr):
         """un-normalised quaternions [>=total,4] f32 + dr -> Trans [total,3,4] f64."""
         T = torch.empty((self.total, 3, 4), dtype=torch.float64, device='cuda')
@@ -361,6 +370,34 @@ class LtBatch:
             _check(lib().roreg_lt_finish_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(q_all, torch.float32), _ptr(dr, torch.int64), _ptr(T),
                                                _stream()), 'roreg_lt_finish_batch')
         return T
+
+
+def yohoc_draw(prob, bin_size, max_iter, max_tries=50000):
+    """The reference's YOHO-C sampling loop (test/estimator.py:220-230) replayed on the GLOBAL numpy generator: same calls, same
+    order, same final generator state as `np.random.choice(range(60), p=prob)` + `np.random.choice(members, 3)` per try, without the
+    per-call Python overhead.  prob f64 [60], bin_size [60] -> (bins int32 [H], picks int64 [H,3] positions inside the bin)."""
+    prob = np.ascontiguousarray(prob, np.float64)
+    cdf = prob.cumsum()
+    cdf /= cdf[-1]                                                  # numpy's RandomState.choice does exactly this
+    sizes = np.ascontiguousarray(bin_size, np.int32)
+    bins = np.empty(max(max_iter, 1), np.int32); picks = np.empty((max(max_iter, 1), 3), np.int64)
+    n_hyp = ctypes.c_int32(0); used = ctypes.c_longlong(0)
+    state = np.random.get_state()
+    n_words = 16 * max_iter + 64
+    while True:
+        np.random.set_state(state)
+        words = np.random.randint(0, 2 ** 32, size=n_words, dtype=np.uint32)       # raw generator words (full-range uint32 draws)
+        rc = lib().roreg_yohoc_draw(words.ctypes.data, n_words, cdf.ctypes.data, sizes.ctypes.data, int(max_iter), int(max_tries),
+                                    bins.ctypes.data, picks.ctypes.data, ctypes.byref(n_hyp), ctypes.byref(used))
+        if rc == 3:
+            n_words *= 4
+            continue
+        _check(rc, 'roreg_yohoc_draw')
+        break
+    np.random.set_state(state)
+    if used.value:
+        np.random.randint(0, 2 ** 32, size=used.value, dtype=np.uint32)            # advance the generator by what the loop consumed
+    return bins[:n_hyp.value].copy(), picks[:n_hyp.value].copy()
 
 
 _RANSAC_TASK = np.dtype([('keys0', np.uint64), ('keys1', np.uint64), ('matches', np.uint64), ('w', np.uint64), ('Trans', np.uint64),

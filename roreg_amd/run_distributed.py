@@ -31,7 +31,8 @@ def build_engine(cfg):
             raise ValueError("No model exists")
         net.load_state_dict(load_checkpoint(fn)['network_state_dict'], strict=strict)
         return net.eval()
-    gf = load('GF_test', 'GF'); et = load('ET_test', 'ET', strict=False)
+    gf = load('GF_test', 'GF')
+    et = load('ET_test', 'ET', strict=False) if cfg.ET == 'yohoo' else None     # yohoc never evaluates the ET network (estimator.py:266-272)
     rd = load('RD_test', 'RD') if cfg.RD else None
     rm = load('RM_test', 'RM') if cfg.RM else None
     return RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
@@ -123,8 +124,6 @@ def main():
     parser = build_parser()
     parser.add_argument('--seed', type=int, default=None, help='re-seed the global RNG per pair range (rank-count independent results)')
     cfg, _ = parser.parse_known_args()
-    if cfg.ET != 'yohoo':
-        raise SystemExit('the device-resident engine implements the yohoo estimator; use the stage classes (Test.py) for yohoc')
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     if world > 1:

@@ -102,6 +102,52 @@ class extractor_dr_index:
             np.save(f'{Save_dir}/{id0}-{id1}.npy', pre_idxs.cpu().numpy())
 
 
+def three_point_transforms(kps0, kps1):
+    """Threepps2Tran (estimator.py:139-147) for a stack of triples [H,3,3] -> [H,3,4]: the same numpy / LAPACK calls per triple, so
+    the result is bitwise the per-triple one.  That matters: the cross-covariance of three centred points has rank <= 2, so the
+    sign of `VT.T @ U.T`'s third direction (rotation or reflection) is whatever LAPACK's null-space vectors give -- the reference's
+    hypotheses ARE LAPACK's, and only the same call reproduces them."""
+    c0 = np.mean(kps0, 1, keepdims=True)
+    c1 = np.mean(kps1, 1, keepdims=True)
+    m = (kps1 - c1).transpose(0, 2, 1) @ (kps0 - c0)
+    U, S, VT = np.linalg.svd(m)
+    R = VT.transpose(0, 2, 1) @ U.transpose(0, 2, 1)
+    offset = c0 - (c1 @ R.transpose(0, 2, 1))
+    return np.concatenate([R, offset.transpose(0, 2, 1)], 2)
+
+
+def dr_bins(Index):
+    """DR_statictic (estimator.py:119-137) without the per-correspondence Python loop -> (counts [60], members, prob or None).
+    members[starts[r] + p] is the p-th correspondence (increasing order) whose coarse rotation is r."""
+    Index = np.asarray(Index, np.int64)
+    counts = np.bincount(Index, minlength=60)
+    num = counts / 100.0
+    prob = np.where(counts < 2, 0.0, num * (num - 0.01) * (num - 0.02))
+    members = np.argsort(Index, kind='stable')
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    if np.sum(prob) == 0:
+        return counts, members, starts, np.zeros(60)
+    return counts, members, starts, prob / np.sum(prob)
+
+
+def yohoc_draws(Index, max_iter):
+    """The draws of the YOHO-C loop (estimator.py:220-230) -> rows [H,3] of the correspondence list, or None when no rotation bin holds
+    two correspondences (:214-216).  The loop's control flow depends only on the global generator and the bin statistics, never on
+    the overlaps, so every hypothesis is drawn first (hip.yohoc_draw: the reference's generator calls, replayed) and all of them are
+    scored in one device launch."""
+    counts, members, starts, prob = dr_bins(Index)
+    if np.sum(prob) < 1e-5:
+        return None
+    bins, picks = hip.yohoc_draw(prob, counts, max_iter)
+    return members[starts[bins][:, None] + picks]
+
+
+def yohoc_hypotheses(Index, Keys_m0, Keys_m1, max_iter):
+    """-> hypotheses [H,3,4] f64 of one pair, or None (see yohoc_draws)."""
+    idxs = yohoc_draws(Index, max_iter)
+    return None if idxs is None else three_point_transforms(Keys_m0[idxs], Keys_m1[idxs])
+
+
 class yohoc_ransac:
     def __init__(self, cfg):
         self.cfg = cfg
@@ -125,13 +171,7 @@ class yohoc_ransac:
         return stat, prob / np.sum(prob)
 
     def Threepps2Tran(self, kps0_init, kps1_init):
-        center0 = np.mean(kps0_init, 0, keepdims=True)
-        center1 = np.mean(kps1_init, 0, keepdims=True)
-        m = (kps1_init - center1).T @ (kps0_init - center0)
-        U, S, VT = np.linalg.svd(m)
-        rotation = VT.T @ U.T
-        offset = center0 - (center1 @ rotation.T)
-        return np.concatenate([rotation, offset.T], 1)          # 3*4
+        return three_point_transforms(np.asarray(kps0_init)[None], np.asarray(kps1_init)[None])[0]          # 3*4
 
     def overlap_cal(self, key_m0, key_m1, T, scores):
         ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist)
@@ -156,29 +196,13 @@ class yohoc_ransac:
         sample_index = np.arange(pps.shape[0])
         if self.cfg.RM:
             sample_index = _select_top(scores, self.cfg.match_n)
-        Keys_m0 = Keys_m0_init[sample_index]
-        Keys_m1 = Keys_m1_init[sample_index]
         Index = np.load(f'{Index_dir}/{id0}-{id1}.npy')[sample_index]
-        stat, prob = self.DR_statictic(Index)
-        if np.sum(prob) < 1e-5:
+        hyps = yohoc_hypotheses(Index, Keys_m0_init[sample_index], Keys_m1_init[sample_index], max_iter)
+        if hyps is None:
             np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=np.random.rand(4, 4), center=np.ones([6, 3]), recalltime=50000)
             return 0
-        # Hypothesis generation consumes the global RNG exactly like the reference's loop (estimator.py:220-241):
-        # its control flow depends only on the RNG and the bin statistics, never on the overlaps, so all
-        # hypotheses can be drawn first and scored in ONE device launch.
-        hyps = []
-        exec_time = 0
-        while len(hyps) < max_iter:
-            if exec_time > 50000:
-                break
-            exec_time += 1
-            R_index = np.random.choice(range(60), p=prob)
-            if len(stat[R_index]) < 2:
-                continue
-            idxs_init = np.random.choice(np.array(stat[R_index]), 3)
-            hyps.append(self.Threepps2Tran(Keys_m0[idxs_init], Keys_m1[idxs_init]))
         k0 = _dev64(Keys_m0_init); k1 = _dev64(Keys_m1_init); w = _dev64(scores)
-        Trans = _dev64(np.stack(hyps))
+        Trans = _dev64(hyps)
         _, best, _ = hip.ransac_score(k0, k1, w, Trans, self.inliner_dist)
         T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=Trans, best=best)
         recall_time = int(best.item()) + 1                      # iter_ransac is 1-based when recorded

@@ -159,6 +159,31 @@ def test_engine_equals_file_coupled_stages(tmp_path):
         assert np.abs(r.trans - want['trans']).max() < 1e-10
 
 
+def test_engine_yohoc_equals_file_coupled_stages(tmp_path):
+    """The rotation-bin estimator inside the device-resident engine against the file-coupled yohoc stages on the same
+    generator stream: same matches, same winning try, same transform."""
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    from roreg_amd.test import name2extractor, name2matcher, name2estimator
+    z = load_golden('pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, ET='yohoc')
+    keynum = int(z['keynum'])
+    np.random.seed(77)
+    name2extractor['yoho_des'](cfg).run(ds)
+    name2matcher['matmul'](cfg).run(ds, keynum)
+    name2estimator['yohoc'](cfg).run(ds, keynum, 1000)
+    md = f'{cfg.output_cache_fn}/{ds.name}/match_{keynum}'
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    eng = RegistrationEngine(cfg, gf, None)
+    np.random.seed(77)
+    res = eng.run_scene(ds.feats, [ds.get_kps(i) for i in ds.pc_ids], ds.pair_ids, keynum=keynum, max_iter=1000, keep_matches=True)
+    for r in res:
+        want = np.load(f'{md}/yohoc/1000iters/{r.id0}-{r.id1}.npz')
+        assert np.array_equal(r.matches.cpu().numpy(), np.load(f'{md}/{r.id0}-{r.id1}.npy'))
+        assert r.recalltime == int(want['recalltime'])
+        assert np.abs(r.trans - want['trans']).max() < 1e-10
+
+
 def test_knn_module_api_shapes():
     from roreg_amd.utils.knn_search import knn_module
     z = load_golden('knn')

@@ -139,6 +139,61 @@ def test_dropin_aliases():
                 sys.modules[k] = v
 
 
+def test_yohoc_sampling_replays_the_reference_generator_calls():
+    """hip.yohoc_draw (a HOST function of the C-ABI) against the literal loop of test/estimator.py:220-230 on the global generator:
+    same bins, same triples, same generator state afterwards; the vectorised bin statistics and the stacked 3-point Kabsch against
+    their per-item forms, bitwise."""
+    from roreg_amd import hip
+    from roreg_amd.test.estimator import yohoc_ransac, dr_bins, three_point_transforms
+
+    class Cfg:
+        ransac_ird = 0.1
+    ref = yohoc_ransac(Cfg())
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        M = int(rng.integers(5, 4000))
+        dr = rng.integers(0, 60, M) if trial % 3 else rng.choice([3, 7, 7, 7, 11], M)
+        if trial == 5:
+            dr = np.arange(M) % 60
+        if trial == 7:
+            dr = np.arange(60)[:min(M, 60)]                              # every bin has < 2 members
+        stat, prob = ref.DR_statictic(dr)
+        counts, members, starts, prob_v = dr_bins(dr)
+        assert np.array_equal(prob, prob_v)
+        if stat is None:
+            assert np.sum(prob_v) < 1e-5
+            continue
+        for r in range(60):
+            assert np.array_equal(members[starts[r]:starts[r] + counts[r]], np.array(stat[r], np.int64))
+        max_iter = int(rng.choice([1, 10, 1000]))
+        np.random.seed(trial)
+        want_bins, want_idx, tries = [], [], 0
+        while len(want_bins) < max_iter:
+            if tries > 50000:
+                break
+            tries += 1
+            R = np.random.choice(range(60), p=prob)
+            if len(stat[R]) < 2:
+                continue
+            want_idx.append(np.random.choice(np.array(stat[R]), 3)); want_bins.append(R)
+        tail = np.random.rand(3)
+        np.random.seed(trial)
+        bins, picks = hip.yohoc_draw(prob_v, counts, max_iter)
+        assert np.array_equal(tail, np.random.rand(3))                      # generator advanced by exactly the same amount
+        assert np.array_equal(bins, np.array(want_bins))
+        assert np.array_equal(members[starts[bins][:, None] + picks], np.array(want_idx).reshape(-1, 3))
+    # stacked Kabsch == per-triple Kabsch (same LAPACK call per matrix), including repeated points
+    K0 = rng.uniform(0, 3, (500, 3)); K1 = K0[:, [1, 2, 0]] + rng.normal(0, 0.01, (500, 3))
+    idx = rng.integers(0, 500, (300, 3)); idx[::7, 1] = idx[::7, 0]; idx[::13] = idx[::13, :1]
+    got = three_point_transforms(K0[idx], K1[idx])
+    for i in range(idx.shape[0]):
+        k0, k1 = K0[idx[i]], K1[idx[i]]
+        c0 = np.mean(k0, 0, keepdims=True); c1 = np.mean(k1, 0, keepdims=True)
+        U, S, VT = np.linalg.svd((k1 - c1).T @ (k0 - c0))
+        R = VT.T @ U.T
+        assert np.array_equal(got[i], np.concatenate([R, (c0 - c1 @ R.T).T], 1))
+
+
 def test_shard_scenes_balanced_and_complete():
     from roreg_amd.distributed import shard_scenes
     counts = dict(zip('abcdefgh', [449, 217, 159, 207, 104, 54, 292, 138]))       # 3DMatch-like pair counts

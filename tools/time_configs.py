@@ -1,5 +1,5 @@
 """Throughput of the other BASELINE.json configurations on the same synthetic chunk (secondary figures for DESIGN.md):
-   A: mutual + yohoo (the bench config)   B: RD detector + mutual + yohoo   C: RD + RM (rotation-coherence matcher, keynum 2500) + yohoo."""
+   A: mutual + yohoo (the bench config)   A': mutual + yohoc (rotation-bin RANSAC)   B: RD detector + mutual + yohoo   C: RD + RM (rotation-coherence matcher, keynum 2500) + yohoo."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -15,7 +15,7 @@ scene = synth.make_scene(1000, n_clouds=n_clouds, n_kpts=5000, overlap=0.6, coor
 order = np.random.default_rng(4242).permutation(len(scene.pair_ids))
 pair_ids = [scene.pair_ids[i] for i in sorted(order[:n_pairs])]
 feats = [torch.from_numpy(f).cuda() for f in scene.feats]; keys = [torch.from_numpy(k).cuda() for k in scene._kps]
-for name, kw in (('mutual+yohoo', dict(keynum=5000, ET='yohoo')), ('RD+mutual+yohoo', dict(keynum=5000, ET='yohoo', RD=True)),
+for name, kw in (('mutual+yohoo', dict(keynum=5000, ET='yohoo')), ('mutual+yohoc', dict(keynum=5000, ET='yohoc')), ('RD+mutual+yohoo', dict(keynum=5000, ET='yohoo', RD=True)),
                  ('RD+RM+yohoo', dict(keynum=2500, ET='yohoo', RD=True, RM=True))):
     cfg = default_config(max_iter=1000, **kw)
     gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
@@ -28,9 +28,12 @@ for name, kw in (('mutual+yohoo', dict(keynum=5000, ET='yohoo')), ('RD+mutual+yo
     eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
     try:
         for rep in range(3):
+            eng.phase_ms = {} if rep == 2 and '--phases' in sys.argv else None
             np.random.seed(7); torch.cuda.synchronize(); t = time.perf_counter()
             res = eng.run_scene(feats, keys, pair_ids, keynum=cfg.keynum)
             torch.cuda.synchronize(); dt = time.perf_counter() - t
+        if eng.phase_ms:
+            print('   phases (ms, synchronised):', {k: round(v, 1) for k, v in eng.phase_ms.items()})
         ok = np.mean([np.isfinite(r.trans).all() for r in res])
         print(f'{name}: {n_pairs / dt:.1f} pairs/s ({dt * 1e3:.1f} ms for {n_clouds} clouds / {n_pairs} pairs; finite results {ok:.2f})')
     except Exception as e:
