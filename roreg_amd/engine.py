@@ -149,21 +149,58 @@ class RegistrationEngine:
             s0 = s0[0:keynum]; s1 = s1[0:keynum]
         return s0, s1
 
-    def match_rm(self, c0, c1, s0, s1):
-        """Rotation-coherence matcher on the sampled keypoints (test/matcher.py:187-206) -> (matches [M,2] int64 device in cloud
-        coordinates, scores float32 host).  The batch carries cloud 1 as feats0/keys0 and cloud 0 as feats1/keys1."""
-        d0 = torch.from_numpy(np.ascontiguousarray(s0, np.int64)).cuda()
-        d1 = torch.from_numpy(np.ascontiguousarray(s1, np.int64)).cuda()
+    def _match_rm_issue(self, c0, c1, s0, s1):
+        """Enqueue the rotation-coherence matcher of one pair on the current stream; no host synchronisation.
+        The batch carries cloud 1 as feats0/keys0 and cloud 0 as feats1/keys1 (test/matcher.py:192-197)."""
+        d0 = torch.from_numpy(np.ascontiguousarray(s0, np.int64)).cuda(non_blocking=True)
+        d1 = torch.from_numpy(np.ascontiguousarray(s1, np.int64)).cuda(non_blocking=True)
         batch = {'feats0': c1.eqv[d1][None], 'feats1': c0.eqv[d0][None],
                  'keys0': c1.keys[d1].float()[None], 'keys1': c0.keys[d0].float()[None]}
         with torch.no_grad():
             r = self.rm(batch)
-        m0 = r['matches0'][0]
-        valid = torch.nonzero(m0 >= 0)[:, 0]
+        return r['matches0'][0], r['matching_scores0'][0]
+
+    @staticmethod
+    def _match_rm_finish(s0, s1, m0, sc0):
+        """matches0 / matching_scores0 (host) -> (matches [M,2] int64 host in cloud coordinates, scores f32); test/matcher.py:198-206."""
+        valid = np.nonzero(m0 >= 0)[0]
         if valid.shape[0] < 3:                       # the reference crashes here; same documented divergence as test/matcher.py
-            return torch.ones((1, 2), dtype=torch.int64, device='cuda'), np.ones(1, np.float32)
-        matches = torch.stack([d0[m0[valid]], d1[valid]], 1).contiguous()
-        return matches, r['matching_scores0'][0][valid].cpu().numpy()
+            return np.ones((1, 2), np.int64), np.ones(1, np.float32)
+        return np.stack([np.asarray(s0, np.int64)[m0[valid]], np.asarray(s1, np.int64)[valid]], 1), sc0[valid]
+
+    def match_rm_many(self, jobs, n_streams=4):
+        """Rotation-coherence matcher of several pairs: jobs [(c0, c1, s0, s1)] -> [(matches [M,2] int64 device, scores f32 host)].
+        One pair's kernels work on 2500 keypoints and leave most of the chip idle, so the pairs are issued round-robin on a few HIP
+        streams and run concurrently; one synchronisation, one download of the read-outs and one upload of the match lists per call."""
+        if not jobs:
+            return []
+        main = torch.cuda.current_stream()
+        if getattr(self, '_rm_streams', None) is None or len(self._rm_streams) != n_streams:
+            self._rm_streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        issued = []
+        for q, (c0, c1, s0, s1) in enumerate(jobs):
+            st = self._rm_streams[q % n_streams]
+            st.wait_stream(main)                                            # the clouds' features come from the main stream
+            with torch.cuda.stream(st):
+                issued.append(self._match_rm_issue(c0, c1, s0, s1))
+        for st in self._rm_streams:
+            main.wait_stream(st)
+        m0_all = torch.cat([m for m, _ in issued]).cpu().numpy()            # the one sync of the matcher stage
+        sc_all = torch.cat([s for _, s in issued]).cpu().numpy()
+        out, o = [], 0
+        for (c0, c1, s0, s1), (m, _) in zip(jobs, issued):
+            n = int(m.shape[0])
+            out.append(self._match_rm_finish(s0, s1, m0_all[o:o + n], sc_all[o:o + n])); o += n
+        flat = torch.from_numpy(np.concatenate([m.reshape(-1) for m, _ in out])).cuda()
+        res, o = [], 0
+        for m, sc in out:
+            res.append((flat[o:o + m.size].view(-1, 2), sc)); o += m.size
+        return res
+
+    def match_rm(self, c0, c1, s0, s1):
+        """Rotation-coherence matcher on the sampled keypoints (test/matcher.py:187-206) -> (matches [M,2] int64 device in cloud
+        coordinates, scores float32 host)."""
+        return self.match_rm_many([(c0, c1, s0, s1)], n_streams=1)[0]
 
     def match_mutual(self, c0, c1, s0, s1):
         """-> (match buffer [m,2] int64 device, count int32[1] device); test/matcher.py:90-107."""
@@ -297,10 +334,11 @@ class RegistrationEngine:
         # stage 3: all pairs
         full, all_scores = [], []
         if self.cfg.RM:
+            jobs = []
             for a, b in pair_ids:
                 c0, c1 = clouds[int(a)], clouds[int(b)]
-                s0, s1 = self.sample(c0, c1, keynum)
-                m, sc = self.match_rm(c0, c1, s0, s1)
+                jobs.append((c0, c1) + tuple(self.sample(c0, c1, keynum)))
+            for (c0, c1, _, _), (m, sc) in zip(jobs, self.match_rm_many(jobs)):
                 full.append((c0, c1, m)); all_scores.append(sc)
             counts = np.array([m.shape[0] for _, _, m in full])
         else:

@@ -176,7 +176,10 @@ class Match_ot(nn.Module):
         sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv)
         source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]))
         target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]))
-        alpha = float(self.ot_layer.bin_score.detach().cpu())
+        bs = self.ot_layer.bin_score
+        if getattr(self, '_alpha', None) is None or self._alpha[0] != (bs.data_ptr(), bs._version):   # one download per weight load, not per pair
+            object.__setattr__(self, '_alpha', ((bs.data_ptr(), bs._version), float(bs.detach().cpu())))
+        alpha = self._alpha[1]
         Z, m0, m1, s0, s1 = hip.sinkhorn(source_final, target_final, alpha, self.ot_layer.iters)
         out = _MatchResult({
             'scores': Z[None], 'matches0': m0[None], 'matches1': m1[None], 'matching_scores0': s0[None], 'matching_scores1': s1[None],
