@@ -237,22 +237,35 @@ int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int wid
  *
  * roreg_topk_dot: for every row of A [m,32] the k (16, 8 or 1) rows of B [n,32] with the largest dot product, descending,
  * lower index first on ties; replaces score_mat + the full descending argsort of Knn_index_extract
- * (rot_coh_match.py:8-12,34-45) without materialising the m x n matrix.  ws: roreg_topk_dot_workspace_size floats. */
+ * (rot_coh_match.py:8-12,34-45) without materialising the m x n matrix.  ws: roreg_topk_dot_workspace_size floats.
+ *
+ * Several pairs per launch ("segments"): the per-point tensors of the pairs are concatenated, seg* are DEVICE int32 [n_seg+1] row
+ * offsets (in points), and every per-pair quantity (neighbour search, InstanceNorm statistics, column maxima, Sinkhorn) stays inside
+ * its pair with the arithmetic of the one-pair call, bit for bit.  In roreg_topk_dot a row of A's segment p searches B's segment p and
+ * idx_out holds GLOBAL rows of B; max_m / max_n = the largest segment.  seg pointers NULL = one pair (the remaining segment arguments
+ * are ignored). */
 size_t roreg_topk_dot_workspace_size(int m, int n, int k);
 int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t *idx_out, float *val_out /* optional [m,k] */,
-                   float *ws, size_t ws_floats, void *stream);
+                   float *ws, size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream);
 
 /* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
  * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119). */
 int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
 
 /* InstanceNorm2d(affine=False) statistics of h [L,C] over all L positions -> mean_rstd [2C] = mean, 1/sqrt(var_biased+eps).
- * ws: 2*C*256 doubles.  (rot_coh_match.py:19,68) */
-int roreg_instnorm_stats(const float *h, int L, int C, float eps, float *mean_rstd, double *ws, void *stream);
+ * ws: 2*C*256 doubles.  (rot_coh_match.py:19,68)   With segments (seg_off in points, `mult` rows of h per point): one statistic
+ * per pair, mean_rstd [n_seg][2C], ws n_seg*2*C*256 doubles. */
+int roreg_instnorm_stats(const float *h, int L, int C, float eps, float *mean_rstd, double *ws, const int32_t *seg_off, int n_seg,
+                         int mult, void *stream);
 
-/* y [L,32] += W2 relu((h - mean) * rstd) + b2  (closing conv of mlp_2layer / Contextnorm; y already holds the residual conv). */
+/* y [L,32] += W2 relu((h - mean) * rstd) + b2  (closing conv of mlp_2layer / Contextnorm; y already holds the residual conv);
+ * with segments every row uses the statistics of its pair. */
 int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2 /* [32,Cmid] */, const float *b2,
-                   float *y, void *stream);
+                   float *y, const int32_t *seg_off, int n_seg, int mult, void *stream);
+
+/* ctx [L,120] = [R [L,60] | max over the points of the row's pair of R]  (Self_attention_block's ambiguity context,
+ * rot_coh_match.py:201-202).  ws: n_seg*(256+1)*60 floats. */
+int roreg_context_colmax(const float *R, int L, const int32_t *seg_off, int n_seg, int max_len, float *ctx_out, float *ws, void *stream);
 
 /* Core of MultiHeadedAttention(4 heads, d_model 32) on k-NN neighbourhoods (rot_coh_match.py:84-119): qp [m,32] projected
  * queries; kp / vp projected keys / values, either dense [m,k,32] or a per-point table [n,32] addressed through idx [m,k].
@@ -270,6 +283,17 @@ int roreg_rm_elementwise(int op, const float *a, const float *b, const float *c,
 size_t roreg_sinkhorn_workspace_size(int m, int n);
 int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n, float alpha, int iters, float *Z_out,
                    int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats, void *stream);
+
+/* The same for several pairs per launch (2*iters + 5 launches for all of them): descriptors concatenated by seg_src / seg_tgt (device
+ * and host copies of the int32 offsets), read-outs concatenated the same way with indices LOCAL to the pair; the coupling matrix
+ * itself is not returned.  consts: DEVICE copy of the 4*n_seg floats of roreg_sinkhorn_batch_consts (a host function: the host
+ * logf values the one-pair call uses). */
+size_t roreg_sinkhorn_batch_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n);
+int roreg_sinkhorn_batch_consts(const int32_t *seg_src_host, const int32_t *seg_tgt_host, int n_seg, float *consts_host);
+int roreg_sinkhorn_batch(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                         const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                         int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                         void *stream);
 
 /* ---- group-Fourier evaluation of the group convolution (csrc/fourier.hip, roreg_amd/fourier.py) ---------------
  * In the basis of the five real irreps (d = 1,3,3,4,5) the 13-stencil group conv is one dense GEMM per irrep,

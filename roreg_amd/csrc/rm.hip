@@ -25,11 +25,18 @@ __device__ __forceinline__ void topk_insert(float (&bv)[K], int (&bi)[K], float 
     }
 }
 
+// Segments (several pairs per launch): rows of A and B are concatenations over the pairs, segA/segB [P+1] are the row offsets and
+// blockIdx.z is the pair; a source row only sees the targets of its own pair and the indices written are GLOBAL rows of B, so the
+// gathers downstream need no per-pair base.  segA == nullptr: one pair (m x n).
 template <int K>
 __global__ __launch_bounds__(256) void topk_dot_kernel(const float *__restrict__ A, int m, const float *__restrict__ B, int n,
-                                                       int slice, float *__restrict__ pv, int *__restrict__ pi) {
+                                                       const int *__restrict__ segA, const int *__restrict__ segB, int slices,
+                                                       float *__restrict__ pv, int *__restrict__ pi) {
+    const int a0 = segA ? segA[blockIdx.z] : 0, mp = segA ? segA[blockIdx.z + 1] - a0 : m;
+    const int b0 = segA ? segB[blockIdx.z] : 0, np_ = segA ? segB[blockIdx.z + 1] - b0 : n;
+    if ((int)(blockIdx.x * 256) >= mp || np_ <= 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int ii = i < m ? i : m - 1;
+    const int ii = a0 + (i < mp ? i : mp - 1);
     float a[RM_F];
 #pragma unroll
     for (int f = 0; f < RM_F; ++f) a[f] = A[(size_t)ii * RM_F + f];
@@ -37,7 +44,8 @@ __global__ __launch_bounds__(256) void topk_dot_kernel(const float *__restrict__
     int bi[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) { bv[q] = -__builtin_inff(); bi[q] = 0x7fffffff; }
-    const int j0 = blockIdx.y * slice, j1 = min(j0 + slice, n);
+    const int slice = (np_ + slices - 1) / slices;
+    const int j0 = b0 + blockIdx.y * slice, j1 = min(j0 + slice, b0 + np_);
     for (int j = j0; j < j1; ++j) {
         const float *b = B + (size_t)j * RM_F;
         float acc = 0.f;
@@ -45,9 +53,9 @@ __global__ __launch_bounds__(256) void topk_dot_kernel(const float *__restrict__
         for (int f = 0; f < RM_F; ++f) acc = fmaf(a[f], b[f], acc);
         topk_insert<K>(bv, bi, acc, j);
     }
-    if (i < m) {
-        float *ov = pv + ((size_t)blockIdx.y * m + i) * K;
-        int *oi = pi + ((size_t)blockIdx.y * m + i) * K;
+    if (i < mp) {
+        float *ov = pv + ((size_t)blockIdx.y * m + a0 + i) * K;
+        int *oi = pi + ((size_t)blockIdx.y * m + a0 + i) * K;
 #pragma unroll
         for (int q = 0; q < K; ++q) { ov[q] = bv[q]; oi[q] = bi[q]; }
     }
@@ -75,6 +83,16 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 }
 
+// segment of row r in offsets off[0..n_seg] (off[n_seg] = total): the last s with off[s] <= r
+__device__ __forceinline__ int seg_of(const int *__restrict__ off, int n_seg, int r) {
+    int lo = 0, hi = n_seg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // =====================================================================================================
 // pointwise linear layers (1x1 convs) on [L, CIN] rows.  One thread per position, weights through the scalar path.
 //   plain : y  = W x + b
@@ -83,10 +101,12 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 template <int CIN, int COUT, bool NORM, bool ACCUM>
 __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int L, const float *__restrict__ W,
                                                      const float *__restrict__ b, const float *__restrict__ mean_rstd,
-                                                     float *__restrict__ y, int ochunk) {
+                                                     float *__restrict__ y, int ochunk, const int *__restrict__ seg_off = nullptr,
+                                                     int n_seg = 1, int mult = 1) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int pp = p < L ? p : L - 1;
     float xi[CIN];
+    if (NORM && seg_off) mean_rstd += (size_t)seg_of(seg_off, n_seg, pp / mult) * 2 * CIN;     // statistics of this row's pair
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
         float v = x[(size_t)pp * CIN + c];
@@ -115,14 +135,21 @@ inline int linear_ochunk(int L, int Cout) {
 
 // InstanceNorm statistics: per channel over all L positions (biased variance), accumulated in fp64, two stages,
 // fixed reduction order (deterministic).  mean_rstd = [mean (C), 1/sqrt(var+eps) (C)].
-__global__ __launch_bounds__(256) void in_stats_partial_kernel(const float *__restrict__ h, int L, int C, double *__restrict__ part) {
+// With segments (seg_off [P+1] in points, `mult` rows per point) blockIdx.y is the pair and every pair keeps the block count and the
+// strided assignment it would have alone, so the statistics are bitwise those of the one-pair launch.
+__global__ __launch_bounds__(256) void in_stats_partial_kernel(const float *__restrict__ h, int L, int C, double *__restrict__ part,
+                                                               const int *__restrict__ seg_off, int mult) {
     extern __shared__ double sh[];                  // [256][2]
     const int lanes = 256 / C;                      // position lanes per block (C <= 128 and divides 256)
+    const int r0 = seg_off ? seg_off[blockIdx.y] * mult : 0, Lp = seg_off ? seg_off[blockIdx.y + 1] * mult - r0 : L;
+    int nblk = (Lp + lanes - 1) / lanes;
+    if (nblk > 256) nblk = 256;
+    if ((int)blockIdx.x >= nblk) return;
     const int c = threadIdx.x % C, pl = threadIdx.x / C;
     double s = 0, s2 = 0;
     if (pl < lanes)
-        for (int p = blockIdx.x * lanes + pl; p < L; p += gridDim.x * lanes) {
-            const double v = h[(size_t)p * C + c];
+        for (int p = blockIdx.x * lanes + pl; p < Lp; p += nblk * lanes) {
+            const double v = h[(size_t)(r0 + p) * C + c];
             s += v; s2 += v * v;
         }
     sh[threadIdx.x * 2] = s; sh[threadIdx.x * 2 + 1] = s2;
@@ -130,15 +157,22 @@ __global__ __launch_bounds__(256) void in_stats_partial_kernel(const float *__re
     if (threadIdx.x < C) {
         double a = 0, a2 = 0;
         for (int q = 0; q < lanes; ++q) { a += sh[(q * C + threadIdx.x) * 2]; a2 += sh[(q * C + threadIdx.x) * 2 + 1]; }
-        part[((size_t)blockIdx.x * C + threadIdx.x) * 2] = a;
-        part[((size_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = a2;
+        double *po = part + (size_t)blockIdx.y * 256 * C * 2;
+        po[((size_t)blockIdx.x * C + threadIdx.x) * 2] = a;
+        po[((size_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = a2;
     }
 }
 
-__global__ __launch_bounds__(256) void in_stats_final_kernel(const double *__restrict__ part, int nblk, int L, int C, float eps,
-                                                             float *__restrict__ mean_rstd) {
+__global__ __launch_bounds__(256) void in_stats_final_kernel(const double *__restrict__ part, int L, int C, float eps,
+                                                             float *__restrict__ mean_rstd, const int *__restrict__ seg_off, int mult) {
     __shared__ double sa[256], sb[256];
-    const int c = blockIdx.x;                       // one block per channel; fixed-order tree => deterministic
+    const int c = blockIdx.x;                       // one block per (channel, pair); fixed-order tree => deterministic
+    const int Lp = seg_off ? (seg_off[blockIdx.y + 1] - seg_off[blockIdx.y]) * mult : L;
+    const int lanes = 256 / C;
+    int nblk = (Lp + lanes - 1) / lanes;
+    if (nblk > 256) nblk = 256;
+    part += (size_t)blockIdx.y * 256 * C * 2;
+    mean_rstd += (size_t)blockIdx.y * 2 * C;
     double a = 0, a2 = 0;
     if ((int)threadIdx.x < nblk) { a = part[((size_t)threadIdx.x * C + c) * 2]; a2 = part[((size_t)threadIdx.x * C + c) * 2 + 1]; }
     sa[threadIdx.x] = a; sb[threadIdx.x] = a2;
@@ -148,8 +182,8 @@ __global__ __launch_bounds__(256) void in_stats_final_kernel(const double *__res
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const double mu = sa[0] / L;
-        double var = sb[0] / L - mu * mu;
+        const double mu = sa[0] / Lp;
+        double var = sb[0] / Lp - mu * mu;
         if (var < 0) var = 0;
         mean_rstd[c] = (float)mu;
         mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -221,32 +255,37 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restric
     for (int c = 0; c < C; ++c) y[(size_t)p * C + c] = x[(size_t)p * C + c] / r;
 }
 
-__global__ __launch_bounds__(256) void colmax_partial_kernel(const float *__restrict__ x, int L, int C, float *__restrict__ part) {
-    // block b reduces rows b, b+grid, ... ; thread c < C owns a column
+__global__ __launch_bounds__(256) void colmax_partial_kernel(const float *__restrict__ x, int L, int C, float *__restrict__ part,
+                                                             const int *__restrict__ seg_off) {
+    // block (b, pair) reduces the pair's rows b, b+grid, ... ; thread c < C owns a column
     const int c = threadIdx.x;
     if (c >= C) return;
+    const int r0 = seg_off ? seg_off[blockIdx.y] : 0, Lp = seg_off ? seg_off[blockIdx.y + 1] - r0 : L;
     float mx = -__builtin_inff();
-    for (int p = blockIdx.x; p < L; p += gridDim.x) mx = fmaxf(mx, x[(size_t)p * C + c]);
-    part[(size_t)blockIdx.x * C + c] = mx;
+    for (int p = blockIdx.x; p < Lp; p += gridDim.x) mx = fmaxf(mx, x[(size_t)(r0 + p) * C + c]);
+    part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + c] = mx;
 }
 
 __global__ __launch_bounds__(256) void colmax_final_kernel(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
     __shared__ float sm[256];
     const int c = blockIdx.x;
+    part += (size_t)blockIdx.y * nblk * C;
     sm[threadIdx.x] = (int)threadIdx.x < nblk ? part[(size_t)threadIdx.x * C + c] : -__builtin_inff();
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = sm[0];
+    if (threadIdx.x == 0) out[(size_t)blockIdx.y * C + c] = sm[0];
 }
 
-// ctx[p] = [R[p,0..59], colmax[0..59]]
-__global__ __launch_bounds__(256) void context_kernel(const float *__restrict__ R, const float *__restrict__ cmax, int m, float *__restrict__ ctx) {
+// ctx[p] = [R[p,0..59], colmax[pair of p][0..59]]
+__global__ __launch_bounds__(256) void context_kernel(const float *__restrict__ R, const float *__restrict__ cmax, int m, float *__restrict__ ctx,
+                                                      const int *__restrict__ seg_off, int n_seg) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m * 120) return;
     const int p = i / 120, c = i - p * 120;
+    if (c >= 60 && seg_off) cmax += (size_t)seg_of(seg_off, n_seg, p) * 60;
     ctx[i] = c < 60 ? R[(size_t)p * 60 + c] : cmax[c - 60];
 }
 
@@ -317,9 +356,19 @@ __global__ __launch_bounds__(256) void mean_g_kernel(const float *__restrict__ e
 // Coupling matrix straight from the final descriptors: M[r][c] = <rowvec[r], colvec[c]> (score, rot_coh_match.py:363) with the
 // dustbin row/column = alpha.  One thread per column (its descriptor in registers), rows arrive through the scalar path, so
 // every store is coalesced; called twice (Z0 and its transpose) instead of transposing through memory.
+// Batched form (several pairs per launch): blockIdx.z = pair; segR/segC [P+1] are the row offsets of the two descriptor lists, every
+// pair owns a slab of `slab` floats of the workspace and R, C are re-derived per pair.  segR == nullptr: the one-pair call.
 __global__ __launch_bounds__(256) void ot_build_kernel(const float *__restrict__ rowvec, int R, const float *__restrict__ colvec, int C,
-                                                       float alpha, int rows_per_block, float *__restrict__ M, int ld) {
+                                                       float alpha, int rows_per_block, float *__restrict__ M, int ld,
+                                                       const int *__restrict__ segR, const int *__restrict__ segC, size_t slab) {
+    if (segR) {
+        const int r0 = segR[blockIdx.z], c0 = segC[blockIdx.z];
+        R = segR[blockIdx.z + 1] - r0; C = segC[blockIdx.z + 1] - c0;
+        rowvec += (size_t)r0 * RM_F; colvec += (size_t)c0 * RM_F; M += blockIdx.z * slab;
+        if (R <= 0 || C <= 0) return;
+    }
     const int c = blockIdx.x * 256 + threadIdx.x;          // column in [0, C]  (C = dustbin)
+    if ((int)(blockIdx.x * 256) > C) return;
     const int cc = c < C ? c : C - 1;
     float t[RM_F];
 #pragma unroll
@@ -339,25 +388,45 @@ __global__ __launch_bounds__(256) void ot_build_kernel(const float *__restrict__
     }
 }
 
+// Per-pair geometry of the batched Sinkhorn passes: pair = blockIdx.y, matrix rows = seg_rows (+1 dustbin), columns = seg_cols (+1).
+struct OtBatch {
+    const int *seg_rows, *seg_cols;      // nullptr = one pair
+    size_t slab;                         // floats between the pairs' workspaces
+    const float *consts;                 // per pair: -log(m+n), log(#columns of this pass) -- host logf values, as in the one-pair call
+};
+
 // out[i] = log_a(i) - LSE_j(Z[i,j] + vec[j]);  log_a = normc for i < R-1, last_extra + normc for the dustbin row
+// One WAVE per row (four rows per workgroup, no LDS, no barrier): a lane streams float4 pieces of its row with an online
+// (max, sum-of-exp) pair updated once per four elements, then the 64 pairs are merged by a butterfly.
 __global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ Z, int R, int C, int ld, const float *__restrict__ vec,
-                                                      float normc, float last_extra, float *__restrict__ out) {
-    __shared__ float smx[4], ssum[4];
-    const int i = blockIdx.x;
+                                                      float normc, float last_extra, float *__restrict__ out, OtBatch ob) {
+    if (ob.seg_rows) {
+        R = ob.seg_rows[blockIdx.y + 1] - ob.seg_rows[blockIdx.y] + 1;
+        C = ob.seg_cols[blockIdx.y + 1] - ob.seg_cols[blockIdx.y] + 1;
+        if ((int)(blockIdx.x * 4) >= R || R <= 1 || C <= 1) return;
+        Z += blockIdx.y * ob.slab; vec += blockIdx.y * ob.slab; out += blockIdx.y * ob.slab;
+        normc = ob.consts[blockIdx.y * 2]; last_extra = ob.consts[blockIdx.y * 2 + 1];
+    }
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= R) return;
     const float *row = Z + (size_t)i * ld;          // ld is a multiple of 4: rows are 16-byte aligned
     float mx = -__builtin_inff(), s = 0.f;
-    auto upd = [&](float x) {
-        if (x > mx) { s = s * __expf(mx - x) + 1.0f; mx = x; }
-        else s += __expf(x - mx);
-    };
     const int C4 = C & ~3;
-    for (int j = threadIdx.x * 4; j < C4; j += 1024) {
+#pragma unroll 4
+    for (int j = lane * 4; j < C4; j += 256) {
         const float4 z = *reinterpret_cast<const float4 *>(row + j);
         const float4 v = *reinterpret_cast<const float4 *>(vec + j);
-        upd(z.x + v.x); upd(z.y + v.y); upd(z.z + v.z); upd(z.w + v.w);
+        const float x0 = z.x + v.x, x1 = z.y + v.y, x2 = z.z + v.z, x3 = z.w + v.w;
+        const float m4 = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+        if (m4 > mx) { s *= __expf(mx - m4); mx = m4; }                      // exp(-inf) = 0 on the first piece
+        s += (__expf(x0 - mx) + __expf(x1 - mx)) + (__expf(x2 - mx) + __expf(x3 - mx));
     }
-    if ((int)threadIdx.x < C - C4) upd(row[C4 + threadIdx.x] + vec[C4 + threadIdx.x]);
-    // combine (mx, s) pairs: wave butterfly then across the 4 waves
+    if (lane < C - C4) {
+        const float x = row[C4 + lane] + vec[C4 + lane];
+        if (x > mx) { s = s * __expf(mx - x) + 1.0f; mx = x; }
+        else s += __expf(x - mx);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float omx = __shfl_xor(mx, o), os = __shfl_xor(s, o);
@@ -365,15 +434,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ 
         s = (mx == -__builtin_inff() ? 0.f : s * __expf(mx - nm)) + (omx == -__builtin_inff() ? 0.f : os * __expf(omx - nm));
         mx = nm;
     }
-    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; ssum[threadIdx.x >> 6] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float M = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-        float S = 0.f;
-        for (int w = 0; w < 4; ++w) S += ssum[w] * __expf(smx[w] - M);
-        const float lse = M + __logf(S);
-        out[i] = (i == R - 1 ? last_extra + normc : normc) - lse;
-    }
+    if (lane == 0) out[i] = (i == R - 1 ? last_extra + normc : normc) - (mx + __logf(s));
 }
 
 __global__ __launch_bounds__(256) void ot_final_kernel(const float *__restrict__ Z0, int ld, int m, int n, const float *__restrict__ u,
@@ -389,9 +450,18 @@ __global__ __launch_bounds__(256) void ot_final_kernel(const float *__restrict__
 template <bool ROWC_FIRST>
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ Z, int R, int C, int ld, const float *__restrict__ vec,
                                                          const float *__restrict__ rowc, float normc, int64_t *__restrict__ idx,
-                                                         float *__restrict__ val) {
+                                                         float *__restrict__ val, OtBatch ob) {
     __shared__ float sv[256];
     __shared__ int si[256];
+    if (ob.seg_rows) {
+        const int r0 = ob.seg_rows[blockIdx.y];
+        R = ob.seg_rows[blockIdx.y + 1] - r0 + 1;
+        C = ob.seg_cols[blockIdx.y + 1] - ob.seg_cols[blockIdx.y] + 1;
+        if ((int)blockIdx.x >= R - 1 || C <= 1) return;
+        Z += blockIdx.y * ob.slab; vec += blockIdx.y * ob.slab; rowc += blockIdx.y * ob.slab;
+        idx += r0; val += r0;                          // read-outs are concatenated over the pairs
+        normc = ob.consts[blockIdx.y * 2];
+    }
     const int i = blockIdx.x;            // < R-1
     const float *row = Z + (size_t)i * ld;
     float bv = -__builtin_inff();
@@ -414,9 +484,16 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict
     if (threadIdx.x == 0) { idx[i] = si[0]; val[i] = sv[0]; }
 }
 
+// batched: blockIdx.y = pair; i0/v0/m0/s0 are concatenated by seg0, i1/m1/s1 by seg1; indices stay LOCAL to the pair
 __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restrict__ i0, const float *__restrict__ v0, int m,
                                                          const int64_t *__restrict__ i1, int n, int64_t *__restrict__ m0,
-                                                         int64_t *__restrict__ m1, float *__restrict__ s0, float *__restrict__ s1) {
+                                                         int64_t *__restrict__ m1, float *__restrict__ s0, float *__restrict__ s1,
+                                                         const int *__restrict__ seg0, const int *__restrict__ seg1) {
+    if (seg0) {
+        const int a = seg0[blockIdx.y], b = seg1[blockIdx.y];
+        m = seg0[blockIdx.y + 1] - a; n = seg1[blockIdx.y + 1] - b;
+        i0 += a; v0 += a; m0 += a; s0 += a; i1 += b; m1 += b; s1 += b;
+    }
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < m) {
         const bool mu = i1[i0[t]] == (int64_t)t;
@@ -434,32 +511,40 @@ __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restri
 }  // namespace
 
 // -----------------------------------------------------------------------------------------------------------
+static int topk_slices(int gx_total, int max_n) {
+    int slices = (320 + gx_total - 1) / gx_total;
+    if (slices > (max_n + 63) / 64) slices = (max_n + 63) / 64;
+    return slices < 1 ? 1 : slices;
+}
+
 extern "C" size_t roreg_topk_dot_workspace_size(int m, int n, int k) {
-    const int gx = (m + 255) / 256;
-    int slices = (320 + gx - 1) / gx;
-    if (slices > (n + 63) / 64) slices = (n + 63) / 64;
-    if (slices < 1) slices = 1;
+    // enough for any segmentation of m x n: the slice count only shrinks when the rows are spread over several pairs
+    const int slices = topk_slices((m + 255) / 256, n);
     return (size_t)slices * m * k * 2;       // floats (values) + ints (indices), 4 bytes each
 }
 
 extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t *idx_out, float *val_out, float *ws,
-                              size_t ws_floats, void *stream) {
+                              size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream) {
     ROREG_REQUIRE(A && B && idx_out && ws && m > 0 && n > 0, "roreg_topk_dot: bad arguments");
     ROREG_REQUIRE(k == 16 || k == 8 || k == 1, "roreg_topk_dot: k must be 16, 8 or 1 (got %d)", k);
-    ROREG_REQUIRE(k <= n, "roreg_topk_dot: k > n");
-    const int gx = (m + 255) / 256;
-    int slices = (320 + gx - 1) / gx;
-    if (slices > (n + 63) / 64) slices = (n + 63) / 64;
-    if (slices < 1) slices = 1;
-    const int slice = (n + slices - 1) / slices;
-    slices = (n + slice - 1) / slice;
+    ROREG_REQUIRE((segA == nullptr) == (segB == nullptr), "roreg_topk_dot: both segment tables or none");
+    if (!segA) { n_seg = 1; max_m = m; max_n = n; }
+    ROREG_REQUIRE(n_seg > 0 && max_m > 0 && max_n > 0 && max_m <= m && max_n <= n, "roreg_topk_dot: bad segment description");
+    ROREG_REQUIRE(segA || k <= n, "roreg_topk_dot: k > n");      // with segments the caller guarantees k <= every pair's target count
+    const int gx = (max_m + 255) / 256;
+    int slices = topk_slices(gx * n_seg, max_n);
+    if (!segA) {                                 // one pair: the slice width the kernel derives must cover n with this many slices
+        const int slice = (n + slices - 1) / slices;
+        slices = (n + slice - 1) / slice;
+    }
     ROREG_REQUIRE(ws_floats >= (size_t)slices * m * k * 2, "roreg_topk_dot: workspace too small");
     float *pv = ws;
     int *pi = reinterpret_cast<int *>(ws + (size_t)slices * m * k);
     hipStream_t s = roreg::as_stream(stream);
-#define RM_TOPK(KK)                                                                                                      \
-    hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices), dim3(256), 0, s, A, m, B, n, slice, pv, pi);               \
-    hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gx), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
+    const int gm = (m + 255) / 256;
+#define RM_TOPK(KK)                                                                                                                  \
+    hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
+    hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
     if (k == 16) { RM_TOPK(16) } else if (k == 8) { RM_TOPK(8) } else { RM_TOPK(1) }
 #undef RM_TOPK
     ROREG_CHECK_LAUNCH("roreg_topk_dot");
@@ -473,7 +558,7 @@ extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, cons
     const dim3 g((L + 255) / 256, (Cout + oc - 1) / oc), t(256);
 #define RM_LIN(CI, CO)                                                                                      \
     if (Cin == CI && Cout == CO) {                                                                           \
-        hipLaunchKernelGGL((linear_kernel<CI, CO, false, false>), g, t, 0, s, x, L, W, b, nullptr, y, oc);  \
+        hipLaunchKernelGGL((linear_kernel<CI, CO, false, false>), g, t, 0, s, x, L, W, b, nullptr, y, oc, nullptr, 1, 1);  \
         ROREG_CHECK_LAUNCH("roreg_linear");                                                              \
         return 0;                                                                                        \
     }
@@ -484,27 +569,31 @@ extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, cons
     return 2;
 }
 
-extern "C" int roreg_instnorm_stats(const float *h, int L, int C, float eps, float *mean_rstd, double *ws /* 2*C*256 doubles */, void *stream) {
+extern "C" int roreg_instnorm_stats(const float *h, int L, int C, float eps, float *mean_rstd, double *ws /* n_seg*2*C*256 doubles */,
+                                    const int32_t *seg_off, int n_seg, int mult, void *stream) {
     ROREG_REQUIRE(h && mean_rstd && ws && L > 0, "roreg_instnorm_stats: bad arguments");
     ROREG_REQUIRE(C > 0 && C <= 128 && 256 % C == 0, "roreg_instnorm_stats: C must divide 256 (got %d)", C);
+    if (!seg_off) { n_seg = 1; mult = 1; }
+    ROREG_REQUIRE(n_seg > 0 && mult > 0, "roreg_instnorm_stats: bad segment description");
     hipStream_t s = roreg::as_stream(stream);
     const int lanes = 256 / C;
-    int nblk = (L + lanes - 1) / lanes;
-    if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL(in_stats_partial_kernel, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, h, L, C, ws);
-    hipLaunchKernelGGL(in_stats_final_kernel, dim3(C), dim3(256), 0, s, ws, nblk, L, C, eps, mean_rstd);
+    int nblk = 256;
+    if (!seg_off) { nblk = (L + lanes - 1) / lanes; if (nblk > 256) nblk = 256; }
+    hipLaunchKernelGGL(in_stats_partial_kernel, dim3(nblk, n_seg), dim3(256), 256 * 2 * sizeof(double), s, h, L, C, ws, seg_off, mult);
+    hipLaunchKernelGGL(in_stats_final_kernel, dim3(C, n_seg), dim3(256), 0, s, ws, L, C, eps, mean_rstd, seg_off, mult);
     ROREG_CHECK_LAUNCH("roreg_instnorm_stats");
     return 0;
 }
 
 extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y,
-                              void *stream) {
+                              const int32_t *seg_off, int n_seg, int mult, void *stream) {
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
+    if (!seg_off) { n_seg = 1; mult = 1; }
     hipStream_t s = roreg::as_stream(stream);
     const int oc = linear_ochunk(L, 32);
     const dim3 g((L + 255) / 256, (32 + oc - 1) / oc), t(256);
-    if (Cmid == 64) hipLaunchKernelGGL((linear_kernel<64, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc);
-    else if (Cmid == 128) hipLaunchKernelGGL((linear_kernel<128, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc);
+    if (Cmid == 64) hipLaunchKernelGGL((linear_kernel<64, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc, seg_off, n_seg, mult);
+    else if (Cmid == 128) hipLaunchKernelGGL((linear_kernel<128, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc, seg_off, n_seg, mult);
     else { roreg::set_error("roreg_mlp_tail: unsupported width %d", Cmid); return 2; }
     ROREG_CHECK_LAUNCH("roreg_mlp_tail");
     return 0;
@@ -522,6 +611,21 @@ extern "C" int roreg_knn_attention(const float *qp, const float *kp, const float
     return 0;
 }
 
+extern "C" int roreg_context_colmax(const float *R, int L, const int32_t *seg_off, int n_seg, int max_len, float *ctx_out, float *ws,
+                                    void *stream) {
+    ROREG_REQUIRE(R && ctx_out && ws && L > 0, "roreg_context_colmax: bad arguments");
+    if (!seg_off) { n_seg = 1; max_len = L; }
+    ROREG_REQUIRE(n_seg > 0 && max_len > 0, "roreg_context_colmax: bad segment description");
+    hipStream_t s = roreg::as_stream(stream);
+    const int nblk = max_len < 256 ? max_len : 256;
+    float *cmax = ws + (size_t)n_seg * 256 * 60;
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3(nblk, n_seg), dim3(256), 0, s, R, L, 60, ws, seg_off);
+    hipLaunchKernelGGL(colmax_final_kernel, dim3(60, n_seg), dim3(256), 0, s, ws, nblk, 60, cmax);
+    hipLaunchKernelGGL(context_kernel, dim3((L * 120 + 255) / 256), dim3(256), 0, s, R, cmax, L, ctx_out, seg_off, n_seg);
+    ROREG_CHECK_LAUNCH("roreg_context_colmax");
+    return 0;
+}
+
 extern "C" int roreg_rm_elementwise(int op, const float *a, const float *b, const float *c, const int64_t *idx, int L, int k, int C,
                                     float *out, float *ws, void *stream) {
     // op 0: l2-normalise rows of a [L,C]           op 1: column max of a [L,C] -> out [C] (ws: 256*C floats)
@@ -535,11 +639,11 @@ extern "C" int roreg_rm_elementwise(int op, const float *a, const float *b, cons
     case 1: {
         ROREG_REQUIRE(ws && C <= 256, "roreg_rm_elementwise: colmax needs a workspace");
         int nblk = L < 256 ? L : 256;
-        hipLaunchKernelGGL(colmax_partial_kernel, dim3(nblk), dim3(256), 0, s, a, L, C, ws);
+        hipLaunchKernelGGL(colmax_partial_kernel, dim3(nblk), dim3(256), 0, s, a, L, C, ws, (const int *)nullptr);
         hipLaunchKernelGGL(colmax_final_kernel, dim3(C), dim3(256), 0, s, ws, nblk, C, out);
         break;
     }
-    case 2: hipLaunchKernelGGL(context_kernel, dim3((L * 120 + 255) / 256), dim3(256), 0, s, a, b, L, out); break;
+    case 2: hipLaunchKernelGGL(context_kernel, dim3((L * 120 + 255) / 256), dim3(256), 0, s, a, b, L, out, (const int *)nullptr, 1); break;
     case 3: hipLaunchKernelGGL(knn_coor_kernel, dim3((L * k + 255) / 256), dim3(256), 0, s, a, idx, L, k, out); break;
     case 4: hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((size_t)L * k * C + 255) / 256)), dim3(256), 0, s, a, idx, (size_t)L * k, C, out); break;
     case 5: hipLaunchKernelGGL(value_input_kernel, dim3((unsigned)(((size_t)L * k * 96 + 255) / 256)), dim3(256), 0, s, a, b, idx, c, L, k, out); break;
@@ -570,27 +674,29 @@ extern "C" int roreg_sinkhorn(const float *src_final, int m, const float *tgt_fi
     ROREG_REQUIRE(reinterpret_cast<char *>(i1 + n) <= reinterpret_cast<char *>(ws + ws_floats), "roreg_sinkhorn: workspace too small");
     const float normc = -logf((float)(m + n));
     const unsigned gb = (unsigned)((tot + 255) / 256);
+    const OtBatch one = {nullptr, nullptr, 0, nullptr};
     {
         const int rpb = 32;
         hipLaunchKernelGGL(ot_build_kernel, dim3((n + 1 + 255) / 256, (m + 1 + rpb - 1) / rpb), dim3(256), 0, s, src_final, m, tgt_final, n,
-                           alpha, rpb, Z0, ldz);
+                           alpha, rpb, Z0, ldz, (const int *)nullptr, (const int *)nullptr, (size_t)0);
         hipLaunchKernelGGL(ot_build_kernel, dim3((m + 1 + 255) / 256, (n + 1 + rpb - 1) / rpb), dim3(256), 0, s, tgt_final, n, src_final, m,
-                           alpha, rpb, Z0T, ldt);
+                           alpha, rpb, Z0T, ldt, (const int *)nullptr, (const int *)nullptr, (size_t)0);
     }
     (void)hipMemsetAsync(u, 0, sizeof(float) * up, s);
     (void)hipMemsetAsync(v, 0, sizeof(float) * vp, s);
     const float ln_n = logf((float)n), ln_m = logf((float)m);
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(row_lse_kernel, dim3(m + 1), dim3(256), 0, s, Z0, m + 1, n + 1, ldz, v, normc, ln_n, u);
-        hipLaunchKernelGGL(row_lse_kernel, dim3(n + 1), dim3(256), 0, s, Z0T, n + 1, m + 1, ldt, u, normc, ln_m, v);
+        hipLaunchKernelGGL(row_lse_kernel, dim3((m + 4) / 4), dim3(256), 0, s, Z0, m + 1, n + 1, ldz, v, normc, ln_n, u, one);
+        hipLaunchKernelGGL(row_lse_kernel, dim3((n + 4) / 4), dim3(256), 0, s, Z0T, n + 1, m + 1, ldt, u, normc, ln_m, v, one);
     }
     hipLaunchKernelGGL(ot_final_kernel, dim3(gb), dim3(256), 0, s, Z0, ldz, m, n, u, v, normc, Z_out);
     if (matches0) {
         ROREG_REQUIRE(matches1 && mscores0 && mscores1, "roreg_sinkhorn: all four readout outputs are needed");
-        hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(m), dim3(256), 0, s, Z0, m + 1, n + 1, ldz, v, u, normc, i0, val0);
-        hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(n), dim3(256), 0, s, Z0T, n + 1, m + 1, ldt, u, v, normc, i1, val1);
+        hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(m), dim3(256), 0, s, Z0, m + 1, n + 1, ldz, v, u, normc, i0, val0, one);
+        hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(n), dim3(256), 0, s, Z0T, n + 1, m + 1, ldt, u, v, normc, i1, val1, one);
         const int mx = m > n ? m : n;
-        hipLaunchKernelGGL(ot_readout_kernel, dim3((mx + 255) / 256), dim3(256), 0, s, i0, val0, m, i1, n, matches0, matches1, mscores0, mscores1);
+        hipLaunchKernelGGL(ot_readout_kernel, dim3((mx + 255) / 256), dim3(256), 0, s, i0, val0, m, i1, n, matches0, matches1, mscores0, mscores1,
+                           (const int *)nullptr, (const int *)nullptr);
     }
     ROREG_CHECK_LAUNCH("roreg_sinkhorn");
     return 0;
@@ -598,4 +704,75 @@ extern "C" int roreg_sinkhorn(const float *src_final, int m, const float *tgt_fi
 
 extern "C" size_t roreg_sinkhorn_workspace_size(int m, int n) {
     return (size_t)(m + 1) * ((n + 4) & ~3) + (size_t)(n + 1) * ((m + 4) & ~3) + 5 * (size_t)(m + n + 8) + 32;
+}
+
+// ---- several pairs per launch --------------------------------------------------------------------------------
+// Workspace: per pair a slab [Z0 | Z0^T | u | v] sized for (max_m, max_n); then, concatenated over the pairs, the row/column arg-max
+// values (floats) and indices (int64), then the per-pair constants.
+static size_t ot_slab(int max_m, int max_n) {
+    const size_t ldz = (max_n + 4) & ~3, ldt = (max_m + 4) & ~3;
+    return (size_t)(max_m + 1) * ldz + (size_t)(max_n + 1) * ldt + ldt + ldz;
+}
+
+extern "C" size_t roreg_sinkhorn_batch_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n) {
+    return (size_t)n_seg * ot_slab(max_m, max_n) + 3 * (size_t)(total_m + total_n) + 64;
+}
+
+// Host helper: the per-pair constants of the two passes, [n_seg][2] (-log(m+n), log n) then [n_seg][2] (-log(m+n), log m), computed
+// with the same host logf calls as roreg_sinkhorn so that the batched passes are bitwise the one-pair ones.
+extern "C" int roreg_sinkhorn_batch_consts(const int32_t *seg_src_host, const int32_t *seg_tgt_host, int n_seg, float *consts_host) {
+    ROREG_REQUIRE(seg_src_host && seg_tgt_host && consts_host && n_seg > 0, "roreg_sinkhorn_batch_consts: bad arguments");
+    for (int p = 0; p < n_seg; ++p) {
+        const int m = seg_src_host[p + 1] - seg_src_host[p], n = seg_tgt_host[p + 1] - seg_tgt_host[p];
+        ROREG_REQUIRE(m > 0 && n > 0, "roreg_sinkhorn_batch_consts: pair %d is empty", p);
+        const float normc = -logf((float)(m + n));
+        consts_host[2 * p] = normc; consts_host[2 * p + 1] = logf((float)n);
+        consts_host[2 * n_seg + 2 * p] = normc; consts_host[2 * n_seg + 2 * p + 1] = logf((float)m);
+    }
+    return 0;
+}
+
+extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                                    const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                                    int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                                    void *stream) {
+    ROREG_REQUIRE(src_final && tgt_final && seg_src && seg_tgt && seg_src_host && seg_tgt_host && consts && n_seg > 0 && iters >= 0 && ws &&
+                      matches0 && matches1 && mscores0 && mscores1, "roreg_sinkhorn_batch: bad arguments");
+    int max_m = 0, max_n = 0;
+    for (int p = 0; p < n_seg; ++p) {
+        const int m = seg_src_host[p + 1] - seg_src_host[p], n = seg_tgt_host[p + 1] - seg_tgt_host[p];
+        ROREG_REQUIRE(m > 0 && n > 0, "roreg_sinkhorn_batch: pair %d is empty", p);
+        if (m > max_m) max_m = m;
+        if (n > max_n) max_n = n;
+    }
+    const long long tm = seg_src_host[n_seg], tn = seg_tgt_host[n_seg];
+    ROREG_REQUIRE(ws_floats >= roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, tm, tn), "roreg_sinkhorn_batch: workspace too small");
+    hipStream_t s = roreg::as_stream(stream);
+    const int ldz = (max_n + 4) & ~3, ldt = (max_m + 4) & ~3;
+    const size_t slab = ot_slab(max_m, max_n);
+    float *Z0 = ws, *Z0T = Z0 + (size_t)(max_m + 1) * ldz, *u = Z0T + (size_t)(max_n + 1) * ldt, *v = u + ldt;
+    float *tail = ws + (size_t)n_seg * slab;
+    float *val0 = tail, *val1 = val0 + tm;
+    const size_t off = ((reinterpret_cast<uintptr_t>(val1 + tn) + 7) & ~(uintptr_t)7) - reinterpret_cast<uintptr_t>(ws);
+    int64_t *i0 = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + off);
+    int64_t *i1 = i0 + tm;
+    ROREG_REQUIRE(reinterpret_cast<char *>(i1 + tn) <= reinterpret_cast<char *>(ws + ws_floats), "roreg_sinkhorn_batch: workspace too small");
+    const OtBatch rows = {seg_src, seg_tgt, slab, consts}, cols = {seg_tgt, seg_src, slab, consts + 2 * n_seg};
+    const int rpb = 32;
+    hipLaunchKernelGGL(ot_build_kernel, dim3((max_n + 1 + 255) / 256, (max_m + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, src_final, 0,
+                       tgt_final, 0, alpha, rpb, Z0, ldz, seg_src, seg_tgt, slab);
+    hipLaunchKernelGGL(ot_build_kernel, dim3((max_m + 1 + 255) / 256, (max_n + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, tgt_final, 0,
+                       src_final, 0, alpha, rpb, Z0T, ldt, seg_tgt, seg_src, slab);
+    for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(row_lse_kernel, dim3((max_m + 4) / 4, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, 0.f, 0.f, u, rows);
+        hipLaunchKernelGGL(row_lse_kernel, dim3((max_n + 4) / 4, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, 0.f, 0.f, v, cols);
+    }
+    hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
+    hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);
+    const int mx = max_m > max_n ? max_m : max_n;
+    hipLaunchKernelGGL(ot_readout_kernel, dim3((mx + 255) / 256, n_seg), dim3(256), 0, s, i0, val0, 0, i1, 0, matches0, matches1, mscores0,
+                       mscores1, seg_src, seg_tgt);
+    ROREG_CHECK_LAUNCH("roreg_sinkhorn_batch");
+    return 0;
 }

@@ -149,17 +149,6 @@ class RegistrationEngine:
             s0 = s0[0:keynum]; s1 = s1[0:keynum]
         return s0, s1
 
-    def _match_rm_issue(self, c0, c1, s0, s1):
-        """Enqueue the rotation-coherence matcher of one pair on the current stream; no host synchronisation.
-        The batch carries cloud 1 as feats0/keys0 and cloud 0 as feats1/keys1 (test/matcher.py:192-197)."""
-        d0 = torch.from_numpy(np.ascontiguousarray(s0, np.int64)).cuda(non_blocking=True)
-        d1 = torch.from_numpy(np.ascontiguousarray(s1, np.int64)).cuda(non_blocking=True)
-        batch = {'feats0': c1.eqv[d1][None], 'feats1': c0.eqv[d0][None],
-                 'keys0': c1.keys[d1].float()[None], 'keys1': c0.keys[d0].float()[None]}
-        with torch.no_grad():
-            r = self.rm(batch)
-        return r['matches0'][0], r['matching_scores0'][0]
-
     @staticmethod
     def _match_rm_finish(s0, s1, m0, sc0):
         """matches0 / matching_scores0 (host) -> (matches [M,2] int64 host in cloud coordinates, scores f32); test/matcher.py:198-206."""
@@ -168,23 +157,36 @@ class RegistrationEngine:
             return np.ones((1, 2), np.int64), np.ones(1, np.float32)
         return np.stack([np.asarray(s0, np.int64)[m0[valid]], np.asarray(s1, np.int64)[valid]], 1), sc0[valid]
 
-    def match_rm_many(self, jobs, n_streams=4):
+    def match_rm_many(self, jobs, max_points=80000):
         """Rotation-coherence matcher of several pairs: jobs [(c0, c1, s0, s1)] -> [(matches [M,2] int64 device, scores f32 host)].
-        One pair's kernels work on 2500 keypoints and leave most of the chip idle, so the pairs are issued round-robin on a few HIP
-        streams and run concurrently; one synchronisation, one download of the read-outs and one upload of the match lists per call."""
+        One pair's kernels work on 2500 keypoints and leave most of the chip idle (and cost ~450 launches), so the sampled points of
+        many pairs are stacked and the network runs ONCE per group of pairs with segmented per-pair operations (Match_ot.match_stacked;
+        bitwise the per-pair forward()); one synchronisation, one download of the read-outs and one upload of the match lists per call.
+        The batch carries cloud 1 as the source (feats0/keys0) and cloud 0 as the target (test/matcher.py:192-197)."""
         if not jobs:
             return []
-        main = torch.cuda.current_stream()
-        if getattr(self, '_rm_streams', None) is None or len(self._rm_streams) != n_streams:
-            self._rm_streams = [torch.cuda.Stream() for _ in range(n_streams)]
-        issued = []
-        for q, (c0, c1, s0, s1) in enumerate(jobs):
-            st = self._rm_streams[q % n_streams]
-            st.wait_stream(main)                                            # the clouds' features come from the main stream
-            with torch.cuda.stream(st):
-                issued.append(self._match_rm_issue(c0, c1, s0, s1))
-        for st in self._rm_streams:
-            main.wait_stream(st)
+        flat = np.concatenate([np.ascontiguousarray(x, np.int64) for _, _, s0, s1 in jobs for x in (s0, s1)])
+        flat_dev = torch.from_numpy(flat).cuda()                            # ONE upload of all sample lists
+        rows, o = [], 0
+        for _, _, s0, s1 in jobs:
+            rows.append((flat_dev[o:o + len(s0)], flat_dev[o + len(s0):o + len(s0) + len(s1)])); o += len(s0) + len(s1)
+        issued, i = [], 0
+        while i < len(jobs):
+            j, pts = i, 0
+            while j < len(jobs) and (j == i or pts + max(len(jobs[j][2]), len(jobs[j][3])) <= max_points):
+                pts += max(len(jobs[j][2]), len(jobs[j][3])); j += 1
+            seg_s = hip.Segments([len(jobs[q][3]) for q in range(i, j)]); seg_t = hip.Segments([len(jobs[q][2]) for q in range(i, j)])
+            se = torch.empty((seg_s.total, 32, 60), dtype=torch.float32, device='cuda'); te = torch.empty((seg_t.total, 32, 60), dtype=torch.float32, device='cuda')
+            sk = torch.empty((seg_s.total, 3), dtype=torch.float64, device='cuda'); tk = torch.empty((seg_t.total, 3), dtype=torch.float64, device='cuda')
+            for q in range(i, j):
+                c0, c1 = jobs[q][0], jobs[q][1]
+                d0, d1 = rows[q]
+                a, b = seg_s.host[q - i], seg_t.host[q - i]
+                torch.index_select(c1.eqv, 0, d1, out=se[a:a + d1.shape[0]]); torch.index_select(c1.keys, 0, d1, out=sk[a:a + d1.shape[0]])
+                torch.index_select(c0.eqv, 0, d0, out=te[b:b + d0.shape[0]]); torch.index_select(c0.keys, 0, d0, out=tk[b:b + d0.shape[0]])
+            with torch.no_grad():
+                issued += self.rm.match_stacked(se, te, sk.float(), tk.float(), seg_s, seg_t)
+            i = j
         m0_all = torch.cat([m for m, _ in issued]).cpu().numpy()            # the one sync of the matcher stage
         sc_all = torch.cat([s for _, s in issued]).cpu().numpy()
         out, o = [], 0
@@ -200,7 +202,7 @@ class RegistrationEngine:
     def match_rm(self, c0, c1, s0, s1):
         """Rotation-coherence matcher on the sampled keypoints (test/matcher.py:187-206) -> (matches [M,2] int64 device in cloud
         coordinates, scores float32 host)."""
-        return self.match_rm_many([(c0, c1, s0, s1)], n_streams=1)[0]
+        return self.match_rm_many([(c0, c1, s0, s1)])[0]
 
     def match_mutual(self, c0, c1, s0, s1):
         """-> (match buffer [m,2] int64 device, count int32[1] device); test/matcher.py:90-107."""

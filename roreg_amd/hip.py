@@ -66,10 +66,14 @@ PROTOTYPES = {
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'roreg_topk_dot_workspace_size': (c_size_t, [c_int, c_int, c_int]),
-    'roreg_topk_dot': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    'roreg_topk_dot': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P, _P, c_int, c_int, c_int, _P]),
+    'roreg_context_colmax': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P]),
+    'roreg_sinkhorn_batch_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong]),
+    'roreg_sinkhorn_batch_consts': (c_int, [_P, _P, c_int, _P]),
+    'roreg_sinkhorn_batch': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_linear': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
-    'roreg_instnorm_stats': (c_int, [_P, c_int, c_int, c_float, _P, _P, _P]),
-    'roreg_mlp_tail': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P]),
+    'roreg_instnorm_stats': (c_int, [_P, c_int, c_int, c_float, _P, _P, _P, c_int, c_int, _P]),
+    'roreg_mlp_tail': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'roreg_knn_attention': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'roreg_rm_elementwise': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'roreg_sinkhorn_workspace_size': (c_size_t, [c_int, c_int]),
@@ -566,13 +570,32 @@ def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpo
     return (cor, idx) if want_idx else cor
 
 
-def topk_dot(A, B, k, want_val=False):
+class Segments:
+    """Row offsets of several pairs' point lists concatenated into one tensor (the matcher's per-pair operations stay inside their
+    pair; see include/roreg_hip.h).  lengths: points per pair."""
+
+    def __init__(self, lengths):
+        lengths = np.asarray(lengths, np.int64)
+        self.host = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+        self.dev = torch.from_numpy(self.host).cuda()
+        self.n = int(lengths.shape[0]); self.max = int(lengths.max()); self.min = int(lengths.min()); self.total = int(self.host[-1])
+
+
+def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
+    """k best rows of B per row of A; with segments, inside the row's pair (indices are global rows of B)."""
     m, n = A.shape[0], B.shape[0]
     idx = torch.empty((m, k), dtype=torch.int64, device=A.device)
     val = torch.empty((m, k), dtype=torch.float32, device=A.device) if want_val else None
     wsn = lib().roreg_topk_dot_workspace_size(m, n, k)
     ws = torch.empty(wsn, dtype=torch.float32, device=A.device)
-    _check(lib().roreg_topk_dot(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, _stream()), 'roreg_topk_dot')
+    if segA is not None:
+        if segB.min < k:
+            raise HipError(f'topk_dot: a pair has fewer than k={k} targets')
+        seg = (_ptr(segA.dev, torch.int32), _ptr(segB.dev, torch.int32), segA.n, segA.max, segB.max)
+    else:
+        seg = (None, None, 1, m, n)
+    _check(lib().roreg_topk_dot(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, *seg, _stream()),
+           'roreg_topk_dot')
     return (idx, val) if want_val else idx
 
 
@@ -585,16 +608,22 @@ def linear(x, W, b):
     return y
 
 
-def mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=1e-5):
-    """mlp_2layer / Contextnorm: conv -> InstanceNorm -> ReLU -> conv, plus the residual conv.  x [L,Cin] -> [L,32]."""
+def mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=1e-5, seg=None):
+    """mlp_2layer / Contextnorm: conv -> InstanceNorm -> ReLU -> conv, plus the residual conv.  x [L,Cin] -> [L,32].
+    seg (Segments of the points; L = mult * seg.total rows): the InstanceNorm statistics are per pair."""
     L = x.shape[0]
     h = linear(x, W1, b1)
     C = h.shape[1]
-    stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * C * 256, dtype=torch.float64, device=x.device)
-    _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), _stream()), 'roreg_instnorm_stats')
+    n_seg = seg.n if seg is not None else 1
+    mult = L // seg.total if seg is not None else 1
+    if seg is not None and mult * seg.total != L:
+        raise HipError('mlp_instnorm: rows are not a multiple of the segmented points')
+    sg = (_ptr(seg.dev, torch.int32) if seg is not None else None, n_seg, mult)
+    stats = torch.empty(n_seg * 2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(n_seg * 2 * C * 256, dtype=torch.float64, device=x.device)
+    _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), *sg, _stream()), 'roreg_instnorm_stats')
     y = linear(x, Wr, br)
-    _check(lib().roreg_mlp_tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), _stream()), 'roreg_mlp_tail')
+    _check(lib().roreg_mlp_tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), *sg, _stream()), 'roreg_mlp_tail')
     return y
 
 
@@ -617,12 +646,15 @@ def l2_normalize_rows(x):
     return _rm_op(0, x, torch.empty_like(x), L=L, C=C)
 
 
-def context_with_colmax(R):
-    """[R | max over points of R, broadcast]  (rot_coh_match.py:201)  [m,60] -> [m,120]."""
+def context_with_colmax(R, seg=None):
+    """[R | max over the pair's points of R, broadcast]  (rot_coh_match.py:201)  [m,60] -> [m,120]."""
     m = R.shape[0]
-    ws = torch.empty(256 * 60, dtype=torch.float32, device=R.device)
-    cmax = _rm_op(1, R, torch.empty(60, dtype=torch.float32, device=R.device), L=m, C=60, ws=ws)
-    return _rm_op(2, R, torch.empty((m, 120), dtype=torch.float32, device=R.device), b=cmax, L=m)
+    n_seg = seg.n if seg is not None else 1
+    ws = torch.empty(n_seg * 257 * 60, dtype=torch.float32, device=R.device)
+    ctx = torch.empty((m, 120), dtype=torch.float32, device=R.device)
+    _check(lib().roreg_context_colmax(_ptr(R, torch.float32), m, _ptr(seg.dev, torch.int32) if seg is not None else None, n_seg,
+                                      seg.max if seg is not None else m, _ptr(ctx), _ptr(ws), _stream()), 'roreg_context_colmax')
+    return ctx
 
 
 def knn_coor(coor, idx):
@@ -657,6 +689,25 @@ def sinkhorn(src_final, tgt_final, alpha, iters):
     _check(lib().roreg_sinkhorn(_ptr(src_final, torch.float32), m, _ptr(tgt_final, torch.float32), n, float(alpha), int(iters), _ptr(Z),
                                 _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, _stream()), 'roreg_sinkhorn')
     return Z, m0, m1, s0, s1
+
+
+def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters):
+    """Sinkhorn + mutual read-out of several pairs (descriptors concatenated by seg_src / seg_tgt) ->
+    (matches0 [sum m] local indices or -1, matches1 [sum n], mscores0, mscores1)."""
+    dev = src_final.device
+    tm, tn = seg_src.total, seg_tgt.total
+    m0 = torch.empty(tm, dtype=torch.int64, device=dev); m1 = torch.empty(tn, dtype=torch.int64, device=dev)
+    s0 = torch.empty(tm, dtype=torch.float32, device=dev); s1 = torch.empty(tn, dtype=torch.float32, device=dev)
+    consts = np.empty(4 * seg_src.n, np.float32)
+    _check(lib().roreg_sinkhorn_batch_consts(seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, seg_src.n, consts.ctypes.data), 'roreg_sinkhorn_batch_consts')
+    cdev = torch.from_numpy(consts).to(dev)
+    wsn = lib().roreg_sinkhorn_batch_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
+    ws = torch.empty(wsn, dtype=torch.float32, device=dev)
+    _check(lib().roreg_sinkhorn_batch(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
+                                      _ptr(seg_tgt.dev, torch.int32), seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, _ptr(cdev), seg_src.n,
+                                      float(alpha), int(iters), _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, _stream()),
+           'roreg_sinkhorn_batch')
+    return m0, m1, s0, s1
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -44,12 +44,13 @@ class mlp_2layer(nn.Module):
         if self.res_sign:
             self.res = nn.Conv2d(in_dim, out_dim, 1, 1)
 
-    def forward(self, x):
-        """x [L,Cin] (every row is one spatial position of the reference's [1,Cin,w,h] map) -> [L,out]."""
+    def forward(self, x, seg=None):
+        """x [L,Cin] (every row is one spatial position of the reference's [1,Cin,w,h] map) -> [L,out].
+        seg: hip.Segments when x stacks several pairs (InstanceNorm statistics are per pair)."""
         if not self.res_sign:
             raise NotImplementedError('mlp_2layer without a residual conv is not used by Match_ot')
         W1, b1 = _wb(self.net[0]); W2, b2 = _wb(self.net[3]); Wr, br = _wb(self.res)
-        return hip.mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=self.net[1].eps)
+        return hip.mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=self.net[1].eps, seg=seg)
 
 
 class Contextnorm(mlp_2layer):
@@ -82,12 +83,13 @@ class Cross_attention_block(nn.Module):
         self.cross_attn = MultiHeadedAttention(4, 32)
         self.merge = mlp_2layer(32 * 3, 64, 32)
 
-    def forward(self, source, target, source_eqv, target_eqv, featinv):
-        """source [m,32], target [n,32], *_eqv [.,32,60], featinv [m,32] -> (feat [m,32], R_indicator [m,60])."""
-        knn = hip.topk_dot(source, target, self.k)                         # k best targets per source point
+    def forward(self, source, target, source_eqv, target_eqv, featinv, seg_s=None, seg_t=None):
+        """source [m,32], target [n,32], *_eqv [.,32,60], featinv [m,32] -> (feat [m,32], R_indicator [m,60]).
+        seg_s / seg_t: hip.Segments of the source / target rows when several pairs are stacked."""
+        knn = hip.topk_dot(source, target, self.k, segA=seg_s, segB=seg_t)  # k best targets (of its own pair) per source point
         nn_ind = knn[:, 0].contiguous()
         att = self.cross_attn(source, target, target, knn, self.k, True, True)
-        feat = self.merge(hip.concat_rows(featinv, source, att))
+        feat = self.merge(hip.concat_rows(featinv, source, att), seg=seg_s)
         if self.s2t:    # R[h] = sum_f sum_g src[f,P[g,h]] * tgt_nn[f,g]
             R = hip.group_corr(source_eqv, target_eqv, perm_rows=None, bcast_rows=nn_ind, transpose=True)
         else:           # R[h] = sum_f sum_g tgt_nn[f,P[g,h]] * src[f,g]
@@ -106,17 +108,17 @@ class Self_attention_block(nn.Module):
         self.val_en = mlp_2layer(32 * 3, 64, 32)
         self.merge = mlp_2layer(32 * 3, 64, 32)
 
-    def forward(self, feat, coor, R_indicator, featinv):
+    def forward(self, feat, coor, R_indicator, featinv, seg=None):
         """feat [m,32], coor [m,3] (already / coor_norm_step), R_indicator [m,60], featinv [m,32] -> [m,32]."""
-        knn = hip.topk_dot(feat, feat, self.k)
-        pos = self.pos_en(hip.knn_coor(coor, knn))                          # [m*k,32]
-        conf = self.ambiguity(hip.context_with_colmax(R_indicator))         # [m,32]
+        knn = hip.topk_dot(feat, feat, self.k, segA=seg, segB=seg)
+        pos = self.pos_en(hip.knn_coor(coor, knn), seg=seg)                 # [m*k,32]
+        conf = self.ambiguity(hip.context_with_colmax(R_indicator, seg), seg=seg)   # [m,32]
         pos = hip.l2_normalize_rows(pos)
         feat_n = hip.l2_normalize_rows(feat)                                # knn_fea / ||knn_fea|| == gather of normalised rows
         conf = hip.l2_normalize_rows(conf)
-        value = self.val_en(hip.value_input(pos, feat_n, conf, knn))        # [m*k,32]
+        value = self.val_en(hip.value_input(pos, feat_n, conf, knn), seg=seg)   # [m*k,32]
         att = self.self_attn(feat, feat_n, value, knn, self.k, True, False)
-        return self.merge(hip.concat_rows(featinv, feat, att))
+        return self.merge(hip.concat_rows(featinv, feat, att), seg=seg)
 
 
 class Merge_info_block(nn.Module):
@@ -127,11 +129,11 @@ class Merge_info_block(nn.Module):
         self.cross_graph_t2s = Cross_attention_block(cross_k, s2t=False)
         self.self_graph_t = Self_attention_block(self_k, source=False)
 
-    def forward(self, source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv):
-        source_s2t, R_ind_s2t = self.cross_graph_s2t(source, target, source_eqv, target_eqv, source_inv)
-        eh_source = self.self_graph_s(source_s2t, source_coor, R_ind_s2t, source_inv)
-        target_t2s, R_ind_t2s = self.cross_graph_t2s(target, source, target_eqv, source_eqv, target_inv)
-        eh_target = self.self_graph_t(target_t2s, target_coor, R_ind_t2s, target_inv)
+    def forward(self, source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s=None, seg_t=None):
+        source_s2t, R_ind_s2t = self.cross_graph_s2t(source, target, source_eqv, target_eqv, source_inv, seg_s, seg_t)
+        eh_source = self.self_graph_s(source_s2t, source_coor, R_ind_s2t, source_inv, seg_s)
+        target_t2s, R_ind_t2s = self.cross_graph_t2s(target, source, target_eqv, source_eqv, target_inv, seg_t, seg_s)
+        eh_target = self.self_graph_t(target_t2s, target_coor, R_ind_t2s, target_inv, seg_t)
         return eh_source, eh_target
 
 
@@ -140,11 +142,11 @@ class Graph_enhance_net(nn.Module):
         super().__init__()
         self.merge_blocks = nn.ModuleList([Merge_info_block(16, 16), Merge_info_block(8, 8)])
 
-    def forward(self, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv):
+    def forward(self, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s=None, seg_t=None):
         sources, targets = [], []
         source, target = source_inv, target_inv                             # mean over g (rot_coh_match.py:266-267)
         for layer in self.merge_blocks:
-            source, target = layer(source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv)
+            source, target = layer(source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t)
             sources.append(source); targets.append(target)
         return sources, targets
 
@@ -165,6 +167,36 @@ class Match_ot(nn.Module):
         self.final_mlp = mlp_2layer(64, 64, 32)
         self.ot_layer = sinkhorn_ot(0.2, 100)
 
+    def _alpha_value(self):
+        bs = self.ot_layer.bin_score
+        if getattr(self, '_alpha', None) is None or self._alpha[0] != (bs.data_ptr(), bs._version):   # one download per weight load, not per pair
+            object.__setattr__(self, '_alpha', ((bs.data_ptr(), bs._version), float(bs.detach().cpu())))
+        return self._alpha[1]
+
+    def match_many(self, pairs):
+        """The matcher on several pairs in ONE pass of the network: pairs = [(feats0 [m,32,60], feats1 [n,32,60], keys0 [m,3],
+        keys1 [n,3])] device float32 tensors (feats0/keys0 = the `source` side of forward()).
+        -> [(matches0 [m] int64 (-1 = unmatched), matching_scores0 [m] f32)] device views."""
+        seg_s = hip.Segments([p[0].shape[0] for p in pairs]); seg_t = hip.Segments([p[1].shape[0] for p in pairs])
+        return self.match_stacked(torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs]), torch.cat([p[2] for p in pairs]),
+                                  torch.cat([p[3] for p in pairs]), seg_s, seg_t)
+
+    def match_stacked(self, source_eqv, target_eqv, source_keys, target_keys, seg_s, seg_t):
+        """match_many on already stacked tensors: the pairs' points are concatenated (hip.Segments seg_s / seg_t give the row ranges);
+        every per-pair operation of the graph (neighbour search, InstanceNorm statistics, the context maximum, Sinkhorn) is
+        segmented, with the arithmetic of forward() bit for bit."""
+        source_eqv = source_eqv.contiguous(); target_eqv = target_eqv.contiguous()
+        source_coor = (source_keys / self.coor_norm_step).contiguous()
+        target_coor = (target_keys / self.coor_norm_step).contiguous()
+        source_inv = hip.mean_over_group(source_eqv)
+        target_inv = hip.mean_over_group(target_eqv)
+        sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t)
+        source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]), seg=seg_s)
+        target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]), seg=seg_t)
+        m0, _, s0, _ = hip.sinkhorn_batch(source_final, target_final, seg_s, seg_t, self._alpha_value(), self.ot_layer.iters)
+        o = seg_s.host
+        return [(m0[o[i]:o[i + 1]], s0[o[i]:o[i + 1]]) for i in range(seg_s.n)]
+
     def forward(self, batch):
         dev = 'cuda'
         source_eqv = batch['feats0'][0].to(dev, torch.float32).contiguous()            # [m,32,60]
@@ -176,10 +208,7 @@ class Match_ot(nn.Module):
         sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv)
         source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]))
         target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]))
-        bs = self.ot_layer.bin_score
-        if getattr(self, '_alpha', None) is None or self._alpha[0] != (bs.data_ptr(), bs._version):   # one download per weight load, not per pair
-            object.__setattr__(self, '_alpha', ((bs.data_ptr(), bs._version), float(bs.detach().cpu())))
-        alpha = self._alpha[1]
+        alpha = self._alpha_value()
         Z, m0, m1, s0, s1 = hip.sinkhorn(source_final, target_final, alpha, self.ot_layer.iters)
         out = _MatchResult({
             'scores': Z[None], 'matches0': m0[None], 'matches1': m1[None], 'matching_scores0': s0[None], 'matching_scores1': s1[None],

@@ -113,6 +113,29 @@ def test_match_ot_forward_vs_reference_golden(rm):
     assert np.abs(out['scores_other'].cpu().numpy() - z['out_scores_other']).max() < 1e-4
 
 
+def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm):
+    """Several ragged pairs through ONE pass of the network (segmented neighbour search, InstanceNorm statistics, context maximum,
+    Sinkhorn) against forward() pair by pair: bit-identical read-outs.  The golden pair is one of them."""
+    net, sd = rm
+    z = load_golden('match_ot')
+    rng = np.random.default_rng(11)
+    pairs = [(cu(z['feats0'][0]), cu(z['feats1'][0]), cu(z['keys0'][0]), cu(z['keys1'][0]))]
+    for m, n in [(300, 257), (64, 190), (513, 512)]:
+        f0 = rng.standard_normal((m, 32, 60)).astype(np.float32); f0 /= np.linalg.norm(f0, axis=1, keepdims=True)
+        perm = rng.permutation(m)[:n] if n <= m else rng.integers(0, m, n)
+        f1 = (f0[perm] + 0.05 * rng.standard_normal((n, 32, 60))).astype(np.float32)
+        k0 = rng.uniform(0, 3, (m, 3)).astype(np.float32); k1 = (k0[perm] + 0.01 * rng.standard_normal((n, 3))).astype(np.float32)
+        pairs.append((cu(f0), cu(f1), cu(k0), cu(k1)))
+    with torch.no_grad():
+        got = net.match_many(pairs)
+        for (f0, f1, k0, k1), (m0, s0) in zip(pairs, got):
+            want = net({'feats0': f0[None], 'feats1': f1[None], 'keys0': k0[None], 'keys1': k1[None]})
+            assert torch.equal(m0, want['matches0'][0])
+            assert torch.equal(s0, want['matching_scores0'][0])
+    assert np.array_equal(got[0][0].cpu().numpy(), z['out_matches0'][0])
+    assert int((got[1][0] >= 0).sum()) > 20                      # the synthetic pairs do produce matches
+
+
 def test_stage_yoho_mat_and_yohoo_with_rm_scores(tmp_path):
     """--RD --RM --ET yohoo pipeline golden: matcher output (matches + float32 scores) and the RM branch of yohoo_ransac."""
     from test_hip_pipeline import _setup, _put_yoho
