@@ -59,6 +59,7 @@ class RegistrationEngine:
         self.rd = rd_net            # detector_eqv_test (needed when cfg.RD)
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
+        self.rm_max_points = 80000  # points per side stacked into one pass of the rotation-coherence matcher (32 pairs at keynum 2500)
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
 
     def _mark(self, name, t0):
@@ -157,7 +158,7 @@ class RegistrationEngine:
             return np.ones((1, 2), np.int64), np.ones(1, np.float32)
         return np.stack([np.asarray(s0, np.int64)[m0[valid]], np.asarray(s1, np.int64)[valid]], 1), sc0[valid]
 
-    def match_rm_many(self, jobs, max_points=80000):
+    def match_rm_many(self, jobs, max_points=None):
         """Rotation-coherence matcher of several pairs: jobs [(c0, c1, s0, s1)] -> [(matches [M,2] int64 device, scores f32 host)].
         One pair's kernels work on 2500 keypoints and leave most of the chip idle (and cost ~450 launches), so the sampled points of
         many pairs are stacked and the network runs ONCE per group of pairs with segmented per-pair operations (Match_ot.match_stacked;
@@ -165,6 +166,7 @@ class RegistrationEngine:
         The batch carries cloud 1 as the source (feats0/keys0) and cloud 0 as the target (test/matcher.py:192-197)."""
         if not jobs:
             return []
+        max_points = self.rm_max_points if max_points is None else max_points
         flat = np.concatenate([np.ascontiguousarray(x, np.int64) for _, _, s0, s1 in jobs for x in (s0, s1)])
         flat_dev = torch.from_numpy(flat).cuda()                            # ONE upload of all sample lists
         rows, o = [], 0
