@@ -127,6 +127,67 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
     }
 }
 
+// The same layer for many rows (several pairs stacked: L >= 65536 and every workgroup owns all output channels): the one-thread-per-row
+// form reads and writes rows at a stride of CIN / COUT floats per lane, which the memory pipeline serves line by line.  Here the
+// workgroup's 256 x CIN input tile and 256 x 32 output tiles go through LDS (pitch 33: conflict-free for the row-per-lane accesses) so
+// that every global access is a run of 128 contiguous bytes per row; the arithmetic (one fmaf chain per output, c ascending, starting
+// from the bias) is the per-row kernel's, bit for bit.
+template <int CIN, int COUT, bool NORM, bool ACCUM>
+__global__ __launch_bounds__(256) void linear_tiled_kernel(const float *__restrict__ x, int L, const float *__restrict__ W,
+                                                           const float *__restrict__ b, const float *__restrict__ mean_rstd,
+                                                           float *__restrict__ y, const int *__restrict__ seg_off, int n_seg, int mult) {
+    static_assert(CIN % 4 == 0 && COUT % 32 == 0, "linear_tiled_kernel: shapes");
+    __shared__ float st[256 * 33];
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * 256;
+    const int p = p0 + tid, pp = p < L ? p : L - 1;
+    if (NORM && seg_off) mean_rstd += (size_t)seg_of(seg_off, n_seg, pp / mult) * 2 * CIN;
+    float xi[CIN];
+#pragma unroll
+    for (int ch = 0; ch < CIN; ch += 32) {
+        const int w = CIN - ch < 32 ? CIN - ch : 32;         // floats of this chunk per row (multiple of 4)
+        const int w4 = w / 4;
+        for (int f = tid; f < 256 * w4; f += 256) {
+            const int row = f / w4, c4 = f - row * w4;
+            const int pr = p0 + row < L ? p0 + row : L - 1;
+            const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)pr * CIN + ch + c4 * 4);
+            float *d = st + row * 33 + c4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (ch + c < CIN) {
+                float v = st[tid * 33 + c];
+                if (NORM) v = fmaxf((v - mean_rstd[ch + c]) * mean_rstd[CIN + ch + c], 0.f);
+                xi[ch + c] = v;
+            }
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int o0 = 0; o0 < COUT; o0 += 32) {
+        float acc[32];
+#pragma unroll
+        for (int oo = 0; oo < 32; ++oo) {
+            float a = b[o0 + oo];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) a = fmaf(xi[c], W[(o0 + oo) * CIN + c], a);
+            acc[oo] = a;
+        }
+#pragma unroll
+        for (int oo = 0; oo < 32; ++oo) st[tid * 33 + oo] = acc[oo];
+        __syncthreads();
+        for (int f = tid; f < 256 * 32; f += 256) {
+            const int row = f >> 5, o = f & 31;
+            if (p0 + row < L) {
+                float *yo = y + (size_t)(p0 + row) * COUT + o0 + o;
+                *yo = ACCUM ? *yo + st[row * 33 + o] : st[row * 33 + o];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline int linear_ochunk(int L, int Cout) {
     int chunk = Cout;
     while (chunk > 4 && (long long)L * (Cout / chunk) < 65536) chunk /= 2;
@@ -253,6 +314,31 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restric
     for (int c = 0; c < C; ++c) { const float v = x[(size_t)p * C + c]; s = fmaf(v, v, s); }
     const float r = sqrtf(s);
     for (int c = 0; c < C; ++c) y[(size_t)p * C + c] = x[(size_t)p * C + c] / r;
+}
+
+// l2norm_rows_kernel for 32-channel rows through an LDS tile (coalesced 128-byte rows in and out, the same sequential sum per row)
+__global__ __launch_bounds__(256) void l2norm_rows32_kernel(const float *__restrict__ x, int L, float *__restrict__ y) {
+    __shared__ float st[256 * 33];
+    const int tid = threadIdx.x, p0 = blockIdx.x * 256;
+    for (int f = tid; f < 256 * 8; f += 256) {
+        const int row = f >> 3, c4 = f & 7;
+        const int pr = p0 + row < L ? p0 + row : L - 1;
+        const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)pr * 32 + c4 * 4);
+        float *d = st + row * 33 + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    float v[32], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { v[c] = st[tid * 33 + c]; s = fmaf(v[c], v[c], s); }
+    const float r = sqrtf(s);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) st[tid * 33 + c] = v[c] / r;
+    __syncthreads();
+    for (int f = tid; f < 256 * 32; f += 256) {
+        const int row = f >> 5, c = f & 31;
+        if (p0 + row < L) y[(size_t)(p0 + row) * 32 + c] = st[row * 33 + c];
+    }
 }
 
 __global__ __launch_bounds__(256) void colmax_partial_kernel(const float *__restrict__ x, int L, int C, float *__restrict__ part,
@@ -556,6 +642,15 @@ extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, cons
     hipStream_t s = roreg::as_stream(stream);
     const int oc = linear_ochunk(L, Cout);
     const dim3 g((L + 255) / 256, (Cout + oc - 1) / oc), t(256);
+#define RM_LIN_T(CI, CO)                                                                                                         \
+    if (Cin == CI && Cout == CO && oc == Cout) {                                                                                 \
+        hipLaunchKernelGGL((linear_tiled_kernel<CI, CO, false, false>), dim3((L + 255) / 256), t, 0, s, x, L, W, b, nullptr, y,  \
+                           nullptr, 1, 1);                                                                                       \
+        ROREG_CHECK_LAUNCH("roreg_linear");                                                                                      \
+        return 0;                                                                                                                \
+    }
+    RM_LIN_T(32, 32) RM_LIN_T(96, 64) RM_LIN_T(120, 128) RM_LIN_T(64, 64) RM_LIN_T(96, 32) RM_LIN_T(120, 32) RM_LIN_T(64, 32)
+#undef RM_LIN_T
 #define RM_LIN(CI, CO)                                                                                      \
     if (Cin == CI && Cout == CO) {                                                                           \
         hipLaunchKernelGGL((linear_kernel<CI, CO, false, false>), g, t, 0, s, x, L, W, b, nullptr, y, oc, nullptr, 1, 1);  \
@@ -592,7 +687,9 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
     hipStream_t s = roreg::as_stream(stream);
     const int oc = linear_ochunk(L, 32);
     const dim3 g((L + 255) / 256, (32 + oc - 1) / oc), t(256);
-    if (Cmid == 64) hipLaunchKernelGGL((linear_kernel<64, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc, seg_off, n_seg, mult);
+    if (oc == 32 && Cmid == 64) hipLaunchKernelGGL((linear_tiled_kernel<64, 32, true, true>), dim3((L + 255) / 256), t, 0, s, h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult);
+    else if (oc == 32 && Cmid == 128) hipLaunchKernelGGL((linear_tiled_kernel<128, 32, true, true>), dim3((L + 255) / 256), t, 0, s, h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult);
+    else if (Cmid == 64) hipLaunchKernelGGL((linear_kernel<64, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc, seg_off, n_seg, mult);
     else if (Cmid == 128) hipLaunchKernelGGL((linear_kernel<128, 32, true, true>), g, t, 0, s, h, L, W2, b2, mean_rstd, y, oc, seg_off, n_seg, mult);
     else { roreg::set_error("roreg_mlp_tail: unsupported width %d", Cmid); return 2; }
     ROREG_CHECK_LAUNCH("roreg_mlp_tail");
@@ -635,7 +732,10 @@ extern "C" int roreg_rm_elementwise(int op, const float *a, const float *b, cons
     hipStream_t s = roreg::as_stream(stream);
     ROREG_REQUIRE(a && out && L > 0, "roreg_rm_elementwise: bad arguments");
     switch (op) {
-    case 0: hipLaunchKernelGGL(l2norm_rows_kernel, dim3((L + 255) / 256), dim3(256), 0, s, a, L, C, out); break;
+    case 0:
+        if (C == 32) hipLaunchKernelGGL(l2norm_rows32_kernel, dim3((L + 255) / 256), dim3(256), 0, s, a, L, out);
+        else hipLaunchKernelGGL(l2norm_rows_kernel, dim3((L + 255) / 256), dim3(256), 0, s, a, L, C, out);
+        break;
     case 1: {
         ROREG_REQUIRE(ws && C <= 256, "roreg_rm_elementwise: colmax needs a workspace");
         int nblk = L < 256 ? L : 256;

@@ -81,6 +81,33 @@ def test_mlp_instnorm_and_attention(rm):
     assert np.abs(got - want).max() < 1e-4
 
 
+def test_many_row_layers_equal_the_per_row_kernels(rm):
+    """At >= 65536 rows (several pairs stacked) the 1x1 layers and the row normalisation go through LDS tiles for coalesced rows;
+    same fmaf chains, so the result is bitwise that of the one-thread-per-row kernels the short calls use."""
+    from roreg_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(3)
+    L = 70001
+    for cin, cout in [(32, 32), (96, 64), (120, 128), (64, 64), (96, 32), (120, 32), (64, 32)]:
+        x = torch.randn((L, cin), device='cuda', generator=g); W = torch.randn((cout, cin), device='cuda', generator=g) * 0.2
+        b = torch.randn(cout, device='cuda', generator=g)
+        big = hip.linear(x, W, b)
+        small = torch.cat([hip.linear(x[i:i + 9000].contiguous(), W, b) for i in range(0, L, 9000)])
+        assert torch.equal(big, small), (cin, cout)
+        ref = x.double() @ W.double().t() + b.double()
+        assert (big.double() - ref).abs().max() < 1e-4
+    x = torch.randn((L, 32), device='cuda', generator=g)
+    assert torch.equal(hip.l2_normalize_rows(x), torch.cat([hip.l2_normalize_rows(x[i:i + 9000].contiguous()) for i in range(0, L, 9000)]))
+    # mlp_2layer with per-pair statistics: 8 pairs of 9000 rows stacked == pair by pair
+    net, sd = rm
+    mlp = net.final_mlp
+    x = torch.randn((72000, 64), device='cuda', generator=g)
+    seg = hip.Segments([9000] * 8)
+    with torch.no_grad():
+        big = mlp(x, seg=seg)
+        small = torch.cat([mlp(x[i:i + 9000].contiguous()) for i in range(0, 72000, 9000)])
+    assert torch.equal(big, small)
+
+
 def test_sinkhorn_and_readout():
     from roreg_amd import hip
     rng = np.random.default_rng(7)
