@@ -136,6 +136,36 @@ class yoho_mat():
         datasetname = scene_feature_name(dataset)
         Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
         print(f'Matching the keypoints with rotation coherence matcher on {dataset.name}')
+        # The reference runs the network pair by pair (matcher.py:187-206); one pair's 2500 points leave most of the chip idle, so the
+        # sampled points of a group of pairs are stacked and go through the network in one pass with segmented per-pair operations
+        # (Match_ot.match_many: bitwise the per-pair forward).  Sampling order (and its generator calls) is the reference's.
+        self.network.eval()
+        group, pend = int(getattr(self.cfg, 'rm_group', 16)), []
+
+        def flush():
+            if not pend:
+                return
+            with torch.no_grad():
+                outs = self.network.match_many([q[2] for q in pend])
+            m0_all = torch.cat([m for m, _ in outs]).cpu().numpy(); sc_all = torch.cat([x for _, x in outs]).cpu().numpy()
+            o = 0
+            for (id0, id1, _, sample0, sample1), (m, _) in zip(pend, outs):
+                n = int(m.shape[0])
+                matches0, sc = m0_all[o:o + n], sc_all[o:o + n]; o += n
+                valid = np.where(matches0 != -1)[0]
+                if valid.shape[0] < 3:
+                    # the reference crashes here (np.ones(1,2) is a TypeError, matcher.py:200-202); documented
+                    # divergence: emit the single dummy correspondence it evidently intended
+                    matches = np.ones((1, 2), np.int64)
+                    scores = np.ones(1, np.float32)
+                else:
+                    matches = np.stack([valid, matches0[valid]], 1)
+                    scores = sc[valid]
+                matches_in_former = np.concatenate([sample0[matches[:, 1]][:, None], sample1[matches[:, 0]][:, None]], axis=1)
+                np.save(f'{Save_dir}/{id0}-{id1}.npy', matches_in_former)
+                np.save(f'{Save_score_dir}/{id0}-{id1}.npy', scores)
+            pend.clear()
+
         for pair in tqdm.tqdm(dataset.pair_ids):
             id0, id1 = pair
             feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')
@@ -145,16 +175,9 @@ class yoho_mat():
             s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
             keys0 = dataset.get_kps(id0)[sample0]
             keys1 = dataset.get_kps(id1)[sample1]
-            # NB the batch carries pc1 as 'feats0/keys0' and pc0 as 'feats1/keys1' (matcher.py:192-197)
-            batch = {'feats0': feats1[s1][None], 'feats1': feats0[s0][None],
-                     'keys0': torch.from_numpy(keys1[None, :, :].astype(np.float32)),
-                     'keys1': torch.from_numpy(keys0[None, :, :].astype(np.float32))}
-            matches, scores, scores1, scores0 = self.get_ot_match(batch)
-            if matches is None:
-                # the reference crashes here (np.ones(1,2) is a TypeError, matcher.py:200-202); documented
-                # divergence: emit the single dummy correspondence it evidently intended
-                matches = np.ones((1, 2), np.int64)
-                scores = np.ones(1, np.float32)
-            matches_in_former = np.concatenate([sample0[matches[:, 1]][:, None], sample1[matches[:, 0]][:, None]], axis=1)
-            np.save(f'{Save_dir}/{id0}-{id1}.npy', matches_in_former)
-            np.save(f'{Save_score_dir}/{id0}-{id1}.npy', scores)
+            # NB the network's source side ('feats0/keys0') is pc1 and its target side pc0 (matcher.py:192-197)
+            pend.append((id0, id1, (feats1[s1], feats0[s0], torch.from_numpy(keys1.astype(np.float32)).cuda(),
+                                    torch.from_numpy(keys0.astype(np.float32)).cuda()), np.asarray(sample0), np.asarray(sample1)))
+            if len(pend) >= group:
+                flush()
+        flush()
