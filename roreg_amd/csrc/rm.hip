@@ -523,6 +523,162 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ 
     if (lane == 0) out[i] = (i == R - 1 ? last_extra + normc : normc) - (mx + __logf(s));
 }
 
+// One Sinkhorn iteration in ONE pass over the coupling matrix (batched path): a workgroup owns 32 consecutive rows and every
+// thread a fixed set of columns (4 consecutive per 1024).  Per row i the workgroup reduces the row in the log domain exactly like the
+// two-matrix pass: M_i = max_j (Z[i,j] + v[j]), e_ij = exp(Z[i,j] + v[j] - M_i), S_i = sum_j e_ij, u[i] = log_mu(i) - M_i - log S_i.
+// The column update needs LSE_i(Z[i,j] + u[i]); since Z[i,j] + u[i] = log e_ij + (M_i + u[i]) - v[j], it is
+//     LSE_i(Z[i,j] + u[i]) = log( sum_i e_ij * a_i ) - v[j]        with a_i = exp(M_i + u[i]) = mu_i / S_i   (<= 1),
+// so the e_ij already in registers are folded into the column sums with ONE fma per element and no further exponential: half the
+// transcendental work of two log-domain passes and the matrix read once per iteration instead of twice.  After its rows the workgroup
+// writes one partial sum per column; ot_col_merge_kernel adds the row blocks' partials in a fixed order and updates v.  Every term is
+// in [0, 1]; a column whose terms all underflowed (it would have to sit e^-87 below the row maxima in EVERY row, the dustbin row included,
+// i.e. v[j] < max v - 87) is clamped to the smallest normal number instead of producing log 0.  The transposed copy is only read by
+// the final column arg-max.
+constexpr int OT_RB = 32;
+
+// Wave-wide reductions on the DPP data path (no LDS crossbar): quad swaps, half-row / row mirrors, then the row broadcasts of gfx9;
+// the full result is in lane 63 and is handed back through a scalar register.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_max(float x) {
+    x = fmaxf(x, dpp_mov<0xB1, 0xf>(x));       // quad_perm [1,0,3,2]
+    x = fmaxf(x, dpp_mov<0x4E, 0xf>(x));       // quad_perm [2,3,0,1]
+    x = fmaxf(x, dpp_mov<0x141, 0xf>(x));      // row_half_mirror
+    x = fmaxf(x, dpp_mov<0x140, 0xf>(x));      // row_mirror: every lane of a 16-lane row holds the row's maximum
+    x = fmaxf(x, dpp_mov<0x142, 0xa>(x));      // row_bcast:15 into rows 1 and 3
+    x = fmaxf(x, dpp_mov<0x143, 0xc>(x));      // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ float wave_sum(float x) {
+    x += dpp_mov<0xB1, 0xf>(x);
+    x += dpp_mov<0x4E, 0xf>(x);
+    x += dpp_mov<0x141, 0xf>(x);
+    x += dpp_mov<0x140, 0xf>(x);
+    {   // rows that are not written keep their own value in the moved operand; only the written rows matter downstream
+        const float t = dpp_mov<0x142, 0xa>(x);
+        x = ((threadIdx.x >> 4) & 1) ? x + t : x;
+    }
+    {
+        const float t = dpp_mov<0x143, 0xc>(x);
+        x = ((threadIdx.x >> 5) & 1) ? x + t : x;
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ot_fused_pass_kernel(const float *__restrict__ Z, int ld, const float *__restrict__ vvec,
+                                                            float *__restrict__ uout, float *__restrict__ part, size_t part_stride, OtBatch ob) {
+    __shared__ float smx[2][4], ssum[2][4];
+    const int pair = blockIdx.y;
+    const int R = ob.seg_rows[pair + 1] - ob.seg_rows[pair] + 1, C = ob.seg_cols[pair + 1] - ob.seg_cols[pair] + 1;
+    const int r0 = blockIdx.x * OT_RB;
+    if (r0 >= R) return;
+    const int r1 = min(r0 + OT_RB, R);
+    Z += pair * ob.slab; vvec += pair * ob.slab; uout += pair * ob.slab;
+    part += pair * part_stride + (size_t)blockIdx.x * ld;
+    const float normc = ob.consts[pair * 2], last_extra = ob.consts[pair * 2 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float NEG = -__builtin_inff();
+    float vv[NV][4], acc[NV][4];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int j = t * 1024 + tid * 4;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < ld) q = *reinterpret_cast<const float4 *>(vvec + j);
+        vv[t][0] = q.x; vv[t][1] = q.y; vv[t][2] = q.z; vv[t][3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    }
+    // rows stream through a ring of four register buffers: three rows are in flight while one is reduced (one row per workgroup in
+    // flight is ~10 KB; memory latency under load is several microseconds, so depth is what buys bandwidth here)
+    float4 buf[4][NV];
+    auto load_row = [&](int r, float4 (&dst)[NV]) {
+        const float *row = Z + (size_t)(r < r1 ? r : r1 - 1) * ld;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int j = t * 1024 + tid * 4;
+            dst[t] = j < ld ? *reinterpret_cast<const float4 *>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto process = [&](int r, const float4 (&cur)[NV]) {
+        float x[NV][4];
+        float mx = NEG;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const float z[4] = {cur[t].x, cur[t].y, cur[t].z, cur[t].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[t][e] = t * 1024 + tid * 4 + e < C ? z[e] + vv[t][e] : NEG;
+                mx = fmaxf(mx, x[t][e]);
+            }
+        }
+        mx = wave_max(mx);
+        const int par = r & 1;
+        if (lane == 0) smx[par][w] = mx;
+        __syncthreads();
+        const float M = fmaxf(fmaxf(smx[par][0], smx[par][1]), fmaxf(smx[par][2], smx[par][3]));      // finite: the dustbin column is
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[t][e] = __expf(x[t][e] - M); sm += x[t][e]; }               // e_ij (0 for the padding)
+        sm = wave_sum(sm);
+        if (lane == 0) ssum[par][w] = sm;
+        __syncthreads();
+        const float S = (ssum[par][0] + ssum[par][1]) + (ssum[par][2] + ssum[par][3]);
+        const float lmu = r == R - 1 ? last_extra + normc : normc;
+        const float logS = __logf(S);
+        if (tid == 0) uout[r] = lmu - (M + logS);
+        const float ai = __expf(lmu - logS);                                                          // exp(M + u[i]) = mu_i / S_i
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(x[t][e], ai, acc[t][e]);
+    };
+    load_row(r0, buf[0]); load_row(r0 + 1, buf[1]); load_row(r0 + 2, buf[2]);
+    for (int r = r0; r < r1; r += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r + k < r1) {                                   // uniform over the workgroup
+                load_row(r + k + 3, buf[(k + 3) & 3]);
+                process(r + k, buf[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int j = t * 1024 + tid * 4;
+        if (j < ld) *reinterpret_cast<float4 *>(part + j) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+}
+
+// v[j] <- log_nu(j) - log( sum over the row blocks of the partial column sums ) + v[j]   (see ot_fused_pass_kernel).  A workgroup owns 64
+// columns; its four waves add every fourth row block, then the four sums are added in wave order.
+__global__ __launch_bounds__(256) void ot_col_merge_kernel(const float *__restrict__ part, size_t part_stride, int ld, float *__restrict__ vio,
+                                                           OtBatch ob) {
+    __shared__ float sh[4][64];
+    const int pair = blockIdx.y;            // ob is the COLUMN pass geometry: its "rows" are the matrix columns
+    const int C = ob.seg_rows[pair + 1] - ob.seg_rows[pair] + 1, R = ob.seg_cols[pair + 1] - ob.seg_cols[pair] + 1;
+    if ((int)(blockIdx.x * 64) >= C) return;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane, jj = j < C ? j : C - 1;
+    part += pair * part_stride + jj;
+    const int nblk = (R + OT_RB - 1) / OT_RB;
+    float T = 0.f;
+#pragma unroll 4
+    for (int b = g; b < nblk; b += 4) T += part[(size_t)b * ld];
+    sh[g][lane] = T;
+    __syncthreads();
+    if (g == 0 && j < C) {
+        T = fmaxf((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]), 1.17549435e-38f);
+        const float normc = ob.consts[pair * 2], last_extra = ob.consts[pair * 2 + 1];       // column constants: (normc, log m)
+        float *v = vio + pair * ob.slab + j;
+        *v = (j == C - 1 ? last_extra + normc : normc) - __logf(T) + *v;
+    }
+}
+
 __global__ __launch_bounds__(256) void ot_final_kernel(const float *__restrict__ Z0, int ld, int m, int n, const float *__restrict__ u,
                                                        const float *__restrict__ v, float normc, float *__restrict__ Z) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -814,8 +970,13 @@ static size_t ot_slab(int max_m, int max_n) {
     return (size_t)(max_m + 1) * ldz + (size_t)(max_n + 1) * ldt + ldt + ldz;
 }
 
+static size_t ot_part_stride(int max_m, int max_n) {          // floats of column partials per pair: [row blocks][ldz]
+    const size_t ldz = (max_n + 4) & ~3;
+    return (size_t)((max_m + 1 + OT_RB - 1) / OT_RB) * ldz;
+}
+
 extern "C" size_t roreg_sinkhorn_batch_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n) {
-    return (size_t)n_seg * ot_slab(max_m, max_n) + 3 * (size_t)(total_m + total_n) + 64;
+    return (size_t)n_seg * (ot_slab(max_m, max_n) + ot_part_stride(max_m, max_n)) + 3 * (size_t)(total_m + total_n) + 64;
 }
 
 // Host helper: the per-pair constants of the two passes, [n_seg][2] (-log(m+n), log n) then [n_seg][2] (-log(m+n), log m), computed
@@ -851,7 +1012,9 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
     const int ldz = (max_n + 4) & ~3, ldt = (max_m + 4) & ~3;
     const size_t slab = ot_slab(max_m, max_n);
     float *Z0 = ws, *Z0T = Z0 + (size_t)(max_m + 1) * ldz, *u = Z0T + (size_t)(max_n + 1) * ldt, *v = u + ldt;
-    float *tail = ws + (size_t)n_seg * slab;
+    const size_t pstride = ot_part_stride(max_m, max_n);
+    float *part = ws + (size_t)n_seg * slab;
+    float *tail = part + (size_t)n_seg * pstride;
     float *val0 = tail, *val1 = val0 + tm;
     const size_t off = ((reinterpret_cast<uintptr_t>(val1 + tn) + 7) & ~(uintptr_t)7) - reinterpret_cast<uintptr_t>(ws);
     int64_t *i0 = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + off);
@@ -864,9 +1027,21 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
     hipLaunchKernelGGL(ot_build_kernel, dim3((max_m + 1 + 255) / 256, (max_n + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, tgt_final, 0,
                        src_final, 0, alpha, rpb, Z0T, ldt, seg_tgt, seg_src, slab);
     for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent
+    const int nv = (ldz + 1023) / 1024;                  // float4 pieces of a row per thread
+    const dim3 gp((max_m + 1 + OT_RB - 1) / OT_RB, n_seg), gm((max_n + 1 + 63) / 64, n_seg);
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(row_lse_kernel, dim3((max_m + 4) / 4, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, 0.f, 0.f, u, rows);
-        hipLaunchKernelGGL(row_lse_kernel, dim3((max_n + 4) / 4, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, 0.f, 0.f, v, cols);
+        if (nv > 8) {                                    // rows beyond 8192 columns: the two-matrix passes
+            hipLaunchKernelGGL(row_lse_kernel, dim3((max_m + 4) / 4, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, 0.f, 0.f, u, rows);
+            hipLaunchKernelGGL(row_lse_kernel, dim3((max_n + 4) / 4, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, 0.f, 0.f, v, cols);
+            continue;
+        }
+#define OT_PASS(NV) hipLaunchKernelGGL(ot_fused_pass_kernel<NV>, gp, dim3(256), 0, s, Z0, ldz, v, u, part, pstride, rows)
+        switch (nv) {
+        case 1: OT_PASS(1); break; case 2: OT_PASS(2); break; case 3: OT_PASS(3); break; case 4: OT_PASS(4); break;
+        case 5: OT_PASS(5); break; case 6: OT_PASS(6); break; case 7: OT_PASS(7); break; default: OT_PASS(8); break;
+        }
+#undef OT_PASS
+        hipLaunchKernelGGL(ot_col_merge_kernel, gm, dim3(256), 0, s, part, pstride, ldz, v, cols);
     }
     hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
     hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);

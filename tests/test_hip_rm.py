@@ -142,7 +142,8 @@ def test_match_ot_forward_vs_reference_golden(rm):
 
 def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm):
     """Several ragged pairs through ONE pass of the network (segmented neighbour search, InstanceNorm statistics, context maximum,
-    Sinkhorn) against forward() pair by pair: bit-identical read-outs.  The golden pair is one of them."""
+    Sinkhorn) against forward() pair by pair: identical matches, scores to rounding (the network part is bit-identical; the stacked
+    Sinkhorn sums the columns in a different order).  The golden pair is one of them and is checked against the reference directly."""
     net, sd = rm
     z = load_golden('match_ot')
     rng = np.random.default_rng(11)
@@ -158,8 +159,10 @@ def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm):
         for (f0, f1, k0, k1), (m0, s0) in zip(pairs, got):
             want = net({'feats0': f0[None], 'feats1': f1[None], 'keys0': k0[None], 'keys1': k1[None]})
             assert torch.equal(m0, want['matches0'][0])
-            assert torch.equal(s0, want['matching_scores0'][0])
+            # the stacked Sinkhorn folds rows into the column sums in one pass (different association than the two-matrix passes)
+            assert (s0 - want['matching_scores0'][0]).abs().max() < 2e-5
     assert np.array_equal(got[0][0].cpu().numpy(), z['out_matches0'][0])
+    assert np.abs(got[0][1].cpu().numpy() - z['out_matching_scores0'][0]).max() < 1e-4
     assert int((got[1][0] >= 0).sum()) > 20                      # the synthetic pairs do produce matches
 
 
