@@ -286,7 +286,8 @@ int roreg_sinkhorn(const float *src_final, int m, const float *tgt_final, int n,
 
 /* The same for several pairs per launch (2*iters + 5 launches for all of them): descriptors concatenated by seg_src / seg_tgt (device
  * and host copies of the int32 offsets), read-outs concatenated the same way with indices LOCAL to the pair; the coupling matrix
- * itself is not returned.  consts: DEVICE copy of the 4*n_seg floats of roreg_sinkhorn_batch_consts (a host function: the host
+ * itself is not returned.  Each iteration reads the matrix once (rows in the log domain, column sums by fma of the same exponentials);
+ * read-outs equal the one-pair call's (indices identical on the tests, scores to rounding).  consts: DEVICE copy of the 4*n_seg floats of roreg_sinkhorn_batch_consts (a host function: the host
  * logf values the one-pair call uses). */
 size_t roreg_sinkhorn_batch_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n);
 int roreg_sinkhorn_batch_consts(const int32_t *seg_src_host, const int32_t *seg_tgt_host, int n_seg, float *consts_host);
