@@ -208,6 +208,15 @@ def main():
     eng.set_gemm_mode(args.gemm)
     max_dT = max([float(np.abs(a.trans - b.trans).max()) for a, b in zip(res, res_other) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()] or [0.0])
 
+    # ---- secondary figure 3: the split SURVEY 8(d) asks for -- per-cloud stages (extractor) vs per-pair stages (matcher, local
+    # transforms, estimator) -- from one extra step with a synchronisation after every phase (diagnostic, outside the timed region) ----
+    phases = None
+    if not args.no_secondary:
+        eng.phase_ms = {}
+        step()
+        phases = {k: round(v, 2) for k, v in eng.phase_ms.items()}
+        eng.phase_ms = None
+
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
     # algorithmic work per launch = sum over the five irreps of 2*(d*O)*(d*C)*(d*B) = 2*O*C*B*244 flop
     def gemm_roofline(events, tagname):
@@ -249,7 +258,10 @@ def main():
                        'pairs_per_step_per_gpu': n_pairs, 'clouds_per_step_per_gpu': args.clouds, 'parallelism': f'pairs-sharded x{world}',
                        'mean_matches': float(np.mean([r.n_match for r in res])), 'registration_recall_synthetic': float(np.mean(rr)),
                        'local_transforms': 'only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M)',
-                       'value_all_local_transforms': (world * n_pairs * n_all / dt_all) if n_all else None, 'results_identical_to_all_local_transforms': bool(same)},
+                       'value_all_local_transforms': (world * n_pairs * n_all / dt_all) if n_all else None, 'results_identical_to_all_local_transforms': bool(same),
+                       'phase_ms_one_synchronised_step': phases,
+                       'pair_stages_only_pairs_per_s_per_gpu': (n_pairs / (sum(v for k, v in phases.items() if k != 'extract') * 1e-3)) if phases else None,
+                       'per_cloud_stage_clouds_per_s_per_gpu': (args.clouds / (phases['extract'] * 1e-3)) if phases else None},
             'roofline': roofline_obj(args.gemm, achieved, ms, n_launch, traffic),
         }
         if n_all:
