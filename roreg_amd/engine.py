@@ -154,8 +154,9 @@ class RegistrationEngine:
     def _match_rm_finish(s0, s1, m0, sc0):
         """matches0 / matching_scores0 (host) -> (matches [M,2] int64 host in cloud coordinates, scores f32); test/matcher.py:198-206."""
         valid = np.nonzero(m0 >= 0)[0]
-        if valid.shape[0] < 3:                       # the reference crashes here; same documented divergence as test/matcher.py
-            return np.ones((1, 2), np.int64), np.ones(1, np.float32)
+        if valid.shape[0] < 3:                       # the reference crashes here; same documented divergence as test/matcher.py:
+            # the single dummy correspondence (1, 1) of the SAMPLED lists, mapped to cloud rows like every other match
+            return np.array([[np.asarray(s0, np.int64)[1], np.asarray(s1, np.int64)[1]]], np.int64), np.ones(1, np.float32)
         return np.stack([np.asarray(s0, np.int64)[m0[valid]], np.asarray(s1, np.int64)[valid]], 1), sc0[valid]
 
     def match_rm_many(self, jobs, max_points=None):

@@ -546,7 +546,9 @@ def stats_rank_deficient(stats, tol=1e-10):
     if not np.isfinite(H).all():
         return False
     sv = np.linalg.svd(H, compute_uv=False)
-    return bool(sv[1] <= tol * max(sv[0], 1e-300))
+    # rank <= 2 (three inliers, coplanar inliers, ...): the third singular pair is a null pair and whether U V^T is a rotation or a
+    # reflection is the SVD routine's sign convention -- the reference's value is LAPACK's
+    return bool(sv[2] <= tol * max(sv[0], 1e-300))
 
 
 def gather_rows_f64(src, rows):

@@ -184,6 +184,19 @@ def test_engine_yohoc_equals_file_coupled_stages(tmp_path):
         assert np.abs(r.trans - want['trans']).max() < 1e-10
 
 
+@pytest.mark.parametrize('n_kpts,keynum,RD,RM,ET', [(40, 24, False, True, 'yohoo'), (40, 24, False, True, 'yohoc'), (40, 50, True, True, 'yohoc'),
+                                                     (250, 150, True, False, 'yohoc'), (250, 260, False, True, 'yohoo')])
+def test_engine_equals_stages_on_small_and_degenerate_scenes(tmp_path, n_kpts, keynum, RD, RM, ET):
+    """Cases from tools/soak_engine_vs_stages.py (all 48 combinations pass there): tiny clouds where the rotation-coherence matcher
+    finds fewer than three matches (the dummy correspondence must be the same sampled row in both paths), refinements on three or
+    coplanar inliers (rank-2 cross-covariance: both paths must end in the same LAPACK call), keynum above and below the cloud size."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from soak_engine_vs_stages import run_case
+    ok, worst, msgs = run_case(n_kpts, keynum, RD, RM, ET, root=str(tmp_path))
+    assert ok, msgs
+
+
 def test_knn_module_api_shapes():
     from roreg_amd.utils.knn_search import knn_module
     z = load_golden('knn')
