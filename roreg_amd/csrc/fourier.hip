@@ -457,8 +457,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     // flat offset (without the lane's keypoint jn) of coefficient q of channel c in keypoint tile tb; the table entries are compile-time
     // constants, so both half-wave candidates are scalar-ALU values and a lane only selects
     const size_t Bp = (size_t)p.Bp;
+    const size_t hmask = (size_t)0 - (size_t)h;                  // all ones for the second half-wave
 #define OFF_Q(Q, c, tb) ((size_t)(kQ.alpha[Q] * C + (c) * kQ.d[Q]) * Bp + (size_t)(tb) * (32 * kQ.d[Q]) + kQ.i[Q] * 32)
-#define OFF_OF(Q0, Q1, c, tb) (OFF_Q(Q0, c, tb) + (size_t)h * (OFF_Q(Q1, c, tb) - OFF_Q(Q0, c, tb)))   // arithmetic select: one load, no exec-masked pair
+#define OFF_OF(Q0, Q1, c, tb) (OFF_Q(Q0, c, tb) + ((OFF_Q(Q1, c, tb) - OFF_Q(Q0, c, tb)) & hmask))   // arithmetic select (mask, not a quarter-rate multiply): one load, no exec-masked pair
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
     constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT != 0 ? 32 : 30);
