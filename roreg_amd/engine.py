@@ -24,7 +24,7 @@ class CloudState:
     inv: torch.Tensor = None        # matcher invariant descriptor [N,32]
     keys: torch.Tensor = None       # keypoints [N,3] f64 (device)
     det: np.ndarray = None          # detector rank scores (host, as det_score/*.npy)
-    keys_host: np.ndarray = None    # keypoints on the host (NMS sampling runs numpy selections like the reference)
+    keys_host: np.ndarray = None    # keypoints on the host (downloaded on first use: the yohoc estimator's 3-point Kabsch runs on LAPACK)
     nms: dict = field(default_factory=dict)   # keynum -> NMS sample of this cloud (a pure function of the cloud)
 
 
@@ -116,19 +116,53 @@ class RegistrationEngine:
                 k = keys_list[q]
                 k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
                 out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], inv=inv[o:o + n], keys=k.to('cuda', torch.float64).contiguous(),
-                                      keys_host=k.cpu().numpy() if self.cfg.RD else None))
+                                      ))
                 o += n
             i = j
         return out
 
     def detect(self, cloud):
         """raw std scores -> rank/N on the host exactly as test/detector.py:45-46."""
+        self.detect_many([cloud])
+        return cloud.det
+
+    def detect_many(self, clouds):
+        """Detector scores of several clouds: every cloud's network pass is enqueued, ONE download, then the rank transform of
+        test/detector.py:45-46 per cloud on the host."""
+        todo = [c for c in clouds if c.det is None]
+        if not todo:
+            return
         with torch.no_grad():
-            s = self.rd({'feats': cloud.eqv})['scores'].cpu().numpy()
-        a = np.argsort(s)
-        s[a] = np.arange(s.shape[0]) / s.shape[0]
-        cloud.det = s
-        return s
+            raw = [self.rd({'feats': c.eqv})['scores'] for c in todo]
+        flat = torch.cat(raw).cpu().numpy()
+        o = 0
+        for c in todo:
+            n = c.eqv.shape[0]
+            s = flat[o:o + n].copy(); o += n
+            a = np.argsort(s)
+            s[a] = np.arange(s.shape[0]) / s.shape[0]
+            c.det = s
+
+    def nms_many(self, clouds, keynum):
+        """NMS sampling (test/matcher.py:11-42) of several clouds: it is a pure function of the cloud (keypoints, detector scores,
+        keynum; no RNG), so it is computed once per cloud -- the reference recomputes it for both clouds of every pair
+        (matcher.py:77-82) -- with every cloud's 5-NN search enqueued first and ONE download of the neighbour lists."""
+        from .test.matcher import NMS_sample
+        sampler = NMS_sample(keynum, 5)
+        todo = [c for c in clouds if keynum not in c.nms]
+        knn = []
+        for c in todo:
+            if c.keys.shape[0] < keynum:
+                c.nms[keynum] = np.arange(c.keys.shape[0])
+            else:
+                k32 = c.keys.float().contiguous()
+                knn.append((c, hip.knn_search(k32, k32, 5)))
+        if knn:
+            flat = torch.cat([i.reshape(-1) for _, i in knn]).cpu().numpy()
+            o = 0
+            for c, i in knn:
+                n = i.shape[0]
+                c.nms[keynum] = sampler.sample_from_neighbours(c.det, flat[o:o + 5 * n].reshape(n, 5)); o += 5 * n
 
     # ---- per pair ------------------------------------------------------------------------------------------
     def sample(self, c0, c1, keynum):
@@ -137,13 +171,8 @@ class RegistrationEngine:
         if self.cfg.RD:
             # NMS sampling is a pure function of the cloud (keypoints, detector scores, keynum; no RNG): the reference recomputes
             # it for both clouds of every pair (matcher.py:77-82), here it is computed once per cloud and reused
-            from .test.matcher import NMS_sample
-            out = []
-            for c in (c0, c1):
-                if keynum not in c.nms:
-                    c.nms[keynum] = NMS_sample(keynum, 5).sample(c.keys_host, c.det)
-                out.append(c.nms[keynum])
-            s0, s1 = out
+            self.nms_many([c0, c1], keynum)
+            s0, s1 = c0.nms[keynum], c1.nms[keynum]
         else:
             s0 = np.arange(n0); s1 = np.arange(n1)
             np.random.shuffle(s0); np.random.shuffle(s1)
@@ -334,8 +363,8 @@ class RegistrationEngine:
         clouds = dict(zip(used, self.extract_many([feats[i] for i in used], [keys[i] for i in used])))
         t0 = self._mark('extract', t0)
         if self.cfg.RD:
-            for i in used:
-                self.detect(clouds[i])
+            self.detect_many([clouds[i] for i in used])
+            self.nms_many([clouds[i] for i in used], keynum)
         # stage 3: all pairs
         full, all_scores = [], []
         if self.cfg.RM:

@@ -32,6 +32,10 @@ class NMS_sample():
         keys = torch.from_numpy(keys.astype(np.float32)[None, :, :]).permute(0, 2, 1)
         d, argmin = self.KNN(keys, keys)
         argmin = argmin[0].permute(1, 0).cpu().numpy()   # N*k
+        return self.sample_from_neighbours(scores, argmin)
+
+    def sample_from_neighbours(self, scores, argmin):
+        """The selection of matcher.py:24-41 given the k nearest neighbours (self included) of every keypoint, argmin [N,k]."""
         scores_nei = scores[argmin.reshape(-1)].reshape(-1, self.k)
         nei_max = np.max(scores_nei, axis=-1)
         sam_indexs = np.where(scores >= nei_max)[0]
