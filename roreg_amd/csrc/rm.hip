@@ -753,15 +753,18 @@ __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restri
 }  // namespace
 
 // -----------------------------------------------------------------------------------------------------------
-static int topk_slices(int gx_total, int max_n) {
-    int slices = (320 + gx_total - 1) / gx_total;
+// target slices x row blocks: ~1 workgroup per CU is enough for one pair (more slices only lengthen the merge); stacked pairs are
+// bandwidth hungrier per launch and want ~4 per CU
+static int topk_slices(int gx_total, int max_n, bool stacked) {
+    const int target = stacked ? 1024 : 320;
+    int slices = (target + gx_total - 1) / gx_total;
     if (slices > (max_n + 63) / 64) slices = (max_n + 63) / 64;
     return slices < 1 ? 1 : slices;
 }
 
 extern "C" size_t roreg_topk_dot_workspace_size(int m, int n, int k) {
     // enough for any segmentation of m x n: the slice count only shrinks when the rows are spread over several pairs
-    const int slices = topk_slices((m + 255) / 256, n);
+    const int slices = topk_slices((m + 255) / 256, n, true);
     return (size_t)slices * m * k * 2;       // floats (values) + ints (indices), 4 bytes each
 }
 
@@ -774,7 +777,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     ROREG_REQUIRE(n_seg > 0 && max_m > 0 && max_n > 0 && max_m <= m && max_n <= n, "roreg_topk_dot: bad segment description");
     ROREG_REQUIRE(segA || k <= n, "roreg_topk_dot: k > n");      // with segments the caller guarantees k <= every pair's target count
     const int gx = (max_m + 255) / 256;
-    int slices = topk_slices(gx * n_seg, max_n);
+    int slices = topk_slices(gx * n_seg, max_n, segA != nullptr);
     if (!segA) {                                 // one pair: the slice width the kernel derives must cover n with this many slices
         const int slice = (n + slices - 1) / slices;
         slices = (n + slice - 1) / slice;
