@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+SUSTAINED_FP16_MFMA_TFLOPS = 1650.0  # measured: tools/mfma_peak.py, random operands, 2-8 waves/SIMD (1840 with one smooth operand pair)
 N_KPTS = 5000
 N_CLOUDS = 16
 N_PAIRS = 60          # 16 clouds : 60 pairs = 0.267 = 3DMatch's 433 clouds : 1623 pairs
@@ -107,7 +108,11 @@ def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic):
         base.update({'kernel': KERNEL_OF[mode], 'achieved': gemm_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': gemm_tflops / PEAK_F32_MFMA_TFLOPS})
     else:
         k = MFMAS_PER_PRODUCT[mode]
-        base.update({'kernel': KERNEL_OF[mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
+        base.update({'kernel': KERNEL_OF[mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS,
+                     # context, not the priced peak: what back-to-back 32x32x16 fp16 MFMAs from registers sustain on this part with
+                     # pseudo-random operands (tools/mfma_peak.py) -- the power-limited ceiling of any 16-bit kernel
+                     'sustained_mfma_ceiling_measured_tflops': SUSTAINED_FP16_MFMA_TFLOPS,
+                     'frac_of_sustained_ceiling': k * gemm_tflops / SUSTAINED_FP16_MFMA_TFLOPS})
     return base
 
 
