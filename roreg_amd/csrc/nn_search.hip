@@ -243,7 +243,7 @@ extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
 
 static int knn_slices(int m, int n) {
     const int gx = (m + 255) / 256;
-    int slices = (1024 + gx - 1) / gx;                 // aim at ~1024 workgroups
+    int slices = (512 + gx - 1) / gx;                  // aim at ~512 workgroups (more slices only lengthen the merge)
     if (slices > (n + 31) / 32) slices = (n + 31) / 32;
     return slices < 1 ? 1 : slices;
 }
