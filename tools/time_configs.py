@@ -16,7 +16,8 @@ order = np.random.default_rng(4242).permutation(len(scene.pair_ids))
 pair_ids = [scene.pair_ids[i] for i in sorted(order[:n_pairs])]
 feats = [torch.from_numpy(f).cuda() for f in scene.feats]; keys = [torch.from_numpy(k).cuda() for k in scene._kps]
 for name, kw in (('mutual+yohoo', dict(keynum=5000, ET='yohoo')), ('mutual+yohoc', dict(keynum=5000, ET='yohoc')), ('RD+mutual+yohoo', dict(keynum=5000, ET='yohoo', RD=True)),
-                 ('RD+RM+yohoo', dict(keynum=2500, ET='yohoo', RD=True, RM=True))):
+                 ('RD+RM+yohoo', dict(keynum=2500, ET='yohoo', RD=True, RM=True)),
+                 ('RD+RM+yohoo@1000', dict(keynum=1000, ET='yohoo', RD=True, RM=True))):      # the reference README's command line
     if '--only' in sys.argv and sys.argv[sys.argv.index('--only') + 1] != name:
         continue
     cfg = default_config(max_iter=1000, **kw)
