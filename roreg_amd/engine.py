@@ -85,6 +85,11 @@ class RegistrationEngine:
         net._fourier.gemm = mode
         if self.et is not None:
             self.et.gemm = mode
+        if self.rd is not None:
+            if self.rd._fourier is None:
+                from .network.gf_fourier import FourierRD
+                object.__setattr__(self.rd, '_fourier', FourierRD(self.rd.eqv_encoder[0]))
+            self.rd._fourier.gemm = mode
 
     # ---- per cloud ---------------------------------------------------------------------------------------
     def extract(self, feats, keys):
@@ -132,8 +137,15 @@ class RegistrationEngine:
         todo = [c for c in clouds if c.det is None]
         if not todo:
             return
+        raw, i = [], 0
         with torch.no_grad():
-            raw = [self.rd({'feats': c.eqv})['scores'] for c in todo]
+            while i < len(todo):                                      # several clouds per pass of the (per-keypoint) detector network
+                j, rows = i, 0
+                while j < len(todo) and (j == i or rows + todo[j].eqv.shape[0] <= 65536):
+                    rows += todo[j].eqv.shape[0]; j += 1
+                x = todo[i].eqv if j - i == 1 else torch.cat([c.eqv for c in todo[i:j]])
+                raw.append(self.rd({'feats': x})['scores'])
+                i = j
         flat = torch.cat(raw).cpu().numpy()
         o = 0
         for c in todo:

@@ -96,3 +96,53 @@ class FourierGF:
         T3 = gemm(X3, self.l_out, 256, 32)
         out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True, split=sp)
         return out
+
+
+class FourierRD:
+    """The detector's Residual_Comb_Conv(32, 64, 16) with its conv short cut (network/rot_detect.py:39, network/ops.py:22-64) in the
+    irrep domain:
+        Xa = FT(relu(bn_in(x)))    T1 = GEMM(Xa, comb_layer_in)         Xs = FT(relu(bn_sc(x)))   S = GEMM(Xs, short_cut_layer)
+        X1 = FT(relu(bn_out(IFT(T1) + b_in)))                            T2 = GEMM(X1, comb_layer_out) + S
+        enc = IFT(T2) + b_out + b_sc                                     [B,16,60]"""
+
+    def __init__(self, block):
+        self.block = block
+        self._key = None
+        self.gemm = hip.GEMM_MODE
+
+    def _plan(self):
+        key = _version_key(self.block)
+        if self._key != key:
+            b = self.block
+            self.l_in = _Layer(b.comb_layer_in[2]); self.bn_in = _fold_bn(b.comb_layer_in[0])
+            self.l_out = _Layer(b.comb_layer_out[2]); self.bn_out = _fold_bn(b.comb_layer_out[0])
+            self.l_sc = _Layer(b.short_cut_layer[2]); self.bn_sc = _fold_bn(b.short_cut_layer[0])
+            self._key = key
+
+    def forward(self, x):
+        self._plan()
+        hip.ensure_fourier()
+        B = x.shape[0]
+        sp = {'f32': False, 'bf16x3': True, 'f16x2': 'f16x2'}[self.gemm]
+        f16 = self.gemm == 'f16x2'
+
+        def gemm(Xa, layer, add=None):
+            X, amax = Xa
+            if f16:
+                return hip.irrep_gemm(X, layer.wpack, layer.C, layer.O, B, f16x2=layer.wsplit2, x_absmax=amax, add=add)
+            return hip.irrep_gemm(X, layer.wpack, layer.C, layer.O, B, split=layer.wsplit if self.gemm == 'bf16x3' else None, add=add)
+
+        def ft(C, **kw):
+            r = hip.ft_nonlin(B, C, split=sp, want_absmax=f16, **kw)
+            return r if f16 else (r, None)
+        Xs = ft(32, x_spatial=x, bn=self.bn_sc)
+        S = gemm(Xs, self.l_sc)
+        del Xs
+        Xa = ft(32, x_spatial=x, bn=self.bn_in)
+        T1 = gemm(Xa, self.l_in)
+        del Xa
+        X1 = ft(64, coef_in=T1, bias=self.l_in.bias, bn=self.bn_out)
+        del T1
+        T2 = gemm(X1, self.l_out, add=S)
+        del X1, S
+        return hip.ft_nonlin(B, 16, coef_in=T2, bias=self.l_out.bias, bias2=self.l_sc.bias, spatial_out=True, split=sp)

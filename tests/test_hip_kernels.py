@@ -94,8 +94,18 @@ def test_rd_forward_vs_golden(group):
     z = load_golden('rd_forward')
     net = name2network['RD_test'](default_config())
     net.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()}, strict=True)
-    enc = net.encode(torch.from_numpy(z['x'])).cpu().numpy()
+    enc = net.encode(torch.from_numpy(z['x'])).cpu().numpy()                    # irrep-domain evaluation (default)
     assert np.abs(enc - z['enc']).max() < 1e-4 * max(1.0, np.abs(z['enc']).max())
+    net.mode = 'direct'
+    enc_d = net.encode(torch.from_numpy(z['x'])).cpu().numpy()                  # 13-stencil kernels
+    net.mode = 'fourier'
+    assert np.abs(enc_d - z['enc']).max() < 1e-4 * max(1.0, np.abs(z['enc']).max())
+    assert np.abs(enc - enc_d).max() < 2e-5 * max(1.0, np.abs(z['enc']).max())
+    for mode in ('bf16x3', 'f32'):
+        net._fourier.gemm = mode
+        e2 = net.encode(torch.from_numpy(z['x'])).cpu().numpy()
+        assert np.abs(e2 - z['enc']).max() < 1e-4 * max(1.0, np.abs(z['enc']).max())
+    net._fourier.gemm = 'f16x2' 
     s = net({'feats': torch.from_numpy(z['x'])})['scores'].cpu().numpy()
     assert np.abs(s - z['scores']).max() < 1e-4
     from roreg_amd import hip
