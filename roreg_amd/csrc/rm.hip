@@ -453,16 +453,16 @@ __global__ __launch_bounds__(256) void ot_build_kernel(const float *__restrict__
         rowvec += (size_t)r0 * RM_F; colvec += (size_t)c0 * RM_F; M += blockIdx.z * slab;
         if (R <= 0 || C <= 0) return;
     }
-    const int c = blockIdx.x * 256 + threadIdx.x;          // column in [0, C]  (C = dustbin)
-    if ((int)(blockIdx.x * 256) > C) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;          // column in [0, C]  (C = dustbin); the pitch padding (C, ld) is zeroed so that
+    if ((int)(blockIdx.x * 256) >= ld) return;             // kernels that stream whole float4 pieces of a row only ever see finite values
     const int cc = c < C ? c : C - 1;
     float t[RM_F];
 #pragma unroll
     for (int f = 0; f < RM_F; ++f) t[f] = colvec[(size_t)cc * RM_F + f];
     const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, R + 1);
-    if (c > C) return;
+    if (c >= ld) return;
     for (int r = r0; r < r1; ++r) {
-        float v = alpha;
+        float v = c > C ? 0.f : alpha;
         if (r < R && c < C) {
             const float *a = rowvec + (size_t)r * RM_F;
             float acc = 0.f;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float *__restrict__ 
 }
 
 // One Sinkhorn iteration in ONE pass over the coupling matrix (batched path): a workgroup owns 32 consecutive rows and every
-// thread a fixed set of columns (4 consecutive per 1024).  Per row i the workgroup reduces the row in the log domain exactly like the
+// thread a fixed set of columns (4 consecutive per 1024).  Per row i the workgroup reduces the row in the log domain like the
 // two-matrix pass: M_i = max_j (Z[i,j] + v[j]), e_ij = exp(Z[i,j] + v[j] - M_i), S_i = sum_j e_ij, u[i] = log_mu(i) - M_i - log S_i.
 // The column update needs LSE_i(Z[i,j] + u[i]); since Z[i,j] + u[i] = log e_ij + (M_i + u[i]) - v[j], it is
 //     LSE_i(Z[i,j] + u[i]) = log( sum_i e_ij * a_i ) - v[j]        with a_i = exp(M_i + u[i]) = mu_i / S_i   (<= 1),
@@ -589,19 +589,25 @@ __global__ __launch_bounds__(256) void ot_fused_pass_kernel(const float *__restr
         if (j < ld) q = *reinterpret_cast<const float4 *>(vvec + j);
         vv[t][0] = q.x; vv[t][1] = q.y; vv[t][2] = q.z; vv[t][3] = q.w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            if (j + e >= C) vv[t][e] = NEG;                  // padding columns: Z + v = -inf, their exponentials are exactly 0
+            acc[t][e] = 0.f;
+        }
     }
     // rows stream through a ring of four register buffers: three rows are in flight while one is reduced (one row per workgroup in
     // flight is ~10 KB; memory latency under load is several microseconds, so depth is what buys bandwidth here)
     float4 buf[4][NV];
+    // unconditional loads (pieces beyond the pitch re-read the row's last piece and are masked by `< C` below): exec-masked loads make
+    // the compiler's wait-count bookkeeping fall back to vmcnt(0), which would drain the whole prefetch ring at every row
+    int jc[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) jc[t] = min(t * 1024 + tid * 4, ld - 4);
     auto load_row = [&](int r, float4 (&dst)[NV]) {
         const float *row = Z + (size_t)(r < r1 ? r : r1 - 1) * ld;
 #pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            const int j = t * 1024 + tid * 4;
-            dst[t] = j < ld ? *reinterpret_cast<const float4 *>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int t = 0; t < NV; ++t) dst[t] = *reinterpret_cast<const float4 *>(row + jc[t]);
     };
+    float my_u = 0.f;
     auto process = [&](int r, const float4 (&cur)[NV]) {
         float x[NV][4];
         float mx = NEG;
@@ -610,43 +616,50 @@ __global__ __launch_bounds__(256) void ot_fused_pass_kernel(const float *__restr
             const float z[4] = {cur[t].x, cur[t].y, cur[t].z, cur[t].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                x[t][e] = t * 1024 + tid * 4 + e < C ? z[e] + vv[t][e] : NEG;
+                x[t][e] = z[e] + vv[t][e];
                 mx = fmaxf(mx, x[t][e]);
             }
         }
+        // exponentials relative to the WAVE's maximum first (no cross-wave dependency), one barrier to combine the four (max, sum)
+        // pairs, then the wave's factor exp(M_w - M) rides on a_i
         mx = wave_max(mx);
-        const int par = r & 1;
-        if (lane == 0) smx[par][w] = mx;
-        __syncthreads();
-        const float M = fmaxf(fmaxf(smx[par][0], smx[par][1]), fmaxf(smx[par][2], smx[par][3]));      // finite: the dustbin column is
+        const float LOG2E = 1.44269504088896340736f;
+        const float mneg = mx > NEG ? -mx * LOG2E : 0.f;     // exp(x - M_w) = 2^(x log2 e - M_w log2 e): one fma + v_exp_f32 per element
         float sm = 0.f;
 #pragma unroll
         for (int t = 0; t < NV; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { x[t][e] = __expf(x[t][e] - M); sm += x[t][e]; }               // e_ij (0 for the padding)
+            for (int e = 0; e < 4; ++e) { x[t][e] = __builtin_amdgcn_exp2f(fmaf(x[t][e], LOG2E, mneg)); sm += x[t][e]; }   // e_ij * exp(M - M_w); 0 for the padding
         sm = wave_sum(sm);
-        if (lane == 0) ssum[par][w] = sm;
+        const int par = r & 1;
+        if (lane == 0) { smx[par][w] = mx; ssum[par][w] = sm; }
         __syncthreads();
-        const float S = (ssum[par][0] + ssum[par][1]) + (ssum[par][2] + ssum[par][3]);
+        const float M = fmaxf(fmaxf(smx[par][0], smx[par][1]), fmaxf(smx[par][2], smx[par][3]));      // finite: the dustbin column is
+        float S = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S += smx[par][q] > NEG ? ssum[par][q] * __expf(smx[par][q] - M) : 0.f;
         const float lmu = r == R - 1 ? last_extra + normc : normc;
         const float logS = __logf(S);
-        if (tid == 0) uout[r] = lmu - (M + logS);
-        const float ai = __expf(lmu - logS);                                                          // exp(M + u[i]) = mu_i / S_i
+        if (tid == r - r0) my_u = lmu - (M + logS);                // written after the loop: a store inside it would be waited on (vmcnt) and drain the prefetch
+        const float ai = (mx > NEG && r < r1) ? __expf((lmu - logS) + (mx - M)) : 0.f;                            // exp(M_w + u[i]) = (mu_i / S_i) exp(M_w - M)
 #pragma unroll
         for (int t = 0; t < NV; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(x[t][e], ai, acc[t][e]);
     };
-    load_row(r0, buf[0]); load_row(r0 + 1, buf[1]); load_row(r0 + 2, buf[2]);
+    // program order of the row loads is pinned (VMEM operations complete in order, so "row r has landed" is a count of younger loads)
+    load_row(r0, buf[0]); __builtin_amdgcn_sched_barrier(0);
+    load_row(r0 + 1, buf[1]); __builtin_amdgcn_sched_barrier(0);
+    load_row(r0 + 2, buf[2]); __builtin_amdgcn_sched_barrier(0);
     for (int r = r0; r < r1; r += 4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (r + k < r1) {                                   // uniform over the workgroup
-                load_row(r + k + 3, buf[(k + 3) & 3]);
-                process(r + k, buf[k]);
-            }
+        for (int k = 0; k < 4; ++k) {                           // branch-free body (rows past the block re-read its last row and add
+            load_row(r + k + 3, buf[(k + 3) & 3]);              // nothing): one basic block keeps the wait counts exact
+            __builtin_amdgcn_sched_barrier(0);
+            process(r + k, buf[k]);
         }
     }
+    if (tid < r1 - r0) uout[r0 + tid] = my_u;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const int j = t * 1024 + tid * 4;
@@ -737,14 +750,16 @@ __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restri
         i0 += a; v0 += a; m0 += a; s0 += a; i1 += b; m1 += b; s1 += b;
     }
     const int t = blockIdx.x * 256 + threadIdx.x;
+    // an arg-max over a row of NaNs (non-finite descriptors) leaves the sentinel index: such a point is unmatched, never dereferenced
     if (t < m) {
-        const bool mu = i1[i0[t]] == (int64_t)t;
-        m0[t] = mu ? i0[t] : -1;
+        const int64_t a = i0[t];
+        const bool mu = a >= 0 && a < n && i1[a] == (int64_t)t;
+        m0[t] = mu ? a : -1;
         s0[t] = mu ? expf(v0[t]) : 0.f;
     }
     if (t < n) {
         const int64_t a = i1[t];
-        const bool mu1 = i0[a] == (int64_t)t;           // mutual1; then valid0[a] is the same predicate seen from a
+        const bool mu1 = a >= 0 && a < m && i0[a] == (int64_t)t;           // mutual1; then valid0[a] is the same predicate seen from a
         m1[t] = mu1 ? a : -1;
         s1[t] = mu1 ? expf(v0[a]) : 0.f;
     }
