@@ -128,7 +128,7 @@ int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, in
 /* Mutual check + ordered compaction: for i in 0..m-1 (increasing) keep (i, nn01[i]) iff nn10[nn01[i]]==i;
  * pairs are mapped through sample0/sample1 (int64, NULL = identity) and written to match_out int64 [*,2];
  * *count_out (device int32) receives the number kept.  test/matcher.py:98-107. */
-int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m,
+int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m, int n /* entries of nn10 */,
                          const int64_t *sample0, const int64_t *sample1,
                          int64_t *match_out, int32_t *count_out, void *stream);
 

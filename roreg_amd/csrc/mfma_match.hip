@@ -266,7 +266,9 @@ __global__ __launch_bounds__(1024) void mm_mutual_kernel(const MatchTask *__rest
         int64_t j = 0;
         if (i < m) {
             j = (int64_t)(p01[i] & 0xffffffffu);
-            keep = (int64_t)(p10[j] & 0xffffffffu) == (int64_t)i;
+            // a key that no candidate ever updated (non-finite descriptors: every comparison with NaN is false) keeps its initial
+            // index bits; such a point is unmatched, and the index is never dereferenced
+            keep = j < (int64_t)t.m1 && (int64_t)(p10[j] & 0xffffffffu) == (int64_t)i;
         }
         const unsigned long long mask = __ballot(keep);
         const int before = __popcll(mask & ((1ull << lane) - 1ull));

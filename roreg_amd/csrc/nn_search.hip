@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float *__restrict_
 }
 
 // mutual check + ordered compaction by a single workgroup (m <= a few thousand)
-__global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict__ nn01, const int64_t *__restrict__ nn10, int m,
+__global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict__ nn01, const int64_t *__restrict__ nn10, int m, int n,
                                                       const int64_t *__restrict__ sample0, const int64_t *__restrict__ sample1,
                                                       int64_t *__restrict__ match_out, int32_t *__restrict__ count_out) {
     __shared__ int wave_cnt[16];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict_
         int64_t j = 0;
         if (i < m) {
             j = nn01[i];
-            keep = nn10[j] == (int64_t)i;
+            keep = j >= 0 && j < (int64_t)n && nn10[j] == (int64_t)i;       // an index no comparison ever set (NaN distances) is "unmatched", never dereferenced
         }
         const unsigned long long mask = __ballot(keep);
         const int before = __popcll(mask & ((1ull << lane) - 1ull));
@@ -277,10 +277,10 @@ extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n
     ROREG_CHECK_LAUNCH("roreg_knn_search");
     return 0;
 }
-extern "C" int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m, const int64_t *sample0,
+extern "C" int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m, int n, const int64_t *sample0,
                                     const int64_t *sample1, int64_t *match_out, int32_t *count_out, void *stream) {
     ROREG_REQUIRE(count_out && m >= 0 && (m == 0 || (nn01 && nn10 && match_out)), "roreg_mutual_matches: bad arguments");
-    hipLaunchKernelGGL(mutual_kernel, dim3(1), dim3(1024), 0, roreg::as_stream(stream), nn01, nn10, m, sample0, sample1,
+    hipLaunchKernelGGL(mutual_kernel, dim3(1), dim3(1024), 0, roreg::as_stream(stream), nn01, nn10, m, n, sample0, sample1,
                        match_out, count_out);
     ROREG_CHECK_LAUNCH("roreg_mutual_matches");
     return 0;

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-        idx[(size_t)i * K + q] = bi[q];
+        // fewer than K comparable targets (NaN dot products compare false): the empty slots point at row 0 -- a valid address for the
+        // gathers downstream; the values are meaningless either way
+        idx[(size_t)i * K + q] = bi[q] == 0x7fffffff ? 0 : bi[q];
         if (val) val[(size_t)i * K + q] = bv[q];
     }
 }

@@ -50,7 +50,7 @@ PROTOTYPES = {
     'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_knn_search_workspace': (c_size_t, [c_int, c_int]),
     'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
-    'roreg_mutual_matches': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P]),
+    'roreg_mutual_matches': (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     'roreg_mutual_match_batch_workspace': (c_size_t, [c_int, c_int]),
     'roreg_mutual_match_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     'roreg_des2r': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
@@ -313,7 +313,7 @@ def mutual_matches(nn01, nn10, sample0=None, sample1=None):
     m = nn01.shape[0]
     out = torch.empty((max(m, 1), 2), dtype=torch.int64, device=nn01.device)
     cnt = torch.zeros(1, dtype=torch.int32, device=nn01.device)
-    _check(lib().roreg_mutual_matches(_ptr(nn01, torch.int64), _ptr(nn10, torch.int64), m, _ptr(sample0, torch.int64),
+    _check(lib().roreg_mutual_matches(_ptr(nn01, torch.int64), _ptr(nn10, torch.int64), m, int(nn10.shape[0]), _ptr(sample0, torch.int64),
                                       _ptr(sample1, torch.int64), _ptr(out), _ptr(cnt), _stream()), 'roreg_mutual_matches')
     return out, cnt
 

@@ -196,3 +196,15 @@ def test_config5_outdoor_scale_scene(group):
         R = r.trans[:3, :3]
         assert np.abs(R @ R.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
         assert r.n_match > 2500
+
+
+@pytest.mark.parametrize('case', ['engine_mutual_yohoo', 'engine_rd_rm_yohoo'])
+def test_non_finite_inputs_do_not_fault_the_device(case):
+    """NaN / inf features and keypoints (tools/nan_robustness.py, one process per case so that a device fault would be a test failure
+    and not the end of the suite): points whose comparisons are all false come out unmatched -- no sentinel index is ever dereferenced
+    (mutual check, top-k lists, Sinkhorn read-out)."""
+    import os, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'nan_robustness.py')
+    r = subprocess.run([sys.executable, tool, case], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert f'{case} ok' in r.stdout
