@@ -1,37 +1,44 @@
-"""Test-time configuration: the same flags, defaults and `get_config()` contract as the reference's
-parses/parses_test.py:24-59 (flat argparse namespace consumed as `cfg` by every stage/network ctor).
-Additions (do not rename anything existing): --devices, --resident."""
+"""Test-time configuration with the reference's flag names, defaults and `get_config()` contract (parses/parses_test.py:24-59):
+one flat argparse namespace that every stage and network constructor receives as `cfg`.  The flags are declared as a table."""
 import argparse
 
 base_dir = './data'
 backbone = 'FCGF'
 
+# (group, flag, default, type or None for a store_true switch, help)
+_FLAGS = [
+    ('Dirs', 'base_dir', base_dir, str, 'root of the data tree; results.log is appended here'),
+    ('Dirs', 'origin_data_dir', f'{base_dir}/origin_data', str, 'benchmark scenes (clouds, keypoint lists, gt.log / gt.info)'),
+    ('Dirs', 'backbone', backbone, str, 'name of the dense descriptor backbone the group features were built from'),
+    ('Dirs', 'output_cache_fn', f'{base_dir}/YOHO_{backbone}/Testset', str, 'inter-stage files of the evaluation'),
+    ('Dirs', 'model_fn', f'./checkpoints/{backbone}', str, 'checkpoints: {GF,RD,RM,ET}/model_best.pth below this directory'),
+    ('Dirs', 'SO3_related_files', './utils/group_related', str, 'icosahedral group tables (.npy); validated against the built-in copy'),
+    ('Test_Args', 'GF', 'yoho_des', str, 'group-feature extractor'),
+    ('Test_Args', 'RD', False, None, 'rotation-guided detector + NMS keypoint sampling'),
+    ('Test_Args', 'RM', False, None, 'rotation-coherence matcher instead of mutual nearest neighbours'),
+    ('Test_Args', 'ET', 'yohoc', str, 'estimator: yohoc (rotation-bin 3-point RANSAC) or yohoo (one-shot RANSAC)'),
+    ('Test_Args', 'testset', '3dmatch', str, '3dmatch | 3dLomatch | ETH | demo'),
+    ('Test_Args', 'keynum', 5000, int, 'keypoints per cloud'),
+    ('Test_Args', 'max_iter', 1000, int, 'RANSAC hypotheses'),
+    ('Test_Args', 'ransac_ird', 0.1, float, 'inlier distance of RANSAC [m]'),
+    ('Test_Args', 'tau_1', 0.05, float, 'inlier-ratio threshold of the feature matching recall'),
+    ('Test_Args', 'tau_2', 0.1, float, 'inlier distance of the feature matching recall [m]'),
+    ('Test_Args', 'tau_3', 0.2, float, 'RMSE threshold of the registration recall [m]'),
+    ('Test_Args', 'match_n', 0.5, float, 'share of the best-scored correspondences handed to the estimator (>= 1: a count; 0.99: all)'),
+    ('Test_Args', 'bs_GF', 1250, int, 'keypoints per extractor batch'),
+    ('Test_Args', 'bs_ET', 1000, int, 'correspondences per local-transform batch'),
+]
+
 
 def build_parser():
     parser = argparse.ArgumentParser()
-    dirs = parser.add_argument_group('Dirs')
-    dirs.add_argument('--base_dir', type=str, default=base_dir, help='base dir containing the whole project')
-    dirs.add_argument('--origin_data_dir', type=str, default=f'{base_dir}/origin_data', help='the dir containing whole datas')
-    dirs.add_argument('--backbone', type=str, default=backbone, help='name of backbone')
-    dirs.add_argument('--output_cache_fn', type=str, default=f'{base_dir}/YOHO_{backbone}/Testset', help='eval cache dir')
-    dirs.add_argument('--model_fn', type=str, default=f'./checkpoints/{backbone}', help='well trained model path')
-    dirs.add_argument('--SO3_related_files', type=str, default='./utils/group_related', help='SO3 related files path')
-    t = parser.add_argument_group('Test_Args')
-    t.add_argument('--GF', default='yoho_des', type=str)
-    t.add_argument('--RD', action='store_true')
-    t.add_argument('--RM', action='store_true')
-    t.add_argument('--ET', default='yohoc', type=str, help='ransac/yohoc/yohoo')
-    t.add_argument('--testset', default='3dmatch', type=str, help='testset name')
-    t.add_argument('--keynum', default=5000, type=int, help='number of keypoints')
-    t.add_argument('--max_iter', default=1000, type=int, help='ransac iterations')
-    t.add_argument('--ransac_ird', default=0.1, type=float, help='inliner threshold of ransac')
-    t.add_argument('--tau_1', default=0.05, type=float, help='tau 1 for FMR, 5%%')
-    t.add_argument('--tau_2', default=0.1, type=float, help='tau 2 for FMR, 0.1m')
-    t.add_argument('--tau_3', default=0.2, type=float, help='tau 3 for RR, 0.2m')
-    t.add_argument('--match_n', default=0.5, type=float,
-                   help='use how many correspondences predicted for transformation estimation, 0.99 to use all, if n>=1, use top-n')
-    t.add_argument('--bs_GF', default=1250, type=int, help='test batch size for group feature extraction')
-    t.add_argument('--bs_ET', default=1000, type=int, help='test batch size for local transformation estimation')
+    groups = {}
+    for group, name, default, kind, text in _FLAGS:
+        g = groups.setdefault(group, parser.add_argument_group(group))
+        if kind is None:
+            g.add_argument(f'--{name}', action='store_true', help=text)
+        else:
+            g.add_argument(f'--{name}', default=default, type=kind, help=text)
     return parser
 
 
@@ -39,8 +46,8 @@ parser = build_parser()
 
 
 def get_config():
-    config, unparsed = parser.parse_known_args()
-    return config, unparsed
+    """(namespace, unparsed arguments) -- Test.py's two parsers read the same sys.argv, hence parse_known_args."""
+    return parser.parse_known_args()
 
 
 def default_config(**overrides):

@@ -1,11 +1,11 @@
-"""Stage registry (mirror of test/__init__.py:6-22)."""
-from .extractor import yoho_des
+"""The reference's stage registries (test/__init__.py:6-22): stage classes are looked up by the names the command line uses."""
+from . import detector, estimator, extractor, matcher
 from .detector import yoho_det
+from .estimator import (R_pre_log, extractor_dr_index, extractor_localtrans, refiner, yohoc, yohoc_ransac, yohoo, yohoo_ransac)
+from .extractor import yoho_des
 from .matcher import NMS_sample, mutual, yoho_mat
-from .estimator import (R_pre_log, refiner, extractor_dr_index, yohoc_ransac, yohoc, extractor_localtrans, yohoo_ransac,
-                        yohoo)
 
-name2extractor = {'yoho_des': yoho_des}
-name2detector = {'yoho_det': yoho_det}
-name2matcher = {'matmul': mutual, 'yoho_mat': yoho_mat}
-name2estimator = {'yohoc': yohoc, 'yohoo': yohoo}
+name2extractor = dict(yoho_des=yoho_des)
+name2detector = dict(yoho_det=yoho_det)
+name2matcher = dict(matmul=mutual, yoho_mat=yoho_mat)
+name2estimator = dict(yohoc=yohoc, yohoo=yohoo)

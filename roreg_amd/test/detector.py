@@ -1,5 +1,9 @@
-"""Stage 2: rotation-guided detector (mirror of test/detector.py:10-47).
-Reads YOHO_Output_Group_feature/{pc}.npy, writes det_score/{pc}.npy [N] f32 holding rank/N."""
+"""Stage 2 -- rotation-guided detector behind the reference's `yoho_det` interface (test/detector.py:10-47).
+
+    in : {cache}/{scene}/YOHO_Output_Group_feature/{pc}.npy   float32 [N,32,60]
+    out: {cache}/{scene}/det_score/{pc}.npy                   float32 [N]: the RANK of the keypoint's saliency divided by N
+
+The rank transform (detector.py:45-46) is what the NMS sampling of the matcher compares; raw scores are never stored."""
 import os
 
 import numpy as np
@@ -9,38 +13,38 @@ from tqdm import tqdm
 from ..group import tables
 from ..network import name2network
 from ..utils import utils
-from .extractor import scene_feature_name
+from .extractor import scene_feature_name, restore_weights
+
+
+def rank_scores(raw):
+    """scores[argsort(scores)] = arange(N)/N, in place on a copy (detector.py:45-46; numpy's default argsort, as there)."""
+    out = np.array(raw, copy=True)
+    out[np.argsort(out)] = np.arange(out.shape[0]) / out.shape[0]
+    return out
 
 
 class yoho_det():
     def __init__(self, cfg):
         self.cfg = cfg
         self.network = name2network['RD_test'](cfg)
-        self.best_model_fn = f'{self.cfg.model_fn}/RD/model_best.pth'
-        self.Rgroup = tables(self.cfg.SO3_related_files).R.astype(np.float32)
+        self.best_model_fn = f'{cfg.model_fn}/RD/model_best.pth'
+        self.Rgroup = tables(cfg.SO3_related_files).R.astype(np.float32)
         self._load_model()
 
     def _load_model(self):
-        if os.path.exists(self.best_model_fn):
-            checkpoint = utils.load_checkpoint(self.best_model_fn)
-            self.network.load_state_dict(checkpoint['network_state_dict'], strict=True)
-        else:
-            raise ValueError("No model exists")
+        restore_weights(self.network, self.best_model_fn, strict=True)
 
     def run(self, dataset):
         self.network.eval()
-        datasetname = scene_feature_name(dataset)
-        savedir = f'{self.cfg.output_cache_fn}/{datasetname}/det_score'
-        utils.make_non_exists_dir(savedir)
+        scene = scene_feature_name(dataset)
+        feat_dir = f'{self.cfg.output_cache_fn}/{scene}/YOHO_Output_Group_feature'
+        out_dir = f'{self.cfg.output_cache_fn}/{scene}/det_score'
+        utils.make_non_exists_dir(out_dir)
         print(f'Evaluating the saliency of points using rotaion guided detector on {dataset.name}')
-        for pc_id in tqdm(range(len(dataset.pc_ids))):
-            if os.path.exists(f'{savedir}/{pc_id}.npy'):
+        for pc in tqdm(range(len(dataset.pc_ids))):
+            if os.path.exists(f'{out_dir}/{pc}.npy'):
                 continue
-            feats = np.load(f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature/{pc_id}.npy')
-            batch = {'feats': torch.from_numpy(feats.astype(np.float32))}
+            feats = torch.from_numpy(np.load(f'{feat_dir}/{pc}.npy').astype(np.float32))
             with torch.no_grad():
-                scores = self.network(batch)['scores'].cpu().numpy()
-            # normalization for NMS comparison only (detector.py:45-46)
-            argscores = np.argsort(scores)
-            scores[argscores] = np.arange(scores.shape[0]) / scores.shape[0]
-            np.save(f'{savedir}/{pc_id}.npy', scores)
+                raw = self.network({'feats': feats})['scores'].cpu().numpy()
+            np.save(f'{out_dir}/{pc}.npy', rank_scores(raw))

@@ -155,20 +155,12 @@ class yohoc_ransac:
         self.refiner = refiner()
 
     def DR_statictic(self, DR_indexs):
-        stat = {i: [] for i in range(60)}
-        for t in range(DR_indexs.shape[0]):
-            stat[int(DR_indexs[t])].append(t)
-        prob = []
-        for i in range(60):
-            if len(stat[i]) < 2:
-                prob.append(0)
-            else:
-                num = float(len(stat[i])) / 100.0
-                prob.append(num * (num - 0.01) * (num - 0.02))
-        prob = np.array(prob)
-        if np.sum(prob) == 0:
-            return None, np.zeros(60)
-        return stat, prob / np.sum(prob)
+        """(correspondences per coarse rotation as {rotation: [rows]}, sampling probability per rotation) -- estimator.py:119-137;
+        (None, zeros) when no rotation collects two correspondences."""
+        counts, members, starts, prob = dr_bins(np.asarray(DR_indexs).reshape(-1))
+        if not prob.any():
+            return None, prob
+        return {r: members[starts[r]:starts[r] + counts[r]].tolist() for r in range(60)}, prob
 
     def Threepps2Tran(self, kps0_init, kps1_init):
         return three_point_transforms(np.asarray(kps0_init)[None], np.asarray(kps1_init)[None])[0]          # 3*4

@@ -1,5 +1,8 @@
-"""Orchestration + metrics (mirror of test/evaluator.py:13-145): runs the four stages per scene, then FMR / IR /
-RR(pointdsc) / RR(predator) and appends {base_dir}/results.log in the reference's text format."""
+"""Scene orchestration and benchmark metrics behind the reference's `yoho_evaluator` interface (test/evaluator.py:13-145).
+
+`process_scene` chains extractor -> [detector] -> matcher -> estimator on the file-coupled stage classes; `run` then reports
+feature-matching recall, inlier ratio, the PointDSC-style registration recall (RRE < 15 deg and RTE < 0.3 m, errors averaged over the
+successes) and the Predator / Redwood recall of utils.RR_cal, and appends the reference's text block to {base_dir}/results.log."""
 import numpy as np
 
 from ..utils import RR_cal
@@ -7,108 +10,84 @@ from ..utils.r_eval import compute_R_diff
 from ..utils.utils import transform_points
 from . import name2extractor, name2detector, name2matcher, name2estimator
 
+RRE_MAX_DEG, RTE_MAX_M = 15, 0.3            # success thresholds of the pointdsc-style recall (evaluator.py:81)
+
+
+def _scenes(datasets):
+    """The dataset objects of a benchmark dict (its string entries are names, evaluator.py:93-95)."""
+    return [d for d in datasets.values() if not isinstance(d, str)]
+
 
 class yoho_evaluator:
     def __init__(self, cfg):
         self.cfg = cfg
-        self.GF = self.cfg.GF
-        self.RD = self.cfg.RD
-        self.RM = self.cfg.RM
-        self.ET = self.cfg.ET
-        self.keynum = self.cfg.keynum
-        self.max_iter = self.cfg.max_iter
-        self.extractor = name2extractor[self.GF](self.cfg)
-        self.detector = None
-        self.matcher = name2matcher['matmul'](self.cfg)
-        self.estimator = name2estimator[self.ET](self.cfg)
-        if self.RD:
-            self.RD = 'yoho_det'
-            self.detector = name2detector['yoho_det'](self.cfg)
-        else:
-            self.RD = 'nodet'
-        if self.RM:
-            self.RM = 'yoho_mat'
-            self.matcher = name2matcher['yoho_mat'](self.cfg)
-        else:
-            self.RM = 'matmul'
+        self.GF, self.ET = cfg.GF, cfg.ET
+        self.keynum, self.max_iter = cfg.keynum, cfg.max_iter
+        # the flags become the stage names that label the results.log entry (evaluator.py:24-37)
+        self.RD = 'yoho_det' if cfg.RD else 'nodet'
+        self.RM = 'yoho_mat' if cfg.RM else 'matmul'
+        self.extractor = name2extractor[self.GF](cfg)
+        self.detector = name2detector[self.RD](cfg) if cfg.RD else None
+        self.matcher = name2matcher[self.RM](cfg)
+        self.estimator = name2estimator[self.ET](cfg)
 
+    # ---- stages ---------------------------------------------------------------------------------------------
     def process_scene(self, dataset):
-        self.extractor.run(dataset)
-        if self.detector is not None:
-            self.detector.run(dataset)
-        self.matcher.run(dataset, self.keynum)
-        self.estimator.run(dataset, self.keynum, self.max_iter)
+        stages = [(self.extractor, ()), (self.detector, ()), (self.matcher, (self.keynum,)), (self.estimator, (self.keynum, self.max_iter))]
+        for stage, args in stages:
+            if stage is not None:
+                stage.run(dataset, *args)
+
+    # ---- metrics --------------------------------------------------------------------------------------------
+    def _match_dir(self, dataset):
+        return f'{self.cfg.output_cache_fn}/{dataset.name}/match_{self.keynum}'
 
     def fmr_ir_scene(self, dataset):
-        fmrs, irs = [], []
-        for pair in dataset.pair_ids:
-            id0, id1 = pair
-            corr = np.load(f'{self.cfg.output_cache_fn}/{dataset.name}/match_{self.keynum}/{id0}-{id1}.npy')
-            corr_s = np.load(f'{self.cfg.output_cache_fn}/{dataset.name}/match_{self.keynum}/scores/{id0}-{id1}.npy')
+        """(feature matching recall, mean inlier ratio) of a scene; with the rotation-coherence matcher only the best-scored
+        share `match_n` of the correspondences counts (evaluator.py:55-59)."""
+        ratios = []
+        for a, b in dataset.pair_ids:
+            pairs = np.load(f'{self._match_dir(dataset)}/{a}-{b}.npy')
             if self.cfg.RM:
-                num = max(corr_s.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
-                corr = corr[np.argsort(corr_s)[-int(num):]]
-            keysm0 = dataset.get_kps(id0)[corr[:, 0]]
-            keysm1 = dataset.get_kps(id1)[corr[:, 1]]
-            gt = dataset.get_transform(id0, id1)
-            keysm1 = transform_points(keysm1, gt)
-            dist = np.sqrt(np.sum(np.square(keysm0 - keysm1), axis=-1))
-            ir = np.mean(dist < self.cfg.tau_2)
-            irs.append(ir)
-            fmrs.append(1 if ir > self.cfg.tau_1 else 0)
-        return np.mean(np.array(fmrs)), np.mean(np.array(irs))
+                w = np.load(f'{self._match_dir(dataset)}/scores/{a}-{b}.npy')
+                keep = max(w.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
+                pairs = pairs[np.argsort(w)[-int(keep):]]
+            p0 = dataset.get_kps(a)[pairs[:, 0]]
+            p1 = transform_points(dataset.get_kps(b)[pairs[:, 1]], dataset.get_transform(a, b))
+            ratios.append(np.mean(np.sqrt(np.sum(np.square(p0 - p1), axis=-1)) < self.cfg.tau_2))
+        hits = [1 if r > self.cfg.tau_1 else 0 for r in ratios]
+        return np.mean(np.array(hits)), np.mean(np.array(ratios))
 
     def rr_scene(self, dataset):
-        rrs, rre, rte = [], [], []
-        for pair in dataset.pair_ids:
-            id0, id1 = pair
-            gt = dataset.get_transform(id0, id1)
-            trans = np.load(f'{self.cfg.output_cache_fn}/{dataset.name}/match_{self.keynum}/{self.ET}/{self.max_iter}iters/{id0}-{id1}.npz')['trans']
-            Rpre, tpre = trans[0:3, 0:3], trans[0:3, -1]
-            Rgt, tgt = gt[0:3, 0:3], gt[0:3, -1]
-            Rdiff = compute_R_diff(Rpre, Rgt)
-            tdiff = np.sqrt(np.sum(np.square(tpre - tgt)))
-            if (Rdiff < 15) and (tdiff < 0.3):
-                rrs.append(1); rre.append(Rdiff); rte.append(tdiff)      # pointdsc: errors over successes only
-            else:
-                rrs.append(0)
-        return np.mean(np.array(rrs)), np.mean(np.array(rre)), np.mean(np.array(rte))
+        """(registration recall, mean RRE, mean RTE) with the errors averaged over the successful pairs only."""
+        ok, e_rot, e_tra = [], [], []
+        for a, b in dataset.pair_ids:
+            T = np.load(f'{self._match_dir(dataset)}/{self.ET}/{self.max_iter}iters/{a}-{b}.npz')['trans']
+            G = dataset.get_transform(a, b)
+            dr = compute_R_diff(T[0:3, 0:3], G[0:3, 0:3])
+            dt = np.sqrt(np.sum(np.square(T[0:3, -1] - G[0:3, -1])))
+            good = (dr < RRE_MAX_DEG) and (dt < RTE_MAX_M)
+            ok.append(1 if good else 0)
+            if good:
+                e_rot.append(dr); e_tra.append(dt)
+        return np.mean(np.array(ok)), np.mean(np.array(e_rot)), np.mean(np.array(e_tra))
 
     def run(self, datasets=None):
         if datasets is None:
             from ..dataops.dataset import get_dataset_name
             datasets = get_dataset_name(self.cfg.testset, self.cfg.origin_data_dir)
-        for name, dataset in datasets.items():
-            if type(dataset) is str:
-                continue
-            self.process_scene(dataset)
-        fmrs, irs = [], []
-        for name, dataset in datasets.items():
-            if type(dataset) is str:
-                continue
-            fmr, ir = self.fmr_ir_scene(dataset)
-            fmrs.append(fmr); irs.append(ir)
-        fmr = np.mean(np.array(fmrs)); ir = np.mean(np.array(irs))
-        rr_dsc, rre_dsc, rte_dsc = [], [], []
-        for name, dataset in datasets.items():
-            if type(dataset) is str:
-                continue
-            rr, rre, rte = self.rr_scene(dataset)
-            rr_dsc.append(rr); rre_dsc.append(rre); rte_dsc.append(rte)
-        rr_dsc = np.mean(np.array(rr_dsc)); rre_dsc = np.mean(np.array(rre_dsc)); rte_dsc = np.mean(np.array(rte_dsc))
-        if datasets['wholesetname'] == 'demo':
-            rr_predator = 1.0
-        else:
-            rr_predator, _, _ = RR_cal.benchmark(self.cfg, datasets, self.keynum, self.max_iter, yoho_sign=self.ET)
-        datasetname = datasets['wholesetname']
-        msg = f'{datasetname}-{self.GF}-{self.RD}-{self.RM}-{self.ET}-{self.keynum}keys-{self.max_iter}iters\n'
-        msg += f'feature matching recall          : {fmr:.5f}\n' \
-               f'inlier ratio                     : {ir:.5f}\n' \
-               f'registration recall(predator)    : {rr_predator:.5f}\n' \
-               f'rotation error(pointdsc)         : {rre_dsc:.5f}\n' \
-               f'translation error(pointdsc)      : {rte_dsc:.5f}\n' \
-               f'registration recall(pointdsc)    : {rr_dsc:.5f}'
+        scenes = _scenes(datasets)
+        for d in scenes:
+            self.process_scene(d)
+        per_scene = np.array([self.fmr_ir_scene(d) + self.rr_scene(d) for d in scenes])      # [scene, (fmr, ir, rr, rre, rte)]
+        fmr, ir, rr, rre, rte = (np.mean(per_scene[:, c]) for c in range(5))
+        whole = datasets['wholesetname']
+        rr_predator = 1.0 if whole == 'demo' else RR_cal.benchmark(self.cfg, datasets, self.keynum, self.max_iter, yoho_sign=self.ET)[0]
+        rows = [('feature matching recall', fmr), ('inlier ratio', ir), ('registration recall(predator)', rr_predator),
+                ('rotation error(pointdsc)', rre), ('translation error(pointdsc)', rte), ('registration recall(pointdsc)', rr)]
+        msg = f'{whole}-{self.GF}-{self.RD}-{self.RM}-{self.ET}-{self.keynum}keys-{self.max_iter}iters\n'
+        msg += '\n'.join(f'{label:<33}: {value:.5f}' for label, value in rows)
         with open(f'{self.cfg.base_dir}/results.log', 'a') as f:
             f.write(msg + '\n')
         print(msg)
-        return {'fmr': fmr, 'ir': ir, 'rr_predator': rr_predator, 'rre': rre_dsc, 'rte': rte_dsc, 'rr': rr_dsc}
+        return {'fmr': fmr, 'ir': ir, 'rr_predator': rr_predator, 'rre': rre, 'rte': rte, 'rr': rr}

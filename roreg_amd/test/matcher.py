@@ -35,23 +35,21 @@ class NMS_sample():
         return self.sample_from_neighbours(scores, argmin)
 
     def sample_from_neighbours(self, scores, argmin):
-        """The selection of matcher.py:24-41 given the k nearest neighbours (self included) of every keypoint, argmin [N,k]."""
-        scores_nei = scores[argmin.reshape(-1)].reshape(-1, self.k)
-        nei_max = np.max(scores_nei, axis=-1)
-        sam_indexs = np.where(scores >= nei_max)[0]
-        if sam_indexs.shape[0] > self.num:
-            sam_scores = scores[sam_indexs]
-            sam_scores = sam_scores / np.sum(sam_scores)
-            resam_indexs = np.argsort(sam_scores)[-self.num:]
-            sam_indexs = sam_indexs[resam_indexs]
-        if sam_indexs.shape[0] < self.num:
-            left = self.num - sam_indexs.shape[0]
-            index_left = np.where(scores < nei_max)[0]
-            scores_left = scores[index_left]
-            left_index = np.argsort(scores_left)[-left:]
-            left_index = index_left[left_index]
-            sam_indexs = np.concatenate([sam_indexs, left_index], axis=0)
-        return sam_indexs
+        """The selection of matcher.py:24-41 given the k nearest neighbours (self included) of every keypoint, argmin [N,k]:
+        keypoints that are the maximum of their neighbourhood survive; too many -> the `num` best of them; too few -> filled up with
+        the best-scoring suppressed keypoints (survivors first, then the fill, each in the order numpy's argsort gives)."""
+        peak = np.max(scores[argmin.reshape(-1)].reshape(-1, self.k), axis=-1)
+        chosen = np.where(scores >= peak)[0]
+        if chosen.shape[0] > self.num:
+            w = scores[chosen]
+            w = w / np.sum(w)                                   # as in the reference: the ranking is taken on the normalised scores
+            chosen = chosen[np.argsort(w)[-self.num:]]
+        missing = self.num - chosen.shape[0]
+        if missing > 0:
+            suppressed = np.where(scores < peak)[0]
+            fill = suppressed[np.argsort(scores[suppressed])[-missing:]]
+            chosen = np.concatenate([chosen, fill], axis=0)
+        return chosen
 
 
 def _sample_pair(cfg, sampler, dataset, datasetname, id0, id1, n0, n1, keynum):

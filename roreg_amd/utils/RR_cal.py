@@ -36,88 +36,74 @@ def computeTransformationErr(trans, info):
 
 
 def read_trajectory(filename, dim=4):
+    """A Redwood .log trajectory: blocks of one header line 'i <tab> j <tab> n' and `dim` matrix rows -> (keys [n,3] str, [n,dim,dim])."""
     with open(filename) as f:
-        lines = f.readlines()
-    keys = lines[0::(dim + 1)]
-    final_keys = [[c.strip() for c in k.split('\t')[0:3]] for k in keys]
-    traj = [lines[i].split('\t')[0:dim] for i in range(len(lines)) if i % 5 != 0]
-    traj = np.asarray(traj, dtype=float).reshape(-1, dim, dim)
-    return np.asarray(final_keys), traj
+        rows = [line.split('\t') for line in f.readlines()]
+    heads = rows[0::dim + 1]
+    body = [r[0:dim] for k, r in enumerate(rows) if k % 5 != 0]            # the reference's `i % 5` (dim = 4), RR_cal.py:108
+    keys = np.asarray([[c.strip() for c in h[0:3]] for h in heads])
+    return keys, np.asarray(body, dtype=float).reshape(-1, dim, dim)
 
 
 read_pre_trajectory = read_trajectory
 
 
 def read_trajectory_info(filename, dim=6):
+    """A Redwood .info file: blocks of 'i j n_frames' + a dim x dim information matrix -> (n_frames, [n,dim,dim])."""
     with open(filename) as fid:
-        contents = fid.readlines()
-    n_pairs = len(contents) // 7
-    assert len(contents) == 7 * n_pairs
-    info_list = []
-    n_frame = 0
-    for i in range(n_pairs):
-        frame_idx0, frame_idx1, n_frame = [int(item) for item in contents[i * 7].strip().split()]
-        info_matrix = np.concatenate([np.array(item.strip().split(), dtype=float).reshape(1, -1)
-                                      for item in contents[i * 7 + 1:i * 7 + 7]], axis=0)
-        info_list.append(info_matrix)
-    return n_frame, np.asarray(info_list, dtype=float).reshape(-1, dim, dim)
+        lines = fid.readlines()
+    block = dim + 1
+    assert len(lines) % block == 0
+    n_frame, mats = 0, []
+    for k in range(0, len(lines), block):
+        n_frame = int(lines[k].strip().split()[2])
+        mats.append([np.array(l.strip().split(), dtype=float) for l in lines[k + 1:k + block]])
+    return n_frame, np.asarray(mats, dtype=float).reshape(-1, dim, dim)
 
 
 def extract_corresponding_trajectors(est_pairs, gt_pairs, gt_traj):
-    ext_traj = np.zeros((len(est_pairs), 4, 4))
-    for est_idx, pair in enumerate(est_pairs):
+    """Ground-truth pose of every estimated pair (its frame count is overwritten with the ground truth's first, RR_cal.py:226)."""
+    out = np.zeros((len(est_pairs), 4, 4))
+    for k, pair in enumerate(est_pairs):
         pair[2] = gt_pairs[0][2]
-        gt_idx = np.where((gt_pairs == pair).all(axis=1))[0]
-        ext_traj[est_idx, :, :] = gt_traj[gt_idx, :, :]
-    return ext_traj
+        out[k] = gt_traj[np.where((gt_pairs == pair).all(axis=1))[0]]
+    return out
 
 
 def evaluate_registration(num_fragment, result, result_pairs, gt_pairs, gt, gt_info, err2=0.2, nonconsecutive=True):
-    """RR_cal.py:236-317."""
-    err2 = err2 ** 2
-    gt_mask = np.zeros((num_fragment, num_fragment), dtype=int)
+    """Redwood protocol (RR_cal.py:236-317): a pair counts when its ground-truth index is > 0 in the lookup (so the very first
+    ground-truth pair is evaluated only in the consecutive protocol, where it is scored up front) and, in the default protocol, when
+    its fragments are not consecutive; success = information-weighted pose error <= err2^2.
+    -> (precision, recall, flags per estimate: 0 hit / 1 miss / 2 not evaluated, errors)."""
+    limit = err2 ** 2
+    lookup = np.zeros((num_fragment, num_fragment), dtype=int)
+    for k in range(gt_pairs.shape[0]):
+        i, j = int(gt_pairs[k, 0]), int(gt_pairs[k, 1])
+        if not nonconsecutive or abs(j - i) > 1:
+            lookup[i, j] = k
+    n_gt = np.sum(lookup > 0) + (0 if nonconsecutive else 1)
     flags, errors = [], []
-    if nonconsecutive:
-        for idx in range(gt_pairs.shape[0]):
-            i = int(gt_pairs[idx, 0]); j = int(gt_pairs[idx, 1])
-            if abs(j - i) > 1:
-                gt_mask[i, j] = idx
-        n_gt = np.sum(gt_mask > 0)
-    else:
-        for idx in range(gt_pairs.shape[0]):
-            i = int(gt_pairs[idx, 0]); j = int(gt_pairs[idx, 1])
-            gt_mask[i, j] = idx
-        n_gt = np.sum(gt_mask > 0) + 1
-    good = 0
-    n_res = 0
-    start_check = 0
-    if not nonconsecutive:
-        start_check = 1
-        n_res += 1
-        pose = result[0, :, :]
-        p = computeTransformationErr(np.linalg.inv(gt[0, :, :]) @ pose, gt_info[0, :, :])
+    tally = {'good': 0, 'seen': 0}
+
+    def score(pose, k):
+        p = computeTransformationErr(np.linalg.inv(gt[k, :, :]) @ pose, gt_info[k, :, :])
         errors.append(np.sqrt(p))
-        if p <= err2:
-            good += 1; flags.append(0)
-        else:
-            flags.append(1)
-    for idx in range(start_check, result_pairs.shape[0]):
-        i = int(result_pairs[idx, 0]); j = int(result_pairs[idx, 1])
-        pose = result[idx, :, :]
-        if gt_mask[i, j] > 0:
-            n_res += 1
-            gt_idx = gt_mask[i, j]
-            p = computeTransformationErr(np.linalg.inv(gt[gt_idx, :, :]) @ pose, gt_info[gt_idx, :, :])
-            errors.append(np.sqrt(p))
-            if p <= err2:
-                good += 1; flags.append(0)
-            else:
-                flags.append(1)
+        tally['seen'] += 1
+        tally['good'] += 1 if p <= limit else 0
+        flags.append(0 if p <= limit else 1)
+
+    first = 0
+    if not nonconsecutive:
+        score(result[0, :, :], 0)
+        first = 1
+    for idx in range(first, result_pairs.shape[0]):
+        k = lookup[int(result_pairs[idx, 0]), int(result_pairs[idx, 1])]
+        if k > 0:
+            score(result[idx, :, :], k)
         else:
             flags.append(2)
-    if n_res == 0:
-        n_res += 1e6
-    return good * 1.0 / n_res, good * 1.0 / n_gt, flags, errors
+    seen = tally['seen'] if tally['seen'] else 1e6
+    return tally['good'] * 1.0 / seen, tally['good'] * 1.0 / n_gt, flags, errors
 
 
 def benchmark(cfg, datasets, keynum, max_iter, yoho_sign='YOHO_O'):

@@ -144,6 +144,7 @@ def test_yohoc_sampling_replays_the_reference_generator_calls():
     same bins, same triples, same generator state afterwards; the vectorised bin statistics and the stacked 3-point Kabsch against
     their per-item forms, bitwise."""
     from roreg_amd import hip
+    from oracle import ref_numpy as O
     from roreg_amd.test.estimator import yohoc_ransac, dr_bins, three_point_transforms
 
     class Cfg:
@@ -157,8 +158,10 @@ def test_yohoc_sampling_replays_the_reference_generator_calls():
             dr = np.arange(M) % 60
         if trial == 7:
             dr = np.arange(60)[:min(M, 60)]                              # every bin has < 2 members
-        stat, prob = ref.DR_statictic(dr)
+        stat, prob = O.dr_statistic(dr)                                  # the oracle's literal loop (pinned to the reference goldens)
         counts, members, starts, prob_v = dr_bins(dr)
+        stat_api, prob_api = ref.DR_statictic(dr)                        # the stage class's method is built on dr_bins
+        assert np.array_equal(prob_api, prob) and (stat is None) == (stat_api is None) and (stat is None or stat_api == stat)
         assert np.array_equal(prob, prob_v)
         if stat is None:
             assert np.sum(prob_v) < 1e-5
