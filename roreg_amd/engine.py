@@ -421,14 +421,18 @@ class RegistrationEngine:
         # (<= 2 inliers: a failed registration) U V^T is not unique and the reference's value is LAPACK's; redo
         # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.
         from .test.estimator import _kabsch_host, _dev64
-        for i, (c0, c1, matches) in enumerate(full):
-            if i in skipped:
-                continue
-            if hip.stats_rank_deficient(st_host[i, 0]) or hip.stats_rank_deficient(st_host[i, 1]):
-                k0 = hip.gather_rows_f64(c0.keys, matches[:, 0].contiguous()); k1 = hip.gather_rows_f64(c1.keys, matches[:, 1].contiguous())
-                w = w_all[i] if w_all[i] is not None else torch.ones(matches.shape[0], dtype=torch.float64, device='cuda')
-                T1 = _kabsch_host(st_host[i, 0])
-                _, st = hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)
+        redo = [i for i in range(len(full)) if i not in skipped and
+                (hip.stats_rank_deficient(st_host[i, 0]) or hip.stats_rank_deficient(st_host[i, 1]))]
+        pending = []
+        for i in redo:                                                      # all second refinements are enqueued before the one download
+            c0, c1, matches = full[i]
+            k0 = hip.gather_rows_f64(c0.keys, matches[:, 0].contiguous()); k1 = hip.gather_rows_f64(c1.keys, matches[:, 1].contiguous())
+            w = w_all[i] if w_all[i] is not None else torch.ones(matches.shape[0], dtype=torch.float64, device='cuda')
+            T1 = _kabsch_host(st_host[i, 0])
+            pending.append(hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)[1])
+        if pending:
+            st_redo = torch.stack(pending).cpu().numpy()
+            for i, st in zip(redo, st_redo):
                 T_host[i] = _kabsch_host(st)
         local = full
         t0 = self._mark('ransac_finish', t0)
