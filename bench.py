@@ -41,7 +41,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--kpts', type=int, default=N_KPTS)
     ap.add_argument('--clouds', type=int, default=N_CLOUDS)
     ap.add_argument('--pairs', type=int, default=N_PAIRS)
