@@ -22,9 +22,8 @@ for rep in range(3):
 print(f'RD + mutual + yohoo: {60 / dt:.1f} pairs/s ({dt * 1e3:.1f} ms per 16-cloud / 60-pair step)')
 clouds = eng.extract_many(feats, keys)
 torch.cuda.synchronize(); t = time.perf_counter()
-for c in clouds: eng.detect(c)
+eng.detect_many(clouds)
 torch.cuda.synchronize(); t1 = time.perf_counter()
-from roreg_amd.test.matcher import NMS_sample
-for c in clouds: NMS_sample(5000, 5).sample(c.keys_host, c.det)
+eng.nms_many(clouds, 5000)
 t2 = time.perf_counter()
-print(f'detect: {(t1 - t) * 1e3 / 16:.2f} ms per cloud;  NMS sample: {(t2 - t1) * 1e3 / 16:.2f} ms per cloud')
+print(f'detector (all clouds per pass): {(t1 - t) * 1e3 / 16:.2f} ms per cloud;  NMS sampling: {(t2 - t1) * 1e3 / 16:.2f} ms per cloud')
