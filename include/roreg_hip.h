@@ -125,6 +125,13 @@ int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, in
                      int64_t *idx_out, void *workspace /* roreg_knn_search_workspace bytes: targets are scanned in slices that fill the chip;
                      NULL = one thread per source scans everything */, size_t workspace_bytes, void *stream);
 
+/* roreg_knn_search for several clouds per launch: the point lists are stacked, seg_src / seg_tgt are DEVICE int32 [n_seg+1] row
+ * offsets, a source only sees the targets of its own segment; idx_out int64 [m_total,k] holds indices LOCAL to the segment (the NMS
+ * sampling of every cloud of a scene in two launches, test/matcher.py:21-23). */
+size_t roreg_knn_search_seg_workspace(long long m_total, int n_seg, int max_m, int max_n);
+int roreg_knn_search_seg(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, int n_seg, long long m_total,
+                         int max_m, int max_n, int F, int k, int64_t *idx_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Mutual check + ordered compaction: for i in 0..m-1 (increasing) keep (i, nn01[i]) iff nn10[nn01[i]]==i;
  * pairs are mapped through sample0/sample1 (int64, NULL = identity) and written to match_out int64 [*,2];
  * *count_out (device int32) receives the number kept.  test/matcher.py:98-107. */

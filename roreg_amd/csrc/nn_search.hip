@@ -108,9 +108,22 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
 
 // the same scan over one slice of the targets (grid.y slices fill the chip: one thread per source alone is 20 workgroups at m = 5000);
 // per-slice sorted lists go to a workspace and are merged in slice order = index order, so ties still resolve to the first index
+// Segments (several clouds per launch, blockIdx.z = cloud): seg_src / seg_tgt [P+1] are row offsets into the stacked point lists, a
+// source only sees the targets of its own segment and the indices written are LOCAL to the segment.  seg_src == nullptr: one search.
 template <int F>
 __global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict__ src, int m, const float *__restrict__ tgt, int n, int k, int slice,
-                                                        float *__restrict__ pd, int *__restrict__ pj) {
+                                                        float *__restrict__ pd, int *__restrict__ pj, const int *__restrict__ seg_src,
+                                                        const int *__restrict__ seg_tgt, int m_total) {
+    if (seg_src) {
+        const int a0 = seg_src[blockIdx.z], b0 = seg_tgt[blockIdx.z];
+        m = seg_src[blockIdx.z + 1] - a0; n = seg_tgt[blockIdx.z + 1] - b0;
+        if ((int)(blockIdx.x * 256) >= m || n <= 0) return;
+        src += (size_t)a0 * F; tgt += (size_t)b0 * F;
+        slice = (n + gridDim.y - 1) / gridDim.y;
+        pd += (size_t)a0 * 8; pj += (size_t)a0 * 8;                // partial lists are laid out [slice][m_total][8]
+    } else {
+        m_total = m;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ii = i < m ? i : m - 1;
     float s[F];
@@ -140,8 +153,8 @@ __global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict_
         }
     }
     if (i < m) {
-        float *od = pd + ((size_t)blockIdx.y * m + i) * 8;
-        int *oj = pj + ((size_t)blockIdx.y * m + i) * 8;
+        float *od = pd + ((size_t)blockIdx.y * m_total + i) * 8;
+        int *oj = pj + ((size_t)blockIdx.y * m_total + i) * 8;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { od[q] = bd[q]; oj[q] = bj[q]; }
     }
@@ -267,8 +280,8 @@ extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n
         int *pj = reinterpret_cast<int *>(pd + (size_t)slices * m * 8);
         const int slice = (n + slices - 1) / slices;
         const dim3 grid((m + 255) / 256, (n + slice - 1) / slice);
-        if (F == 3) hipLaunchKernelGGL(knn_slice_kernel<3>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj);
-        else hipLaunchKernelGGL(knn_slice_kernel<32>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj);
+        if (F == 3) hipLaunchKernelGGL(knn_slice_kernel<3>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj, (const int *)nullptr, (const int *)nullptr, m);
+        else hipLaunchKernelGGL(knn_slice_kernel<32>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj, (const int *)nullptr, (const int *)nullptr, m);
         hipLaunchKernelGGL(knn_merge_kernel, dim3((m + 255) / 256), dim3(256), 0, s, pd, pj, m, (int)grid.y, k, idx_out);
     } else {                                           // no workspace: the single-pass scan (one thread per source)
         if (F == 3) hipLaunchKernelGGL(knn_search_kernel<3>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
@@ -277,6 +290,37 @@ extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n
     ROREG_CHECK_LAUNCH("roreg_knn_search");
     return 0;
 }
+extern "C" size_t roreg_knn_search_seg_workspace(long long m_total, int n_seg, int max_m, int max_n) {
+    const int gx = (max_m + 255) / 256;
+    int slices = (512 + gx * n_seg - 1) / (gx * n_seg);
+    if (slices > (max_n + 31) / 32) slices = (max_n + 31) / 32;
+    if (slices < 1) slices = 1;
+    return (size_t)slices * (size_t)m_total * 8 * (sizeof(float) + sizeof(int));
+}
+
+extern "C" int roreg_knn_search_seg(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, int n_seg, long long m_total,
+                                    int max_m, int max_n, int F, int k, int64_t *idx_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (m_total == 0 || n_seg == 0) return 0;
+    ROREG_REQUIRE(src && tgt && seg_src && seg_tgt && idx_out && workspace && n_seg > 0 && max_m > 0 && max_n > 0, "roreg_knn_search_seg: bad arguments");
+    ROREG_REQUIRE(k >= 1 && k <= 8, "roreg_knn_search_seg: k must be in 1..8 (got %d)", k);
+    ROREG_REQUIRE(F == 3 || F == 32, "roreg_knn_search_seg: F must be 3 or 32 (got %d)", F);
+    const size_t need = roreg_knn_search_seg_workspace(m_total, n_seg, max_m, max_n);
+    ROREG_REQUIRE(workspace_bytes >= need, "roreg_knn_search_seg: workspace of %zu bytes needed", need);
+    hipStream_t s = roreg::as_stream(stream);
+    const int gx = (max_m + 255) / 256;
+    int slices = (512 + gx * n_seg - 1) / (gx * n_seg);
+    if (slices > (max_n + 31) / 32) slices = (max_n + 31) / 32;
+    if (slices < 1) slices = 1;
+    float *pd = reinterpret_cast<float *>(workspace);
+    int *pj = reinterpret_cast<int *>(pd + (size_t)slices * m_total * 8);
+    const dim3 grid(gx, slices, n_seg);
+    if (F == 3) hipLaunchKernelGGL(knn_slice_kernel<3>, grid, dim3(256), 0, s, src, 0, tgt, 0, k, 0, pd, pj, seg_src, seg_tgt, (int)m_total);
+    else hipLaunchKernelGGL(knn_slice_kernel<32>, grid, dim3(256), 0, s, src, 0, tgt, 0, k, 0, pd, pj, seg_src, seg_tgt, (int)m_total);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, pd, pj, (int)m_total, slices, k, idx_out);
+    ROREG_CHECK_LAUNCH("roreg_knn_search_seg");
+    return 0;
+}
+
 extern "C" int roreg_mutual_matches(const int64_t *nn01, const int64_t *nn10, int m, int n, const int64_t *sample0,
                                     const int64_t *sample1, int64_t *match_out, int32_t *count_out, void *stream) {
     ROREG_REQUIRE(count_out && m >= 0 && (m == 0 || (nn01 && nn10 && match_out)), "roreg_mutual_matches: bad arguments");

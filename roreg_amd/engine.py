@@ -158,23 +158,22 @@ class RegistrationEngine:
     def nms_many(self, clouds, keynum):
         """NMS sampling (test/matcher.py:11-42) of several clouds: it is a pure function of the cloud (keypoints, detector scores,
         keynum; no RNG), so it is computed once per cloud -- the reference recomputes it for both clouds of every pair
-        (matcher.py:77-82) -- with every cloud's 5-NN search enqueued first and ONE download of the neighbour lists."""
+        (matcher.py:77-82) -- with the 5-NN search of all clouds in one segmented launch and ONE download of the neighbour lists."""
         from .test.matcher import NMS_sample
         sampler = NMS_sample(keynum, 5)
         todo = [c for c in clouds if keynum not in c.nms]
-        knn = []
+        need = []
         for c in todo:
             if c.keys.shape[0] < keynum:
                 c.nms[keynum] = np.arange(c.keys.shape[0])
             else:
-                k32 = c.keys.float().contiguous()
-                knn.append((c, hip.knn_search(k32, k32, 5)))
-        if knn:
-            flat = torch.cat([i.reshape(-1) for _, i in knn]).cpu().numpy()
-            o = 0
-            for c, i in knn:
-                n = i.shape[0]
-                c.nms[keynum] = sampler.sample_from_neighbours(c.det, flat[o:o + 5 * n].reshape(n, 5)); o += 5 * n
+                need.append(c)
+        if need:
+            seg = hip.Segments([c.keys.shape[0] for c in need])
+            pts = torch.cat([c.keys.float() for c in need]).contiguous()
+            flat = hip.knn_search_seg(pts, seg, 5).cpu().numpy()          # every cloud's 5-NN lists (self included) in two launches
+            for c, a, b in zip(need, seg.host[:-1], seg.host[1:]):
+                c.nms[keynum] = sampler.sample_from_neighbours(c.det, flat[a:b])
 
     # ---- per pair ------------------------------------------------------------------------------------------
     def sample(self, c0, c1, keynum):

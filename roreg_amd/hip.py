@@ -50,6 +50,8 @@ PROTOTYPES = {
     'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_knn_search_workspace': (c_size_t, [c_int, c_int]),
     'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    'roreg_knn_search_seg_workspace': (c_size_t, [ctypes.c_longlong, c_int, c_int, c_int]),
+    'roreg_knn_search_seg': (c_int, [_P, _P, _P, _P, c_int, ctypes.c_longlong, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     'roreg_mutual_matches': (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     'roreg_mutual_match_batch_workspace': (c_size_t, [c_int, c_int]),
     'roreg_mutual_match_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
@@ -305,6 +307,21 @@ def knn_search(src, tgt, k):
     ws_n = lib().roreg_knn_search_workspace(m, n)
     ws = torch.empty(ws_n // 4, dtype=torch.int32, device=src.device) if ws_n else None
     _check(lib().roreg_knn_search(_ptr(src, torch.float32), m, _ptr(tgt, torch.float32), n, F, k, _ptr(idx), _ptr(ws), ws_n, _stream()), 'roreg_knn_search')
+    return idx
+
+
+def knn_search_seg(pts, seg, k):
+    """k nearest neighbours of every point among the points of its own segment (pts [total,F] stacked clouds, seg: Segments) ->
+    int64 [total,k] indices local to the segment."""
+    total, F = pts.shape
+    idx = torch.empty((total, k), dtype=torch.int64, device=pts.device)
+    if seg.min < k:
+        raise HipError(f'knn_search_seg: a segment has fewer than k={k} points')
+    ws_n = lib().roreg_knn_search_seg_workspace(total, seg.n, seg.max, seg.max)
+    ws = torch.empty(ws_n // 4, dtype=torch.int32, device=pts.device)
+    sp = _ptr(seg.dev, torch.int32)
+    _check(lib().roreg_knn_search_seg(_ptr(pts, torch.float32), _ptr(pts, torch.float32), sp, sp, seg.n, total, seg.max, seg.max, F, k, _ptr(idx),
+                                      _ptr(ws), ws_n, _stream()), 'roreg_knn_search_seg')
     return idx
 
 

@@ -421,3 +421,19 @@ def test_mfma_matcher_is_exact_on_adversarial_descriptors(scale):
         _, nn01 = O.knn(T, S, 1); _, nn10 = O.knn(S, T, 1)
         want = O.mutual_check(nn01, nn10)
         assert cnt[q] == want.shape[0] and np.array_equal(mbuf[q, :cnt[q]], want), (scale, q)
+
+
+def test_knn_search_segmented_equals_per_cloud():
+    """Several clouds stacked (ragged sizes around the 256-row blocks): local indices equal the per-cloud search, ties included."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(2)
+    sizes = [5, 255, 256, 257, 1000, 77]
+    clouds = [rng.uniform(0, 1, (n, 3)).astype(np.float32) for n in sizes]
+    clouds[3][10:20] = clouds[3][0]                                       # exact duplicates: first index wins
+    pts = cu(np.concatenate(clouds))
+    got = hip.knn_search_seg(pts, hip.Segments(sizes), 5).cpu().numpy()
+    o = 0
+    for c in clouds:
+        want = hip.knn_search(cu(c), cu(c), 5).cpu().numpy()
+        assert np.array_equal(got[o:o + len(c)], want)
+        o += len(c)
