@@ -292,7 +292,7 @@ extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n
 }
 extern "C" size_t roreg_knn_search_seg_workspace(long long m_total, int n_seg, int max_m, int max_n) {
     const int gx = (max_m + 255) / 256;
-    int slices = (512 + gx * n_seg - 1) / (gx * n_seg);
+    int slices = (2048 + gx * n_seg - 1) / (gx * n_seg);
     if (slices > (max_n + 31) / 32) slices = (max_n + 31) / 32;
     if (slices < 1) slices = 1;
     return (size_t)slices * (size_t)m_total * 8 * (sizeof(float) + sizeof(int));
@@ -308,7 +308,7 @@ extern "C" int roreg_knn_search_seg(const float *src, const float *tgt, const in
     ROREG_REQUIRE(workspace_bytes >= need, "roreg_knn_search_seg: workspace of %zu bytes needed", need);
     hipStream_t s = roreg::as_stream(stream);
     const int gx = (max_m + 255) / 256;
-    int slices = (512 + gx * n_seg - 1) / (gx * n_seg);
+    int slices = (2048 + gx * n_seg - 1) / (gx * n_seg);
     if (slices > (max_n + 31) / 32) slices = (max_n + 31) / 32;
     if (slices < 1) slices = 1;
     float *pd = reinterpret_cast<float *>(workspace);
