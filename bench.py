@@ -242,13 +242,13 @@ def main():
     if os.path.exists(pmc):                      # HBM bytes per launch from the rocprofv3 --pmc passes of this same command
         traffic = json.load(open(pmc)).get('hbm_bytes_per_launch', {}).get(args.gemm) if isinstance(json.load(open(pmc)).get('hbm_bytes_per_launch'), dict) else None
 
-    # ---- accuracy on the synthetic chunk (outside the timed region) ----
-    from oracle import ref_numpy as O
+    # ---- accuracy on the synthetic chunk (outside the timed region; the evaluator's own metric code) ----
+    from roreg_amd.utils.r_eval import compute_R_diff
     rr = []
     for r in res:
         gt = scene.get_transform(r.id0, r.id1)
         if np.isfinite(r.trans).all():
-            rd = O.compute_R_diff(r.trans[:3, :3], gt[:3, :3]); td = float(np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))))
+            rd = compute_R_diff(r.trans[:3, :3], gt[:3, :3]); td = float(np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))))
             rr.append(1 if (rd < 15 and td < 0.3) else 0)
         else:
             rr.append(0)
