@@ -68,15 +68,17 @@ int roreg_dense_split(const float *x, const void *wsplit, const float *bias, con
                       const float *residual, float *out, int B, int K, int O, void *stream);
 
 /* fp16 x 2 variants of the two entries above (half the matrix-core work; operands as hi + lo fp16 under a power-of-two block scale, see
- * roreg_irrep_gemm_f16x2).  The activation scale is derived on the device from the bound |act(x)| <= act_smax * (*in_absmax_dev) + act_tmax
- * (act_smax = max |scale| or 1, act_tmax = max |shift| or 0); the weights were scaled by 2^w_exp when split (layouts as above with two
- * planes hi, lo of fp16 bits).  out_absmax_dev (nullable, zeroed by the caller) receives max |out| for the next layer. */
+ * roreg_irrep_gemm_f16x2).  The block is ONE ROW (keypoint / correspondence) b of x: its scale is derived on the device from the bound
+ * |act(x[b])| <= act_smax * in_rowmax_dev[b] + act_tmax (act_smax = max |scale| or 1, act_tmax = max |shift| or 0; in_rowmax_dev [B] =
+ * max |x[b]| maintained by the producing kernel), so a row's result never depends on which other rows share the launch (the reference's
+ * batch-size independence, test/extractor.py:51-58, test/estimator.py:338-352).  The weights were scaled by 2^w_exp when split (layouts as
+ * above with two planes hi, lo of fp16 bits).  out_rowmax_dev (nullable, [B], zeroed by the caller) receives max |out[b]| for the next layer. */
 int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *bn_scale, const float *bn_shift,
-                           float act_smax, float act_tmax, const float *in_absmax_dev, float *out, float *out_absmax_dev,
+                           float act_smax, float act_tmax, const float *in_rowmax_dev, float *out, float *out_rowmax_dev,
                            const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
 int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
-                      float act_smax, float act_tmax, const float *in_absmax_dev, const float *residual, float *out,
-                      float *out_absmax_dev, int B, int K, int O, void *stream);
+                      float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, float *out,
+                      float *out_rowmax_dev, int B, int K, int O, void *stream);
 
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
@@ -330,21 +332,34 @@ int roreg_irrep_gemm(const float *const *X, float *const *Out, const float *cons
  * Wsplit[rho]: uint16 bf16 bits, layout [3 splits][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
 int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit, int C, int O, int B,
                            const int32_t *tiles_dev, int n_tiles, void *stream);
-/* The same GEMMs with fp16 x 2 operands and power-of-two block scaling (half the matrix-core work of the bf16 x 3 split): activations
- * are scaled by 2^e so that their absolute maximum (*x_absmax_dev, a device scalar maintained by the producer; NULL = 1) is <= 2^14, the
- * weights were scaled by 2^w_exp when split; hi = fp16(x), lo = fp16(x - hi) keep 22 significant bits of every operand within 18 binades
- * of the maximum (absolute error < 2^-39 of the maximum below that); products hi.hi + hi.lo + lo.hi, f32 accumulate, exact rescale.
- * Wsplit2[rho]: fp16 bits, layout [2 (hi, lo)][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
+/* The same GEMMs with fp16 x 2 operands and power-of-two block scaling (half the matrix-core work of the bf16 x 3 split).  The block is
+ * ONE KEYPOINT: all coefficients of keypoint b (every channel, every irrep) share the scale 2^e(b), e(b) = 14 - exponent(x_bound_dev[b]),
+ * where x_bound_dev [B] is a bound on |coefficient| known BEFORE the coefficients exist (below), so the producer roreg_ft_nonlin(split = 2)
+ * writes them already split -- X[rho] holds 32-bit words fp16(x 2^e) | fp16(x 2^e - hi) << 16 at the float pitch -- and the GEMM only
+ * permutes bytes while staging.  hi + lo keep 22 significant bits of every operand within ~11 binades of the bound and an absolute error
+ * below 2^-39 of the bound beneath that; products hi.hi + hi.lo + lo.hi, f32 accumulate, exact rescale per column by 2^-(e(b) + w_exp).
+ * A keypoint's output depends on its own column only: results are independent of batch composition (test/extractor.py:51-58).
+ * Bound propagation: with next_u_dev / next_v_dev [O] and out_bound_dev [B] (zeroed by the caller) the epilogue reduces
+ * max over (o, q) of u_o |T_oq(b)| + v_o per keypoint (atomic max), which bounds the coefficients of the NEXT transform's output when
+ * u_o = 60 |bn_scale_o| and v_o = sqrt(60) (|bn_scale_o| |bias_o| + |bn_shift_o|) (orthonormal transform: |IFT(T)(g)| <= sqrt(60) max_q |T_q|,
+ * |FT(x)_q| <= sqrt(60) max_g |x(g)|).  Wsplit2[rho]: fp16 bits, layout [2 (hi, lo)][d*C/16][2 k-octets][round_up(d*O,128)][8]. */
 int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
-                           const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles,
+                           const float *x_bound_dev, int w_exp, const float *next_u_dev, const float *next_v_dev, float *out_bound_dev,
+                           int C, int O, int B, const int32_t *tiles_dev, int n_tiles,
                            int tile_m /* 128 | 256 (O % 256 == 0): the m-tile the list was built with; 256 = 8-wave workgroups */, void *stream);
+/* bound_out[b] (b < round_up(B,32); 0 for pad keypoints) = sqrt(60) max_{c,g} |act(x[b,c,g])| >= every coefficient of FT(act(x[b])), act =
+ * ReLU(bn_scale_c x + bn_shift_c) or the identity (bn NULL): the x_bound of a layer whose input is a group-domain tensor [B,C,60]. */
+int roreg_row_bound(const float *x_spatial, const float *bn_scale, const float *bn_shift, float *bound_out, int B, int C, void *stream);
 int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
                     const int32_t *g_map /* optional [60]: group column -> compact output column (< Lvalid) or -1 */,
                     int Lout /* row pitch of the compact output, >= Lvalid; pad columns are zero */, int Lvalid,
                     int B, int C, int split /* 0: f32-input MFMA; 1: 3 x bf16 split MFMAs; 2: fp16 x 2 with per-column (per-keypoint) power-of-two scales */,
-                    float *out_absmax /* optional device scalar, zeroed by the caller: receives max |coefficient written| (block scale of roreg_irrep_gemm_f16x2) */,
+                    const float *out_bound /* split = 2 with Xout: per-keypoint bound [round_up(B,32)] on |coefficient|; Xout then holds the fp16 hi/lo
+                                              words roreg_irrep_gemm_f16x2 consumes (NOT floats) */,
+                    float *out_rowmax /* optional, with out_spatial: [B], zeroed by the caller; receives max |out_spatial[b]| per keypoint (the block
+                                         scale of roreg_group_conv_f16x2) */,
                     void *stream);
 
 #ifdef __cplusplus

@@ -151,16 +151,31 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_kernel(GemmDescs p, const i
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmSplitDescs {
-    const float *X[NIRR];
+    const float *X[NIRR];         // NP = 3: float32 coefficients.  NP = 2: fp16 hi | lo << 16 pairs written by ft_nonlin (same 4-byte pitch)
     float *Out[NIRR];
     const float *Add[NIRR];
-    const float *xabsmax;         // NP = 2: device scalar, absolute maximum of the activation tensor (null = 1)
+    const float *xbound;          // NP = 2: per-keypoint bound [Bp] the packed activations were scaled with (column scale 2^bound_exp)
     int w_exp;                    // NP = 2: the weights were scaled by 2^w_exp before the fp16 split
+    const float *nb_u, *nb_v;     // NP = 2, optional [O]: the next nonlinearity's bound  |FT(act(IFT(T)))| <= max_{o,q} (u_o |T_oq| + v_o)
+    float *out_bound;             // NP = 2, optional [Bp] (zeroed by the caller): receives that bound per keypoint (atomic max)
+    int O;                        // output channels (row m of irrep rho = j * O + o)
     const void *W[NIRR];          // [NP][K/16][2][Mpad] 16-byte fragments
     int K[NIRR], M[NIRR], Mpad[NIRR], N[NIRR];
 };
+
+// Block scale of the fp16 x 2 operand split: e with bound * 2^e < 2^14 (bound = f * 2^ex, f in [0.5, 1)).  A pure function of the
+// keypoint's own bound, so the producer (ft_nonlin) and the consumer (the GEMM's epilogue) derive the same exponent independently.
+__device__ __forceinline__ int bound_exp(float mx) {
+    int e = 0;
+    if (mx > 0.f && mx < __builtin_inff()) { int ex; (void)frexpf(mx, &ex); e = 14 - ex; }
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__constant__ int kIrrDim[NIRR] = {1, 3, 3, 4, 5};
+// keypoint of GEMM column n of an irrep of dimension d (columns are blocked by 32 keypoints: n = (b/32)*32d + i*32 + b%32)
+__device__ __forceinline__ int column_keypoint(int n, int d) { return ((n >> 5) / d) * 32 + (n & 31); }
 
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
 #pragma unroll
@@ -215,18 +230,10 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
     const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
     const int wo = w % WO, wb = w / WO;
-    const int m_wave = mt * OT + wo * 64;
     const int n0 = nt * NCOL;
     const int ncol_wave = wb * 128;
 
-    // NP = 2: 2^e with |x| * 2^e <= 2^14 for the tensor's absolute maximum
-    float xscale = 1.f, oscale = 1.f;
-    if constexpr (NP == 2) {
-        const float mx = p.xabsmax ? *p.xabsmax : 1.f;
-        int e = 0;
-        if (mx > 0.f && mx < __builtin_inff()) { int ex; (void)frexpf(mx, &ex); e = 14 - ex; }       // mx = f * 2^ex, f in [0.5, 1)
-        xscale = ldexpf(1.f, e); oscale = ldexpf(1.f, -(e + p.w_exp));
-    }
+    const int dirr = kIrrDim[irr];
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -264,9 +271,15 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
                 split3(v, b1, b2, b3);
                 dst[slot[c]] = b1; dst[2 * NCOL + slot[c]] = b2; dst[4 * NCOL + slot[c]] = b3;
             } else {
-                f16x8 hi, lo;
-                split2(v, xscale, hi, lo);
-                dst[slot[c]] = hi; dst[2 * NCOL + slot[c]] = lo;
+                // the activations arrive split: word e = fp16 hi | fp16 lo << 16 of k = 8 po + e; a k-octet is four byte permutes per plane
+                u32x4 H, L;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned a = __float_as_uint(v[2 * i]), b = __float_as_uint(v[2 * i + 1]);
+                    H[i] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+                    L[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+                }
+                dst[slot[c]] = __builtin_bit_cast(f16x8, H); dst[2 * NCOL + slot[c]] = __builtin_bit_cast(f16x8, L);
             }
         }
     };
@@ -348,6 +361,29 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     }
     float *__restrict__ Out = p.Out[irr];
     const float *__restrict__ Add = p.Add[irr];
+    // NP = 2: every column carries its keypoint's own power-of-two scale (undone here together with the weights' 2^w_exp), and the
+    // epilogue can emit the bound the NEXT transform needs to split its output: max over this tile's rows of u_o |T| + v_o per column,
+    // merged per keypoint with an atomic max (order-independent, hence deterministic).
+    float oscale[4] = {1.f, 1.f, 1.f, 1.f};
+    float bmax[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bound = NP == 2 && p.out_bound != nullptr;
+    float *su = reinterpret_cast<float *>(smem), *sv = su + OT;
+    unsigned *cm = reinterpret_cast<unsigned *>(sv + OT);
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + ncol_wave + t * 32 + j;
+            if (n < N) oscale[t] = ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(n, dirr)]) + p.w_exp));
+        }
+        if (want_bound) {                                        // (the LDS tiles are dead: the loop ended with a barrier)
+            for (int i = tid; i < OT; i += NT) {
+                const int m = mt * OT + i;
+                su[i] = m < M ? p.nb_u[m % p.O] : 0.f; sv[i] = m < M ? p.nb_v[m % p.O] : 0.f;
+            }
+            for (int i = tid; i < NCOL; i += NT) cm[i] = 0u;
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -356,15 +392,31 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = mt * OT + row;
                 if (m < M) {
                     float o = acc[ot][t][r];
-                    if constexpr (NP == 2) o *= oscale;
+                    if constexpr (NP == 2) o *= oscale[t];
                     if (Add) o += Add[(size_t)m * N + n];
                     Out[(size_t)m * N + n] = o;
+                    if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(su[row], fabsf(o), sv[row])); }
                 }
             }
         }
+    if constexpr (NP == 2) {
+        if (want_bound) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bm = fmaxf(bmax[t], __shfl_xor(bmax[t], 32));
+                if (h == 0) atomicMax(cm + ncol_wave + t * 32 + j, __float_as_uint(bm));      // non-negative floats order like their bit patterns
+            }
+            __syncthreads();
+            for (int i = tid; i < NCOL; i += NT) {
+                const int n = n0 + i;
+                if (n < N) atomicMax(reinterpret_cast<unsigned *>(p.out_bound) + column_keypoint(n, dirr), cm[i]);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -380,7 +432,10 @@ struct NonlinParams {
     const bf16x8 *A1s, *A2s;     // the same tables as 3 x bf16 split fragments of the K=16 bf16 MFMA (SPLIT = 3 kernels)
     const f16x8 *A1h, *A2h;      // ... and as fp16 hi/lo fragments scaled by 2^f_exp (SPLIT = 2 kernels)
     int f_exp;
-    float *out_absmax;           // optional device scalar (zeroed by the caller): max |coefficient| written, for the fp16 x 2 GEMM's block scale
+    const float *out_bound;      // SPLIT = 2, coefficient output: per-keypoint bound [Bp] on |coefficient| (from the producing GEMM's epilogue or
+                                 // roreg_row_bound); the output is then written SPLIT for the GEMM: fp16 hi | fp16 lo << 16 of coef * 2^bound_exp(bound)
+    float *out_rowmax;           // optional, group-domain output: per-keypoint max |value written| [B] (zeroed by the caller; atomic max), the
+                                 // block scale of the fp16 x 2 convolution that consumes the tensor
     float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
@@ -463,11 +518,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
     constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT != 0 ? 32 : 30);
-    float cn[NCV];
-    auto load_coefs = [&](int tile, float (&dst)[NCV]) {
+    constexpr bool PACK_OUT = SPLIT == 2 && !OUT_SPATIAL;         // coefficients leave as fp16 hi/lo pairs under the keypoint's block scale
+    float cn[NCV + 1];                                           // slot NCV: the keypoint's bound (PACK_OUT), prefetched with the coefficients
+    auto load_coefs = [&](int tile, float (&dst)[NCV + 1]) {
         const int c = (IN_SPATIAL || OUT_SPATIAL) ? tile % C : tile / p.tiles_per_c;      // group-domain tensors are [b][c][.]: channel-fastest tiles
         const int tb = (IN_SPATIAL || OUT_SPATIAL) ? tile / C : tile - c * p.tiles_per_c;         // make the waves of a workgroup touch adjacent rows
-        if constexpr (SPLIT != 0) {
+        if constexpr (PACK_OUT) dst[NCV] = p.out_bound[tb * 32 + jn];
+        if constexpr (IN_SPATIAL) {
+            // (group-domain input is read in process(); nothing to prefetch)
+        } else if constexpr (SPLIT != 0) {
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
                 constexpr int q0 = 16 * st + e, q1 = 16 * st + 8 + e;
@@ -513,8 +572,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     // tile old (the stores and loads issued after them stay in flight).  The explicit wait after the first loads gives the loop ONE
     // wait state on both entry paths -- otherwise the compiler merges "first loads just issued" with the steady state and drains the
     // prefetch at every tile.  A wave with an odd number of tiles processes its last tile twice (idempotent stores): branch-free.
-    float wmax = 0.f;                                            // running max |coefficient| written by this lane
-    auto process = [&](int tile, int next_tile, float (&cv)[NCV], float (&cnext)[NCV]) {
+    auto process = [&](int tile, int next_tile, float (&cv)[NCV + 1], float (&cnext)[NCV + 1]) {
         asm volatile("" ::: "memory");      // keep the transform fragments in LDS: without this the compiler hoists all 62 of them into VGPRs
         const int c = (IN_SPATIAL || OUT_SPATIAL) ? tile % C : tile / p.tiles_per_c;
         const int tbi = (IN_SPATIAL || OUT_SPATIAL) ? tile / C : tile - c * p.tiles_per_c;
@@ -522,7 +580,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         const bool valid = b < B;
         const int bb = valid ? b : B - 1;
         f32x16 v[2];
+        float wmax = 0.f;                                        // max |value written| for this lane's keypoint (group-domain output)
         if (IN_SPATIAL) {
+            if constexpr (PACK_OUT) cv[NCV] = p.out_bound[b];    // (b < Bp: the bound buffer covers the pad keypoints)
             const float *src = p.x_spatial + ((size_t)bb * C + c) * ROREG_G;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -606,6 +666,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
                 if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (p.out_rowmax) {                                   // every lane issues the atomic (no branch around a VMEM operation in the pipelined loop)
+                wmax = fmaxf(wmax, __shfl_xor(wmax, 32));
+                unsigned *dst = (h == 0 && valid) ? reinterpret_cast<unsigned *>(p.out_rowmax) + b : reinterpret_cast<unsigned *>(p.dump) + lane;
+                atomicMax(dst, __float_as_uint(wmax));
+            }
         }
         if (!OUT_SPATIAL) {
             f32x16 o[2];
@@ -642,10 +707,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     o[0] = mfma3(sA2h + ((st * 2 + 0) * 2) * 64 + lane, bh, bl, o[0]);
                     o[1] = mfma3(sA2h + ((st * 2 + 1) * 2) * 64 + lane, bh, bl, o[1]);
                 }
+                // undo the transform's scale and apply the keypoint's block scale in one exact multiplication, then split:
+                // word = fp16(x) | fp16(x - hi) << 16  (what the GEMM's staging reads)
+                const float psc = osc * ldexpf(1.f, bound_exp(cv[NCV]));
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[t][r] *= osc;
+                    for (int r = 0; r < 16; ++r) {
+                        const float x = o[t][r] * psc;
+                        const _Float16 h1 = (_Float16)x;
+                        const _Float16 l1 = (_Float16)(x - (float)h1);
+                        o[t][r] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16));
+                    }
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -658,10 +731,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             }
             {
                 const int tb = tbi;                           // pad keypoints (b >= B) get zeros: the buffers stay fully defined
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) wmax = fmaxf(wmax, fabsf(o[t][r]));             // (rows q >= 60 and pad keypoints are exact zeros)
                 static_for<32>([&](auto ic) {
                     constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
                     constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
@@ -679,7 +748,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     };
     if (wave_global < n_tiles) {
         const int last = wave_global + ((n_tiles - 1 - wave_global) / n_waves) * n_waves;        // this wave's last tile
-        float cb[NCV];
+        float cb[NCV + 1];
         if (!IN_SPATIAL) {
             load_coefs(wave_global, cn);
             __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
@@ -689,11 +758,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             process(tile, t1, cn, cb);
             process(t1, t2, cb, cn);
         }
-    }
-    if (p.out_absmax) {                                              // one atomic per wave (non-negative floats order like their bit patterns)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(p.out_absmax), __float_as_uint(wmax));
     }
 }
 
@@ -888,7 +952,8 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
 
 template <int NP, int WO>
 static int launch_gemm_split(const char *what, const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit,
-                             const float *xabsmax, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, void *stream) {
+                             const float *xbound, int w_exp, const float *nb_u, const float *nb_v, float *out_bound, int C, int O, int B,
+                             const int32_t *tiles_dev, int n_tiles, void *stream) {
     static const int dims[5] = {1, 3, 3, 4, 5};
     GemmSplitDescs p;
     for (int r = 0; r < 5; ++r) {
@@ -896,7 +961,7 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
         p.K[r] = dims[r] * C; p.M[r] = dims[r] * O; p.Mpad[r] = round_up(dims[r] * O, 128); p.N[r] = dims[r] * B;
         if (WO == 4 && p.Mpad[r] % 256 != 0) { roreg::set_error("%s: tile_m = 256 needs O %% 256 == 0 (got %d)", what, O); return 2; }
     }
-    p.xabsmax = xabsmax; p.w_exp = w_exp;
+    p.xbound = xbound; p.w_exp = w_exp; p.nb_u = nb_u; p.nb_v = nb_v; p.out_bound = out_bound; p.O = O;
     constexpr int CT = 32;
     const size_t lds = 2 * (NP * 2 * 256 + NP * (WO * 64) * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
     auto kern = irrep_gemm_split_kernel<CT, NP, WO>;
@@ -912,23 +977,58 @@ extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, 
                                       const int32_t *tiles_dev, int n_tiles, void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_split: bad arguments");
     ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_split: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
-    return launch_gemm_split<3, 2>("roreg_irrep_gemm_split", X, Out, Add, Wsplit, nullptr, 0, C, O, B, tiles_dev, n_tiles, stream);
+    return launch_gemm_split<3, 2>("roreg_irrep_gemm_split", X, Out, Add, Wsplit, nullptr, 0, nullptr, nullptr, nullptr, C, O, B, tiles_dev, n_tiles, stream);
 }
 
 extern "C" int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
-                                      const float *x_absmax_dev, int w_exp, int C, int O, int B, const int32_t *tiles_dev, int n_tiles, int tile_m,
-                                      void *stream) {
+                                      const float *x_bound_dev, int w_exp, const float *next_u_dev, const float *next_v_dev, float *out_bound_dev,
+                                      int C, int O, int B, const int32_t *tiles_dev, int n_tiles, int tile_m, void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit2 && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_f16x2: bad arguments");
-    ROREG_REQUIRE(C % 32 == 0 && B % 4 == 0, "roreg_irrep_gemm_f16x2: C %% 32 and B %% 4 must be 0 (got %d, %d)", C, B);
+    ROREG_REQUIRE(C % 32 == 0 && B % 32 == 0, "roreg_irrep_gemm_f16x2: C %% 32 and B %% 32 must be 0 (got %d, %d)", C, B);
+    ROREG_REQUIRE(x_bound_dev, "roreg_irrep_gemm_f16x2: x_bound_dev (the per-keypoint bound the activations were split under) is required");
+    ROREG_REQUIRE(!out_bound_dev || (next_u_dev && next_v_dev), "roreg_irrep_gemm_f16x2: out_bound_dev needs next_u_dev / next_v_dev");
     ROREG_REQUIRE(tile_m == 128 || tile_m == 256, "roreg_irrep_gemm_f16x2: tile_m must be 128 or 256 (the value the tile list was built with)");
     if (tile_m == 256)
-        return launch_gemm_split<2, 4>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_absmax_dev, w_exp, C, O, B, tiles_dev, n_tiles, stream);
-    return launch_gemm_split<2, 2>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_absmax_dev, w_exp, C, O, B, tiles_dev, n_tiles, stream);
+        return launch_gemm_split<2, 4>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_bound_dev, w_exp, next_u_dev, next_v_dev, out_bound_dev, C, O, B,
+                                       tiles_dev, n_tiles, stream);
+    return launch_gemm_split<2, 2>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_bound_dev, w_exp, next_u_dev, next_v_dev, out_bound_dev, C, O, B,
+                                   tiles_dev, n_tiles, stream);
+}
+
+// Per-keypoint bound on the coefficients of FT(act(x)) for a group-domain tensor x [B][C][60]: the transform is orthonormal, so
+// |coefficient| <= |act(x_c)|_2 <= sqrt(60) max_g |act(x_c(g))|, act = ReLU(scale_c x + shift_c) or the identity.  One wave per keypoint;
+// entries [B, Bp) (pad keypoints: their coefficients are exact zeros) get 0.
+__global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
+                                                        float *__restrict__ bound, int B, int Bp, int C) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= Bp) return;
+    float mx = 0.f;
+    if (b < B) {
+        const float *row = x + (size_t)b * C * ROREG_G;
+        for (int i = lane; i < C * ROREG_G; i += 64) {
+            float v = row[i];
+            if (bn_scale) { const int c = i / ROREG_G; v = fmaxf(fmaf(v, bn_scale[c], bn_shift[c]), 0.f); }
+            mx = fmaxf(mx, fabsf(v));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) bound[b] = mx * 7.7536f;                      // sqrt(60) = 7.7460, plus slack for the f32 rounding of the transform itself
+}
+
+extern "C" int roreg_row_bound(const float *x_spatial, const float *bn_scale, const float *bn_shift, float *bound_out, int B, int C, void *stream) {
+    ROREG_REQUIRE(x_spatial && bound_out && B > 0 && C > 0, "roreg_row_bound: bad arguments");
+    ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_row_bound: bn_scale and bn_shift go together");
+    const int Bp = (B + 31) / 32 * 32;
+    hipLaunchKernelGGL(row_bound_kernel, dim3((Bp + 3) / 4), dim3(256), 0, roreg::as_stream(stream), x_spatial, bn_scale, bn_shift, bound_out, B, Bp, C);
+    ROREG_CHECK_LAUNCH("roreg_row_bound");
+    return 0;
 }
 
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
-                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, float *out_absmax, void *stream) {
+                               const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, const float *out_bound, float *out_rowmax,
+                               void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
@@ -941,13 +1041,15 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
-    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_absmax = out_absmax;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_bound = out_bound; p.out_rowmax = out_rowmax;
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
     hipStream_t s = roreg::as_stream(stream);
     const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
     if (in_sp && out_sp) { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
+    ROREG_REQUIRE(split != 2 || out_sp || out_bound, "roreg_ft_nonlin: split = 2 writes the coefficients as fp16 hi/lo pairs and needs out_bound");
+    ROREG_REQUIRE(!out_rowmax || out_sp, "roreg_ft_nonlin: out_rowmax goes with a group-domain output");
     auto grid_for = [&](int nw, long long cap) { long long b = (n_tiles + nw - 1) / nw; return dim3((unsigned)(b > cap ? cap : b)); };
     ROREG_REQUIRE(split >= 0 && split <= 2, "roreg_ft_nonlin: split must be 0 (f32 MFMA), 1 (bf16 x 3) or 2 (fp16 x 2)");
     if (split == 2) {

@@ -223,27 +223,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// NP = 3: bf16 x 3 pieces.  NP = 2: fp16 hi/lo with power-of-two block scaling (fourier.hip, irrep_gemm_split_kernel): the activation
-// scale comes from a bound on |act(x)| <= act_smax * (*in_absmax) + act_tmax (act_smax = max |BN scale| or 1, act_tmax = max |BN shift|
-// or 0; *in_absmax is the device-tracked maximum of the input tensor), the weights carry 2^w_exp; the kernel tracks max |out| for the
-// next layer (one atomicMax per wave).
+// NP = 3: bf16 x 3 pieces.  NP = 2: fp16 hi/lo with power-of-two block scaling; the block is ONE ROW b of x (a keypoint / correspondence):
+// its scale comes from the bound |act(x[b])| <= act_smax * in_rowmax[b] + act_tmax (act_smax = max |BN scale| or 1, act_tmax = max |BN
+// shift| or 0; in_rowmax[b] = max |x[b]| tracked by the producing kernel), the weights carry 2^w_exp; the kernel tracks max |out[b]| per row
+// for the next layer (atomic max: order-independent).  A row's result therefore never depends on the other rows of the launch.
 struct SplitScale {
-    const float *in_absmax;        // device scalar (NP = 2)
+    const float *in_rowmax;        // [B] (NP = 2)
     float act_smax, act_tmax;
     int w_exp;
-    float *out_absmax;             // device scalar or null
+    float *out_rowmax;             // [B] or null
 };
-__device__ __forceinline__ void split_scales(const SplitScale &q, float &xscale, float &oscale) {
-    const float mx = q.act_smax * (q.in_absmax ? *q.in_absmax : 1.f) + q.act_tmax;
+__device__ __forceinline__ int row_scale_exp(const SplitScale &q, int b) {
+    const float mx = q.act_smax * q.in_rowmax[b] + q.act_tmax;
     int e = 0;
     if (mx > 0.f && mx < __builtin_inff()) { int ex; (void)frexpf(mx, &ex); e = 14 - ex; }
-    xscale = ldexpf(1.f, e); oscale = ldexpf(1.f, -(e + q.w_exp));
-}
-__device__ __forceinline__ void track_absmax(float *dst, float wmax) {
-    if (!dst) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(dst), __float_as_uint(wmax));
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
 }
 __device__ __forceinline__ void gc_split2(const float (&v)[8], float scale, f16x8 &hi, f16x8 &lo) {
 #pragma unroll
@@ -318,8 +312,11 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
     const bool has_bn = p.bn_scale != nullptr;
-    float xscale = 1.f, oscale = 1.f;
-    if constexpr (NP == 2) split_scales(p.sc, xscale, oscale);
+    float oscale[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) oscale[t] = ldexpf(1.f, -(row_scale_exp(p.sc, bcol[t]) + p.sc.w_exp));
+    }
     const frag *wsb = reinterpret_cast<const frag *>(p.ws);
     const size_t ws_plane = (size_t)KS * (p.Cin / 16) * 2 * p.CoutPad;    // fragments per split plane
 
@@ -345,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                 dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
             } else {
                 f16x8 hi, lo;
-                gc_split2(v, xscale, hi, lo);
+                gc_split2(v, ldexpf(1.f, row_scale_exp(p.sc, b_first + kp)), hi, lo);
                 dst[0] = hi; dst[plane_stride] = lo;
             }
         }
@@ -403,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     }
 
     // ---- epilogue: bias, masked store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-    float wmax = 0.f;
+    float wmax[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
 #pragma unroll
@@ -413,14 +410,22 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
             for (int r = 0; r < 16; ++r) {
                 const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (o < p.Cout) {
-                    const float v = (NP == 2 ? acc[ot][t][r] * oscale : acc[ot][t][r]) + p.bias[o];
+                    const float v = (NP == 2 ? acc[ot][t][r] * oscale[t] : acc[ot][t][r]) + p.bias[o];
                     p.out[((size_t)bcol[t] * p.Cout + o) * Lout + gi[t]] = v;
-                    wmax = fmaxf(wmax, fabsf(v));
+                    wmax[t] = fmaxf(wmax[t], fabsf(v));
                 }
             }
         }
     }
-    track_absmax(p.sc.out_absmax, wmax);
+    if constexpr (NP == 2) {
+        if (p.sc.out_rowmax) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float m = fmaxf(wmax[t], __shfl_xor(wmax[t], 32));
+                if (h == 0 && valid[t]) atomicMax(reinterpret_cast<unsigned *>(p.sc.out_rowmax) + bcol[t], __float_as_uint(m));
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -460,8 +465,6 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
     const int nsteps = p.K / 16;
     const size_t wplane = (size_t)nsteps * 2 * p.Opad;            // fragments per split plane
     const frag *wsb = reinterpret_cast<const frag *>(p.ws);
-    float xscale = 1.f, oscale = 1.f;
-    if constexpr (NP == 2) split_scales(p.sc, xscale, oscale);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -476,6 +479,8 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
     int brow = b0 + srow;
     if (brow >= p.B) brow = p.B - 1;                              // clamped rows are never stored
     const float *xrow = p.x + (size_t)brow * p.K + 8 * sho;
+    float xscale = 1.f;
+    if constexpr (NP == 2) xscale = ldexpf(1.f, row_scale_exp(p.sc, brow));     // this thread stages one row: the row's own block scale
     const bool has_act = p.scale != nullptr;
     float4 xa, xb;
     auto load_x = [&](int ks) {
@@ -567,7 +572,22 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
         buf ^= 1;
     }
     // ---- epilogue: C/D map: column (lane&31) = output channel, rows (r&3)+8*(r>>2)+4*h = keypoints --------------------------
-    float wmax = 0.f;
+    // NP = 2: per-row rescale factors and the per-row output maxima go through LDS (the tiles are dead: the loop ended with a barrier)
+    float *so = reinterpret_cast<float *>(smem);                 // [128] 2^-(e(row) + w_exp)
+    unsigned *rm = reinterpret_cast<unsigned *>(so + TB);        // [128] max |out[row]| of this tile
+    if constexpr (NP == 2) {
+        if (tid < TB) {
+            const int b = min(b0 + tid, p.B - 1);
+            so[tid] = ldexpf(1.f, -(row_scale_exp(p.sc, b) + p.sc.w_exp));
+            rm[tid] = 0u;
+        }
+        __syncthreads();
+    }
+    float wmax[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wmax[rt][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int o = o0 + wc * 128 + t * 32 + j;
@@ -577,16 +597,26 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int b = b0 + wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int b = b0 + row;
                 if (b < p.B) {
-                    float v = (NP == 2 ? acc[rt][t][r] * oscale : acc[rt][t][r]) + bo;
+                    float v = (NP == 2 ? acc[rt][t][r] * so[row] : acc[rt][t][r]) + bo;
                     if (p.res) v += p.res[(size_t)b * p.O + o];
                     p.out[(size_t)b * p.O + o] = v;
-                    wmax = fmaxf(wmax, fabsf(v));
+                    wmax[rt][r] = fmaxf(wmax[rt][r], fabsf(v));
                 }
             }
     }
-    track_absmax(p.sc.out_absmax, wmax);
+    if constexpr (NP == 2) {
+        if (p.sc.out_rowmax) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicMax(rm + wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, __float_as_uint(wmax[rt][r]));
+            __syncthreads();
+            if (tid < TB && b0 + tid < p.B) atomicMax(reinterpret_cast<unsigned *>(p.sc.out_rowmax) + b0 + tid, rm[tid]);
+        }
+    }
 }
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -772,10 +802,10 @@ extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const 
 }
 
 extern "C" int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *bn_scale, const float *bn_shift,
-                                      float act_smax, float act_tmax, const float *in_absmax_dev, float *out, float *out_absmax_dev,
+                                      float act_smax, float act_tmax, const float *in_rowmax_dev, float *out, float *out_rowmax_dev,
                                       const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
-    ROREG_REQUIRE(in_absmax_dev, "roreg_group_conv_f16x2: in_absmax_dev is required");
-    SplitScale sc = {in_absmax_dev, act_smax, act_tmax, w_exp, out_absmax_dev};
+    ROREG_REQUIRE(in_rowmax_dev, "roreg_group_conv_f16x2: in_rowmax_dev is required");
+    SplitScale sc = {in_rowmax_dev, act_smax, act_tmax, w_exp, out_rowmax_dev};
     return conv_split_common(2, x, wsplit2, bias, bn_scale, bn_shift, out, gather, B, Cin, Cout, Lin, Lout, KS, sc, stream);
 }
 
@@ -810,9 +840,9 @@ extern "C" int roreg_dense_split(const float *x, const void *wsplit, const float
 }
 
 extern "C" int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
-                                 float act_smax, float act_tmax, const float *in_absmax_dev, const float *residual, float *out,
-                                 float *out_absmax_dev, int B, int K, int O, void *stream) {
-    ROREG_REQUIRE(in_absmax_dev, "roreg_dense_f16x2: in_absmax_dev is required");
-    SplitScale sc = {in_absmax_dev, act_smax, act_tmax, w_exp, out_absmax_dev};
+                                 float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, float *out,
+                                 float *out_rowmax_dev, int B, int K, int O, void *stream) {
+    ROREG_REQUIRE(in_rowmax_dev, "roreg_dense_f16x2: in_rowmax_dev is required");
+    SplitScale sc = {in_rowmax_dev, act_smax, act_tmax, w_exp, out_rowmax_dev};
     return dense_common(2, x, wsplit2, bias, scale, shift, residual, out, B, K, O, sc, stream);
 }

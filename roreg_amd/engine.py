@@ -176,8 +176,10 @@ class RegistrationEngine:
                 c.nms[keynum] = sampler.sample_from_neighbours(c.det, flat[a:b])
 
     # ---- per pair ------------------------------------------------------------------------------------------
-    def sample(self, c0, c1, keynum):
-        """Keypoint sampling; consumes the global numpy RNG exactly like test/matcher.py:75-88."""
+    def sample(self, c0, c1, keynum, seed=None):
+        """Keypoint sampling; consumes the global numpy RNG exactly like test/matcher.py:75-88 (seed: re-seed it for this pair first)."""
+        if seed is not None:
+            np.random.seed(int(seed) % (2 ** 32))
         n0, n1 = c0.before.shape[0], c1.before.shape[0]
         if self.cfg.RD:
             # NMS sampling is a pure function of the cloud (keypoints, detector scores, keynum; no RNG): the reference recomputes
@@ -295,7 +297,7 @@ class RegistrationEngine:
         T2, st2 = hip.refine(k0, k1, scores, ird, T_in=T1, want_stats=True)
         return T2, best, (k0, k1, st1, st2)
 
-    def _yohoo_tasks(self, full, all_scores, max_iter, all_local_transforms):
+    def _yohoo_tasks(self, full, all_scores, max_iter, all_local_transforms, pair_seeds=None):
         """Estimator-tail tasks of the one-shot estimator (test/estimator.py:405-436)."""
         # One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
         # (estimator.py:423-425), and that draw depends on M (and, with --RM, on the scores) alone, so the hypothesis order is drawn
@@ -303,7 +305,9 @@ class RegistrationEngine:
         # The registration result is identical; the reference computes all M local transforms because its stages are coupled through
         # Trans_pre files.  all_local_transforms=True evaluates every correspondence like the reference does.
         hyps = []
-        for (c0, c1, matches), sc in zip(full, all_scores):
+        for q, ((c0, c1, matches), sc) in enumerate(zip(full, all_scores)):
+            if pair_seeds is not None:
+                np.random.seed((int(pair_seeds[q]) + 1) % (2 ** 32))
             rows = np.arange(matches.shape[0])
             if self.cfg.RM:                                                 # hypotheses only from the best-scored matches (:415-421)
                 num = max(sc.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
@@ -325,7 +329,7 @@ class RegistrationEngine:
             rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
         return rt, w_all
 
-    def _yohoc_tasks(self, full, all_scores, max_iter):
+    def _yohoc_tasks(self, full, all_scores, max_iter, pair_seeds=None):
         """Estimator-tail tasks of the rotation-bin RANSAC (test/estimator.py:173-241): coarse rotation of every correspondence of every
         pair in one launch (Des2R), one download, then per pair (host, the reference's order of generator calls) the bin statistics,
         the hypothesis draws and the 3-point Kabsch stack; ONE upload of all hypotheses.  -> (tasks, weights, {pair: (T, recalltime)}
@@ -338,6 +342,8 @@ class RegistrationEngine:
         jobs, skipped, o = [], {}, 0
         for i, ((c0, c1, _), sc, (off, n)) in enumerate(zip(full, all_scores, batch.offsets)):     # sequential: the global generator
             pps = m_host[o:o + sizes[i]]; o += sizes[i]
+            if pair_seeds is not None:
+                np.random.seed((int(pair_seeds[i]) + 1) % (2 ** 32))
             if c0.keys_host is None:
                 c0.keys_host = c0.keys.cpu().numpy()
             if c1.keys_host is None:
@@ -361,8 +367,11 @@ class RegistrationEngine:
         return rt, w_all, skipped
 
     # ---- whole scene -----------------------------------------------------------------------------------------
-    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False):
+    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None):
         """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
+        pair_seeds: optional one integer per pair -- the global numpy generator is re-seeded with it before the pair's keypoint sampling
+        and with seed + 1 before its hypothesis draws, so a pair's result is a function of the pair alone (whatever other pairs this
+        call processes: the multi-GPU driver's rank-count independence).  None = the reference's single global stream.
         Returns [PairResult]."""
         keynum = self.cfg.keynum if keynum is None else keynum
         max_iter = self.cfg.max_iter if max_iter is None else max_iter
@@ -380,16 +389,17 @@ class RegistrationEngine:
         full, all_scores = [], []
         if self.cfg.RM:
             jobs = []
-            for a, b in pair_ids:
+            for q, (a, b) in enumerate(pair_ids):
                 c0, c1 = clouds[int(a)], clouds[int(b)]
-                jobs.append((c0, c1) + tuple(self.sample(c0, c1, keynum)))
+                jobs.append((c0, c1) + tuple(self.sample(c0, c1, keynum, None if pair_seeds is None else pair_seeds[q])))
             for (c0, c1, _, _), (m, sc) in zip(jobs, self.match_rm_many(jobs)):
                 full.append((c0, c1, m)); all_scores.append(sc)
             counts = np.array([m.shape[0] for _, _, m in full])
         else:
             # every pair's sampling first (host RNG in the reference's order), ONE upload of all row lists, then the whole
             # matcher stage in three launches
-            samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum) for a, b in pair_ids]   # host; runs under the extractor's kernels
+            samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
+                       for q, (a, b) in enumerate(pair_ids)]                                        # host; runs under the extractor's kernels
             flat = np.concatenate([np.ascontiguousarray(x, np.int64) for s in samples for x in s]) if samples else np.zeros(0, np.int64)
             flat_dev = torch.from_numpy(flat).cuda()
             tasks, o = [], 0
@@ -406,9 +416,9 @@ class RegistrationEngine:
         # stage 4: all pairs
         yohoc = getattr(self.cfg, 'ET', 'yohoo') == 'yohoc'
         if yohoc:
-            rt, w_all, skipped = self._yohoc_tasks(full, all_scores, max_iter)
+            rt, w_all, skipped = self._yohoc_tasks(full, all_scores, max_iter, pair_seeds)
         else:
-            (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms), {}
+            (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms, pair_seeds), {}
         t0 = self._mark('local_transforms', t0)
         ird = float(self.cfg.ransac_ird)
         best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird)

@@ -85,8 +85,9 @@ PROTOTYPES = {
     'roreg_irrep_gemm_tiles_m': (c_size_t, [c_int, c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    'roreg_row_bound': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }
 
 
@@ -222,9 +223,10 @@ def full_gather():
     return gather_table('nei60', tables().Nei)
 
 
-def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False, in_absmax=None, want_absmax=False):
+def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False, in_rowmax=None, want_rowmax=False):
     """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32.  split: use the 3 x bf16 split kernel (f32-accurate) where its shape constraints hold;
-    with in_absmax (device float32[1], tracked max |x|) the fp16 x 2 kernel, which can also return the tracked max |out| (want_absmax)."""
+    with in_rowmax (device float32 [B], tracked max |x[b]| per row) the fp16 x 2 kernel, whose block scale is per row (a row's result does
+    not depend on the other rows of the batch); it can also return the tracked per-row max |out[b]| (want_rowmax)."""
     ensure_tables()
     B, Cin, Lin = x.shape
     assert Cin == layer.Cin, (Cin, layer.Cin)
@@ -234,15 +236,17 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
     split_ok = residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0
-    if in_absmax is not None:
+    if in_rowmax is not None:
         if not split_ok:
             raise HipError('group_conv: the fp16 x 2 kernel does not support this shape')
+        if in_rowmax.numel() != B:
+            raise HipError(f'group_conv: in_rowmax must hold one value per row ({B}), got {in_rowmax.numel()}')
         w2, w_exp, smax, tmax = _conv_wsplit2(layer)
-        amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_absmax else None
+        amax = torch.zeros(B, dtype=torch.float32, device=x.device) if want_rowmax else None
         _check(lib().roreg_group_conv_f16x2(_ptr(x, torch.float32), _ptr(w2), w_exp, _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift), smax, tmax,
-                                            _ptr(in_absmax, torch.float32), _ptr(out, torch.float32), _ptr(amax), _ptr(gather, torch.int32),
+                                            _ptr(in_rowmax, torch.float32), _ptr(out, torch.float32), _ptr(amax), _ptr(gather, torch.int32),
                                             B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv_f16x2')
-        return (out, amax) if want_absmax else out
+        return (out, amax) if want_rowmax else out
     if split and split_ok:
         _check(lib().roreg_group_conv_split(_ptr(x, torch.float32), _ptr(_conv_wsplit(layer)), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
                                             _ptr(out, torch.float32), _ptr(gather, torch.int32), B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()),
@@ -769,10 +773,13 @@ def coef_views(buf, C, B):
 _tile_cache = {}
 
 
-def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_absmax=None):
+def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound=None, next_bound=None):
     """coefficients [60*C*Bp] -> [60*O*Bp] through the five per-irrep GEMMs (Bp = coef_pitch(B): the GEMMs run on the padded width).
     split: the five 3xbf16-split weight tensors (f32-accurate GEMM on the bf16 matrix cores) or None for the f32-input MFMA kernel.
-    add: optional coefficient buffer [60*O*Bp] summed onto the result in the epilogue (residual short cut in the irrep domain)."""
+    add: optional coefficient buffer [60*O*Bp] summed onto the result in the epilogue (residual short cut in the irrep domain).
+    f16x2 = (five fp16x2 weight tensors, w_exp): X_buf holds the fp16 hi/lo words ft_nonlin(split='f16x2', out_bound=x_bound) wrote under the
+    per-keypoint bound x_bound [Bp]; next_bound = (u [O], v [O]) (NextBound of the following nonlinearity) additionally returns the
+    per-keypoint bound [Bp] of the NEXT transform's coefficients: -> (out, bound)."""
     Bp = coef_pitch(B)
     if X_buf.numel() != 60 * C * Bp or (add is not None and add.numel() != 60 * O * Bp):
         raise HipError(f'irrep_gemm: coefficient buffers must hold 60*C*{Bp} floats (B={B} padded to the 32-keypoint pitch)')
@@ -790,9 +797,19 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_absma
     av = _ptr_array(coef_views(add, O, B)) if add is not None else None
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    if f16x2 is not None:                               # (five fp16x2 weight tensors, w_exp); x_absmax: device scalar float32[1]
+    bound_out = None
+    if f16x2 is not None:
         wl, w_exp = f16x2
-        _check(lib().roreg_irrep_gemm_f16x2(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(wl), _ptr(x_absmax, torch.float32), int(w_exp), C, O, Bp,
+        if x_bound is None or x_bound.numel() != Bp:
+            raise HipError(f'irrep_gemm: the fp16 x 2 GEMM needs x_bound with one value per (padded) keypoint ({Bp})')
+        nu = nv = None
+        if next_bound is not None:
+            nu, nv = next_bound
+            if nu.numel() != O or nv.numel() != O:
+                raise HipError('irrep_gemm: next_bound must hold one (u, v) per output channel')
+            bound_out = torch.zeros(Bp, dtype=torch.float32, device=X_buf.device)
+        _check(lib().roreg_irrep_gemm_f16x2(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(wl), _ptr(x_bound, torch.float32), int(w_exp),
+                                            _ptr(nu, torch.float32), _ptr(nv, torch.float32), _ptr(bound_out), C, O, Bp,
                                             _ptr(t, torch.int32), int(t.shape[0]), tile_m, _stream()), 'roreg_irrep_gemm_f16x2')
     elif split is not None:
         _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]),
@@ -802,11 +819,87 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_absma
                'roreg_irrep_gemm')
     if PROFILE is not None:
         e1.record(); PROFILE.append((('irrep_gemm_f16x2' if f16x2 is not None else 'irrep_gemm_split' if split is not None else 'irrep_gemm', Bp, C, O), e0, e1))
+    return (out, bound_out) if next_bound is not None else out
+
+
+def row_bound(x, bn=None):
+    """x [B,C,60] group-domain tensor -> float32 [Bp]: sqrt(60) * max_{c,g} |act(x[b])| (act = ReLU(BN(.)) with bn = (scale, shift), else the
+    identity), a bound on every coefficient of FT(act(x[b])); 0 for the pad keypoints.  The x_bound of a layer fed from the group domain."""
+    B, C = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty(coef_pitch(B), dtype=torch.float32, device=x.device)
+    scale, shift = bn if bn is not None else (None, None)
+    _check(lib().roreg_row_bound(_ptr(x, torch.float32), _ptr(scale), _ptr(shift), _ptr(out), B, C, _stream()), 'roreg_row_bound')
     return out
 
 
+def _keypoint_of_columns(d, Bp):
+    """keypoint index of every GEMM column of an irrep of dimension d (columns are blocked by 32 keypoints)."""
+    n = torch.arange(d * Bp, device='cuda')
+    return ((n // 32) // d) * 32 + (n % 32)
+
+
+def bound_exp(bound):
+    """e with bound * 2^e < 2^14, as the kernels derive it (tensor in, int32 tensor out)."""
+    _, ex = torch.frexp(bound.float())
+    e = torch.where((bound > 0) & torch.isfinite(bound), 14 - ex, torch.zeros_like(ex))
+    return e.clamp(-100, 100)
+
+
+def pack_coefs_f16x2(X_buf, C, B, bound=None):
+    """float32 coefficient buffer -> (fp16 hi/lo words in the layout roreg_ft_nonlin(split=2) writes, per-keypoint bound [Bp]).
+    Test / tooling helper (torch ops): the product path gets its split operands from ft_nonlin directly."""
+    Bp = coef_pitch(B)
+    views = coef_views(X_buf, C, B)
+    if bound is None:
+        bound = torch.zeros(Bp, dtype=torch.float32, device=X_buf.device)
+        for r, v in enumerate(views):
+            kp = _keypoint_of_columns(IRREP_DIMS[r], Bp)
+            bound.scatter_reduce_(0, kp, v.abs().amax(0), 'amax')
+    e = bound_exp(bound)
+    out = torch.empty_like(X_buf)
+    for r, (v, o) in enumerate(zip(views, coef_views(out, C, B))):
+        kp = _keypoint_of_columns(IRREP_DIMS[r], Bp)
+        y = torch.ldexp(v, e[kp][None, :])
+        hi = y.half()
+        lo = (y - hi.float()).half()
+        w = (hi.view(torch.int16).to(torch.int32) & 0xffff) | (lo.view(torch.int16).to(torch.int32) << 16)
+        o.copy_(w.view(torch.float32))
+    return out, bound
+
+
+def unpack_coefs_f16x2(X_words, bound, C, B):
+    """Inverse of the split: fp16 hi/lo words + per-keypoint bound -> float32 coefficients (hi + lo) * 2^-e.  Test helper."""
+    Bp = coef_pitch(B)
+    e = bound_exp(bound)
+    out = torch.empty_like(X_words)
+    for r, (v, o) in enumerate(zip(coef_views(X_words, C, B), coef_views(out, C, B))):
+        kp = _keypoint_of_columns(IRREP_DIMS[r], Bp)
+        w = v.view(torch.int32)
+        hi = (w & 0xffff).to(torch.int16).view(torch.float16).float()
+        lo = (w >> 16).to(torch.int16).view(torch.float16).float()
+        o.copy_(torch.ldexp(hi + lo, -e[kp][None, :]))
+    return out
+
+
+def next_bound(bn, bias, bias2=None):
+    """(u, v) device float32 [O] of the bound a GEMM epilogue propagates to the next transform (include/roreg_hip.h, roreg_irrep_gemm_f16x2):
+    the next nonlinearity is x = ReLU(scale_o (IFT(T)_o + bias_o) + shift_o); with an orthonormal 60 x 60 transform
+    |FT(x)_q| <= sqrt(60) max_g |x(g)| and |IFT(T)(g)| <= sqrt(60) max_q |T_q|, so  |FT(x)| <= max_{o,q} (60 |scale_o| |T_oq| + sqrt(60) (|scale_o| |bias_o| + |shift_o|)).
+    A 2^-9 margin covers the float32 rounding of the transforms themselves."""
+    scale, shift = bn
+    sc = scale.detach().double().abs().cpu(); sh = shift.detach().double().abs().cpu()
+    b = bias.detach().double().cpu() + (bias2.detach().double().cpu() if bias2 is not None else 0.0)
+    k = 1.0 + 2.0 ** -9
+    u = (60.0 * k) * sc
+    v = (np.sqrt(60.0) * k) * (sc * b.abs() + sh) + 1e-30
+    return u.float().cuda().contiguous(), v.float().cuda().contiguous()
+
+
 def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
-              g_map=None, Lout=60, Lvalid=60, split=False, want_absmax=False):
+              g_map=None, Lout=60, Lvalid=60, split=False, out_bound=None, want_rowmax=False):
+    """split='f16x2' with coefficient output: out_bound [Bp] (row_bound() or the producing GEMM's propagated bound) is required and the
+    result holds fp16 hi/lo words for irrep_gemm(f16x2=...) instead of floats.  want_rowmax (group-domain output): also return the
+    per-keypoint max |out[b]| [B] (the block scale of the fp16 x 2 convolution that follows)."""
     ensure_fourier()
     dev = (coef_in if coef_in is not None else x_spatial).device
     if spatial_out:
@@ -814,13 +907,18 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     else:
         out = torch.empty(coef_size(C, B), dtype=torch.float32, device=dev); xout = _ptr(out); osp = None
     scale, shift = bn if bn is not None else (None, None)
-    amax = torch.zeros(1, dtype=torch.float32, device=dev) if want_absmax else None
+    if want_rowmax and not spatial_out:
+        raise HipError('ft_nonlin: want_rowmax goes with spatial_out')
+    amax = torch.zeros(B, dtype=torch.float32, device=dev) if want_rowmax else None
     if coef_in is not None and coef_in.numel() != coef_size(C, B):
         raise HipError(f'ft_nonlin: coef_in must hold 60*C*{coef_pitch(B)} floats')
+    if out_bound is not None and out_bound.numel() != coef_pitch(B):
+        raise HipError(f'ft_nonlin: out_bound must hold one value per (padded) keypoint ({coef_pitch(B)})')
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
-                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 2 if split == 'f16x2' else (1 if split else 0), _ptr(amax), _stream()), 'roreg_ft_nonlin')
-    return (out, amax) if want_absmax else out
+                                 _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 2 if split == 'f16x2' else (1 if split else 0),
+                                 _ptr(out_bound, torch.float32), _ptr(amax), _stream()), 'roreg_ft_nonlin')
+    return (out, amax) if want_rowmax else out
 
 
 def _bf16_split3(x):
@@ -893,19 +991,21 @@ class DenseSplitLayer:
         self.shift = torch.from_numpy(np.ascontiguousarray(shift, np.float32)).cuda() if shift is not None else None
 
 
-def dense_split(x, layer, residual=None, in_absmax=None, want_absmax=False):
-    """x [B, K] float32 (device, contiguous) -> [B, O].  in_absmax (device float32[1], the tracked max |x|): use the fp16 x 2 kernel;
-    want_absmax: also return the tracked max |out| (device float32[1]) for the next layer."""
+def dense_split(x, layer, residual=None, in_rowmax=None, want_rowmax=False):
+    """x [B, K] float32 (device, contiguous) -> [B, O].  in_rowmax (device float32 [B], the tracked max |x[b]| per row): use the fp16 x 2
+    kernel (per-row block scale); want_rowmax: also return the tracked per-row max |out[b]| (device float32 [B]) for the next layer."""
     B, K = x.shape
     if K != layer.K:
         raise HipError(f'dense_split: K mismatch ({K} vs {layer.K})')
     out = torch.empty((B, layer.O), dtype=torch.float32, device=x.device)
-    if in_absmax is not None:
-        amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_absmax else None
+    if in_rowmax is not None:
+        if in_rowmax.numel() != B:
+            raise HipError(f'dense_split: in_rowmax must hold one value per row ({B}), got {in_rowmax.numel()}')
+        amax = torch.zeros(B, dtype=torch.float32, device=x.device) if want_rowmax else None
         _check(lib().roreg_dense_f16x2(_ptr(x, torch.float32), _ptr(layer.ws2), layer.w_exp, _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
-                                       layer.act_smax, layer.act_tmax, _ptr(in_absmax, torch.float32), _ptr(residual, torch.float32), _ptr(out),
+                                       layer.act_smax, layer.act_tmax, _ptr(in_rowmax, torch.float32), _ptr(residual, torch.float32), _ptr(out),
                                        _ptr(amax), B, K, layer.O, _stream()), 'roreg_dense_f16x2')
-        return (out, amax) if want_absmax else out
+        return (out, amax) if want_rowmax else out
     _check(lib().roreg_dense_split(_ptr(x, torch.float32), _ptr(layer.ws), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
                                    _ptr(residual, torch.float32), _ptr(out), B, K, layer.O, _stream()), 'roreg_dense_split')
     return out

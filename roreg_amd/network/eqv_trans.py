@@ -125,20 +125,23 @@ class ET_test(nn.Module):
                 hip.ensure_fourier()
                 sp = self.gemm != 'f32'
                 if self.gemm == 'f16x2':
-                    # fp16 x 2 all the way: every kernel tracks max |output| on the device as the next kernel's block scale
-                    X0, a0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', want_absmax=True)
-                    T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, f16x2=layer.wsplit2, x_absmax=a0)
+                    # fp16 x 2 all the way, every block scale PER ROW (correspondence): Conv_init's coefficients are split under the
+                    # row's own bound (hip.row_bound), every later kernel tracks max |output row| on the device as the next kernel's scale,
+                    # so a correspondence's quaternion does not depend on which other correspondences share the batch
+                    b0 = hip.row_bound(x, bn=bn)
+                    X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', out_bound=b0)
+                    T0 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0)
                     del X0
                     h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split='f16x2',
-                                          want_absmax=True)                                                          # [B,256,48]
+                                          want_rowmax=True)                                                          # [B,256,48]
                     del T0
-                    m, am = res._b_in(h, gather=gb, in_absmax=ah, want_absmax=True)                                  # [B,512,13]
+                    m, am = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True)                                  # [B,512,13]
                     sc = h[:, :, p0:p0 + 1].contiguous()                                                             # identity short cut at g=0
                     d_out, d0, d1, d2 = self._dense_plans()
-                    t, at = hip.dense_split(m.view(B, -1), d_out, residual=sc.view(B, -1), in_absmax=am, want_absmax=True)   # [B,256]
-                    z, az = hip.dense_split(t, d0, in_absmax=at, want_absmax=True)
-                    z, az = hip.dense_split(z, d1, in_absmax=az, want_absmax=True)
-                    return hip.dense_split(z, d2, in_absmax=az)                                                      # [B,4]
+                    t, at = hip.dense_split(m.view(B, -1), d_out, residual=sc.view(B, -1), in_rowmax=am, want_rowmax=True)   # [B,256]
+                    z, az = hip.dense_split(t, d0, in_rowmax=at, want_rowmax=True)
+                    z, az = hip.dense_split(z, d1, in_rowmax=az, want_rowmax=True)
+                    return hip.dense_split(z, d2, in_rowmax=az)                                                      # [B,4]
                 X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split=sp)
                 T0 = hip.irrep_gemm(X0, layer.wpack, 128, 256, B, split=layer.wsplit if sp else None)
                 del X0

@@ -64,23 +64,46 @@ class FourierGF:
             self.l_out = _Layer(self.net.Conv_out.comb_layer[2]); self.bn_3 = _fold_bn(self.net.Conv_out.comb_layer[0])
             self._key = key
 
+    def _plan_bounds(self):
+        """(u, v) tables of the bound each GEMM epilogue propagates to the transform that follows it (hip.next_bound)."""
+        if getattr(self, '_nb_key', None) != self._key:
+            self.nb_1 = hip.next_bound(self.bn_1, self.l_in.bias)
+            self.nb_2 = hip.next_bound(self.bn_2, self.l_1.bias)
+            self.nb_3 = hip.next_bound(self.bn_3, self.l_2.bias, self.l_in.bias)
+            self._nb_key = self._key
+
     def forward_raw(self, x):
         """x [B,32,60] device float32 -> eqv_raw = conv stack(x) + x  [B,32,60]."""
         self._plan()
         hip.ensure_fourier()
         B = x.shape[0]
         sp = {'f32': False, 'bf16x3': True, 'f16x2': 'f16x2'}[self.gemm]      # matrix-core mode of the transforms
-        f16 = self.gemm == 'f16x2'                    # GEMMs with fp16 x 2 operands: every transform also tracks max |coefficient|
+        if self.gemm == 'f16x2':
+            # fp16 x 2 GEMMs: every coefficient tensor is written already split (fp16 hi/lo words) under a PER-KEYPOINT power-of-two
+            # scale; the scale comes from a bound that exists before the tensor does -- from the group-domain input (row_bound) or
+            # propagated by the previous GEMM's epilogue (next_bound) -- so a keypoint's result depends on that keypoint alone.
+            self._plan_bounds()
+            b0 = hip.row_bound(x)
+            X0 = hip.ft_nonlin(B, 32, x_spatial=x, split=sp, out_bound=b0)
+            T0, b1 = hip.irrep_gemm(X0, None, 32, 256, B, f16x2=self.l_in.wsplit2, x_bound=b0, next_bound=self.nb_1)
+            del X0
+            X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=sp, out_bound=b1)
+            T1, b2 = hip.irrep_gemm(X1, None, 256, 512, B, f16x2=self.l_1.wsplit2, x_bound=b1, next_bound=self.nb_2)
+            del X1
+            X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split=sp, out_bound=b2)
+            del T1
+            T2, b3 = hip.irrep_gemm(X2, None, 512, 256, B, f16x2=self.l_2.wsplit2, x_bound=b2, next_bound=self.nb_3, add=T0)   # + identity short cut
+            del X2, T0
+            X3 = hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3, split=sp, out_bound=b3)
+            del T2
+            T3 = hip.irrep_gemm(X3, None, 256, 32, B, f16x2=self.l_out.wsplit2, x_bound=b3)
+            return hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True, split=sp)
 
-        def gemm(Xa, layer, C, O, add=None):
-            X, amax = Xa
-            if f16:
-                return hip.irrep_gemm(X, layer.wpack, C, O, B, f16x2=layer.wsplit2, x_absmax=amax, add=add)
+        def gemm(X, layer, C, O, add=None):
             return hip.irrep_gemm(X, layer.wpack, C, O, B, split=layer.wsplit if self.gemm == 'bf16x3' else None, add=add)
 
         def ft(C, **kw):
-            r = hip.ft_nonlin(B, C, split=sp, want_absmax=f16, **kw)
-            return r if f16 else (r, None)
+            return hip.ft_nonlin(B, C, split=sp, **kw)
         X0 = ft(32, x_spatial=x)
         T0 = gemm(X0, self.l_in, 32, 256)
         del X0
@@ -94,8 +117,7 @@ class FourierGF:
         X3 = ft(256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3)
         del T2
         T3 = gemm(X3, self.l_out, 256, 32)
-        out = hip.ft_nonlin(B, 32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True, split=sp)
-        return out
+        return ft(32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True)
 
 
 class FourierRD:
@@ -124,17 +146,29 @@ class FourierRD:
         hip.ensure_fourier()
         B = x.shape[0]
         sp = {'f32': False, 'bf16x3': True, 'f16x2': 'f16x2'}[self.gemm]
-        f16 = self.gemm == 'f16x2'
+        if self.gemm == 'f16x2':                                  # per-keypoint block scales, see FourierGF.forward_raw
+            if getattr(self, '_nb_key', None) != self._key:
+                self.nb_out = hip.next_bound(self.bn_out, self.l_in.bias)
+                self._nb_key = self._key
+            bs = hip.row_bound(x, bn=self.bn_sc)
+            Xs = hip.ft_nonlin(B, 32, x_spatial=x, bn=self.bn_sc, split=sp, out_bound=bs)
+            S = hip.irrep_gemm(Xs, None, self.l_sc.C, self.l_sc.O, B, f16x2=self.l_sc.wsplit2, x_bound=bs)
+            del Xs
+            ba = hip.row_bound(x, bn=self.bn_in)
+            Xa = hip.ft_nonlin(B, 32, x_spatial=x, bn=self.bn_in, split=sp, out_bound=ba)
+            T1, b1 = hip.irrep_gemm(Xa, None, self.l_in.C, self.l_in.O, B, f16x2=self.l_in.wsplit2, x_bound=ba, next_bound=self.nb_out)
+            del Xa
+            X1 = hip.ft_nonlin(B, 64, coef_in=T1, bias=self.l_in.bias, bn=self.bn_out, split=sp, out_bound=b1)
+            del T1
+            T2 = hip.irrep_gemm(X1, None, self.l_out.C, self.l_out.O, B, f16x2=self.l_out.wsplit2, x_bound=b1, add=S)
+            del X1, S
+            return hip.ft_nonlin(B, 16, coef_in=T2, bias=self.l_out.bias, bias2=self.l_sc.bias, spatial_out=True, split=sp)
 
-        def gemm(Xa, layer, add=None):
-            X, amax = Xa
-            if f16:
-                return hip.irrep_gemm(X, layer.wpack, layer.C, layer.O, B, f16x2=layer.wsplit2, x_absmax=amax, add=add)
+        def gemm(X, layer, add=None):
             return hip.irrep_gemm(X, layer.wpack, layer.C, layer.O, B, split=layer.wsplit if self.gemm == 'bf16x3' else None, add=add)
 
         def ft(C, **kw):
-            r = hip.ft_nonlin(B, C, split=sp, want_absmax=f16, **kw)
-            return r if f16 else (r, None)
+            return hip.ft_nonlin(B, C, split=sp, **kw)
         Xs = ft(32, x_spatial=x, bn=self.bn_sc)
         S = gemm(Xs, self.l_sc)
         del Xs
@@ -145,4 +179,4 @@ class FourierRD:
         del T1
         T2 = gemm(X1, self.l_out, add=S)
         del X1, S
-        return hip.ft_nonlin(B, 16, coef_in=T2, bias=self.l_out.bias, bias2=self.l_sc.bias, spatial_out=True, split=sp)
+        return ft(16, coef_in=T2, bias=self.l_out.bias, bias2=self.l_sc.bias, spatial_out=True)

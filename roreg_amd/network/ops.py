@@ -33,8 +33,8 @@ class _PlannedConv(nn.Module):
             self._plan_key = key
         return self._plan
 
-    def forward(self, x, gather=None, residual=None, split=False, in_absmax=None, want_absmax=False):
-        return hip.group_conv(x, self.plan(), gather=gather, residual=residual, split=split, in_absmax=in_absmax, want_absmax=want_absmax)
+    def forward(self, x, gather=None, residual=None, split=False, in_rowmax=None, want_rowmax=False):
+        return hip.group_conv(x, self.plan(), gather=gather, residual=residual, split=split, in_rowmax=in_rowmax, want_rowmax=want_rowmax)
 
 
 class Comb_Conv(_PlannedConv):

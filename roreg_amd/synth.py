@@ -102,7 +102,7 @@ class SynthScene:
 
 
 def make_scene(seed, n_clouds=2, n_kpts=256, overlap=0.6, feat_noise=0.05, coord_noise=0.0,
-               pair_ids=None, name='synth/scene0', extent=3.0):
+               pair_ids=None, name='synth/scene0', extent=3.0, portable=False):
     """Clouds share a common set of round(overlap*N) world points; the rest are private.
     Cloud c sees world point x_w at x_c = R_{g_c}^T (x_w - t_c) and its group feature as
     f_w[:, :, P[g_c]] + noise, so that descriptors are consistent with the pose (the same
@@ -126,7 +126,8 @@ def make_scene(seed, n_clouds=2, n_kpts=256, overlap=0.6, feat_noise=0.05, coord
         fw = np.concatenate([fs, fp], 0)
         g = 0 if c == 0 else int(rng.integers(0, G))
         t = np.zeros(3) if c == 0 else rng.uniform(-0.5, 0.5, 3)
-        xc = (xw - t) @ T.R[g]                       # rows: R_g^T (x - t)
+        # rows: R_g^T (x - t); portable: fixed evaluation order instead of a BLAS matmul (full-size golden cases, see below)
+        xc = _rows_times_matrix(xw - t, T.R[g]) if portable else (xw - t) @ T.R[g]
         if coord_noise > 0:
             xc = xc + rng.normal(0, coord_noise, xc.shape)
         fc = fw[:, :, T.P[g]] + feat_noise * rng.standard_normal(fw.shape).astype(np.float32)
@@ -137,3 +138,83 @@ def make_scene(seed, n_clouds=2, n_kpts=256, overlap=0.6, feat_noise=0.05, coord
     if pair_ids is None:
         pair_ids = [(a, b) for a in range(n_clouds) for b in range(a + 1, n_clouds)]
     return SynthScene(name, kps, feats, poses, pair_ids)
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size parity cases (tests/golden/full_*.npz store only the reference's small outputs; the inputs are rebuilt here from the seed)
+# ------------------------------------------------------------------------------------------------
+# These generators use only stream-stable Generator draws and correctly rounded elementwise numpy arithmetic (+ - * / sqrt written out
+# term by term: no BLAS matmul, no einsum, no sin/cos, whose last bit may depend on the host CPU), so the GPU box rebuilds bit-identical
+# inputs to the ones the reference was run on in the build container.
+def _rows_times_matrix(x, A):
+    """x [n,3] @ A [3,3] (or A [n,3,3]) with a fixed evaluation order."""
+    A = np.asarray(A)
+    col = (lambda j: A[:, j]) if A.ndim == 2 else (lambda j: A[:, :, j])
+    out = np.empty_like(x)
+    for j in range(3):
+        a = col(j)
+        a0, a1, a2 = (a[0], a[1], a[2]) if A.ndim == 2 else (a[:, 0], a[:, 1], a[:, 2])
+        out[:, j] = (x[:, 0] * a0 + x[:, 1] * a1) + x[:, 2] * a2
+    return out
+
+
+def make_neartie_scene(seed, n_clouds=2, n_kpts=5000, copies=4, name='synth/neartie', extent=3.0):
+    """Like make_scene(), but the world has only n_kpts/copies distinct descriptors: every cloud holds `copies` perturbed copies of each
+    (perturbation scales 0, 1e-6, 1e-4, 1e-2 in turn), so nearest-neighbour searches and 60x60 correlations meet exact duplicates and
+    thousands of near ties -- the cases in which summation order and tie-breaking decide an index."""
+    rng = np.random.default_rng(int(seed))
+    T = tables()
+    n_base = n_kpts // copies
+    xb = rng.uniform(0.0, extent, (n_base, 3))
+    fb = rng.standard_normal((n_base, 32, G)).astype(np.float32)
+    fb /= np.sqrt((fb * fb).sum(1, keepdims=True))
+    scales = np.array([0.0, 1e-6, 1e-4, 1e-2], np.float32)
+    kps, feats, poses = [], [], []
+    for c in range(n_clouds):
+        src = np.arange(n_kpts) % n_base
+        eps = scales[(np.arange(n_kpts) // n_base + c) % len(scales)]
+        xw = xb[src] + 0.02 * rng.standard_normal((n_kpts, 3))
+        fw = fb[src] + eps[:, None, None] * rng.standard_normal((n_kpts, 32, G)).astype(np.float32)
+        g = 0 if c == 0 else int(rng.integers(0, G))
+        t = np.zeros(3) if c == 0 else rng.uniform(-0.5, 0.5, 3)
+        xc = _rows_times_matrix(xw - t, T.R[g])       # rows: R_g^T (x - t)
+        fc = np.ascontiguousarray(fw[:, :, T.P[g]])
+        perm = rng.permutation(n_kpts)
+        kps.append(np.ascontiguousarray(xc[perm]))
+        feats.append(np.ascontiguousarray(fc[perm].astype(np.float32)))
+        poses.append((g, t))
+    pair_ids = [(a, b) for a in range(n_clouds) for b in range(a + 1, n_clouds)]
+    return SynthScene(name, kps, feats, poses, pair_ids)
+
+
+def make_ransac_case(seed, M=5000, H=1000, outlier=0.6, f32_scores=False, anchor=17):
+    """Correspondences + per-correspondence local transforms for the one-shot RANSAC stage at full size:
+    -> (k0 [M,3], k1 [M,3], scores [M], Trans [M,3,4], hyp int64 [H])."""
+    rng = np.random.default_rng(int(seed))
+    T = tables()
+    Rgt = T.R[anchor]; tgt = np.array([0.2, -0.4, 0.1])
+    k1 = rng.uniform(0, 3, (M, 3))
+    k0 = _rows_times_matrix(k1, Rgt.T) + tgt + 0.01 * rng.standard_normal((M, 3))
+    bad = rng.random(M) < outlier
+    k0[bad] = rng.uniform(0, 3, (int(bad.sum()), 3))
+    scores = rng.uniform(0.1, 1.0, M).astype(np.float32) if f32_scores else np.ones(M)
+    g = np.where(rng.random(M) < 0.3, anchor, rng.integers(0, G, M))
+    # small random rotation from the unit quaternion (1, v) / |(1, v)|  (sqrt and rational arithmetic only)
+    v = 0.025 * rng.standard_normal((M, 3))
+    nrm = np.sqrt(1.0 + v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2])
+    w, x, y, z = 1.0 / nrm, v[:, 0] / nrm, v[:, 1] / nrm, v[:, 2] / nrm
+    dR = np.empty((M, 3, 3))
+    dR[:, 0, 0] = 1 - 2 * (y * y + z * z); dR[:, 0, 1] = 2 * (x * y - z * w); dR[:, 0, 2] = 2 * (x * z + y * w)
+    dR[:, 1, 0] = 2 * (x * y + z * w); dR[:, 1, 1] = 1 - 2 * (x * x + z * z); dR[:, 1, 2] = 2 * (y * z - x * w)
+    dR[:, 2, 0] = 2 * (x * z - y * w); dR[:, 2, 1] = 2 * (y * z + x * w); dR[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    Rg = T.R[g]
+    R = np.empty((M, 3, 3))
+    for i in range(3):
+        for j in range(3):
+            R[:, i, j] = (dR[:, i, 0] * Rg[:, 0, j] + dR[:, i, 1] * Rg[:, 1, j]) + dR[:, i, 2] * Rg[:, 2, j]
+    Trans = np.zeros((M, 3, 4))
+    Trans[:, :, :3] = R
+    for i in range(3):
+        Trans[:, i, 3] = k0[:, i] - ((k1[:, 0] * R[:, i, 0] + k1[:, 1] * R[:, i, 1]) + k1[:, 2] * R[:, i, 2])
+    hyp = rng.permutation(M)[:H].astype(np.int64)
+    return k0, k1, scores, Trans, hyp

@@ -71,13 +71,17 @@ def test_ft_nonlin_split_matches_f32_path(group):
     assert float((Z32 - Zsp).abs().max()) < 1e-6 * float(Z32.abs().max())
     back = hip.ft_nonlin(B, C, coef_in=Xsp, resid_spatial=x, spatial_out=True, split=True)      # F^-1 F x + x = 2x
     assert float((back - 2 * x).abs().max()) < 2e-6 * float(x.abs().max())
-    # fp16 x 2 with per-keypoint-column scales
-    X16 = hip.ft_nonlin(B, C, x_spatial=x, split='f16x2')
+    # fp16 x 2 with per-keypoint-column scales; coefficient outputs leave as fp16 hi/lo words under the keypoint's bound
+    b0 = hip.row_bound(x)
+    assert bool((b0[:B] >= hip.pack_coefs_f16x2(X32, C, B)[1][:B]).all()) and float(b0[B:].abs().max() if b0.numel() > B else 0) == 0
+    X16 = hip.unpack_coefs_f16x2(hip.ft_nonlin(B, C, x_spatial=x, split='f16x2', out_bound=b0), b0, C, B)
     assert float((X32 - X16).abs().max()) < 6e-7 * scale
-    Y16 = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, bn=bn, split='f16x2')
+    yb = 1.01 * hip.pack_coefs_f16x2(Y32, C, B)[1]
+    Y16 = hip.unpack_coefs_f16x2(hip.ft_nonlin(B, C, coef_in=X32, bias=bias, bn=bn, split='f16x2', out_bound=yb), yb, C, B)
     assert float((Y32 - Y16).abs().max()) < 1.5e-6 * float(Y32.abs().max())
-    Z16 = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, spatial_out=True, g_map=gm, Lout=48, Lvalid=45, split='f16x2')
+    Z16, zmax = hip.ft_nonlin(B, C, coef_in=X32, bias=bias, spatial_out=True, g_map=gm, Lout=48, Lvalid=45, split='f16x2', want_rowmax=True)
     assert float((Z32 - Z16).abs().max()) < 1.5e-6 * float(Z32.abs().max())
+    assert torch.equal(zmax, Z16.abs().amax((1, 2)))                      # the tracked per-keypoint scale is the exact maximum of what was written
 
 
 def test_group_conv_split_is_f32_accurate(group):
@@ -99,9 +103,11 @@ def test_group_conv_split_is_f32_accurate(group):
     a = np.maximum(x.astype(np.float64) * scale[None, :, None] + shift[None, :, None], 0.0)
     ref = np.einsum('ock,bcjk->boj', conv.weight.detach().double().numpy()[:, :, 0, :], a[:, :, gather]) + conv.bias.detach().double().numpy()[None, :, None]
     s = np.abs(ref).max()
-    amax = xd.abs().max().reshape(1)
-    y16t, omax = hip.group_conv(xd, layer, gather=gd, in_absmax=amax, want_absmax=True)
-    assert float(omax) == float(y16t.abs().max())                          # the kernel tracks the exact maximum of what it wrote
+    amax = xd.abs().amax((1, 2))
+    y16t, omax = hip.group_conv(xd, layer, gather=gd, in_rowmax=amax, want_rowmax=True)
+    assert torch.equal(omax, y16t.abs().amax((1, 2)))                      # the kernel tracks the exact per-row maximum of what it wrote
+    sub = slice(5, 19)                                                     # a row's result does not depend on the other rows of the launch
+    assert torch.equal(hip.group_conv(xd[sub].contiguous(), layer, gather=gd, in_rowmax=amax[sub].contiguous()), y16t[sub])
     y16 = y16t.double().cpu().numpy()
     e32 = np.abs(y32 - ref).max() / s; esp = np.abs(ysp - ref).max() / s; e16 = np.abs(y16 - ref).max() / s
     assert e32 < 2e-6 and esp < 2e-6 and e16 < 2e-6, (e32, esp, e16)
@@ -120,8 +126,12 @@ def test_dense_split_is_f32_accurate():
         layer = hip.DenseSplitLayer(W, bias, sc, sh)
         xd = torch.from_numpy(x).cuda(); rd = torch.from_numpy(r).cuda() if res else None
         got = hip.dense_split(xd, layer, residual=rd).double().cpu().numpy()
-        g16, omax = hip.dense_split(xd, layer, residual=rd, in_absmax=xd.abs().max().reshape(1), want_absmax=True)
-        assert float(omax) == float(g16.abs().max())
+        rmax = xd.abs().amax(1)
+        g16, omax = hip.dense_split(xd, layer, residual=rd, in_rowmax=rmax, want_rowmax=True)
+        assert torch.equal(omax, g16.abs().amax(1))
+        if B > 40:                                                          # batch-composition independence of a row's result
+            sub = slice(17, 40)
+            assert torch.equal(hip.dense_split(xd[sub].contiguous(), layer, residual=rd[sub].contiguous() if res else None, in_rowmax=rmax[sub].contiguous()), g16[sub])
         a = x.astype(np.float64)
         if act:
             a = np.maximum(a * sc.astype(np.float64) + sh.astype(np.float64), 0.0)
@@ -143,9 +153,9 @@ def test_gemm_epilogue_residual_is_exact(group):
         plain = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp)
         fused = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=sp, add=A)
         assert torch.equal(fused, plain + A)
-    amax = X.abs().max().reshape(1)
-    plain = hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=amax)
-    assert torch.equal(hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=amax, add=A), plain + A)
+    Xp, xb = hip.pack_coefs_f16x2(X, C, B)
+    plain = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb)
+    assert torch.equal(hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb, add=A), plain + A)
 
 
 def test_gf_fourier_vs_direct_vs_golden(group):
@@ -181,11 +191,11 @@ def test_split_bf16_gemm_is_f32_accurate(group):
     x = rng.standard_normal((B, C, 60)).astype(np.float32) * np.abs(rng.standard_normal((B, C, 1))).astype(np.float32)
     xd = torch.from_numpy(x).cuda()
     X = hip.ft_nonlin(B, C, x_spatial=xd)
-    X, amax = hip.ft_nonlin(B, C, x_spatial=xd, want_absmax=True)
-    assert float(amax) == float(X.abs().max())                                           # the tracked block scale is the tensor's exact maximum
+    xb = hip.row_bound(xd)
+    Xp = hip.ft_nonlin(B, C, x_spatial=xd, split='f16x2', out_bound=xb)
     T32 = hip.irrep_gemm(X, L.wpack, C, Oc, B)
     Tsp = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=L.wsplit)
-    T16 = hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=amax)
+    T16 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb)
     y32 = hip.ft_nonlin(B, Oc, coef_in=T32, bias=L.bias, spatial_out=True).double().cpu().numpy()
     ysp = hip.ft_nonlin(B, Oc, coef_in=Tsp, bias=L.bias, spatial_out=True).double().cpu().numpy()
     y16 = hip.ft_nonlin(B, Oc, coef_in=T16, bias=L.bias, spatial_out=True).double().cpu().numpy()
@@ -198,8 +208,8 @@ def test_split_bf16_gemm_is_f32_accurate(group):
 
 
 def test_f16x2_block_scale_survives_outliers(group):
-    """One activation column 10^4 times larger than the rest sets the tensor-wide block scale of the fp16 x 2 GEMM; the OTHER columns must keep
-    their accuracy (the hi/lo split keeps 22 bits within 18 binades of the maximum)."""
+    """One coefficient 10^4 times larger than the rest sets the block scale of ITS keypoint in the fp16 x 2 GEMM; the keypoint's other columns
+    must keep their accuracy (the hi/lo split keeps 22 bits within ~11 binades of the bound), and other keypoints are not affected at all."""
     from roreg_amd import hip
     from roreg_amd.network.gf_fourier import _Layer
     rng = np.random.default_rng(3)
@@ -208,7 +218,8 @@ def test_f16x2_block_scale_survives_outliers(group):
     X = torch.from_numpy(rng.standard_normal(hip.coef_size(C, B)).astype(np.float32)).cuda()
     v = hip.coef_views(X, C, B)
     v[4][:, 7] *= 1e4
-    T16 = hip.irrep_gemm(X, L.wpack, C, Oc, B, f16x2=L.wsplit2, x_absmax=X.abs().max().reshape(1))
+    Xp, xb = hip.pack_coefs_f16x2(X, C, B)
+    T16 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb)
     T32 = hip.irrep_gemm(X, L.wpack, C, Oc, B)
     ref = L.dense[4].astype(np.float64) @ v[4].double().cpu().numpy()
     cols = [c for c in range(600) if c != 7]
@@ -218,6 +229,66 @@ def test_f16x2_block_scale_survives_outliers(group):
         g = hip.coef_views(T, Oc, B)[4].double().cpu().numpy()[:ref.shape[0]]
         err[name] = float((np.abs(g[:, cols] - ref[:, cols]).max(0) / scale).max())
     assert err['f16'] < 3 * err['f32'] + 1e-7 and err['f16'] < 4e-6, err
+
+
+def test_gemm_bound_propagation(group):
+    """The bound a GEMM epilogue hands to the next transform really bounds that transform's coefficients, per keypoint, and is not
+    absurdly loose (the split keeps full accuracy while bound / max <= ~2^11)."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(21)
+    B, C, Oc = 200, 64, 256
+    L = _Layer(torch.nn.Conv2d(C, Oc, (1, 13)))
+    x = torch.from_numpy((rng.standard_normal((B, C, 60)) * np.exp(2 * rng.standard_normal((B, 1, 1)))).astype(np.float32)).cuda()
+    bn = (torch.from_numpy(rng.uniform(0.5, 1.5, Oc).astype(np.float32)).cuda(), torch.from_numpy(rng.standard_normal(Oc).astype(np.float32)).cuda())
+    xb = hip.row_bound(x)
+    Xp = hip.ft_nonlin(B, C, x_spatial=x, split='f16x2', out_bound=xb)
+    T, nb = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb, next_bound=hip.next_bound(bn, L.bias))
+    Y = hip.ft_nonlin(B, Oc, coef_in=T, bias=L.bias, bn=bn, split=True)              # float32 coefficients of the next transform
+    actual = hip.pack_coefs_f16x2(Y, Oc, B)[1]
+    assert bool((nb >= actual).all())
+    assert float((nb[:B] / actual[:B].clamp_min(1e-30)).max()) < 2.0 ** 9
+    # and the split written under it decodes to the float32 coefficients
+    Y16 = hip.unpack_coefs_f16x2(hip.ft_nonlin(B, Oc, coef_in=T, bias=L.bias, bn=bn, split='f16x2', out_bound=nb), nb, Oc, B)
+    kp_scale = actual[hip._keypoint_of_columns(5, hip.coef_pitch(B))]                 # per-keypoint magnitude, irrep of dimension 5
+    err = (hip.coef_views(Y16, Oc, B)[4] - hip.coef_views(Y, Oc, B)[4]).abs().amax(0) / kp_scale.clamp_min(1e-30)
+    assert float(err.max()) < 2e-6
+
+
+def test_extractor_is_batch_invariant(group):
+    """A cloud's features are bit-identical whether it is extracted alone or inside a batch with other clouds, in every matrix-core mode
+    (the reference's bs_GF independence, test/extractor.py:51-58): all block scales are per keypoint."""
+    from roreg_amd.network import name2network
+    net = name2network['GF_test'](default_config())
+    synth.seeded_state_dict(net, 101)
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((333, 32, 60))).astype(np.float32)
+    big = (50.0 * rng.standard_normal((700, 32, 60))).astype(np.float32)                # much larger magnitudes than `a`
+    net.PartI_net.mode = 'fourier'
+    net(torch.from_numpy(a[:8]))
+    for mode in ('f16x2', 'bf16x3', 'f32'):
+        net.PartI_net._fourier.gemm = mode
+        alone = net(torch.from_numpy(a))['eqv']
+        both = net(torch.from_numpy(np.concatenate([big[:401], a, big[401:]])))['eqv'][401:401 + 333]
+        assert torch.equal(alone, both), mode
+    net.PartI_net._fourier.gemm = 'f16x2'
+
+
+def test_et_is_batch_invariant(group):
+    from roreg_amd.network import name2network
+    z = load_golden('et_forward')
+    net = name2network['ET_test'](default_config())
+    synth.seeded_state_dict(net, int(z['seed']))
+    keys = ('before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx')
+    rng = np.random.default_rng(6)
+    for mode in ('f16x2', 'bf16x3'):
+        net.gemm = mode
+        full = net({k: torch.from_numpy(z[k].copy()) for k in keys})['quaternion_pre']
+        sub = slice(7, 23)
+        scaled = {k: torch.from_numpy(z[k][sub].copy()) for k in keys}
+        part = net(scaled)['quaternion_pre']
+        assert torch.equal(part, full[sub]), mode
+    net.gemm = 'f16x2'
 
 
 def test_gf_both_gemm_modes_vs_golden(group):

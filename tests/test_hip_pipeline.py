@@ -311,6 +311,19 @@ def test_distributed_driver_equals_evaluator(tmp_path, RD, RM, ET):
             assert np.abs(T - want).max() < 1e-10
 
 
+def test_evaluate_world_1_equals_world_2_on_device(tmp_path):
+    """The real engine behind run_distributed.evaluate(seed=...): two ranks (gloo, both on GPU 0; a scene's pair list is cut across them,
+    so its clouds are extracted in different batches on each rank) give bit-identical per-pair results to one rank -- per-keypoint block
+    scales (no batch-composition dependence) + per-pair generator streams."""
+    from test_host_logic import run_distributed_worlds
+    one, two = run_distributed_worlds(tmp_path, 'real', timeout=900)
+    assert int(two['split']) == 1
+    assert sorted(one.files) == sorted(two.files)
+    for k in one.files:
+        if k != 'split':
+            assert np.array_equal(one[k], two[k]), k
+
+
 def test_dropin_end_to_end_on_a_demo_layout(tmp_path, monkeypatch):
     """The reference's entry point flow (parse flags -> yoho_evaluator(cfg).run()) through the drop-in aliases, on a dataset laid out
     like data/origin_data/demo/kitchen (binary PLY clouds, keypoint index files, gt.log) with checkpoints under --model_fn."""

@@ -252,6 +252,36 @@ def test_gather_table_world_size_2_gloo(tmp_path):
         assert 'ok' in o
 
 
+def run_distributed_worlds(tmp_path, mode, timeout=600):
+    """run_distributed.evaluate(seed=...) at world size 1 and 2 (tests/_dist_worker.py) -> the two rank-0 result files."""
+    worker = os.path.join(ROOT, 'tests', '_dist_worker.py')
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    outs = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = str(s.getsockname()[1]); s.close()
+        work = tmp_path / f'w{world}'; work.mkdir()
+        out = str(tmp_path / f'result_w{world}.npz')
+        procs = [subprocess.Popen([sys.executable, worker, ROOT, str(work), str(r), str(world), port, mode, out], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, env=env) for r in range(world)]
+        logs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+        for p, o in zip(procs, logs):
+            assert p.returncode == 0 and 'ok' in o, o
+        outs[world] = np.load(out)
+    return outs[1], outs[2]
+
+
+def test_evaluate_does_not_depend_on_the_number_of_ranks(tmp_path):
+    """--seed: every pair draws from its own generator stream, so the result table at world size 2 (one scene cut across the ranks by
+    the shard plan, the whole multi-rank control flow over gloo) equals the one at world size 1.  Host logic only (stub engine); the
+    same check with the real engine is a GPU test (tests/test_hip_pipeline.py)."""
+    one, two = run_distributed_worlds(tmp_path, 'stub')
+    assert int(two['split']) == 1                                # the plan really cut a scene
+    assert sorted(one.files) == sorted(two.files)
+    for k in one.files:
+        if k != 'split':
+            assert np.array_equal(one[k], two[k]), k
+
+
 def test_rr_cal_benchmark_matches_reference(tmp_path):
     """Redwood-protocol registration recall (utils/RR_cal.py) on the reference's own inputs/outputs."""
     from types import SimpleNamespace as NS

@@ -1,0 +1,133 @@
+"""Full-size (BASELINE-size) parity fixtures: tests/golden/full_*.npz.
+
+Same rules as tools/gen_golden.py (build container only; the reference is imported from /root/reference and run on CPU; only
+vectors are written).  The INPUTS of every case are rebuilt from a seed by roreg_amd/synth.py (portable arithmetic only), so the
+fixtures hold just the reference's small outputs: index lists, packed inlier masks, transforms and strided samples of the big tensors.
+
+    python tools/gen_golden_full.py [stages] [ransac] [match_ot] [pipeline]        (no argument = all; ~10 minutes on 8 cores)
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_golden as gg                       # noqa: E402  (shims + reference imports; changes cwd to /root/reference)
+from gen_golden import synth, tables, name2network, name2extractor, name2matcher, name2estimator, ref_est, ref_utils, save, REF   # noqa: E402
+
+STAGE_SEED, RANSAC_SEED, OT_SEED, PIPE_SEED = 31, 41, 51, 61
+
+
+def _i16(a):
+    a = np.asarray(a)
+    assert a.min() >= -1 and a.max() < 32768
+    return a.astype(np.int16)
+
+
+def gen_stages():
+    """matcher -> Des2R -> ET/Trans_pre -> one-shot RANSAC of the reference on a 5000-keypoint near-tie pair, stage outputs stored."""
+    root = tempfile.mkdtemp(prefix='golden_full_')
+    try:
+        cfg = gg.make_cfg(root, keynum=5000)
+        cfg.bs_ET = 500
+        ds = synth.make_neartie_scene(STAGE_SEED, n_clouds=2, n_kpts=5000)
+        ds.write_inputs(cfg.output_cache_fn)
+        base = f'{cfg.output_cache_fn}/{ds.name}'
+        os.makedirs(f'{base}/YOHO_Output_Group_feature')
+        for pc, f in zip(ds.pc_ids, ds.feats):                       # the extractor stage is skipped: eqv := the scene's group features
+            np.save(f'{base}/YOHO_Output_Group_feature/{pc}.npy', f)
+        np.random.seed(1234)
+        name2matcher['matmul'](cfg).run(ds, 5000)
+        np.random.seed(4321)
+        name2estimator['yohoo'](cfg).run(ds, 5000, 1000)
+        md = f'{base}/match_5000'
+        m = np.load(f'{md}/0-1.npy'); dr = np.load(f'{md}/DR_index/0-1.npy'); tp = np.load(f'{md}/Trans_pre/0-1.npy')
+        r = np.load(f'{md}/yohoo/1000iters/0-1.npz', allow_pickle=True)
+        print('   matches', m.shape, 'recalltime', int(r['recalltime']))
+        save('full_stages', scene_seed=np.int64(STAGE_SEED), match=_i16(m), dr=dr.astype(np.int8), transpre=tp,
+             trans=r['trans'], recalltime=np.int64(r['recalltime']))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def gen_ransac():
+    out = {}
+    for tag, f32s in (('ones', False), ('f32', True)):
+        k0, k1, scores, Trans, hyp = synth.make_ransac_case(RANSAC_SEED + int(f32s), M=5000, H=1000, f32_scores=f32s)
+        rs = ref_est.yohoo_ransac(gg.make_cfg_like(gg.NS(ransac_ird=0.1, RM=f32s, match_n=0.5, output_cache_fn='/tmp', SO3_related_files=f'{REF}/utils/group_related')))
+        ov = np.array([rs.overlap_cal(k0, k1, Trans[i], scores) for i in hyp])
+        masks = np.stack([np.sum(np.square(k0 - ref_utils.transform_points(k1, Trans[i])), -1) < 0.1 * 0.1 for i in hyp])
+        best = int(np.argmax(ov))
+        r1 = rs.refiner.Refine_trans(k0, k1, Trans[hyp[best]], scores, inlinerdist=0.2)
+        r2 = rs.refiner.Refine_trans(k0, k1, r1, scores, inlinerdist=0.1)
+        print('   ', tag, 'best', best, 'overlap', ov[best], 'inliers', int(masks[best].sum()))
+        out.update({f'{tag}_seed': np.int64(RANSAC_SEED + int(f32s)), f'{tag}_overlap': ov, f'{tag}_masks': np.packbits(masks, axis=1),
+                    f'{tag}_best': np.int64(best), f'{tag}_refine1': r1, f'{tag}_refine2': r2})
+    save('full_ransac', **out)
+
+
+def gen_match_ot():
+    cfg = gg.make_cfg(tempfile.mkdtemp(prefix='golden_full_cfg_'))
+    net = name2network['RM_test'](cfg)
+    ck = torch.load(f'{REF}/checkpoints/FCGF/RM/model_best.pth')
+    net.load_state_dict(ck['network_state_dict'], strict=True); net.eval()
+    n = 2500
+    ds = synth.make_scene(OT_SEED, n_clouds=2, n_kpts=n, overlap=0.6, coord_noise=0.005, portable=True)
+    f0 = ds.feats[0]; f1 = ds.feats[1]
+    f0 = f0 / np.sqrt((f0 * f0).sum(1, keepdims=True)); f1 = f1 / np.sqrt((f1 * f1).sum(1, keepdims=True))
+    k0 = ds.get_kps('0').astype(np.float32); k1 = ds.get_kps('1').astype(np.float32)
+    batch = {'feats0': torch.from_numpy(f1[None].copy()), 'feats1': torch.from_numpy(f0[None].copy()),
+             'keys0': torch.from_numpy(k1[None].copy()), 'keys1': torch.from_numpy(k0[None].copy())}
+    with torch.no_grad():
+        r = net(batch)
+    m0 = r['matches0'][0].numpy(); m1 = r['matches1'][0].numpy()
+    print('   valid matches', int((m0 >= 0).sum()))
+    Z = r['scores'][0].numpy()
+    save('full_match_ot', scene_seed=np.int64(OT_SEED), n=np.int64(n), matches0=_i16(m0), matches1=_i16(m1),
+         matching_scores0=r['matching_scores0'][0].numpy(), matching_scores1=r['matching_scores1'][0].numpy(),
+         scores_sample=Z[::40, ::40].copy(), scores_lastrow=Z[-1, ::10].copy(), scores_lastcol=Z[::10, -1].copy(),
+         source_final_sample=r['source_final'][0, :, ::25, 0].numpy(), target_final_sample=r['target_final'][0, :, ::25, 0].numpy())
+    shutil.rmtree(cfg.base_dir, ignore_errors=True)
+
+
+def gen_pipeline():
+    """The reference end to end (GF -> mutual -> yohoo; seeded GF/ET weights) on three 5000-keypoint clouds."""
+    root = tempfile.mkdtemp(prefix='golden_full_')
+    try:
+        cfg = gg.make_cfg(root, keynum=5000)
+        cfg.bs_GF = 250; cfg.bs_ET = 500
+        ds = synth.make_scene(PIPE_SEED, n_clouds=3, n_kpts=5000, overlap=0.6, coord_noise=0.005, name='synth/scene0', portable=True)
+        ds.write_inputs(cfg.output_cache_fn)
+        name2extractor['yoho_des'](cfg).run(ds)
+        np.random.seed(1234)
+        name2matcher['matmul'](cfg).run(ds, 5000)
+        np.random.seed(4321)
+        name2estimator['yohoo'](cfg).run(ds, 5000, 1000)
+        base = f'{cfg.output_cache_fn}/{ds.name}'
+        out = {'scene_seed': np.int64(PIPE_SEED)}
+        for pc in ds.pc_ids:
+            y = np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')
+            out[f'yoho_sample_{pc}'] = y[::250].copy()
+            inv = y.mean(-1); inv = inv / (np.sqrt((inv * inv).sum(1, keepdims=True)) + 1e-5)
+            out[f'yoho_absmax_{pc}'] = np.float32(np.abs(y).max())
+        md = f'{base}/match_5000'
+        for a, b in ds.pair_ids:
+            out[f'match_{a}_{b}'] = _i16(np.load(f'{md}/{a}-{b}.npy'))
+            out[f'dr_{a}_{b}'] = np.load(f'{md}/DR_index/{a}-{b}.npy').astype(np.int8)
+            out[f'transpre_sample_{a}_{b}'] = np.load(f'{md}/Trans_pre/{a}-{b}.npy')[::16].copy()
+            r = np.load(f'{md}/yohoo/1000iters/{a}-{b}.npz', allow_pickle=True)
+            out[f'trans_{a}_{b}'] = r['trans']; out[f'recall_{a}_{b}'] = np.int64(r['recalltime'])
+            print('   pair', a, b, 'matches', out[f'match_{a}_{b}'].shape[0], 'recalltime', int(r['recalltime']))
+        save('full_pipeline', **out)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    todo = sys.argv[1:] or ['ransac', 'stages', 'match_ot', 'pipeline']
+    for name in todo:
+        print(name)
+        {'stages': gen_stages, 'ransac': gen_ransac, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline}[name]()
