@@ -387,20 +387,21 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = n0 + ncol_wave + t * 32 + j;
-            if (n >= N) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = mt * OT + row;
+            if (m >= M) continue;
+            float ur = 0.f, vr = 0.f;
+            if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = mt * OT + row;
-                if (m < M) {
-                    float o = acc[ot][t][r];
-                    if constexpr (NP == 2) o *= oscale[t];
-                    if (Add) o += Add[(size_t)m * N + n];
-                    Out[(size_t)m * N + n] = o;
-                    if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(su[row], fabsf(o), sv[row])); }
-                }
+            for (int t = 0; t < 4; ++t) {
+                const int n = n0 + ncol_wave + t * 32 + j;
+                if (n >= N) continue;
+                float o = acc[ot][t][r];
+                if constexpr (NP == 2) o *= oscale[t];
+                if (Add) o += Add[(size_t)m * N + n];
+                Out[(size_t)m * N + n] = o;
+                if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr)); }
             }
         }
     if constexpr (NP == 2) {
@@ -666,10 +667,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
                 if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (p.out_rowmax) {                                   // every lane issues the atomic (no branch around a VMEM operation in the pipelined loop)
+            if (p.out_rowmax) {
+                // every lane issues the atomic (no branch around a VMEM operation in the pipelined loop): both half-waves hold their
+                // keypoint's maximum, pad keypoints contribute 0 to the last valid one -- never a shared dump word, which would serialise
+                // every wave of the chip on one L2 atomic unit
                 wmax = fmaxf(wmax, __shfl_xor(wmax, 32));
-                unsigned *dst = (h == 0 && valid) ? reinterpret_cast<unsigned *>(p.out_rowmax) + b : reinterpret_cast<unsigned *>(p.dump) + lane;
-                atomicMax(dst, __float_as_uint(wmax));
+                atomicMax(reinterpret_cast<unsigned *>(p.out_rowmax) + bb, __float_as_uint(valid ? wmax : 0.f));
             }
         }
         if (!OUT_SPATIAL) {

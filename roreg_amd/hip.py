@@ -784,7 +784,7 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound
     if X_buf.numel() != 60 * C * Bp or (add is not None and add.numel() != 60 * O * Bp):
         raise HipError(f'irrep_gemm: coefficient buffers must hold 60*C*{Bp} floats (B={B} padded to the 32-keypoint pitch)')
     out = torch.empty(60 * O * Bp, dtype=torch.float32, device=X_buf.device)
-    tile_m = 256 if (f16x2 is not None and O % 256 == 0) else 128          # 256-row tiles = 8-wave workgroups (fp16 x 2 kernel)
+    tile_m = 256 if (f16x2 is not None and O % 256 == 0 and not os.environ.get('ROREG_TILE_M128')) else 128          # 256-row tiles = 8-wave workgroups (fp16 x 2 kernel)
     key = (O, Bp, tile_m)
     t = _tile_cache.get(key)
     if t is None:

@@ -9,15 +9,19 @@ for (C, O) in [(256, 512), (512, 256)]:
     conv = torch.nn.Conv2d(C, O, (1, 13))
     L = _Layer(conv)
     X = torch.randn(hip.coef_size(C, B), device='cuda') * torch.exp(torch.randn(hip.coef_size(C, B), device='cuda'))
-    amax = X.abs().max().reshape(1).float()
-    variants = [('f32', dict()), ('bf16x3', dict(split=L.wsplit)), ('fp16x2', dict(f16x2=L.wsplit2, x_absmax=amax))]
+    Xp, xb = hip.pack_coefs_f16x2(X, C, B)
+    bn = (torch.rand(O, device='cuda') + 0.5, torch.randn(O, device='cuda') * 0.1)
+    nb = hip.next_bound(bn, L.bias)
+    variants = [('f32', X, dict()), ('bf16x3', X, dict(split=L.wsplit)), ('fp16x2', Xp, dict(f16x2=L.wsplit2, x_bound=xb)),
+                ('fp16x2+bound', Xp, dict(f16x2=L.wsplit2, x_bound=xb, next_bound=nb))]
     outs = {}
-    for name, kw in variants:
+    for name, Xin, kw in variants:
         for _ in range(2):
-            hip.irrep_gemm(X, L.wpack, C, O, B, **kw)
+            hip.irrep_gemm(Xin, L.wpack, C, O, B, **kw)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(3):
-            outs[name] = hip.irrep_gemm(X, L.wpack, C, O, B, **kw)
+            r = hip.irrep_gemm(Xin, L.wpack, C, O, B, **kw)
+        outs[name] = r[0] if isinstance(r, tuple) else r
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 3
         print(f'{C}->{O} B={B} {name}: {dt*1e3:.2f} ms  {2.0*O*C*B*244/dt/1e12:.1f} TFLOP/s (f32-equivalent)')
     # accuracy on a slice against float64 (irrep 4, d = 5)
