@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- pair-registrations/sec of the RoReg hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload 3dmatch-full | kitchen | chunk] [--gemm f16x2 | bf16x3 | f32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the whole hot path (GF extractor on every cloud, mutual matcher, Des2R + ET local
-transforms, one-shot RANSAC + 2 refinements on every pair) over one resident scene chunk of 5000-keypoint clouds
-(BASELINE.json configs[1]: one 3DMatch-'kitchen'-like scene, 60-rotation group features, random-init GF/ET
-weights of the reference's architecture; data synthetic).  The chunk has the 3DMatch clouds:pairs ratio
-(16 clouds, 60 pairs = 0.267 = 433/1623), so `value` already includes the amortised per-cloud work.
-With N ranks every rank registers its own chunk (pairs shard with no data-path collective; weak scaling)
-and the per-pair result table is all-gathered once per step over RCCL.
+A "step" is one pass of the whole hot path (GF extractor on every cloud, mutual matcher, Des2R + ET local transforms, one-shot
+RANSAC + 2 refinements on every pair) over the workload, inputs resident in HBM before the timed region:
 
-The JSON line also carries the roofline of the dominant kernel (the exact-f32 MFMA GEMMs of the group convolution in
-the irrep domain, timed with HIP events inside the timed region) and a CPU baseline (the numpy oracle, rank 0,
-bounded sample).
+  3dmatch-full (default, every N): the full 3DMatch test shape (BASELINE.json configs[2]) -- 8 synthetic scenes with the benchmark's
+           station counts [60,60,60,55,57,37,66,38] (dataops/dataset.py:152) = 433 clouds x 5000 keypoints and 1623 pairs (kitchen: 60 clouds,
+           449 pairs), random-init GF/ET weights of the reference's architecture.  With N ranks the pairs are sharded by
+           roreg_amd.distributed.shard_scenes (whole scenes first, the largest scene cut into pair ranges), no data-path collective,
+           ONE all_gather of the result table per step: STRONG scaling, the same command for every N.  At N = 1 the whole benchmark runs
+           on one GPU (it fits: 16.6 GB of inputs); the kitchen scene alone (configs[1]) is timed inside the same steps and reported as
+           `config.kitchen_scene`.
+  kitchen: only the kitchen-like scene (60 clouds, 449 pairs), pairs sharded across the ranks.
+  chunk  : round 1's 16-cloud / 60-pair scene chunk per rank (weak scaling), kept for comparison.
+
+The JSON line carries the roofline of the dominant kernel (the fp16x2 MFMA GEMMs of the group convolution in the irrep domain, HIP events
+on the launch stream inside the timed region), measured rooflines of the kernels north_star names (the descriptor distance matrix on the
+matrix cores, the RANSAC scoring kernel), the other matrix-core modes, and a CPU baseline (the numpy oracle, rank 0, bounded sample).
 """
 import argparse
 import json
@@ -29,32 +34,54 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input MFMA peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
-SUSTAINED_FP16_MFMA_TFLOPS = 1650.0  # measured: tools/mfma_peak.py, random operands, 2-8 waves/SIMD (1840 with one smooth operand pair)
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (no sparsity)
+PEAK_F64_VALU_TFLOPS = 78.6         # MI355X_MICROARCH.md: vector fp64
+PEAK_HBM_GBS = 8000.0
 N_KPTS = 5000
-N_CLOUDS = 16
-N_PAIRS = 60          # 16 clouds : 60 pairs = 0.267 = 3DMatch's 433 clouds : 1623 pairs
 OVERLAP = 0.6
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='3dmatch-full', choices=['3dmatch-full', 'kitchen', 'chunk'])
     ap.add_argument('--kpts', type=int, default=N_KPTS)
-    ap.add_argument('--clouds', type=int, default=N_CLOUDS)
-    ap.add_argument('--pairs', type=int, default=N_PAIRS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="torch.distributed backend: 'nccl' (= RCCL, one GPU per rank); "
                     "'gloo' with ROREG_BENCH_SHARED_GPU=1 runs all ranks on GPU 0 -- a control-flow check of the multi-rank path on a 1-GPU box")
-    ap.add_argument('--no-secondary', action='store_true', help='skip the all-local-transforms figure (profiling runs)')
-    ap.add_argument('--gemm', choices=['f16x2', 'bf16x3', 'f32'], default='f16x2', help="matrix-core mode of the group-conv GEMMs: fp16 x 2 operands with power-of-two block scaling (default), bf16 x 3, or f32-input MFMA; all accumulate in f32")
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary figures (profiling runs)')
+    ap.add_argument('--gemm', choices=['f16x2', 'bf16x3', 'f32'], default='f16x2', help="matrix-core mode of the group-conv GEMMs: fp16 x 2 operands with "
+                    "per-keypoint power-of-two block scaling (default), bf16 x 3, or f32-input MFMA; all accumulate in f32")
+    ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32', help='descriptor storage (BASELINE config 5: bf16 = group features stored and '
+                    'streamed as bfloat16, float32 accumulation)')
     return ap.parse_args()
 
 
-def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
-    """Oracle (numpy port of the reference's algorithm) timed on a bounded sample, scaled to the step's workload."""
+# ---- workload ---------------------------------------------------------------------------------------------------------------------------
+def build_workload(args, rank, world):
+    """-> (scenes {name: (feats, keys, poses, pair_ids)} for the scenes this rank touches, plan [(scene, a, b)] of this rank, totals)."""
+    from roreg_amd import synth
+    from roreg_amd.distributed import shard_scenes
+    if args.workload == 'chunk':
+        feats, keys, poses = synth.make_scene_device(1000 + rank, 16, args.kpts, OVERLAP)
+        pairs = [(str(a), str(b)) for a, b in synth.scene_pair_list(16, 60, 4242)]
+        return {'chunk': (feats, keys, poses, pairs)}, [('chunk', 0, len(pairs))], {'pairs': 60 * world, 'clouds': 16 * world, 'scaling': 'weak'}
+    names = synth.THREEDMATCH_SCENES if args.workload == '3dmatch-full' else synth.THREEDMATCH_SCENES[:1]
+    clouds = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_PAIRS))
+    plan = shard_scenes({s: npairs[s] for s in names}, world, {s: clouds[s] for s in names})
+    scenes = {}
+    for s in sorted({p[0] for p in plan[rank]}):
+        i = synth.THREEDMATCH_SCENES.index(s)
+        feats, keys, poses = synth.make_scene_device(500 + i, clouds[s], args.kpts, OVERLAP)
+        scenes[s] = (feats, keys, poses, [(str(a), str(b)) for a, b in synth.scene_pair_list(clouds[s], npairs[s], 900 + i)])
+    return scenes, plan[rank], {'pairs': sum(npairs[s] for s in names), 'clouds': sum(clouds[s] for s in names), 'scaling': 'strong',
+                                'plan': [[list(p) for p in r] for r in plan]}
+
+
+def cpu_baseline(cfg_nets, feats0, feats1):
+    """Oracle (numpy port of the reference's algorithm) timed on a bounded sample (per-unit costs)."""
     from oracle import ref_numpy as O
     from roreg_amd.group import tables
     T = tables()
@@ -62,20 +89,19 @@ def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
     threads = torch.get_num_threads()
     t = {}
     nb = 1024
-    x = scene.feats[0][:nb]
-    t0 = time.perf_counter(); eq = O.gf_forward(x, gf_sd, T.Nei)['eqv']; t['gf_per_kpt'] = (time.perf_counter() - t0) / nb
+    x = feats0[:nb]
+    t0 = time.perf_counter(); O.gf_forward(x, gf_sd, T.Nei); t['gf_per_kpt'] = (time.perf_counter() - t0) / nb
     n = 3500
-    e0 = scene.feats[0][:n]; e1 = scene.feats[1][:n]
+    e0 = feats0[:n]; e1 = feats1[:n]
     s = np.arange(n)
-    t0 = time.perf_counter(); m = O.mutual_match(e0, e1, s, s); dt = time.perf_counter() - t0
-    t['mutual_per_pair'] = dt * (scene.feats[0].shape[0] / n) ** 2          # O(N^2)
+    t0 = time.perf_counter(); O.mutual_match(e0, e1, s, s); dt = time.perf_counter() - t0
+    t['mutual_per_pair'] = dt * (feats0.shape[0] / n) ** 2                  # O(N^2)
     nm = 1024
-    d1 = scene.feats[1][:nm]; d0 = scene.feats[0][:nm]
+    d1 = feats1[:nm]; d0 = feats0[:nm]
     t0 = time.perf_counter(); dr = O.des2r(d1, d0, T.P); t['des2r_per_corr'] = (time.perf_counter() - t0) / nm
     nb = 768
-    batch = {'before_eqv0': scene.feats[1][:nb], 'before_eqv1': scene.feats[0][:nb], 'after_eqv0': scene.feats[1][:nb],
-             'after_eqv1': scene.feats[0][:nb], 'pre_idx': dr[:nb]}
-    t0 = time.perf_counter(); q = O.et_forward(batch, et_sd, T.Nei, T.P); t['et_per_corr'] = (time.perf_counter() - t0) / nb
+    batch = {'before_eqv0': feats1[:nb], 'before_eqv1': feats0[:nb], 'after_eqv0': feats1[:nb], 'after_eqv1': feats0[:nb], 'pre_idx': dr[:nb]}
+    t0 = time.perf_counter(); O.et_forward(batch, et_sd, T.Nei, T.P); t['et_per_corr'] = (time.perf_counter() - t0) / nb
     M, H = 3000, 200
     rng = np.random.default_rng(0)
     k0 = rng.uniform(0, 3, (M, 3)); k1 = rng.uniform(0, 3, (M, 3)); Tr = rng.standard_normal((H, 3, 4))
@@ -86,35 +112,45 @@ def cpu_baseline(cfg_nets, scene, n_pairs, n_clouds):
     return t, threads
 
 
-DTYPE_OF = {'f16x2': 'f32 (f32-accurate, NOT reduced precision: every f32 operand enters the fp16 matrix cores as hi+lo fp16 under a power-of-two block '
-                     'scale = 22 significant bits, 3 cross products, f32 accumulate; measured error <= the f32-input MFMA kernel\'s, 4.0e-7 vs 5.1e-7 '
-                     'against the reference; every MFMA kernel of the path); f64 estimator',
+DTYPE_OF = {'f16x2': 'f32 (f32-accurate, NOT reduced precision: every f32 operand enters the fp16 matrix cores as hi+lo fp16 under a per-keypoint '
+                     'power-of-two block scale = 22 significant bits, 3 cross products, f32 accumulate; measured error <= the f32-input MFMA '
+                     'kernel\'s; results independent of batch composition and rank count); f64 estimator',
             'bf16x3': 'f32 (f32-accurate: every f32 operand as 3 bf16 pieces = 24 bits, 6 cross products, f32 accumulate); f64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); f64 estimator'}
 MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}
-KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2> (GF 256->512 / 512->256 in the irrep domain, fp16 x 2 block-scaled operands: 3 fp16 MFMAs per product)',
-             'bf16x3': 'irrep_gemm_split_kernel<32,3> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
+KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2,4,1> (GF 256->512 / 512->256 in the irrep domain, fp16 x 2 operands pre-split by ft_nonlin under '
+                      'per-keypoint block scales: 3 fp16 MFMAs per product)',
+             'bf16x3': 'irrep_gemm_split_kernel<32,3,2,1> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
              'f32': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, f32-input MFMA)'}
 
 
-def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic):
+def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
     """MFMA roofline of the dominant kernel, in EXECUTED matrix-core flops: the kernel performs, per irrep, the GEMM
     [d*O x d*C] . [d*C x d*B], i.e. 2*O*C*B*244 flop per launch = `gemm_tflops` when divided by its time.
     'f32': v_mfma_f32_32x32x2_f32, priced against the f32-input MFMA peak.  'bf16x3' / 'f16x2': every product is six bf16 / three fp16
     MFMAs, so 6x / 3x gemm_tflops are executed and priced against the dense bf16 = fp16 peak; the f32-equivalent rate is reported too.
     (In the reference's own 13-stencil form the same layer is 780/244 = 3.2x more flops: SURVEY 8d's per-keypoint figure.)"""
     base = {'bound': 'mfma', 'unit': 'TFLOP/s', 'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic,
-            'f32_equivalent_gemm_tflops': gemm_tflops, 'reference_stencil_form_equivalent_tflops': gemm_tflops * 780.0 / 244.0}
+            'algorithmic_bytes_per_launch': alg_bytes, 'f32_equivalent_gemm_tflops': gemm_tflops,
+            'reference_stencil_form_equivalent_tflops': gemm_tflops * 780.0 / 244.0}
     if mode == 'f32':
         base.update({'kernel': KERNEL_OF[mode], 'achieved': gemm_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': gemm_tflops / PEAK_F32_MFMA_TFLOPS})
     else:
         k = MFMAS_PER_PRODUCT[mode]
-        base.update({'kernel': KERNEL_OF[mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS,
-                     # context, not the priced peak: what back-to-back 32x32x16 fp16 MFMAs from registers sustain on this part with
-                     # pseudo-random operands (tools/mfma_peak.py, DESIGN.md 4.0) -- the power-limited ceiling of any 16-bit kernel
-                     'sustained_mfma_ceiling_measured_tflops': SUSTAINED_FP16_MFMA_TFLOPS,
-                     'frac_of_sustained_ceiling': k * gemm_tflops / SUSTAINED_FP16_MFMA_TFLOPS})
+        base.update({'kernel': KERNEL_OF[mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
     return base
+
+
+def gemm_roofline(events, tagname):
+    """(f32-equivalent TFLOP/s, total ms, launches, mean algorithmic bytes) of the big-layer GEMM launches (C * O = 256 * 512)."""
+    flops = 0.0; ms = 0.0; n_launch = 0; alg = 0.0
+    for (tag, e0, e1) in events:
+        if tag[0] == tagname and tag[2] * tag[3] == 256 * 512:
+            _, B_, C_, O_ = tag
+            flops += 2.0 * O_ * C_ * B_ * 244
+            alg += 60.0 * B_ * 4 * (C_ + O_ + (O_ if C_ == 512 else 0))         # X + Out (+ the short-cut operand of 512 -> 256)
+            ms += e0.elapsed_time(e1); n_launch += 1
+    return (flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), ms, n_launch, (alg / n_launch if n_launch else None)
 
 
 def main():
@@ -133,62 +169,60 @@ def main():
     from roreg_amd.engine import RegistrationEngine
     from roreg_amd.network import name2network
     from roreg_amd.parses.parses_test import default_config
+    from roreg_amd.utils.r_eval import compute_R_diff
 
     cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
     gf = name2network['GF_test'](cfg); gf_sd = synth.seeded_state_dict(gf, 101)
     et = name2network['ET_test'](cfg); et_sd = synth.seeded_state_dict(et, 202)
     eng = RegistrationEngine(cfg, gf, et)
     eng.set_gemm_mode(args.gemm)
+    if args.dtype == 'bf16':
+        eng.set_descriptor_dtype('bf16')
 
-    scene = synth.make_scene(1000 + rank, n_clouds=args.clouds, n_kpts=args.kpts, overlap=OVERLAP, coord_noise=0.005)
-    # a fixed pseudo-random subset of the cloud pairs that touches every cloud (like a scene's gt.log lists the overlapping pairs)
-    order = np.random.default_rng(4242).permutation(len(scene.pair_ids))
-    pair_ids = [scene.pair_ids[i] for i in sorted(order[:min(args.pairs, len(order))])]
-    feats = [torch.from_numpy(f).cuda() for f in scene.feats]            # inputs resident in HBM before timing
-    keys = [torch.from_numpy(k).cuda() for k in scene._kps]
-    n_pairs = len(pair_ids)
+    scenes, my_plan, totals = build_workload(args, rank, world)            # inputs resident in HBM before timing
+    import zlib
+    seeds = {s: [(7 + zlib.crc32(f'{s}:{a}:{b}'.encode())) % (2 ** 32) for a, b in scenes[s][3]] for s in scenes}
+    kitchen = synth.THREEDMATCH_SCENES[0]
+    kitchen_whole = any(p == (kitchen, 0, synth.THREEDMATCH_PAIRS[0]) for p in my_plan)
+    kitchen_ms = []
 
-    def step(all_lt=False):
-        np.random.seed(7)
-        res = eng.run_scene(feats, keys, pair_ids, all_local_transforms=all_lt)
-        table = torch.tensor([[float(r.id0), float(r.id1), r.n_match, r.recalltime] + r.trans.reshape(-1).tolist() for r in res],
+    def run_range(s, a, b, **kw):
+        feats, keys, _, pairs = scenes[s]
+        return eng.run_scene(feats, keys, pairs[a:b], pair_seeds=seeds[s][a:b], **kw)
+
+    def step(timed_kitchen=False, only=None, **kw):
+        rows = []
+        for (s, a, b) in my_plan:
+            if only is not None and s != only:
+                continue
+            if timed_kitchen and s == kitchen and kitchen_whole:
+                torch.cuda.synchronize(); tk = time.perf_counter()
+                res = run_range(s, a, b, **kw)
+                torch.cuda.synchronize(); kitchen_ms.append(1e3 * (time.perf_counter() - tk))
+            else:
+                res = run_range(s, a, b, **kw)
+            rows += [(s, r) for r in res]
+        table = torch.tensor([[float(r.id0), float(r.id1), r.n_match, r.recalltime] + r.trans.reshape(-1).tolist() for _, r in rows] or [[0.0] * 20],
                              dtype=torch.float64, device=coll_dev)
-        if dist is not None:
-            out = [torch.empty_like(table) for _ in range(world)]
-            dist.all_gather(out, table)                                     # the single result-table collective (RCCL/xGMI)
-        return res
+        if dist is not None:                                                  # the single result-table collective (RCCL/xGMI); ragged -> padded
+            n = torch.tensor([table.shape[0]], dtype=torch.int64, device=coll_dev)
+            ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n)
+            mx = max(int(x.item()) for x in ns)
+            pad = torch.zeros((mx, table.shape[1]), dtype=torch.float64, device=coll_dev); pad[:table.shape[0]] = table
+            out = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(out, pad)
+        return rows
 
-    for _ in range(args.warmup):
-        step()
-
-    hip.PROFILE = []                                                         # per-launch HIP events of the group conv
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    prof = hip.PROFILE; hip.PROFILE = None
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    def timed(n, **kw):
-        """n timed steps (after one untimed one) with the same barrier + synchronise bracket; MAX over ranks."""
-        if n == 0:
-            return 0.0, res
-        step(**kw)
+    def bracket(n, **kw):
+        """n timed steps with the barrier + synchronise bracket on both sides; MAX over ranks."""
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        rows = None
         for _ in range(n):
-            r = step(**kw)
+            rows = step(**kw)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -197,56 +231,71 @@ def main():
             tt = torch.tensor([d], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
-        return d, r
+        return d, rows
 
-    # ---- secondary figure 1: the same steps with the local transform of EVERY correspondence evaluated, as the reference's
-    # file-coupled estimator does (the default evaluates only the <= max_iter hypotheses one-shot RANSAC draws; same results) ----
-    n_all = 0 if args.no_secondary else max(1, args.steps // 2)
-    dt_all, res_all = timed(n_all, all_lt=True)
-    same = all(np.array_equal(a.trans, b.trans) and a.recalltime == b.recalltime for a, b in zip(res, res_all))
-
-    # ---- secondary figure 2: the other GEMM mode (3 x bf16 split operands, f32 accumulate: f32-accurate, not bit-equal) ----
-    other = 'f32' if args.gemm != 'f32' else 'f16x2'
-    eng.set_gemm_mode(other)
-    hip.PROFILE = []
-    dt_other, res_other = timed(n_all)
-    prof_other = hip.PROFILE; hip.PROFILE = None
-    eng.set_gemm_mode(args.gemm)
-    max_dT = max([float(np.abs(a.trans - b.trans).max()) for a, b in zip(res, res_other) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()] or [0.0])
-
-    # ---- secondary figure 3: the split SURVEY 8(d) asks for -- per-cloud stages (extractor) vs per-pair stages (matcher, local
-    # transforms, estimator) -- from one extra step with a synchronisation after every phase (diagnostic, outside the timed region) ----
-    phases = None
-    if not args.no_secondary:
-        eng.phase_ms = {}
+    for _ in range(args.warmup):
         step()
-        phases = {k: round(v, 2) for k, v in eng.phase_ms.items()}
+
+    hip.PROFILE = []                                                         # per-launch HIP events of the group-conv GEMMs
+    hip.profile_enable(True)                                                 # library-side events: distance-matrix and RANSAC-scoring kernels
+    dt, rows = bracket(args.steps, timed_kitchen=True)
+    prof = hip.PROFILE; hip.PROFILE = None
+    mm_ms, mm_n = hip.profile_read('mm_tile'); rs_ms, rs_n = hip.profile_read('ransac_score')
+    d2_ms, d2_n = hip.profile_read('des2r'); ft_ms, ft_n = hip.profile_read('ft_nonlin')
+    hip.profile_enable(False)
+    my_pairs = sum(b - a for _, a, b in my_plan)
+
+    # work terms of the named kernels on this rank, per step (from the result rows: M per pair; N = kpts; H = min(M, 1000))
+    Ms = np.array([r.n_match for _, r in rows], np.float64)
+    Hs = np.minimum(Ms, 1000.0)
+
+    # ---- secondary figures (outside the headline's timed region; kitchen scene only, so the default run stays short) ----
+    sec = {}
+    sec_scene = kitchen if kitchen in scenes else sorted(scenes)[0]
+    if not args.no_secondary:
+        n_sec = 1
+        d_def, rows_def = bracket(n_sec, only=sec_scene)
+        n_sec_pairs = len(rows_def)
+        d_all, rows_all = bracket(n_sec, only=sec_scene, all_local_transforms=True)
+        same = all(np.array_equal(a.trans, b.trans, equal_nan=True) and a.recalltime == b.recalltime for (_, a), (_, b) in zip(rows_def, rows_all))
+        sec['value_all_local_transforms_on_secondary_scene'] = world * n_sec_pairs * n_sec / d_all if n_sec_pairs else None
+        sec['value_default_on_secondary_scene'] = world * n_sec_pairs * n_sec / d_def if n_sec_pairs else None
+        sec['results_identical_to_all_local_transforms'] = bool(same)
+        sec['secondary_scene'] = sec_scene
+        other = {}
+        for mode in [m for m in ('f16x2', 'bf16x3', 'f32') if m != args.gemm]:
+            eng.set_gemm_mode(mode)
+            step(only=sec_scene)
+            hip.PROFILE = []
+            d_o, rows_o = bracket(n_sec, only=sec_scene)
+            pr = hip.PROFILE; hip.PROFILE = None
+            tag_of = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
+            ach, ms_o, nl_o, alg_o = gemm_roofline(pr, tag_of[mode])
+            diffs = [float(np.abs(a.trans - b.trans).max()) for (_, a), (_, b) in zip(rows_def, rows_o) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()]
+            other[mode] = {'dtype': DTYPE_OF[mode], 'value_on_secondary_scene': world * n_sec_pairs * n_sec / d_o if n_sec_pairs else None,
+                           'ms_per_pass': 1e3 * d_o / n_sec, 'pairs_with_identical_transform_to_default': int(sum(1 for d in diffs if d == 0.0)),
+                           'pairs_compared': len(diffs), 'max_abs_diff_of_transforms_vs_default': max(diffs or [0.0]),
+                           'roofline': roofline_obj(mode, ach, ms_o, nl_o, None, alg_o)}
+        eng.set_gemm_mode(args.gemm)
+        sec['other_gemm_modes'] = other
+        eng.phase_ms = {}
+        step(only=sec_scene)
+        sec['phase_ms_one_synchronised_pass_of_secondary_scene'] = {k: round(v, 2) for k, v in eng.phase_ms.items()}
         eng.phase_ms = None
 
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
-    # algorithmic work per launch = sum over the five irreps of 2*(d*O)*(d*C)*(d*B) = 2*O*C*B*244 flop
-    def gemm_roofline(events, tagname):
-        flops = 0.0; ms = 0.0; n_launch = 0
-        for (tag, e0, e1) in events:
-            if tag[0] == tagname and tag[2] * tag[3] == 256 * 512:
-                _, B_, C_, O_ = tag
-                flops += 2.0 * O_ * C_ * B_ * 244
-                ms += e0.elapsed_time(e1); n_launch += 1
-        return (flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), ms, n_launch
-
     tag_of = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
-    achieved, ms, n_launch = gemm_roofline(prof, tag_of[args.gemm])
-    achieved_other, ms_other, n_other = gemm_roofline(prof_other or [], tag_of[other])
+    achieved, ms, n_launch, alg_bytes = gemm_roofline(prof, tag_of[args.gemm])
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_irrep_gemm_pmc.json')
-    if os.path.exists(pmc):                      # HBM bytes per launch from the rocprofv3 --pmc passes of this same command
-        traffic = json.load(open(pmc)).get('hbm_bytes_per_launch', {}).get(args.gemm) if isinstance(json.load(open(pmc)).get('hbm_bytes_per_launch'), dict) else None
+    pmc = os.path.join(ROOT, 'profiles', 'r02_irrep_gemm_pmc.json')
+    if os.path.exists(pmc):                      # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (same launch population)
+        j = json.load(open(pmc))
+        traffic = (j.get('hbm_bytes_per_launch') or {}).get(f'{args.workload}:{args.gemm}')
 
-    # ---- accuracy on the synthetic chunk (outside the timed region; the evaluator's own metric code) ----
-    from roreg_amd.utils.r_eval import compute_R_diff
+    # ---- accuracy on the synthetic scenes (outside the timed region; the evaluator's own metric code) ----
     rr = []
-    for r in res:
-        gt = scene.get_transform(r.id0, r.id1)
+    for s, r in rows:
+        gt = synth.pose_transform(scenes[s][2], r.id0, r.id1)
         if np.isfinite(r.trans).all():
             rd = compute_R_diff(r.trans[:3, :3], gt[:3, :3]); td = float(np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))))
             rr.append(1 if (rd < 15 and td < 0.3) else 0)
@@ -254,38 +303,67 @@ def main():
             rr.append(0)
 
     if rank == 0:
-        value = world * n_pairs * args.steps / dt
+        total_pairs = totals['pairs']
+        value = total_pairs * args.steps / dt
+        wl = {'3dmatch-full': f"full 3DMatch test shape, synthetic: 8 scenes, {totals['clouds']} clouds x {args.kpts} kpts, {total_pairs} pairs "
+                              f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats); pairs sharded over the ranks by scene",
+              'kitchen': f"3DMatch-kitchen-like scene: {totals['clouds']} clouds x {args.kpts} kpts, {total_pairs} pairs (mutual + yohoo, max_iter=1000)",
+              'chunk': f"scene chunk per GPU: 16 clouds x {args.kpts} kpts, 60 pairs (mutual + yohoo, max_iter=1000)"}[args.workload]
+        mm_flop = float(np.sum(2.0 * args.kpts * args.kpts * 32)) * len(rows) * args.steps            # algorithmic: one N x N x 32 product per pair
+        rs_flop = float(np.sum(Hs * Ms * 27.0)) * args.steps
+        rs_bytes = float(np.sum(Ms * 56.0 + Hs * 96.0)) * args.steps
+        d2_bytes = float(np.sum(Hs * 15360.0)) * args.steps
         out = {
             'metric': 'pair-registrations/sec', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': DTYPE_OF[args.gemm], 'data': 'synthetic',
-            'config': {'workload': f"3DMatch-kitchen-like scene chunk per GPU: {args.clouds} clouds x {args.kpts} kpts, {n_pairs} pairs "
-                                   f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats)",
-                       'pairs_per_step_per_gpu': n_pairs, 'clouds_per_step_per_gpu': args.clouds, 'parallelism': f'pairs-sharded x{world}',
-                       'mean_matches': float(np.mean([r.n_match for r in res])), 'registration_recall_synthetic': float(np.mean(rr)),
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': totals['scaling'],
+            'vs_baseline': None, 'dtype': DTYPE_OF[args.gemm] + ('' if args.dtype == 'fp32' else '; group features stored as bfloat16'), 'data': 'synthetic',
+            'config': {'workload': wl, 'pairs_per_step': total_pairs, 'clouds_per_step': totals['clouds'], 'parallelism': f'pairs-sharded x{world}',
+                       'descriptor_dtype': args.dtype,
+                       'rank0_pairs_per_step': my_pairs, 'shard_plan': totals.get('plan'),
+                       'mean_matches_rank0': float(np.mean(Ms)) if len(Ms) else None, 'registration_recall_synthetic_rank0': float(np.mean(rr)) if rr else None,
                        'local_transforms': 'only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M)',
-                       'value_all_local_transforms': (world * n_pairs * n_all / dt_all) if n_all else None, 'results_identical_to_all_local_transforms': bool(same),
-                       'phase_ms_one_synchronised_step': phases,
-                       'pair_stages_only_pairs_per_s_per_gpu': (n_pairs / (sum(v for k, v in phases.items() if k != 'extract') * 1e-3)) if phases else None,
-                       'per_cloud_stage_clouds_per_s_per_gpu': (args.clouds / (phases['extract'] * 1e-3)) if phases else None},
-            'roofline': roofline_obj(args.gemm, achieved, ms, n_launch, traffic),
+                       'kitchen_scene': ({'clouds': synth.THREEDMATCH_CLOUDS[0], 'pairs': synth.THREEDMATCH_PAIRS[0], 'ms_per_pass': float(np.mean(kitchen_ms)),
+                                          'pairs_per_s': synth.THREEDMATCH_PAIRS[0] / (np.mean(kitchen_ms) * 1e-3),
+                                          'note': 'BASELINE configs[1]: the kitchen scene alone, timed (synchronised) inside the same steps'} if kitchen_ms else None),
+                       **sec},
+            'roofline': roofline_obj(args.gemm, achieved, ms, n_launch, traffic, alg_bytes),
+            # the kernels north_star names, measured with HIP events on the launch stream in the same timed steps (rank 0)
+            'roofline_distance_gemm': None if not mm_n else {
+                'kernel': 'mm_tile_kernel<false> + mm_tile_kernel<true> (5000 x 5000 x 32 descriptor distances of every pair of a scene, both search directions; '
+                          'bf16 x 3 split MFMA bound + exact re-check)', 'bound': 'mfma', 'unit': 'TFLOP/s', 'launch_pairs': mm_n, 'avg_ms': mm_ms / mm_n,
+                'algorithmic_tflops': mm_flop / (mm_ms * 1e-3) / 1e12, 'achieved': 24.0 * mm_flop / (mm_ms * 1e-3) / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS,
+                'frac': 24.0 * mm_flop / (mm_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                'note': 'executed = 24 x algorithmic: two passes x two products (S.T^T and T.S^T) x six bf16 MFMAs per f32-accurate product; K = 32 makes the '
+                        'kernel epilogue-bound (min / candidate search per 128 x 128 tile after 8 MFMA steps)'},
+            'roofline_ransac': None if not rs_n else {
+                'kernel': 'ransac_score_batch_kernel (one wave per hypothesis over the pair\'s M correspondences, fp64, no FMA contraction: bit-exact masks)',
+                'bound': 'fp64-valu', 'unit': 'TFLOP/s', 'launches': rs_n, 'avg_ms': rs_ms / rs_n, 'achieved': rs_flop / (rs_ms * 1e-3) / 1e12,
+                'peak': PEAK_F64_VALU_TFLOPS, 'frac': rs_flop / (rs_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
+                'hbm': {'algorithmic_GBps': rs_bytes / (rs_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': rs_bytes / (rs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        'note': 'M*56 + H*96 B per pair: the correspondences are re-read by every hypothesis from L2, the stage is not HBM-bound'}},
+            'roofline_des2r': None if not d2_n else {
+                'kernel': 'des2r_batch_kernel', 'bound': 'hbm', 'unit': 'GB/s', 'launches': d2_n, 'avg_ms': d2_ms / d2_n,
+                'achieved': d2_bytes / (d2_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': d2_bytes / (d2_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            'transforms': None if not ft_n else {'kernel': 'ft_nonlin_kernel (all variants)', 'launches': ft_n, 'ms_per_step': ft_ms / args.steps},
         }
-        if n_all:
-            out['config']['other_gemm_mode'] = {
-                'mode': other, 'dtype': DTYPE_OF[other], 'value': world * n_pairs * n_all / dt_other, 'ms_per_step': 1e3 * dt_other / n_all,
-                'max_abs_diff_of_transforms_vs_default': max_dT,
-                'roofline': roofline_obj(other, achieved_other, ms_other, n_other, None)}
         if not args.no_cpu_baseline and world == 1:
             gf_np = {k: v.numpy() for k, v in gf_sd.items()}; et_np = {k: v.numpy() for k, v in et_sd.items()}
-            t, threads = cpu_baseline((gf_np, et_np), scene, n_pairs, args.clouds)
-            M = float(np.mean([r.n_match for r in res])); H = min(M, 1000)
+            s0 = sorted(scenes)[0]
+            t, threads = cpu_baseline((gf_np, et_np), scenes[s0][0][0].cpu().numpy(), scenes[s0][0][1].cpu().numpy())
+            M = float(np.mean(Ms)); H = min(M, 1000)
             per_cloud = t['gf_per_kpt'] * args.kpts
-            per_pair = t['mutual_per_pair'] + M * (t['des2r_per_corr'] + t['et_per_corr']) + H * t['ransac_per_hyp'] * (M / 3000.0)
-            sec = args.clouds * per_cloud + n_pairs * per_pair
-            out['cpu_baseline'] = {'value': n_pairs / sec, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            tail = H * t['ransac_per_hyp'] * (M / 3000.0)
+            per_pair_all = t['mutual_per_pair'] + M * (t['des2r_per_corr'] + t['et_per_corr']) + tail          # the reference: every correspondence
+            per_pair_drawn = t['mutual_per_pair'] + H * (t['des2r_per_corr'] + t['et_per_corr']) + tail        # only the drawn hypotheses (what `value` does)
+            sec_all = totals['clouds'] * per_cloud + total_pairs * per_pair_all
+            sec_drawn = totals['clouds'] * per_cloud + total_pairs * per_pair_drawn
+            out['cpu_baseline'] = {'value': total_pairs / sec_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
                                    'sample': 'oracle/ref_numpy.py on this host: GF on 1024 kpts, mutual on 3500x3500 (scaled N^2), Des2R on 1024, '
-                                             'ET on 768 correspondences, RANSAC scoring on 200 hypotheses x 3000; scaled to the step workload',
-                                   'components_s': {'gf_per_cloud': per_cloud, 'per_pair': per_pair}}
+                                             'ET on 768 correspondences, RANSAC scoring on 200 hypotheses x 3000; scaled to the step workload with the '
+                                             'local transform of EVERY correspondence, as the reference computes it (pair with value_all_local_transforms)',
+                                   'value_if_only_drawn_hypotheses': total_pairs / sec_drawn,
+                                   'components_s': {'gf_per_cloud': per_cloud, 'per_pair_all_local_transforms': per_pair_all,
+                                                    'per_pair_drawn_hypotheses_only': per_pair_drawn}}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -362,6 +362,15 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                                          scale of roreg_group_conv_f16x2) */,
                     void *stream);
 
+/* Optional kernel timing for bench.py's measured rooflines (no reference counterpart: the reference has no profiler hooks).
+ * While enabled, the library brackets selected launches with HIP events recorded ON THE LAUNCH STREAM; roreg_profile_read synchronises
+ * on them and returns the summed duration and the number of brackets of a slot:
+ *   0 = the two mm_tile_kernel passes of roreg_mutual_match_batch (the descriptor distance matrix on the matrix cores),
+ *   1 = ransac_score_batch_kernel of roreg_ransac_batch, 2 = des2r_batch_kernel of roreg_lt_prepare_batch, 3 = roreg_ft_nonlin.
+ * roreg_profile_enable(1) clears earlier records; (0) stops recording. */
+int roreg_profile_enable(int on);
+int roreg_profile_read(int slot, double *total_ms, int *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,17 @@ __device__ __forceinline__ void lt_rows(const LtTask &t, int i, size_t &r0, size
 }
 void launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, hipStream_t s);
 
+// Optional per-kernel timing (roreg_profile_enable): HIP events recorded on the launch stream around selected launches.
+enum ProfSlot { PROF_MM_TILE = 0, PROF_RANSAC_SCORE = 1, PROF_DES2R = 2, PROF_FT_NONLIN = 3, PROF_N = 4 };
+bool prof_on();
+void prof_begin(int slot, hipStream_t s);
+void prof_end(int slot, hipStream_t s);
+struct ProfScope {
+    int slot; hipStream_t s; bool on;
+    ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(prof_on()) { if (on) prof_begin(slot, s); }
+    ~ProfScope() { if (on) prof_end(slot, s); }
+};
+
 #define ROREG_CHECK_LAUNCH(name)                                                     \
     do {                                                                             \
         hipError_t e__ = hipGetLastError();                                          \

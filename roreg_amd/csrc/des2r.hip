@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void des2r_batch_kernel(const roreg::LtTask *_
 }  // namespace
 
 void roreg::launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, hipStream_t s) {
+    roreg::ProfScope prof(roreg::PROF_DES2R, s);
     hipLaunchKernelGGL(des2r_batch_kernel, dim3((max_n + 3) / 4, n_tasks), dim3(256), 0, s, tasks, roreg::group_tables().P8, dr_all);
 }
 

@@ -213,7 +213,9 @@ __device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &
 // WO = number of 64-row wave groups: WO = 2 -> 128 x 256 workgroup tile, 4 waves (two workgroups per CU); WO = 4 -> 256 x 256 tile, 8 waves
 // (one workgroup per CU, the same 2 waves per SIMD): a third less L2 -> CU traffic per MFMA and half the conversion work per MFMA,
 // because one converted activation tile now feeds 256 output rows.
-template <int CT, int NP, int WO>
+// BIG: a name tag only (C * O = 256 * 512, GF's two dominant layers), so that profiler output can be filtered to exactly the launch
+// population bench.py prices in `roofline` -- the instantiations are otherwise identical.
+template <int CT, int NP, int WO, int BIG>
 __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -967,7 +969,7 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
     p.xbound = xbound; p.w_exp = w_exp; p.nb_u = nb_u; p.nb_v = nb_v; p.out_bound = out_bound; p.O = O;
     constexpr int CT = 32;
     const size_t lds = 2 * (NP * 2 * 256 + NP * (WO * 64) * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
-    auto kern = irrep_gemm_split_kernel<CT, NP, WO>;
+    auto kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(WO * 128), lds, roreg::as_stream(stream), p, tiles_dev);
@@ -1049,6 +1051,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
     hipStream_t s = roreg::as_stream(stream);
+    roreg::ProfScope prof(roreg::PROF_FT_NONLIN, s);
     const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
     if (in_sp && out_sp) { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
     ROREG_REQUIRE(split != 2 || out_sp || out_bound, "roreg_ft_nonlin: split = 2 writes the coefficients as fp16 hi/lo pairs and needs out_bound");

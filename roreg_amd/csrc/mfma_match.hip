@@ -317,6 +317,7 @@ extern "C" int roreg_mutual_match_batch(const roreg_match_task *tasks_dev, int n
         hipLaunchKernelGGL(mm_prepare_kernel, dim3(P / 8, 1, 2 * n_tasks), dim3(256), 0, s, tasks, P, ws);
         hipLaunchKernelGGL(mm_maxnorm_kernel, dim3(P / 256 + 1, 1, 2 * n_tasks), dim3(256), 0, s, tasks, P, ws);
         const dim3 grid(P / TILE, P / TILE, n_tasks);
+        roreg::ProfScope prof(roreg::PROF_MM_TILE, s);        // (one scope = the two passes of the distance matrix)
         hipLaunchKernelGGL(mm_tile_kernel<false>, grid, dim3(256), 0, s, tasks, P, ws);
         hipLaunchKernelGGL(mm_tile_kernel<true>, grid, dim3(256), 0, s, tasks, P, ws);
     }

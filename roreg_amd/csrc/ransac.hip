@@ -369,7 +369,10 @@ extern "C" int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_task
     const int pitch_h = max_H > 0 ? max_H : 1;
     hipLaunchKernelGGL(ransac_gather_batch_kernel, dim3((max_M + 255) / 256, n_tasks), dim3(256), 0, s, tasks, k0, k1);
     if (max_H > 0)
+    {
+        roreg::ProfScope prof(roreg::PROF_RANSAC_SCORE, s);
         hipLaunchKernelGGL(ransac_score_batch_kernel, dim3((max_H + 3) / 4, n_tasks), dim3(256), 0, s, tasks, k0, k1, ird * ird, pitch_h, overlap);
+    }
     hipLaunchKernelGGL(first_best_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, pitch_h, overlap, best_out);
     hipLaunchKernelGGL(refine_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
                        (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);

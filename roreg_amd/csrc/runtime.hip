@@ -2,6 +2,8 @@
 #include "common.h"
 #include <stdarg.h>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 namespace roreg {
 
@@ -19,7 +21,51 @@ static std::mutex g_tables_mu;
 
 const GroupTablesDev &group_tables() { return g_tables; }
 
+// ---- optional kernel timing ---------------------------------------------------------------------------------------------------------
+static bool g_prof = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_N];
+static hipEvent_t g_prof_open[PROF_N];
+bool prof_on() { return g_prof; }
+void prof_begin(int slot, hipStream_t s) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    g_prof_open[slot] = e;
+}
+void prof_end(int slot, hipStream_t s) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    g_prof_ev[slot].push_back({g_prof_open[slot], e});
+}
+
 }  // namespace roreg
+
+extern "C" int roreg_profile_enable(int on) {
+    using namespace roreg;
+    for (int k = 0; k < PROF_N; ++k) {
+        for (auto &pr : g_prof_ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        g_prof_ev[k].clear();
+    }
+    g_prof = on != 0;
+    return 0;
+}
+
+extern "C" int roreg_profile_read(int slot, double *total_ms, int *launches) {
+    using namespace roreg;
+    ROREG_REQUIRE(slot >= 0 && slot < PROF_N && total_ms && launches, "roreg_profile_read: bad arguments");
+    double t = 0.0;
+    for (auto &pr : g_prof_ev[slot]) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) != hipSuccess || hipEventElapsedTime(&ms, pr.first, pr.second) != hipSuccess) {
+            set_error("roreg_profile_read: event query failed");
+            return 1;
+        }
+        t += ms;
+    }
+    *total_ms = t; *launches = (int)g_prof_ev[slot].size();
+    return 0;
+}
 
 extern "C" int roreg_abi_version(void) { return 1; }
 

@@ -80,6 +80,8 @@ PROTOTYPES = {
     'roreg_rm_elementwise': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'roreg_sinkhorn_workspace_size': (c_size_t, [c_int, c_int]),
     'roreg_sinkhorn': (c_int, [_P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'roreg_profile_enable': (c_int, [c_int]),
+    'roreg_profile_read': (c_int, [c_int, _P, _P]),
     'roreg_set_fourier_tables': (c_int, [_P]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm_tiles_m': (c_size_t, [c_int, c_int, c_int, _P]),
@@ -208,6 +210,21 @@ def _conv_wsplit2(layer):
 # bench.py sets this to a list to collect (shape tag, start event, end event) per group-conv launch; the
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
+
+
+PROFILE_SLOTS = {'mm_tile': 0, 'ransac_score': 1, 'des2r': 2, 'ft_nonlin': 3}
+
+
+def profile_enable(on=True):
+    """Library-side kernel timing (HIP events on the launch stream around selected launches; include/roreg_hip.h)."""
+    _check(lib().roreg_profile_enable(1 if on else 0), 'roreg_profile_enable')
+
+
+def profile_read(name):
+    """-> (total ms, number of timed brackets) of slot `name` (PROFILE_SLOTS) since profile_enable()."""
+    ms = c_double(0.0); n = c_int(0)
+    _check(lib().roreg_profile_read(PROFILE_SLOTS[name], ctypes.byref(ms), ctypes.byref(n)), 'roreg_profile_read')
+    return ms.value, n.value
 
 
 def gather_table(key, array):

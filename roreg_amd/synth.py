@@ -218,3 +218,67 @@ def make_ransac_case(seed, M=5000, H=1000, outlier=0.6, f32_scores=False, anchor
         Trans[:, i, 3] = k0[:, i] - ((k1[:, 0] * R[:, i, 0] + k1[:, 1] * R[:, i, 1]) + k1[:, 2] * R[:, i, 2])
     hyp = rng.permutation(M)[:H].astype(np.int64)
     return k0, k1, scores, Trans, hyp
+
+
+# ------------------------------------------------------------------------------------------------
+# benchmark-sized scenes generated on the device (bench.py: 433 clouds = 16.6 GB of group features would take minutes on the host)
+# ------------------------------------------------------------------------------------------------
+# 3DMatch test split: clouds per scene (dataops/dataset.py:152 `stationnums`) and a 1623-pair split over the scenes (synthetic stand-in for
+# the benchmark's gt.log pair lists: kitchen is the largest scene, like in the dataset)
+THREEDMATCH_SCENES = ['kitchen', 'sun3d-home_at-home_at_scan1_2013_jan_1', 'sun3d-home_md-home_md_scan9_2012_sep_30', 'sun3d-hotel_uc-scan3',
+                      'sun3d-hotel_umd-maryland_hotel1', 'sun3d-hotel_umd-maryland_hotel3', 'sun3d-mit_76_studyroom-76-1studyroom2',
+                      'sun3d-mit_lab_hj-lab_hj_tea_nov_2_2012_scan1_erika']
+THREEDMATCH_CLOUDS = [60, 60, 60, 55, 57, 37, 66, 38]
+THREEDMATCH_PAIRS = [449, 217, 159, 207, 104, 54, 295, 138]          # sum = 1623
+
+
+def scene_pair_list(n_clouds, n_pairs, seed):
+    """A fixed pseudo-random subset of the cloud pairs that touches every cloud (like a scene's gt.log lists its overlapping pairs):
+    the chain (0,1), (1,2), ... first, then random further pairs; sorted."""
+    rng = np.random.default_rng(int(seed))
+    allp = [(a, b) for a in range(n_clouds) for b in range(a + 1, n_clouds)]
+    chain = [(a, a + 1) for a in range(n_clouds - 1)]
+    rest = [p for p in allp if p[1] != p[0] + 1]
+    order = rng.permutation(len(rest))
+    extra = [rest[i] for i in order[:max(0, n_pairs - len(chain))]]
+    return sorted((chain + extra)[:n_pairs])
+
+
+def make_scene_device(seed, n_clouds, n_kpts=5000, overlap=0.6, feat_noise=0.05, coord_noise=0.005, extent=3.0, device='cuda'):
+    """make_scene() on the device with torch's generator: -> (feats [n_clouds] of [N,32,60] f32, keys [n_clouds] of [N,3] f64, poses).
+    Same construction (shared world points, pose = group element + translation, features permuted by P[g]); not bit-identical to the
+    numpy version, which is what the parity tests use."""
+    import torch
+    T = tables()
+    gen = torch.Generator(device=device); gen.manual_seed(int(seed))
+    rng = np.random.default_rng(int(seed))
+    P = torch.from_numpy(np.ascontiguousarray(T.P, np.int64)).to(device)
+    R = torch.from_numpy(np.ascontiguousarray(T.R, np.float64)).to(device)
+    n_sh = int(round(overlap * n_kpts)); n_pr = n_kpts - n_sh
+
+    def world(n):
+        x = torch.rand((n, 3), generator=gen, device=device, dtype=torch.float64) * extent
+        f = torch.randn((n, 32, G), generator=gen, device=device, dtype=torch.float32)
+        f /= torch.sqrt((f * f).sum(1, keepdim=True))
+        return x, f
+    xs, fs = world(n_sh)
+    feats, keys, poses = [], [], []
+    for c in range(n_clouds):
+        xp, fp = world(n_pr)
+        xw = torch.cat([xs, xp]); fw = torch.cat([fs, fp])
+        g = 0 if c == 0 else int(rng.integers(0, G))
+        t = np.zeros(3) if c == 0 else rng.uniform(-0.5, 0.5, 3)
+        xc = (xw - torch.from_numpy(t).to(device)) @ R[g]
+        if coord_noise > 0:
+            xc = xc + coord_noise * torch.randn(xc.shape, generator=gen, device=device, dtype=torch.float64)
+        fc = fw[:, :, P[g]] + feat_noise * torch.randn(fw.shape, generator=gen, device=device, dtype=torch.float32)
+        perm = torch.randperm(n_kpts, generator=gen, device=device)
+        keys.append(xc[perm].contiguous()); feats.append(fc[perm].contiguous()); poses.append((g, t))
+    return feats, keys, poses
+
+
+def pose_transform(poses, id0, id1):
+    """[3,4] float64 ground truth x_0 = R x_1 + t of two clouds of a make_scene_device() scene."""
+    R = tables().R
+    g0, t0 = poses[int(id0)]; g1, t1 = poses[int(id1)]
+    return np.concatenate([R[g0].T @ R[g1], (R[g0].T @ (t1 - t0))[:, None]], 1)

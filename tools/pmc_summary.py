@@ -1,8 +1,9 @@
 """Summarise rocprofv3 --pmc CSVs (one pass per counter group) per kernel+grid into a text table and, for the dominant
 kernel of each matrix-core mode, the per-launch HBM traffic figure bench.py reports as roofline.traffic.
-usage: python tools/pmc_summary.py <out.txt> <out.json> <mode>=<dir> [<mode>=<dir> ...]     (mode: f16x2 | bf16x3 | f32)
+usage: python tools/pmc_summary.py <out.txt> <out.json> <workload>:<mode>=<dir> [...]     (mode: f16x2 | bf16x3 | f32)
 Each <dir> holds the counter_collection.csv files of the passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
---no-secondary --gemm <mode>`."""
+--no-secondary --workload <workload> --gemm <mode>`.  The dominant-kernel figures are taken over exactly the launches bench.py prices in
+`roofline`: the instantiations tagged BIG = 1 (C * O = 256 * 512: GF's 256->512 and 512->256 layers)."""
 import collections
 import csv
 import glob
@@ -35,6 +36,7 @@ def main():
     res = {'hbm_bytes_per_launch': {}, 'detail': {}}
     for spec in sys.argv[3:]:
         mode, d = spec.split('=')
+        gm = mode.split(':')[-1]
         agg = load(d)
         lines.append('')
         lines.append(f'## mode {mode}')
@@ -57,15 +59,28 @@ def main():
                     cal = (rows, known, f)
         if cal:
             lines.append(f'calibration: gf_finalize on {cal[0]} keypoints reads {cal[1]:.0f} KiB; FETCH_SIZE reports {cal[2]:.0f} KiB -> factor {cal[1] / cal[2]:.3f}')
-        kern = 'irrep_gemm_kernel' if mode == 'f32' else 'irrep_gemm_split_kernel'
-        big = [k for k in agg if k[0].startswith(kern) and k[1] >= 4000000 and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]]
+        kern = 'irrep_gemm_kernel' if gm == 'f32' else 'irrep_gemm_split_kernel'
+        tagged = (lambda k: k[1] >= 4000000) if gm == 'f32' else (lambda k: k[0].rstrip().endswith(', 1>'))
+        big = [k for k in agg if k[0].startswith(kern) and tagged(k) and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]]
         if big:
             nf = sum(len(agg[k]['FETCH_SIZE']) for k in big); nw = sum(len(agg[k]['WRITE_SIZE']) for k in big)
             f_kib = sum(sum(agg[k]['FETCH_SIZE']) for k in big) / nf
             w_kib = sum(sum(agg[k]['WRITE_SIZE']) for k in big) / nw
             factor = 2.0
             res['hbm_bytes_per_launch'][mode] = (factor * f_kib + w_kib) * 1024.0
-            res['detail'][mode] = {'kernel': kern + '<32>: the GF 256->512 / 512->256 launches of bench.py (grids >= 4M threads)',
+            busy = [k for k in agg if k[0].startswith(kern) and tagged(k) and 'SQ_VALU_MFMA_BUSY_CYCLES' in agg[k] and 'SQ_BUSY_CYCLES' in agg[k]]
+            clk = [k for k in agg if k[0].startswith(kern) and tagged(k) and 'GRBM_GUI_ACTIVE' in agg[k]]
+            extra = {}
+            if busy:
+                mf = sum(sum(agg[k]['SQ_VALU_MFMA_BUSY_CYCLES']) for k in busy); n_b = sum(len(agg[k]['SQ_VALU_MFMA_BUSY_CYCLES']) for k in busy)
+                extra['SQ_VALU_MFMA_BUSY_CYCLES_per_launch'] = mf / n_b
+            if clk:
+                ga = sum(sum(agg[k]['GRBM_GUI_ACTIVE']) for k in clk); n_c = sum(len(agg[k]['GRBM_GUI_ACTIVE']) for k in clk)
+                extra['GRBM_GUI_ACTIVE_per_launch'] = ga / n_c
+                if busy:
+                    extra['mfma_busy_fraction_of_1024_simds'] = (mf / n_b) / ((ga / n_c) * 1024.0)
+            res['detail'][mode] = {'kernel': kern + (': the BIG-tagged launches (C*O = 256*512) = the population of roofline.launches' if gm != 'f32' else '<32>: grids >= 4M threads'),
+                                   'launches_counted': nf, **extra,
                                    'FETCH_SIZE_KiB_per_launch': f_kib, 'WRITE_SIZE_KiB_per_launch': w_kib, 'read_factor': factor,
                                    'calibration_factor_measured_on_gf_finalize': (cal[1] / cal[2]) if cal else None}
     res['note'] = ('traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (wide coalesced reads are '
