@@ -671,8 +671,11 @@ __global__ __launch_bounds__(256) void ot_fused_pass_kernel(const float *__restr
 
 // v[j] <- log_nu(j) - log( sum over the row blocks of the partial column sums ) + v[j]   (see ot_fused_pass_kernel).  A workgroup owns 64
 // columns; its four waves add every fourth row block, then the four sums are added in wave order.
+// If every coupling of a column underflowed in the row pass (its entries lie more than ~87 below the row maxima in EVERY row -- a score
+// spread no trained matcher produces, but a legal input), the accumulated sum is 0 and its logarithm would be a clamp, not the value: that
+// column is then evaluated exactly in the log domain from the transposed matrix, like the one-pair path (roreg_sinkhorn) does for all columns.
 __global__ __launch_bounds__(256) void ot_col_merge_kernel(const float *__restrict__ part, size_t part_stride, int ld, float *__restrict__ vio,
-                                                           OtBatch ob) {
+                                                           OtBatch ob, const float *__restrict__ Z0T, int ldt, const float *__restrict__ u) {
     __shared__ float sh[4][64];
     const int pair = blockIdx.y;            // ob is the COLUMN pass geometry: its "rows" are the matrix columns
     const int C = ob.seg_rows[pair + 1] - ob.seg_rows[pair] + 1, R = ob.seg_cols[pair + 1] - ob.seg_cols[pair] + 1;
@@ -687,10 +690,20 @@ __global__ __launch_bounds__(256) void ot_col_merge_kernel(const float *__restri
     sh[g][lane] = T;
     __syncthreads();
     if (g == 0 && j < C) {
-        T = fmaxf((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]), 1.17549435e-38f);
+        T = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
         const float normc = ob.consts[pair * 2], last_extra = ob.consts[pair * 2 + 1];       // column constants: (normc, log m)
         float *v = vio + pair * ob.slab + j;
-        *v = (j == C - 1 ? last_extra + normc : normc) - __logf(T) + *v;
+        const float lognu = j == C - 1 ? last_extra + normc : normc;
+        if (T > 1.17549435e-38f) {
+            *v = lognu - __logf(T) + *v;
+        } else {                                             // all-underflowed column: exact log-sum-exp over the column (rare, one lane)
+            const float *zc = Z0T + pair * ob.slab + (size_t)j * ldt, *uu = u + pair * ob.slab;
+            float mx = -__builtin_inff();
+            for (int i = 0; i < R; ++i) mx = fmaxf(mx, zc[i] + uu[i]);
+            float sum = 0.f;
+            for (int i = 0; i < R; ++i) sum += __expf(zc[i] + uu[i] - mx);
+            *v = lognu - (mx + __logf(sum));
+        }
     }
 }
 
@@ -1061,7 +1074,7 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
         case 5: OT_PASS(5); break; case 6: OT_PASS(6); break; case 7: OT_PASS(7); break; default: OT_PASS(8); break;
         }
 #undef OT_PASS
-        hipLaunchKernelGGL(ot_col_merge_kernel, gm, dim3(256), 0, s, part, pstride, ldz, v, cols);
+        hipLaunchKernelGGL(ot_col_merge_kernel, gm, dim3(256), 0, s, part, pstride, ldz, v, cols, Z0T, ldt, u);
     }
     hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
     hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);

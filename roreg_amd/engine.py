@@ -51,6 +51,66 @@ class PairResult:
     scores: np.ndarray = None
 
 
+class StageFileWriter:
+    """Asynchronous writer of the reference's inter-stage files for the device-resident engine:
+
+        {cache}/{scene}/match_{keynum}/{a}-{b}.npy            [M,2] int64     test/matcher.py:108, :209
+        {cache}/{scene}/match_{keynum}/scores/{a}-{b}.npy     [M] f64 ones (mutual) / f32 (rotation-coherence matcher)   matcher.py:109, :210
+        {cache}/{scene}/match_{keynum}/DR_index/{a}-{b}.npy   [M] int64       test/estimator.py:111
+        {cache}/{scene}/match_{keynum}/Trans_pre/{a}-{b}.npy  [M,3,4] f64     test/estimator.py:367
+
+    byte for byte what the file-coupled stage classes write.  Off the critical path: a device tensor is copied to pinned host memory on
+    a side stream (ordered after its producing kernels by an event), and a worker thread waits for that copy and calls np.save; the
+    engine never synchronises for it.  close() joins the worker (call it before reading the files)."""
+
+    def __init__(self, cfg, dataset_name, keynum):
+        import queue
+        import threading
+        from .utils.utils import make_non_exists_dir
+        self.dir = f'{cfg.output_cache_fn}/{dataset_name}/match_{keynum}'
+        for d in ('', '/scores', '/DR_index', '/Trans_pre'):
+            make_non_exists_dir(self.dir + d)
+        self.stream = torch.cuda.Stream()
+        self.q = queue.Queue()
+        self.error = None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            path, host, done = item
+            try:
+                if done is not None:
+                    done.synchronize()
+                np.save(path, host.numpy() if torch.is_tensor(host) else host)
+            except Exception as e:                                  # surfaced by close()
+                self.error = e
+
+    def save(self, rel, a):
+        """rel: path below match_{keynum}/ without '.npy'; a: device tensor or host ndarray (dtype as it must appear on disk)."""
+        path = f'{self.dir}/{rel}.npy'
+        if not torch.is_tensor(a):
+            self.q.put((path, np.ascontiguousarray(a), None))
+            return
+        ready = torch.cuda.Event(); ready.record()                  # after the producing kernels on the current stream
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            host = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
+            host.copy_(a, non_blocking=True)
+            done = torch.cuda.Event(); done.record(self.stream)
+        a.record_stream(self.stream)                                # the allocator must not hand the block out before the copy ran
+        self.q.put((path, host, done))
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+
 class RegistrationEngine:
     def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None):
         self.cfg = cfg
@@ -297,7 +357,7 @@ class RegistrationEngine:
         T2, st2 = hip.refine(k0, k1, scores, ird, T_in=T1, want_stats=True)
         return T2, best, (k0, k1, st1, st2)
 
-    def _yohoo_tasks(self, full, all_scores, max_iter, all_local_transforms, pair_seeds=None):
+    def _yohoo_tasks(self, full, all_scores, max_iter, all_local_transforms, pair_seeds=None, writer=None, pair_ids=None):
         """Estimator-tail tasks of the one-shot estimator (test/estimator.py:405-436)."""
         # One-shot RANSAC only ever reads the local transforms of the (<= max_iter) hypotheses it draws
         # (estimator.py:423-425), and that draw depends on M (and, with --RM, on the scores) alone, so the hypothesis order is drawn
@@ -321,6 +381,9 @@ class RegistrationEngine:
             hyp_dev.append(hyp_flat[o:o + h.shape[0]]); o += h.shape[0]
         items = [(c0, c1, m, None if all_local_transforms else h) for (c0, c1, m), h in zip(full, hyp_dev)]
         lts = self.local_transforms_many(items)
+        if writer is not None:                                             # (all_local_transforms is on: complete DR_index / Trans_pre files)
+            for (a, b), (dr, Trans) in zip(pair_ids, lts):
+                writer.save(f'DR_index/{a}-{b}', dr); writer.save(f'Trans_pre/{a}-{b}', Trans)
         # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
         rt, w_all = [], []
         for (c0, c1, matches), h, sc, (dr, Trans) in zip(full, hyp_dev, all_scores, lts):
@@ -329,7 +392,7 @@ class RegistrationEngine:
             rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
         return rt, w_all
 
-    def _yohoc_tasks(self, full, all_scores, max_iter, pair_seeds=None):
+    def _yohoc_tasks(self, full, all_scores, max_iter, pair_seeds=None, writer=None, pair_ids=None):
         """Estimator-tail tasks of the rotation-bin RANSAC (test/estimator.py:173-241): coarse rotation of every correspondence of every
         pair in one launch (Des2R), one download, then per pair (host, the reference's order of generator calls) the bin statistics,
         the hypothesis draws and the 3-point Kabsch stack; ONE upload of all hypotheses.  -> (tasks, weights, {pair: (T, recalltime)}
@@ -337,6 +400,9 @@ class RegistrationEngine:
         from .test.estimator import yohoc_draws, three_point_transforms, _select_top
         batch = hip.LtBatch([(c0.eqv, c1.eqv, c0.eqv, c1.eqv, c0.keys, c1.keys, m, None) for c0, c1, m in full])
         dr_all = batch.des2r().cpu().numpy()
+        if writer is not None:
+            for (a, b), (off, n) in zip(pair_ids, batch.offsets):
+                writer.save(f'DR_index/{a}-{b}', dr_all[off:off + n].copy())
         sizes = [int(m.shape[0]) for _, _, m in full]
         m_host = torch.cat([m.reshape(-1) for _, _, m in full]).cpu().numpy().reshape(-1, 2) if full else np.zeros((0, 2), np.int64)
         jobs, skipped, o = [], {}, 0
@@ -367,12 +433,18 @@ class RegistrationEngine:
         return rt, w_all, skipped
 
     # ---- whole scene -----------------------------------------------------------------------------------------
-    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None):
+    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None,
+                  writer=None):
         """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
         pair_seeds: optional one integer per pair -- the global numpy generator is re-seeded with it before the pair's keypoint sampling
         and with seed + 1 before its hypothesis draws, so a pair's result is a function of the pair alone (whatever other pairs this
         call processes: the multi-GPU driver's rank-count independence).  None = the reference's single global stream.
+        writer: optional StageFileWriter -- the inter-stage files of every pair (matches, scores, DR_index, Trans_pre) are written
+        asynchronously, byte for byte what the file-coupled stage classes write; this turns all_local_transforms on (the files hold
+        every correspondence's local transform, like the reference's).
         Returns [PairResult]."""
+        if writer is not None:
+            all_local_transforms = True
         keynum = self.cfg.keynum if keynum is None else keynum
         max_iter = self.cfg.max_iter if max_iter is None else max_iter
         import time
@@ -412,13 +484,17 @@ class RegistrationEngine:
             counts = cnt.cpu().numpy()                                       # the one sync of the matcher stage
             full = [(clouds[int(a)], clouds[int(b)], mbuf[q, :int(M)]) for q, ((a, b), M) in enumerate(zip(pair_ids, counts))]
             all_scores = [None] * len(full)
+        if writer is not None:
+            for (a, b), (_, _, m), sc in zip(pair_ids, full, all_scores):
+                writer.save(f'{a}-{b}', m)
+                writer.save(f'scores/{a}-{b}', np.ones(int(m.shape[0])) if sc is None else sc)
         t0 = self._mark('match', t0)
         # stage 4: all pairs
         yohoc = getattr(self.cfg, 'ET', 'yohoo') == 'yohoc'
         if yohoc:
-            rt, w_all, skipped = self._yohoc_tasks(full, all_scores, max_iter, pair_seeds)
+            rt, w_all, skipped = self._yohoc_tasks(full, all_scores, max_iter, pair_seeds, writer, pair_ids)
         else:
-            (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms, pair_seeds), {}
+            (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms, pair_seeds, writer, pair_ids), {}
         t0 = self._mark('local_transforms', t0)
         ird = float(self.cfg.ransac_ird)
         best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird)
@@ -449,5 +525,7 @@ class RegistrationEngine:
         for i, (a, b) in enumerate(pair_ids):
             # recalltime: index of the winning hypothesis (yohoo, estimator.py:436) / its 1-based try count (yohoc, :241)
             T, rec = skipped[i] if i in skipped else (T_host[i], int(best_host[i]) + 1 if yohoc else max(int(best_host[i]), 0))
+            if int(counts[i]) == 0 and i not in skipped:                  # no correspondence at all: the stage classes' result (NaN, 0)
+                T = np.full((4, 4), np.nan); T[3] = [0.0, 0.0, 0.0, 1.0]; rec = 0
             out.append(PairResult(a, b, int(counts[i]), T, rec, matches=local[i][2] if keep_matches else None, scores=all_scores[i]))
         return out

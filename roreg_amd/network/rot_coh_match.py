@@ -184,7 +184,9 @@ class Match_ot(nn.Module):
     def match_stacked(self, source_eqv, target_eqv, source_keys, target_keys, seg_s, seg_t):
         """match_many on already stacked tensors: the pairs' points are concatenated (hip.Segments seg_s / seg_t give the row ranges);
         every per-pair operation of the graph (neighbour search, InstanceNorm statistics, the context maximum, Sinkhorn) is
-        segmented, with the arithmetic of forward() bit for bit."""
+        segmented.  The network part is the arithmetic of forward() bit for bit; the stacked Sinkhorn reads the coupling matrix once per
+        iteration and associates the column sums differently (include/roreg_hip.h: matches identical, scores to rounding; a column whose
+        couplings all underflow in that pass is evaluated exactly in the log domain, like forward() does for every column)."""
         source_eqv = source_eqv.contiguous(); target_eqv = target_eqv.contiguous()
         source_coor = (source_keys / self.coor_norm_step).contiguous()
         target_coor = (target_keys / self.coor_norm_step).contiguous()

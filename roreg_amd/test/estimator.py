@@ -279,6 +279,8 @@ class yohoo_ransac:
         self.refiner = refiner()
 
     def overlap_cal(self, key_m0, key_m1, T, scores):
+        if len(key_m0) == 0:
+            return float('nan')                                  # 0 / 0 in the reference (estimator.py:396-403)
         ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist)
         return float(ov[0].item())
 
@@ -299,6 +301,12 @@ class yohoo_ransac:
             Keys1 = dataset.get_kps(id1)
             scores = np.load(f'{match_dir}/scores/{id0}-{id1}.npy')
             pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
+            if pps.shape[0] == 0:
+                # an empty match list (the reference's matcher crashes before writing one, matcher.py:98-107): the engine's result for
+                # such a pair -- no hypothesis, no inlier, NaN transform, recalltime 0 -- so the two supported paths agree
+                T = np.full((4, 4), np.nan); T[3] = [0.0, 0.0, 0.0, 1.0]
+                np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T, recalltime=0)
+                continue
             k0 = _dev64(Keys0[pps[:, 0]]); k1 = _dev64(Keys1[pps[:, 1]])
             Trans = np.load(f'{Trans_dir}/{id0}-{id1}.npy')
             rows = np.arange(Trans.shape[0])

@@ -159,6 +159,50 @@ def test_engine_equals_file_coupled_stages(tmp_path):
         assert np.abs(r.trans - want['trans']).max() < 1e-10
 
 
+@pytest.mark.parametrize('RD,RM,ET', [(False, False, 'yohoo'), (True, True, 'yohoo'), (False, False, 'yohoc')])
+def test_engine_writer_files_equal_the_stage_classes_files(tmp_path, RD, RM, ET):
+    """with a StageFileWriter the engine emits the reference's inter-stage files (matches, scores, DR_index, Trans_pre)
+    asynchronously; they are byte for byte the files the file-coupled stage classes write from the same generator stream."""
+    import filecmp
+    from roreg_amd.engine import RegistrationEngine, StageFileWriter
+    from roreg_amd.network import name2network
+    from roreg_amd.test import name2extractor, name2detector, name2matcher, name2estimator
+    z = load_golden('pipeline_rd_rm_yohoo' if RM else 'pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, ET=ET, RD=RD, RM=RM)
+    keynum = int(z['keynum'])
+    np.random.seed(99)
+    name2extractor['yoho_des'](cfg).run(ds)
+    if RD:
+        name2detector['yoho_det'](cfg).run(ds)
+    name2matcher['yoho_mat' if RM else 'matmul'](cfg).run(ds, keynum)
+    name2estimator[ET](cfg).run(ds, keynum, 1000)
+    ref_dir = f'{cfg.output_cache_fn}/{ds.name}/match_{keynum}'
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    rd = rm = None
+    if RD:
+        rd = name2network['RD_test'](cfg); rd.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()})
+    if RM:
+        rm = name2network['RM_test'](cfg); rm.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RM').items()})
+    from types import SimpleNamespace as NS
+    cfg2 = NS(**{**vars(cfg), 'output_cache_fn': f'{tmp_path}/cache_engine'})
+    eng = RegistrationEngine(cfg2, gf, et if ET == 'yohoo' else None, rd_net=rd, rm_net=rm)
+    w = StageFileWriter(cfg2, ds.name, keynum)
+    np.random.seed(99)
+    res = eng.run_scene(ds.feats, [ds.get_kps(i) for i in ds.pc_ids], ds.pair_ids, keynum=keynum, max_iter=1000, writer=w)
+    w.close()
+    got_dir = f'{cfg2.output_cache_fn}/{ds.name}/match_{keynum}'
+    kinds = ['', 'scores/', 'DR_index/'] + (['Trans_pre/'] if ET == 'yohoo' else [])
+    for a, b in ds.pair_ids:
+        for k in kinds:
+            assert filecmp.cmp(f'{got_dir}/{k}{a}-{b}.npy', f'{ref_dir}/{k}{a}-{b}.npy', shallow=False), (k, a, b)
+    for r in res:                                                       # and the registration itself is the stages'
+        want = np.load(f'{ref_dir}/{ET}/1000iters/{r.id0}-{r.id1}.npz')
+        assert r.recalltime == int(want['recalltime'])
+        if np.isfinite(want['trans']).all():
+            assert np.abs(r.trans - want['trans']).max() < 1e-10
+
+
 def test_engine_yohoc_equals_file_coupled_stages(tmp_path):
     """The rotation-bin estimator inside the device-resident engine against the file-coupled yohoc stages on the same
     generator stream: same matches, same winning try, same transform."""

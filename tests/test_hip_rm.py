@@ -123,6 +123,27 @@ def test_sinkhorn_and_readout():
         assert (w0 >= 0).sum() >= min(m, n) // 2 - 2
 
 
+def test_sinkhorn_batch_with_widely_spread_scores():
+    """Final descriptors whose scores spread over several hundred: whole columns underflow in the one-pass (linear-domain column sums)
+    iteration of the stacked Sinkhorn; the exact log-domain fallback for those columns keeps it equal to the one-pair path."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(17)
+    m, n = 300, 260
+    src = rng.standard_normal((m, 32)).astype(np.float32)
+    tgt = rng.standard_normal((n, 32)).astype(np.float32)
+    src[:, 0] = np.abs(src[:, 0]) + 1.0                      # every source has a positive first component ...
+    tgt[::7, 0] = -150.0                                     # ... so these target columns score <= -150 against every source
+    tgt[3::7] *= 6.0                                          # and these reach several tens
+    s, t = cu(src), cu(tgt)
+    Z, m0, m1, s0, s1 = hip.sinkhorn(s, t, 1.0, 100)
+    seg_s = hip.Segments([m, m]); seg_t = hip.Segments([n, n])
+    b0, b1, bs0, bs1 = hip.sinkhorn_batch(torch.cat([s, s]), torch.cat([t, t]), seg_s, seg_t, 1.0, 100)
+    assert float(Z.max() - Z.min()) > 200 and bool(torch.isfinite(Z).all())
+    for k in range(2):
+        assert torch.equal(b0[k * m:(k + 1) * m], m0) and torch.equal(b1[k * n:(k + 1) * n], m1)
+        assert float((bs0[k * m:(k + 1) * m] - s0).abs().max()) < 1e-4 and float((bs1[k * n:(k + 1) * n] - s1).abs().max()) < 1e-4
+
+
 def test_match_ot_forward_vs_reference_golden(rm):
     net, sd = rm
     z = load_golden('match_ot')

@@ -78,7 +78,7 @@ def main():
                 ga = sum(sum(agg[k]['GRBM_GUI_ACTIVE']) for k in clk); n_c = sum(len(agg[k]['GRBM_GUI_ACTIVE']) for k in clk)
                 extra['GRBM_GUI_ACTIVE_per_launch'] = ga / n_c
                 if busy:
-                    extra['mfma_busy_fraction_of_1024_simds'] = (mf / n_b) / ((ga / n_c) * 1024.0)
+                    extra['mfma_busy_fraction'] = (mf / n_b) / ((ga / n_c) / 8.0 * 1024.0)      # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
             res['detail'][mode] = {'kernel': kern + (': the BIG-tagged launches (C*O = 256*512) = the population of roofline.launches' if gm != 'f32' else '<32>: grids >= 4M threads'),
                                    'launches_counted': nf, **extra,
                                    'FETCH_SIZE_KiB_per_launch': f_kib, 'WRITE_SIZE_KiB_per_launch': w_kib, 'read_factor': factor,
