@@ -156,10 +156,28 @@ int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, 
 int roreg_group_corr(const float *perm_feats, const int64_t *perm_rows, const float *bcast_feats, const int64_t *bcast_rows,
                      int M, int transpose_table, int64_t *idx_out, float *cor_out, void *stream);
 
+/* The same arg-max (test/estimator.py:85-89, bit for bit) with 10x fewer operations: the 60 correlations are first BOUNDED in the irrep
+ * domain of the icosahedral group -- cor[a] = sum_rho sum_ij rho(a)[j][i] (sum_f X2_f(rho) X1_f(rho)^T)[i][j], sum_d d^3 = 244
+ * multiply-adds per channel instead of 3600, from per-keypoint coefficients computed once per cloud (roreg_feat_coefs) -- and only the
+ * candidates within a rigorous margin of the bound's maximum (near ties, duplicates) are re-evaluated with the literal formula in the
+ * reference's evaluation order from the group-domain rows; the first maximum of those is returned.
+ * coef1 / coef0 = roreg_feat_coefs(feats1 / feats0) [*,32,60] f32; feats* are float32 or (feat_bf16) bfloat16 [*,32,60].
+ * roreg_set_des2r_tables uploads the index / representation tables (roreg_amd/fourier.py derives them from the multiplication table and
+ * checks the identity to 1e-12): ia, ib uint8 [60][5] (coefficient indices of the k-th product term of entry q = (rho,i,j)), cnt uint8 [60]
+ * (terms = d), NT float32 [60 (q)][60 (a)] = rho(a)[j][i].  roreg_des2r_recheck_count: how many correspondences took the exact path. */
+int roreg_set_des2r_tables(const uint8_t *ia_host, const uint8_t *ib_host, const uint8_t *cnt_host, const float *NT_host);
+int roreg_des2r_irrep(const float *coef1, const int64_t *rows1, const float *coef0, const int64_t *rows0, const void *feats1,
+                      const void *feats0, int feat_bf16, int M, int64_t *idx_out, void *stream);
+int roreg_des2r_recheck_count(int reset, int32_t *count_out);
+/* out[b,c,q] (f32 [B,C,60]) = sum_g F[q][g] x[b,c,g]: the orthonormal group-Fourier coefficients of a group-domain tensor x [B,C,60]
+ * (float32, or bfloat16 with x_bf16) in per-keypoint layout -- the operand of roreg_des2r_irrep.  split as roreg_ft_nonlin. */
+int roreg_feat_coefs(const void *x, int x_bf16, float *out, int B, int C, int split, void *stream);
+
 /* Build the ET network input x [M,128,60] = cat(before1[r1][:, :, P[a]], before0[r0], after1[r1][:, :, P[a]],
  * after0[r0]) for correspondence rows (r0,r1) and anchor a=pre_idx[b].
  * Replaces batch_create + the per-row permutation loop (test/estimator.py:293-306; network/eqv_trans.py:126-129). */
-int roreg_et_gather(const float *before0, const float *before1, const float *after0, const float *after1,
+int roreg_et_gather(const void *before0, const void *before1, const void *after0, const void *after1,
+                    int feat_bf16 /* the four feature tensors are bfloat16 instead of float32 (BASELINE config 5) */,
                     const int64_t *rows0, const int64_t *rows1, const int64_t *pre_idx, int M,
                     float *x_out, void *stream);
 
@@ -200,14 +218,17 @@ int roreg_refine(const double *k0, const double *k1, const double *w, int M,
  * rows [off, off+n): dr_out int64, x_out [*,128,60] f32 (ET input; NULL = Des2R only, the YOHO-C estimator's DR_index),
  * Trans_out [*,3,4] f64.  tasks_dev is a DEVICE array. */
 typedef struct {
-    const float *before0, *before1, *after0, *after1;
+    const void *before0, *before1, *after0, *after1;   /* the clouds' group features [*,32,60]: float32, or bfloat16 with flags bit 1 */
     const double *keys0, *keys1;
     const int64_t *matches;
     const int64_t *sel;
     int32_t n, pad_;
     int64_t off;
+    const float *coef0, *coef1;                        /* roreg_feat_coefs(after0 / after1) [*,32,60] f32, needed with flags bit 0 */
 } roreg_lt_task;
-int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int64_t *dr_out, float *x_out, void *stream);
+/* flags: bit 0 = Des2R through the irrep-domain bound + exact re-check (roreg_des2r_irrep; tasks carry coef0 / coef1), else the literal
+ * kernel; bit 1 = the features are bfloat16 (needs bit 0). */
+int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int flags, int64_t *dr_out, float *x_out, void *stream);
 int roreg_lt_finish_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, const float *q_all, const int64_t *dr_all,
                           double *Trans_out, void *stream);
 
@@ -349,7 +370,8 @@ int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float
                            int tile_m /* 128 | 256 (O % 256 == 0): the m-tile the list was built with; 256 = 8-wave workgroups */, void *stream);
 /* bound_out[b] (b < round_up(B,32); 0 for pad keypoints) = sqrt(60) max_{c,g} |act(x[b,c,g])| >= every coefficient of FT(act(x[b])), act =
  * ReLU(bn_scale_c x + bn_shift_c) or the identity (bn NULL): the x_bound of a layer whose input is a group-domain tensor [B,C,60]. */
-int roreg_row_bound(const float *x_spatial, const float *bn_scale, const float *bn_shift, float *bound_out, int B, int C, void *stream);
+int roreg_row_bound(const void *x_spatial, int x_bf16 /* x is bfloat16 instead of float32 */, const float *bn_scale, const float *bn_shift,
+                    float *bound_out, int B, int C, void *stream);
 int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial, const float *bias,
                     const float *bias2, const float *bn_scale, const float *bn_shift, const float *resid_spatial,
                     float *Xout /* flat [60*C*B] */, float *out_spatial /* [B,C,Lout] */,
@@ -360,6 +382,7 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                                               words roreg_irrep_gemm_f16x2 consumes (NOT floats) */,
                     float *out_rowmax /* optional, with out_spatial: [B], zeroed by the caller; receives max |out_spatial[b]| per keypoint (the block
                                          scale of roreg_group_conv_f16x2) */,
+                    int spatial_bf16 /* x_spatial / resid_spatial point to bfloat16 tensors (BASELINE config 5: group features stored as bf16) */,
                     void *stream);
 
 /* Optional kernel timing for bench.py's measured rooflines (no reference counterpart: the reference has no profiler hooks).

@@ -36,12 +36,14 @@ struct LtTask {
     const int64_t *sel;                                 // [n] rows of `matches` to evaluate, or null (= 0..n-1)
     int32_t n, pad_;
     int64_t off;                                        // first output row of this pair
+    const float *coef0, *coef1;                         // irrep coefficients of after0 / after1 [*,32,60] (roreg_feat_coefs), or null
 };
 __device__ __forceinline__ void lt_rows(const LtTask &t, int i, size_t &r0, size_t &r1) {
     const int64_t m = t.sel ? t.sel[i] : (int64_t)i;
     r0 = (size_t)t.matches[2 * m]; r1 = (size_t)t.matches[2 * m + 1];
 }
-void launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, hipStream_t s);
+void launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, bool irrep, bool feat_bf16, hipStream_t s);
+bool des2r_tables_ready();
 
 // Optional per-kernel timing (roreg_profile_enable): HIP events recorded on the launch stream around selected launches.
 enum ProfSlot { PROF_MM_TILE = 0, PROF_RANSAC_SCORE = 1, PROF_DES2R = 2, PROF_FT_NONLIN = 3, PROF_N = 4 };

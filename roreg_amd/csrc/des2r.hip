@@ -92,11 +92,255 @@ __global__ __launch_bounds__(256) void des2r_batch_kernel(const roreg::LtTask *_
     des2r_body(t.after1, r1, t.after0, r0, live, P8, (size_t)(t.off + i), dr_all, nullptr);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Des2R in the irrep domain: bound on the matrix of all 60 correlations from 244 multiply-adds per channel, exact re-evaluation of the
+// candidates.
+//
+// x -> x[P[a, .]] is a translation on the group, so with the orthonormal transform of roreg_amd/fourier.py (coefficient matrices
+// X(rho) [d x d], d = 1,3,3,4,5) the correlation is
+//     cor[a] = sum_rho sum_ij rho(a)[j][i] * C_rho[i][j],     C_rho = sum_f X2_f(rho) . X1_f(rho)^T          (X1: permuted side)
+// i.e. per channel sum_rho d^3 = 244 multiply-adds for C instead of 3600, plus ONE 60 x 60 product per correspondence -- 10x fewer
+// operations, no permuted gather.  The per-keypoint coefficients are computed once per cloud (roreg_feat_coefs).  That value is an
+// approximation of the float32 number the reference computes (different arithmetic), so it only BOUNDS: every a with
+// cor~[a] >= max cor~ - margin is a candidate, margin = 1e-4 |d1| |d2| >= 2 (|cor~ - exact| + |literal f32 - exact|) (the literal
+// evaluation is two-level, 60 then 32 terms: its error is <= (93 eps) sum |terms| <= 5.6e-6 |d1||d2|; the irrep evaluation with
+// f32-accurate transforms is of the same order), so the literal first arg-max is always among the candidates.  One candidate: done.
+// Several (near ties, duplicates -- a few per cent of random correspondences, none of the well-matched ones): the candidates are
+// re-evaluated with the literal formula in the reference's order (des2r_body above, bit for bit) from the group-domain rows, and the first
+// maximum of those wins.  Result: the index of the literal evaluation, always.
+//
+// One wave per correspondence, eight per workgroup; every workgroup walks DES2R_ITER correspondences per wave with the next rows
+// prefetched into registers under the current one's arithmetic.
+struct Des2rTabs {
+    const uint8_t *ia, *ib;     // [60][5]: lane q = (rho,i,j): X2 index off + i*d + k, X1 index off + j*d + k  (k < cnt[q])
+    const uint8_t *cnt;         // [60]
+    const float *NT;            // [60 q][60 a] = rho(a)[j][i]
+};
+Des2rTabs g_tabs = {nullptr, nullptr, nullptr, nullptr};
+int32_t *g_recheck = nullptr;                                 // device counter of correspondences that took the exact path (diagnostics)
+
+constexpr int DES2R_ITER = 4;
+constexpr int DES2R_ROW = ROREG_F * ROREG_G;                  // 1920 floats per keypoint
+
+template <typename FT> __device__ __forceinline__ float feat_ld(const FT *p, size_t i) { return (float)p[i]; }
+
+struct Des2rRows { const float *c1, *c0; size_t r1, r0; bool live; };
+
+template <typename FT, typename RowFn>
+__device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, const void *feats1_v, const void *feats0_v, Des2rTabs tabs,
+                                                 const uint8_t *__restrict__ P8, int64_t *__restrict__ idx_out, size_t out_base, int32_t *recheck) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *NTs = lds;                                         // [60][60]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float *X1 = lds + ROREG_G * ROREG_G + w * (2 * DES2R_ROW), *X2 = X1 + DES2R_ROW;
+    for (int i = tid; i < ROREG_G * ROREG_G; i += 512) NTs[i] = tabs.NT[i];
+    const bool act = lane < ROREG_G;
+    const int q = act ? lane : 0;
+    int ia[5], ib[5];
+    const int dl = tabs.cnt[q];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { ia[k] = tabs.ia[q * 5 + k]; ib[k] = tabs.ib[q * 5 + k]; }
+    // prefetch registers: 480 float4 per row = 7.5 per lane
+    float4 p1[8], p0[8];
+    auto fetch = [&](const Des2rRows &r) {
+        const float4 *s1 = reinterpret_cast<const float4 *>(r.c1 + r.r1 * DES2R_ROW), *s0 = reinterpret_cast<const float4 *>(r.c0 + r.r0 * DES2R_ROW);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = lane + 64 * i;
+            if (e < DES2R_ROW / 4) { p1[i] = s1[e]; p0[i] = s0[e]; }
+        }
+    };
+    Des2rRows cur = rows_of(0, w);
+    fetch(cur);
+    for (int it = 0; it < n_iter; ++it) {
+        __syncthreads();                                      // the previous correspondence's LDS rows are dead (and NTs is filled)
+        float n1 = 0.f, n0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = lane + 64 * i;
+            if (e < DES2R_ROW / 4) {
+                reinterpret_cast<float4 *>(X1)[e] = p1[i]; reinterpret_cast<float4 *>(X2)[e] = p0[i];
+                n1 += p1[i].x * p1[i].x + p1[i].y * p1[i].y + p1[i].z * p1[i].z + p1[i].w * p1[i].w;
+                n0 += p0[i].x * p0[i].x + p0[i].y * p0[i].y + p0[i].z * p0[i].z + p0[i].w * p0[i].w;
+            }
+        }
+        const Des2rRows me = cur;
+        if (it + 1 < n_iter) { cur = rows_of(it + 1, w); fetch(cur); }          // in flight under this correspondence's arithmetic
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o); n0 += __shfl_xor(n0, o); }
+        // ---- C[q] = sum_f sum_k X2[f][ia_k] * X1[f][ib_k] ----------------------------------------------------------------------------
+        float c = 0.f;
+#pragma unroll 4
+        for (int f = 0; f < ROREG_F; ++f) {
+            const float *x2 = X2 + f * ROREG_G, *x1 = X1 + f * ROREG_G;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (k < dl) c = fmaf(x2[ia[k]], x1[ib[k]], c);
+        }
+        if (!act) c = 0.f;
+        // ---- cor~[a] = sum_q NT[q][a] * C[q] -----------------------------------------------------------------------------------------
+        float cor = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < ROREG_G; ++qq) {
+            const float cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), qq));
+            cor = fmaf(NTs[qq * ROREG_G + q], cq, cor);
+        }
+        float bv = act ? cor : -__builtin_inff();
+        if (bv != bv) bv = -__builtin_inff();
+        int bi = act ? lane : 0x7fffffff;
+        const float mine = bv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const float margin = 1e-4f * sqrtf(n1 * n0);
+        unsigned long long cand = __ballot(act && !(mine < bv - margin));        // (NaN-safe: a NaN correlation stays a candidate)
+        if (!(margin == margin) || !(bv > -__builtin_inff())) cand = 0xfffffffffffffffull;     // non-finite input: evaluate every a literally
+        if (__popcll(cand) > 1 && me.live) {
+            // ---- exact path: the literal evaluation (des2r_body's arithmetic) for the candidates only ---------------------------------
+            __builtin_amdgcn_wave_barrier();
+            const FT *f1 = reinterpret_cast<const FT *>(feats1_v) + me.r1 * DES2R_ROW, *f0 = reinterpret_cast<const FT *>(feats0_v) + me.r0 * DES2R_ROW;
+            for (int e = lane; e < DES2R_ROW; e += 64) { X1[e] = feat_ld(f1, e); X2[e] = feat_ld(f0, e); }
+            __builtin_amdgcn_wave_barrier();
+            float best = -__builtin_inff();
+            int best_a = 0x7fffffff;
+            const int fl = lane & 31;
+            while (cand) {
+                const int a = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const uint8_t *prow = P8 + a * ROREG_G;
+                float sf = 0.f;
+                for (int g = 0; g < ROREG_G; ++g) sf = __fadd_rn(sf, __fmul_rn(X1[fl * ROREG_G + prow[g]], X2[fl * ROREG_G + g]));
+                float v = 0.f;
+#pragma unroll
+                for (int f = 0; f < ROREG_F; ++f)
+                    v = __fadd_rn(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sf), f)));
+                if (v != v) v = -__builtin_inff();
+                if (v > best || best_a == 0x7fffffff) { best = v; best_a = a; }
+            }
+            bi = best_a;
+            if (recheck && lane == 0) atomicAdd(recheck, 1);
+        }
+        if (me.live && lane == 0) idx_out[out_base + (size_t)it * 8 + w] = bi;
+    }
+}
+
+template <typename FT>
+__global__ __launch_bounds__(512) void des2r_irrep_kernel(const float *__restrict__ coef1, const int64_t *__restrict__ rows1,
+                                                          const float *__restrict__ coef0, const int64_t *__restrict__ rows0,
+                                                          const void *__restrict__ feats1, const void *__restrict__ feats0, Des2rTabs tabs,
+                                                          const uint8_t *__restrict__ P8, int M, int64_t *__restrict__ idx_out, int32_t *recheck) {
+    const int base = blockIdx.x * (8 * DES2R_ITER);
+    const int n_iter = min(DES2R_ITER, (M - base + 7) / 8);
+    auto rows_of = [&](int it, int w) {
+        const int b = base + it * 8 + w;
+        Des2rRows r;
+        r.live = b < M;
+        const int bb = r.live ? b : M - 1;
+        r.c1 = coef1; r.c0 = coef0;
+        r.r1 = rows1 ? (size_t)rows1[bb] : (size_t)bb; r.r0 = rows0 ? (size_t)rows0[bb] : (size_t)bb;
+        return r;
+    };
+    des2r_irrep_loop<FT>(rows_of, n_iter, feats1, feats0, tabs, P8, idx_out, (size_t)base, recheck);
+}
+
+// all pairs of a scene in one launch: blockIdx.y = pair, cloud 1 is the permuted side (test/estimator.py:108-110)
+template <typename FT>
+__global__ __launch_bounds__(512) void des2r_irrep_batch_kernel(const roreg::LtTask *__restrict__ tasks, Des2rTabs tabs,
+                                                                const uint8_t *__restrict__ P8, int64_t *__restrict__ dr_all, int32_t *recheck) {
+    const roreg::LtTask t = tasks[blockIdx.y];
+    const int base = blockIdx.x * (8 * DES2R_ITER);
+    if (base >= t.n) return;
+    const int n_iter = min(DES2R_ITER, (t.n - base + 7) / 8);
+    auto rows_of = [&](int it, int w) {
+        const int i = base + it * 8 + w;
+        Des2rRows r;
+        r.live = i < t.n;
+        r.c1 = t.coef1; r.c0 = t.coef0;
+        roreg::lt_rows(t, r.live ? i : t.n - 1, r.r0, r.r1);
+        return r;
+    };
+    des2r_irrep_loop<FT>(rows_of, n_iter, t.after1, t.after0, tabs, P8, dr_all, (size_t)(t.off + base), recheck);
+}
+
 }  // namespace
 
-void roreg::launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, hipStream_t s) {
+void roreg::launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr_all, bool irrep, bool feat_bf16, hipStream_t s) {
     roreg::ProfScope prof(roreg::PROF_DES2R, s);
-    hipLaunchKernelGGL(des2r_batch_kernel, dim3((max_n + 3) / 4, n_tasks), dim3(256), 0, s, tasks, roreg::group_tables().P8, dr_all);
+    if (!irrep) {
+        hipLaunchKernelGGL(des2r_batch_kernel, dim3((max_n + 3) / 4, n_tasks), dim3(256), 0, s, tasks, roreg::group_tables().P8, dr_all);
+        return;
+    }
+    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_ROW) * sizeof(float);
+    const dim3 grid((max_n + 8 * DES2R_ITER - 1) / (8 * DES2R_ITER), n_tasks);
+    if (feat_bf16) {
+        auto kern = des2r_irrep_batch_kernel<__bf16>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, tasks, g_tabs, roreg::group_tables().P8, dr_all, g_recheck);
+    } else {
+        auto kern = des2r_irrep_batch_kernel<float>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, tasks, g_tabs, roreg::group_tables().P8, dr_all, g_recheck);
+    }
+}
+
+bool roreg::des2r_tables_ready() { return g_tabs.NT != nullptr; }
+
+extern "C" int roreg_set_des2r_tables(const uint8_t *ia_host, const uint8_t *ib_host, const uint8_t *cnt_host, const float *NT_host) {
+    ROREG_REQUIRE(ia_host && ib_host && cnt_host && NT_host, "roreg_set_des2r_tables: null table");
+    for (int q = 0; q < ROREG_G; ++q) {
+        ROREG_REQUIRE(cnt_host[q] >= 1 && cnt_host[q] <= 5, "roreg_set_des2r_tables: bad count");
+        for (int k = 0; k < 5; ++k) ROREG_REQUIRE(ia_host[q * 5 + k] < ROREG_G && ib_host[q * 5 + k] < ROREG_G, "roreg_set_des2r_tables: index out of range");
+    }
+    if (!g_tabs.NT) {
+        uint8_t *b = nullptr; float *f = nullptr;
+        if (hipMalloc(&b, 1024) != hipSuccess || hipMalloc(&f, 3600 * sizeof(float)) != hipSuccess || hipMalloc(&g_recheck, 64) != hipSuccess) {
+            roreg::set_error("roreg_set_des2r_tables: hipMalloc failed");
+            return 1;
+        }
+        g_tabs.ia = b; g_tabs.ib = b + 320; g_tabs.cnt = b + 640; g_tabs.NT = f;
+        (void)hipMemset(g_recheck, 0, 64);
+    }
+    if (hipMemcpy(const_cast<uint8_t *>(g_tabs.ia), ia_host, 300, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(const_cast<uint8_t *>(g_tabs.ib), ib_host, 300, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(const_cast<uint8_t *>(g_tabs.cnt), cnt_host, 60, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(const_cast<float *>(g_tabs.NT), NT_host, 3600 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        roreg::set_error("roreg_set_des2r_tables: hipMemcpy failed");
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int roreg_des2r_recheck_count(int reset, int32_t *count_out) {
+    ROREG_REQUIRE(g_recheck && count_out, "roreg_des2r_recheck_count: tables not set");
+    if (hipMemcpy(count_out, g_recheck, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { roreg::set_error("roreg_des2r_recheck_count: copy failed"); return 1; }
+    if (reset) (void)hipMemset(g_recheck, 0, sizeof(int32_t));
+    return 0;
+}
+
+extern "C" int roreg_des2r_irrep(const float *coef1, const int64_t *rows1, const float *coef0, const int64_t *rows0, const void *feats1,
+                                 const void *feats0, int feat_bf16, int M, int64_t *idx_out, void *stream) {
+    if (M == 0) return 0;
+    ROREG_REQUIRE(coef1 && coef0 && feats1 && feats0 && idx_out && M > 0, "roreg_des2r_irrep: bad arguments");
+    ROREG_REQUIRE(roreg::group_tables().ready && g_tabs.NT, "roreg_des2r_irrep: group / des2r tables not set");
+    hipStream_t s = roreg::as_stream(stream);
+    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_ROW) * sizeof(float);
+    const dim3 grid((M + 8 * DES2R_ITER - 1) / (8 * DES2R_ITER));
+    if (feat_bf16) {
+        auto kern = des2r_irrep_kernel<__bf16>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, coef1, rows1, coef0, rows0, feats1, feats0, g_tabs, roreg::group_tables().P8, M, idx_out, g_recheck);
+    } else {
+        auto kern = des2r_irrep_kernel<float>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, coef1, rows1, coef0, rows0, feats1, feats0, g_tabs, roreg::group_tables().P8, M, idx_out, g_recheck);
+    }
+    ROREG_CHECK_LAUNCH("roreg_des2r_irrep");
+    return 0;
 }
 
 extern "C" int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, const int64_t *rows0, int M,

@@ -439,6 +439,7 @@ struct NonlinParams {
                                  // roreg_row_bound); the output is then written SPLIT for the GEMM: fp16 hi | fp16 lo << 16 of coef * 2^bound_exp(bound)
     float *out_rowmax;           // optional, group-domain output: per-keypoint max |value written| [B] (zeroed by the caller; atomic max), the
                                  // block scale of the fp16 x 2 convolution that consumes the tensor
+    int x_bf16;                  // the group-domain input / residual tensors are bfloat16 instead of float32
     float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
@@ -475,7 +476,9 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 // accumulate -- see irrep_gemm_split_kernel): 96 K=16 MFMAs (3072 cycles) per 32-keypoint tile instead of 124 f32 MFMAs (7936), which
 // turns the kernel from matrix-core-bound into HBM-bound.  K orders: inverse step st feeds coefficients q = 16 st + 8 h + e; the forward
 // product's step st consumes this lane's accumulator registers v[st>>1][8 (st&1) + e], i.e. again no transpose between the products.
-template <bool IN_SPATIAL, bool OUT_SPATIAL, int SPLIT /* 0: f32 MFMA, 3: bf16 x 3, 2: fp16 x 2 with per-column scales */, int NW /* waves per workgroup */, int MINW /* waves per SIMD to fit */>
+// OUT_ROWS (with IN_SPATIAL): the coefficients leave in per-keypoint layout [b][c][60] (float32) instead of the GEMM operand layout -- the
+// operand of the irrep-domain Des2R (roreg_feat_coefs).
+template <bool IN_SPATIAL, bool OUT_SPATIAL, int SPLIT /* 0: f32 MFMA, 3: bf16 x 3, 2: fp16 x 2 with per-column scales */, int NW /* waves per workgroup */, int MINW /* waves per SIMD to fit */, bool OUT_ROWS = false>
 __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p) {
     constexpr int NT = NW * 64;
     const int lane = threadIdx.x & 63;
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     constexpr int NA1 = SPLIT ? 4 * 2 * NPL * 64 * 4 : 30 * 2 * 64, NA2 = SPLIT ? 4 * 2 * NPL * 64 * 4 : 32 * 2 * 64;   // floats (a fragment = 4 floats)
     __shared__ __attribute__((aligned(16))) float sA1[IN_SPATIAL ? 64 : NA1];
     __shared__ __attribute__((aligned(16))) float sA2[OUT_SPATIAL ? 64 : NA2];
-    __shared__ float sT[OUT_SPATIAL ? NW * 32 * 65 : 64];
+    __shared__ float sT[(OUT_SPATIAL || OUT_ROWS) ? NW * 32 * 65 : 64];
     {
         const float *g1 = SPLIT == 3 ? reinterpret_cast<const float *>(p.A1s) : SPLIT == 2 ? reinterpret_cast<const float *>(p.A1h) : p.A1;
         const float *g2 = SPLIT == 3 ? reinterpret_cast<const float *>(p.A2s) : SPLIT == 2 ? reinterpret_cast<const float *>(p.A2h) : p.A2;
@@ -521,7 +524,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
     constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT != 0 ? 32 : 30);
-    constexpr bool PACK_OUT = SPLIT == 2 && !OUT_SPATIAL;         // coefficients leave as fp16 hi/lo pairs under the keypoint's block scale
+    constexpr bool PACK_OUT = SPLIT == 2 && !OUT_SPATIAL && !OUT_ROWS;      // coefficients leave as fp16 hi/lo pairs under the keypoint's block scale
+    // group-domain tensors are float32 or (x_bf16) bfloat16 as stored (BASELINE config 5)
+    auto ld_sp = [&](const float *base, size_t i) -> float {
+        return p.x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(base)[i] << 16) : base[i];
+    };
     float cn[NCV + 1];                                           // slot NCV: the keypoint's bound (PACK_OUT), prefetched with the coefficients
     auto load_coefs = [&](int tile, float (&dst)[NCV + 1]) {
         const int c = (IN_SPATIAL || OUT_SPATIAL) ? tile % C : tile / p.tiles_per_c;      // group-domain tensors are [b][c][.]: channel-fastest tiles
@@ -586,13 +593,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         float wmax = 0.f;                                        // max |value written| for this lane's keypoint (group-domain output)
         if (IN_SPATIAL) {
             if constexpr (PACK_OUT) cv[NCV] = p.out_bound[b];    // (b < Bp: the bound buffer covers the pad keypoints)
-            const float *src = p.x_spatial + ((size_t)bb * C + c) * ROREG_G;
+            const size_t src = ((size_t)bb * C + c) * ROREG_G;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    v[t][r] = g < ROREG_G ? src[g] : 0.f;
+                    v[t][r] = g < ROREG_G ? ld_sp(p.x_spatial, src + g) : 0.f;
                 }
         } else {
             load_coefs(next_tile, cnext);
@@ -644,15 +651,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         const float bsum = sBias[c];
         const bool bn = p.bn_scale != nullptr;
         const float sc = sScale[c], sh = sShift[c];
-        const float *rs = (OUT_SPATIAL && p.r_spatial) ? p.r_spatial + ((size_t)bb * C + c) * ROREG_G : nullptr;
-        float *tb = OUT_SPATIAL ? sT + (threadIdx.x >> 6) * (32 * 65) : nullptr;      // this wave's [32 keypoints][65] transpose buffer
+        const bool has_rs = OUT_SPATIAL && p.r_spatial;
+        const size_t rs = ((size_t)bb * C + c) * ROREG_G;
+        float *tb = (OUT_SPATIAL || OUT_ROWS) ? sT + (threadIdx.x >> 6) * (32 * 65) : nullptr;      // this wave's [32 keypoints][65] transpose buffer
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float x = v[t][r] + bsum;
-                if (OUT_SPATIAL && rs && g < ROREG_G) x += rs[g];
+                if (OUT_SPATIAL && has_rs && g < ROREG_G) x += ld_sp(p.r_spatial, rs + g);
                 if (bn) x = fmaxf(fmaf(x, sc, sh), 0.f);
                 if (g >= ROREG_G || !valid) x = 0.f;          // pad keypoints carry zeros through the forward transform: their coefficients are exact 0
                 v[t][r] = x;
@@ -712,18 +720,25 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     o[0] = mfma3(sA2h + ((st * 2 + 0) * 2) * 64 + lane, bh, bl, o[0]);
                     o[1] = mfma3(sA2h + ((st * 2 + 1) * 2) * 64 + lane, bh, bl, o[1]);
                 }
-                // undo the transform's scale and apply the keypoint's block scale in one exact multiplication, then split:
-                // word = fp16(x) | fp16(x - hi) << 16  (what the GEMM's staging reads)
-                const float psc = osc * ldexpf(1.f, bound_exp(cv[NCV]));
+                if constexpr (PACK_OUT) {
+                    // undo the transform's scale and apply the keypoint's block scale in one exact multiplication, then split:
+                    // word = fp16(x) | fp16(x - hi) << 16  (what the GEMM's staging reads)
+                    const float psc = osc * ldexpf(1.f, bound_exp(cv[NCV]));
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float x = o[t][r] * psc;
-                        const _Float16 h1 = (_Float16)x;
-                        const _Float16 l1 = (_Float16)(x - (float)h1);
-                        o[t][r] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16));
-                    }
+                        for (int r = 0; r < 16; ++r) {
+                            const float x = o[t][r] * psc;
+                            const _Float16 h1 = (_Float16)x;
+                            const _Float16 l1 = (_Float16)(x - (float)h1);
+                            o[t][r] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16));
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[t][r] *= osc;
+                }
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -734,7 +749,21 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                         o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA2[(s * 2 + 1) * 64 + lane], v[t][r], o[1], 0, 0, 0);
                     }
             }
-            {
+            if constexpr (OUT_ROWS) {
+                // per-keypoint layout [b][c][q]: through the wave's transpose buffer, one keypoint's 60 coefficients per store instruction
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qq = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (qq < ROREG_G) tb[jn * 65 + qq] = o[t][r];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int b0 = tbi * 32;
+                for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
+                    if (lane < ROREG_G) p.out_spatial[((size_t)(b0 + bl) * C + c) * ROREG_G + lane] = tb[bl * 65 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
                 const int tb = tbi;                           // pad keypoints (b >= B) get zeros: the buffers stay fully defined
                 static_for<32>([&](auto ic) {
                     constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
@@ -1003,15 +1032,15 @@ extern "C" int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, 
 // Per-keypoint bound on the coefficients of FT(act(x)) for a group-domain tensor x [B][C][60]: the transform is orthonormal, so
 // |coefficient| <= |act(x_c)|_2 <= sqrt(60) max_g |act(x_c(g))|, act = ReLU(scale_c x + shift_c) or the identity.  One wave per keypoint;
 // entries [B, Bp) (pad keypoints: their coefficients are exact zeros) get 0.
-__global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
-                                                        float *__restrict__ bound, int B, int Bp, int C) {
+__global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, int x_bf16, const float *__restrict__ bn_scale,
+                                                        const float *__restrict__ bn_shift, float *__restrict__ bound, int B, int Bp, int C) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= Bp) return;
     float mx = 0.f;
     if (b < B) {
-        const float *row = x + (size_t)b * C * ROREG_G;
+        const size_t row = (size_t)b * C * ROREG_G;
         for (int i = lane; i < C * ROREG_G; i += 64) {
-            float v = row[i];
+            float v = x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(x)[row + i] << 16) : x[row + i];
             if (bn_scale) { const int c = i / ROREG_G; v = fmaxf(fmaf(v, bn_scale[c], bn_shift[c]), 0.f); }
             mx = fmaxf(mx, fabsf(v));
         }
@@ -1021,11 +1050,13 @@ __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict_
     if (lane == 0) bound[b] = mx * 7.7536f;                      // sqrt(60) = 7.7460, plus slack for the f32 rounding of the transform itself
 }
 
-extern "C" int roreg_row_bound(const float *x_spatial, const float *bn_scale, const float *bn_shift, float *bound_out, int B, int C, void *stream) {
+extern "C" int roreg_row_bound(const void *x_spatial, int x_bf16, const float *bn_scale, const float *bn_shift, float *bound_out, int B, int C,
+                               void *stream) {
     ROREG_REQUIRE(x_spatial && bound_out && B > 0 && C > 0, "roreg_row_bound: bad arguments");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_row_bound: bn_scale and bn_shift go together");
     const int Bp = (B + 31) / 32 * 32;
-    hipLaunchKernelGGL(row_bound_kernel, dim3((Bp + 3) / 4), dim3(256), 0, roreg::as_stream(stream), x_spatial, bn_scale, bn_shift, bound_out, B, Bp, C);
+    hipLaunchKernelGGL(row_bound_kernel, dim3((Bp + 3) / 4), dim3(256), 0, roreg::as_stream(stream), reinterpret_cast<const float *>(x_spatial), x_bf16, bn_scale, bn_shift,
+                       bound_out, B, Bp, C);
     ROREG_CHECK_LAUNCH("roreg_row_bound");
     return 0;
 }
@@ -1033,7 +1064,7 @@ extern "C" int roreg_row_bound(const float *x_spatial, const float *bn_scale, co
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
                                const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, const float *out_bound, float *out_rowmax,
-                               void *stream) {
+                               int spatial_bf16, void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
@@ -1046,7 +1077,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
-    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_bound = out_bound; p.out_rowmax = out_rowmax;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_bound = out_bound; p.out_rowmax = out_rowmax; p.x_bf16 = spatial_bf16;
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
@@ -1055,6 +1086,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     const bool in_sp = x_spatial != nullptr, out_sp = out_spatial != nullptr;
     if (in_sp && out_sp) { roreg::set_error("roreg_ft_nonlin: spatial -> spatial is not a transform"); return 2; }
     ROREG_REQUIRE(split != 2 || out_sp || out_bound, "roreg_ft_nonlin: split = 2 writes the coefficients as fp16 hi/lo pairs and needs out_bound");
+    ROREG_REQUIRE(!spatial_bf16 || in_sp || resid_spatial, "roreg_ft_nonlin: spatial_bf16 refers to x_spatial / resid_spatial");
     ROREG_REQUIRE(!out_rowmax || out_sp, "roreg_ft_nonlin: out_rowmax goes with a group-domain output");
     auto grid_for = [&](int nw, long long cap) { long long b = (n_tiles + nw - 1) / nw; return dim3((unsigned)(b > cap ? cap : b)); };
     ROREG_REQUIRE(split >= 0 && split <= 2, "roreg_ft_nonlin: split must be 0 (f32 MFMA), 1 (bf16 x 3) or 2 (fp16 x 2)");
@@ -1073,5 +1105,27 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
         else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
     }
     ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
+    return 0;
+}
+
+extern "C" int roreg_feat_coefs(const void *x, int x_bf16, float *out, int B, int C, int split, void *stream) {
+    if (B == 0) return 0;
+    ROREG_REQUIRE(g_A1 && g_A2, "roreg_feat_coefs: roreg_set_fourier_tables has not been called");
+    ROREG_REQUIRE(x && out && B > 0 && C > 0 && C <= 512 && split >= 0 && split <= 2, "roreg_feat_coefs: bad arguments");
+    NonlinParams p;
+    memset(&p, 0, sizeof(p));
+    p.x_spatial = reinterpret_cast<const float *>(x); p.x_bf16 = x_bf16; p.out_spatial = out;
+    p.Lout = ROREG_G; p.Lvalid = ROREG_G; p.A1 = g_A1; p.A2 = g_A2;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump;
+    p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
+    p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
+    const long long n_tiles = (long long)C * p.tiles_per_c;
+    const long long blocks = (n_tiles + 3) / 4;
+    const dim3 grid((unsigned)(blocks > 2048 ? 2048 : blocks));
+    hipStream_t s = roreg::as_stream(stream);
+    if (split == 2) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 2, 4, 1, true>), grid, dim3(256), 0, s, p);
+    else if (split == 1) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 3, 4, 1, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 0, 4, 1, true>), grid, dim3(256), 0, s, p);
+    ROREG_CHECK_LAUNCH("roreg_feat_coefs");
     return 0;
 }

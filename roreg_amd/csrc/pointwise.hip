@@ -151,35 +151,39 @@ __global__ __launch_bounds__(256) void det_score_kernel(const float *__restrict_
 }
 
 // ---- et_gather: one block per correspondence ------------------------------------------------------------
-__device__ __forceinline__ void et_gather_body(const float *__restrict__ before0, const float *__restrict__ before1,
-                                               const float *__restrict__ after0, const float *__restrict__ after1, size_t r0, size_t r1,
+// FT = float or __bf16: the clouds' group features as stored (BASELINE config 5 keeps them in bfloat16); the assembled ET input is float32
+template <typename FT>
+__device__ __forceinline__ void et_gather_body(const void *__restrict__ before0_v, const void *__restrict__ before1_v,
+                                               const void *__restrict__ after0_v, const void *__restrict__ after1_v, size_t r0, size_t r1,
                                                int a, const int32_t *__restrict__ P, float *__restrict__ dst) {
     __shared__ int perm[ROREG_G];
     if (threadIdx.x < ROREG_G) perm[threadIdx.x] = P[a * ROREG_G + threadIdx.x];
     __syncthreads();
-    const float *s_b1 = before1 + r1 * (ROREG_F * ROREG_G), *s_b0 = before0 + r0 * (ROREG_F * ROREG_G);
-    const float *s_a1 = after1 + r1 * (ROREG_F * ROREG_G), *s_a0 = after0 + r0 * (ROREG_F * ROREG_G);
+    const FT *s_b1 = reinterpret_cast<const FT *>(before1_v) + r1 * (ROREG_F * ROREG_G), *s_b0 = reinterpret_cast<const FT *>(before0_v) + r0 * (ROREG_F * ROREG_G);
+    const FT *s_a1 = reinterpret_cast<const FT *>(after1_v) + r1 * (ROREG_F * ROREG_G), *s_a0 = reinterpret_cast<const FT *>(after0_v) + r0 * (ROREG_F * ROREG_G);
     for (int i = threadIdx.x; i < ROREG_F * ROREG_G; i += 256) {
         const int c = i / ROREG_G, g = i - c * ROREG_G;
         const int pg = c * ROREG_G + perm[g];
-        dst[i] = s_b1[pg];
-        dst[ROREG_F * ROREG_G + i] = s_b0[i];
-        dst[2 * ROREG_F * ROREG_G + i] = s_a1[pg];
-        dst[3 * ROREG_F * ROREG_G + i] = s_a0[i];
+        dst[i] = (float)s_b1[pg];
+        dst[ROREG_F * ROREG_G + i] = (float)s_b0[i];
+        dst[2 * ROREG_F * ROREG_G + i] = (float)s_a1[pg];
+        dst[3 * ROREG_F * ROREG_G + i] = (float)s_a0[i];
     }
 }
 
-__global__ __launch_bounds__(256) void et_gather_kernel(const float *__restrict__ before0, const float *__restrict__ before1,
-                                                        const float *__restrict__ after0, const float *__restrict__ after1,
+template <typename FT>
+__global__ __launch_bounds__(256) void et_gather_kernel(const void *__restrict__ before0, const void *__restrict__ before1,
+                                                        const void *__restrict__ after0, const void *__restrict__ after1,
                                                         const int64_t *__restrict__ rows0, const int64_t *__restrict__ rows1,
                                                         const int64_t *__restrict__ pre_idx, const int32_t *__restrict__ P,
                                                         float *__restrict__ x, int M) {
     const int b = blockIdx.x;
     if (b >= M) return;
     const size_t r0 = rows0 ? (size_t)rows0[b] : (size_t)b, r1 = rows1 ? (size_t)rows1[b] : (size_t)b;
-    et_gather_body(before0, before1, after0, after1, r0, r1, (int)pre_idx[b], P, x + (size_t)b * (4 * ROREG_F * ROREG_G));
+    et_gather_body<FT>(before0, before1, after0, after1, r0, r1, (int)pre_idx[b], P, x + (size_t)b * (4 * ROREG_F * ROREG_G));
 }
 
+template <typename FT>
 __global__ __launch_bounds__(256) void et_gather_batch_kernel(const roreg::LtTask *__restrict__ tasks, const int64_t *__restrict__ dr_all,
                                                               const int32_t *__restrict__ P, float *__restrict__ x_all) {
     const roreg::LtTask t = tasks[blockIdx.y];
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void et_gather_batch_kernel(const roreg::LtTas
     if (i >= t.n) return;
     size_t r0, r1;
     roreg::lt_rows(t, i, r0, r1);
-    et_gather_body(t.before0, t.before1, t.after0, t.after1, r0, r1, (int)dr_all[t.off + i], P, x_all + (size_t)(t.off + i) * (4 * ROREG_F * ROREG_G));
+    et_gather_body<FT>(t.before0, t.before1, t.after0, t.after1, r0, r1, (int)dr_all[t.off + i], P, x_all + (size_t)(t.off + i) * (4 * ROREG_F * ROREG_G));
 }
 
 // ---- quat_to_trans: one thread per correspondence --------------------------------------------------------
@@ -290,15 +294,19 @@ extern "C" int roreg_det_score(const float *enc, float *scores, int B, void *str
     return 0;
 }
 
-extern "C" int roreg_et_gather(const float *before0, const float *before1, const float *after0, const float *after1,
+extern "C" int roreg_et_gather(const void *before0, const void *before1, const void *after0, const void *after1, int feat_bf16,
                                const int64_t *rows0, const int64_t *rows1, const int64_t *pre_idx, int M, float *x_out,
                                void *stream) {
     if (M == 0) return 0;
     ROREG_REQUIRE(before0 && before1 && after0 && after1 && pre_idx && x_out && M > 0, "roreg_et_gather: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_et_gather: group tables not set");
     if (M == 0) return 0;
-    hipLaunchKernelGGL(et_gather_kernel, dim3(M), dim3(256), 0, roreg::as_stream(stream), before0, before1, after0, after1,
-                       rows0, rows1, pre_idx, roreg::group_tables().P, x_out, M);
+    if (feat_bf16)
+        hipLaunchKernelGGL(et_gather_kernel<__bf16>, dim3(M), dim3(256), 0, roreg::as_stream(stream), before0, before1, after0, after1,
+                           rows0, rows1, pre_idx, roreg::group_tables().P, x_out, M);
+    else
+        hipLaunchKernelGGL(et_gather_kernel<float>, dim3(M), dim3(256), 0, roreg::as_stream(stream), before0, before1, after0, after1,
+                           rows0, rows1, pre_idx, roreg::group_tables().P, x_out, M);
     ROREG_CHECK_LAUNCH("roreg_et_gather");
     return 0;
 }
@@ -326,15 +334,23 @@ extern "C" int roreg_gather_rows_f64(const double *src, const int64_t *rows, int
     return 0;
 }
 
-extern "C" int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int64_t *dr_out, float *x_out, void *stream) {
+extern "C" int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int flags, int64_t *dr_out, float *x_out,
+                                      void *stream) {
     if (n_tasks == 0 || max_n == 0) return 0;
     ROREG_REQUIRE(tasks_dev && dr_out && n_tasks > 0 && max_n > 0, "roreg_lt_prepare_batch: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_lt_prepare_batch: group tables not set");
+    ROREG_REQUIRE(!(flags & 1) || roreg::des2r_tables_ready(), "roreg_lt_prepare_batch: roreg_set_des2r_tables has not been called");
+    ROREG_REQUIRE(!(flags & 2) || (flags & 1), "roreg_lt_prepare_batch: bfloat16 features need the irrep-domain Des2R (flags bit 0)");
     static_assert(sizeof(roreg_lt_task) == sizeof(roreg::LtTask), "roreg_lt_task layout");
     const roreg::LtTask *tasks = reinterpret_cast<const roreg::LtTask *>(tasks_dev);
     hipStream_t s = roreg::as_stream(stream);
-    roreg::launch_des2r_batch(tasks, n_tasks, max_n, dr_out, s);
-    if (x_out) hipLaunchKernelGGL(et_gather_batch_kernel, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+    roreg::launch_des2r_batch(tasks, n_tasks, max_n, dr_out, (flags & 1) != 0, (flags & 2) != 0, s);
+    if (x_out) {
+        if (flags & 2)
+            hipLaunchKernelGGL(et_gather_batch_kernel<__bf16>, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+        else
+            hipLaunchKernelGGL(et_gather_batch_kernel<float>, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+    }
     ROREG_CHECK_LAUNCH("roreg_lt_prepare_batch");
     return 0;
 }

@@ -21,6 +21,7 @@ from .group import tables
 class CloudState:
     before: torch.Tensor            # FCGF-like input group features [N,32,60] f32 (device)
     eqv: torch.Tensor = None        # GF output [N,32,60]
+    eqv_ft: torch.Tensor = None     # group-Fourier coefficients of eqv [N,32,60] f32 (hip.feat_coefs): operand of the irrep-domain Des2R
     inv: torch.Tensor = None        # matcher invariant descriptor [N,32]
     keys: torch.Tensor = None       # keypoints [N,3] f64 (device)
     det: np.ndarray = None          # detector rank scores (host, as det_score/*.npy)
@@ -159,7 +160,7 @@ class RegistrationEngine:
         with torch.no_grad():
             eqv = self.gf.PartI_net(x, want_inv=False)['eqv']
         k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
-        return CloudState(before=x, eqv=eqv, inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
+        return CloudState(before=x, eqv=eqv, eqv_ft=hip.feat_coefs(eqv), inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
 
     def extract_many(self, feats_list, keys_list, max_rows=65536):
         """Several clouds per group-conv launch: a 5000-keypoint cloud is 9.2 waves of workgroups on the 512 resident slots,
@@ -175,13 +176,14 @@ class RegistrationEngine:
             with torch.no_grad():
                 eqv = self.gf.PartI_net(xcat, want_inv=False)['eqv']
             inv = hip.inv_descriptor(eqv)
+            eft = hip.feat_coefs(eqv)
             o = 0
             for q in range(i, j):
                 n = xs[q].shape[0]
                 k = keys_list[q]
                 k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
-                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], inv=inv[o:o + n], keys=k.to('cuda', torch.float64).contiguous(),
-                                      ))
+                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], eqv_ft=eft[o:o + n], inv=inv[o:o + n],
+                                      keys=k.to('cuda', torch.float64).contiguous()))
                 o += n
             i = j
         return out
@@ -327,7 +329,7 @@ class RegistrationEngine:
             j, rows = i, 0
             while j < len(items) and (j == i or rows + sizes[j] <= max_rows):
                 rows += sizes[j]; j += 1
-            batch = hip.LtBatch([(c0.before, c1.before, c0.eqv, c1.eqv, c0.keys, c1.keys, m, sel) for c0, c1, m, sel in items[i:j]])
+            batch = hip.LtBatch([(c0.before, c1.before, c0.eqv, c1.eqv, c0.keys, c1.keys, m, sel, c0.eqv_ft, c1.eqv_ft) for c0, c1, m, sel in items[i:j]])
             dr_all, x_all = batch.prepare()
             with torch.no_grad():
                 q_all = self.et.trunk_and_head(x_all) if rows else torch.empty((0, 4), dtype=torch.float32, device='cuda')
@@ -341,7 +343,7 @@ class RegistrationEngine:
     def local_transforms(self, c0, c1, matches):
         """Des2R + ET + assembly: matches [M,2] int64 device -> (dr_index [M], Trans [M,3,4] f64)."""
         rows0 = matches[:, 0].contiguous(); rows1 = matches[:, 1].contiguous()
-        dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0)
+        dr = hip.des2r(c1.eqv, c0.eqv, rows1=rows1, rows0=rows0, coefs1=c1.eqv_ft, coefs0=c0.eqv_ft)
         x = hip.et_gather(c0.before, c1.before, c0.eqv, c1.eqv, dr, rows0=rows0, rows1=rows1)
         with torch.no_grad():
             q = self.et.trunk_and_head(x)
@@ -398,7 +400,7 @@ class RegistrationEngine:
         the hypothesis draws and the 3-point Kabsch stack; ONE upload of all hypotheses.  -> (tasks, weights, {pair: (T, recalltime)}
         for the pairs the reference gives up on)."""
         from .test.estimator import yohoc_draws, three_point_transforms, _select_top
-        batch = hip.LtBatch([(c0.eqv, c1.eqv, c0.eqv, c1.eqv, c0.keys, c1.keys, m, None) for c0, c1, m in full])
+        batch = hip.LtBatch([(c0.eqv, c1.eqv, c0.eqv, c1.eqv, c0.keys, c1.keys, m, None, c0.eqv_ft, c1.eqv_ft) for c0, c1, m in full])
         dr_all = batch.des2r().cpu().numpy()
         if writer is not None:
             for (a, b), (off, n) in zip(pair_ids, batch.offsets):

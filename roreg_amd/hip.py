@@ -56,11 +56,15 @@ PROTOTYPES = {
     'roreg_mutual_match_batch_workspace': (c_size_t, [c_int, c_int]),
     'roreg_mutual_match_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     'roreg_des2r': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
-    'roreg_et_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    'roreg_set_des2r_tables': (c_int, [_P, _P, _P, _P]),
+    'roreg_des2r_irrep': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    'roreg_des2r_recheck_count': (c_int, [c_int, _P]),
+    'roreg_feat_coefs': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    'roreg_et_gather': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
     'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
-    'roreg_lt_prepare_batch': (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    'roreg_lt_prepare_batch': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'roreg_lt_finish_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
     'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -88,8 +92,8 @@ PROTOTYPES = {
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
-    'roreg_row_bound': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'roreg_row_bound': (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
 }
 
 
@@ -144,6 +148,16 @@ def _ptr(t, dtype=None):
     if dtype is not None and t.dtype != dtype:
         raise HipError(f'expected dtype {dtype}, got {t.dtype}')
     return c_void_p(t.data_ptr())
+
+
+def _feat(t):
+    """Pointer + 'is bfloat16' flag of a group-feature tensor [*,32,60]: float32, or bfloat16 (BASELINE config 5: descriptors stored and
+    streamed as bf16, every consumer accumulates in float32)."""
+    if t is None:
+        return None, 0
+    if t.dtype == torch.bfloat16:
+        return _ptr(t, torch.bfloat16), 1
+    return _ptr(t, torch.float32), 0
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -357,29 +371,43 @@ def mutual_matches(nn01, nn10, sample0=None, sample1=None):
 
 
 _LT_TASK = np.dtype([('before0', np.uint64), ('before1', np.uint64), ('after0', np.uint64), ('after1', np.uint64), ('keys0', np.uint64),
-                     ('keys1', np.uint64), ('matches', np.uint64), ('sel', np.uint64), ('n', np.int32), ('pad', np.int32), ('off', np.int64)])
+                     ('keys1', np.uint64), ('matches', np.uint64), ('sel', np.uint64), ('n', np.int32), ('pad', np.int32), ('off', np.int64),
+                     ('coef0', np.uint64), ('coef1', np.uint64)])
 
 
 class LtBatch:
-    """Task table of the batched local-transform stage.  tasks: [(before0, before1, after0, after1 [*,32,60] f32, keys0, keys1 [*,3] f64,
-    matches [M,2] int64, sel int64 [n] or None)] device tensors; task p owns output rows [off[p], off[p]+n[p])."""
+    """Task table of the batched local-transform stage.  tasks: [(before0, before1, after0, after1 [*,32,60] f32 (or all bf16), keys0, keys1
+    [*,3] f64, matches [M,2] int64, sel int64 [n] or None[, coef0, coef1 = feat_coefs(after0 / after1)])] device tensors; task p owns
+    output rows [off[p], off[p]+n[p]).  With the coefficient tensors Des2R runs through the irrep-domain bound + exact re-check."""
 
     def __init__(self, tasks):
         self.n_tasks = len(tasks)
         table = np.zeros(self.n_tasks, _LT_TASK)
         off = 0
         self.offsets = []
-        for i, (b0, b1, a0, a1, k0, k1, m, sel) in enumerate(tasks):
-            for t in (b0, b1, a0, a1):
-                _ptr(t, torch.float32)
+        n_coef = 0; n_bf16 = 0
+        for i, task in enumerate(tasks):
+            b0, b1, a0, a1, k0, k1, m, sel = task[:8]
+            c0, c1 = (task[8], task[9]) if len(task) > 8 else (None, None)
+            flags = {_feat(t)[1] for t in (b0, b1, a0, a1)}
+            if len(flags) != 1:
+                raise HipError('LtBatch: the four feature tensors of a task must share one dtype')
+            n_bf16 += flags.pop()
             _ptr(k0, torch.float64); _ptr(k1, torch.float64); _ptr(m, torch.int64)
             if sel is not None:
                 _ptr(sel, torch.int64)
+            if c0 is not None:
+                _ptr(c0, torch.float32); _ptr(c1, torch.float32); n_coef += 1
             n = int(sel.shape[0]) if sel is not None else int(m.shape[0])
             table[i] = (b0.data_ptr(), b1.data_ptr(), a0.data_ptr(), a1.data_ptr(), k0.data_ptr(), k1.data_ptr(), m.data_ptr() if n else 0,
-                        sel.data_ptr() if sel is not None else 0, n, 0, off)
+                        sel.data_ptr() if sel is not None else 0, n, 0, off, c0.data_ptr() if c0 is not None else 0, c1.data_ptr() if c1 is not None else 0)
             self.offsets.append((off, n))
             off += n
+        if n_coef not in (0, self.n_tasks) or n_bf16 not in (0, self.n_tasks):
+            raise HipError('LtBatch: either every task carries coefficient tensors / bfloat16 features or none does')
+        self.flags = (1 if n_coef else 0) | (2 if n_bf16 else 0)
+        if self.flags & 1:
+            ensure_des2r()
         self.total = off
         self.max_n = int(table['n'].max()) if self.n_tasks else 0
         self.keep = tasks                              # the table holds raw pointers: keep the tensors alive
@@ -394,7 +422,7 @@ class LtBatch:
         if rows_alloc > self.total:
             x[self.total:].zero_()
         if self.total:
-            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(dr), _ptr(x), _stream()), 'roreg_lt_prepare_batch')
+            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, self.flags, _ptr(dr), _ptr(x), _stream()), 'roreg_lt_prepare_batch')
         return dr, x
 
     def des2r(self):
@@ -402,7 +430,7 @@ class LtBatch:
         ensure_tables()
         dr = torch.empty(self.total, dtype=torch.int64, device='cuda')
         if self.total:
-            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, _ptr(dr), None, _stream()), 'roreg_lt_prepare_batch')
+            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, self.flags, _ptr(dr), None, _stream()), 'roreg_lt_prepare_batch')
         return dr
 
     def finish(self, q_all, dr):
@@ -512,9 +540,75 @@ def mutual_match_batch(tasks):
     return out, cnt
 
 
-def des2r(feats1, feats0, rows1=None, rows0=None, want_cor=False):
+_des2r_ready = False
+
+
+def des2r_tables():
+    """(ia, ib uint8 [60,5], cnt uint8 [60], NT float32 [60 (q), 60 (a)]) of the irrep-domain Des2R, derived from the multiplication table:
+    x -> x[P[a,.]] acts on the coefficient matrices as X(rho) -> rho(a)^T X(rho), so
+        cor[a] = sum_g x1[P[a,g]] x2[g] = sum_rho <rho(a)^T X1, X2> = sum_q NT[q][a] C[q],   C[(rho,i,j)] = sum_k X2[(rho,i,k)] X1[(rho,j,k)]
+    (coefficient index of (rho,r,c) = offset_rho + r*d + c).  The identity is asserted here in float64 on random data."""
+    from .fourier import group_fourier, DIMS
+    gf = group_fourier(); T = tables()
+    ia = np.zeros((60, 5), np.uint8); ib = np.zeros((60, 5), np.uint8); cnt = np.zeros(60, np.uint8)
+    NT = np.zeros((60, 60), np.float64)
+    for q, (ri, i, j) in enumerate(gf.index):
+        d = DIMS[ri]; off = int(gf.offsets[ri])
+        cnt[q] = d
+        for k in range(5):
+            kk = min(k, d - 1)
+            ia[q, k] = off + i * d + kk; ib[q, k] = off + j * d + kk
+        NT[q, :] = gf.rho[ri][:, j, i]
+    rng = np.random.default_rng(0)
+    d1 = rng.standard_normal((4, 60)); d2 = rng.standard_normal((4, 60))
+    want = np.array([(d1[:, T.P[a]] * d2).sum() for a in range(60)])
+    X1 = d1 @ gf.F.T; X2 = d2 @ gf.F.T
+    C = np.array([sum((X2[f, ia[q, :cnt[q]]] * X1[f, ib[q, :cnt[q]]]).sum() for f in range(4)) for q in range(60)])
+    assert np.abs(C @ NT - want).max() < 1e-11, 'irrep-domain correlation identity violated'
+    return ia, ib, cnt, np.ascontiguousarray(NT, np.float32)
+
+
+def ensure_des2r():
+    global _des2r_ready
+    if not _des2r_ready:
+        ensure_tables(); ensure_fourier()
+        ia, ib, cnt, NT = des2r_tables()
+        _check(lib().roreg_set_des2r_tables(ia.ctypes.data, ib.ctypes.data, cnt.ctypes.data, NT.ctypes.data), 'roreg_set_des2r_tables')
+        _des2r_ready = True
+
+
+def feat_coefs(x):
+    """Group-Fourier coefficients of a group-domain tensor x [B,C,60] (float32 or bfloat16) in per-keypoint layout -> float32 [B,C,60]
+    (the operand of the irrep-domain Des2R; computed once per cloud)."""
+    ensure_fourier()
+    B, C = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty((B, C, 60), dtype=torch.float32, device=x.device)
+    xp, bf = _feat(x)
+    _check(lib().roreg_feat_coefs(xp, bf, _ptr(out), B, C, {'f16x2': 2, 'bf16x3': 1, 'f32': 0}[GEMM_MODE], _stream()), 'roreg_feat_coefs')
+    return out
+
+
+def des2r_recheck_count(reset=True):
+    """Correspondences that took the exact (literal) path of the irrep-domain Des2R since the last reset (synchronises)."""
+    n = ctypes.c_int32(0)
+    _check(lib().roreg_des2r_recheck_count(1 if reset else 0, ctypes.byref(n)), 'roreg_des2r_recheck_count')
+    return n.value
+
+
+def des2r(feats1, feats0, rows1=None, rows0=None, want_cor=False, coefs1=None, coefs0=None):
+    """First arg-max of the 60 local-rotation correlations per correspondence (test/estimator.py:85-89).  With coefs1 / coefs0 =
+    feat_coefs(feats1 / feats0): the irrep-domain bound + exact re-check of near ties (same index, ~10x fewer operations)."""
     ensure_tables()
     M = int(rows1.shape[0]) if rows1 is not None else int(feats1.shape[0])
+    if coefs1 is not None and not want_cor:
+        ensure_des2r()
+        idx = torch.empty(M, dtype=torch.int64, device=feats1.device)
+        p1, bf1 = _feat(feats1); p0, bf0 = _feat(feats0)
+        if bf1 != bf0:
+            raise HipError('des2r: feats1 and feats0 must share one dtype')
+        _check(lib().roreg_des2r_irrep(_ptr(coefs1, torch.float32), _ptr(rows1, torch.int64), _ptr(coefs0, torch.float32), _ptr(rows0, torch.int64),
+                                       p1, p0, bf1, M, _ptr(idx), _stream()), 'roreg_des2r_irrep')
+        return idx
     idx = torch.empty(M, dtype=torch.int64, device=feats1.device)
     cor = torch.empty((M, 60), dtype=torch.float32, device=feats1.device) if want_cor else None
     _check(lib().roreg_des2r(_ptr(feats1, torch.float32), _ptr(rows1, torch.int64), _ptr(feats0, torch.float32), _ptr(rows0, torch.int64),
@@ -527,8 +621,10 @@ def et_gather(before0, before1, after0, after1, pre_idx, rows0=None, rows1=None,
     M = pre_idx.shape[0]
     x = out if out is not None else torch.empty((M, 128, 60), dtype=torch.float32, device=before0.device)
     assert x.shape == (M, 128, 60)
-    _check(lib().roreg_et_gather(_ptr(before0, torch.float32), _ptr(before1, torch.float32), _ptr(after0, torch.float32),
-                                 _ptr(after1, torch.float32), _ptr(rows0, torch.int64), _ptr(rows1, torch.int64),
+    ptrs = [_feat(t) for t in (before0, before1, after0, after1)]
+    if len({f for _, f in ptrs}) != 1:
+        raise HipError('et_gather: the four feature tensors must share one dtype')
+    _check(lib().roreg_et_gather(ptrs[0][0], ptrs[1][0], ptrs[2][0], ptrs[3][0], ptrs[0][1], _ptr(rows0, torch.int64), _ptr(rows1, torch.int64),
                                  _ptr(pre_idx, torch.int64), M, _ptr(x), _stream()), 'roreg_et_gather')
     return x
 
@@ -845,7 +941,8 @@ def row_bound(x, bn=None):
     B, C = int(x.shape[0]), int(x.shape[1])
     out = torch.empty(coef_pitch(B), dtype=torch.float32, device=x.device)
     scale, shift = bn if bn is not None else (None, None)
-    _check(lib().roreg_row_bound(_ptr(x, torch.float32), _ptr(scale), _ptr(shift), _ptr(out), B, C, _stream()), 'roreg_row_bound')
+    xp, bf = _feat(x)
+    _check(lib().roreg_row_bound(xp, bf, _ptr(scale), _ptr(shift), _ptr(out), B, C, _stream()), 'roreg_row_bound')
     return out
 
 
@@ -931,10 +1028,13 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
         raise HipError(f'ft_nonlin: coef_in must hold 60*C*{coef_pitch(B)} floats')
     if out_bound is not None and out_bound.numel() != coef_pitch(B):
         raise HipError(f'ft_nonlin: out_bound must hold one value per (padded) keypoint ({coef_pitch(B)})')
-    _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), _ptr(x_spatial, torch.float32), _ptr(bias),
-                                 _ptr(bias2), _ptr(scale), _ptr(shift), _ptr(resid_spatial, torch.float32), xout, osp,
+    xs, bf_x = _feat(x_spatial); rs, bf_r = _feat(resid_spatial)
+    if x_spatial is not None and resid_spatial is not None and bf_x != bf_r:
+        raise HipError('ft_nonlin: x_spatial and resid_spatial must share one dtype')
+    _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), xs, _ptr(bias),
+                                 _ptr(bias2), _ptr(scale), _ptr(shift), rs, xout, osp,
                                  _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 2 if split == 'f16x2' else (1 if split else 0),
-                                 _ptr(out_bound, torch.float32), _ptr(amax), _stream()), 'roreg_ft_nonlin')
+                                 _ptr(out_bound, torch.float32), _ptr(amax), bf_x or bf_r, _stream()), 'roreg_ft_nonlin')
     return (out, amax) if want_rowmax else out
 
 

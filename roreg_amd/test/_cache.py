@@ -31,6 +31,23 @@ def load_device(path, dtype=torch.float32):
     return t
 
 
+def load_coefs(path):
+    """Group-Fourier coefficients (hip.feat_coefs) of the feature file `path`, cached like the file itself: the operand of the
+    irrep-domain Des2R, computed once per cloud instead of once per pair."""
+    global _bytes
+    from .. import hip
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, 'coefs')
+    t = _store.get(key)
+    if t is not None:
+        _store.move_to_end(key)
+        return t
+    t = hip.feat_coefs(load_device(path))
+    _store[key] = t
+    _bytes += t.numel() * t.element_size()
+    return t
+
+
 def clear():
     global _bytes
     _store.clear()

@@ -236,6 +236,59 @@ def test_des2r_bit_exact(group):
     assert np.array_equal(idx2, O.des2r(z['d1'][r1], z['d2'][r0], group.P))
 
 
+def test_feat_coefs_are_the_orthonormal_transform(group):
+    from roreg_amd import hip
+    from roreg_amd.fourier import group_fourier
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((77, 32, 60)).astype(np.float32)
+    got = hip.feat_coefs(cu(x)).cpu().numpy()
+    want = x.astype(np.float64) @ group_fourier().F.T
+    assert got.shape == (77, 32, 60) and np.abs(got - want).max() < 2e-6
+    gb = hip.feat_coefs(cu(x).to(torch.bfloat16)).cpu().numpy()                  # bfloat16 storage, float32 arithmetic
+    wb = cu(x).to(torch.bfloat16).float().cpu().numpy().astype(np.float64) @ group_fourier().F.T
+    assert np.abs(gb - wb).max() < 2e-6
+
+
+@pytest.mark.parametrize('scale', [1.0, 300.0, 1e-3])
+def test_des2r_irrep_bound_with_exact_recheck_is_the_literal_argmax(group, scale):
+    """The irrep-domain Des2R (bound from sum_d d^3 = 244 multiply-adds per channel + literal re-evaluation of the candidates) returns the
+    literal kernel's index on every row, including exact ties (duplicated rotations), near ties at the 1e-7..1e-3 level and
+    correspondences whose correlation is pure noise; and it only re-evaluates a small share of ordinary rows."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(12)
+    n = 3000
+    d2 = rng.standard_normal((n, 32, 60)).astype(np.float32)
+    d1 = rng.standard_normal((n, 32, 60)).astype(np.float32)                      # rows 0..999: unrelated (noise-level correlations)
+    a = rng.integers(0, 60, n)
+    for i in range(1000, 2000):                                                  # planted rotation + noise: a clear winner
+        d1[i][:, group.P[a[i]]] = d2[i]
+        d1[i] += 0.3 * rng.standard_normal((32, 60)).astype(np.float32)
+    for i in range(2000, 2400):                                                  # two planted rotations with equal weight: exact / near ties
+        b = (a[i] + 1 + i % 58) % 60
+        d1[i] = 0
+        d1[i][:, group.P[a[i]]] += d2[i]
+        tmp = np.zeros((32, 60), np.float32); tmp[:, group.P[b]] = d2[i]
+        d1[i] += tmp * np.float32(1.0 + (0.0 if i % 4 == 0 else 10.0 ** -(i % 7 + 1)))
+    d1[2400:2700] = d1[2000:2300]; d2[2400:2700] = d2[2000:2300]                  # duplicates of the tie rows
+    d1[2700:] = 0                                                                # all-zero side: every correlation is 0 -> index 0
+    d1 *= np.float32(scale); d2 *= np.float32(scale)
+    D1, D2 = cu(d1), cu(d2)
+    want = hip.des2r(D1, D2)                                                     # the literal kernel (itself bit-exact vs the oracle / golden)
+    c1, c2 = hip.feat_coefs(D1), hip.feat_coefs(D2)
+    hip.des2r_recheck_count()
+    got = hip.des2r(D1, D2, coefs1=c1, coefs0=c2)
+    assert torch.equal(got, want)
+    n_all = hip.des2r_recheck_count()
+    assert n_all >= 600                                                          # the tie rows and the all-zero rows took the exact path
+    got = hip.des2r(D1, D2, rows1=cu(np.arange(2000)), rows0=cu(np.arange(2000)), coefs1=c1, coefs0=c2)
+    assert torch.equal(got, want[:2000]) and hip.des2r_recheck_count() < 0.15 * 2000    # ordinary rows: mostly the bound alone
+    # bfloat16 feature storage: coefficients and literal re-evaluation both see the bf16-rounded values
+    B1, B2 = D1.to(torch.bfloat16), D2.to(torch.bfloat16)
+    wantb = hip.des2r(B1.float(), B2.float())
+    gotb = hip.des2r(B1, B2, coefs1=hip.feat_coefs(B1), coefs0=hip.feat_coefs(B2))
+    assert torch.equal(gotb, wantb)
+
+
 def test_des2r_recovers_planted_rotation(group):
     from roreg_amd import hip
     rng = np.random.default_rng(2)
@@ -383,6 +436,11 @@ def test_lt_batch_equals_per_pair_calls(group):
         md = cu(m); sd = cu(sel) if sel is not None else None
         tasks.append((c0['before'], c1['before'], c0['eqv'], c1['eqv'], c0['keys'], c1['keys'], md, sd))
         host.append((c0, c1, m if sel is None else m[sel]))
+    # the same tasks with coefficient tensors: Des2R through the irrep-domain bound + exact re-check -> identical indices
+    for c in clouds:
+        c['ft'] = hip.feat_coefs(c['eqv'])
+    tasks_ft = [t + (clouds[a]['ft'], clouds[b]['ft']) for t, (a, b, _, _) in zip(tasks, specs)]
+    assert torch.equal(hip.LtBatch(tasks_ft).des2r(), hip.LtBatch(tasks).des2r())
     batch = hip.LtBatch(tasks)
     dr, x = batch.prepare(batch.total + 3)
     assert float(x[batch.total:].abs().max()) == 0.0
