@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void des2r_batch_kernel(const roreg::LtTask *_
 // i.e. per channel sum_rho d^3 = 244 multiply-adds for C instead of 3600, plus ONE 60 x 60 product per correspondence -- 10x fewer
 // operations, no permuted gather.  The per-keypoint coefficients are computed once per cloud (roreg_feat_coefs).  That value is an
 // approximation of the float32 number the reference computes (different arithmetic), so it only BOUNDS: every a with
-// cor~[a] >= max cor~ - margin is a candidate, margin = 1e-4 |d1| |d2| >= 2 (|cor~ - exact| + |literal f32 - exact|) (the literal
-// evaluation is two-level, 60 then 32 terms: its error is <= (93 eps) sum |terms| <= 5.6e-6 |d1||d2|; the irrep evaluation with
-// f32-accurate transforms is of the same order), so the literal first arg-max is always among the candidates.  One candidate: done.
+// cor~[a] >= max cor~ - margin is a candidate, margin = 6e-5 |d1| |d2| >= 2 (|cor~ - exact| + |literal f32 - exact|): the literal
+// evaluation is two-level, 60 then 32 terms, error <= (93 eps) sum |terms| <= 5.6e-6 |d1||d2|; the irrep evaluation -- f32-accurate
+// transforms (a few eps per coefficient), 160 + 60 chained fmas -- <= 1.5e-5 |d1||d2|; so the literal first arg-max is always among the
+// candidates.  One candidate: done.
 // Several (near ties, duplicates -- a few per cent of random correspondences, none of the well-matched ones): the candidates are
 // re-evaluated with the literal formula in the reference's order (des2r_body above, bit for bit) from the group-domain rows, and the first
 // maximum of those wins.  Result: the index of the literal evaluation, always.
@@ -122,6 +123,8 @@ int32_t *g_recheck = nullptr;                                 // device counter 
 
 constexpr int DES2R_ITER = 4;
 constexpr int DES2R_ROW = ROREG_F * ROREG_G;                  // 1920 floats per keypoint
+constexpr int DES2R_PITCH = 64;                               // LDS row pitch: columns 60..63 stay zero (the target of padded product terms)
+constexpr int DES2R_LROW = ROREG_F * DES2R_PITCH;             // floats per staged keypoint
 
 template <typename FT> __device__ __forceinline__ float feat_ld(const FT *p, size_t i) { return (float)p[i]; }
 
@@ -133,14 +136,18 @@ __device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, cons
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *NTs = lds;                                         // [60][60]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float *X1 = lds + ROREG_G * ROREG_G + w * (2 * DES2R_ROW), *X2 = X1 + DES2R_ROW;
+    float *X1 = lds + ROREG_G * ROREG_G + w * (2 * DES2R_LROW), *X2 = X1 + DES2R_LROW;
     for (int i = tid; i < ROREG_G * ROREG_G; i += 512) NTs[i] = tabs.NT[i];
+    if (lane < 32) {                                          // zero pads of this wave's rows (never overwritten)
+        *reinterpret_cast<float4 *>(X1 + lane * DES2R_PITCH + ROREG_G) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(X2 + lane * DES2R_PITCH + ROREG_G) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const bool act = lane < ROREG_G;
     const int q = act ? lane : 0;
-    int ia[5], ib[5];
+    int ia[5], ib[5];                                         // terms beyond the irrep's dimension read the zero pad: branch-free loop
     const int dl = tabs.cnt[q];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { ia[k] = tabs.ia[q * 5 + k]; ib[k] = tabs.ib[q * 5 + k]; }
+    for (int k = 0; k < 5; ++k) { ia[k] = k < dl ? tabs.ia[q * 5 + k] : ROREG_G; ib[k] = k < dl ? tabs.ib[q * 5 + k] : ROREG_G; }
     // prefetch registers: 480 float4 per row = 7.5 per lane
     float4 p1[8], p0[8];
     auto fetch = [&](const Des2rRows &r) {
@@ -153,31 +160,35 @@ __device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, cons
     };
     Des2rRows cur = rows_of(0, w);
     fetch(cur);
+    __syncthreads();                                          // NTs is filled; from here on every wave works on its own LDS rows only
+    auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     for (int it = 0; it < n_iter; ++it) {
-        __syncthreads();                                      // the previous correspondence's LDS rows are dead (and NTs is filled)
+        // (no workgroup barrier in the loop: a wave's LDS operations execute in program order, and a correspondence that takes the
+        // exact path then delays only its own wave)
+        wave_fence();
         float n1 = 0.f, n0 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = lane + 64 * i;
             if (e < DES2R_ROW / 4) {
-                reinterpret_cast<float4 *>(X1)[e] = p1[i]; reinterpret_cast<float4 *>(X2)[e] = p0[i];
+                const int le = (e / 15) * (DES2R_PITCH / 4) + e % 15;          // 15 float4 per 60-float row -> pitch of 16
+                reinterpret_cast<float4 *>(X1)[le] = p1[i]; reinterpret_cast<float4 *>(X2)[le] = p0[i];
                 n1 += p1[i].x * p1[i].x + p1[i].y * p1[i].y + p1[i].z * p1[i].z + p1[i].w * p1[i].w;
                 n0 += p0[i].x * p0[i].x + p0[i].y * p0[i].y + p0[i].z * p0[i].z + p0[i].w * p0[i].w;
             }
         }
         const Des2rRows me = cur;
         if (it + 1 < n_iter) { cur = rows_of(it + 1, w); fetch(cur); }          // in flight under this correspondence's arithmetic
-        __syncthreads();
+        wave_fence();
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o); n0 += __shfl_xor(n0, o); }
         // ---- C[q] = sum_f sum_k X2[f][ia_k] * X1[f][ib_k] ----------------------------------------------------------------------------
         float c = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int f = 0; f < ROREG_F; ++f) {
-            const float *x2 = X2 + f * ROREG_G, *x1 = X1 + f * ROREG_G;
+            const float *x2 = X2 + f * DES2R_PITCH, *x1 = X1 + f * DES2R_PITCH;
 #pragma unroll
-            for (int k = 0; k < 5; ++k)
-                if (k < dl) c = fmaf(x2[ia[k]], x1[ib[k]], c);
+            for (int k = 0; k < 5; ++k) c = fmaf(x2[ia[k]], x1[ib[k]], c);
         }
         if (!act) c = 0.f;
         // ---- cor~[a] = sum_q NT[q][a] * C[q] -----------------------------------------------------------------------------------------
@@ -197,24 +208,30 @@ __device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, cons
             const int oi = __shfl_xor(bi, o);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        const float margin = 1e-4f * sqrtf(n1 * n0);
+        const float margin = 6e-5f * sqrtf(n1 * n0);
         unsigned long long cand = __ballot(act && !(mine < bv - margin));        // (NaN-safe: a NaN correlation stays a candidate)
         if (!(margin == margin) || !(bv > -__builtin_inff())) cand = 0xfffffffffffffffull;     // non-finite input: evaluate every a literally
         if (__popcll(cand) > 1 && me.live) {
             // ---- exact path: the literal evaluation (des2r_body's arithmetic) for the candidates only ---------------------------------
-            __builtin_amdgcn_wave_barrier();
+            wave_fence();
             const FT *f1 = reinterpret_cast<const FT *>(feats1_v) + me.r1 * DES2R_ROW, *f0 = reinterpret_cast<const FT *>(feats0_v) + me.r0 * DES2R_ROW;
-            for (int e = lane; e < DES2R_ROW; e += 64) { X1[e] = feat_ld(f1, e); X2[e] = feat_ld(f0, e); }
-            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < DES2R_ROW; e += 64) {
+                const int le = (e / ROREG_G) * DES2R_PITCH + e % ROREG_G;
+                X1[le] = feat_ld(f1, e); X2[le] = feat_ld(f0, e);
+            }
+            wave_fence();
             float best = -__builtin_inff();
             int best_a = 0x7fffffff;
             const int fl = lane & 31;
             while (cand) {
                 const int a = __builtin_ctzll(cand);
                 cand &= cand - 1;
-                const uint8_t *prow = P8 + a * ROREG_G;
+                const int pmine = P8[a * ROREG_G + q];          // lane g holds P[a][g]; broadcast per step
                 float sf = 0.f;
-                for (int g = 0; g < ROREG_G; ++g) sf = __fadd_rn(sf, __fmul_rn(X1[fl * ROREG_G + prow[g]], X2[fl * ROREG_G + g]));
+                for (int g = 0; g < ROREG_G; ++g) {
+                    const int pg = __builtin_amdgcn_readlane(pmine, g);
+                    sf = __fadd_rn(sf, __fmul_rn(X1[fl * DES2R_PITCH + pg], X2[fl * DES2R_PITCH + g]));
+                }
                 float v = 0.f;
 #pragma unroll
                 for (int f = 0; f < ROREG_F; ++f)
@@ -275,7 +292,7 @@ void roreg::launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int6
         hipLaunchKernelGGL(des2r_batch_kernel, dim3((max_n + 3) / 4, n_tasks), dim3(256), 0, s, tasks, roreg::group_tables().P8, dr_all);
         return;
     }
-    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_ROW) * sizeof(float);
+    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_LROW) * sizeof(float);
     const dim3 grid((max_n + 8 * DES2R_ITER - 1) / (8 * DES2R_ITER), n_tasks);
     if (feat_bf16) {
         auto kern = des2r_irrep_batch_kernel<__bf16>;
@@ -328,7 +345,7 @@ extern "C" int roreg_des2r_irrep(const float *coef1, const int64_t *rows1, const
     ROREG_REQUIRE(coef1 && coef0 && feats1 && feats0 && idx_out && M > 0, "roreg_des2r_irrep: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready && g_tabs.NT, "roreg_des2r_irrep: group / des2r tables not set");
     hipStream_t s = roreg::as_stream(stream);
-    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_ROW) * sizeof(float);
+    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_LROW) * sizeof(float);
     const dim3 grid((M + 8 * DES2R_ITER - 1) / (8 * DES2R_ITER));
     if (feat_bf16) {
         auto kern = des2r_irrep_kernel<__bf16>;

@@ -590,6 +590,7 @@ def feat_coefs(x):
 
 def des2r_recheck_count(reset=True):
     """Correspondences that took the exact (literal) path of the irrep-domain Des2R since the last reset (synchronises)."""
+    ensure_des2r()
     n = ctypes.c_int32(0)
     _check(lib().roreg_des2r_recheck_count(1 if reset else 0, ctypes.byref(n)), 'roreg_des2r_recheck_count')
     return n.value
