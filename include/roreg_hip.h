@@ -82,7 +82,8 @@ int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const floa
 
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
-int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream);
+int roreg_gf_finalize(const float *eqv_raw, void *eqv, int eqv_bf16 /* store eqv as bfloat16 (round to nearest even) instead of float32 */,
+                      float *inv, int B, void *stream);
 
 /* ---- detector ------------------------------------------------------------------------------------
  * enc [B,16,60] -> scores[b] = std_a( sum_f sum_g fn[f,P[a,g]] fn[f,g] ), fn = enc/||enc||_2 over 16 ch,
@@ -91,7 +92,8 @@ int roreg_det_score(const float *enc, float *scores, int B, void *stream);
 
 /* ---- descriptors / nearest neighbours ------------------------------------------------------------
  * eqv [N,32,60] -> inv [N,32] = mean_g / (||.||_2 + 1e-5).  test/matcher.py:69-72. */
-int roreg_inv_descriptor(const float *eqv, float *inv, int N, void *stream);
+int roreg_inv_descriptor(const void *eqv, int eqv_bf16 /* eqv is stored as bfloat16; float32 arithmetic on the stored values */, float *inv, int N,
+                         void *stream);
 
 /* For every source row the nearest target row: d = sqrt(sum_f (s_f-t_f)^2 + 1e-7) accumulated in f order
  * (fp32, no FMA), first minimum wins.  src [m,F], tgt [n,F] row-major; optional row index lists

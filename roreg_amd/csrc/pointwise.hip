@@ -29,13 +29,15 @@ __device__ __forceinline__ float np_pairwise_sum(const float *a, int n) {
 }
 
 // ---- gf_finalize: one wave per keypoint ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void gf_finalize_kernel(const float *__restrict__ raw, float *__restrict__ eqv,
+// OT = float, or __bf16: the descriptors are STORED in bfloat16 (round to nearest even), BASELINE config 5
+template <typename OT>
+__global__ __launch_bounds__(256) void gf_finalize_kernel(const float *__restrict__ raw, void *__restrict__ eqv_v,
                                                           float *__restrict__ inv, int B) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
     if (b >= B) return;
     const float *src = raw + (size_t)b * (ROREG_F * ROREG_G);
-    float *dst = eqv + (size_t)b * (ROREG_F * ROREG_G);
+    OT *dst = reinterpret_cast<OT *>(eqv_v) + (size_t)b * (ROREG_F * ROREG_G);
     const bool act = lane < ROREG_G;
     float v[ROREG_F];
     float n2 = 0.f;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void gf_finalize_kernel(const float *__restric
     const float nrm = fmaxf(sqrtf(n2), 1e-4f);
     if (act) {
 #pragma unroll
-        for (int f = 0; f < ROREG_F; ++f) dst[f * ROREG_G + lane] = v[f] / nrm;
+        for (int f = 0; f < ROREG_F; ++f) dst[f * ROREG_G + lane] = (OT)(v[f] / nrm);
     }
     if (inv) {
         // mean over g of the un-normalised features, then normalise over the 32 channels
@@ -67,15 +69,16 @@ __global__ __launch_bounds__(256) void gf_finalize_kernel(const float *__restric
 }
 
 // ---- inv_descriptor: one wave per keypoint; lanes 0..31 own one channel row each ---------------------
-__global__ __launch_bounds__(256) void inv_descriptor_kernel(const float *__restrict__ eqv, float *__restrict__ inv, int N) {
+// FT = float or __bf16 (descriptors stored in bfloat16; the arithmetic below is float32 on the stored values either way)
+template <typename FT>
+__global__ __launch_bounds__(256) void inv_descriptor_kernel(const void *__restrict__ eqv_v, float *__restrict__ inv, int N) {
     __shared__ float tile[4][ROREG_F * ROREG_G + 32];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = blockIdx.x * 4 + w;
     const bool live = n < N;
     if (live) {
-        const float4 *src = reinterpret_cast<const float4 *>(eqv + (size_t)n * (ROREG_F * ROREG_G));
-        float4 *t4 = reinterpret_cast<float4 *>(tile[w]);
-        for (int i = lane; i < ROREG_F * ROREG_G / 4; i += 64) t4[i] = src[i];
+        const FT *src = reinterpret_cast<const FT *>(eqv_v) + (size_t)n * (ROREG_F * ROREG_G);
+        for (int i = lane; i < ROREG_F * ROREG_G; i += 64) tile[w][i] = (float)src[i];
     }
     __syncthreads();
     if (!live) return;
@@ -267,18 +270,20 @@ __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double *__re
 
 }  // namespace
 
-extern "C" int roreg_gf_finalize(const float *eqv_raw, float *eqv, float *inv, int B, void *stream) {
+extern "C" int roreg_gf_finalize(const float *eqv_raw, void *eqv, int eqv_bf16, float *inv, int B, void *stream) {
     if (B == 0) return 0;
     ROREG_REQUIRE(eqv_raw && eqv && B > 0, "roreg_gf_finalize: bad arguments");
-    hipLaunchKernelGGL(gf_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv_raw, eqv, inv, B);
+    if (eqv_bf16) hipLaunchKernelGGL(gf_finalize_kernel<__bf16>, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv_raw, eqv, inv, B);
+    else hipLaunchKernelGGL(gf_finalize_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv_raw, eqv, inv, B);
     ROREG_CHECK_LAUNCH("roreg_gf_finalize");
     return 0;
 }
 
-extern "C" int roreg_inv_descriptor(const float *eqv, float *inv, int N, void *stream) {
+extern "C" int roreg_inv_descriptor(const void *eqv, int eqv_bf16, float *inv, int N, void *stream) {
     if (N == 0) return 0;
     ROREG_REQUIRE(eqv && inv && N > 0, "roreg_inv_descriptor: bad arguments");
-    hipLaunchKernelGGL(inv_descriptor_kernel, dim3((N + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv, inv, N);
+    if (eqv_bf16) hipLaunchKernelGGL(inv_descriptor_kernel<__bf16>, dim3((N + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv, inv, N);
+    else hipLaunchKernelGGL(inv_descriptor_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, roreg::as_stream(stream), eqv, inv, N);
     ROREG_CHECK_LAUNCH("roreg_inv_descriptor");
     return 0;
 }

@@ -121,6 +121,7 @@ class RegistrationEngine:
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
         self.rm_max_points = 80000  # points per side stacked into one pass of the rotation-coherence matcher (32 pairs at keynum 2500)
+        self.feat_dtype = torch.bfloat16 if getattr(cfg, 'dtype', 'fp32') == 'bf16' else torch.float32
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
 
     def _mark(self, name, t0):
@@ -132,6 +133,15 @@ class RegistrationEngine:
         t1 = time.perf_counter()
         self.phase_ms[name] = self.phase_ms.get(name, 0.0) + 1e3 * (t1 - t0)
         return t1
+
+    def set_descriptor_dtype(self, name):
+        """'fp32' | 'bf16' (BASELINE config 5): device storage of the group features -- the FCGF-like input is rounded to bfloat16 once when it
+        is taken in, the extractor's last kernel stores its output in bfloat16, and every consumer (matcher descriptor, Des2R, ET input
+        assembly, detector, rotation-coherence matcher) reads the stored values and accumulates in float32.  Parity is then defined on
+        the bf16-rounded tensors: indices equal the oracle's fed those tensors (tests/test_hip_bf16.py)."""
+        if name not in ('fp32', 'bf16'):
+            raise ValueError("descriptor dtype must be 'fp32' or 'bf16'")
+        self.feat_dtype = torch.bfloat16 if name == 'bf16' else torch.float32
 
     def set_gemm_mode(self, mode):
         """'f16x2' | 'bf16x3' | 'f32': how the group-conv GEMMs / convolutions feed the matrix cores (hip.GEMM_MODE)."""
@@ -156,16 +166,17 @@ class RegistrationEngine:
     def extract(self, feats, keys):
         """feats: [N,32,60] f32 (host ndarray or device tensor); keys [N,3] f64."""
         x = feats if torch.is_tensor(feats) else torch.from_numpy(np.ascontiguousarray(feats, np.float32))
-        x = x.to('cuda', torch.float32).contiguous()
+        x = x.to('cuda', torch.float32).to(self.feat_dtype).contiguous()
         with torch.no_grad():
-            eqv = self.gf.PartI_net(x, want_inv=False)['eqv']
+            eqv = self.gf.PartI_net(x, want_inv=False, out_dtype=self.feat_dtype)['eqv']
         k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
         return CloudState(before=x, eqv=eqv, eqv_ft=hip.feat_coefs(eqv), inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
 
     def extract_many(self, feats_list, keys_list, max_rows=65536):
         """Several clouds per group-conv launch: a 5000-keypoint cloud is 9.2 waves of workgroups on the 512 resident slots,
         so a lone cloud wastes ~8 % in the partial last wave; batching clouds makes that tail negligible."""
-        xs = [(f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32) for f in feats_list]
+        xs = [(f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32).to(self.feat_dtype)
+              for f in feats_list]
         out = []
         i = 0
         while i < len(xs):
@@ -174,7 +185,7 @@ class RegistrationEngine:
                 rows += xs[j].shape[0]; j += 1
             xcat = torch.cat(xs[i:j], 0) if j - i > 1 else xs[i].contiguous()
             with torch.no_grad():
-                eqv = self.gf.PartI_net(xcat, want_inv=False)['eqv']
+                eqv = self.gf.PartI_net(xcat, want_inv=False, out_dtype=self.feat_dtype)['eqv']
             inv = hip.inv_descriptor(eqv)
             eft = hip.feat_coefs(eqv)
             o = 0
@@ -283,7 +294,7 @@ class RegistrationEngine:
             while j < len(jobs) and (j == i or pts + max(len(jobs[j][2]), len(jobs[j][3])) <= max_points):
                 pts += max(len(jobs[j][2]), len(jobs[j][3])); j += 1
             seg_s = hip.Segments([len(jobs[q][3]) for q in range(i, j)]); seg_t = hip.Segments([len(jobs[q][2]) for q in range(i, j)])
-            se = torch.empty((seg_s.total, 32, 60), dtype=torch.float32, device='cuda'); te = torch.empty((seg_t.total, 32, 60), dtype=torch.float32, device='cuda')
+            se = torch.empty((seg_s.total, 32, 60), dtype=self.feat_dtype, device='cuda'); te = torch.empty((seg_t.total, 32, 60), dtype=self.feat_dtype, device='cuda')
             sk = torch.empty((seg_s.total, 3), dtype=torch.float64, device='cuda'); tk = torch.empty((seg_t.total, 3), dtype=torch.float64, device='cuda')
             for q in range(i, j):
                 c0, c1 = jobs[q][0], jobs[q][1]
@@ -292,7 +303,7 @@ class RegistrationEngine:
                 torch.index_select(c1.eqv, 0, d1, out=se[a:a + d1.shape[0]]); torch.index_select(c1.keys, 0, d1, out=sk[a:a + d1.shape[0]])
                 torch.index_select(c0.eqv, 0, d0, out=te[b:b + d0.shape[0]]); torch.index_select(c0.keys, 0, d0, out=tk[b:b + d0.shape[0]])
             with torch.no_grad():
-                issued += self.rm.match_stacked(se, te, sk.float(), tk.float(), seg_s, seg_t)
+                issued += self.rm.match_stacked(se.float(), te.float(), sk.float(), tk.float(), seg_s, seg_t)   # (bf16 rows: lossless up-cast)
             i = j
         m0_all = torch.cat([m for m, _ in issued]).cpu().numpy()            # the one sync of the matcher stage
         sc_all = torch.cat([s for _, s in issued]).cpu().numpy()

@@ -44,9 +44,9 @@ PROTOTYPES = {
     'roreg_group_conv_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'roreg_dense_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    'roreg_gf_finalize': (c_int, [_P, _P, _P, c_int, _P]),
+    'roreg_gf_finalize': (c_int, [_P, _P, c_int, _P, c_int, _P]),
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
-    'roreg_inv_descriptor': (c_int, [_P, _P, c_int, _P]),
+    'roreg_inv_descriptor': (c_int, [_P, c_int, _P, c_int, _P]),
     'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_knn_search_workspace': (c_size_t, [c_int, c_int]),
     'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
@@ -297,11 +297,13 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
     return out
 
 
-def gf_finalize(eqv_raw, want_inv=True):
+def gf_finalize(eqv_raw, want_inv=True, out_dtype=torch.float32):
+    """out_dtype=torch.bfloat16: the descriptors are stored in bfloat16 (BASELINE config 5); `inv` is computed from the float32 values."""
     B = eqv_raw.shape[0]
-    eqv = torch.empty_like(eqv_raw)
+    eqv = torch.empty(eqv_raw.shape, dtype=out_dtype, device=eqv_raw.device)
     inv = torch.empty((B, 32), dtype=torch.float32, device=eqv_raw.device) if want_inv else None
-    _check(lib().roreg_gf_finalize(_ptr(eqv_raw, torch.float32), _ptr(eqv), _ptr(inv), B, _stream()), 'roreg_gf_finalize')
+    ep, bf = _feat(eqv)
+    _check(lib().roreg_gf_finalize(_ptr(eqv_raw, torch.float32), ep, bf, _ptr(inv), B, _stream()), 'roreg_gf_finalize')
     return eqv, inv
 
 
@@ -318,7 +320,8 @@ def inv_descriptor(eqv):
     N = eqv.shape[0]
     assert eqv.shape[1:] == (32, 60)
     out = torch.empty((N, 32), dtype=torch.float32, device=eqv.device)
-    _check(lib().roreg_inv_descriptor(_ptr(eqv, torch.float32), _ptr(out), N, _stream()), 'roreg_inv_descriptor')
+    ep, bf = _feat(eqv)
+    _check(lib().roreg_inv_descriptor(ep, bf, _ptr(out), N, _stream()), 'roreg_inv_descriptor')
     return out
 
 

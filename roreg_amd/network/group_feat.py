@@ -22,21 +22,23 @@ class Group_feat_network(nn.Module):
         object.__setattr__(self, 'mode', 'fourier')
         object.__setattr__(self, '_fourier', None)
 
-    def forward(self, feats, want_inv=True):
+    def forward(self, feats, want_inv=True, out_dtype=torch.float32):
+        """feats float32 or bfloat16 [B,32,60] (bfloat16: read as stored, float32 arithmetic); out_dtype: storage of 'eqv'."""
         if feats.dim() != 3 or feats.shape[1:] != (32, 60):
             raise ValueError(f'GF expects [B,32,60], got {tuple(feats.shape)}')
-        x = feats.to('cuda', torch.float32).contiguous()
+        x = feats.to('cuda', torch.bfloat16 if feats.dtype == torch.bfloat16 else torch.float32).contiguous()
         if self.mode == 'fourier':
             if self._fourier is None:
                 from .gf_fourier import FourierGF
                 object.__setattr__(self, '_fourier', FourierGF(self))
             raw = self._fourier.forward_raw(x)
         else:
+            x = x.float()
             h = self._b_in(x)
             for layer in self.SO3_Conv_layers:
                 h = layer(h)
             raw = self.Conv_out(h, residual=x)          # feats_eqv + feats  (group_feat.py:37)
-        eqv, inv = hip.gf_finalize(raw, want_inv=want_inv)
+        eqv, inv = hip.gf_finalize(raw, want_inv=want_inv, out_dtype=out_dtype)
         return {'inv': inv, 'eqv': eqv}
 
 

@@ -27,6 +27,8 @@ _FLAGS = [
     ('Test_Args', 'match_n', 0.5, float, 'share of the best-scored correspondences handed to the estimator (>= 1: a count; 0.99: all)'),
     ('Test_Args', 'bs_GF', 1250, int, 'keypoints per extractor batch'),
     ('Test_Args', 'bs_ET', 1000, int, 'correspondences per local-transform batch'),
+    # not a reference flag: storage precision of the group features on the device
+    ('Test_Args', 'dtype', 'fp32', str, 'fp32 | bf16: keep the group features (FCGF input and YOHO output) in bfloat16 on the device; arithmetic stays float32'),
 ]
 
 

@@ -31,18 +31,26 @@ def load_device(path, dtype=torch.float32):
     return t
 
 
-def load_coefs(path):
+def feat_dtype(cfg):
+    """Device storage of the group features for this run: cfg.dtype 'bf16' (BASELINE config 5) or float32."""
+    name = getattr(cfg, 'dtype', 'fp32')
+    if name not in ('fp32', 'bf16'):
+        raise ValueError(f"--dtype must be fp32 or bf16, got {name!r}")
+    return torch.bfloat16 if name == 'bf16' else torch.float32
+
+
+def load_coefs(path, dtype=torch.float32):
     """Group-Fourier coefficients (hip.feat_coefs) of the feature file `path`, cached like the file itself: the operand of the
     irrep-domain Des2R, computed once per cloud instead of once per pair."""
     global _bytes
     from .. import hip
     st = os.stat(path)
-    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, 'coefs')
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, 'coefs', dtype)
     t = _store.get(key)
     if t is not None:
         _store.move_to_end(key)
         return t
-    t = hip.feat_coefs(load_device(path))
+    t = hip.feat_coefs(load_device(path, dtype))
     _store[key] = t
     _bytes += t.numel() * t.element_size()
     return t

@@ -96,11 +96,12 @@ class extractor_dr_index:
         for pair in tqdm(dataset.pair_ids):
             id0, id1 = pair
             match_pps = torch.from_numpy(np.load(f'{match_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
-            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')
-            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy')
+            ft = _cache.feat_dtype(self.cfg)
+            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy', ft)
+            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy', ft)
             # irrep-domain bound + exact re-check of near ties: the literal arg-max with ~10x fewer operations (coefficients cached per cloud)
             pre_idxs = hip.des2r(feats1, feats0, rows1=match_pps[:, 1].contiguous(), rows0=match_pps[:, 0].contiguous(),
-                                 coefs1=_cache.load_coefs(f'{Feature_dir}/{id1}.npy'), coefs0=_cache.load_coefs(f'{Feature_dir}/{id0}.npy'))
+                                 coefs1=_cache.load_coefs(f'{Feature_dir}/{id1}.npy', ft), coefs0=_cache.load_coefs(f'{Feature_dir}/{id0}.npy', ft))
             np.save(f'{Save_dir}/{id0}-{id1}.npy', pre_idxs.cpu().numpy())
 
 
@@ -255,8 +256,9 @@ class extractor_localtrans():
             id0, id1 = pair
             pps = torch.from_numpy(np.load(f'{match_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
             rows0 = pps[:, 0].contiguous(); rows1 = pps[:, 1].contiguous()
-            f0_in = _cache.load_device(f'{FCGF_dir}/{id0}.npy'); f1_in = _cache.load_device(f'{FCGF_dir}/{id1}.npy')
-            f0_out = _cache.load_device(f'{YOMO_dir}/{id0}.npy'); f1_out = _cache.load_device(f'{YOMO_dir}/{id1}.npy')
+            ft = _cache.feat_dtype(self.cfg)
+            f0_in = _cache.load_device(f'{FCGF_dir}/{id0}.npy', ft); f1_in = _cache.load_device(f'{FCGF_dir}/{id1}.npy', ft)
+            f0_out = _cache.load_device(f'{YOMO_dir}/{id0}.npy', ft); f1_out = _cache.load_device(f'{YOMO_dir}/{id1}.npy', ft)
             Index_pre = torch.from_numpy(np.load(f'{DRindex_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
             keys0 = _dev64(dataset.get_kps(id0)); keys1 = _dev64(dataset.get_kps(id1))
             outs = []

@@ -48,10 +48,14 @@ class yoho_des():
         make_non_exists_dir(dst)
         print(f'Extracting the PartI descriptors on {dataset.name}')
         step = self.test_batch_size                      # bounds the activation footprint only: the result does not depend on it
+        from ._cache import feat_dtype
+        ft = feat_dtype(self.cfg)
         for pc in tqdm(dataset.pc_ids):
             if os.path.exists(f'{dst}/{pc}.npy'):
                 continue
-            x = torch.from_numpy(np.load(f'{src}/{pc}.npy').astype(np.float32)).cuda()
+            # --dtype bf16: the features live on the device in bfloat16 (input rounded once here, output rounded by the network's last
+            # kernel); the .npy contract stays float32 (the stored values are then exactly representable in bfloat16)
+            x = torch.from_numpy(np.load(f'{src}/{pc}.npy').astype(np.float32)).cuda().to(ft)
             with torch.no_grad():
-                chunks = [self.network(x[i:i + step])['eqv'] for i in range(0, x.shape[0], step)]
-            np.save(f'{dst}/{pc}.npy', torch.cat(chunks, 0).cpu().numpy())
+                chunks = [self.network.PartI_net(x[i:i + step], want_inv=False, out_dtype=ft)['eqv'] for i in range(0, x.shape[0], step)]
+            np.save(f'{dst}/{pc}.npy', torch.cat(chunks, 0).float().cpu().numpy())

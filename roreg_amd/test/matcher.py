@@ -85,8 +85,9 @@ class mutual():
         Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
         for pair in tqdm.tqdm(dataset.pair_ids):
             id0, id1 = pair
-            eqv0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')       # N*32*60, HBM-resident across pairs
-            eqv1 = _cache.load_device(f'{Feature_dir}/{id1}.npy')
+            ft = _cache.feat_dtype(self.cfg)
+            eqv0 = _cache.load_device(f'{Feature_dir}/{id0}.npy', ft)   # N*32*60, HBM-resident across pairs
+            eqv1 = _cache.load_device(f'{Feature_dir}/{id1}.npy', ft)
             inv0 = hip.inv_descriptor(eqv0)                               # mean over g, / (norm + 1e-5)  (matcher.py:69-72)
             inv1 = hip.inv_descriptor(eqv1)
             sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, eqv0.shape[0], eqv1.shape[0], keynum)
@@ -170,15 +171,16 @@ class yoho_mat():
 
         for pair in tqdm.tqdm(dataset.pair_ids):
             id0, id1 = pair
-            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy')
-            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy')
+            ft = _cache.feat_dtype(self.cfg)
+            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy', ft)
+            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy', ft)
             sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, feats0.shape[0], feats1.shape[0], keynum)
             s0 = torch.from_numpy(np.ascontiguousarray(sample0, np.int64)).cuda()
             s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
             keys0 = dataset.get_kps(id0)[sample0]
             keys1 = dataset.get_kps(id1)[sample1]
             # NB the network's source side ('feats0/keys0') is pc1 and its target side pc0 (matcher.py:192-197)
-            pend.append((id0, id1, (feats1[s1], feats0[s0], torch.from_numpy(keys1.astype(np.float32)).cuda(),
+            pend.append((id0, id1, (feats1[s1].float(), feats0[s0].float(), torch.from_numpy(keys1.astype(np.float32)).cuda(),
                                     torch.from_numpy(keys0.astype(np.float32)).cuda()), np.asarray(sample0), np.asarray(sample1)))
             if len(pend) >= group:
                 flush()
