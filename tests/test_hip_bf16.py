@@ -39,7 +39,7 @@ def test_extractor_bf16_io_vs_oracle_on_rounded_input(group):
     assert got['eqv'].dtype == torch.bfloat16
     want32 = O.gf_forward(xb, sd, group.Nei)['eqv']
     g = got['eqv'].float().cpu().numpy(); w = bf16_round(want32)
-    ulp = np.abs(w) * 2.0 ** -7 + 1e-30                                      # >= one bfloat16 ulp of the value
+    ulp = np.abs(w) * 2.0 ** -7 + 2e-6                                       # >= one bfloat16 ulp of the value, + the float32 evaluation noise near 0
     assert (np.abs(g - w) <= ulp).all()
     assert np.mean(g != w) < 0.01
     assert np.abs(g - want32).max() < 2.0 ** -8                                # i.e. the stored value is the float32 result to bf16 precision
