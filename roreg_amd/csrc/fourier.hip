@@ -16,6 +16,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -198,6 +199,76 @@ __device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &
     }
 }
 
+// Epilogue shared by the fp16 x 2 / bf16 x 3 GEMM kernels: rescale, optional residual, store, optional bound propagation.
+template <int NP, int WO>
+__device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int ncol_wave, f32x16 (&acc)[2][4],
+                                                    char *smem) {
+    constexpr int NCOL = 256, OT = WO * 64, NT = WO * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int M = p.M[irr], N = p.N[irr];
+    const int dirr = kIrrDim[irr];
+    float *__restrict__ Out = p.Out[irr];
+    const float *__restrict__ Add = p.Add[irr];
+    // NP = 2: every column carries its keypoint's own power-of-two scale (undone here together with the weights' 2^w_exp), and the
+    // epilogue can emit the bound the NEXT transform needs to split its output: max over this tile's rows of u_o |T| + v_o per column,
+    // merged per keypoint with an atomic max (order-independent, hence deterministic).
+    float oscale[4] = {1.f, 1.f, 1.f, 1.f};
+    float bmax[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bound = NP == 2 && p.out_bound != nullptr;
+    float *su = reinterpret_cast<float *>(smem), *sv = su + OT;
+    unsigned *cm = reinterpret_cast<unsigned *>(sv + OT);
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + ncol_wave + t * 32 + j;
+            if (n < N) oscale[t] = ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(n, dirr)]) + p.w_exp));
+        }
+        if (want_bound) {                                        // (the LDS tiles are dead: the loop ended with a barrier)
+            for (int i = tid; i < OT; i += NT) {
+                const int m = mt * OT + i;
+                su[i] = m < M ? p.nb_u[m % p.O] : 0.f; sv[i] = m < M ? p.nb_v[m % p.O] : 0.f;
+            }
+            for (int i = tid; i < NCOL; i += NT) cm[i] = 0u;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = mt * OT + row;
+            if (m >= M) continue;
+            float ur = 0.f, vr = 0.f;
+            if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = n0 + ncol_wave + t * 32 + j;
+                if (n >= N) continue;
+                float o = acc[ot][t][r];
+                if constexpr (NP == 2) o *= oscale[t];
+                if (Add) o += Add[(size_t)m * N + n];
+                Out[(size_t)m * N + n] = o;
+                if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr)); }
+            }
+        }
+    if constexpr (NP == 2) {
+        if (want_bound) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bm = fmaxf(bmax[t], __shfl_xor(bmax[t], 32));
+                if (h == 0) atomicMax(cm + ncol_wave + t * 32 + j, __float_as_uint(bm));      // non-negative floats order like their bit patterns
+            }
+            __syncthreads();
+            for (int i = tid; i < NCOL; i += NT) {
+                const int n = n0 + i;
+                if (n < N) atomicMax(reinterpret_cast<unsigned *>(p.out_bound) + column_keypoint(n, dirr), cm[i]);
+            }
+        }
+    }
+}
+
 // Data flow of one K16 step: the packed weight fragments of the NEXT step (3 planes x 2 k-octets x 128 rows = 12 KiB) go
 // global -> LDS with LDS-DMA (no VGPR staging); every thread owns an 8(k) x 2(n) patch of the f32 activations, loaded two steps
 // ahead into registers, split ONCE (v_cvt_pk_bf16_f32) and written as three 16-byte k-octets into LDS in B-fragment order, so the
@@ -229,13 +300,12 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     if (irr < 0) return;
     const float *__restrict__ X = p.X[irr];
     const frag *__restrict__ W = reinterpret_cast<const frag *>(p.W[irr]);
-    const int K = p.K[irr], M = p.M[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const int K = p.K[irr], Mpad = p.Mpad[irr], N = p.N[irr];
     const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
     const int wo = w % WO, wb = w / WO;
     const int n0 = nt * NCOL;
     const int ncol_wave = wb * 128;
 
-    const int dirr = kIrrDim[irr];
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -361,65 +431,139 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
         step(ks, 0, xr0, xr1);
         step(ks + 1, 1, xr1, xr0);
     }
-    float *__restrict__ Out = p.Out[irr];
-    const float *__restrict__ Add = p.Add[irr];
-    // NP = 2: every column carries its keypoint's own power-of-two scale (undone here together with the weights' 2^w_exp), and the
-    // epilogue can emit the bound the NEXT transform needs to split its output: max over this tile's rows of u_o |T| + v_o per column,
-    // merged per keypoint with an atomic max (order-independent, hence deterministic).
-    float oscale[4] = {1.f, 1.f, 1.f, 1.f};
-    float bmax[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_bound = NP == 2 && p.out_bound != nullptr;
-    float *su = reinterpret_cast<float *>(smem), *sv = su + OT;
-    unsigned *cm = reinterpret_cast<unsigned *>(sv + OT);
-    if constexpr (NP == 2) {
+    gemm_split_epilogue<NP, WO>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp16 x 2 GEMM, 256 x 256 tile, 8 waves, "ping-pong" schedule.  The two waves that share a SIMD (w and w + 4: the two column halves of
+// the tile) alternate roles inside every K16 step instead of both interleaving matrix and memory work: after the step's barrier group 0
+// issues its 24 MFMAs back to back from fragment REGISTERS while group 1 does its LDS/VMEM work (fragment reads, staging of a later
+// step), then group 1's MFMAs run while group 0 reads its next fragments and stages -- the matrix pipe of the SIMD sees one unbroken
+// MFMA stream, and no MFMA ever waits on an LDS read issued after a barrier.  That needs the operands one step deeper in flight: a ring
+// of THREE LDS stages (stage k+2 is written during step k, complete at barrier k+1, read into registers during step k+1 (group 0) or at the
+// top of step k+2 (group 1)), 96 KB, one workgroup per CU.  Same MFMA sequence per accumulator as irrep_gemm_split_kernel<.., 2, 4>: results
+// are bitwise identical.
+template <int BIG>
+__global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCOL = 256, OT = 256;
+    constexpr int XBUF = 2 * 2 * NCOL, ABUF = 2 * 2 * OT, STAGE = XBUF + ABUF;       // 16-byte fragments per stage (32 KB)
+    f16x8 *ring = reinterpret_cast<f16x8 *>(smem);                                   // [3][X planes | W planes]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
+    if (irr < 0) return;
+    const float *__restrict__ X = p.X[irr];
+    const f16x8 *__restrict__ W = reinterpret_cast<const f16x8 *>(p.W[irr]);
+    const int K = p.K[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;
+    const int wo = w & 3;
+    const int grp = __builtin_amdgcn_readfirstlane(w >> 2);                          // wave-uniform role: 0 computes first, 1 loads first
+    const int n0 = nt * NCOL, ncol_wave = grp * 128;
+    const int nsteps = K / 16;
+
+    f32x16 acc[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = n0 + ncol_wave + t * 32 + j;
-            if (n < N) oscale[t] = ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(n, dirr)]) + p.w_exp));
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    // staging patch of this thread: column n0 + pp (clamped), k-octet po of a step: 8 words fp16 hi | lo << 16
+    const int pp = tid & 255, po = tid >> 8;
+    int ncol = n0 + pp;
+    if (ncol > N - 1) ncol = N - 1;
+    const float *xcol = X + ncol + (size_t)(8 * po) * N;
+    auto load_x = [&](int kstep, float (&xr)[8]) {
+        const float *q = xcol + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 16 * N;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[e] = q[(size_t)e * N];
+    };
+    const int slot = po * NCOL + (pp ^ ((pp >> 3) & 1));
+    auto store_x = [&](int stage, const float (&xr)[8]) {
+        u32x4 H, L;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned a = __float_as_uint(xr[2 * i]), b = __float_as_uint(xr[2 * i + 1]);
+            H[i] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+            L[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);
         }
-        if (want_bound) {                                        // (the LDS tiles are dead: the loop ended with a barrier)
-            for (int i = tid; i < OT; i += NT) {
-                const int m = mt * OT + i;
-                su[i] = m < M ? p.nb_u[m % p.O] : 0.f; sv[i] = m < M ? p.nb_v[m % p.O] : 0.f;
-            }
-            for (int i = tid; i < NCOL; i += NT) cm[i] = 0u;
-            __syncthreads();
+        f16x8 *dst = ring + stage * STAGE;
+        dst[slot] = __builtin_bit_cast(f16x8, H); dst[2 * NCOL + slot] = __builtin_bit_cast(f16x8, L);
+    };
+    const f16x8 *wsrc = W + (size_t)(tid >> 8) * Mpad + mt * OT + (tid & 255);
+    auto issue_a = [&](int kstep, int stage) {
+        const f16x8 *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * split_stride),
+                                             (__attribute__((address_space(3))) void *)(ring + stage * STAGE + XBUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+    };
+    int xslot[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int n = ncol_wave + t * 32 + j; xslot[t] = h * NCOL + (n ^ ((n >> 3) & 1)); }
+    const int aslot = XBUF + h * OT + wo * 64 + j;
+
+    f16x8 fa[2][2], fb[4][2];                                   // this wave's fragments of one step: [row block][plane], [column block][plane]
+    auto read_frags = [&](int stage) {
+        const f16x8 *st = ring + stage * STAGE;
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) fa[ot][sp] = st[aslot + sp * (2 * OT) + ot * 32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fb[t][0] = st[xslot[t]]; fb[t][1] = st[2 * NCOL + xslot[t]]; }
+    };
+    auto mfma_phase = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        // lo.hi, hi.lo, hi.hi -- the same three-term sequence per accumulator as the interleaved kernel, products outermost (8 MFMAs between
+        // two uses of one accumulator)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][1], fb[t][0], acc[ot][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][0], fb[t][1], acc[ot][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][0], fb[t][0], acc[ot][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float xr_cur[8], xr_next[8];
+    load_x(0, xr_cur); load_x(1, xr_next);
+    issue_a(0, 0); issue_a(1, 1);
+    store_x(0, xr_cur); store_x(1, xr_next);
+    load_x(2, xr_cur);                                          // staged during step 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp == 0) read_frags(0);
+    int sk = 0;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+        const int s1 = sk == 2 ? 0 : sk + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        load_x(k + 3, xr_next);                                 // stored into LDS during the next step
+        issue_a(k + 2, s2);                                     // lands under this step's MFMAs
+        if (grp != 0) {                                         // group 1: memory work first, under group 0's MFMAs
+            read_frags(sk);
+            store_x(s2, xr_cur);
         }
+        mfma_phase();                                           // (group 0: the fragments of step k are already in registers)
+        if (grp == 0) {                                         // group 0: memory work second, under group 1's MFMAs
+            read_frags(s1);                                     // step k + 1 (stage complete since the barrier that opened this step)
+            store_x(s2, xr_cur);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the weight DMA of stage s2 (and the patch loads) have landed
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr_cur[e] = xr_next[e];
+        sk = s1;
     }
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = mt * OT + row;
-            if (m >= M) continue;
-            float ur = 0.f, vr = 0.f;
-            if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int n = n0 + ncol_wave + t * 32 + j;
-                if (n >= N) continue;
-                float o = acc[ot][t][r];
-                if constexpr (NP == 2) o *= oscale[t];
-                if (Add) o += Add[(size_t)m * N + n];
-                Out[(size_t)m * N + n] = o;
-                if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr)); }
-            }
-        }
-    if constexpr (NP == 2) {
-        if (want_bound) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float bm = fmaxf(bmax[t], __shfl_xor(bmax[t], 32));
-                if (h == 0) atomicMax(cm + ncol_wave + t * 32 + j, __float_as_uint(bm));      // non-negative floats order like their bit patterns
-            }
-            __syncthreads();
-            for (int i = tid; i < NCOL; i += NT) {
-                const int n = n0 + i;
-                if (n < N) atomicMax(reinterpret_cast<unsigned *>(p.out_bound) + column_keypoint(n, dirr), cm[i]);
-            }
-        }
-    }
+    gemm_split_epilogue<2, 4>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -998,6 +1142,21 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
     p.xbound = xbound; p.w_exp = w_exp; p.nb_u = nb_u; p.nb_v = nb_v; p.out_bound = out_bound; p.O = O;
     constexpr int CT = 32;
     const size_t lds = 2 * (NP * 2 * 256 + NP * (WO * 64) * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
+    if constexpr (NP == 2 && WO == 4) {
+        // opt-in (ROREG_GEMM_PP=1): measured 13.2 vs 12.2 ms per launch against the interleaved kernel on the same box (round 2) -- the
+        // unbroken MFMA stream does not pay because the kernel is limited by the power the chip may draw, not by matrix-pipe issue slots
+        static const bool pingpong = [] { const char *e = getenv("ROREG_GEMM_PP"); return e && e[0] == '1'; }();
+        if (pingpong) {
+            const size_t lds_pp = 3 * (2 * 2 * 256 + 2 * 2 * 256) * 16;      // three stages of (activation planes + weight fragments)
+            auto kpp = (long long)C * O == 256ll * 512 ? irrep_gemm_pp_kernel<1> : irrep_gemm_pp_kernel<0>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kpp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp);
+            if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
+            hipLaunchKernelGGL(kpp, dim3(n_tiles), dim3(512), lds_pp, roreg::as_stream(stream), p, tiles_dev);
+            hipError_t e2 = hipGetLastError();
+            if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
+            return 0;
+        }
+    }
     auto kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
