@@ -70,12 +70,13 @@ def build_workload(args, rank, world):
         return {'chunk': (feats, keys, poses, pairs)}, [('chunk', 0, len(pairs))], {'pairs': 60 * world, 'clouds': 16 * world, 'scaling': 'weak'}
     names = synth.THREEDMATCH_SCENES if args.workload == '3dmatch-full' else synth.THREEDMATCH_SCENES[:1]
     clouds = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_PAIRS))
-    plan = shard_scenes({s: npairs[s] for s in names}, world, {s: clouds[s] for s in names})
+    lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + synth.THREEDMATCH_SCENES.index(s)) for s in names}
+    plan = shard_scenes({s: npairs[s] for s in names}, world, {s: clouds[s] for s in names}, pair_lists=lists)
     scenes = {}
     for s in sorted({p[0] for p in plan[rank]}):
         i = synth.THREEDMATCH_SCENES.index(s)
         feats, keys, poses = synth.make_scene_device(500 + i, clouds[s], args.kpts, OVERLAP)
-        scenes[s] = (feats, keys, poses, [(str(a), str(b)) for a, b in synth.scene_pair_list(clouds[s], npairs[s], 900 + i)])
+        scenes[s] = (feats, keys, poses, [(str(a), str(b)) for a, b in lists[s]])
     return scenes, plan[rank], {'pairs': sum(npairs[s] for s in names), 'clouds': sum(clouds[s] for s in names), 'scaling': 'strong',
                                 'plan': [[list(p) for p in r] for r in plan]}
 

@@ -49,7 +49,7 @@ def evaluate(cfg, datasets, engine, rank=0, world=1, seed=None):
     scenes = [s for s in datasets if s not in ('wholesetname', 'valscenes')]
     pair_counts = {s: len(datasets[s].pair_ids) for s in scenes}
     cloud_counts = {s: len(datasets[s].pc_ids) for s in scenes}
-    plan = D.shard_scenes(pair_counts, world, cloud_counts)
+    plan = D.shard_scenes(pair_counts, world, cloud_counts, pair_lists={s: datasets[s].pair_ids for s in scenes})
     rows = []
     for scene, a, b in plan[rank]:
         ds = datasets[scene]

@@ -60,7 +60,8 @@ def main():
         engine = RegistrationEngine(cfg, gf, et)
     else:
         engine = StubEngine()
-    plan = D.shard_scenes({s: len(datasets[s].pair_ids) for s in ('scene0', 'scene1')}, world, {s: len(datasets[s].pc_ids) for s in ('scene0', 'scene1')})
+    plan = D.shard_scenes({s: len(datasets[s].pair_ids) for s in ('scene0', 'scene1')}, world, {s: len(datasets[s].pc_ids) for s in ('scene0', 'scene1')},
+                          pair_lists={s: datasets[s].pair_ids for s in ('scene0', 'scene1')})
     res = RD.evaluate(cfg, datasets, engine, rank=rank, world=world, seed=2024)
     if rank == 0:
         out = {'split': np.int64(sum(1 for r in plan for p in r if p[0] == 'scene0') > 1)}

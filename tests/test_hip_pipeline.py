@@ -368,6 +368,42 @@ def test_evaluate_world_1_equals_world_2_on_device(tmp_path):
             assert np.array_equal(one[k], two[k]), k
 
 
+def test_config3_full_benchmark_shape_through_the_distributed_driver(tmp_path):
+    """BASELINE config 3's shape on one GPU: 8 scenes with the 3DMatch station counts [60,60,60,55,57,37,66,38] (dataops/dataset.py:152) =
+    433 clouds and 1623 pairs through run_distributed.evaluate (shard plan, engine, result table, metrics), at 256 keypoints per cloud so
+    that the feature files stay small.  Every pair comes back once, registers, and the plan for 8 ranks is balanced on this very shape."""
+    from roreg_amd import run_distributed as RD_, distributed as D
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    root = str(tmp_path)
+    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=256, ET='yohoo',
+                         testset='synth', max_iter=1000)
+    datasets = {'wholesetname': 'synth'}
+    for i, (name, nc, npairs) in enumerate(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_CLOUDS, synth.THREEDMATCH_PAIRS)):
+        ds = synth.make_scene(300 + i, n_clouds=nc, n_kpts=256, overlap=0.6, name=f'synth/{name}', pair_ids=synth.scene_pair_list(nc, npairs, 900 + i))
+        ds.write_inputs(cfg.output_cache_fn)
+        ds.gt_dir = f'{root}/nonexistent/{ds.name}/gt.log'
+        datasets[name] = ds
+    assert sum(len(datasets[s].pair_ids) for s in synth.THREEDMATCH_SCENES) == 1623 and sum(len(datasets[s].pc_ids) for s in synth.THREEDMATCH_SCENES) == 433
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    out = RD_.evaluate(cfg, datasets, RegistrationEngine(cfg, gf, et), rank=0, world=1, seed=3)
+    assert out['pairs'] == 1623
+    assert out['rr'] > 0.9 and out['fmr'] > 0.95                        # synthetic scenes with 60 % overlap register
+    n_files = sum(len([f for f in os.listdir(f'{cfg.output_cache_fn}/{datasets[s].name}/match_256/yohoo/1000iters') if f.endswith('.npz')])
+                  for s in synth.THREEDMATCH_SCENES)
+    assert n_files == 1623
+    # the 8-GPU shard plan of this shape: every pair exactly once, loads within 25 % of the mean (pair + cloud-extraction cost units)
+    pc = {s: len(datasets[s].pair_ids) for s in synth.THREEDMATCH_SCENES}; cc = {s: len(datasets[s].pc_ids) for s in synth.THREEDMATCH_SCENES}
+    plan = D.shard_scenes(pc, 8, cc, pair_lists={s: datasets[s].pair_ids for s in pc})
+    seen = sorted((s, a, b) for r in plan for s, a, b in r)
+    for s in pc:
+        rs = [(a, b) for t, a, b in seen if t == s]
+        assert rs[0][0] == 0 and rs[-1][1] == pc[s] and all(rs[i][1] == rs[i + 1][0] for i in range(len(rs) - 1))
+    loads = [sum((b - a) + 6.0 * len({i for pr in datasets[s].pair_ids[a:b] for i in pr}) for s, a, b in r) for r in plan]
+    assert max(loads) < 1.3 * np.mean(loads), loads             # extraction is replicated when a scene is cut: ~80 % efficiency at 8 ranks
+
+
 def test_dropin_end_to_end_on_a_demo_layout(tmp_path, monkeypatch):
     """The reference's entry point flow (parse flags -> yoho_evaluator(cfg).run()) through the drop-in aliases, on a dataset laid out
     like data/origin_data/demo/kitchen (binary PLY clouds, keypoint index files, gt.log) with checkpoints under --model_fn."""
