@@ -281,7 +281,7 @@ def test_et_is_batch_invariant(group):
     synth.seeded_state_dict(net, int(z['seed']))
     keys = ('before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx')
     rng = np.random.default_rng(6)
-    for mode in ('f16x2', 'bf16x3'):
+    for mode in ('f16x2', 'bf16x3', 'f32'):
         net.gemm = mode
         full = net({k: torch.from_numpy(z[k].copy()) for k in keys})['quaternion_pre']
         sub = slice(7, 23)

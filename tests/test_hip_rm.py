@@ -150,9 +150,12 @@ def test_match_ot_forward_vs_reference_golden(rm):
     batch = {k: torch.from_numpy(z[k]) for k in ['feats0', 'feats1', 'keys0', 'keys1']}
     with torch.no_grad():
         out = net(batch)
-    assert np.abs(out['source_final'].cpu().numpy() - z['out_source_final']).max() < 5e-4
-    assert np.abs(out['target_final'].cpu().numpy() - z['out_target_final']).max() < 5e-4
-    assert np.abs(out['scores'].cpu().numpy() - z['out_scores']).max() < 2e-3
+    # 1e-4 on every floating-point output (measured: 2.5e-6 on the final descriptors, 1.5e-5 on the log-couplings of
+    # magnitude up to 17, 2e-7 on the matching scores; the reference's own float32-vs-float64 noise on this case is 2e-6 / 1e-5 / 1e-7,
+    # tests/golden/match_ot_noise.json)
+    assert np.abs(out['source_final'].cpu().numpy() - z['out_source_final']).max() < 1e-4
+    assert np.abs(out['target_final'].cpu().numpy() - z['out_target_final']).max() < 1e-4
+    assert np.abs(out['scores'].cpu().numpy() - z['out_scores']).max() < 1e-4
     assert np.array_equal(out['matches0'].cpu().numpy(), z['out_matches0'])
     assert np.array_equal(out['matches1'].cpu().numpy(), z['out_matches1'])
     assert np.abs(out['matching_scores0'].cpu().numpy() - z['out_matching_scores0']).max() < 1e-4
