@@ -167,7 +167,12 @@ int roreg_group_corr(const float *perm_feats, const int64_t *perm_rows, const fl
  * roreg_set_des2r_tables uploads the index / representation tables (roreg_amd/fourier.py derives them from the multiplication table and
  * checks the identity to 1e-12): ia, ib uint8 [60][5] (coefficient indices of the k-th product term of entry q = (rho,i,j)), cnt uint8 [60]
  * (terms = d), NT float32 [60 (q)][60 (a)] = rho(a)[j][i].  roreg_des2r_recheck_count: how many correspondences took the exact path. */
-int roreg_set_des2r_tables(const uint8_t *ia_host, const uint8_t *ib_host, const uint8_t *cnt_host, const float *NT_host);
+int roreg_set_des2r_tables(int transpose_table /* 0: x[P[a,.]] (Des2R); 1: x[P[.,a]] (R_indicator) */, const uint8_t *ia_host,
+                           const uint8_t *ib_host, const uint8_t *cnt_host, const float *NT_host);
+/* All 60 correlations of roreg_group_corr from the coefficient rows alone (no arg-max, no re-check): cor_out [M,60] f32, equal to the
+ * literal float32 evaluation to its rounding level (~1e-6 |d1||d2|).  For the matcher's R_indicator feature (network/rot_coh_match.py:154-163). */
+int roreg_group_corr_irrep(const float *perm_coefs, const int64_t *perm_rows, const float *bcast_coefs, const int64_t *bcast_rows, int M,
+                           int transpose_table, float *cor_out, void *stream);
 int roreg_des2r_irrep(const float *coef1, const int64_t *rows1, const float *coef0, const int64_t *rows0, const void *feats1,
                       const void *feats0, int feat_bf16, int M, int64_t *idx_out, void *stream);
 int roreg_des2r_recheck_count(int reset, int32_t *count_out);

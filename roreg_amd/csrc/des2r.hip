@@ -118,7 +118,8 @@ struct Des2rTabs {
     const uint8_t *cnt;         // [60]
     const float *NT;            // [60 q][60 a] = rho(a)[j][i]
 };
-Des2rTabs g_tabs = {nullptr, nullptr, nullptr, nullptr};
+Des2rTabs g_tabs = {nullptr, nullptr, nullptr, nullptr};        // x -> x[P[a,.]]  (Des2R)
+Des2rTabs g_tabs_t = {nullptr, nullptr, nullptr, nullptr};      // x -> x[P[.,a]]  (the matcher's R_indicator)
 int32_t *g_recheck = nullptr;                                 // device counter of correspondences that took the exact path (diagnostics)
 
 constexpr int DES2R_ITER = 4;
@@ -130,9 +131,11 @@ template <typename FT> __device__ __forceinline__ float feat_ld(const FT *p, siz
 
 struct Des2rRows { const float *c1, *c0; size_t r1, r0; bool live; };
 
-template <typename FT, typename RowFn>
+// COR_ONLY: write the 60 (approximate) correlations instead of the exact arg-max (no candidate stage): the matcher's R_indicator feature.
+template <typename FT, bool COR_ONLY, typename RowFn>
 __device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, const void *feats1_v, const void *feats0_v, Des2rTabs tabs,
-                                                 const uint8_t *__restrict__ P8, int64_t *__restrict__ idx_out, size_t out_base, int32_t *recheck) {
+                                                 const uint8_t *__restrict__ P8, int64_t *__restrict__ idx_out, size_t out_base, int32_t *recheck,
+                                                 float *__restrict__ cor_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *NTs = lds;                                         // [60][60]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -198,6 +201,10 @@ __device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, cons
             const float cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), qq));
             cor = fmaf(NTs[qq * ROREG_G + q], cq, cor);
         }
+        if constexpr (COR_ONLY) {
+            if (me.live && act) cor_out[(out_base + (size_t)it * 8 + w) * ROREG_G + lane] = cor;
+            continue;
+        }
         float bv = act ? cor : -__builtin_inff();
         if (bv != bv) bv = -__builtin_inff();
         int bi = act ? lane : 0x7fffffff;
@@ -262,7 +269,24 @@ __global__ __launch_bounds__(512) void des2r_irrep_kernel(const float *__restric
         r.r1 = rows1 ? (size_t)rows1[bb] : (size_t)bb; r.r0 = rows0 ? (size_t)rows0[bb] : (size_t)bb;
         return r;
     };
-    des2r_irrep_loop<FT>(rows_of, n_iter, feats1, feats0, tabs, P8, idx_out, (size_t)base, recheck);
+    des2r_irrep_loop<FT, false>(rows_of, n_iter, feats1, feats0, tabs, P8, idx_out, (size_t)base, recheck);
+}
+
+__global__ __launch_bounds__(512) void group_corr_irrep_kernel(const float *__restrict__ coef1, const int64_t *__restrict__ rows1,
+                                                               const float *__restrict__ coef0, const int64_t *__restrict__ rows0, Des2rTabs tabs,
+                                                               int M, float *__restrict__ cor_out) {
+    const int base = blockIdx.x * (8 * DES2R_ITER);
+    const int n_iter = min(DES2R_ITER, (M - base + 7) / 8);
+    auto rows_of = [&](int it, int w) {
+        const int b = base + it * 8 + w;
+        Des2rRows r;
+        r.live = b < M;
+        const int bb = r.live ? b : M - 1;
+        r.c1 = coef1; r.c0 = coef0;
+        r.r1 = rows1 ? (size_t)rows1[bb] : (size_t)bb; r.r0 = rows0 ? (size_t)rows0[bb] : (size_t)bb;
+        return r;
+    };
+    des2r_irrep_loop<float, true>(rows_of, n_iter, nullptr, nullptr, tabs, nullptr, nullptr, (size_t)base, nullptr, cor_out);
 }
 
 // all pairs of a scene in one launch: blockIdx.y = pair, cloud 1 is the permuted side (test/estimator.py:108-110)
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(512) void des2r_irrep_batch_kernel(const roreg::LtT
         roreg::lt_rows(t, r.live ? i : t.n - 1, r.r0, r.r1);
         return r;
     };
-    des2r_irrep_loop<FT>(rows_of, n_iter, t.after1, t.after0, tabs, P8, dr_all, (size_t)(t.off + base), recheck);
+    des2r_irrep_loop<FT, false>(rows_of, n_iter, t.after1, t.after0, tabs, P8, dr_all, (size_t)(t.off + base), recheck);
 }
 
 }  // namespace
@@ -307,28 +331,47 @@ void roreg::launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int6
 
 bool roreg::des2r_tables_ready() { return g_tabs.NT != nullptr; }
 
-extern "C" int roreg_set_des2r_tables(const uint8_t *ia_host, const uint8_t *ib_host, const uint8_t *cnt_host, const float *NT_host) {
-    ROREG_REQUIRE(ia_host && ib_host && cnt_host && NT_host, "roreg_set_des2r_tables: null table");
+extern "C" int roreg_set_des2r_tables(int transpose_table, const uint8_t *ia_host, const uint8_t *ib_host, const uint8_t *cnt_host, const float *NT_host) {
+    ROREG_REQUIRE(ia_host && ib_host && cnt_host && NT_host && (transpose_table == 0 || transpose_table == 1), "roreg_set_des2r_tables: bad arguments");
     for (int q = 0; q < ROREG_G; ++q) {
         ROREG_REQUIRE(cnt_host[q] >= 1 && cnt_host[q] <= 5, "roreg_set_des2r_tables: bad count");
         for (int k = 0; k < 5; ++k) ROREG_REQUIRE(ia_host[q * 5 + k] < ROREG_G && ib_host[q * 5 + k] < ROREG_G, "roreg_set_des2r_tables: index out of range");
     }
-    if (!g_tabs.NT) {
+    Des2rTabs &t = transpose_table ? g_tabs_t : g_tabs;
+    if (!t.NT) {
         uint8_t *b = nullptr; float *f = nullptr;
-        if (hipMalloc(&b, 1024) != hipSuccess || hipMalloc(&f, 3600 * sizeof(float)) != hipSuccess || hipMalloc(&g_recheck, 64) != hipSuccess) {
+        if (hipMalloc(&b, 1024) != hipSuccess || hipMalloc(&f, 3600 * sizeof(float)) != hipSuccess) {
             roreg::set_error("roreg_set_des2r_tables: hipMalloc failed");
             return 1;
         }
-        g_tabs.ia = b; g_tabs.ib = b + 320; g_tabs.cnt = b + 640; g_tabs.NT = f;
+        t.ia = b; t.ib = b + 320; t.cnt = b + 640; t.NT = f;
+    }
+    if (!g_recheck) {
+        if (hipMalloc(&g_recheck, 64) != hipSuccess) { roreg::set_error("roreg_set_des2r_tables: hipMalloc failed"); return 1; }
         (void)hipMemset(g_recheck, 0, 64);
     }
-    if (hipMemcpy(const_cast<uint8_t *>(g_tabs.ia), ia_host, 300, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(const_cast<uint8_t *>(g_tabs.ib), ib_host, 300, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(const_cast<uint8_t *>(g_tabs.cnt), cnt_host, 60, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(const_cast<float *>(g_tabs.NT), NT_host, 3600 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpy(const_cast<uint8_t *>(t.ia), ia_host, 300, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(const_cast<uint8_t *>(t.ib), ib_host, 300, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(const_cast<uint8_t *>(t.cnt), cnt_host, 60, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(const_cast<float *>(t.NT), NT_host, 3600 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         roreg::set_error("roreg_set_des2r_tables: hipMemcpy failed");
         return 1;
     }
+    return 0;
+}
+
+extern "C" int roreg_group_corr_irrep(const float *perm_coefs, const int64_t *perm_rows, const float *bcast_coefs, const int64_t *bcast_rows, int M,
+                                      int transpose_table, float *cor_out, void *stream) {
+    if (M == 0) return 0;
+    ROREG_REQUIRE(perm_coefs && bcast_coefs && cor_out && M > 0, "roreg_group_corr_irrep: bad arguments");
+    const Des2rTabs &t = transpose_table ? g_tabs_t : g_tabs;
+    ROREG_REQUIRE(t.NT, "roreg_group_corr_irrep: roreg_set_des2r_tables has not been called for this table");
+    const size_t lds = (ROREG_G * ROREG_G + 8 * 2 * DES2R_LROW) * sizeof(float);
+    auto kern = group_corr_irrep_kernel;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((M + 8 * DES2R_ITER - 1) / (8 * DES2R_ITER)), dim3(512), lds, roreg::as_stream(stream), perm_coefs, perm_rows,
+                       bcast_coefs, bcast_rows, t, M, cor_out);
+    ROREG_CHECK_LAUNCH("roreg_group_corr_irrep");
     return 0;
 }
 

@@ -122,6 +122,8 @@ class RegistrationEngine:
         hip.ensure_tables()
         self.rm_max_points = 80000  # points per side stacked into one pass of the rotation-coherence matcher (32 pairs at keynum 2500)
         self.feat_dtype = torch.bfloat16 if getattr(cfg, 'dtype', 'fp32') == 'bf16' else torch.float32
+        import os
+        self.extract_rows = int(os.environ.get('ROREG_EXTRACT_ROWS', 65536))    # keypoints per extractor launch (activations: ~370 KB per keypoint at peak)
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
 
     def _mark(self, name, t0):
@@ -172,9 +174,10 @@ class RegistrationEngine:
         k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
         return CloudState(before=x, eqv=eqv, eqv_ft=hip.feat_coefs(eqv), inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
 
-    def extract_many(self, feats_list, keys_list, max_rows=65536):
+    def extract_many(self, feats_list, keys_list, max_rows=None):
         """Several clouds per group-conv launch: a 5000-keypoint cloud is 9.2 waves of workgroups on the 512 resident slots,
         so a lone cloud wastes ~8 % in the partial last wave; batching clouds makes that tail negligible."""
+        max_rows = self.extract_rows if max_rows is None else max_rows
         xs = [(f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32).to(self.feat_dtype)
               for f in feats_list]
         out = []

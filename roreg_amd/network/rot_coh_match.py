@@ -83,17 +83,22 @@ class Cross_attention_block(nn.Module):
         self.cross_attn = MultiHeadedAttention(4, 32)
         self.merge = mlp_2layer(32 * 3, 64, 32)
 
-    def forward(self, source, target, source_eqv, target_eqv, featinv, seg_s=None, seg_t=None):
+    def forward(self, source, target, source_eqv, target_eqv, featinv, seg_s=None, seg_t=None, coefs=None):
         """source [m,32], target [n,32], *_eqv [.,32,60], featinv [m,32] -> (feat [m,32], R_indicator [m,60]).
-        seg_s / seg_t: hip.Segments of the source / target rows when several pairs are stacked."""
+        seg_s / seg_t: hip.Segments of the source / target rows when several pairs are stacked.
+        coefs: {id(eqv tensor): hip.feat_coefs(eqv)} -- R_indicator is then evaluated in the irrep domain (244 instead of 3600
+        multiply-adds per channel; it is a feature of the attention blocks, equal to the literal evaluation at float32 rounding level)."""
         knn = hip.topk_dot(source, target, self.k, segA=seg_s, segB=seg_t)  # k best targets (of its own pair) per source point
         nn_ind = knn[:, 0].contiguous()
         att = self.cross_attn(source, target, target, knn, self.k, True, True)
         feat = self.merge(hip.concat_rows(featinv, source, att), seg=seg_s)
+        cs = ct = None
+        if coefs is not None:
+            cs, ct = coefs[id(source_eqv)], coefs[id(target_eqv)]
         if self.s2t:    # R[h] = sum_f sum_g src[f,P[g,h]] * tgt_nn[f,g]
-            R = hip.group_corr(source_eqv, target_eqv, perm_rows=None, bcast_rows=nn_ind, transpose=True)
+            R = hip.group_corr(source_eqv, target_eqv, perm_rows=None, bcast_rows=nn_ind, transpose=True, perm_coefs=cs, bcast_coefs=ct)
         else:           # R[h] = sum_f sum_g tgt_nn[f,P[g,h]] * src[f,g]
-            R = hip.group_corr(target_eqv, source_eqv, perm_rows=nn_ind, bcast_rows=None, transpose=True)
+            R = hip.group_corr(target_eqv, source_eqv, perm_rows=nn_ind, bcast_rows=None, transpose=True, perm_coefs=ct, bcast_coefs=cs)
         return feat, R
 
 
@@ -129,10 +134,10 @@ class Merge_info_block(nn.Module):
         self.cross_graph_t2s = Cross_attention_block(cross_k, s2t=False)
         self.self_graph_t = Self_attention_block(self_k, source=False)
 
-    def forward(self, source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s=None, seg_t=None):
-        source_s2t, R_ind_s2t = self.cross_graph_s2t(source, target, source_eqv, target_eqv, source_inv, seg_s, seg_t)
+    def forward(self, source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s=None, seg_t=None, coefs=None):
+        source_s2t, R_ind_s2t = self.cross_graph_s2t(source, target, source_eqv, target_eqv, source_inv, seg_s, seg_t, coefs)
         eh_source = self.self_graph_s(source_s2t, source_coor, R_ind_s2t, source_inv, seg_s)
-        target_t2s, R_ind_t2s = self.cross_graph_t2s(target, source, target_eqv, source_eqv, target_inv, seg_t, seg_s)
+        target_t2s, R_ind_t2s = self.cross_graph_t2s(target, source, target_eqv, source_eqv, target_inv, seg_t, seg_s, coefs)
         eh_target = self.self_graph_t(target_t2s, target_coor, R_ind_t2s, target_inv, seg_t)
         return eh_source, eh_target
 
@@ -141,12 +146,18 @@ class Graph_enhance_net(nn.Module):
     def __init__(self):
         super().__init__()
         self.merge_blocks = nn.ModuleList([Merge_info_block(16, 16), Merge_info_block(8, 8)])
+        # 'irrep': R_indicator from the group-Fourier coefficients of the two feature sets (computed once per forward, used by all four
+        # cross blocks); 'literal': the reference's operation order (network/rot_coh_match.py:154-163)
+        object.__setattr__(self, 'r_indicator', 'irrep')
 
     def forward(self, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s=None, seg_t=None):
         sources, targets = [], []
         source, target = source_inv, target_inv                             # mean over g (rot_coh_match.py:266-267)
+        coefs = None
+        if self.r_indicator == 'irrep':
+            coefs = {id(source_eqv): hip.feat_coefs(source_eqv), id(target_eqv): hip.feat_coefs(target_eqv)}
         for layer in self.merge_blocks:
-            source, target = layer(source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t)
+            source, target = layer(source, target, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t, coefs)
             sources.append(source); targets.append(target)
         return sources, targets
 

@@ -61,6 +61,25 @@ def test_group_corr_transposed_is_r_indicator(group):
         assert np.abs(got.cpu().numpy() - want).max() < 2e-4
 
 
+def test_group_corr_irrep_equals_literal_to_rounding(group):
+    """R_indicator in the irrep domain (both table orientations, with and without row lists) against the literal float32 kernel: equal to
+    the float32 rounding level of a 1920-term sum (the literal kernel itself is bit-exact against the oracle, test above)."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((400, 32, 60)).astype(np.float32); B = rng.standard_normal((350, 32, 60)).astype(np.float32)
+    Ad, Bd = cu(A), cu(B)
+    ca, cb = hip.feat_coefs(Ad), hip.feat_coefs(Bd)
+    rows = cu(rng.integers(0, 350, 400))
+    for tr in (True, False):
+        lit = hip.group_corr(Ad, Bd, perm_rows=None, bcast_rows=rows, transpose=tr)
+        irr = hip.group_corr(Ad, Bd, perm_rows=None, bcast_rows=rows, transpose=tr, perm_coefs=ca, bcast_coefs=cb)
+        scale = float(torch.linalg.vector_norm(Ad, dim=(1, 2)).max() * torch.linalg.vector_norm(Bd, dim=(1, 2)).max())
+        assert float((lit - irr).abs().max()) < 5e-6 * scale
+        lit = hip.group_corr(Bd, Ad, perm_rows=rows, bcast_rows=None, transpose=tr)
+        irr = hip.group_corr(Bd, Ad, perm_rows=rows, bcast_rows=None, transpose=tr, perm_coefs=cb, bcast_coefs=ca)
+        assert float((lit - irr).abs().max()) < 5e-6 * scale
+
+
 def test_mlp_instnorm_and_attention(rm):
     from roreg_amd import hip
     net, sd = rm
