@@ -146,9 +146,12 @@ class Graph_enhance_net(nn.Module):
     def __init__(self):
         super().__init__()
         self.merge_blocks = nn.ModuleList([Merge_info_block(16, 16), Merge_info_block(8, 8)])
-        # 'irrep': R_indicator from the group-Fourier coefficients of the two feature sets (computed once per forward, used by all four
-        # cross blocks); 'literal': the reference's operation order (network/rot_coh_match.py:154-163)
-        object.__setattr__(self, 'r_indicator', 'irrep')
+        # 'literal' (default): R_indicator in the reference's operation order (network/rot_coh_match.py:154-163), bit-exact against the oracle;
+        # 'irrep': from the group-Fourier coefficients of the two feature sets (10x fewer operations).  Measured at keynum 2500 against the
+        # reference: matches identical either way, but the rounding-level change of the feature moves a few neighbourhood selections of the
+        # second block, and the log-couplings then differ by up to 2.5e-4 instead of 2.3e-5 -- outside SURVEY 8c's 1e-4 -- for 0 % gain on
+        # the config (R_indicator is 6 % of it, the coefficient transforms cost about as much as they save): opt-in only.
+        object.__setattr__(self, 'r_indicator', 'literal')
 
     def forward(self, source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s=None, seg_t=None):
         sources, targets = [], []
