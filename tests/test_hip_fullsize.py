@@ -197,3 +197,45 @@ def test_full_pipeline_vs_reference(tmp_path, mode, monkeypatch):
         exact += int(int(r['recalltime']) == int(z[f'recall_{a}_{b}']) and d < 1e-8)
         assert d < 1e-4, (a, b, d)
     print(f'[{mode}] pairs with the reference\'s recalltime and transform (1e-8): {exact}/3')
+
+
+# ---- the rotation-bin estimator and the detector at full size ---------------------------------------------------------------------------
+def test_full_yohoc_on_the_neartie_pair(tmp_path):
+    """yohoc_ransac.ransac_once (test/estimator.py:173-241) on the 1252 matches / DR indices of the 5000-keypoint near-tie pair: the same
+    generator calls, the same hypotheses (3-point Kabsch through LAPACK), the same winning try and transform as the reference."""
+    from roreg_amd.test import name2estimator
+    z = load_golden('full_stages'); want = load_golden('full_yohoc')
+    root = str(tmp_path)
+    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=5000, ET='yohoc')
+    ds = synth.make_neartie_scene(int(z['scene_seed']), n_clouds=2, n_kpts=5000)
+    md = f'{cfg.output_cache_fn}/{ds.name}/match_5000'
+    for d in ('scores', 'DR_index', 'yohoc/1000iters'):
+        os.makedirs(f'{md}/{d}')
+    m = z['match'].astype(np.int64)
+    np.save(f'{md}/0-1.npy', m); np.save(f'{md}/scores/0-1.npy', np.ones(m.shape[0])); np.save(f'{md}/DR_index/0-1.npy', z['dr'].astype(np.int64))
+    est = name2estimator['yohoc'](cfg)
+    np.random.seed(4321)
+    est.ransacer.ransac_once(ds, 5000, 1000, ('0', '1'))
+    r = np.load(f'{md}/yohoc/1000iters/0-1.npz')
+    assert int(r['recalltime']) == int(want['recalltime'])
+    assert np.abs(r['trans'] - want['trans']).max() < 1e-8
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_full_detector_on_a_whole_cloud(mode):
+    """detector_eqv_test with the shipped weights on 5000 keypoints in one batch: raw saliency within 5e-5 of the reference's (the score is
+    the standard deviation ~3e-3 of 60 correlations ~60: float32 cancellation noise ~1e-5 is inherent), hence rank scores within a few
+    places of 5000."""
+    from roreg_amd.network import name2network
+    z = load_golden('full_rd')
+    net = name2network['RD_test'](default_config())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()}, strict=True)
+    ds = synth.make_scene(int(z['scene_seed']), n_clouds=1, n_kpts=5000, overlap=0.6, portable=True)
+    x = ds.feats[0] / np.sqrt((ds.feats[0] * ds.feats[0]).sum(1, keepdims=True))
+    net.encode(torch.from_numpy(x[:8].copy()))
+    net._fourier.gemm = mode
+    raw = net({'feats': torch.from_numpy(x.copy())})['scores'].cpu().numpy()
+    assert np.abs(raw - z['raw']).max() < 5e-5
+    rank = raw.copy(); rank[np.argsort(raw)] = np.arange(5000) / 5000
+    moved = np.abs(rank - z['rank']) * 5000
+    assert moved.max() <= 30 and moved.mean() < 3.0, (moved.max(), moved.mean())         # measured: at most 11 places of 5000, 69 % within 2

@@ -126,8 +126,45 @@ def gen_pipeline():
         shutil.rmtree(root, ignore_errors=True)
 
 
+def gen_yohoc():
+    """The rotation-bin estimator (test/estimator.py:173-241, run without its Pool like tools/gen_golden.py does) on the matches and
+    DR_index of the full-size near-tie pair (inputs = arrays of full_stages.npz + the seed-rebuilt keypoints)."""
+    z = np.load(os.path.join(gg.OUT, 'full_stages.npz'))
+    root = tempfile.mkdtemp(prefix='golden_full_')
+    try:
+        cfg = gg.make_cfg(root, keynum=5000, ET='yohoc')
+        ds = synth.make_neartie_scene(int(z['scene_seed']), n_clouds=2, n_kpts=5000)
+        md = f'{cfg.output_cache_fn}/{ds.name}/match_5000'
+        os.makedirs(f'{md}/scores'); os.makedirs(f'{md}/DR_index'); os.makedirs(f'{md}/yohoc/1000iters')
+        m = z['match'].astype(np.int64)
+        np.save(f'{md}/0-1.npy', m); np.save(f'{md}/scores/0-1.npy', np.ones(m.shape[0])); np.save(f'{md}/DR_index/0-1.npy', z['dr'].astype(np.int64))
+        est = name2estimator['yohoc'](cfg)
+        np.random.seed(4321)
+        est.ransacer.ransac_once(ds, 5000, 1000, ('0', '1'))
+        r = np.load(f'{md}/yohoc/1000iters/0-1.npz', allow_pickle=True)
+        print('   yohoc recalltime', int(r['recalltime']))
+        save('full_yohoc', trans=r['trans'], recalltime=np.int64(r['recalltime']))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def gen_rd():
+    """The detector with the shipped RD weights on a whole 5000-keypoint cloud (network/rot_detect.py:43-55, test/detector.py:45-46)."""
+    cfg = gg.make_cfg(tempfile.mkdtemp(prefix='golden_full_cfg_'))
+    net = name2network['RD_test'](cfg)
+    ck = torch.load(f'{REF}/checkpoints/FCGF/RD/model_best.pth')
+    net.load_state_dict(ck['network_state_dict'], strict=True); net.eval()
+    ds = synth.make_scene(PIPE_SEED + 1, n_clouds=1, n_kpts=5000, overlap=0.6, portable=True)
+    x = ds.feats[0] / np.sqrt((ds.feats[0] * ds.feats[0]).sum(1, keepdims=True))
+    with torch.no_grad():
+        raw = net({'feats': torch.from_numpy(x.copy())})['scores'].numpy()
+    rank = raw.copy(); rank[np.argsort(raw)] = np.arange(raw.shape[0]) / raw.shape[0]
+    save('full_rd', scene_seed=np.int64(PIPE_SEED + 1), raw=raw, rank=rank.astype(np.float32))
+    shutil.rmtree(cfg.base_dir, ignore_errors=True)
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['ransac', 'stages', 'match_ot', 'pipeline']
+    todo = sys.argv[1:] or ['ransac', 'stages', 'match_ot', 'pipeline', 'yohoc', 'rd']
     for name in todo:
         print(name)
-        {'stages': gen_stages, 'ransac': gen_ransac, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline}[name]()
+        {'stages': gen_stages, 'ransac': gen_ransac, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
