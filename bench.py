@@ -343,7 +343,7 @@ def main():
                 'hbm': {'algorithmic_GBps': rs_bytes / (rs_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': rs_bytes / (rs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                         'note': 'M*56 + H*96 B per pair: the correspondences are re-read by every hypothesis from L2, the stage is not HBM-bound'}},
             'roofline_des2r': None if not d2_n else {
-                'kernel': 'des2r_batch_kernel', 'bound': 'hbm', 'unit': 'GB/s', 'launches': d2_n, 'avg_ms': d2_ms / d2_n,
+                'kernel': 'des2r_irrep_batch_kernel (irrep-domain bound + exact re-check of near ties; M*15,360 algorithmic bytes)', 'bound': 'hbm', 'unit': 'GB/s', 'launches': d2_n, 'avg_ms': d2_ms / d2_n,
                 'achieved': d2_bytes / (d2_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': d2_bytes / (d2_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             'transforms': None if not ft_n else {'kernel': 'ft_nonlin_kernel (all variants)', 'launches': ft_n, 'ms_per_step': ft_ms / args.steps},
         }

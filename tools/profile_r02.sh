@@ -19,5 +19,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
 done
 python3 tools/pmc_summary.py $OUT/pmc_${WL}_$MODE.txt $OUT/pmc_${WL}_$MODE.json $WL:$MODE=$OUT/pmc_${WL}_$MODE | tail -5
 find $OUT -name '*agent_info.csv' -delete
-find $OUT -name '*counter_collection.csv' -size +20M -delete
+find $OUT -name '*counter_collection.csv' -delete
 du -sh $OUT

@@ -8,12 +8,14 @@ hip.ensure_fourier()
 for C in (256, 512):
     X = torch.randn(hip.coef_size(C, B), device='cuda')
     bias = torch.randn(C, device='cuda'); bn = (torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda'))
+    ob = torch.full((hip.coef_pitch(B),), 300.0, device='cuda')        # per-keypoint bound of the fp16 x 2 output split
     for sp in (False, True, 'f16x2'):
+        kw = dict(out_bound=ob) if sp == 'f16x2' else {}
         for _ in range(2):
-            hip.ft_nonlin(B, C, coef_in=X, bias=bias, bn=bn, split=sp)
+            hip.ft_nonlin(B, C, coef_in=X, bias=bias, bn=bn, split=sp, **kw)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(5):
-            hip.ft_nonlin(B, C, coef_in=X, bias=bias, bn=bn, split=sp)
+            hip.ft_nonlin(B, C, coef_in=X, bias=bias, bn=bn, split=sp, **kw)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
         gb = 2 * 60 * C * B * 4 / 1e9
         print(f'ft_nonlin coef->coef C={C} B={B} split={sp}: {dt*1e3:.2f} ms  {gb/dt/1e3:.2f} TB/s  {2*2*64*64*C*B/dt/1e12:.1f} TFLOP/s (padded 64x64 transforms)')
@@ -22,9 +24,10 @@ B2 = 60000
 X = torch.randn(hip.coef_size(256, B2), device='cuda'); bias = torch.randn(256, device='cuda')
 gmap = torch.full((60,), -1, dtype=torch.int32); gmap[:45] = torch.arange(45, dtype=torch.int32); gmap = gmap.cuda()
 xs = torch.randn(B2, 128, 60, device='cuda'); bn = (torch.rand(128, device='cuda') + 0.5, torch.randn(128, device='cuda'))
+ob2 = torch.full((hip.coef_pitch(B2),), 300.0, device='cuda')
 for sp in (False, True, 'f16x2'):
     for name, fn, gb in (('irrep->group(45 of 60) C=256', lambda: hip.ft_nonlin(B2, 256, coef_in=X, bias=bias, spatial_out=True, g_map=gmap, Lout=48, Lvalid=45, split=sp), (60 + 48) * 256 * B2 * 4 / 1e9),
-                         ('group->irrep C=128', lambda: hip.ft_nonlin(B2, 128, x_spatial=xs, bn=bn, split=sp), 120 * 128 * B2 * 4 / 1e9)):
+                         ('group->irrep C=128', lambda: hip.ft_nonlin(B2, 128, x_spatial=xs, bn=bn, split=sp, **(dict(out_bound=ob2) if sp == 'f16x2' else {})), 120 * 128 * B2 * 4 / 1e9)):
         for _ in range(2): fn()
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(5): fn()
