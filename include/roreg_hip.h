@@ -235,7 +235,10 @@ typedef struct {
 } roreg_lt_task;
 /* flags: bit 0 = Des2R through the irrep-domain bound + exact re-check (roreg_des2r_irrep; tasks carry coef0 / coef1), else the literal
  * kernel; bit 1 = the features are bfloat16 (needs bit 0). */
-int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int flags, int64_t *dr_out, float *x_out, void *stream);
+int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int flags, int64_t *dr_out, float *x_out,
+                           const float *bn_scale /* [128] */, const float *bn_shift, float *x_bound_out /* nullable, with x_out: per output row
+                           sqrt(60) max |ReLU(bn_scale_c x + bn_shift_c)| = roreg_row_bound(x_out, bn) computed while assembling (the block scale of the
+                           fp16 x 2 Conv_init GEMM, network/eqv_trans.py:88) */, void *stream);
 int roreg_lt_finish_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, const float *q_all, const int64_t *dr_all,
                           double *Trans_out, void *stream);
 

@@ -158,19 +158,37 @@ __global__ __launch_bounds__(256) void det_score_kernel(const float *__restrict_
 template <typename FT>
 __device__ __forceinline__ void et_gather_body(const void *__restrict__ before0_v, const void *__restrict__ before1_v,
                                                const void *__restrict__ after0_v, const void *__restrict__ after1_v, size_t r0, size_t r1,
-                                               int a, const int32_t *__restrict__ P, float *__restrict__ dst) {
+                                               int a, const int32_t *__restrict__ P, float *__restrict__ dst,
+                                               const float *__restrict__ bn_scale = nullptr, const float *__restrict__ bn_shift = nullptr,
+                                               float *__restrict__ bound_row = nullptr) {
     __shared__ int perm[ROREG_G];
+    __shared__ float red[4];
     if (threadIdx.x < ROREG_G) perm[threadIdx.x] = P[a * ROREG_G + threadIdx.x];
     __syncthreads();
     const FT *s_b1 = reinterpret_cast<const FT *>(before1_v) + r1 * (ROREG_F * ROREG_G), *s_b0 = reinterpret_cast<const FT *>(before0_v) + r0 * (ROREG_F * ROREG_G);
     const FT *s_a1 = reinterpret_cast<const FT *>(after1_v) + r1 * (ROREG_F * ROREG_G), *s_a0 = reinterpret_cast<const FT *>(after0_v) + r0 * (ROREG_F * ROREG_G);
+    float mx = 0.f;
     for (int i = threadIdx.x; i < ROREG_F * ROREG_G; i += 256) {
         const int c = i / ROREG_G, g = i - c * ROREG_G;
         const int pg = c * ROREG_G + perm[g];
-        dst[i] = (float)s_b1[pg];
-        dst[ROREG_F * ROREG_G + i] = (float)s_b0[i];
-        dst[2 * ROREG_F * ROREG_G + i] = (float)s_a1[pg];
-        dst[3 * ROREG_F * ROREG_G + i] = (float)s_a0[i];
+        const float v0 = (float)s_b1[pg], v1 = (float)s_b0[i], v2 = (float)s_a1[pg], v3 = (float)s_a0[i];
+        dst[i] = v0;
+        dst[ROREG_F * ROREG_G + i] = v1;
+        dst[2 * ROREG_F * ROREG_G + i] = v2;
+        dst[3 * ROREG_F * ROREG_G + i] = v3;
+        if (bound_row) {       // the row's bound for the fp16 x 2 split of FT(ReLU(BN(x))): what roreg_row_bound computes, without re-reading x
+            mx = fmaxf(mx, fmaxf(fmaf(v0, bn_scale[c], bn_shift[c]), 0.f));
+            mx = fmaxf(mx, fmaxf(fmaf(v1, bn_scale[ROREG_F + c], bn_shift[ROREG_F + c]), 0.f));
+            mx = fmaxf(mx, fmaxf(fmaf(v2, bn_scale[2 * ROREG_F + c], bn_shift[2 * ROREG_F + c]), 0.f));
+            mx = fmaxf(mx, fmaxf(fmaf(v3, bn_scale[3 * ROREG_F + c], bn_shift[3 * ROREG_F + c]), 0.f));
+        }
+    }
+    if (bound_row) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) *bound_row = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 7.7536f;      // sqrt(60) with the margin of row_bound_kernel
     }
 }
 
@@ -188,13 +206,16 @@ __global__ __launch_bounds__(256) void et_gather_kernel(const void *__restrict__
 
 template <typename FT>
 __global__ __launch_bounds__(256) void et_gather_batch_kernel(const roreg::LtTask *__restrict__ tasks, const int64_t *__restrict__ dr_all,
-                                                              const int32_t *__restrict__ P, float *__restrict__ x_all) {
+                                                              const int32_t *__restrict__ P, float *__restrict__ x_all,
+                                                              const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
+                                                              float *__restrict__ bound_all) {
     const roreg::LtTask t = tasks[blockIdx.y];
     const int i = blockIdx.x;
     if (i >= t.n) return;
     size_t r0, r1;
     roreg::lt_rows(t, i, r0, r1);
-    et_gather_body<FT>(t.before0, t.before1, t.after0, t.after1, r0, r1, (int)dr_all[t.off + i], P, x_all + (size_t)(t.off + i) * (4 * ROREG_F * ROREG_G));
+    et_gather_body<FT>(t.before0, t.before1, t.after0, t.after1, r0, r1, (int)dr_all[t.off + i], P, x_all + (size_t)(t.off + i) * (4 * ROREG_F * ROREG_G),
+                       bn_scale, bn_shift, bound_all ? bound_all + t.off + i : nullptr);
 }
 
 // ---- quat_to_trans: one thread per correspondence --------------------------------------------------------
@@ -340,21 +361,24 @@ extern "C" int roreg_gather_rows_f64(const double *src, const int64_t *rows, int
 }
 
 extern "C" int roreg_lt_prepare_batch(const roreg_lt_task *tasks_dev, int n_tasks, int max_n, int flags, int64_t *dr_out, float *x_out,
-                                      void *stream) {
+                                      const float *bn_scale, const float *bn_shift, float *x_bound_out, void *stream) {
     if (n_tasks == 0 || max_n == 0) return 0;
     ROREG_REQUIRE(tasks_dev && dr_out && n_tasks > 0 && max_n > 0, "roreg_lt_prepare_batch: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_lt_prepare_batch: group tables not set");
     ROREG_REQUIRE(!(flags & 1) || roreg::des2r_tables_ready(), "roreg_lt_prepare_batch: roreg_set_des2r_tables has not been called");
     ROREG_REQUIRE(!(flags & 2) || (flags & 1), "roreg_lt_prepare_batch: bfloat16 features need the irrep-domain Des2R (flags bit 0)");
+    ROREG_REQUIRE(!x_bound_out || (x_out && bn_scale && bn_shift), "roreg_lt_prepare_batch: x_bound_out needs x_out and the BatchNorm constants of Conv_init");
     static_assert(sizeof(roreg_lt_task) == sizeof(roreg::LtTask), "roreg_lt_task layout");
     const roreg::LtTask *tasks = reinterpret_cast<const roreg::LtTask *>(tasks_dev);
     hipStream_t s = roreg::as_stream(stream);
     roreg::launch_des2r_batch(tasks, n_tasks, max_n, dr_out, (flags & 1) != 0, (flags & 2) != 0, s);
     if (x_out) {
         if (flags & 2)
-            hipLaunchKernelGGL(et_gather_batch_kernel<__bf16>, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+            hipLaunchKernelGGL(et_gather_batch_kernel<__bf16>, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out,
+                               bn_scale, bn_shift, x_bound_out);
         else
-            hipLaunchKernelGGL(et_gather_batch_kernel<float>, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out);
+            hipLaunchKernelGGL(et_gather_batch_kernel<float>, dim3(max_n, n_tasks), dim3(256), 0, s, tasks, dr_out, roreg::group_tables().P, x_out,
+                               bn_scale, bn_shift, x_bound_out);
     }
     ROREG_CHECK_LAUNCH("roreg_lt_prepare_batch");
     return 0;

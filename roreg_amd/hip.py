@@ -65,7 +65,7 @@ PROTOTYPES = {
     'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
     'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
-    'roreg_lt_prepare_batch': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    'roreg_lt_prepare_batch': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'roreg_lt_finish_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
     'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -417,24 +417,30 @@ class LtBatch:
         self.keep = tasks                              # the table holds raw pointers: keep the tensors alive
         self.table = torch.from_numpy(table.view(np.uint8).reshape(self.n_tasks, _LT_TASK.itemsize).copy()).cuda() if self.n_tasks else None
 
-    def prepare(self, rows_alloc=None):
-        """Des2R + ET input assembly -> (dr int64 [total], x [rows_alloc,128,60] f32; rows beyond total are zero)."""
+    def prepare(self, rows_alloc=None, bound_bn=None):
+        """Des2R + ET input assembly -> (dr int64 [total], x [rows_alloc,128,60] f32; rows beyond total are zero).
+        bound_bn = (scale, shift) of Conv_init's BatchNorm: also returns the per-row bound row_bound(x, bn) [coef_pitch(rows_alloc)], computed
+        while x is assembled instead of in a pass of its own."""
         ensure_tables()
         rows_alloc = self.total if rows_alloc is None else rows_alloc
         dr = torch.empty(self.total, dtype=torch.int64, device='cuda')
         x = torch.empty((rows_alloc, 128, 60), dtype=torch.float32, device='cuda')
         if rows_alloc > self.total:
             x[self.total:].zero_()
+        bound = torch.zeros(coef_pitch(rows_alloc), dtype=torch.float32, device='cuda') if bound_bn is not None else None
+        sc, sh = bound_bn if bound_bn is not None else (None, None)
         if self.total:
-            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, self.flags, _ptr(dr), _ptr(x), _stream()), 'roreg_lt_prepare_batch')
-        return dr, x
+            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, self.flags, _ptr(dr), _ptr(x), _ptr(sc, torch.float32),
+                                                _ptr(sh, torch.float32), _ptr(bound), _stream()), 'roreg_lt_prepare_batch')
+        return (dr, x, bound) if bound_bn is not None else (dr, x)
 
     def des2r(self):
         """Des2R alone -> dr int64 [total] (the YOHO-C estimator's DR_index, test/estimator.py:85-111)."""
         ensure_tables()
         dr = torch.empty(self.total, dtype=torch.int64, device='cuda')
         if self.total:
-            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, self.flags, _ptr(dr), None, _stream()), 'roreg_lt_prepare_batch')
+            _check(lib().roreg_lt_prepare_batch(_ptr(self.table), self.n_tasks, self.max_n, self.flags, _ptr(dr), None, None, None, None, _stream()),
+                   'roreg_lt_prepare_batch')
         return dr
 
     def finish(self, q_all, dr):

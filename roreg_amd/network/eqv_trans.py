@@ -113,8 +113,15 @@ class ET_test(nn.Module):
         # "1" = the permuted side; in the reference's batch the permuted side is before_eqv0/after_eqv0.
         return hip.et_gather(b1, b0, a1, a0, pre), pre
 
-    def trunk_and_head(self, x):
-        """x [B,128,60] -> un-normalised quaternion [B,4]."""
+    def conv_init_bn(self):
+        """(scale, shift) device tensors of Conv_init's folded BatchNorm when the fp16 x 2 irrep path will use them, else None
+        (lets the caller compute the rows' block-scale bound while it assembles x: hip.LtBatch.prepare(bound_bn=...))."""
+        if self.pruned and self.fourier_init and self.gemm == 'f16x2':
+            return self._fourier_init()[1]
+        return None
+
+    def trunk_and_head(self, x, x_bound=None):
+        """x [B,128,60] -> un-normalised quaternion [B,4].  x_bound: hip.row_bound(x, Conv_init's BatchNorm) if the caller has it."""
         res = self.PartII_SO3_Conv_layers[0]
         h0p, h1p, h2p = self._head_plans()
         if self.pruned:
@@ -128,7 +135,7 @@ class ET_test(nn.Module):
                     # fp16 x 2 all the way, every block scale PER ROW (correspondence): Conv_init's coefficients are split under the
                     # row's own bound (hip.row_bound), every later kernel tracks max |output row| on the device as the next kernel's scale,
                     # so a correspondence's quaternion does not depend on which other correspondences share the batch
-                    b0 = hip.row_bound(x, bn=bn)
+                    b0 = x_bound if x_bound is not None else hip.row_bound(x, bn=bn)
                     X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', out_bound=b0)
                     T0 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0)
                     del X0

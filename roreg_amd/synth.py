@@ -263,6 +263,7 @@ def make_scene_device(seed, n_clouds, n_kpts=5000, overlap=0.6, feat_noise=0.05,
         return x, f
     xs, fs = world(n_sh)
     feats, keys, poses = [], [], []
+    pool = torch.empty((n_clouds * n_kpts, 32, G), dtype=torch.float32, device=device)      # one allocation: the clouds are views of it
     for c in range(n_clouds):
         xp, fp = world(n_pr)
         xw = torch.cat([xs, xp]); fw = torch.cat([fs, fp])
@@ -273,7 +274,9 @@ def make_scene_device(seed, n_clouds, n_kpts=5000, overlap=0.6, feat_noise=0.05,
             xc = xc + coord_noise * torch.randn(xc.shape, generator=gen, device=device, dtype=torch.float64)
         fc = fw[:, :, P[g]] + feat_noise * torch.randn(fw.shape, generator=gen, device=device, dtype=torch.float32)
         perm = torch.randperm(n_kpts, generator=gen, device=device)
-        keys.append(xc[perm].contiguous()); feats.append(fc[perm].contiguous()); poses.append((g, t))
+        view = pool[c * n_kpts:(c + 1) * n_kpts]
+        view.copy_(fc[perm])
+        keys.append(xc[perm].contiguous()); feats.append(view); poses.append((g, t))
     return feats, keys, poses
 
 
