@@ -440,10 +440,9 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
 // the tile) alternate roles inside every K16 step instead of both interleaving matrix and memory work: after the step's barrier group 0
 // issues its 24 MFMAs back to back from fragment REGISTERS while group 1 does its LDS/VMEM work (fragment reads, staging of a later
 // step), then group 1's MFMAs run while group 0 reads its next fragments and stages -- the matrix pipe of the SIMD sees one unbroken
-// MFMA stream, and no MFMA ever waits on an LDS read issued after a barrier.  That needs the operands one step deeper in flight: a ring
-// of THREE LDS stages (stage k+2 is written during step k, complete at barrier k+1, read into registers during step k+1 (group 0) or at the
-// top of step k+2 (group 1)), 96 KB, one workgroup per CU.  Same MFMA sequence per accumulator as irrep_gemm_split_kernel<.., 2, 4>: results
-// are bitwise identical.
+// MFMA stream, and no MFMA ever waits on an LDS read issued after a barrier.  That needs the operands deeper in flight: a ring of FOUR
+// LDS stages (128 KB, one workgroup per CU; details at the loop).  Same MFMA sequence per accumulator as
+// irrep_gemm_split_kernel<.., 2, 4>: results are bitwise identical.  Measured slower than that kernel: opt-in experiment.
 template <int BIG>
 __global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -494,12 +493,17 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p,
         dst[slot] = __builtin_bit_cast(f16x8, H); dst[2 * NCOL + slot] = __builtin_bit_cast(f16x8, L);
     };
     const f16x8 *wsrc = W + (size_t)(tid >> 8) * Mpad + mt * OT + (tid & 255);
+    // The weight DMA is issued through inline assembly so that the compiler's wait-count pass does not see a pending LDS write it would
+    // have to drain (vmcnt(0)) before every later LDS access; the explicit vmcnt(10) below orders it.  (Hidden VMEM operations only make the
+    // compiler's own counted waits for the patch loads stricter, never laxer: VMEM retires in order.)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     auto issue_a = [&](int kstep, int stage) {
         const f16x8 *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * split_stride),
-                                             (__attribute__((address_space(3))) void *)(ring + stage * STAGE + XBUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+        for (int sp = 0; sp < 2; ++sp) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((stage * STAGE + XBUF + sp * (2 * OT) + w * 64) * 16));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(q + sp * split_stride), "s"(dst) : "memory");
+        }
     };
     int xslot[4];
 #pragma unroll
@@ -534,35 +538,47 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p,
             for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][0], fb[t][0], acc[ot][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    float xr_cur[8], xr_next[8];
-    load_x(0, xr_cur); load_x(1, xr_next);
-    issue_a(0, 0); issue_a(1, 1);
-    store_x(0, xr_cur); store_x(1, xr_next);
-    load_x(2, xr_cur);                                          // staged during step 0
+    // Operands are two steps deep in flight: a ring of FOUR LDS stages; at step k the weight DMA of stage k+3 and the patch loads of step
+    // k+4 are issued, the patch of step k+2 (loaded two steps ago) is staged, and the step ends waiting only for what was issued BEFORE
+    // this step (vmcnt(10): VMEM operations retire in order; this step's 8 loads + 2 DMA pieces stay in flight across the barrier).
+    // The barrier is a RAW s_barrier behind lgkmcnt(0): __syncthreads() would fence with vmcnt(0) (an LDS-DMA is a pending LDS write on
+    // the VM counter) and drain exactly the loads that are meant to stay in flight.
+    float R0[8], R1[8], R2[8];                                  // the patch of step j lives in R[j % 3]: no register copies, so no load is waited for early
+    load_x(0, R0); load_x(1, R1);
+    issue_a(0, 0); issue_a(1, 1); issue_a(2, 2);
+    store_x(0, R0); store_x(1, R1);
+    load_x(2, R2); load_x(3, R0);                               // staged during steps 0 and 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (grp == 0) read_frags(0);
     int sk = 0;
-#pragma unroll 1
-    for (int k = 0; k < nsteps; ++k) {
-        const int s1 = sk == 2 ? 0 : sk + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-        load_x(k + 3, xr_next);                                 // stored into LDS during the next step
-        issue_a(k + 2, s2);                                     // lands under this step's MFMAs
+    auto step = [&](int k, const float (&r_store)[8], float (&r_load)[8]) {
+        const int s1 = (sk + 1) & 3, s2 = (sk + 2) & 3, s3 = (sk + 3) & 3;
+        load_x(k + 4, r_load);
+        issue_a(k + 3, s3);
         if (grp != 0) {                                         // group 1: memory work first, under group 0's MFMAs
             read_frags(sk);
-            store_x(s2, xr_cur);
+            store_x(s2, r_store);
         }
         mfma_phase();                                           // (group 0: the fragments of step k are already in registers)
         if (grp == 0) {                                         // group 0: memory work second, under group 1's MFMAs
             read_frags(s1);                                     // step k + 1 (stage complete since the barrier that opened this step)
-            store_x(s2, xr_cur);
+            store_x(s2, r_store);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the weight DMA of stage s2 (and the patch loads) have landed
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xr_cur[e] = xr_next[e];
+        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everything issued before this step has landed
         sk = s1;
+    };
+    int k = 0;
+#pragma unroll 1
+    for (; k + 3 <= nsteps; k += 3) {                           // whole triples: a fixed number of VMEM operations per trip, so the
+        step(k, R2, R1);                                        // compiler's own wait-count bookkeeping stays exact across the back edge
+        step(k + 1, R0, R2);
+        step(k + 2, R1, R0);
     }
+    if (k < nsteps) step(k, R2, R1);
+    if (k + 1 < nsteps) step(k + 1, R0, R2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     gemm_split_epilogue<2, 4>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
 }
 
@@ -1143,11 +1159,11 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
     constexpr int CT = 32;
     const size_t lds = 2 * (NP * 2 * 256 + NP * (WO * 64) * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
     if constexpr (NP == 2 && WO == 4) {
-        // opt-in (ROREG_GEMM_PP=1): measured 13.2 vs 12.2 ms per launch against the interleaved kernel on the same box (round 2) -- the
-        // unbroken MFMA stream does not pay because the kernel is limited by the power the chip may draw, not by matrix-pipe issue slots
+        // opt-in (ROREG_GEMM_PP=1): measured 13.4 vs 12.7 ms per launch against the interleaved kernel on the same box (round 2) -- neither
+        // the unbroken MFMA stream nor operands two steps deep in flight pay: the kernel is limited by the power the chip may draw
         static const bool pingpong = [] { const char *e = getenv("ROREG_GEMM_PP"); return e && e[0] == '1'; }();
         if (pingpong) {
-            const size_t lds_pp = 3 * (2 * 2 * 256 + 2 * 2 * 256) * 16;      // three stages of (activation planes + weight fragments)
+            const size_t lds_pp = 4 * (2 * 2 * 256 + 2 * 2 * 256) * 16;      // four stages of (activation planes + weight fragments)
             auto kpp = (long long)C * O == 256ll * 512 ? irrep_gemm_pp_kernel<1> : irrep_gemm_pp_kernel<0>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kpp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp);
             if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
