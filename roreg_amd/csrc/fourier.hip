@@ -233,26 +233,69 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
             __syncthreads();
         }
     }
+    // Interior tiles (every tile of GF's and ET's layers when B % 256 == 0): straight-line stores from one uniform base pointer with
+    // 32-bit lane offsets, the four (residual, bound) combinations as separate branch-free bodies -- the generic body below spends ~200
+    // cycles per element on its per-element range / option branches (measured: 27.6 k cycles per workgroup, 12 % of the d = 5 tile).
+    const bool interior = (mt + 1) * OT <= M && n0 + NCOL <= N;
+    if (interior) {
+        const size_t base = (size_t)(mt * OT + wo * 64) * N + n0 + ncol_wave;
+        float *__restrict__ ob = Out + base;
+        const float *__restrict__ ab = Add ? Add + base : nullptr;
+        const unsigned un = (unsigned)N;
+        auto body = [&](auto has_add, auto has_bound) {
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
+            for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = mt * OT + row;
-            if (m >= M) continue;
-            float ur = 0.f, vr = 0.f;
-            if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
+                for (int rq = 0; rq < 4; ++rq) {                 // four accumulator rows at a time: their 16 residual loads go out together
+                    float res[4][4];
+                    if constexpr (decltype(has_add)::value) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int n = n0 + ncol_wave + t * 32 + j;
-                if (n >= N) continue;
-                float o = acc[ot][t][r];
-                if constexpr (NP == 2) o *= oscale[t];
-                if (Add) o += Add[(size_t)m * N + n];
-                Out[(size_t)m * N + n] = o;
-                if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr)); }
+                        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) res[rr][t] = ab[(unsigned)(ot * 32 + rr + 8 * rq + 4 * h) * un + (unsigned)j + t * 32];
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = rq * 4 + rr;
+                        const int rl = ot * 32 + rr + 8 * rq + 4 * h;          // row inside the wave's 64
+                        const unsigned off = (unsigned)rl * un + (unsigned)j;
+                        float ur = 0.f, vr = 0.f;
+                        if constexpr (decltype(has_bound)::value) { ur = su[wo * 64 + rl]; vr = sv[wo * 64 + rl]; }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float o = acc[ot][t][r];
+                            if constexpr (NP == 2) o *= oscale[t];
+                            if constexpr (decltype(has_add)::value) o += res[rr][t];
+                            ob[off + t * 32] = o;
+                            if constexpr (decltype(has_bound)::value) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr));
+                        }
+                    }
+                }
+        };
+        if (Add) { if (want_bound) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+        else     { if (want_bound) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+    } else {
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wo * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = mt * OT + row;
+                if (m >= M) continue;
+                float ur = 0.f, vr = 0.f;
+                if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int n = n0 + ncol_wave + t * 32 + j;
+                    if (n >= N) continue;
+                    float o = acc[ot][t][r];
+                    if constexpr (NP == 2) o *= oscale[t];
+                    if (Add) o += Add[(size_t)m * N + n];
+                    Out[(size_t)m * N + n] = o;
+                    if constexpr (NP == 2) { if (want_bound) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr)); }
+                }
             }
-        }
+    }
     if constexpr (NP == 2) {
         if (want_bound) {
 #pragma unroll
@@ -286,7 +329,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
 // because one converted activation tile now feeds 256 output rows.
 // BIG: a name tag only (C * O = 256 * 512, GF's two dominant layers), so that profiler output can be filtered to exactly the launch
 // population bench.py prices in `roofline` -- the instantiations are otherwise identical.
-template <int CT, int NP, int WO, int BIG>
+template <int CT, int NP, int WO, int BIG, int PIPE = 0>
 __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -421,15 +464,129 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     };
 
     xpatch xr0[8], xr1[8];
-    load_x(0, xr0);
-    issue_a(0, 0);
-    load_x(1, xr1);
-    convert_store(0, xr0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int ks = 0; ks < nsteps; ks += 2) {
-        step(ks, 0, xr0, xr1);
-        step(ks + 1, 1, xr1, xr0);
+    if constexpr (PIPE == 1 && NP == 2 && WO == 4) {
+        // Fragment-pipelined loop: every MFMA of step k reads fragment REGISTERS that were filled during step k - 1, so no MFMA waits on
+        // an LDS read issued after a barrier.  Per step: LDS-DMA of the weights of step k + 2 and the staging store of the activations of
+        // step k + 2 go into stage k % 2 (all of whose fragments were read during step k - 1); the fragments of step k + 1 are read from
+        // stage (k + 1) % 2 -- the four weight fragments into the alternate register set, the activation fragments of column block t
+        // into the registers the MFMAs of block t have just released.  Two LDS stages, one barrier per step, +16 VGPRs.
+        frag aA[2][2], aB[2][2], b[4][2];
+        auto read_a = [&](int buf, frag (&a)[2][2]) {
+            const frag *at = as + buf * ABUF + aslot;
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) a[ot][sp] = at[sp * (2 * OT) + ot * 32];
+        };
+        auto read_b = [&](int buf, int t) {
+            const frag *xt = xs + buf * XBUF;
+            b[t][0] = xt[xslot[t]]; b[t][1] = xt[2 * NCOL + xslot[t]];
+        };
+        // The activation loads are issued from inline assembly: the compiler's wait-count pass then neither sees them nor widens the
+        // waits of this loop to vmcnt(0) (it loses count across the raw barrier); wait_x is the explicit, counted wait -- the patch
+        // registers are its in/out operands, so no use can be scheduled above it.
+        static_assert(CPT == 1, "the pipelined loop is written for the 8-wave tile (one activation column per thread)");
+        auto load_xa = [&](int kstep, float (&xr)[8]) {
+            const float *q = xcol + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 16 * N;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("global_load_dword %0, %1, off" : "=v"(xr[e]) : "v"(q + (size_t)e * N) : "memory");
+        };
+#define ROREG_WAIT_X(cnt, xr) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory")
+        auto store_x = [&](int buf, const float (&v)[8]) {       // word e = fp16 hi | fp16 lo << 16 of k = 8 po + e -> the two planes' k-octets
+            frag *dst = xs + buf * XBUF;
+            u32x4 H, L;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned lo2 = __float_as_uint(v[2 * i]), hi2 = __float_as_uint(v[2 * i + 1]);
+                H[i] = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
+                L[i] = __builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
+            }
+            dst[slot[0]] = __builtin_bit_cast(f16x8, H); dst[2 * NCOL + slot[0]] = __builtin_bit_cast(f16x8, L);
+        };
+        // One step = 24 MFMAs per wave in 12 pairs; every memory operation of the step sits BETWEEN two pairs (sched_barrier pins the order),
+        // never in a burst at the step's head: a wave that is queueing its ten VMEM instructions cannot issue MFMAs (in-order issue), and
+        // with all eight waves doing so right after the barrier the matrix pipes idled ~1000 cycles per step (measured: 2450 cycles per
+        // step with the burst, 1820 with no memory operations at all, 1536 = the MFMAs alone).
+        auto step2 = [&](int ks, int buf, float (&xr_load)[8], float (&xr_use)[8], const frag (&a)[2][2], frag (&an)[2][2]) {
+            const int kw = ks + 2 < nsteps ? ks + 2 : nsteps - 1, kx = ks + 3 < nsteps ? ks + 3 : nsteps - 1;
+            const frag *wq = wsrc + (size_t)kw * 2 * Mpad;
+            const float *xq = xcol + (size_t)kx * 16 * N;
+            const frag *xn = xs + (buf ^ 1) * XBUF, *aq = as + (buf ^ 1) * ABUF + aslot;
+            frag *xd = xs + buf * XBUF;
+            auto mm = [&](int t, int i) {                        // pair i of column block t: 0 = lo.hi, 1 = hi.lo, 2 = hi.hi (both row blocks)
+                const f16x8 bb = b[t][i == 1 ? 1 : 0];
+                const int ai = i == 0 ? 1 : 0;
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][ai], bb, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][ai], bb, acc[1][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto dma = [&](int sp) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wq + sp * split_stride),
+                                                 (__attribute__((address_space(3))) void *)(as + buf * ABUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto ldx = [&](int e0, int e1) {
+#pragma unroll
+                for (int e = e0; e < e1; ++e) asm volatile("global_load_dword %0, %1, off" : "=v"(xr_load[e]) : "v"(xq + (size_t)e * N) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto rb = [&](int t) { b[t][0] = xn[xslot[t]]; b[t][1] = xn[2 * NCOL + xslot[t]]; __builtin_amdgcn_sched_barrier(0); };
+            auto ra = [&](int ot) { an[ot][0] = aq[ot * 32]; an[ot][1] = aq[2 * OT + ot * 32]; __builtin_amdgcn_sched_barrier(0); };
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0, 0); dma(0); mm(0, 1); dma(1); mm(0, 2); rb(0);
+            mm(1, 0); ra(0);  mm(1, 1); ra(1);  mm(1, 2); rb(1);
+            mm(2, 0);
+            ROREG_WAIT_X(2, xr_use);                             // the patch loaded during the previous step: only this step's two LDS-DMA pieces are newer
+            {
+                u32x4 H, L;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned lo2 = __float_as_uint(xr_use[2 * i]), hi2 = __float_as_uint(xr_use[2 * i + 1]);
+                    H[i] = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
+                    L[i] = __builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
+                }
+                xd[slot[0]] = __builtin_bit_cast(f16x8, H);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(2, 1);
+                xd[2 * NCOL + slot[0]] = __builtin_bit_cast(f16x8, L);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mm(2, 2); rb(2);
+            mm(3, 0); ldx(0, 3); mm(3, 1); ldx(3, 6); mm(3, 2); ldx(6, 8); rb(3);
+            // the two LDS-DMA pieces are the oldest of this step's ten VMEM operations: vmcnt(8) = they have landed (the activation
+            // loads stay in flight across the barrier); lgkmcnt(0) = this wave's staging stores and fragment reads are done
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        float xa0[8], xa1[8];
+        load_xa(0, xa0); issue_a(0, 0);
+        load_xa(1, xa1); issue_a(1, 1);
+        ROREG_WAIT_X(0, xa0);
+        ROREG_WAIT_X(0, xa1);
+        store_x(0, xa0);
+        load_xa(2, xa0);
+        store_x(1, xa1);
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_a(0, aA);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) read_b(0, t);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // stage 0 is overwritten from step 0 on
+        for (int ks = 0; ks < nsteps; ks += 2) {
+            step2(ks, 0, xa1, xa0, aA, aB);
+            step2(ks + 1, 1, xa0, xa1, aB, aA);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped look-ahead loads still target the patch registers
+#undef ROREG_WAIT_X
+    } else {
+        load_x(0, xr0);
+        issue_a(0, 0);
+        load_x(1, xr1);
+        convert_store(0, xr0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ks = 0; ks < nsteps; ks += 2) {
+            step(ks, 0, xr0, xr1);
+            step(ks + 1, 1, xr1, xr0);
+        }
     }
     gemm_split_epilogue<NP, WO>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
 }
@@ -1173,7 +1330,10 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
             return 0;
         }
     }
+    // ROREG_GEMM_PIPE=0 selects the loop without fragment pipelining (kept for A/B runs: results are bitwise the same)
+    static const int pipe = [] { const char *e = getenv("ROREG_GEMM_PIPE"); return e ? atoi(e) : 1; }();
     auto kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0>;
+    if constexpr (NP == 2 && WO == 4) { if (pipe == 1) kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0, 1>; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(WO * 128), lds, roreg::as_stream(stream), p, tiles_dev);
