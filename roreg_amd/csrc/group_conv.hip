@@ -320,17 +320,33 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     const frag *wsb = reinterpret_cast<const frag *>(p.ws);
     const size_t ws_plane = (size_t)KS * (p.Cin / 16) * 2 * p.CoutPad;    // fragments per split plane
 
-    for (int c0 = 0; c0 < p.Cin; c0 += 16) {
-        __syncthreads();   // previous chunk fully consumed (also orders the gather-table fill)
-        // ---- stage act(x[b_first .. +nkp) [c0 .. c0+16) [0 .. Lin)) as three bf16 planes of k-octets ----------------
+    // Activation staging: the raw float32 chunk x[b_first .. +nkp)[c0 .. c0+16)[0 .. Lin) -- 16 * Lin contiguous floats per keypoint -- of the
+    // NEXT chunk travels global -> LDS by LDS-DMA while this chunk's MFMAs run (no registers, no wave waits on HBM latency); after the
+    // stencil loop every thread converts its k-octets from the raw LDS copy (BatchNorm, ReLU, split) into the fragment slab.  (The earlier
+    // form loaded each k-octet with eight dependent global loads, one item after the other: 12-16 us of exposed latency per chunk against
+    // 4 us of MFMAs -- the kernel ran at 42 % matrix-pipe duty, independent of the operands, i.e. stall-bound, not power-bound.)
+    float *raw = reinterpret_cast<float *>(slab + (size_t)NP * plane_stride);       // [nkp_max][16][Lin]
+    const int pieces = nkp * 4 * Lin;                                                // 16-byte pieces of a chunk
+    auto issue_raw = [&](int c0) {
+        for (int base = w * 64; base < pieces; base += 256) {                        // (wave-uniform trip count)
+            const int pc = base + lane;
+            if (pc < pieces) {
+                const int kp = pc / (4 * Lin), r = pc - kp * (4 * Lin);
+                const float *src = p.x + ((size_t)(b_first + kp) * p.Cin + c0) * Lin + 4 * r;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(raw + (size_t)base * 4), 16, 0, 0);
+            }
+        }
+    };
+    auto convert = [&](int c0) {
         const int items = nkp * 2 * Lin;
         for (int i = tid; i < items; i += 256) {
             const int col = i % Lin, r = i / Lin;
             const int ho = r & 1, kp = r >> 1;
-            const float *src = p.x + ((size_t)(b_first + kp) * p.Cin + c0 + 8 * ho) * Lin + col;
+            const float *src = raw + (kp * 16 + 8 * ho) * Lin + col;
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * Lin];
+            for (int e = 0; e < 8; ++e) v[e] = src[e * Lin];
             if (has_bn) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.bn_scale[c0 + 8 * ho + e], p.bn_shift[c0 + 8 * ho + e]), 0.f);
@@ -346,10 +362,20 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                 dst[0] = hi; dst[plane_stride] = lo;
             }
         }
-        __syncthreads();
+    };
+    issue_raw(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                                 // (also orders the gather-table fill)
+    convert(0);
+
+    for (int c0 = 0; c0 < p.Cin; c0 += 16) {
+        __syncthreads();                                                             // the slab of this chunk is complete, the raw buffer is free
+        const bool more = c0 + 16 < p.Cin;
 
         // ---- MFMA over the stencil; the weight fragments of position k+1 are in flight during position k ----------------
-        frag a_cur[2][NP], a_nxt[2][NP];
+        // (the stencil loop is fully unrolled with two named fragment sets: a rolled loop with a register copy made the compiler wait for
+        //  the weight loads of position k + 1 BEFORE the MFMAs of position k -- one exposed L2 round trip per stencil position)
+        frag aw[2][2][NP];
         auto load_a = [&](int k, frag (&a)[2][NP]) {
             const frag *wk = wsb + (((size_t)k * (p.Cin / 16) + c0 / 16) * 2 + h) * p.CoutPad + o_wave + j;
 #pragma unroll
@@ -357,10 +383,13 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
                 for (int sp = 0; sp < NP; ++sp) a[ot][sp] = wk[sp * ws_plane + ot * 32];
         };
-        load_a(0, a_cur);
-#pragma unroll 1
+        load_a(0, aw[0]);
+#pragma unroll
         for (int k = 0; k < KS; ++k) {
-            if (k + 1 < KS) load_a(k + 1, a_nxt);
+            const frag (&a_cur)[2][NP] = aw[k & 1];
+            if (k + 1 < KS) load_a(k + 1, aw[(k + 1) & 1]);
+            if (k == 0 && more) issue_raw(c0 + 16);                 // (after the weight loads of k = 1: their wait does not cover the DMA)
+            __builtin_amdgcn_sched_barrier(0);                      // the loads stay ahead of this position's MFMAs (the scheduler would sink them to their use)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const frag *bp = slab + rowbase[t] + gt[gi[t] * KS + k];
@@ -390,12 +419,11 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                 }
                 acc[0][t] = c0v; acc[1][t] = c1v;
             }
-            if (k + 1 < KS) {
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-                    for (int sp = 0; sp < NP; ++sp) a_cur[ot][sp] = a_nxt[ot][sp];
-            }
+        }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's DMA pieces have landed ...
+            __syncthreads();                                                         // ... everyone's have, and nobody reads the slab any more
+            convert(c0 + 16);
         }
     }
 
@@ -769,8 +797,8 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
 
 template <int NP>
 static int launch_conv_split(GCSplitParams p, hipStream_t s) {
-    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.Lin * 16;
-    ROREG_REQUIRE(lds <= 80 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
+    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.Lin * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4;     // gather table, fragment slab, raw chunk
+    ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
     auto kern = group_conv_split_kernel<13, NP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
