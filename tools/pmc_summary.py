@@ -8,7 +8,7 @@ import collections
 import csv
 import glob
 import json
-import sys
+import re, sys
 
 KEEP = ('irrep_gemm', 'group_conv', 'ft_nonlin', 'nn_search', 'des2r', 'ransac', 'refine', 'gf_finalize', 'et_gather', 'match_prepare')
 
@@ -60,7 +60,10 @@ def main():
         if cal:
             lines.append(f'calibration: gf_finalize on {cal[0]} keypoints reads {cal[1]:.0f} KiB; FETCH_SIZE reports {cal[2]:.0f} KiB -> factor {cal[1] / cal[2]:.3f}')
         kern = 'irrep_gemm_kernel' if gm == 'f32' else 'irrep_gemm_split_kernel'
-        tagged = (lambda k: k[1] >= 4000000) if gm == 'f32' else (lambda k: k[0].rstrip().endswith(', 1>'))
+        def big_tag(name):          # irrep_gemm_split_kernel<CT, NP, WO, BIG[, PIPE]>: the fourth template argument
+            m = re.search(r'irrep_gemm_split_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name)
+            return bool(m) and m.group(1) == '1'
+        tagged = (lambda k: k[1] >= 4000000) if gm == 'f32' else (lambda k: big_tag(k[0]))
         big = [k for k in agg if k[0].startswith(kern) and tagged(k) and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]]
         if big:
             nf = sum(len(agg[k]['FETCH_SIZE']) for k in big); nw = sum(len(agg[k]['WRITE_SIZE']) for k in big)
