@@ -6,21 +6,23 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // RANDOM = 1: eight operand sets of pseudo-random fp16 values (every MFMA sees different multiplier inputs, as in a real GEMM);
-// RANDOM = 0: one smooth operand pair for every MFMA (minimal switching activity)
+// RANDOM = 0: one smooth operand pair for every MFMA (minimal switching activity); RANDOM = 2: all-zero operands (no switching at all)
 template <int NACC, int RANDOM>
 __global__ __launch_bounds__(256) void mfma_loop(float *out, int iters, int sleep) {
     f16x8 av[8], bv[8];
     unsigned seed = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
     for (int q = 0; q < 8; ++q)
         for (int e = 0; e < 8; ++e) {
-            if (RANDOM) {
+            if (RANDOM == 1) {
                 seed = seed * 1664525u + 1013904223u; av[q][e] = (_Float16)(((int)(seed >> 8) % 2001 - 1000) * 0.001f);
                 seed = seed * 1664525u + 1013904223u; bv[q][e] = (_Float16)(((int)(seed >> 8) % 2001 - 1000) * 0.001f);
-            } else { av[q][e] = (_Float16)(0.001f * (threadIdx.x + e)); bv[q][e] = (_Float16)(0.002f * (threadIdx.x - e)); }
+            } else if (RANDOM == 2) { av[q][e] = (_Float16)0.f; bv[q][e] = (_Float16)0.f; }
+            else { av[q][e] = (_Float16)(0.001f * (threadIdx.x + e)); bv[q][e] = (_Float16)(0.002f * (threadIdx.x - e)); }
         }
     f32x16 acc[NACC];
     for (int q = 0; q < NACC; ++q)
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();          // s_memtime: shader-clock cycles
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 8; ++rep)
@@ -31,13 +33,15 @@ __global__ __launch_bounds__(256) void mfma_loop(float *out, int iters, int slee
     float s = 0.f;
     for (int q = 0; q < NACC; ++q)
         for (int r = 0; r < 16; ++r) s += acc[q][r];
+    const unsigned long long t1 = __builtin_readcyclecounter();
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x < 256) out[(1 << 21) + blockIdx.x] = (float)(t1 - t0);      // cycles of this wave's loop
 }
 
 extern "C" double mfma_peak_run(int blocks, int threads, int iters, int sleep, int random, float *out_dev) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    auto kern = random ? mfma_loop<4, 1> : mfma_loop<4, 0>;
+    auto kern = random == 1 ? mfma_loop<4, 1> : random == 2 ? mfma_loop<4, 2> : mfma_loop<4, 0>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out_dev, iters / 10, sleep);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);

@@ -9,7 +9,10 @@ lib.mfma_peak_run.restype = ctypes.c_double
 lib.mfma_peak_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 out = torch.empty(1 << 22, device='cuda')
 for blocks, threads, label in ((256, 256, '1 wave/SIMD'), (512, 256, '2 waves/SIMD'), (1024, 256, '4 waves/SIMD'), (2048, 256, '8 waves/SIMD (two rounds)')):
-    for sleep, rnd in ((0, 0), (0, 1), (1, 1)):
-        tf = lib.mfma_peak_run(blocks, threads, 20000, sleep, rnd, ctypes.c_void_p(out.data_ptr()))
-        clk = tf * 1e12 / (256 * 4 * 1024.0) / 1e9
-        print(f'{label:28s} operands={"random" if rnd else "smooth"} sleep={sleep}: {tf:7.1f} TFLOP/s  (= {clk:.2f} GHz x 100 % duty of the 1024 flop/clk/SIMD pipes)')
+    for sleep, rnd in ((0, 2), (0, 0), (0, 1), (1, 1)):
+        iters = 20000
+        tf = lib.mfma_peak_run(blocks, threads, iters, sleep, rnd, ctypes.c_void_p(out.data_ptr()))
+        torch.cuda.synchronize()
+        cyc = float(out[(1 << 21):(1 << 21) + 256].mean())                    # s_memtime ticks of one wave's loop
+        per = cyc / (iters * 32.0)                                                # ticks per MFMA of that wave (32 = back to back on a free pipe)
+        print(f'{label:28s} operands={("smooth", "random", "zeros")[rnd]:6s} sleep={sleep}: {tf:7.1f} TFLOP/s   {per:6.1f} s_memtime ticks per MFMA of one wave')
