@@ -40,16 +40,16 @@ __global__ __launch_bounds__(256) void mfma_loop(float *out, int iters, int slee
 
 extern "C" double mfma_peak_run(int blocks, int threads, int iters, int sleep, int random, float *out_dev) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     auto kern = random == 1 ? mfma_loop<4, 1> : random == 2 ? mfma_loop<4, 2> : mfma_loop<4, 0>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out_dev, iters / 10, sleep);
-    hipDeviceSynchronize();
-    hipEventRecord(e0, 0);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out_dev, iters, sleep);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)blocks * (threads / 64) * iters * 8.0 * 4.0 * 32768.0;
     return flops / (ms * 1e-3) / 1e12;      // TFLOP/s
 }
