@@ -812,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     constexpr int NA1 = SPLIT ? 4 * 2 * NPL * 64 * 4 : 30 * 2 * 64, NA2 = SPLIT ? 4 * 2 * NPL * 64 * 4 : 32 * 2 * 64;   // floats (a fragment = 4 floats)
     __shared__ __attribute__((aligned(16))) float sA1[IN_SPATIAL ? 64 : NA1];
     __shared__ __attribute__((aligned(16))) float sA2[OUT_SPATIAL ? 64 : NA2];
-    __shared__ float sT[(OUT_SPATIAL || OUT_ROWS) ? NW * 32 * 65 : 64];
+    __shared__ float sT[(IN_SPATIAL || OUT_SPATIAL || OUT_ROWS) ? NW * 32 * 65 : 64];     // per wave: [32 keypoints][65] transpose buffer
     {
         const float *g1 = SPLIT == 3 ? reinterpret_cast<const float *>(p.A1s) : SPLIT == 2 ? reinterpret_cast<const float *>(p.A1h) : p.A1;
         const float *g2 = SPLIT == 3 ? reinterpret_cast<const float *>(p.A2s) : SPLIT == 2 ? reinterpret_cast<const float *>(p.A2h) : p.A2;
@@ -824,6 +824,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     // per-channel epilogue constants also live in LDS: as vector loads inside the tile loop they would force s_waitcnt vmcnt(0), i.e.
     // drain the coefficient prefetch of the next tile (VMEM operations of a wave complete in order)
     __shared__ float sBias[512], sScale[512], sShift[512];
+    __shared__ int sGmap[64];                                   // output column of group element g (-1 = not written); same reason
+    if (threadIdx.x < 64) sGmap[threadIdx.x] = (OUT_SPATIAL && p.g_map && threadIdx.x < ROREG_G) ? p.g_map[threadIdx.x] : (int)threadIdx.x;
     for (int i = threadIdx.x; i < p.C; i += NT) {
         sBias[i] = (p.bias ? p.bias[i] : 0.f) + (p.bias2 ? p.bias2[i] : 0.f);
         sScale[i] = p.bn_scale ? p.bn_scale[i] : 1.f;
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
 #define OFF_OF(Q0, Q1, c, tb) (OFF_Q(Q0, c, tb) + ((OFF_Q(Q1, c, tb) - OFF_Q(Q0, c, tb)) & hmask))   // arithmetic select (mask, not a quarter-rate multiply): one load, no exec-masked pair
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
-    constexpr int NCV = IN_SPATIAL ? 1 : (SPLIT != 0 ? 32 : 30);
+    constexpr int NCV = IN_SPATIAL ? 32 : (SPLIT != 0 ? 32 : 30);
     constexpr bool PACK_OUT = SPLIT == 2 && !OUT_SPATIAL && !OUT_ROWS;      // coefficients leave as fp16 hi/lo pairs under the keypoint's block scale
     // group-domain tensors are float32 or (x_bf16) bfloat16 as stored (BASELINE config 5)
     auto ld_sp = [&](const float *base, size_t i) -> float {
@@ -852,7 +854,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         const int tb = (IN_SPATIAL || OUT_SPATIAL) ? tile / C : tile - c * p.tiles_per_c;         // make the waves of a workgroup touch adjacent rows
         if constexpr (PACK_OUT) dst[NCV] = p.out_bound[tb * 32 + jn];
         if constexpr (IN_SPATIAL) {
-            // (group-domain input is read in process(); nothing to prefetch)
+            // group-domain input [b][c][60]: ONE keypoint's contiguous 240-byte row per load instruction (lane = group element), slot i = the
+            // tile's keypoint i; process() transposes through the wave's LDS buffer.  (Lane = keypoint reads -- 64 addresses 30 KB apart per
+            // instruction -- ran at 2.7 TB/s.)
+            const int b0 = tb * 32;
+            static_for<32>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const size_t src = ((size_t)(b0 + i < B ? b0 + i : B - 1) * C + c) * ROREG_G;
+                dst[i] = lane < ROREG_G ? ld_sp(p.x_spatial, src + lane) : 0.f;
+            });
         } else if constexpr (SPLIT != 0) {
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
@@ -909,15 +919,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         f32x16 v[2];
         float wmax = 0.f;                                        // max |value written| for this lane's keypoint (group-domain output)
         if (IN_SPATIAL) {
-            if constexpr (PACK_OUT) cv[NCV] = p.out_bound[b];    // (b < Bp: the bound buffer covers the pad keypoints)
-            const size_t src = ((size_t)bb * C + c) * ROREG_G;
+            load_coefs(next_tile, cnext);                 // the next tile's rows are in flight while this one is transformed
+            __builtin_amdgcn_sched_barrier(0);
+            float *ti = sT + (threadIdx.x >> 6) * (32 * 65);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) ti[i * 65 + lane] = cv[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the buffer is this wave's own: no barrier)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    v[t][r] = g < ROREG_G ? ld_sp(p.x_spatial, src + g) : 0.f;
+                    v[t][r] = g < ROREG_G ? ti[jn * 65 + g] : 0.f;
                 }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // read out before OUT_ROWS reuses the buffer
         } else {
             load_coefs(next_tile, cnext);
             __builtin_amdgcn_sched_barrier(0);          // the prefetch stays ahead of this tile's MFMAs (the scheduler would sink it to save registers)
@@ -982,7 +997,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 if (g >= ROREG_G || !valid) x = 0.f;          // pad keypoints carry zeros through the forward transform: their coefficients are exact 0
                 v[t][r] = x;
                 if (OUT_SPATIAL && g < ROREG_G) {
-                    const int go = p.g_map ? p.g_map[g] : g;
+                    const int go = sGmap[g];
                     if (go >= 0) { tb[jn * 65 + go] = x; wmax = fmaxf(wmax, fabsf(x)); }      // (pad keypoints were zeroed above)
                 }
             }
@@ -1100,10 +1115,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     if (wave_global < n_tiles) {
         const int last = wave_global + ((n_tiles - 1 - wave_global) / n_waves) * n_waves;        // this wave's last tile
         float cb[NCV + 1];
-        if (!IN_SPATIAL) {
-            load_coefs(wave_global, cn);
-            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
-        }
+        load_coefs(wave_global, cn);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
         for (int tile = wave_global; tile <= last; tile += 2 * n_waves) {
             const int t1 = min(tile + n_waves, last), t2 = min(tile + 2 * n_waves, last);
             process(tile, t1, cn, cb);
