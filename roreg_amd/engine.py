@@ -124,6 +124,7 @@ class RegistrationEngine:
         self.feat_dtype = torch.bfloat16 if getattr(cfg, 'dtype', 'fp32') == 'bf16' else torch.float32
         import os
         self.extract_rows = int(os.environ.get('ROREG_EXTRACT_ROWS', 65536))    # keypoints per extractor launch (activations: ~370 KB per keypoint at peak)
+        self.lt_rows = int(os.environ.get('ROREG_LT_ROWS', 131072))                  # correspondences per pass of the ET network (local_transforms_many)
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
 
     def _mark(self, name, t0):
@@ -341,10 +342,11 @@ class RegistrationEngine:
         buf, cnt = hip.mutual_match_batch([(c0.inv, c1.inv, d0, d1)])
         return buf[0], cnt
 
-    def local_transforms_many(self, items, max_rows=32768):
+    def local_transforms_many(self, items, max_rows=None):
         """Des2R + ET + assembly for several pairs: per group of pairs, 2 launches (Des2R, ET input assembly), ONE pass of the ET
         network and 1 launch (quaternion -> transform).  items: [(c0, c1, matches [M,2], sel)] with sel = device int64 rows of
         `matches` to evaluate or None (= all M).  -> [(dr [n], Trans [n,3,4])] per item."""
+        max_rows = self.lt_rows if max_rows is None else max_rows
         out = [None] * len(items)
         sizes = [int(it[3].shape[0]) if it[3] is not None else int(it[2].shape[0]) for it in items]
         i = 0
