@@ -384,18 +384,39 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                 for (int sp = 0; sp < NP; ++sp) a[ot][sp] = wk[sp * ws_plane + ot * 32];
         };
         load_a(0, aw[0]);
+        // The gathered activation fragments are software-pipelined one (position, column block) ahead of their MFMAs, the gather-table
+        // entries one stencil position ahead: the dependent LDS chain index -> fragment (with 65 % of the kernel's LDS cycles being bank
+        // conflicts of the gathered reads) is then off the MFMAs' critical path.
+        int gix[2][4];
+        frag fb[2][NP];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gix[0][t] = gt[gi[t] * KS];
+        auto read_frags = [&](int slot, int t, int set) {
+            const frag *bp = slab + rowbase[t] + slot;
+#pragma unroll
+            for (int sp = 0; sp < NP; ++sp) fb[set][sp] = bp[sp * plane_stride];
+        };
+        read_frags(gix[0][0], 0, 0);
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const frag (&a_cur)[2][NP] = aw[k & 1];
             if (k + 1 < KS) load_a(k + 1, aw[(k + 1) & 1]);
             if (k == 0 && more) issue_raw(c0 + 16);                 // (after the weight loads of k = 1: their wait does not cover the DMA)
+            if (k + 1 < KS) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gix[(k + 1) & 1][t] = gt[gi[t] * KS + k + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);                      // the loads stay ahead of this position's MFMAs (the scheduler would sink them to their use)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const frag *bp = slab + rowbase[t] + gt[gi[t] * KS + k];
+                const int s = k * 4 + t;
+                if (t < 3) read_frags(gix[k & 1][t + 1], t + 1, (s + 1) & 1);
+                else if (k + 1 < KS) read_frags(gix[(k + 1) & 1][0], 0, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const frag (&f)[NP] = fb[s & 1];
                 f32x16 c0v = acc[0][t], c1v = acc[1][t];
                 if constexpr (NP == 3) {
-                    const bf16x8 b1 = bp[0], b2 = bp[plane_stride], b3 = bp[2 * plane_stride];
+                    const bf16x8 b1 = f[0], b2 = f[1], b3 = f[2];
                     c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][2], b1, c0v, 0, 0, 0);
                     c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][2], b1, c1v, 0, 0, 0);
                     c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][1], b2, c0v, 0, 0, 0);
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                     c0v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[0][0], b1, c0v, 0, 0, 0);
                     c1v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[1][0], b1, c1v, 0, 0, 0);
                 } else {
-                    const f16x8 bh = bp[0], bl = bp[plane_stride];
+                    const f16x8 bh = f[0], bl = f[1];
                     c0v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][1], bh, c0v, 0, 0, 0);
                     c1v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][1], bh, c1v, 0, 0, 0);
                     c0v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0][0], bl, c0v, 0, 0, 0);
@@ -418,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                     c1v = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1][0], bh, c1v, 0, 0, 0);
                 }
                 acc[0][t] = c0v; acc[1][t] = c1v;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (more) {
