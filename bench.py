@@ -119,7 +119,7 @@ DTYPE_OF = {'f16x2': 'f32 (f32-accurate, NOT reduced precision: every f32 operan
             'bf16x3': 'f32 (f32-accurate: every f32 operand as 3 bf16 pieces = 24 bits, 6 cross products, f32 accumulate); f64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); f64 estimator'}
 MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}
-KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2,4,1> (GF 256->512 / 512->256 in the irrep domain, fp16 x 2 operands pre-split by ft_nonlin under '
+KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2,4,1,1> (fragment-pipelined 8-wave loop; GF 256->512 / 512->256 in the irrep domain, fp16 x 2 operands pre-split by ft_nonlin under '
                       'per-keypoint block scales: 3 fp16 MFMAs per product)',
              'bf16x3': 'irrep_gemm_split_kernel<32,3,2,1> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
              'f32': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, f32-input MFMA)'}
