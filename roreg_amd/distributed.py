@@ -11,9 +11,9 @@ import torch
 ROW = 21     # scene, id0, id1, n_match, recalltime, trans[0:15] (row-major 4x4 without the final 1), inlier ratio
 
 
-def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=6.0, tolerance=1.05, pair_lists=None):
+def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=7.0, tolerance=1.02, pair_lists=None):
     """pair_counts: {scene: n_pairs}; cloud_counts: {scene: n_clouds}.  Extracting a cloud costs about `cloud_cost` pair-units (measured:
-    ~340 clouds/s against ~2000 pairs/s of the per-pair stages) and is paid again by every rank that holds a slice of the scene --
+    ~380 clouds/s against ~2800 pairs/s of the per-pair stages) and is paid again by every rank that holds a slice of the scene --
     but only for the clouds the slice touches: with pair_lists = {scene: [(id0, id1), ...]} the cost of a range is exact, otherwise
     every slice is charged the whole scene.
     -> list (per rank) of [(scene, start, stop)] pair ranges; every pair appears exactly once."""
@@ -45,18 +45,70 @@ def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=6.0, tol
     for _ in range(8 * max(world_size, 1)):
         if world_size <= 1 or max(loads) <= tolerance * (sum(loads) / world_size):
             break
-        # cut the largest piece of the most loaded rank in two and pack again; keep the cut only if the makespan improves
-        r = int(np.argmax(loads))
-        big = max((p for p in out[r] if p[2] - p[1] >= 2), key=cost, default=None)
-        if big is None:
+        # try cutting every piece in two (at the pair count's midpoint) and pack again; keep the cut that lowers the makespan most.
+        # (Cutting only the largest piece of the most loaded rank, as round 1 did, stops at the first cut LPT packs badly.)
+        best = None
+        for big in pieces:
+            if big[2] - big[1] < 2:
+                continue
+            mid = (big[1] + big[2]) // 2
+            cand = [p for p in pieces if p != big] + [(big[0], big[1], mid), (big[0], mid, big[2])]
+            c_out, c_loads = assign(cand)
+            key = (max(c_loads), sum(c_loads))
+            if best is None or key < best[0]:
+                best = (key, cand, c_out, c_loads)
+        if best is None or best[0][0] >= max(loads) - 1e-9:
             break
-        mid = (big[1] + big[2]) // 2
-        cand = [p for p in pieces if p != big] + [(big[0], big[1], mid), (big[0], mid, big[2])]
-        c_out, c_loads = assign(cand)
-        if max(c_loads) < max(loads) - 1e-9:
-            pieces, out, loads = cand, c_out, c_loads
-        else:
-            break
+        _, pieces, out, loads = best
+    if world_size > 1 and max(loads) > tolerance * (sum(loads) / world_size):
+        # Wrap-around fill: walk the scenes in a fixed order and fill rank after rank up to a makespan T, cutting the scene that does not
+        # fit at the pair where the rank reaches T (the rest goes on to the next rank); the smallest feasible T by bisection.  Every rank
+        # then holds whole scenes plus at most two partial ones -- what a packing of whole pieces cannot do when scenes ~ ranks.
+        def range_end(sc, a, n, budget):
+            """largest b in (a, n] with cost((sc, a, b)) <= budget, or a if even one pair does not fit"""
+            lo, hi = a, n
+            while lo < hi:
+                mid = (lo + hi + 1) // 2
+                if cost((sc, a, mid)) <= budget:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            return lo
+
+        def fill(order, T):
+            plan, r, load = [[] for _ in range(world_size)], 0, 0.0
+            for sc in order:
+                a, n = 0, pair_counts[sc]
+                while a < n:
+                    if r >= world_size:
+                        return None
+                    b = range_end(sc, a, n, T - load)
+                    if b == a:                                     # nothing of this scene fits on this rank any more
+                        if load == 0.0:
+                            return None                            # ... not even on an empty rank: T is too small
+                        r += 1; load = 0.0
+                        continue
+                    plan[r].append((sc, a, b)); load += cost((sc, a, b)); a = b
+            return plan
+
+        whole = {sc: cost((sc, 0, n)) for sc, n in pair_counts.items() if n > 0}
+        orders = [sorted(whole, key=lambda q: (-whole[q], q)), sorted(whole, key=lambda q: (whole[q], q)), sorted(whole)]
+        best_plan, best_T = None, max(loads)
+        for order in orders:
+            lo, hi = sum(whole.values()) / world_size, max(loads)
+            for _ in range(24):
+                mid = 0.5 * (lo + hi)
+                if fill(order, mid) is not None:
+                    hi = mid
+                else:
+                    lo = mid
+            cand = fill(order, hi)
+            if cand is not None:
+                T = max(sum(cost(p) for p in r) for r in cand)
+                if T < best_T - 1e-9:
+                    best_plan, best_T = cand, T
+        if best_plan is not None:
+            out = best_plan
     # contiguous ranges of one scene that landed on the same rank are merged
     for r in range(world_size):
         out[r].sort()

@@ -215,6 +215,33 @@ def test_shard_scenes_balanced_and_complete():
         assert max(loads) <= 1.25 * sum(counts.values()) / world + 1
 
 
+def test_shard_scenes_full_benchmark_shape_with_pair_lists():
+    """bench.py's plan: exact per-range cloud counts; complete at every world size; modelled efficiency (one-rank cost / (N x makespan)) >= 0.97
+    at 2 and 4 ranks and >= 0.83 at 8 (a scene's slices each re-extract the clouds they touch; the wrap-around fill cuts at most one
+    scene per rank boundary)."""
+    from roreg_amd import synth
+    from roreg_amd.distributed import shard_scenes
+    names = synth.THREEDMATCH_SCENES
+    clouds = dict(zip(names, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(names, synth.THREEDMATCH_PAIRS))
+    lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + i) for i, s in enumerate(names)}
+    cost1 = sum(npairs.values()) + 7.0 * sum(clouds.values())
+    for world, floor in ((1, 0.999), (2, 0.97), (4, 0.97), (8, 0.83)):
+        plan = shard_scenes(npairs, world, clouds, pair_lists=lists)
+        seen = {}
+        loads = []
+        for r in plan:
+            load = 0.0
+            for scene, a, b in r:
+                assert 0 <= a < b <= npairs[scene]
+                seen.setdefault(scene, []).append((a, b))
+                load += (b - a) + 7.0 * len({i for pr in lists[scene][a:b] for i in pr})
+            loads.append(load)
+        for scene, n in npairs.items():
+            rs = sorted(seen[scene])
+            assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(len(rs) - 1))
+        assert cost1 / (world * max(loads)) >= floor, (world, cost1 / (world * max(loads)))
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
