@@ -21,6 +21,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -113,6 +114,32 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[
     return c;
 }
 
+// fp16 x 2 operands (round 2): every descriptor ROW carries its own power-of-two scale 2^e with 2^e |x_f| <= 2^e |x| < 2^14, taken from the
+// row's squared norm; hi = fp16(2^e x), lo = fp16(2^e x - hi); three cross products (lo.hi, hi.lo, hi.hi), f32 accumulate, the tile
+// element rescaled by the exact 2^-(e_i + e_j).  Error of the dot product <= ~3 * 2^-22 sum_f |s_f t_f| + 32 * 2^-39 |s||t| (elements
+// more than 11 binades below the row's norm keep an absolute error of 2^-39 of it) < 1e-6 |s||t|: fifty times inside the candidate
+// margin of 1e-4 (|s_i|^2 + max |t|^2), which is relative to the ROW's own norm -- hence the per-row scale.  Half the MFMAs of 3 x bf16.
+__device__ __forceinline__ int norm_exp(float n2) {
+    if (!(n2 > 0.f) || !(n2 < __builtin_inff())) return 0;
+    int ex;
+    (void)frexpf(n2, &ex);                          // n2 = m 2^ex, m in [0.5, 1): |x| = sqrt(n2) < 2^ceil(ex / 2)
+    return 14 - ((ex + 1) >> 1);
+}
+__device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * scale;
+        const _Float16 h1 = (_Float16)x;
+        hi[e] = h1; lo[e] = (_Float16)(x - (float)h1);
+    }
+}
+__device__ __forceinline__ f32x16 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+
 // the reference's literal distance (nn_search_kernel's arithmetic)
 __device__ __forceinline__ float exact_dist(const float *__restrict__ s, const float *__restrict__ t) {
     float acc = 0.f;
@@ -126,10 +153,11 @@ __device__ __forceinline__ float exact_dist(const float *__restrict__ s, const f
 
 // One 128 x 128 tile of the distance matrix of one pair.  VERIFY = false: approximate row / column minima.  VERIFY = true:
 // candidates -> exact distances -> packed keys.  4 waves as a 2 x 2 grid of 64 x 64 blocks (2 x 2 MFMA tiles each).
-template <bool VERIFY>
+template <bool VERIFY, int NP /* 3: bf16 x 3, 2: fp16 x 2 with per-row scales */>
 __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__restrict__ tasks, int P, char *__restrict__ wsb) {
     __shared__ __attribute__((aligned(16))) float S[TILE * LP], T[TILE * LP];
     __shared__ float n0s[TILE], n1s[TILE], thr0[TILE], thr1[TILE];
+    __shared__ float xs0[TILE], xs1[TILE], is0[TILE], is1[TILE];     // NP = 2: the rows' scales 2^e and 2^-e (1 for NP = 3)
     const int task = blockIdx.z;
     const MatchTask t = tasks[task];
     const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
@@ -150,6 +178,8 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
         if (tid < TILE) {
             const float a = w.N[i0 + tid], b = w.N[(size_t)P + j0 + tid];
             n0s[tid] = a; n1s[tid] = b;
+            const int ea = NP == 2 ? norm_exp(a) : 0, eb = NP == 2 ? norm_exp(b) : 0;
+            xs0[tid] = ldexpf(1.f, ea); is0[tid] = ldexpf(1.f, -ea); xs1[tid] = ldexpf(1.f, eb); is1[tid] = ldexpf(1.f, -eb);
             if (VERIFY) {
                 const float mx0 = __uint_as_float(w.MX[0]), mx1 = __uint_as_float(w.MX[1]);
                 thr0[tid] = o2f(w.AM[i0 + tid]) + (1e-4f * (a + mx1) + 1e-6f);
@@ -169,27 +199,37 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
             for (int r = 0; r < 16; ++r) { c[a][b][r] = 0.f; ct[a][b][r] = 0.f; }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-        bf16x8 sf[2][3], tf[2][3];                  // fragments of the wave's two 32-row groups of S (rows wm*64..) and T (rows wn*64..)
+        using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
+        frag sf[2][NP], tf[2][NP];                  // fragments of the wave's two 32-row groups of S (rows wm*64..) and T (rows wn*64..)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             float x8[8];
-            const float4 *ps = reinterpret_cast<const float4 *>(S + (wm * 64 + g * 32 + jl) * LP + st * 16 + h * 8);
+            const int rs = wm * 64 + g * 32 + jl, rt = wn * 64 + g * 32 + jl;
+            const float4 *ps = reinterpret_cast<const float4 *>(S + rs * LP + st * 16 + h * 8);
             const float4 u0 = ps[0], u1 = ps[1];
             x8[0] = u0.x; x8[1] = u0.y; x8[2] = u0.z; x8[3] = u0.w; x8[4] = u1.x; x8[5] = u1.y; x8[6] = u1.z; x8[7] = u1.w;
-            split3(x8, sf[g][0], sf[g][1], sf[g][2]);
-            const float4 *pt = reinterpret_cast<const float4 *>(T + (wn * 64 + g * 32 + jl) * LP + st * 16 + h * 8);
+            if constexpr (NP == 3) split3(x8, sf[g][0], sf[g][1], sf[g][2]); else split2(x8, xs0[rs], sf[g][0], sf[g][1]);
+            const float4 *pt = reinterpret_cast<const float4 *>(T + rt * LP + st * 16 + h * 8);
             const float4 v0 = pt[0], v1 = pt[1];
             x8[0] = v0.x; x8[1] = v0.y; x8[2] = v0.z; x8[3] = v0.w; x8[4] = v1.x; x8[5] = v1.y; x8[6] = v1.z; x8[7] = v1.w;
-            split3(x8, tf[g][0], tf[g][1], tf[g][2]);
+            if constexpr (NP == 3) split3(x8, tf[g][0], tf[g][1], tf[g][2]); else split2(x8, xs1[rt], tf[g][0], tf[g][1]);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                c[a][b] = mfma6(sf[a], tf[b], c[a][b]);                 // rows i = wm*64 + a*32 + .., column j = wn*64 + b*32 + jl
-                if (!VERIFY) ct[a][b] = mfma6(tf[a], sf[b], ct[a][b]);  // rows j = wn*64 + a*32 + .., column i = wm*64 + b*32 + jl
+                if constexpr (NP == 3) {
+                    c[a][b] = mfma6(sf[a], tf[b], c[a][b]);                 // rows i = wm*64 + a*32 + .., column j = wn*64 + b*32 + jl
+                    if (!VERIFY) ct[a][b] = mfma6(tf[a], sf[b], ct[a][b]);  // rows j = wn*64 + a*32 + .., column i = wm*64 + b*32 + jl
+                } else {
+                    c[a][b] = mfma3(sf[a], tf[b], c[a][b]);
+                    if (!VERIFY) ct[a][b] = mfma3(tf[a], sf[b], ct[a][b]);
+                }
             }
     }
+    // the dot product of row i and column j in real units: accumulator * 2^-e_i * 2^-e_j (exact; both factors are 1 for NP = 3)
+#define DOT_C(a, b, r, ir, jc) (NP == 2 ? (c[a][b][r] * is0[ir]) * is1[jc] : c[a][b][r])
+#define DOT_CT(a, b, r, jr, ic) (NP == 2 ? (ct[a][b][r] * is1[jr]) * is0[ic] : ct[a][b][r])
 
     if (!VERIFY) {
         // column minima of C: over the wave's 64 rows i, for column j  -> amin1[j]
@@ -203,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ir = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mn = fminf(mn, (n0s[ir] + nj) - 2.f * c[a][b][r]);
+                    mn = fminf(mn, (n0s[ir] + nj) - 2.f * DOT_C(a, b, r, ir, jc));
                 }
             mn = fminf(mn, __shfl_xor(mn, 32));
             if (h == 0 && j0 + jc < t.m1) atomicMin(&w.AM[(size_t)P + j0 + jc], f2o(mn));
@@ -219,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int jr = wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mn = fminf(mn, (ni + n1s[jr]) - 2.f * ct[a][b][r]);
+                    mn = fminf(mn, (ni + n1s[jr]) - 2.f * DOT_CT(a, b, r, jr, ic));
                 }
             mn = fminf(mn, __shfl_xor(mn, 32));
             if (h == 0 && i0 + ic < t.m0) atomicMin(&w.AM[i0 + ic], f2o(mn));
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ir = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float av = (n0s[ir] + nj) - 2.f * c[a][b][r];
+                    const float av = (n0s[ir] + nj) - 2.f * DOT_C(a, b, r, ir, jc);
                     const bool k0 = av <= thr0[ir], k1 = av <= tj;          // candidate of row i / of column j
                     if (k0 || k1) {
                         const float d = exact_dist(S + ir * LP, T + jc * LP);
@@ -245,6 +285,8 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
                 }
         }
     }
+#undef DOT_C
+#undef DOT_CT
 }
 
 __global__ __launch_bounds__(1024) void mm_mutual_kernel(const MatchTask *__restrict__ tasks, int P, char *__restrict__ wsb, int out_pitch,
@@ -318,8 +360,15 @@ extern "C" int roreg_mutual_match_batch(const roreg_match_task *tasks_dev, int n
         hipLaunchKernelGGL(mm_maxnorm_kernel, dim3(P / 256 + 1, 1, 2 * n_tasks), dim3(256), 0, s, tasks, P, ws);
         const dim3 grid(P / TILE, P / TILE, n_tasks);
         roreg::ProfScope prof(roreg::PROF_MM_TILE, s);        // (one scope = the two passes of the distance matrix)
-        hipLaunchKernelGGL(mm_tile_kernel<false>, grid, dim3(256), 0, s, tasks, P, ws);
-        hipLaunchKernelGGL(mm_tile_kernel<true>, grid, dim3(256), 0, s, tasks, P, ws);
+        // ROREG_MATCH_BF16X3=1 selects the 3 x bf16 operand split of round 1 (twice the MFMAs; same results: the exact check decides)
+        static const bool bf16x3 = [] { const char *e = getenv("ROREG_MATCH_BF16X3"); return e && e[0] == '1'; }();
+        if (bf16x3) {
+            hipLaunchKernelGGL((mm_tile_kernel<false, 3>), grid, dim3(256), 0, s, tasks, P, ws);
+            hipLaunchKernelGGL((mm_tile_kernel<true, 3>), grid, dim3(256), 0, s, tasks, P, ws);
+        } else {
+            hipLaunchKernelGGL((mm_tile_kernel<false, 2>), grid, dim3(256), 0, s, tasks, P, ws);
+            hipLaunchKernelGGL((mm_tile_kernel<true, 2>), grid, dim3(256), 0, s, tasks, P, ws);
+        }
     }
     hipLaunchKernelGGL(mm_mutual_kernel, dim3(n_tasks), dim3(1024), 0, s, tasks, P, ws, out_pitch, match_out, counts_out);
     ROREG_CHECK_LAUNCH("roreg_mutual_match_batch");
