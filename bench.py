@@ -342,14 +342,15 @@ def main():
             'roofline': roofline_obj(args.gemm, achieved, ms, n_launch, traffic, alg_bytes),
             # the kernels north_star names, measured with HIP events on the launch stream in the same timed steps (rank 0)
             'roofline_distance_gemm': None if not mm_n else {
-                'kernel': 'mm_tile_kernel<false> + mm_tile_kernel<true> (5000 x 5000 x 32 descriptor distances of every pair of a scene, both search directions; '
-                          'fp16 x 2 split MFMA bound under per-row scales + exact re-check)', 'bound': 'mfma', 'unit': 'TFLOP/s', 'launch_pairs': mm_n, 'avg_ms': mm_ms / mm_n,
-                'algorithmic_tflops': mm_flop / (mm_ms * 1e-3) / 1e12, 'achieved': 9.0 * mm_flop / (mm_ms * 1e-3) / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS,
-                'frac': 9.0 * mm_flop / (mm_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                'note': 'executed = 9 x algorithmic: three products (pass A: S.T^T for the column minima and T.S^T for the row minima; pass B: S.T^T again for the '
-                        'candidate test) x three fp16 MFMAs per f32-accurate product (round 1 used six bf16 MFMAs; rounds 1-2 reported 24 x, counting a fourth '
-                        'product that pass B never computes).  K = 32: the matrix cores are ~20 % of the kernel, the rest is tile staging, operand split and '
-                        'the min / candidate search over every one of the 128 x 128 tile elements (VALU)'},
+                'kernel': 'mm_strip_kernel<false> + mm_strip_kernel<true> (5000 x 5000 x 32 descriptor distances of every pair of a scene, both search directions; '
+                          'fp16 x 2 split MFMA bound under per-row scales + exact re-check; one workgroup per 128-row strip, column tiles streamed by LDS-DMA)',
+                'bound': 'mfma', 'unit': 'TFLOP/s', 'launch_pairs': mm_n, 'avg_ms': mm_ms / mm_n,
+                'algorithmic_tflops': mm_flop / (mm_ms * 1e-3) / 1e12, 'achieved': 6.0 * mm_flop / (mm_ms * 1e-3) / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS,
+                'frac': 6.0 * mm_flop / (mm_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                'note': 'executed = 6 x algorithmic: two products (S.T^T in pass A for the row AND column minima, again in pass B for the candidate test) x '
+                        'three fp16 MFMAs per f32-accurate product (round 1: a third product T.S^T and six bf16 MFMAs each = 18 x, reported as 24 x).  With K = 32 '
+                        'the matrix cores are a small part of the kernel: the rest is the operand split and the min / candidate search over every one '
+                        'of the tile elements on the vector ALUs'},
             'roofline_ransac': None if not rs_n else {
                 'kernel': 'ransac_score_batch_kernel (one wave per hypothesis over the pair\'s M correspondences, fp64, no FMA contraction: bit-exact masks)',
                 'bound': 'fp64-valu', 'unit': 'TFLOP/s', 'launches': rs_n, 'avg_ms': rs_ms / rs_n, 'achieved': rs_flop / (rs_ms * 1e-3) / 1e12,

@@ -289,6 +289,198 @@ __global__ __launch_bounds__(256, 2) void mm_tile_kernel(const MatchTask *__rest
 #undef DOT_CT
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-strip form of the two passes (round 2): one workgroup owns a 128-row strip of S and walks ALL column tiles of T.
+//  * S is staged and split into fragment registers once per strip; the T tiles stream through a double-buffered LDS area by LDS-DMA,
+//    the NEXT tile in flight under the current tile's MFMAs and epilogue -- the per-tile form above stages 32 KB
+//    and waits for it before every 48-96 MFMAs (latency-bound: 2 workgroups per CU cannot cover a 1-2 us round trip per tile);
+//  * row minima are an ELEMENTWISE running minimum in registers across the strip (one cross-lane reduction at the end), so the second
+//    product C' = T.S^T of pass A is not needed at all: two products per pair instead of three;
+//  * column minima go to an LDS array over all columns (LDS atomics) and are flushed once per strip.
+// Tiles are stored unpadded with their 16-byte pieces swizzled (piece c of row r at slot c ^ ((r >> 1) & 7)): what LDS-DMA can write
+// (lane-linear destination, the permutation applied to the SOURCE address) and conflict-free for the fragment reads' lane groups.
+constexpr int TP = TILE * F;                         // floats per tile
+__device__ __forceinline__ int swz_piece(int row, int c) { return row * 8 + (c ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ float exact_dist_swz(const float *__restrict__ s_tile, int ir, const float *__restrict__ t_tile, int jc) {
+    float acc = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const float sv = s_tile[swz_piece(ir, f >> 2) * 4 + (f & 3)], tv = t_tile[swz_piece(jc, f >> 2) * 4 + (f & 3)];
+        const float d = __fsub_rn(sv, tv);
+        acc = __fadd_rn(acc, __fmul_rn(d, d));
+    }
+    return sqrtf(__fadd_rn(acc, 1e-7f));
+}
+
+template <bool VERIFY>
+__global__ __launch_bounds__(256, 2) void mm_strip_kernel(const MatchTask *__restrict__ tasks, int P, char *__restrict__ wsb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *S = reinterpret_cast<float *>(smem);                  // [128][32] swizzled
+    float *Tb = S + TP;                                           // [2][128][32] swizzled
+    float *n0s = Tb + 2 * TP, *xs0 = n0s + TILE, *is0 = xs0 + TILE, *thr0 = is0 + TILE;
+    float *n1s = thr0 + TILE, *xs1 = n1s + 2 * TILE, *is1 = xs1 + 2 * TILE, *thr1 = is1 + 2 * TILE;      // [2][128] each
+    unsigned *cm = reinterpret_cast<unsigned *>(thr1 + 2 * TILE);                                          // [P] (pass A)
+    const int task = blockIdx.y;
+    const MatchTask t = tasks[task];
+    const int i0 = blockIdx.x * TILE;
+    if (i0 >= t.m0 || t.m1 <= 0) return;
+    const WS w = ws_of(wsb, task, P);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv & 1, wn = wv >> 1, jl = lane & 31, h = lane >> 5;
+    const int ntj = (t.m1 + TILE - 1) / TILE;
+    const float mx0 = VERIFY ? __uint_as_float(w.MX[0]) : 0.f, mx1 = VERIFY ? __uint_as_float(w.MX[1]) : 0.f;
+
+    auto dma_tile = [&](const float *src, float *dst) {          // 128 rows x 128 B, contiguous in global memory
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = k * 256 + tid, row = q >> 3, cs = q & 7;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + swz_piece(row, cs) * 4),
+                                             (__attribute__((address_space(3))) void *)(dst + (k * 256 + wv * 64) * 4), 16, 0, 0);
+        }
+    };
+    // per-column constants of a tile: waves 0-1 fetch the squared norms, waves 2-3 (pass B) the approximate column minima
+    auto load_consts = [&](int jt) -> float {
+        const int r = tid & (TILE - 1);
+        if (tid < TILE) return w.N[(size_t)P + jt * TILE + r];
+        return VERIFY ? o2f(w.AM[(size_t)P + jt * TILE + r]) : 0.f;
+    };
+    auto store_consts = [&](int buf, float v) {                  // (the norm's thread also derives the scales; the threshold needs the norm: second half reads it)
+        const int r = tid & (TILE - 1);
+        if (tid < TILE) {
+            const int e = norm_exp(v);
+            n1s[buf * TILE + r] = v; xs1[buf * TILE + r] = ldexpf(1.f, e); is1[buf * TILE + r] = ldexpf(1.f, -e);
+        } else if (VERIFY) thr1[buf * TILE + r] = v;             // approximate minimum; the margin is added at use (it needs the norm)
+    };
+
+    dma_tile(w.G + (size_t)i0 * F, S);
+    dma_tile(w.G + (size_t)P * F, Tb);
+    {
+        const float c0 = load_consts(0);
+        if (tid < TILE) {
+            const float a = w.N[i0 + tid];
+            const int e = norm_exp(a);
+            n0s[tid] = a; xs0[tid] = ldexpf(1.f, e); is0[tid] = ldexpf(1.f, -e);
+            if (VERIFY) thr0[tid] = o2f(w.AM[i0 + tid]) + (1e-4f * (a + mx1) + 1e-6f);
+        }
+        store_consts(0, c0);
+        if (!VERIFY)
+            for (int j = tid; j < P; j += 256) cm[j] = 0xffffffffu;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // the strip's S fragments: [st][g][hi, lo]
+    f16x8 sf[2][2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int rs = wm * 64 + g * 32 + jl;
+            const float4 u0 = *reinterpret_cast<const float4 *>(S + swz_piece(rs, st * 4 + h * 2) * 4);
+            const float4 u1 = *reinterpret_cast<const float4 *>(S + swz_piece(rs, st * 4 + h * 2 + 1) * 4);
+            const float x8[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            split2(x8, xs0[rs], sf[st][g][0], sf[st][g][1]);
+        }
+    f32x16 rmin[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rmin[a][r] = __builtin_inff();
+
+    for (int jt = 0; jt < ntj; ++jt) {
+        const int buf = jt & 1, j0 = jt * TILE;
+        const float *T = Tb + buf * TP;
+        float cnext = 0.f;
+        if (jt + 1 < ntj) {                                      // (uniform) the next tile travels under this tile's work
+            dma_tile(w.G + ((size_t)P + j0 + TILE) * F, Tb + (buf ^ 1) * TP);
+            cnext = load_consts(jt + 1);
+        }
+        f32x16 c[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 tf[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int rt = wn * 64 + g * 32 + jl;
+                const float4 v0 = *reinterpret_cast<const float4 *>(T + swz_piece(rt, st * 4 + h * 2) * 4);
+                const float4 v1 = *reinterpret_cast<const float4 *>(T + swz_piece(rt, st * 4 + h * 2 + 1) * 4);
+                const float x8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split2(x8, xs1[buf * TILE + rt], tf[g][0], tf[g][1]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) c[a][b] = mfma3(sf[st][a], tf[b], c[a][b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int jc = wn * 64 + b * 32 + jl;
+            const float nj = n1s[buf * TILE + jc], isj = is1[buf * TILE + jc];
+            if constexpr (!VERIFY) {
+                float mn = __builtin_inff();
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ir = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float av = (n0s[ir] + nj) - 2.f * ((c[a][b][r] * is0[ir]) * isj);
+                        mn = fminf(mn, av);
+                        rmin[a][r] = fminf(rmin[a][r], av);
+                    }
+                mn = fminf(mn, __shfl_xor(mn, 32));
+                if (h == 0) atomicMin(cm + j0 + jc, f2o(mn));                      // LDS
+            } else {
+                const float tj = thr1[buf * TILE + jc] + (1e-4f * (nj + mx0) + 1e-6f);
+                // candidate masks first (bit a*16 + r), the rare exact evaluations afterwards in ONE loop body: 64 inlined copies of the
+                // literal distance made the kernel 100 KB of code and spilled registers
+                unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ir = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float av = (n0s[ir] + nj) - 2.f * ((c[a][b][r] * is0[ir]) * isj);
+                        m0 |= (av <= thr0[ir] ? 1u : 0u) << (a * 16 + r);          // candidate of row i
+                        m1 |= (av <= tj ? 1u : 0u) << (a * 16 + r);                // candidate of column j
+                    }
+                unsigned m = m0 | m1;
+                while (m) {
+                    const int q = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int ir = wm * 64 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
+                    const float d = exact_dist_swz(S, ir, T, jc);
+                    const unsigned long long db = (unsigned long long)__float_as_uint(d) << 32;
+                    if (((m0 >> q) & 1u) && j0 + jc < t.m1) atomicMin(&w.PK[i0 + ir], db | (unsigned)(j0 + jc));
+                    if (((m1 >> q) & 1u) && i0 + ir < t.m0) atomicMin(&w.PK[(size_t)P + j0 + jc], db | (unsigned)(i0 + ir));
+                }
+            }
+        }
+        if (jt + 1 < ntj) store_consts(buf ^ 1, cnext);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // the next tile has landed, this wave is done with the current one
+        __syncthreads();
+    }
+    if constexpr (!VERIFY) {
+        // row minima: reduce the elementwise minima over the 32 column lanes; the two column-half waves of a row group meet in the atomic
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = rmin[a][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+                const int ir = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (jl == 0 && i0 + ir < t.m0) atomicMin(&w.AM[i0 + ir], f2o(v));
+            }
+        for (int j = tid; j < t.m1; j += 256) atomicMin(&w.AM[(size_t)P + j], cm[j]);     // (complete: the loop ended with a barrier)
+    }
+}
+
 __global__ __launch_bounds__(1024) void mm_mutual_kernel(const MatchTask *__restrict__ tasks, int P, char *__restrict__ wsb, int out_pitch,
                                                          int64_t *__restrict__ match_all, int32_t *__restrict__ counts) {
     __shared__ int wave_cnt[16];
@@ -360,9 +552,20 @@ extern "C" int roreg_mutual_match_batch(const roreg_match_task *tasks_dev, int n
         hipLaunchKernelGGL(mm_maxnorm_kernel, dim3(P / 256 + 1, 1, 2 * n_tasks), dim3(256), 0, s, tasks, P, ws);
         const dim3 grid(P / TILE, P / TILE, n_tasks);
         roreg::ProfScope prof(roreg::PROF_MM_TILE, s);        // (one scope = the two passes of the distance matrix)
-        // ROREG_MATCH_BF16X3=1 selects the 3 x bf16 operand split of round 1 (twice the MFMAs; same results: the exact check decides)
+        // ROREG_MATCH_BF16X3=1 selects the 3 x bf16 operand split of round 1 (twice the MFMAs; same results: the exact check decides);
+        // ROREG_MATCH_TILES=1 the per-tile form of the fp16 x 2 kernel instead of the row-strip form
         static const bool bf16x3 = [] { const char *e = getenv("ROREG_MATCH_BF16X3"); return e && e[0] == '1'; }();
-        if (bf16x3) {
+        static const bool tiles = [] { const char *e = getenv("ROREG_MATCH_TILES"); return e && e[0] == '1'; }();
+        const size_t lds_strip = (size_t)(3 * TP + 12 * TILE) * 4 + (size_t)P * 4;
+        if (!bf16x3 && !tiles && lds_strip <= 80 * 1024) {
+            const dim3 sgrid(P / TILE, n_tasks);
+            auto ka = mm_strip_kernel<false>; auto kb = mm_strip_kernel<true>;
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_strip);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_strip);
+            if (e1 != hipSuccess || e2 != hipSuccess) { roreg::set_error("roreg_mutual_match_batch: hipFuncSetAttribute(%zu) failed", lds_strip); return 1; }
+            hipLaunchKernelGGL(ka, sgrid, dim3(256), lds_strip, s, tasks, P, ws);
+            hipLaunchKernelGGL(kb, sgrid, dim3(256), lds_strip, s, tasks, P, ws);
+        } else if (bf16x3) {
             hipLaunchKernelGGL((mm_tile_kernel<false, 3>), grid, dim3(256), 0, s, tasks, P, ws);
             hipLaunchKernelGGL((mm_tile_kernel<true, 3>), grid, dim3(256), 0, s, tasks, P, ws);
         } else {
