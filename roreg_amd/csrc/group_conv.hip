@@ -532,18 +532,20 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
     float xscale = 1.f;
     if constexpr (NP == 2) xscale = ldexpf(1.f, row_scale_exp(p.sc, brow));     // this thread stages one row: the row's own block scale
     const bool has_act = p.scale != nullptr;
-    float4 xa, xb;
+    float4 xa, xb, s0, s1, t0, t1;
     auto load_x = [&](int ks) {
         const int kk = (ks < nsteps ? ks : nsteps - 1) * 16;
         xa = *reinterpret_cast<const float4 *>(xrow + kk);
         xb = *reinterpret_cast<const float4 *>(xrow + kk + 4);
+        if (has_act) {      // the k-octet's BatchNorm constants travel with it (loaded inside convert_store they cost an exposed L2 round trip per step)
+            const int kq = kk + 8 * sho;
+            s0 = *reinterpret_cast<const float4 *>(p.scale + kq); s1 = *reinterpret_cast<const float4 *>(p.scale + kq + 4);
+            t0 = *reinterpret_cast<const float4 *>(p.shift + kq); t1 = *reinterpret_cast<const float4 *>(p.shift + kq + 4);
+        }
     };
     auto convert_store = [&](int ks, int buf) {
         float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         if (has_act) {
-            const int kk = (ks < nsteps ? ks : nsteps - 1) * 16 + 8 * sho;
-            const float4 s0 = *reinterpret_cast<const float4 *>(p.scale + kk), s1 = *reinterpret_cast<const float4 *>(p.scale + kk + 4);
-            const float4 t0 = *reinterpret_cast<const float4 *>(p.shift + kk), t1 = *reinterpret_cast<const float4 *>(p.shift + kk + 4);
             const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
