@@ -495,3 +495,38 @@ def test_knn_search_segmented_equals_per_cloud():
         want = hip.knn_search(cu(c), cu(c), 5).cpu().numpy()
         assert np.array_equal(got[o:o + len(c)], want)
         o += len(c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env', [{'ROREG_MATCH_TILES': '1'}, {'ROREG_MATCH_BF16X3': '1'}, {'ROREG_GEMM_PIPE': '0'}],
+                         ids=['matcher per-tile form', 'matcher 3 x bf16 split', 'GEMM loop without fragment pipelining'])
+def test_alternative_kernel_forms_stay_correct(env):
+    """The kernel variants kept behind environment switches (the per-tile matcher passes, the matcher's 3 x bf16 operand split, the
+    irrep GEMM's plain loop) are chosen once per process, so each runs the relevant exactness tests in a process of its own."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if 'ROREG_GEMM_PIPE' in env:
+        args = ['tests/test_hip_fourier.py', '-k', 'gemm or extractor or batch_invariant']
+    else:
+        args = ['tests/test_hip_kernels.py', '-k', 'mutual or matcher']
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'] + args + ['--deselect',
+                        'tests/test_hip_kernels.py::test_alternative_kernel_forms_stay_correct'], cwd=root, env=dict(os.environ, **env),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and ' passed' in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_gemm_pipelined_loop_is_bitwise_the_plain_loop():
+    """irrep GEMM (fp16 x 2, 256 x 256 tile): the fragment-pipelined loop issues the same MFMAs per accumulator in the same order as
+    the plain loop -- identical bits on a 61440-keypoint launch with heavy-tailed operands and bound propagation (tools/gemm_checksum.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for pipe in ('1', '0'):
+        r = subprocess.run([sys.executable, 'tools/gemm_checksum.py'], cwd=root, env=dict(os.environ, ROREG_GEMM_PIPE=pipe), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith('checksum')]
+        assert r.returncode == 0 and lines, r.stdout.decode()[-2000:]
+        sums.append(lines[-1])
+    assert sums[0] == sums[1], sums
