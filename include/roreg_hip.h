@@ -61,11 +61,12 @@ int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias
 
 /* Dense layer on row-major activations with the same f32-accurate 3 x bf16 split:
  *   out[b][o] = bias[o] + sum_k W[o][k] * act_k(x[b][k]) (+ residual[b][o]),  act_k(v) = max(v*scale[k] + shift[k], 0) or identity (scale NULL).
- * x [B][K] f32 (K % 16 == 0), out / residual [B][O].  wsplit: bf16 bits [3 planes][K/16][2 k-octets][round_up(O,256)][8] (zero rows beyond O).
+ * x [B][K] f32 (K % 16 == 0), out [B][O]; residual element (b, o) is read at residual[(b*O + o) * residual_stride] (1 = a dense [B][O]
+ * tensor; 48 = column 0 of a [B][O][48] group-domain tensor: the ET trunk's identity short cut without a gathering copy).  wsplit: bf16 bits [3 planes][K/16][2 k-octets][round_up(O,256)][8] (zero rows beyond O).
  * Used for the ET trunk's last layer (K = 512*13: the 13-column stencil of the single live output column, gather folded into the weight
  * order; network/eqv_trans.py:101-117, network/ops.py:58-62) and the 1x1 head (network/eqv_trans.py:91-99,130-136). */
 int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
-                      const float *residual, float *out, int B, int K, int O, void *stream);
+                      const float *residual, int residual_stride, float *out, int B, int K, int O, void *stream);
 
 /* fp16 x 2 variants of the two entries above (half the matrix-core work; operands as hi + lo fp16 under a power-of-two block scale, see
  * roreg_irrep_gemm_f16x2).  The block is ONE ROW (keypoint / correspondence) b of x: its scale is derived on the device from the bound
@@ -77,7 +78,7 @@ int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const
                            float act_smax, float act_tmax, const float *in_rowmax_dev, float *out, float *out_rowmax_dev,
                            const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
 int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
-                      float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, float *out,
+                      float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, int residual_stride, float *out,
                       float *out_rowmax_dev, int B, int K, int O, void *stream);
 
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);

@@ -492,7 +492,8 @@ struct DenseParams {
     const void *ws;                // [NP][K/16][2][Opad][8], Opad = round_up(O, 256)
     const float *bias;             // [O]
     const float *scale, *shift;    // [K] or null
-    const float *res;              // [B][O] or null
+    const float *res;              // [B][O] or null; element (b, o) at res[(b * O + o) * res_stride]
+    int res_stride;
     float *out;                    // [B][O]
     int B, K, O, Opad;
     SplitScale sc;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
                 const int b = b0 + row;
                 if (b < p.B) {
                     float v = (NP == 2 ? acc[rt][t][r] * so[row] : acc[rt][t][r]) + bo;
-                    if (p.res) v += p.res[(size_t)b * p.O + o];
+                    if (p.res) v += p.res[((size_t)b * p.O + o) * p.res_stride];
                     p.out[(size_t)b * p.O + o] = v;
                     wmax[rt][r] = fmaxf(wmax[rt][r], fabsf(v));
                 }
@@ -877,27 +878,28 @@ static int launch_dense(DenseParams p, hipStream_t s) {
 }
 
 static int dense_common(int np, const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
-                        const float *residual, float *out, int B, int K, int O, SplitScale sc, void *stream) {
+                        const float *residual, int residual_stride, float *out, int B, int K, int O, SplitScale sc, void *stream) {
     if (B == 0) return 0;
     ROREG_REQUIRE(x && wsplit && bias && out && B > 0 && K > 0 && O > 0, "roreg_dense_split: bad arguments");
     ROREG_REQUIRE((scale == nullptr) == (shift == nullptr), "roreg_dense_split: scale/shift must come together");
     ROREG_REQUIRE(K % 16 == 0, "roreg_dense_split: K must be a multiple of 16 (got %d)", K);
+    ROREG_REQUIRE(!residual || residual_stride >= 1, "roreg_dense_split: residual_stride must be >= 1 (got %d)", residual_stride);
     DenseParams p;
-    p.x = x; p.ws = wsplit; p.bias = bias; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
+    p.x = x; p.ws = wsplit; p.bias = bias; p.scale = scale; p.shift = shift; p.res = residual; p.res_stride = residual_stride; p.out = out;
     p.B = B; p.K = K; p.O = O; p.Opad = round_up(O, 256); p.sc = sc;
     return np == 3 ? launch_dense<3>(p, roreg::as_stream(stream)) : launch_dense<2>(p, roreg::as_stream(stream));
 }
 
 extern "C" int roreg_dense_split(const float *x, const void *wsplit, const float *bias, const float *scale, const float *shift,
-                                 const float *residual, float *out, int B, int K, int O, void *stream) {
+                                 const float *residual, int residual_stride, float *out, int B, int K, int O, void *stream) {
     SplitScale sc = {nullptr, 1.f, 0.f, 0, nullptr};
-    return dense_common(3, x, wsplit, bias, scale, shift, residual, out, B, K, O, sc, stream);
+    return dense_common(3, x, wsplit, bias, scale, shift, residual, residual_stride, out, B, K, O, sc, stream);
 }
 
 extern "C" int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
-                                 float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, float *out,
-                                 float *out_rowmax_dev, int B, int K, int O, void *stream) {
+                                 float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, int residual_stride,
+                                 float *out, float *out_rowmax_dev, int B, int K, int O, void *stream) {
     ROREG_REQUIRE(in_rowmax_dev, "roreg_dense_f16x2: in_rowmax_dev is required");
     SplitScale sc = {in_rowmax_dev, act_smax, act_tmax, w_exp, out_rowmax_dev};
-    return dense_common(2, x, wsplit2, bias, scale, shift, residual, out, B, K, O, sc, stream);
+    return dense_common(2, x, wsplit2, bias, scale, shift, residual, residual_stride, out, B, K, O, sc, stream);
 }

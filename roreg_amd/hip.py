@@ -42,8 +42,8 @@ PROTOTYPES = {
     'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'roreg_group_conv_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    'roreg_dense_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'roreg_dense_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, c_int, _P, c_int, _P]),
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
     'roreg_inv_descriptor': (c_int, [_P, c_int, _P, c_int, _P]),
@@ -1137,8 +1137,18 @@ class DenseSplitLayer:
         self.shift = torch.from_numpy(np.ascontiguousarray(shift, np.float32)).cuda() if shift is not None else None
 
 
-def dense_split(x, layer, residual=None, in_rowmax=None, want_rowmax=False):
-    """x [B, K] float32 (device, contiguous) -> [B, O].  in_rowmax (device float32 [B], the tracked max |x[b]| per row): use the fp16 x 2
+def _res_ptr(t):
+    """data pointer of a residual operand that may be a strided VIEW (its first element is what the kernel indexes from)"""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise HipError('dense_split: residual must be a float32 device tensor')
+    return c_void_p(t.data_ptr())
+
+
+def dense_split(x, layer, residual=None, in_rowmax=None, want_rowmax=False, residual_stride=1):
+    """x [B, K] float32 (device, contiguous) -> [B, O].  residual: element (b, o) at residual.flat[(b*O + o) * residual_stride] (pass a
+    [B, O, L] tensor's column c as residual=t[:, :, c:] -- a view, no copy -- with residual_stride=L).  in_rowmax (device float32 [B], the tracked max |x[b]| per row): use the fp16 x 2
     kernel (per-row block scale); want_rowmax: also return the tracked per-row max |out[b]| (device float32 [B]) for the next layer."""
     B, K = x.shape
     if K != layer.K:
@@ -1149,11 +1159,11 @@ def dense_split(x, layer, residual=None, in_rowmax=None, want_rowmax=False):
             raise HipError(f'dense_split: in_rowmax must hold one value per row ({B}), got {in_rowmax.numel()}')
         amax = torch.zeros(B, dtype=torch.float32, device=x.device) if want_rowmax else None
         _check(lib().roreg_dense_f16x2(_ptr(x, torch.float32), _ptr(layer.ws2), layer.w_exp, _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
-                                       layer.act_smax, layer.act_tmax, _ptr(in_rowmax, torch.float32), _ptr(residual, torch.float32), _ptr(out),
+                                       layer.act_smax, layer.act_tmax, _ptr(in_rowmax, torch.float32), _res_ptr(residual), int(residual_stride), _ptr(out),
                                        _ptr(amax), B, K, layer.O, _stream()), 'roreg_dense_f16x2')
         return (out, amax) if want_rowmax else out
     _check(lib().roreg_dense_split(_ptr(x, torch.float32), _ptr(layer.ws), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
-                                   _ptr(residual, torch.float32), _ptr(out), B, K, layer.O, _stream()), 'roreg_dense_split')
+                                   _res_ptr(residual), int(residual_stride), _ptr(out), B, K, layer.O, _stream()), 'roreg_dense_split')
     return out
 
 

@@ -143,9 +143,9 @@ class ET_test(nn.Module):
                                           want_rowmax=True)                                                          # [B,256,48]
                     del T0
                     m, am = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True)                                  # [B,512,13]
-                    sc = h[:, :, p0:p0 + 1].contiguous()                                                             # identity short cut at g=0
                     d_out, d0, d1, d2 = self._dense_plans()
-                    t, at = hip.dense_split(m.view(B, -1), d_out, residual=sc.view(B, -1), in_rowmax=am, want_rowmax=True)   # [B,256]
+                    # identity short cut = column g = 0 of h, read in place (element (b, o) at stride LIVE_PAD from h[0, 0, p0])
+                    t, at = hip.dense_split(m.view(B, -1), d_out, residual=h[:, :, p0:], residual_stride=self.LIVE_PAD, in_rowmax=am, want_rowmax=True)   # [B,256]
                     z, az = hip.dense_split(t, d0, in_rowmax=at, want_rowmax=True)
                     z, az = hip.dense_split(z, d1, in_rowmax=az, want_rowmax=True)
                     return hip.dense_split(z, d2, in_rowmax=az)                                                      # [B,4]

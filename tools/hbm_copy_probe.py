@@ -12,3 +12,11 @@ t = time.perf_counter()
 for _ in range(10): s = x.sum()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
 print(f'read-only reduction: {dt * 1e3:.3f} ms  {n * 4 / dt / 1e12:.2f} TB/s')
+t = time.perf_counter()
+for _ in range(10): y.fill_(1.5)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
+print(f'write-only fill: {dt * 1e3:.3f} ms  {n * 4 / dt / 1e12:.2f} TB/s')
+t = time.perf_counter()
+for _ in range(10): torch.add(x, 1.0, out=y)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
+print(f'read + write elementwise add: {dt * 1e3:.3f} ms  {2 * n * 4 / dt / 1e12:.2f} TB/s')
