@@ -464,7 +464,7 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     };
 
     xpatch xr0[8], xr1[8];
-    if constexpr (PIPE == 1 && NP == 2 && WO == 4) {
+    if constexpr (PIPE == 1 && NP == 2) {
         // Fragment-pipelined loop: every MFMA of step k reads fragment REGISTERS that were filled during step k - 1, so no MFMA waits on
         // an LDS read issued after a barrier.  Per step: LDS-DMA of the weights of step k + 2 and the staging store of the activations of
         // step k + 2 go into stage k % 2 (all of whose fragments were read during step k - 1); the fragments of step k + 1 are read from
@@ -485,29 +485,37 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
         // The activation loads are issued from inline assembly: the compiler's wait-count pass then neither sees them nor widens the
         // waits of this loop to vmcnt(0) (it loses count across the raw barrier); wait_x is the explicit, counted wait -- the patch
         // registers are its in/out operands, so no use can be scheduled above it.
-        static_assert(CPT == 1, "the pipelined loop is written for the 8-wave tile (one activation column per thread)");
-        auto load_xa = [&](int kstep, float (&xr)[8]) {
+        // (a patch word = the thread's CPT columns of one k row: 4 bytes for the 8-wave tile, 8 bytes for the 4-wave tile)
+        typedef typename std::conditional<CPT == 1, float, unsigned long long>::type xword;
+        auto load_one = [&](xword &dst, const float *src) {
+            if constexpr (CPT == 1) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+        };
+        auto load_xa = [&](int kstep, xword (&xr)[8]) {
             const float *q = xcol + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 16 * N;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("global_load_dword %0, %1, off" : "=v"(xr[e]) : "v"(q + (size_t)e * N) : "memory");
+            for (int e = 0; e < 8; ++e) load_one(xr[e], q + (size_t)e * N);
+        };
+        auto word_of = [&](const xword &v, int c) -> unsigned {
+            if constexpr (CPT == 1) return __float_as_uint(v); else return (unsigned)(v >> (32 * c));
         };
 #define ROREG_WAIT_X(cnt, xr) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory")
-        auto store_x = [&](int buf, const float (&v)[8]) {       // word e = fp16 hi | fp16 lo << 16 of k = 8 po + e -> the two planes' k-octets
-            frag *dst = xs + buf * XBUF;
-            u32x4 H, L;
+        // word e = fp16 hi | fp16 lo << 16 of k = 8 po + e -> the k-octet of plane `plane` (0 = hi, 1 = lo) of the thread's column c
+        auto store_plane = [&](frag *dst, const xword (&v)[8], int c, int plane) {
+            u32x4 Q;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned lo2 = __float_as_uint(v[2 * i]), hi2 = __float_as_uint(v[2 * i + 1]);
-                H[i] = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
-                L[i] = __builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
-            }
-            dst[slot[0]] = __builtin_bit_cast(f16x8, H); dst[2 * NCOL + slot[0]] = __builtin_bit_cast(f16x8, L);
+            for (int i = 0; i < 4; ++i) Q[i] = __builtin_amdgcn_perm(word_of(v[2 * i + 1], c), word_of(v[2 * i], c), plane ? 0x07060302u : 0x05040100u);
+            dst[plane * 2 * NCOL + slot[c]] = __builtin_bit_cast(f16x8, Q);
+        };
+        auto store_x = [&](int buf, const xword (&v)[8]) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) { store_plane(xs + buf * XBUF, v, c, 0); store_plane(xs + buf * XBUF, v, c, 1); }
         };
         // One step = 24 MFMAs per wave in 12 pairs; every memory operation of the step sits BETWEEN two pairs (sched_barrier pins the order),
         // never in a burst at the step's head: a wave that is queueing its ten VMEM instructions cannot issue MFMAs (in-order issue), and
         // with all eight waves doing so right after the barrier the matrix pipes idled ~1000 cycles per step (measured: 2450 cycles per
         // step with the burst, 1820 with no memory operations at all, 1536 = the MFMAs alone).
-        auto step2 = [&](int ks, int buf, float (&xr_load)[8], float (&xr_use)[8], const frag (&a)[2][2], frag (&an)[2][2]) {
+        auto step2 = [&](int ks, int buf, xword (&xr_load)[8], xword (&xr_use)[8], const frag (&a)[2][2], frag (&an)[2][2]) {
             const int kw = ks + 2 < nsteps ? ks + 2 : nsteps - 1, kx = ks + 3 < nsteps ? ks + 3 : nsteps - 1;
             const frag *wq = wsrc + (size_t)kw * 2 * Mpad;
             const float *xq = xcol + (size_t)kx * 16 * N;
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
             };
             auto ldx = [&](int e0, int e1) {
 #pragma unroll
-                for (int e = e0; e < e1; ++e) asm volatile("global_load_dword %0, %1, off" : "=v"(xr_load[e]) : "v"(xq + (size_t)e * N) : "memory");
+                for (int e = e0; e < e1; ++e) load_one(xr_load[e], xq + (size_t)e * N);
                 __builtin_amdgcn_sched_barrier(0);
             };
             auto rb = [&](int t) { b[t][0] = xn[xslot[t]]; b[t][1] = xn[2 * NCOL + xslot[t]]; __builtin_amdgcn_sched_barrier(0); };
@@ -537,27 +545,20 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
             mm(1, 0); ra(0);  mm(1, 1); ra(1);  mm(1, 2); rb(1);
             mm(2, 0);
             ROREG_WAIT_X(2, xr_use);                             // the patch loaded during the previous step: only this step's two LDS-DMA pieces are newer
-            {
-                u32x4 H, L;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned lo2 = __float_as_uint(xr_use[2 * i]), hi2 = __float_as_uint(xr_use[2 * i + 1]);
-                    H[i] = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
-                    L[i] = __builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
-                }
-                xd[slot[0]] = __builtin_bit_cast(f16x8, H);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(2, 1);
-                xd[2 * NCOL + slot[0]] = __builtin_bit_cast(f16x8, L);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            store_plane(xd, xr_use, 0, 0);
+            if constexpr (CPT == 2) store_plane(xd, xr_use, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(2, 1);
+            store_plane(xd, xr_use, 0, 1);
+            if constexpr (CPT == 2) store_plane(xd, xr_use, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
             mm(2, 2); rb(2);
             mm(3, 0); ldx(0, 3); mm(3, 1); ldx(3, 6); mm(3, 2); ldx(6, 8); rb(3);
             // the two LDS-DMA pieces are the oldest of this step's ten VMEM operations: vmcnt(8) = they have landed (the activation
             // loads stay in flight across the barrier); lgkmcnt(0) = this wave's staging stores and fragment reads are done
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
-        float xa0[8], xa1[8];
+        xword xa0[8], xa1[8];
         load_xa(0, xa0); issue_a(0, 0);
         load_xa(1, xa1); issue_a(1, 1);
         ROREG_WAIT_X(0, xa0);
@@ -1346,7 +1347,7 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
     // ROREG_GEMM_PIPE=0 selects the loop without fragment pipelining (kept for A/B runs: results are bitwise the same)
     static const int pipe = [] { const char *e = getenv("ROREG_GEMM_PIPE"); return e ? atoi(e) : 1; }();
     auto kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0>;
-    if constexpr (NP == 2 && WO == 4) { if (pipe == 1) kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0, 1>; }
+    if constexpr (NP == 2) { if (pipe == 1) kern = (long long)C * O == 256ll * 512 ? irrep_gemm_split_kernel<CT, NP, WO, 1, 1> : irrep_gemm_split_kernel<CT, NP, WO, 0, 1>; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(WO * 128), lds, roreg::as_stream(stream), p, tiles_dev);
