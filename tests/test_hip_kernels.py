@@ -519,7 +519,7 @@ def test_alternative_kernel_forms_stay_correct(env):
 @pytest.mark.gpu
 def test_gemm_pipelined_loop_is_bitwise_the_plain_loop():
     """irrep GEMM (fp16 x 2, 256 x 256 tile): the fragment-pipelined loop issues the same MFMAs per accumulator in the same order as
-    the plain loop -- identical bits on a 61440-keypoint launch with heavy-tailed operands and bound propagation (tools/gemm_checksum.py)."""
+    the plain loop -- identical bits on 61440-keypoint launches of four layer shapes with heavy-tailed operands and bound propagation (tools/gemm_checksum.py)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = []
@@ -528,5 +528,6 @@ def test_gemm_pipelined_loop_is_bitwise_the_plain_loop():
                            stderr=subprocess.STDOUT, timeout=600)
         lines = [l for l in r.stdout.decode().splitlines() if l.startswith('checksum')]
         assert r.returncode == 0 and lines, r.stdout.decode()[-2000:]
-        sums.append(lines[-1])
+        assert len(lines) == 4, lines                       # GF's big layer, its two thin ones (4-wave and 8-wave tiles), ET's Conv_init
+        sums.append(lines)
     assert sums[0] == sums[1], sums
