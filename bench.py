@@ -54,6 +54,9 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary figures (profiling runs)')
     ap.add_argument('--gemm', choices=['f16x2', 'bf16x3', 'f32'], default='f16x2', help="matrix-core mode of the group-conv GEMMs: fp16 x 2 operands with "
                     "per-keypoint power-of-two block scaling (default), bf16 x 3, or f32-input MFMA; all accumulate in f32")
+    ap.add_argument('--pair-lists', choices=['banded', 'uniform'], default='banded', help='synthetic pair lists of a scene: beyond the chain (i, i+1), pair (i, j) is '
+                    'drawn with probability ~ exp(-|i-j|/8) (default: overlapping fragments of a scan sequence are mostly temporally close) or uniformly over '
+                    'all cloud pairs (the worst case for cutting a scene across ranks); same pair and cloud counts, same single-GPU work')
     ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32', help='descriptor storage (BASELINE config 5: bf16 = group features stored and '
                     'streamed as bfloat16, float32 accumulation)')
     return ap.parse_args()
@@ -70,7 +73,8 @@ def build_workload(args, rank, world):
         return {'chunk': (feats, keys, poses, pairs)}, [('chunk', 0, len(pairs))], {'pairs': 60 * world, 'clouds': 16 * world, 'scaling': 'weak'}
     names = synth.THREEDMATCH_SCENES if args.workload == '3dmatch-full' else synth.THREEDMATCH_SCENES[:1]
     clouds = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_PAIRS))
-    lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + synth.THREEDMATCH_SCENES.index(s)) for s in names}
+    loc = 8.0 if getattr(args, 'pair_lists', 'banded') == 'banded' else None
+    lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + synth.THREEDMATCH_SCENES.index(s), locality=loc) for s in names}
     plan = shard_scenes({s: npairs[s] for s in names}, world, {s: clouds[s] for s in names}, pair_lists=lists)
     scenes = {}
     for s in sorted({p[0] for p in plan[rank]}):
@@ -332,6 +336,8 @@ def main():
             'vs_baseline': None, 'dtype': DTYPE_OF[args.gemm] + ('' if args.dtype == 'fp32' else '; group features stored as bfloat16'), 'data': 'synthetic',
             'config': {'workload': wl, 'pairs_per_step': total_pairs, 'clouds_per_step': totals['clouds'], 'parallelism': f'pairs-sharded x{world}',
                        'descriptor_dtype': args.dtype,
+                       'pair_lists': ('chain (i, i+1) + pairs (i, j) drawn with probability ~ exp(-|i-j|/8): scan-sequence-like locality' if args.pair_lists == 'banded'
+                                      else 'chain (i, i+1) + pairs drawn uniformly over all cloud pairs') if args.workload != 'chunk' else None,
                        'rank0_pairs_per_step': my_pairs, 'shard_plan': totals.get('plan'),
                        'mean_matches_rank0': float(np.mean(Ms)) if len(Ms) else None, 'registration_recall_synthetic_rank0': float(np.mean(rr)) if rr else None,
                        'local_transforms': 'only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M)',

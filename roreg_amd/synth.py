@@ -232,15 +232,22 @@ THREEDMATCH_CLOUDS = [60, 60, 60, 55, 57, 37, 66, 38]
 THREEDMATCH_PAIRS = [449, 217, 159, 207, 104, 54, 295, 138]          # sum = 1623
 
 
-def scene_pair_list(n_clouds, n_pairs, seed):
+def scene_pair_list(n_clouds, n_pairs, seed, locality=None):
     """A fixed pseudo-random subset of the cloud pairs that touches every cloud (like a scene's gt.log lists its overlapping pairs):
-    the chain (0,1), (1,2), ... first, then random further pairs; sorted."""
+    the chain (0,1), (1,2), ... first, then random further pairs; sorted.  locality=None: the further pairs are uniform over all pairs
+    (every contiguous range of the list touches most clouds: the worst case for cutting a scene across ranks); locality=tau: pair (i, j)
+    is drawn with probability ~ exp(-|i - j| / tau), as in a scan sequence whose overlapping fragments are mostly temporally close."""
     rng = np.random.default_rng(int(seed))
     allp = [(a, b) for a in range(n_clouds) for b in range(a + 1, n_clouds)]
     chain = [(a, a + 1) for a in range(n_clouds - 1)]
     rest = [p for p in allp if p[1] != p[0] + 1]
-    order = rng.permutation(len(rest))
-    extra = [rest[i] for i in order[:max(0, n_pairs - len(chain))]]
+    k = max(0, n_pairs - len(chain))
+    if locality is None:
+        order = rng.permutation(len(rest))
+        extra = [rest[i] for i in order[:k]]
+    else:
+        w = np.array([np.exp(-(b - a) / float(locality)) for a, b in rest]); w /= w.sum()
+        extra = [rest[i] for i in rng.choice(len(rest), size=min(k, len(rest)), replace=False, p=w)]
     return sorted((chain + extra)[:n_pairs])
 
 

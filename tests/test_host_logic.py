@@ -217,15 +217,15 @@ def test_shard_scenes_balanced_and_complete():
 
 def test_shard_scenes_full_benchmark_shape_with_pair_lists():
     """bench.py's plan: exact per-range cloud counts; complete at every world size; modelled efficiency (one-rank cost / (N x makespan)) >= 0.97
-    at 2 and 4 ranks and >= 0.83 at 8 (a scene's slices each re-extract the clouds they touch; the wrap-around fill cuts at most one
-    scene per rank boundary)."""
+    at 2 and 4 ranks and >= 0.83 at 8 with uniformly random pair lists, >= 0.90 with bench.py's default lists (scan-sequence-like locality):
+    a scene's slices each re-extract the clouds they touch; the wrap-around fill cuts at most one scene per rank boundary."""
     from roreg_amd import synth
     from roreg_amd.distributed import shard_scenes
     names = synth.THREEDMATCH_SCENES
     clouds = dict(zip(names, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(names, synth.THREEDMATCH_PAIRS))
-    lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + i) for i, s in enumerate(names)}
     cost1 = sum(npairs.values()) + 7.0 * sum(clouds.values())
-    for world, floor in ((1, 0.999), (2, 0.97), (4, 0.97), (8, 0.83)):
+    for world, floor, locality in ((1, 0.999, None), (2, 0.97, None), (4, 0.97, None), (8, 0.83, None), (8, 0.90, 8.0)):
+        lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + i, locality=locality) for i, s in enumerate(names)}
         plan = shard_scenes(npairs, world, clouds, pair_lists=lists)
         seen = {}
         loads = []
