@@ -33,3 +33,14 @@ for sp in (False, True, 'f16x2'):
         for _ in range(5): fn()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
         print(f'ft_nonlin {name} B={B2} split={sp}: {dt*1e3:.2f} ms  {gb/dt/1e3:.2f} TB/s')
+# GF's last transform: irrep -> group with the input residual (32 channels, all 60 columns)
+B3 = 65536
+X = torch.randn(hip.coef_size(32, B3), device='cuda'); bias = torch.randn(32, device='cuda')
+xr = torch.randn(B3, 32, 60, device='cuda')
+for sp in ('f16x2',):
+    fn = lambda: hip.ft_nonlin(B3, 32, coef_in=X, bias=bias, resid_spatial=xr, spatial_out=True, split=sp)
+    for _ in range(2): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): fn()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
+    print(f'ft_nonlin irrep->group + residual C=32 B={B3} split={sp}: {dt*1e3:.2f} ms  {3 * 60 * 32 * B3 * 4 / dt / 1e12:.2f} TB/s')
