@@ -215,6 +215,23 @@ def test_shard_scenes_balanced_and_complete():
         assert max(loads) <= 1.25 * sum(counts.values()) / world + 1
 
 
+def test_scene_pair_lists_touch_every_cloud_and_are_reproducible():
+    """bench.py's synthetic pair lists (both kinds): the requested number of distinct pairs (i < j), sorted, every cloud touched (the chain
+    (i, i+1) is always in), the same list for the same seed; with locality the pairs sit closer to the diagonal than uniformly drawn ones."""
+    from roreg_amd import synth
+    for n_clouds, n_pairs in ((60, 449), (37, 54), (16, 60)):
+        spans = {}
+        for loc in (None, 8.0):
+            a = synth.scene_pair_list(n_clouds, n_pairs, 901, locality=loc)
+            assert a == synth.scene_pair_list(n_clouds, n_pairs, 901, locality=loc)
+            assert len(a) == n_pairs and len(set(a)) == n_pairs and a == sorted(a)
+            assert all(0 <= i < j < n_clouds for i, j in a)
+            assert {i for p in a for i in p} == set(range(n_clouds))
+            spans[loc] = np.mean([j - i for i, j in a])
+        if n_pairs > 2 * n_clouds:
+            assert spans[8.0] < spans[None]
+
+
 def test_shard_scenes_full_benchmark_shape_with_pair_lists():
     """bench.py's plan: exact per-range cloud counts; complete at every world size; modelled efficiency (one-rank cost / (N x makespan)) >= 0.97
     at 2 and 4 ranks and >= 0.83 at 8 with uniformly random pair lists, >= 0.90 with bench.py's default lists (scan-sequence-like locality):
