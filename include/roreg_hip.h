@@ -262,6 +262,14 @@ int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long lon
                        int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* Seeded shuffles, HOST function (no device work): for every job j, `np.random.seed(seeds[j])` followed by, for each of its per_job lists
+ * (sizes int32 [n_jobs][per_job]), `idx = np.arange(n); np.random.shuffle(idx); idx[:take]` -- numpy's legacy MT19937 stream and its
+ * Fisher-Yates shuffle, replayed bit for bit.  out int64 [n_jobs][per_job][take] (-1 beyond a list's length).  Replaces the per-pair
+ * Python loops of the matcher's keypoint sampling (test/matcher.py:83-88: two lists per pair, take = keynum) and of the one-shot
+ * estimator's hypothesis order (test/estimator.py:423-425: one list per pair, take = max_iter) when every pair has a generator stream of
+ * its own; jobs are spread over n_threads host threads. */
+int roreg_mt_shuffle_prefix(const uint32_t *seeds, int n_jobs, const int32_t *sizes, int per_job, int take, int64_t *out, int n_threads);
+
 /* YOHO-C hypothesis draws, HOST function (no device work): replays the generator calls of the reference's sampling loop
  * (test/estimator.py:220-230: np.random.choice(range(60), p=prob), then np.random.choice(bin_members, 3)) over a block of raw MT19937
  * words drawn by the caller from the global generator.  cdf f64 [60] = prob.cumsum()/prob.sum(); bin_size int32 [60] = members per

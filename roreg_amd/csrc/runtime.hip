@@ -1,5 +1,8 @@
 // Library state: last-error text and the device copies of the icosahedral group tables.
 #include "common.h"
+#include <thread>
+#include <vector>
+#include <utility>
 #include <stdarg.h>
 #include <mutex>
 #include <utility>
@@ -153,5 +156,71 @@ extern "C" int roreg_yohoc_draw(const uint32_t *words, long long n_words, const 
     }
     *n_hyp_out = n_hyp;
     *words_used = pos;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Seeded shuffles of the matcher's keypoint sampling and the one-shot estimator's hypothesis order (HOST code; test/matcher.py:83-88,
+// test/estimator.py:423-425): per job `np.random.seed(seed)` followed by, for each of its `per_job` lists, `idx = np.arange(n);
+// np.random.shuffle(idx); idx[:take]`.  numpy's legacy generator is MT19937 seeded by init_genrand(seed); its shuffle of a 1-d array is
+// Fisher-Yates from the top -- for i = n-1 .. 1: j = random_interval(i), swap(x[i], x[j]) -- and random_interval(max) draws 32-bit words
+// masked to the smallest 2^k - 1 >= max until one is <= max.  The same calls in C, jobs spread over host threads: the Python loop cost
+// ~35 us per pair with the GPU idle behind a synchronisation (7 ms per scene).
+namespace {
+struct Mt19937 {
+    uint32_t key[624];
+    int pos;
+    explicit Mt19937(uint32_t seed) {
+        for (int i = 0; i < 624; ++i) { key[i] = seed; seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u; }
+        pos = 624;
+    }
+    void refill() {
+        const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+        int i = 0;
+        for (; i < 624 - 397; ++i) { const uint32_t y = (key[i] & UPPER) | (key[i + 1] & LOWER); key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u); }
+        for (; i < 623; ++i) { const uint32_t y = (key[i] & UPPER) | (key[i + 1] & LOWER); key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u); }
+        const uint32_t y = (key[623] & UPPER) | (key[0] & LOWER);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        pos = 0;
+    }
+    uint32_t next() {
+        if (pos == 624) refill();
+        uint32_t y = key[pos++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+};
+}  // namespace
+
+extern "C" int roreg_mt_shuffle_prefix(const uint32_t *seeds, int n_jobs, const int32_t *sizes, int per_job, int take, int64_t *out, int n_threads) {
+    if (n_jobs == 0) return 0;
+    ROREG_REQUIRE(seeds && sizes && out && n_jobs > 0 && per_job > 0 && take >= 0, "roreg_mt_shuffle_prefix: bad arguments");
+    for (long long i = 0; i < (long long)n_jobs * per_job; ++i)
+        ROREG_REQUIRE(sizes[i] >= 0, "roreg_mt_shuffle_prefix: negative list size");
+    auto work = [&](int j0, int j1) {
+        std::vector<int64_t> x;
+        for (int job = j0; job < j1; ++job) {
+            Mt19937 g(seeds[job]);
+            for (int s = 0; s < per_job; ++s) {
+                const int n = sizes[(size_t)job * per_job + s];
+                x.resize((size_t)n);
+                for (int i = 0; i < n; ++i) x[i] = i;
+                for (int i = n - 1; i >= 1; --i) {
+                    uint32_t mask = (uint32_t)i;
+                    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                    uint32_t v;
+                    do { v = g.next() & mask; } while (v > (uint32_t)i);
+                    std::swap(x[i], x[v]);
+                }
+                int64_t *dst = out + ((size_t)job * per_job + s) * take;
+                for (int i = 0; i < take; ++i) dst[i] = i < n ? x[i] : -1;
+            }
+        }
+    };
+    int nt = n_threads < 1 ? 1 : (n_threads > n_jobs ? n_jobs : n_threads);
+    if (nt == 1) { work(0, n_jobs); return 0; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((long long)n_jobs * t / nt), (int)((long long)n_jobs * (t + 1) / nt));
+    for (auto &t : th) t.join();
     return 0;
 }

@@ -263,9 +263,10 @@ class RegistrationEngine:
 
     # ---- per pair ------------------------------------------------------------------------------------------
     def sample(self, c0, c1, keynum, seed=None):
-        """Keypoint sampling; consumes the global numpy RNG exactly like test/matcher.py:75-88 (seed: re-seed it for this pair first)."""
-        if seed is not None:
-            np.random.seed(int(seed) % (2 ** 32))
+        """Keypoint sampling; consumes the numpy generator exactly like test/matcher.py:75-88.  seed=None: the process-global generator (the
+        reference's single stream); a seed: a generator of this pair's own, `RandomState(seed)` -- the same legacy MT19937 stream that
+        `np.random.seed(seed)` would start, without touching the process-global state (so pairs can be prepared on several host threads)."""
+        rng = np.random if seed is None else np.random.RandomState(int(seed) % (2 ** 32))
         n0, n1 = c0.before.shape[0], c1.before.shape[0]
         if self.cfg.RD:
             # NMS sampling is a pure function of the cloud (keypoints, detector scores, keynum; no RNG): the reference recomputes
@@ -274,7 +275,7 @@ class RegistrationEngine:
             s0, s1 = c0.nms[keynum], c1.nms[keynum]
         else:
             s0 = np.arange(n0); s1 = np.arange(n1)
-            np.random.shuffle(s0); np.random.shuffle(s1)
+            rng.shuffle(s0); rng.shuffle(s1)
             s0 = s0[0:keynum]; s1 = s1[0:keynum]
         return s0, s1
 
@@ -396,16 +397,25 @@ class RegistrationEngine:
         # The registration result is identical; the reference computes all M local transforms because its stages are coupled through
         # Trans_pre files.  all_local_transforms=True evaluates every correspondence like the reference does.
         hyps = []
-        for q, ((c0, c1, matches), sc) in enumerate(zip(full, all_scores)):
-            if pair_seeds is not None:
-                np.random.seed((int(pair_seeds[q]) + 1) % (2 ** 32))
-            rows = np.arange(matches.shape[0])
+        rows_of = []
+        for (c0, c1, matches), sc in zip(full, all_scores):
+            rows = None                                                     # None = arange(M)
             if self.cfg.RM:                                                 # hypotheses only from the best-scored matches (:415-421)
                 num = max(sc.shape[0] * self.cfg.match_n, 10) if self.cfg.match_n < 0.999 else self.cfg.match_n
                 rows = np.argsort(sc)[-int(num):]
-            index = np.arange(rows.shape[0])
-            np.random.shuffle(index)                                        # estimator.py:423-424
-            hyps.append(np.ascontiguousarray(rows[index[0:max_iter]], np.int64))
+            rows_of.append(rows)
+        n_of = [int(m.shape[0]) if r is None else int(r.shape[0]) for (_, _, m), r in zip(full, rows_of)]
+        if pair_seeds is not None and len(full):
+            # one threaded host call for every pair's `seed(pair seed + 1); shuffle(arange(n))[:max_iter]` (hip.mt_shuffle_prefix)
+            drawn = hip.mt_shuffle_prefix(np.asarray(pair_seeds, np.int64) + 1, np.array(n_of, np.int32)[:, None], max_iter)
+            for q, (rows, n) in enumerate(zip(rows_of, n_of)):
+                index = drawn[q, 0, :min(max_iter, n)]
+                hyps.append(np.ascontiguousarray(index if rows is None else rows[index], np.int64))
+        else:
+            for rows, n in zip(rows_of, n_of):
+                index = np.arange(n)
+                np.random.shuffle(index)                                    # estimator.py:423-424 (the reference's single global stream)
+                hyps.append(np.ascontiguousarray((index if rows is None else rows[index])[0:max_iter], np.int64))
         hyp_flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros(0, np.int64)).cuda()   # ONE upload of all hypothesis lists
         hyp_dev, o = [], 0
         for h in hyps:
@@ -501,8 +511,15 @@ class RegistrationEngine:
         else:
             # every pair's sampling first (host RNG in the reference's order), ONE upload of all row lists, then the whole
             # matcher stage in three launches
-            samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
-                       for q, (a, b) in enumerate(pair_ids)]                                        # host; runs under the extractor's kernels
+            if pair_seeds is not None and not self.cfg.RD and len(pair_ids):
+                # every pair has a generator stream of its own: all of the scene's seeded shuffles in one threaded host call (the same
+                # MT19937 streams and Fisher-Yates steps as sample()'s RandomState(seed).shuffle, replayed in C: hip.mt_shuffle_prefix)
+                sizes = np.array([[clouds[int(a)].before.shape[0], clouds[int(b)].before.shape[0]] for a, b in pair_ids], np.int32)
+                drawn = hip.mt_shuffle_prefix(pair_seeds, sizes, keynum)
+                samples = [(drawn[q, 0, :min(keynum, int(sizes[q, 0]))], drawn[q, 1, :min(keynum, int(sizes[q, 1]))]) for q in range(len(pair_ids))]
+            else:
+                samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
+                           for q, (a, b) in enumerate(pair_ids)]                                    # host; runs under the extractor's kernels
             flat = np.concatenate([np.ascontiguousarray(x, np.int64) for s in samples for x in s]) if samples else np.zeros(0, np.int64)
             flat_dev = torch.from_numpy(flat).cuda()
             tasks, o = [], 0
@@ -537,8 +554,8 @@ class RegistrationEngine:
         # (<= 2 inliers: a failed registration) U V^T is not unique and the reference's value is LAPACK's; redo
         # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.
         from .test.estimator import _kabsch_host, _dev64
-        redo = [i for i in range(len(full)) if i not in skipped and
-                (hip.stats_rank_deficient(st_host[i, 0]) or hip.stats_rank_deficient(st_host[i, 1]))]
+        deficient = hip.stats_rank_deficient_many(st_host).any(axis=1) if len(full) else np.zeros(0, bool)       # [pairs, 2 refinements]
+        redo = [i for i in range(len(full)) if i not in skipped and deficient[i]]
         pending = []
         for i in redo:                                                      # all second refinements are enqueued before the one download
             c0, c1, matches = full[i]

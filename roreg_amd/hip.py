@@ -88,6 +88,7 @@ PROTOTYPES = {
     'roreg_profile_enable': (c_int, [c_int]),
     'roreg_profile_read': (c_int, [c_int, _P, _P]),
     'roreg_set_fourier_tables': (c_int, [_P]),
+    'roreg_mt_shuffle_prefix': (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm_tiles_m': (c_size_t, [c_int, c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
@@ -703,6 +704,30 @@ def stats_rank_deficient(stats, tol=1e-10):
     # rank <= 2 (three inliers, coplanar inliers, ...): the third singular pair is a null pair and whether U V^T is a rotation or a
     # reflection is the SVD routine's sign convention -- the reference's value is LAPACK's
     return bool(sv[2] <= tol * max(sv[0], 1e-300))
+
+
+def stats_rank_deficient_many(stats, tol=1e-10):
+    """stats_rank_deficient for a stack of refinement statistics [..., >= 9] in ONE batched SVD -> bool array [...] (the per-pair loop cost
+    ~8 us x 2 x pairs of host time with the GPU idle).  Singular values do not depend on the batching (LAPACK gesdd per matrix either way)."""
+    s = np.asarray(stats)
+    H = s[..., 0:9].reshape(s.shape[:-1] + (3, 3))
+    finite = np.isfinite(H).all(axis=(-1, -2))
+    sv = np.linalg.svd(np.where(finite[..., None, None], H, 0.0), compute_uv=False)
+    return finite & (sv[..., 2] <= tol * np.maximum(sv[..., 0], 1e-300))
+
+
+def mt_shuffle_prefix(seeds, sizes, take, n_threads=None):
+    """Host function: per job j `np.random.seed(seeds[j])`, then for each list of sizes[j] `idx = np.arange(n); np.random.shuffle(idx);
+    idx[:take]` (numpy's legacy MT19937 stream, replayed in C over host threads).  seeds [J] (any integers; taken modulo 2^32), sizes [J, L]
+    -> int64 [J, L, take] with -1 beyond a list's length."""
+    seeds = np.ascontiguousarray(np.asarray(seeds, np.int64) % (2 ** 32), np.uint32)
+    sizes = np.ascontiguousarray(sizes, np.int32).reshape(seeds.shape[0], -1)
+    out = np.empty((seeds.shape[0], sizes.shape[1], int(take)), np.int64)
+    if seeds.shape[0]:
+        nt = n_threads if n_threads is not None else max(1, min(16, (os.cpu_count() or 2) // 2))
+        _check(lib().roreg_mt_shuffle_prefix(c_void_p(seeds.ctypes.data), seeds.shape[0], c_void_p(sizes.ctypes.data), sizes.shape[1], int(take),
+                                             c_void_p(out.ctypes.data), int(nt)), 'roreg_mt_shuffle_prefix')
+    return out
 
 
 def gather_rows_f64(src, rows):

@@ -215,6 +215,28 @@ def test_shard_scenes_balanced_and_complete():
         assert max(loads) <= 1.25 * sum(counts.values()) / world + 1
 
 
+def test_mt_shuffle_prefix_replays_numpys_seeded_shuffles():
+    """roreg_mt_shuffle_prefix (host C, threaded) == np.random.seed(seed); shuffle(arange(n))[:take] for consecutive lists on one stream:
+    the matcher's keypoint sampling (two lists per pair) and the one-shot estimator's hypothesis order (one list per pair)."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(5)
+    seeds = np.concatenate([[0, 1, 2 ** 32 - 1, 2 ** 32 + 5, 123456789], rng.integers(0, 2 ** 40, 60)])
+    for per_job, take, hi in ((2, 500, 5200), (1, 1000, 4000), (3, 7, 1)):
+        sizes = rng.integers(0, hi + 1, (seeds.shape[0], per_job))
+        sizes[0, 0] = 0; sizes[1, 0] = 1; sizes[2, 0] = 2
+        for nt in (1, 5):
+            got = hip.mt_shuffle_prefix(seeds, sizes, take, n_threads=nt)
+            for j, seed in enumerate(seeds):
+                st = np.random.RandomState(int(seed) % (2 ** 32))
+                for l in range(per_job):
+                    x = np.arange(int(sizes[j, l])); st.shuffle(x)
+                    want = np.full(take, -1, np.int64); want[:min(take, x.shape[0])] = x[:take]
+                    assert np.array_equal(got[j, l], want), (per_job, take, j, l, int(sizes[j, l]))
+    # and the process-global spelling gives the same stream as RandomState(seed)
+    np.random.seed(77); a = np.arange(300); np.random.shuffle(a)
+    assert np.array_equal(hip.mt_shuffle_prefix([77], [[300]], 300)[0, 0], a)
+
+
 def test_scene_pair_lists_touch_every_cloud_and_are_reproducible():
     """bench.py's synthetic pair lists (both kinds): the requested number of distinct pairs (i < j), sorted, every cloud touched (the chain
     (i, i+1) is always in), the same list for the same seed; with locality the pairs sit closer to the diagonal than uniformly drawn ones."""
