@@ -298,7 +298,7 @@ class RegistrationEngine:
             return []
         max_points = self.rm_max_points if max_points is None else max_points
         flat = np.concatenate([np.ascontiguousarray(x, np.int64) for _, _, s0, s1 in jobs for x in (s0, s1)])
-        flat_dev = hip.upload(flat)                                         # ONE upload of all sample lists
+        flat_dev = torch.from_numpy(flat).cuda()                            # ONE upload of all sample lists
         rows, o = [], 0
         for _, _, s0, s1 in jobs:
             rows.append((flat_dev[o:o + len(s0)], flat_dev[o + len(s0):o + len(s0) + len(s1)])); o += len(s0) + len(s1)
@@ -325,7 +325,7 @@ class RegistrationEngine:
         for (c0, c1, s0, s1), (m, _) in zip(jobs, issued):
             n = int(m.shape[0])
             out.append(self._match_rm_finish(s0, s1, m0_all[o:o + n], sc_all[o:o + n])); o += n
-        flat = hip.upload(np.concatenate([m.reshape(-1) for m, _ in out]))
+        flat = torch.from_numpy(np.concatenate([m.reshape(-1) for m, _ in out])).cuda()
         res, o = [], 0
         for m, sc in out:
             res.append((flat[o:o + m.size].view(-1, 2), sc)); o += m.size
@@ -416,7 +416,7 @@ class RegistrationEngine:
                 index = np.arange(n)
                 np.random.shuffle(index)                                    # estimator.py:423-424 (the reference's single global stream)
                 hyps.append(np.ascontiguousarray((index if rows is None else rows[index])[0:max_iter], np.int64))
-        hyp_flat = hip.upload(np.concatenate(hyps) if hyps else np.zeros(0, np.int64))               # ONE upload of all hypothesis lists
+        hyp_flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros(0, np.int64)).cuda()   # ONE upload of all hypothesis lists
         hyp_dev, o = [], 0
         for h in hyps:
             hyp_dev.append(hyp_flat[o:o + h.shape[0]]); o += h.shape[0]
@@ -429,7 +429,7 @@ class RegistrationEngine:
         rt, w_all = [], []
         for (c0, c1, matches), h, sc, (dr, Trans) in zip(full, hyp_dev, all_scores, lts):
             hyp = h if all_local_transforms else None                                      # else Trans is already in hypothesis order
-            w = None if sc is None else hip.upload(sc.astype(np.float64))                  # None = ones(M)  (matcher.py:109)
+            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()     # None = ones(M)  (matcher.py:109)
             rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
         return rt, w_all
 
@@ -465,10 +465,10 @@ class RegistrationEngine:
         # the 3-point Kabsch stacks are pure functions of the draws: LAPACK releases the GIL, so the pairs run on a few host threads
         kabsch = lambda j: np.zeros((0, 3, 4)) if j is None else three_point_transforms(j[0][j[2]], j[1][j[3]])
         hyps = list(_host_pool().map(kabsch, jobs))
-        flat = hip.upload(np.concatenate(hyps) if hyps else np.zeros((0, 3, 4)))
+        flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros((0, 3, 4))).cuda()
         rt, w_all, o = [], [], 0
         for (c0, c1, matches), sc, T in zip(full, all_scores, hyps):
-            w = None if sc is None else hip.upload(sc.astype(np.float64))
+            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()
             rt.append((c0.keys, c1.keys, matches, w, flat[o:o + T.shape[0]], None)); w_all.append(w)
             o += T.shape[0]
         return rt, w_all, skipped
@@ -521,7 +521,7 @@ class RegistrationEngine:
                 samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
                            for q, (a, b) in enumerate(pair_ids)]                                    # host; runs under the extractor's kernels
             flat = np.concatenate([np.ascontiguousarray(x, np.int64) for s in samples for x in s]) if samples else np.zeros(0, np.int64)
-            flat_dev = hip.upload(flat)
+            flat_dev = torch.from_numpy(flat).cuda()
             tasks, o = [], 0
             for (a, b), (s0, s1) in zip(pair_ids, samples):
                 c0, c1 = clouds[int(a)], clouds[int(b)]

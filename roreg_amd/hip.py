@@ -140,17 +140,6 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def upload(array):
-    """numpy array -> device tensor through pinned memory, NOT blocking the host: a pageable `.cuda()` waits for everything queued on the
-    stream before it copies, i.e. every task-table / index-list upload in the middle of a scene was a full synchronisation after which
-    the host prepared the next launches with the GPU idle.  (torch's caching host allocator keeps the pinned block alive until the copy
-    has run.)"""
-    t = torch.from_numpy(np.ascontiguousarray(array))
-    if t.numel() == 0:
-        return t.cuda()
-    return t.pin_memory().cuda(non_blocking=True)
-
-
 def _ptr(t, dtype=None):
     if t is None:
         return None
@@ -427,7 +416,7 @@ class LtBatch:
         self.total = off
         self.max_n = int(table['n'].max()) if self.n_tasks else 0
         self.keep = tasks                              # the table holds raw pointers: keep the tensors alive
-        self.table = upload(table.view(np.uint8).reshape(self.n_tasks, _LT_TASK.itemsize)) if self.n_tasks else None
+        self.table = torch.from_numpy(table.view(np.uint8).reshape(self.n_tasks, _LT_TASK.itemsize).copy()).cuda() if self.n_tasks else None
 
     def prepare(self, rows_alloc=None, bound_bn=None):
         """Des2R + ET input assembly -> (dr int64 [total], x [rows_alloc,128,60] f32; rows beyond total are zero).
@@ -520,7 +509,7 @@ def ransac_batch(tasks, ird):
                     hr.data_ptr() if hr is not None else 0, M, H, koff)
         koff += M
     max_M = int(table['M'].max()); max_H = int(table['H'].max())
-    tdev = upload(table.view(np.uint8).reshape(n, _RANSAC_TASK.itemsize))
+    tdev = torch.from_numpy(table.view(np.uint8).reshape(n, _RANSAC_TASK.itemsize).copy()).to(dev)
     ws_n = lib().roreg_ransac_batch_workspace(n, koff, max_H)
     ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.float64, device=dev)
     _check(lib().roreg_ransac_batch(_ptr(tdev), n, koff, max(max_M, 1), max_H, float(ird), _ptr(best), _ptr(T1), _ptr(st1), _ptr(T2), _ptr(st2),
@@ -555,7 +544,7 @@ def mutual_match_batch(tasks):
     cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)[:n]
     if n == 0:
         return out, cnt
-    tdev = upload(table.view(np.uint8).reshape(n, _MATCH_TASK.itemsize))
+    tdev = torch.from_numpy(table.view(np.uint8).reshape(n, _MATCH_TASK.itemsize).copy()).to(dev)
     ws_n = lib().roreg_mutual_match_batch_workspace(n, max_m)
     ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.int64, device=dev)
     _check(lib().roreg_mutual_match_batch(_ptr(tdev), n, max_m, _ptr(out), _ptr(cnt), _ptr(ws), ws_n, _stream()), 'roreg_mutual_match_batch')
@@ -778,7 +767,7 @@ class Segments:
     def __init__(self, lengths):
         lengths = np.asarray(lengths, np.int64)
         self.host = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
-        self.dev = upload(self.host)
+        self.dev = torch.from_numpy(self.host).cuda()
         self.n = int(lengths.shape[0]); self.max = int(lengths.max()); self.min = int(lengths.min()); self.total = int(self.host[-1])
 
 
@@ -901,7 +890,7 @@ def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters):
     s0 = torch.empty(tm, dtype=torch.float32, device=dev); s1 = torch.empty(tn, dtype=torch.float32, device=dev)
     consts = np.empty(4 * seg_src.n, np.float32)
     _check(lib().roreg_sinkhorn_batch_consts(seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, seg_src.n, consts.ctypes.data), 'roreg_sinkhorn_batch_consts')
-    cdev = upload(consts)
+    cdev = torch.from_numpy(consts).to(dev)
     wsn = lib().roreg_sinkhorn_batch_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
     ws = torch.empty(wsn, dtype=torch.float32, device=dev)
     _check(lib().roreg_sinkhorn_batch(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
