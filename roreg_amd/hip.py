@@ -391,23 +391,43 @@ class LtBatch:
         off = 0
         self.offsets = []
         n_coef = 0; n_bf16 = 0
-        for i, task in enumerate(tasks):
+        # a scene's pairs share its clouds: every distinct tensor is validated once per batch (449 kitchen pairs touch 60 clouds), the
+        # table is filled column by column -- this constructor runs with the GPU idle behind the match-count download
+        seen = {}
+
+        def feat(t):                                           # -> (device pointer, is bfloat16)
+            r = seen.get(id(t))
+            if r is None:
+                r = seen[id(t)] = (t.data_ptr(), _feat(t)[1])
+            return r
+
+        def vptr(t, dtype):
+            r = seen.get(id(t))
+            if r is None:
+                _ptr(t, dtype)
+                r = seen[id(t)] = (t.data_ptr(), False)
+            return r[0]
+
+        cols = [[] for _ in range(12)]
+        for task in tasks:
             b0, b1, a0, a1, k0, k1, m, sel = task[:8]
             c0, c1 = (task[8], task[9]) if len(task) > 8 else (None, None)
-            flags = {_feat(t)[1] for t in (b0, b1, a0, a1)}
-            if len(flags) != 1:
+            f = [feat(t) for t in (b0, b1, a0, a1)]
+            if not (f[0][1] == f[1][1] == f[2][1] == f[3][1]):
                 raise HipError('LtBatch: the four feature tensors of a task must share one dtype')
-            n_bf16 += flags.pop()
-            _ptr(k0, torch.float64); _ptr(k1, torch.float64); _ptr(m, torch.int64)
-            if sel is not None:
-                _ptr(sel, torch.int64)
-            if c0 is not None:
-                _ptr(c0, torch.float32); _ptr(c1, torch.float32); n_coef += 1
+            n_bf16 += f[0][1]
             n = int(sel.shape[0]) if sel is not None else int(m.shape[0])
-            table[i] = (b0.data_ptr(), b1.data_ptr(), a0.data_ptr(), a1.data_ptr(), k0.data_ptr(), k1.data_ptr(), m.data_ptr() if n else 0,
-                        sel.data_ptr() if sel is not None else 0, n, 0, off, c0.data_ptr() if c0 is not None else 0, c1.data_ptr() if c1 is not None else 0)
+            if c0 is not None:
+                n_coef += 1
+            row = (f[0][0], f[1][0], f[2][0], f[3][0], vptr(k0, torch.float64), vptr(k1, torch.float64), vptr(m, torch.int64) if n else 0,
+                   vptr(sel, torch.int64) if sel is not None else 0, n, off,
+                   vptr(c0, torch.float32) if c0 is not None else 0, vptr(c1, torch.float32) if c1 is not None else 0)
+            for col, v in zip(cols, row):
+                col.append(v)
             self.offsets.append((off, n))
             off += n
+        for name, col in zip(('before0', 'before1', 'after0', 'after1', 'keys0', 'keys1', 'matches', 'sel', 'n', 'off', 'coef0', 'coef1'), cols):
+            table[name] = col
         if n_coef not in (0, self.n_tasks) or n_bf16 not in (0, self.n_tasks):
             raise HipError('LtBatch: either every task carries coefficient tensors / bfloat16 features or none does')
         self.flags = (1 if n_coef else 0) | (2 if n_bf16 else 0)
