@@ -179,8 +179,11 @@ class RegistrationEngine:
         """Several clouds per group-conv launch: a 5000-keypoint cloud is 9.2 waves of workgroups on the 512 resident slots,
         so a lone cloud wastes ~8 % in the partial last wave; batching clouds makes that tail negligible."""
         max_rows = self.extract_rows if max_rows is None else max_rows
-        xs = [(f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32).to(self.feat_dtype)
-              for f in feats_list]
+        def on_device(f):                                        # (tensors that already sit on the device in the storage type pass untouched:
+            if torch.is_tensor(f) and f.is_cuda and f.dtype == self.feat_dtype:      #  a no-op `.to()` still costs ~60 us of host time each)
+                return f
+            return (f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32).to(self.feat_dtype)
+        xs = [on_device(f) for f in feats_list]
         out = []
         i = 0
         while i < len(xs):
@@ -206,8 +209,9 @@ class RegistrationEngine:
                 n = xs[q].shape[0]
                 k = keys_list[q]
                 k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
-                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], eqv_ft=eft[o:o + n], inv=inv[o:o + n],
-                                      keys=k.to('cuda', torch.float64).contiguous()))
+                if not (k.is_cuda and k.dtype == torch.float64 and k.is_contiguous()):
+                    k = k.to('cuda', torch.float64).contiguous()
+                out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], eqv_ft=eft[o:o + n], inv=inv[o:o + n], keys=k))
                 o += n
             i = j
         return out
