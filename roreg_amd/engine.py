@@ -420,7 +420,7 @@ class RegistrationEngine:
                 index = np.arange(n)
                 np.random.shuffle(index)                                    # estimator.py:423-424 (the reference's single global stream)
                 hyps.append(np.ascontiguousarray((index if rows is None else rows[index])[0:max_iter], np.int64))
-        hyp_flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros(0, np.int64)).cuda()   # ONE upload of all hypothesis lists
+        hyp_flat = hip.upload(np.concatenate(hyps) if hyps else np.zeros(0, np.int64))               # ONE upload of all hypothesis lists
         hyp_dev, o = [], 0
         for h in hyps:
             hyp_dev.append(hyp_flat[o:o + h.shape[0]]); o += h.shape[0]
@@ -525,7 +525,7 @@ class RegistrationEngine:
                 samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
                            for q, (a, b) in enumerate(pair_ids)]                                    # host; runs under the extractor's kernels
             flat = np.concatenate([np.ascontiguousarray(x, np.int64) for s in samples for x in s]) if samples else np.zeros(0, np.int64)
-            flat_dev = torch.from_numpy(flat).cuda()
+            flat_dev = hip.upload(flat)                   # does not wait for the extractor's kernels: the task table is built under them
             tasks, o = [], 0
             for (a, b), (s0, s1) in zip(pair_ids, samples):
                 c0, c1 = clouds[int(a)], clouds[int(b)]

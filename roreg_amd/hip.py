@@ -140,6 +140,48 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _StagingRing:
+    """Host -> device uploads that do not block the host: a ring of persistent pinned buffers, each guarded by an event recorded behind
+    its last copy.  (A pageable `.cuda()` waits for everything queued on the stream before it copies -- in the middle of a scene that is
+    a full synchronisation after which the host prepares the next launches with the GPU idle; `pin_memory()` per call costs more than
+    that.)  A slot is reused only after its event has completed."""
+
+    def __init__(self, slots=8):
+        self.bufs = [None] * slots
+        self.events = [None] * slots
+        self.next = 0
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        nbytes = a.nbytes
+        if nbytes == 0:
+            return torch.from_numpy(a).cuda()
+        k = self.next
+        self.next = (k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        if self.bufs[k] is None or self.bufs[k].shape[0] < nbytes:
+            self.bufs[k] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        host = self.bufs[k][:nbytes]
+        host.numpy()[:] = a.reshape(-1).view(np.uint8)
+        dev = host.cuda(non_blocking=True).view(torch.from_numpy(a[:0].reshape(-1)).dtype).reshape(a.shape)
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+        return dev
+
+
+_staging = None
+
+
+def upload(array):
+    """numpy array -> device tensor (same shape and dtype) through the staging ring: does not wait for the kernels queued on the stream."""
+    global _staging
+    if _staging is None:
+        _staging = _StagingRing()
+    return _staging.upload(array)
+
+
 def _ptr(t, dtype=None):
     if t is None:
         return None
@@ -436,7 +478,7 @@ class LtBatch:
         self.total = off
         self.max_n = int(table['n'].max()) if self.n_tasks else 0
         self.keep = tasks                              # the table holds raw pointers: keep the tensors alive
-        self.table = torch.from_numpy(table.view(np.uint8).reshape(self.n_tasks, _LT_TASK.itemsize).copy()).cuda() if self.n_tasks else None
+        self.table = upload(table.view(np.uint8).reshape(self.n_tasks, _LT_TASK.itemsize)) if self.n_tasks else None
 
     def prepare(self, rows_alloc=None, bound_bn=None):
         """Des2R + ET input assembly -> (dr int64 [total], x [rows_alloc,128,60] f32; rows beyond total are zero).
@@ -529,7 +571,7 @@ def ransac_batch(tasks, ird):
                     hr.data_ptr() if hr is not None else 0, M, H, koff)
         koff += M
     max_M = int(table['M'].max()); max_H = int(table['H'].max())
-    tdev = torch.from_numpy(table.view(np.uint8).reshape(n, _RANSAC_TASK.itemsize).copy()).to(dev)
+    tdev = upload(table.view(np.uint8).reshape(n, _RANSAC_TASK.itemsize))
     ws_n = lib().roreg_ransac_batch_workspace(n, koff, max_H)
     ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.float64, device=dev)
     _check(lib().roreg_ransac_batch(_ptr(tdev), n, koff, max(max_M, 1), max_H, float(ird), _ptr(best), _ptr(T1), _ptr(st1), _ptr(T2), _ptr(st2),
@@ -564,7 +606,7 @@ def mutual_match_batch(tasks):
     cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)[:n]
     if n == 0:
         return out, cnt
-    tdev = torch.from_numpy(table.view(np.uint8).reshape(n, _MATCH_TASK.itemsize).copy()).to(dev)
+    tdev = upload(table.view(np.uint8).reshape(n, _MATCH_TASK.itemsize))
     ws_n = lib().roreg_mutual_match_batch_workspace(n, max_m)
     ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.int64, device=dev)
     _check(lib().roreg_mutual_match_batch(_ptr(tdev), n, max_m, _ptr(out), _ptr(cnt), _ptr(ws), ws_n, _stream()), 'roreg_mutual_match_batch')
