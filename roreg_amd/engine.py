@@ -302,7 +302,7 @@ class RegistrationEngine:
             return []
         max_points = self.rm_max_points if max_points is None else max_points
         flat = np.concatenate([np.ascontiguousarray(x, np.int64) for _, _, s0, s1 in jobs for x in (s0, s1)])
-        flat_dev = torch.from_numpy(flat).cuda()                            # ONE upload of all sample lists
+        flat_dev = hip.upload(flat)                                         # ONE upload of all sample lists
         rows, o = [], 0
         for _, _, s0, s1 in jobs:
             rows.append((flat_dev[o:o + len(s0)], flat_dev[o + len(s0):o + len(s0) + len(s1)])); o += len(s0) + len(s1)
@@ -329,7 +329,7 @@ class RegistrationEngine:
         for (c0, c1, s0, s1), (m, _) in zip(jobs, issued):
             n = int(m.shape[0])
             out.append(self._match_rm_finish(s0, s1, m0_all[o:o + n], sc_all[o:o + n])); o += n
-        flat = torch.from_numpy(np.concatenate([m.reshape(-1) for m, _ in out])).cuda()
+        flat = hip.upload(np.concatenate([m.reshape(-1) for m, _ in out]))
         res, o = [], 0
         for m, sc in out:
             res.append((flat[o:o + m.size].view(-1, 2), sc)); o += m.size
@@ -431,9 +431,14 @@ class RegistrationEngine:
                 writer.save(f'DR_index/{a}-{b}', dr); writer.save(f'Trans_pre/{a}-{b}', Trans)
         # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
         rt, w_all = [], []
+        have = [sc is not None for sc in all_scores]
+        w_flat = hip.upload(np.concatenate([sc.astype(np.float64) for sc in all_scores if sc is not None])) if any(have) else None   # ONE upload
+        o = 0
         for (c0, c1, matches), h, sc, (dr, Trans) in zip(full, hyp_dev, all_scores, lts):
             hyp = h if all_local_transforms else None                                      # else Trans is already in hypothesis order
-            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()     # None = ones(M)  (matcher.py:109)
+            w = None                                                                       # None = ones(M)  (matcher.py:109)
+            if sc is not None:
+                w = w_flat[o:o + sc.shape[0]]; o += sc.shape[0]
             rt.append((c0.keys, c1.keys, matches, w, Trans, hyp)); w_all.append(w)
         return rt, w_all
 

@@ -829,7 +829,7 @@ class Segments:
     def __init__(self, lengths):
         lengths = np.asarray(lengths, np.int64)
         self.host = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
-        self.dev = torch.from_numpy(self.host).cuda()
+        self.dev = upload(self.host)
         self.n = int(lengths.shape[0]); self.max = int(lengths.max()); self.min = int(lengths.min()); self.total = int(self.host[-1])
 
 
@@ -952,7 +952,7 @@ def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters):
     s0 = torch.empty(tm, dtype=torch.float32, device=dev); s1 = torch.empty(tn, dtype=torch.float32, device=dev)
     consts = np.empty(4 * seg_src.n, np.float32)
     _check(lib().roreg_sinkhorn_batch_consts(seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, seg_src.n, consts.ctypes.data), 'roreg_sinkhorn_batch_consts')
-    cdev = torch.from_numpy(consts).to(dev)
+    cdev = upload(consts)
     wsn = lib().roreg_sinkhorn_batch_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
     ws = torch.empty(wsn, dtype=torch.float32, device=dev)
     _check(lib().roreg_sinkhorn_batch(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
