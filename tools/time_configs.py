@@ -30,11 +30,13 @@ for name, kw in (('mutual+yohoo', dict(keynum=5000, ET='yohoo')), ('mutual+yohoc
         rm = name2network['RM_test'](cfg); rm.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RM').items()})
     eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
     try:
-        for rep in range(3):
-            eng.phase_ms = {} if rep == 2 and '--phases' in sys.argv else None
+        times = []
+        for rep in range(7):                                      # two warm-up passes, then the median of five
+            eng.phase_ms = {} if rep == 6 and '--phases' in sys.argv else None
             np.random.seed(7); torch.cuda.synchronize(); t = time.perf_counter()
             res = eng.run_scene(feats, keys, pair_ids, keynum=cfg.keynum)
-            torch.cuda.synchronize(); dt = time.perf_counter() - t
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t)
+        dt = float(np.median(times[2:]))
         if eng.phase_ms:
             print('   phases (ms, synchronised):', {k: round(v, 1) for k, v in eng.phase_ms.items()})
         ok = np.mean([np.isfinite(r.trans).all() for r in res])
