@@ -411,10 +411,10 @@ class RegistrationEngine:
         n_of = [int(m.shape[0]) if r is None else int(r.shape[0]) for (_, _, m), r in zip(full, rows_of)]
         if pair_seeds is not None and len(full):
             # one threaded host call for every pair's `seed(pair seed + 1); shuffle(arange(n))[:max_iter]` (hip.mt_shuffle_prefix)
-            drawn = hip.mt_shuffle_prefix(np.asarray(pair_seeds, np.int64) + 1, np.array(n_of, np.int32)[:, None], max_iter)
+            drawn = hip.mt_shuffle_prefix(np.asarray(pair_seeds, np.int64) + 1, np.array(n_of, np.int32)[:, None], max_iter)[:, 0]
             for q, (rows, n) in enumerate(zip(rows_of, n_of)):
-                index = drawn[q, 0, :min(max_iter, n)]
-                hyps.append(np.ascontiguousarray(index if rows is None else rows[index], np.int64))
+                index = drawn[q, :min(max_iter, n)]                         # (a contiguous int64 row view: no per-pair copy)
+                hyps.append(index if rows is None else np.ascontiguousarray(rows[index], np.int64))
         else:
             for rows, n in zip(rows_of, n_of):
                 index = np.arange(n)

@@ -786,7 +786,7 @@ def mt_shuffle_prefix(seeds, sizes, take, n_threads=None):
     sizes = np.ascontiguousarray(sizes, np.int32).reshape(seeds.shape[0], -1)
     out = np.empty((seeds.shape[0], sizes.shape[1], int(take)), np.int64)
     if seeds.shape[0]:
-        nt = n_threads if n_threads is not None else max(1, min(16, (os.cpu_count() or 2) // 2))
+        nt = n_threads if n_threads is not None else max(1, min(32, (os.cpu_count() or 2) // 2, seeds.shape[0] // 8 + 1))
         _check(lib().roreg_mt_shuffle_prefix(c_void_p(seeds.ctypes.data), seeds.shape[0], c_void_p(sizes.ctypes.data), sizes.shape[1], int(take),
                                              c_void_p(out.ctypes.data), int(nt)), 'roreg_mt_shuffle_prefix')
     return out
