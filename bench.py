@@ -2,6 +2,7 @@
 """bench.py -- pair-registrations/sec of the RoReg hot path on MI355X.
 
     python bench.py [--gpus N --steps K --warmup W] [--workload 3dmatch-full | kitchen | chunk] [--gemm f16x2 | bf16x3 | f32]
+                    [--dtype fp32 | bf16] [--pair-lists banded | uniform]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the whole hot path (GF extractor on every cloud, mutual matcher, Des2R + ET local transforms, one-shot
@@ -9,7 +10,8 @@ RANSAC + 2 refinements on every pair) over the workload, inputs resident in HBM 
 
   3dmatch-full (default, every N): the full 3DMatch test shape (BASELINE.json configs[2]) -- 8 synthetic scenes with the benchmark's
            station counts [60,60,60,55,57,37,66,38] (dataops/dataset.py:152) = 433 clouds x 5000 keypoints and 1623 pairs (kitchen: 60 clouds,
-           449 pairs), random-init GF/ET weights of the reference's architecture.  With N ranks the pairs are sharded by
+           449 pairs; pair lists: the chain (i, i+1) plus pairs drawn with probability ~ exp(-|i-j|/8), --pair-lists uniform for uniformly
+           drawn ones), random-init GF/ET weights of the reference's architecture.  With N ranks the pairs are sharded by
            roreg_amd.distributed.shard_scenes (whole scenes first, the largest scene cut into pair ranges), no data-path collective,
            ONE all_gather of the result table per step: STRONG scaling, the same command for every N.  At N = 1 the whole benchmark runs
            on one GPU (it fits: 16.6 GB of inputs); the kitchen scene alone (configs[1]) is timed inside the same steps and reported as
