@@ -21,6 +21,12 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------ */
+/* Version of THIS header.  It is bumped whenever an existing entry point changes its argument list or a shared struct its size
+ * (2: round 2's per-keypoint block scales -- roreg_gf_finalize, roreg_inv_descriptor, roreg_et_gather, roreg_dense_split/_f16x2,
+ * roreg_lt_prepare_batch, roreg_group_conv_f16x2, roreg_lt_task 80 -> 96 bytes; 3: round 3 -- roreg_ransac_score / roreg_refine /
+ * roreg_ransac_batch take `w_f32`, the scores' storage type).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
+#define ROREG_ABI_VERSION 3
 int roreg_abi_version(void);
 const char *roreg_last_error(void);
 
@@ -202,8 +208,12 @@ int roreg_quat_to_trans(const float *q, const int64_t *anchor, const double *key
  * increasing i.  k0,k1 f64 [M,3] (already gathered by match), w f64 [M].  best_out (device int32[1]) gets
  * the first h with the strictly greatest overlap (estimator.py:430-436; -1 if every overlap is 0);
  * mask_out (uint8 [H,M], optional) the inlier masks.
+ * w_f32 != 0: the scores are the rotation-coherence matcher's float32 array (test/matcher.py:210; every w_i is a float32 value): the
+ * reference's np.sum(scores[inliers]) is then numpy's PAIRWISE float32 reduction over the compacted inlier array and its quotient by M a
+ * float32 division (test/estimator.py:381), which the kernel rebuilds bit for bit, so that hypotheses whose overlaps tie only after
+ * float32 rounding keep the reference's order under the strict `>` of :433; overlap_out holds those float32 values widened.
  * Replaces yohoo_ransac.overlap_cal and the hypothesis loop (test/estimator.py:377-382,426-436). */
-int roreg_ransac_score(const double *k0, const double *k1, const double *w, int M,
+int roreg_ransac_score(const double *k0, const double *k1, const double *w, int w_f32, int M,
                        const double *Trans, const int64_t *hyp_rows, int H, double ird,
                        double *overlap_out, int32_t *best_out, uint8_t *mask_out, void *stream);
 
@@ -212,9 +222,10 @@ int roreg_ransac_score(const double *k0, const double *k1, const double *w, int 
  * the 3x3 SVD (no reflection guard); t = c0 - c1 R^T.  T_out f64 [4,4].  The SVD runs on the device
  * (one-sided Jacobi); when H is rank-deficient (<= 2 inliers, collinear inliers) U V^T is not unique and the
  * reference's value is whatever LAPACK's null-space basis gives, so stats_out exposes H, the centroids and
- * the weight sum for a host LAPACK evaluation of exactly that case.
+ * the weight sum for a host LAPACK evaluation of exactly that case.  w_f32 != 0 (float32 scores, as in roreg_ransac_score): the
+ * normalisation scores / np.sum(scores) runs in float32 like the reference's (:50), pairwise sum and per-weight float32 quotient.
  * Replaces refiner.Refine_trans (test/estimator.py:28-72). */
-int roreg_refine(const double *k0, const double *k1, const double *w, int M,
+int roreg_refine(const double *k0, const double *k1, const double *w, int w_f32, int M,
                  const double *T_in, int t_in_stride /* 4 for 3x4/4x4 rows */,
                  const double *Trans, const int64_t *hyp_rows, const int32_t *best,
                  double dist, double *T_out, double *stats_out /* optional f64[16]: H(9), c0(3), c1(3), sum w */,
@@ -259,6 +270,7 @@ typedef struct {
 } roreg_ransac_task;
 size_t roreg_ransac_batch_workspace(int n_tasks, long long total_M, int max_H);
 int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long long total_M, int max_M, int max_H, double ird,
+                       int w_f32 /* the tasks' scores are float32 values: numpy's float32 reductions, see roreg_ransac_score */,
                        int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 

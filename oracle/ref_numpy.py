@@ -270,6 +270,43 @@ def overlap_cal(k0, k1, T, scores, ird):
     return np.sum(scores[inl]) / scores.shape[0]
 
 
+def np_sum_f32_model(a):
+    """What np.sum does to a contiguous float32 vector, written out (numpy/_core/src/umath/loops_utils.h.src `pairwise_sum`, the reduction
+    loop's 8192-element buffer): the order the HIP kernels rebuild for float32 match scores (csrc/ransac.hip).  Pure-Python loops, small
+    cases only; tests compare it with np.sum itself."""
+    f = np.float32
+
+    def leaf(x):
+        n = len(x)
+        if n < 8:
+            r = f(0)
+            for v in x:
+                r = f(r + v)
+            return r
+        r = [x[j] for j in range(8)]
+        nb = n - n % 8
+        for i in range(8, nb, 8):
+            for j in range(8):
+                r[j] = f(r[j] + x[i + j])
+        res = f(f(f(r[0] + r[1]) + f(r[2] + r[3])) + f(f(r[4] + r[5]) + f(r[6] + r[7])))
+        for i in range(nb, n):
+            res = f(res + x[i])
+        return res
+
+    def pairwise(x):
+        n = len(x)
+        if n <= 128:
+            return leaf(x)
+        n2 = 8 * (n // 16)
+        return f(pairwise(x[:n2]) + pairwise(x[n2:]))
+
+    a = [f(v) for v in a]
+    res = f(0)
+    for i in range(0, max(len(a), 1), 8192):
+        res = f(res + pairwise(a[i:i + 8192]))
+    return res
+
+
 def refine_trans(k0, k1, T, scores, dist):
     """refiner.Refine_trans (estimator.py:28-72)."""
     T = np.asarray(T, np.float64)[:3]

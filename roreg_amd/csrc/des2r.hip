@@ -103,10 +103,14 @@ __global__ __launch_bounds__(256) void des2r_batch_kernel(const roreg::LtTask *_
 // i.e. per channel sum_rho d^3 = 244 multiply-adds for C instead of 3600, plus ONE 60 x 60 product per correspondence -- 10x fewer
 // operations, no permuted gather.  The per-keypoint coefficients are computed once per cloud (roreg_feat_coefs).  That value is an
 // approximation of the float32 number the reference computes (different arithmetic), so it only BOUNDS: every a with
-// cor~[a] >= max cor~ - margin is a candidate, margin = 6e-5 |d1| |d2| >= 2 (|cor~ - exact| + |literal f32 - exact|): the literal
-// evaluation is two-level, 60 then 32 terms, error <= (93 eps) sum |terms| <= 5.6e-6 |d1||d2|; the irrep evaluation -- f32-accurate
-// transforms (a few eps per coefficient), 160 + 60 chained fmas -- <= 1.5e-5 |d1||d2|; so the literal first arg-max is always among the
-// candidates.  One candidate: done.
+// cor~[a] >= max cor~ - margin is a candidate, margin = 1e-4 |d1| |d2| >= 2 (|cor~ - exact| + |literal f32 - exact|):
+//   * the literal evaluation is two-level, 60 then 32 terms: error <= (93 eps) sum |terms| <= 5.6e-6 |d1||d2|;
+//   * the irrep evaluation: its terms are rho(a)[j][i] C_rho[i][j] with sum over (rho,i,j) of |terms| <= || |rho(a)| ||_2 |d1||d2| and the
+//     entrywise-absolute representation matrices have spectral norm <= sqrt(5) (largest irrep, d = 5), NOT 1 -- so the 160 + 60 chained
+//     fmas err by <= 220 eps sqrt(5) |d1||d2| = 2.9e-5 |d1||d2|, plus the coefficient transform's own rounding (a few eps per coefficient
+//     in f32 / bf16x3 mode, ~2^-22 relative in fp16x2 mode) <= 1e-6 |d1||d2|: together <= 3.0e-5 |d1||d2|;
+//   2 (3.0e-5 + 5.6e-6) = 7.1e-5 < 1e-4 (round 2 used 6e-5 from an under-estimate of the first bound; the candidate rate rises from 0.7 %
+//   to ~1.2 % of noise-level correspondences), so the literal first arg-max is always among the candidates.  One candidate: done.
 // Several (near ties, duplicates -- a few per cent of random correspondences, none of the well-matched ones): the candidates are
 // re-evaluated with the literal formula in the reference's order (des2r_body above, bit for bit) from the group-domain rows, and the first
 // maximum of those wins.  Result: the index of the literal evaluation, always.
@@ -215,7 +219,7 @@ __device__ __forceinline__ void des2r_irrep_loop(RowFn rows_of, int n_iter, cons
             const int oi = __shfl_xor(bi, o);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        const float margin = 6e-5f * sqrtf(n1 * n0);
+        const float margin = 1e-4f * sqrtf(n1 * n0);
         unsigned long long cand = __ballot(act && !(mine < bv - margin));        // (NaN-safe: a NaN correlation stays a candidate)
         if (!(margin == margin) || !(bv > -__builtin_inff())) cand = 0xfffffffffffffffull;     // non-finite input: evaluate every a literally
         if (__popcll(cand) > 1 && me.live) {

@@ -35,6 +35,142 @@ __device__ __forceinline__ bool point_inlier(const double *__restrict__ T, doubl
 // floating-point operation as adding a loaded 1.0.
 __device__ __forceinline__ double weight_of(const double *__restrict__ w, int i) { return w ? w[i] : 1.0; }
 
+// ---- float32 match scores (the rotation-coherence matcher's, test/matcher.py:210): numpy's float32 sum, bit for bit ------------------
+// With --RM the reference's scores are a float32 array, so `np.sum(scores[overlap])` (test/estimator.py:381) and `np.sum(scores)` of the
+// refinement (:50) are float32 reductions in numpy's PAIRWISE order over the compacted inlier array, and `overlap` is that float32 sum
+// divided by M in float32 (numpy 2 promotion: float32 scalar / Python int); the running `overlap > best_overlap` (:433) compares those
+// float32 values.  Accumulating the same weights in float64 orders two hypotheses differently whenever their overlaps tie only after
+// float32 rounding, so in this mode (w_f32) the kernels rebuild numpy's reduction tree:
+//   pairwise(a, n): n < 8: ((0 + a0) + a1) + ...;  n <= 128: r[j] = a[j] + a[8+j] + ... over the multiple-of-8 prefix (j < 8),
+//   ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then the < 8 trailing elements one by one;  n > 128: pairwise(a, n2) + pairwise(a + n2, n - n2)
+//   with n2 = 8 * floor(n / 16);  and the reduction loop hands pairwise() at most 8192 elements at a time (numpy's buffer size), adding
+//   the chunk sums to a running float32 total  (numpy/_core/src/umath/loops_utils.h.src; checked against np.sum for n = 0..30000 by
+//   tests/test_oracle_golden.py::test_numpy_pairwise_model).
+// One wavefront owns one compacted array in LDS (`buf`, filled in increasing i by ballot + prefix count); `tab` / `lsum` hold the leaf
+// table (start, length) and the leaf sums (<= NP_MAX_LEAVES for 8192 elements).
+constexpr int NP_CHUNK = 8192;
+constexpr int NP_MAX_LEAVES = 80;                       // leaves hold 57..128 elements once n > 128: 8192 / 128 = 64 (+ slack)
+
+struct NpSumScratch {
+    int32_t start[NP_MAX_LEAVES], len[NP_MAX_LEAVES];
+    float lsum[NP_MAX_LEAVES];
+    int32_t stack[40];
+    float vstack[24];
+};
+
+// pairwise float32 sum of buf[0..n) (n <= NP_CHUNK) by one wavefront; every lane returns the value.  buf / sc: this wave's LDS.
+__device__ float np_pairwise_sum_wave(const float *buf, int n, NpSumScratch *sc) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");         // the compaction's LDS writes of the other lanes
+    __builtin_amdgcn_wave_barrier();
+    if (n == 0) return 0.f;
+    // leaf table, in the recursion's left-to-right order (uniform control flow; lane 0 writes)
+    int L = 0;
+    if (lane == 0) {
+        int sp = 0, at = 0;
+        sc->stack[sp++] = n;
+        while (sp > 0) {
+            const int m = sc->stack[--sp];
+            if (m <= 128) { sc->start[L] = at; sc->len[L] = m; at += m; ++L; }
+            else { const int n2 = 8 * (m / 16); sc->stack[sp++] = m - n2; sc->stack[sp++] = n2; }
+        }
+    }
+    L = __builtin_amdgcn_readfirstlane(L);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // leaf sums: eight lanes per leaf (lane j owns r[j]), eight leaves per round
+    const int grp = lane >> 3, j = lane & 7;
+    for (int l0 = 0; l0 < L; l0 += 8) {
+        const int l = l0 + grp;
+        const bool live = l < L;
+        const int s0 = live ? sc->start[l] : 0, len = live ? sc->len[l] : 0;
+        float res;
+        if (len < 8) {                                            // only the whole array can be this short
+            res = 0.f;
+            for (int i = 0; i < len; ++i) res = __fadd_rn(res, buf[s0 + i]);
+        } else {
+            const int nb = len - (len & 7);
+            float r = buf[s0 + j];
+            for (int i = 8; i < nb; i += 8) r = __fadd_rn(r, buf[s0 + i + j]);
+            r = __fadd_rn(r, __shfl_xor(r, 1));                   // (r0+r1), (r2+r3), ...
+            r = __fadd_rn(r, __shfl_xor(r, 2));                   // ((r0+r1)+(r2+r3)), ((r4+r5)+(r6+r7))
+            r = __fadd_rn(r, __shfl_xor(r, 4));
+            res = r;
+            for (int i = nb; i < len; ++i) res = __fadd_rn(res, buf[s0 + i]);
+        }
+        if (live && j == 0) sc->lsum[l] = res;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // the recursion's additions, post-order (left + right), lane 0
+    float total = 0.f;
+    if (lane == 0) {
+        int sp = 0, vp = 0, next = 0;
+        sc->stack[sp++] = n;
+        while (sp > 0) {
+            const int m = sc->stack[--sp];
+            if (m < 0) { const float b = sc->vstack[--vp], a = sc->vstack[--vp]; sc->vstack[vp++] = __fadd_rn(a, b); }
+            else if (m <= 128) sc->vstack[vp++] = sc->lsum[next++];
+            else { const int n2 = 8 * (m / 16); sc->stack[sp++] = -1; sc->stack[sp++] = m - n2; sc->stack[sp++] = n2; }
+        }
+        total = sc->vstack[0];
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, total)));
+}
+
+// np.sum of the float32 weights of the inliers among i in [0, M), in increasing i: streamed through the wave's LDS buffer in numpy's
+// chunks of 8192 compacted elements.  `in_at(i)` is evaluated once per i by lane i % 64.  Every lane returns the float32 sum.
+template <int CAP, class InlierFn>
+__device__ float np_sum_f32_of_inliers(const double *__restrict__ w, int M, float *buf, NpSumScratch *sc, InlierFn in_at, int *count_out) {
+    static_assert(CAP <= NP_CHUNK && (CAP == NP_CHUNK || CAP % 64 == 0), "buffer is one numpy chunk at most");
+    const int lane = threadIdx.x & 63;
+    int fill = 0, total_n = 0;
+    float res = 0.f;
+    bool any_chunk = false;
+    for (int base = 0; base < M; base += 64) {
+        const int i = base + lane;
+        const bool in = i < M && in_at(i);
+        const unsigned long long b = __ballot(in);
+        const int pos = fill + __popcll(b & ((1ull << lane) - 1ull));
+        const int cnt = __popcll(b);
+        const float wi = in ? (float)w[i] : 0.f;
+        if (in && pos < CAP) buf[pos] = wi;
+        if (fill + cnt >= CAP && CAP == NP_CHUNK) {               // a full numpy chunk: reduce it, carry the spill over
+            res = __fadd_rn(res, np_pairwise_sum_wave(buf, CAP, sc));
+            any_chunk = true;
+            __builtin_amdgcn_wave_barrier();
+            if (in && pos >= CAP) buf[pos - CAP] = wi;
+            fill = fill + cnt - CAP;
+        } else {
+            fill += cnt;
+        }
+        total_n += cnt;
+    }
+    if (fill > 0 || !any_chunk) res = __fadd_rn(res, np_pairwise_sum_wave(buf, fill, sc));
+    if (count_out) *count_out = total_n;
+    return res;
+}
+
+// float32-score form of the scoring (see above): overlap[h] = float32(np.sum(float32 w[inliers])) / float32(M), stored widened.
+template <int CAP>
+__device__ __forceinline__ void ransac_score_body_f32(const double *__restrict__ k0, const double *__restrict__ k1,
+                                                      const double *__restrict__ w, int M, const double *__restrict__ Trans,
+                                                      const int64_t *__restrict__ hyp_rows, int H, double thr2, int h,
+                                                      double *__restrict__ overlap, uint8_t *__restrict__ mask, float *buf, NpSumScratch *sc) {
+    const int lane = threadIdx.x & 63;
+    if (h >= H) return;                                            // (wave-uniform)
+    const size_t row = hyp_rows ? (size_t)hyp_rows[h] : (size_t)h;
+    double T[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) T[q] = Trans[row * 12 + q];
+    const float sum = np_sum_f32_of_inliers<CAP>(w, M, buf, sc, [&](int i) {
+        const bool in = point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2);
+        if (mask) mask[(size_t)h * M + i] = in ? 1 : 0;
+        return in;
+    }, nullptr);
+    if (lane == 0) overlap[h] = (double)__fdiv_rn(sum, (float)M);
+}
+
 __device__ __forceinline__ void ransac_score_body(const double *__restrict__ k0, const double *__restrict__ k1,
                                                   const double *__restrict__ w, int M, const double *__restrict__ Trans,
                                                   const int64_t *__restrict__ hyp_rows, int H, double thr2, int h,
@@ -60,6 +196,19 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restr
                                                            const int64_t *__restrict__ hyp_rows, int H, double thr2,
                                                            double *__restrict__ overlap, uint8_t *__restrict__ mask) {
     ransac_score_body(k0, k1, w, M, Trans, hyp_rows, H, thr2, blockIdx.x * 4 + (threadIdx.x >> 6), overlap, mask);
+}
+
+// float32-score variants: WAVES hypotheses per workgroup, each wave with a compaction buffer of CAP floats in LDS
+// (<4, 4096>: M <= 4096, 64 KB; <2, 8192>: any M, one numpy chunk per wave, 64 KB)
+template <int WAVES, int CAP>
+__global__ __launch_bounds__(WAVES * 64) void ransac_score_f32_kernel(const double *__restrict__ k0, const double *__restrict__ k1,
+                                                                     const double *__restrict__ w, int M, const double *__restrict__ Trans,
+                                                                     const int64_t *__restrict__ hyp_rows, int H, double thr2,
+                                                                     double *__restrict__ overlap, uint8_t *__restrict__ mask) {
+    __shared__ float buf[WAVES][CAP];
+    __shared__ NpSumScratch sc[WAVES];
+    const int wv = threadIdx.x >> 6;
+    ransac_score_body_f32<CAP>(k0, k1, w, M, Trans, hyp_rows, H, thr2, blockIdx.x * WAVES + wv, overlap, mask, buf[wv], &sc[wv]);
 }
 
 // first index of the strictly greatest overlap (> 0), as the reference's running '>' scan
@@ -165,13 +314,19 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// F32W: the match scores are float32 (rotation-coherence matcher): the reference normalises them in float32 -- scores / np.sum(scores),
+// test/estimator.py:50, numpy's pairwise float32 sum over the compacted inliers and a float32 division per weight -- before the float64
+// centroid / cross-covariance sums, and so does this body (wave 0 rebuilds the sum; see np_pairwise_sum_wave above).
+template <bool F32W>
 __device__ __forceinline__ void refine_body(const double *__restrict__ k0, const double *__restrict__ k1,
                                             const double *__restrict__ w, int M, const double *__restrict__ T_in,
                                             int t_stride, const double *__restrict__ Trans,
                                             const int64_t *__restrict__ hyp_rows, const int32_t *__restrict__ best,
-                                            double thr2, double *__restrict__ T_out, double *__restrict__ stats) {
+                                            double thr2, double *__restrict__ T_out, double *__restrict__ stats,
+                                            float *npbuf = nullptr, NpSumScratch *npsc = nullptr) {
     __shared__ double red[4];
     __shared__ double Ts[12];
+    __shared__ float S32s;
     const int tid = threadIdx.x;
     if (tid < 12) {
         double v;
@@ -191,11 +346,23 @@ __device__ __forceinline__ void refine_body(const double *__restrict__ k0, const
     double T[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) T[q] = Ts[q];
+    float S32 = 1.f;
+    if (F32W) {
+        if (tid < 64) {
+            const float v = np_sum_f32_of_inliers<NP_CHUNK>(w, M, npbuf, npsc, [&](int i) {
+                return point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2); }, nullptr);
+            if (tid == 0) S32s = v;
+        }
+        __syncthreads();
+        S32 = S32s;
+    }
+    // the weight a correspondence enters the sums with: w_i (normalised by the sum afterwards) / float32(w_i) / float32 sum (already normalised)
+    auto weight = [&](int i) -> double { return F32W ? (double)__fdiv_rn((float)w[i], S32) : weight_of(w, i); };
     // pass 1: sum of weights and weighted sums of the inlier keypoints
     double sw = 0, a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
     for (int i = tid; i < M; i += 256) {
         if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) {
-            const double wi = weight_of(w, i);
+            const double wi = weight(i);
             sw += wi;
             a0 += wi * k0[3 * i]; a1 += wi * k0[3 * i + 1]; a2 += wi * k0[3 * i + 2];
             b0 += wi * k1[3 * i]; b1 += wi * k1[3 * i + 1]; b2 += wi * k1[3 * i + 2];
@@ -206,13 +373,14 @@ __device__ __forceinline__ void refine_body(const double *__restrict__ k0, const
         if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) cnt += 1.0;
     const int n_inl = (int)block_sum(cnt, red, tid);
     sw = block_sum(sw, red, tid);
+    if (F32W) sw = n_inl > 0 ? 1.0 : 0.0;                          // the weights are normalised already (their float32 sum is stats[15])
     double c0x = block_sum(a0, red, tid) / sw, c0y = block_sum(a1, red, tid) / sw, c0z = block_sum(a2, red, tid) / sw;
     double c1x = block_sum(b0, red, tid) / sw, c1y = block_sum(b1, red, tid) / sw, c1z = block_sum(b2, red, tid) / sw;
     // pass 2: H = sum w' (k0-c0)(k1-c1)^T
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < M; i += 256) {
         if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) {
-            const double wi = weight_of(w, i) / sw;
+            const double wi = F32W ? weight(i) : weight_of(w, i) / sw;
             const double ax = k0[3 * i] - c0x, ay = k0[3 * i + 1] - c0y, az = k0[3 * i + 2] - c0z;
             const double bx = k1[3 * i] - c1x, by = k1[3 * i + 1] - c1y, bz = k1[3 * i + 2] - c1z;
             h[0] += wi * ax * bx; h[1] += wi * ax * by; h[2] += wi * ax * bz;
@@ -232,9 +400,16 @@ __device__ __forceinline__ void refine_body(const double *__restrict__ k0, const
         for (int i = 0; i < M && n < 7; ++i)
             if (point_inlier(T, k0[3 * i], k0[3 * i + 1], k0[3 * i + 2], k1[3 * i], k1[3 * i + 1], k1[3 * i + 2], thr2)) id[n++] = i;
         double ssum = 0.0;
-        for (int q = 0; q < n; ++q) ssum = ssum + weight_of(w, id[q]);
         double sk[7], c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
-        for (int q = 0; q < n; ++q) sk[q] = weight_of(w, id[q]) / ssum;
+        if (F32W) {                                                // float32 scores: the sequential float32 sum and float32 quotients
+            float s32 = 0.f;
+            for (int q = 0; q < n; ++q) s32 = __fadd_rn(s32, (float)w[id[q]]);
+            for (int q = 0; q < n; ++q) sk[q] = (double)__fdiv_rn((float)w[id[q]], s32);
+            ssum = 1.0;
+        } else {
+            for (int q = 0; q < n; ++q) ssum = ssum + weight_of(w, id[q]);
+            for (int q = 0; q < n; ++q) sk[q] = weight_of(w, id[q]) / ssum;
+        }
         for (int q = 0; q < n; ++q)
             for (int d = 0; d < 3; ++d) {
                 const double pa = k0[3 * id[q] + d] * sk[q], pb = k1[3 * id[q] + d] * sk[q];
@@ -264,17 +439,21 @@ __device__ __forceinline__ void refine_body(const double *__restrict__ k0, const
         T_out[12] = 0; T_out[13] = 0; T_out[14] = 0; T_out[15] = 1;
         if (stats) {      // [H (9), c0 (3), c1 (3), sum of weights]: lets the host redo the 3x3 SVD with LAPACK when H is rank-deficient
             for (int q = 0; q < 9; ++q) stats[q] = Hm[q];
-            stats[9] = c0x; stats[10] = c0y; stats[11] = c0z; stats[12] = c1x; stats[13] = c1y; stats[14] = c1z; stats[15] = sw;
+            stats[9] = c0x; stats[10] = c0y; stats[11] = c0z; stats[12] = c1x; stats[13] = c1y; stats[14] = c1z;
+            stats[15] = F32W ? (double)S32 : sw;
         }
     }
 }
 
+template <bool F32W>
 __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ k0, const double *__restrict__ k1,
                                                      const double *__restrict__ w, int M, const double *__restrict__ T_in,
                                                      int t_stride, const double *__restrict__ Trans,
                                                      const int64_t *__restrict__ hyp_rows, const int32_t *__restrict__ best,
                                                      double thr2, double *__restrict__ T_out, double *__restrict__ stats) {
-    refine_body(k0, k1, w, M, T_in, t_stride, Trans, hyp_rows, best, thr2, T_out, stats);
+    __shared__ float npbuf[F32W ? NP_CHUNK : 1];
+    __shared__ NpSumScratch npsc;
+    refine_body<F32W>(k0, k1, w, M, T_in, t_stride, Trans, hyp_rows, best, thr2, T_out, stats, npbuf, &npsc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -310,29 +489,60 @@ __global__ __launch_bounds__(256) void ransac_score_batch_kernel(const RansacTas
                       blockIdx.x * 4 + (threadIdx.x >> 6), overlap_all + (size_t)blockIdx.y * pitch_h, nullptr);
 }
 
+template <int WAVES, int CAP>
+__global__ __launch_bounds__(WAVES * 64) void ransac_score_batch_f32_kernel(const RansacTask *__restrict__ tasks, const double *__restrict__ k0_all,
+                                                                           const double *__restrict__ k1_all, double thr2, int pitch_h,
+                                                                           double *__restrict__ overlap_all) {
+    __shared__ float buf[WAVES][CAP];
+    __shared__ NpSumScratch sc[WAVES];
+    const RansacTask t = tasks[blockIdx.y];
+    if ((int)blockIdx.x * WAVES >= t.H) return;
+    const int wv = threadIdx.x >> 6;
+    if (t.w)
+        ransac_score_body_f32<CAP>(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, t.Trans, t.hyp_rows, t.H, thr2, blockIdx.x * WAVES + wv,
+                                   overlap_all + (size_t)blockIdx.y * pitch_h, nullptr, buf[wv], &sc[wv]);
+    else                                                           // no scores = ones: any order gives the exact integer count
+        ransac_score_body(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, t.Trans, t.hyp_rows, t.H, thr2, blockIdx.x * WAVES + wv,
+                          overlap_all + (size_t)blockIdx.y * pitch_h, nullptr);
+}
+
 __global__ __launch_bounds__(256) void first_best_batch_kernel(const RansacTask *__restrict__ tasks, int pitch_h,
                                                                const double *__restrict__ overlap_all, int32_t *__restrict__ best_all) {
     first_best_body(overlap_all + (size_t)blockIdx.x * pitch_h, tasks[blockIdx.x].H, best_all + blockIdx.x);
 }
 
+template <bool F32W>
 __global__ __launch_bounds__(256) void refine_batch_kernel(const RansacTask *__restrict__ tasks, const double *__restrict__ k0_all,
                                                            const double *__restrict__ k1_all, const double *__restrict__ T_in_all,
                                                            const int32_t *__restrict__ best_all, double thr2,
                                                            double *__restrict__ T_out_all, double *__restrict__ stats_all) {
+    __shared__ float npbuf[F32W ? NP_CHUNK : 1];
+    __shared__ NpSumScratch npsc;
     const RansacTask t = tasks[blockIdx.x];
-    refine_body(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, T_in_all ? T_in_all + (size_t)blockIdx.x * 16 : nullptr, 4, t.Trans,
+    if (F32W && t.w)
+        refine_body<true>(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, T_in_all ? T_in_all + (size_t)blockIdx.x * 16 : nullptr, 4, t.Trans,
+                          t.hyp_rows, T_in_all ? nullptr : best_all + blockIdx.x, thr2, T_out_all + (size_t)blockIdx.x * 16,
+                          stats_all + (size_t)blockIdx.x * 16, npbuf, &npsc);
+    else
+    refine_body<false>(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, T_in_all ? T_in_all + (size_t)blockIdx.x * 16 : nullptr, 4, t.Trans,
                 t.hyp_rows, T_in_all ? nullptr : best_all + blockIdx.x, thr2, T_out_all + (size_t)blockIdx.x * 16,
                 stats_all + (size_t)blockIdx.x * 16);
 }
 
 }  // namespace
 
-extern "C" int roreg_ransac_score(const double *k0, const double *k1, const double *w, int M, const double *Trans,
+extern "C" int roreg_ransac_score(const double *k0, const double *k1, const double *w, int w_f32, int M, const double *Trans,
                                   const int64_t *hyp_rows, int H, double ird, double *overlap_out, int32_t *best_out,
                                   uint8_t *mask_out, void *stream) {
     ROREG_REQUIRE(k0 && k1 && w && Trans && overlap_out && M > 0 && H >= 0, "roreg_ransac_score: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
-    if (H > 0)
+    if (H > 0 && w_f32 && M <= 4096)
+        hipLaunchKernelGGL((ransac_score_f32_kernel<4, 4096>), dim3((H + 3) / 4), dim3(256), 0, s, k0, k1, w, M, Trans, hyp_rows, H, ird * ird,
+                           overlap_out, mask_out);
+    else if (H > 0 && w_f32)
+        hipLaunchKernelGGL((ransac_score_f32_kernel<2, NP_CHUNK>), dim3((H + 1) / 2), dim3(128), 0, s, k0, k1, w, M, Trans, hyp_rows, H, ird * ird,
+                           overlap_out, mask_out);
+    else if (H > 0)
         hipLaunchKernelGGL(ransac_score_kernel, dim3((H + 3) / 4), dim3(256), 0, s, k0, k1, w, M, Trans, hyp_rows, H, ird * ird,
                            overlap_out, mask_out);
     if (best_out) hipLaunchKernelGGL(first_best_kernel, dim3(1), dim3(256), 0, s, overlap_out, H, best_out);
@@ -340,13 +550,17 @@ extern "C" int roreg_ransac_score(const double *k0, const double *k1, const doub
     return 0;
 }
 
-extern "C" int roreg_refine(const double *k0, const double *k1, const double *w, int M, const double *T_in, int t_in_stride,
+extern "C" int roreg_refine(const double *k0, const double *k1, const double *w, int w_f32, int M, const double *T_in, int t_in_stride,
                             const double *Trans, const int64_t *hyp_rows, const int32_t *best, double dist, double *T_out,
                             double *stats_out, void *stream) {
     ROREG_REQUIRE(k0 && k1 && w && T_out && M > 0, "roreg_refine: bad arguments");
     ROREG_REQUIRE((best && Trans) || T_in, "roreg_refine: need T_in or (Trans, best)");
-    hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(256), 0, roreg::as_stream(stream), k0, k1, w, M, T_in, t_in_stride, Trans,
-                       hyp_rows, best, dist * dist, T_out, stats_out);
+    if (w_f32)
+        hipLaunchKernelGGL(refine_kernel<true>, dim3(1), dim3(256), 0, roreg::as_stream(stream), k0, k1, w, M, T_in, t_in_stride, Trans,
+                           hyp_rows, best, dist * dist, T_out, stats_out);
+    else
+        hipLaunchKernelGGL(refine_kernel<false>, dim3(1), dim3(256), 0, roreg::as_stream(stream), k0, k1, w, M, T_in, t_in_stride, Trans,
+                           hyp_rows, best, dist * dist, T_out, stats_out);
     ROREG_CHECK_LAUNCH("roreg_refine");
     return 0;
 }
@@ -355,7 +569,7 @@ extern "C" size_t roreg_ransac_batch_workspace(int n_tasks, long long total_M, i
     return ((size_t)total_M * 6 + (size_t)n_tasks * (size_t)(max_H > 0 ? max_H : 1)) * sizeof(double);
 }
 
-extern "C" int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long long total_M, int max_M, int max_H, double ird,
+extern "C" int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long long total_M, int max_M, int max_H, double ird, int w_f32,
                                   int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
                                   void *workspace, size_t workspace_bytes, void *stream) {
     if (n_tasks == 0) return 0;
@@ -371,13 +585,25 @@ extern "C" int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_task
     if (max_H > 0)
     {
         roreg::ProfScope prof(roreg::PROF_RANSAC_SCORE, s);
-        hipLaunchKernelGGL(ransac_score_batch_kernel, dim3((max_H + 3) / 4, n_tasks), dim3(256), 0, s, tasks, k0, k1, ird * ird, pitch_h, overlap);
+        if (w_f32 && max_M <= 4096)
+            hipLaunchKernelGGL((ransac_score_batch_f32_kernel<4, 4096>), dim3((max_H + 3) / 4, n_tasks), dim3(256), 0, s, tasks, k0, k1, ird * ird, pitch_h, overlap);
+        else if (w_f32)
+            hipLaunchKernelGGL((ransac_score_batch_f32_kernel<2, NP_CHUNK>), dim3((max_H + 1) / 2, n_tasks), dim3(128), 0, s, tasks, k0, k1, ird * ird, pitch_h, overlap);
+        else
+            hipLaunchKernelGGL(ransac_score_batch_kernel, dim3((max_H + 3) / 4, n_tasks), dim3(256), 0, s, tasks, k0, k1, ird * ird, pitch_h, overlap);
     }
     hipLaunchKernelGGL(first_best_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, pitch_h, overlap, best_out);
-    hipLaunchKernelGGL(refine_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
-                       (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);
-    hipLaunchKernelGGL(refine_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)T1_out, (const int32_t *)nullptr,
-                       ird * ird, T2_out, stats2_out);
+    if (w_f32) {
+        hipLaunchKernelGGL(refine_batch_kernel<true>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
+                           (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);
+        hipLaunchKernelGGL(refine_batch_kernel<true>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)T1_out, (const int32_t *)nullptr,
+                           ird * ird, T2_out, stats2_out);
+    } else {
+        hipLaunchKernelGGL(refine_batch_kernel<false>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
+                           (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);
+        hipLaunchKernelGGL(refine_batch_kernel<false>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)T1_out, (const int32_t *)nullptr,
+                           ird * ird, T2_out, stats2_out);
+    }
     ROREG_CHECK_LAUNCH("roreg_ransac_batch");
     return 0;
 }

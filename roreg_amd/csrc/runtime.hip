@@ -70,7 +70,7 @@ extern "C" int roreg_profile_read(int slot, double *total_ms, int *launches) {
     return 0;
 }
 
-extern "C" int roreg_abi_version(void) { return 1; }
+extern "C" int roreg_abi_version(void) { return ROREG_ABI_VERSION; }
 
 extern "C" const char *roreg_last_error(void) { return roreg::g_err; }
 

@@ -2,20 +2,28 @@
 
 Pairs only connect clouds of the same scene, so the unit of sharding is the scene (each rank extracts only the clouds it
 needs and keeps them HBM-resident): scenes are assigned by longest-processing-time bin packing on their pair counts,
-and a scene larger than the ideal share is split into contiguous pair ranges (its clouds are then extracted on every
-rank that holds a slice -- 38 MB per cloud, cheap next to the pair work).  The only collective is an all_gather of the
-fixed-width float64 result table [pairs, 20] (= backend 'nccl', i.e. RCCL over xGMI, on GPUs; 'gloo' in CPU tests)."""
+and a scene larger than the ideal share is split into contiguous pair ranges.  A cloud of a cut scene that several ranks
+need is extracted ONCE, by its owner (the rank holding the first pair of the scene's list that touches it), and its
+extractor output `eqv` (38.4 MB) travels to the other ranks point to point over xGMI at the start of the step
+(exchange_plan / run_plan; test/extractor.py:47 extracts every cloud once, and so does an N-rank run); the receivers
+rebuild the two cheap per-cloud derivatives (matcher descriptor, Des2R coefficients) locally.  The only collective is an
+all_gather of the fixed-width float64 result table [pairs, 21] (= backend 'nccl', i.e. RCCL over xGMI, on GPUs; 'gloo'
+in CPU tests)."""
 import numpy as np
 import torch
 
 ROW = 21     # scene, id0, id1, n_match, recalltime, trans[0:15] (row-major 4x4 without the final 1), inlier ratio
 
 
-def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=7.0, tolerance=1.02, pair_lists=None):
+def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=7.0, tolerance=1.02, pair_lists=None, exchange=False, recv_cost=0.5):
     """pair_counts: {scene: n_pairs}; cloud_counts: {scene: n_clouds}.  Extracting a cloud costs about `cloud_cost` pair-units (measured:
     ~380 clouds/s against ~2800 pairs/s of the per-pair stages) and is paid again by every rank that holds a slice of the scene --
     but only for the clouds the slice touches: with pair_lists = {scene: [(id0, id1), ...]} the cost of a range is exact, otherwise
     every slice is charged the whole scene.
+    exchange=True (needs pair_lists): a cloud is extracted by ONE rank only -- the one whose range holds the first pair of the scene's
+    list that touches it -- and shipped to the other ranges that touch it (exchange_plan); a range [a, b) then pays `cloud_cost` for the
+    clouds no earlier pair [0, a) of its scene touches and `recv_cost` (rebuilding the per-cloud derivatives; the transfer itself runs
+    beside the rank's whole scenes) for the others.
     -> list (per rank) of [(scene, start, stop)] pair ranges; every pair appears exactly once."""
     cloud_counts = cloud_counts or {s: 0 for s in pair_counts}
     memo = {}
@@ -27,7 +35,23 @@ def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=7.0, tol
             memo[p] = len({int(i) for pr in pair_lists[p[0]][p[1]:p[2]] for i in pr})
         return memo[p]
 
+    seen_before = {}
+
+    def new_clouds_of(p):
+        """clouds of range p that no earlier pair of the scene touches (= the ones range p owns under exchange)"""
+        if p not in seen_before:
+            pl = pair_lists[p[0]]
+            first = {}
+            for q, pr in enumerate(pl[:p[2]]):
+                for i in pr:
+                    first.setdefault(int(i), q)
+            seen_before[p] = sum(1 for i, q in first.items() if q >= p[1])
+        return seen_before[p]
+
     def cost(p):
+        if exchange and pair_lists is not None and p[0] in pair_lists:
+            own = new_clouds_of(p)
+            return (p[2] - p[1]) + cloud_cost * own + recv_cost * (clouds_of(p) - own)
         return (p[2] - p[1]) + cloud_cost * clouds_of(p)
 
     pieces = [(s, 0, n) for s, n in pair_counts.items() if n > 0]
@@ -159,3 +183,125 @@ def gather_table(local, device=None):
     outs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
     return np.concatenate([o[:c].cpu().numpy() for o, c in zip(outs, counts)], 0).reshape(-1, ROW)
+
+
+# ---- cut scenes: every cloud is extracted once, its `eqv` travels point to point ------------------------------------------------------
+def exchange_plan(plan, pair_lists):
+    """plan: shard_scenes() output; pair_lists {scene: [(id0, id1)]}.
+    -> (owner {(scene, cloud): rank} for the clouds of scenes held by more than one rank, transfers [(scene, cloud, src, dst)] in one
+    canonical (sorted) order that every rank derives identically).  The owner of a cloud is the rank whose pair range holds the first
+    pair of the scene's list that touches it -- the rule shard_scenes(exchange=True) prices."""
+    where = {}
+    for r, pieces in enumerate(plan):
+        for s, a, b in pieces:
+            where.setdefault(s, []).append((a, b, r))
+    owner, transfers = {}, []
+    for s in sorted(where):
+        ranges = sorted(where[s])
+        if len({r for _, _, r in ranges}) == 1:
+            continue                                              # the whole scene lives on one rank
+        need = {}
+        for a, b, r in ranges:
+            for pr in pair_lists[s][a:b]:
+                for i in pr:
+                    i = int(i)
+                    owner.setdefault((s, i), r)
+                    need.setdefault(i, set()).add(r)
+        for i in sorted(need):
+            transfers += [(s, i, owner[(s, i)], d) for d in sorted(need[i] - {owner[(s, i)]})]
+    return owner, transfers
+
+
+def extractions_per_rank(plan, pair_lists, exchange=True):
+    """Cloud extractions every rank performs in one pass of `plan` (diagnostics / tests): with the exchange a cloud is extracted by its
+    owner only, without it by every rank whose ranges touch it."""
+    owner, _ = exchange_plan(plan, pair_lists) if exchange else ({}, [])
+    out = []
+    for r, pieces in enumerate(plan):
+        touched = {(s, int(i)) for s, a, b in pieces for pr in pair_lists[s][a:b] for i in pr}
+        out.append(sum(1 for c in touched if owner.get(c, r) == r))
+    return out
+
+
+class EqvExchange:
+    """The point-to-point exchange of extractor outputs at the start of a step: one torch.distributed.batch_isend_irecv (backend nccl = RCCL:
+    one grouped launch, device buffers, xGMI peer-to-peer; the sends read `eqv` on the stream it was produced on, the transfer itself runs on
+    the communicator's stream beside this rank's whole scenes).  Under gloo (CPU tests; the shared-GPU control-flow check) the payload is
+    staged through host memory."""
+
+    def __init__(self, rank, device_payloads=None):
+        import torch.distributed as dist
+        self.rank = rank
+        self.on_device = (dist.get_backend() == 'nccl') if device_payloads is None else device_payloads
+        self.works, self.landed = [], []
+
+    def start(self, transfers, get_eqv, alloc):
+        """transfers: the canonical list (all ranks'); get_eqv(scene, cloud) -> the tensor to send; alloc(scene, cloud) -> the tensor to
+        receive into (device tensors; staged here when the backend cannot move them)."""
+        import torch.distributed as dist
+        ops, keep = [], []
+        for tag, (s, i, src, dst) in enumerate(transfers):
+            if src == self.rank:
+                t = get_eqv(s, i)
+                t = t if self.on_device else t.cpu()
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, dst, tag=tag))
+            elif dst == self.rank:
+                buf = alloc(s, i)
+                stage = buf if self.on_device else torch.empty(buf.shape, dtype=buf.dtype)
+                self.landed.append(((s, i), buf, stage))
+                ops.append(dist.P2POp(dist.irecv, stage, src, tag=tag))
+        self.keep = keep
+        self.works = dist.batch_isend_irecv(ops) if ops else []
+
+    def wait(self):
+        """Orders the current stream behind the transfers (nccl) / blocks until they have arrived (gloo) -> {(scene, cloud): eqv tensor}."""
+        for w in self.works:
+            w.wait()
+        out = {}
+        for key, buf, stage in self.landed:
+            if stage is not buf:
+                buf.copy_(stage)
+            out[key] = buf
+        self.works, self.landed, self.keep = [], [], []
+        return out
+
+
+def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, **run_kw):
+    """One pass of this rank's share of a shard plan.  pieces [(scene, a, b)]; scene_inputs(scene) -> (feats, keys, pair_ids, pair_seeds or
+    None) with feats / keys indexable by int cloud id; transfers: exchange_plan()'s list (empty: every rank extracts what it touches).
+    Order: (0) the clouds this rank owns and others need are extracted and sent, the receives are posted; (1) the scenes this rank
+    holds without imports; (2) the pair ranges that wait for imported clouds.  -> [(scene, a, b, [PairResult])] in `pieces` order."""
+    sends = [t for t in transfers if t[2] == rank]
+    recvs = [t for t in transfers if t[3] == rank]
+    cache = {}                                                     # scene -> {cloud: CloudState}: exported, imported, reused across ranges
+    shared = {s for s, _, _, _ in transfers}
+    ex = None
+    if sends or recvs:
+        by_scene = {}
+        for s, i, _, _ in sends:
+            by_scene.setdefault(s, set()).add(i)
+        for s in sorted(by_scene):
+            feats, keys = scene_inputs(s)[:2]
+            ids = sorted(by_scene[s])
+            cache.setdefault(s, {}).update(zip(ids, engine.extract_many([feats[i] for i in ids], [keys[i] for i in ids])))
+        ex = exchange if exchange is not None else EqvExchange(rank)
+        ex.start(transfers, lambda s, i: cache[s][i].eqv,
+                 lambda s, i: engine.alloc_eqv(scene_inputs(s)[0][i]))
+    importing = {s for s, _, _, _ in recvs}
+    order = sorted(range(len(pieces)), key=lambda q: (pieces[q][0] in importing, q))
+    out = [None] * len(pieces)
+    waited = not recvs
+    for q in order:
+        s, a, b = pieces[q]
+        feats, keys, pairs, seeds = scene_inputs(s)
+        if s in importing and not waited:
+            for (sc, i), eqv in ex.wait().items():
+                f, k = scene_inputs(sc)[:2]
+                cache.setdefault(sc, {})[i] = engine.cloud_from_eqv(f[i], eqv, k[i])
+            waited = True
+        ready = cache.setdefault(s, {}) if s in shared else None
+        out[q] = (s, a, b, engine.run_scene(feats, keys, pairs[a:b], pair_seeds=None if seeds is None else seeds[a:b], ready=ready, **run_kw))
+    if ex is not None and not waited:                              # a rank that only sends: its sends complete before the step ends
+        ex.wait()
+    return out

@@ -216,6 +216,23 @@ class RegistrationEngine:
             i = j
         return out
 
+    def alloc_eqv(self, before):
+        """Receive buffer for the extractor output of the cloud whose input features are `before` ([N,32,60])."""
+        return torch.empty((int(before.shape[0]), 32, 60), dtype=self.feat_dtype, device='cuda')
+
+    def cloud_from_eqv(self, before, eqv, keys):
+        """CloudState of a cloud whose extractor output `eqv` was computed elsewhere (multi-GPU: the owner rank of a cut scene's cloud
+        ships it over xGMI, distributed.run_plan): only the two cheap per-cloud derivatives are rebuilt here.  Bitwise the state
+        extract_many() would have produced (the extractor's block scales are per keypoint, so `eqv` does not depend on who computed it)."""
+        x = before if torch.is_tensor(before) else torch.from_numpy(np.ascontiguousarray(before, np.float32))
+        if not (x.is_cuda and x.dtype == self.feat_dtype):
+            x = x.to('cuda', torch.float32).to(self.feat_dtype)
+        k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
+        if not (k.is_cuda and k.dtype == torch.float64 and k.is_contiguous()):
+            k = k.to('cuda', torch.float64).contiguous()
+        eqv = eqv.to('cuda', self.feat_dtype).contiguous()
+        return CloudState(before=x.contiguous(), eqv=eqv, eqv_ft=hip.feat_coefs(eqv), inv=hip.inv_descriptor(eqv), keys=k)
+
     def detect(self, cloud):
         """raw std scores -> rank/N on the host exactly as test/detector.py:45-46."""
         self.detect_many([cloud])
@@ -384,13 +401,13 @@ class RegistrationEngine:
         Trans = hip.quat_to_trans(q, dr, c0.keys, c1.keys, rows0=rows0, rows1=rows1)
         return dr, Trans, rows0, rows1
 
-    def ransac(self, c0, c1, rows0, rows1, Trans, scores, hyp_rows):
+    def ransac(self, c0, c1, rows0, rows1, Trans, scores, hyp_rows, w_f32=False):
         """One-shot RANSAC + two refinements; everything stays on the device.  -> (T [4,4], best int32[1])."""
         k0 = hip.gather_rows_f64(c0.keys, rows0); k1 = hip.gather_rows_f64(c1.keys, rows1)
         ird = float(self.cfg.ransac_ird)
-        _, best, _ = hip.ransac_score(k0, k1, scores, Trans, ird, hyp_rows=hyp_rows)
-        T1, st1 = hip.refine(k0, k1, scores, ird * 2.0, Trans=Trans, hyp_rows=hyp_rows, best=best, want_stats=True)
-        T2, st2 = hip.refine(k0, k1, scores, ird, T_in=T1, want_stats=True)
+        _, best, _ = hip.ransac_score(k0, k1, scores, Trans, ird, hyp_rows=hyp_rows, w_f32=w_f32)
+        T1, st1 = hip.refine(k0, k1, scores, ird * 2.0, Trans=Trans, hyp_rows=hyp_rows, best=best, want_stats=True, w_f32=w_f32)
+        T2, st2 = hip.refine(k0, k1, scores, ird, T_in=T1, want_stats=True, w_f32=w_f32)
         return T2, best, (k0, k1, st1, st2)
 
     def _yohoo_tasks(self, full, all_scores, max_iter, all_local_transforms, pair_seeds=None, writer=None, pair_ids=None):
@@ -458,16 +475,17 @@ class RegistrationEngine:
         jobs, skipped, o = [], {}, 0
         for i, ((c0, c1, _), sc, (off, n)) in enumerate(zip(full, all_scores, batch.offsets)):     # sequential: the global generator
             pps = m_host[o:o + sizes[i]]; o += sizes[i]
-            if pair_seeds is not None:
-                np.random.seed((int(pair_seeds[i]) + 1) % (2 ** 32))
+            # a pair's draws come from a stream of its own, RandomState(seed + 1) -- the same MT19937 stream np.random.seed(seed + 1) would
+            # start -- so the process-global generator is neither consumed nor left in a state that depends on the shard plan
+            rng = None if pair_seeds is None else np.random.RandomState((int(pair_seeds[i]) + 1) % (2 ** 32))
             if c0.keys_host is None:
                 c0.keys_host = c0.keys.cpu().numpy()
             if c1.keys_host is None:
                 c1.keys_host = c1.keys.cpu().numpy()
             sel = _select_top(sc, self.cfg.match_n) if self.cfg.RM else np.arange(n)
-            idxs = yohoc_draws(dr_all[off:off + n][sel], max_iter)
+            idxs = yohoc_draws(dr_all[off:off + n][sel], max_iter, rng=rng)
             if idxs is None:                                               # no rotation bin with two correspondences (:214-216)
-                skipped[i] = (np.random.rand(4, 4), 50000)
+                skipped[i] = ((np.random if rng is None else rng).rand(4, 4), 50000)
                 jobs.append(None)
             else:
                 jobs.append((c0.keys_host, c1.keys_host, pps[sel, 0][idxs], pps[sel, 1][idxs]))
@@ -484,14 +502,17 @@ class RegistrationEngine:
 
     # ---- whole scene -----------------------------------------------------------------------------------------
     def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None,
-                  writer=None):
+                  writer=None, ready=None):
         """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
-        pair_seeds: optional one integer per pair -- the global numpy generator is re-seeded with it before the pair's keypoint sampling
-        and with seed + 1 before its hypothesis draws, so a pair's result is a function of the pair alone (whatever other pairs this
-        call processes: the multi-GPU driver's rank-count independence).  None = the reference's single global stream.
+        pair_seeds: optional one integer per pair -- the pair's keypoint sampling draws from a generator stream of its own,
+        RandomState(seed) (the stream np.random.seed(seed) would start), and its hypothesis draws from RandomState(seed + 1), so a pair's
+        result is a function of the pair alone (whatever other pairs this call processes: the multi-GPU driver's rank-count
+        independence) and the process-global generator is left untouched.  None = the reference's single global stream.
         writer: optional StageFileWriter -- the inter-stage files of every pair (matches, scores, DR_index, Trans_pre) are written
         asynchronously, byte for byte what the file-coupled stage classes write; this turns all_local_transforms on (the files hold
         every correspondence's local transform, like the reference's).
+        ready: optional {int cloud id: CloudState} of clouds that need no extraction (received from their owner rank, or extracted for
+        an earlier pair range of the same scene); the clouds this call extracts are added to it.
         Returns [PairResult]."""
         if writer is not None:
             all_local_transforms = True
@@ -502,7 +523,12 @@ class RegistrationEngine:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         used = sorted({int(i) for p in pair_ids for i in p})
-        clouds = dict(zip(used, self.extract_many([feats[i] for i in used], [keys[i] for i in used])))
+        have = {} if ready is None else ready
+        todo = [i for i in used if i not in have]
+        fresh = dict(zip(todo, self.extract_many([feats[i] for i in todo], [keys[i] for i in todo])))
+        clouds = {i: (have[i] if i in have else fresh[i]) for i in used}
+        if ready is not None:
+            ready.update(fresh)
         t0 = self._mark('extract', t0)
         if self.cfg.RD:
             self.detect_many([clouds[i] for i in used])
@@ -554,7 +580,8 @@ class RegistrationEngine:
             (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms, pair_seeds, writer, pair_ids), {}
         t0 = self._mark('local_transforms', t0)
         ird = float(self.cfg.ransac_ird)
-        best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird)
+        f32_scores = any(sc is not None and sc.dtype == np.float32 for sc in all_scores)      # the rotation-coherence matcher's (matcher.py:210)
+        best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird, w_f32=f32_scores)
         t0 = self._mark('ransac_issue', t0)
         T_host = T2_d.cpu().numpy()                                         # the one sync of the estimator stage
         best_host = best_d.cpu().numpy()
@@ -571,7 +598,7 @@ class RegistrationEngine:
             k0 = hip.gather_rows_f64(c0.keys, matches[:, 0].contiguous()); k1 = hip.gather_rows_f64(c1.keys, matches[:, 1].contiguous())
             w = w_all[i] if w_all[i] is not None else torch.ones(matches.shape[0], dtype=torch.float64, device='cuda')
             T1 = _kabsch_host(st_host[i, 0])
-            pending.append(hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)[1])
+            pending.append(hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True, w_f32=f32_scores and w_all[i] is not None)[1])
         if pending:
             st_redo = torch.stack(pending).cpu().numpy()
             for i, st in zip(redo, st_redo):

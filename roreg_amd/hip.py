@@ -27,6 +27,7 @@ if GEMM_MODE == 'split':
     GEMM_MODE = 'bf16x3'
 if GEMM_MODE not in GEMM_MODES:
     raise ValueError(f"ROREG_GEMM must be one of {GEMM_MODES}, got {GEMM_MODE!r}")
+ABI_VERSION = 3          # == ROREG_ABI_VERSION of include/roreg_hip.h; lib() refuses a library that reports another one
 _lib = None
 _tables_uploaded = False
 
@@ -63,12 +64,12 @@ PROTOTYPES = {
     'roreg_feat_coefs': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     'roreg_et_gather': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     'roreg_quat_to_trans': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
-    'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
-    'roreg_refine': (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
+    'roreg_ransac_score': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_double, _P, _P, _P, _P]),
+    'roreg_refine': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, c_double, _P, _P, _P]),
     'roreg_lt_prepare_batch': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'roreg_lt_finish_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
-    'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_yohoc_draw': (c_int, [_P, ctypes.c_longlong, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
@@ -115,6 +116,10 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = L.roreg_abi_version()
+        if got != ABI_VERSION:                 # a stale or foreign build: its entry points take other argument lists
+            raise HipError(f'{_LIB_PATH} reports C-ABI version {got}, this binding was written against {ABI_VERSION} '
+                           f'(include/roreg_hip.h ROREG_ABI_VERSION): rebuild with `make -C roreg_amd/csrc`')
         _lib = L
     return _lib
 
@@ -515,21 +520,23 @@ class LtBatch:
         return T
 
 
-def yohoc_draw(prob, bin_size, max_iter, max_tries=50000):
-    """The reference's YOHO-C sampling loop (test/estimator.py:220-230) replayed on the GLOBAL numpy generator: same calls, same
+def yohoc_draw(prob, bin_size, max_iter, max_tries=50000, rng=None):
+    """The reference's YOHO-C sampling loop (test/estimator.py:220-230) replayed on a legacy numpy generator -- rng=None: the process-GLOBAL
+    one, as the reference uses it; or a `np.random.RandomState` of the caller's (the engine's per-pair streams): same calls, same
     order, same final generator state as `np.random.choice(range(60), p=prob)` + `np.random.choice(members, 3)` per try, without the
     per-call Python overhead.  prob f64 [60], bin_size [60] -> (bins int32 [H], picks int64 [H,3] positions inside the bin)."""
+    rng = np.random if rng is None else rng
     prob = np.ascontiguousarray(prob, np.float64)
     cdf = prob.cumsum()
     cdf /= cdf[-1]                                                  # numpy's RandomState.choice does exactly this
     sizes = np.ascontiguousarray(bin_size, np.int32)
     bins = np.empty(max(max_iter, 1), np.int32); picks = np.empty((max(max_iter, 1), 3), np.int64)
     n_hyp = ctypes.c_int32(0); used = ctypes.c_longlong(0)
-    state = np.random.get_state()
+    state = rng.get_state()
     n_words = 16 * max_iter + 64
     while True:
-        np.random.set_state(state)
-        words = np.random.randint(0, 2 ** 32, size=n_words, dtype=np.uint32)       # raw generator words (full-range uint32 draws)
+        rng.set_state(state)
+        words = rng.randint(0, 2 ** 32, size=n_words, dtype=np.uint32)       # raw generator words (full-range uint32 draws)
         rc = lib().roreg_yohoc_draw(words.ctypes.data, n_words, cdf.ctypes.data, sizes.ctypes.data, int(max_iter), int(max_tries),
                                     bins.ctypes.data, picks.ctypes.data, ctypes.byref(n_hyp), ctypes.byref(used))
         if rc == 3:
@@ -537,9 +544,9 @@ def yohoc_draw(prob, bin_size, max_iter, max_tries=50000):
             continue
         _check(rc, 'roreg_yohoc_draw')
         break
-    np.random.set_state(state)
+    rng.set_state(state)
     if used.value:
-        np.random.randint(0, 2 ** 32, size=used.value, dtype=np.uint32)            # advance the generator by what the loop consumed
+        rng.randint(0, 2 ** 32, size=used.value, dtype=np.uint32)            # advance the generator by what the loop consumed
     return bins[:n_hyp.value].copy(), picks[:n_hyp.value].copy()
 
 
@@ -547,10 +554,11 @@ _RANSAC_TASK = np.dtype([('keys0', np.uint64), ('keys1', np.uint64), ('matches',
                          ('hyp_rows', np.uint64), ('M', np.int32), ('H', np.int32), ('koff', np.int64)])
 
 
-def ransac_batch(tasks, ird):
+def ransac_batch(tasks, ird, w_f32=False):
     """tasks: [(keys0 [*,3] f64, keys1 [*,3] f64, matches [M,2] int64, w [M] f64 or None, Trans [*,3,4] f64, hyp_rows int64 [H] or None)]
     (device tensors).  One-shot RANSAC + the two refinements of every task in five launches ->
-    (best int32 [n], T1 [n,4,4], stats1 [n,16], T2 [n,4,4], stats2 [n,16]) device tensors."""
+    (best int32 [n], T1 [n,4,4], stats1 [n,16], T2 [n,4,4], stats2 [n,16]) device tensors.
+    w_f32: the tasks' weights are float32 scores (widened to f64 for the upload): numpy's float32 reductions, see ransac_score."""
     n = len(tasks)
     dev = tasks[0][0].device if n else torch.device('cuda')
     best = torch.empty(n, dtype=torch.int32, device=dev)
@@ -574,7 +582,7 @@ def ransac_batch(tasks, ird):
     tdev = upload(table.view(np.uint8).reshape(n, _RANSAC_TASK.itemsize))
     ws_n = lib().roreg_ransac_batch_workspace(n, koff, max_H)
     ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.float64, device=dev)
-    _check(lib().roreg_ransac_batch(_ptr(tdev), n, koff, max(max_M, 1), max_H, float(ird), _ptr(best), _ptr(T1), _ptr(st1), _ptr(T2), _ptr(st2),
+    _check(lib().roreg_ransac_batch(_ptr(tdev), n, koff, max(max_M, 1), max_H, float(ird), int(bool(w_f32)), _ptr(best), _ptr(T1), _ptr(st1), _ptr(T2), _ptr(st2),
                                     _ptr(ws), ws_n, _stream()), 'roreg_ransac_batch')
     return best, T1, st1, T2, st2
 
@@ -722,23 +730,26 @@ def quat_to_trans(q, anchor, keys0, keys1, rows0=None, rows1=None, want_quat=Fal
     return (T, qn) if want_quat else T
 
 
-def ransac_score(k0, k1, w, Trans, ird, hyp_rows=None, want_mask=False):
+def ransac_score(k0, k1, w, Trans, ird, hyp_rows=None, want_mask=False, w_f32=False):
+    """w_f32: `w` holds the rotation-coherence matcher's float32 scores (widened): overlaps are numpy's float32 pairwise sums / float32 M,
+    as test/estimator.py:381 computes them on a float32 score array."""
     M = k0.shape[0]
     H = int(hyp_rows.shape[0]) if hyp_rows is not None else int(Trans.shape[0])
     ov = torch.empty(max(H, 1), dtype=torch.float64, device=k0.device)
     best = torch.empty(1, dtype=torch.int32, device=k0.device)
     mask = torch.empty((H, M), dtype=torch.uint8, device=k0.device) if want_mask else None
-    _check(lib().roreg_ransac_score(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), M, _ptr(Trans, torch.float64),
+    _check(lib().roreg_ransac_score(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), int(bool(w_f32)), M, _ptr(Trans, torch.float64),
                                     _ptr(hyp_rows, torch.int64), H, float(ird), _ptr(ov), _ptr(best), _ptr(mask), _stream()), 'roreg_ransac_score')
     return ov[:H], best, mask
 
 
-def refine(k0, k1, w, dist, T_in=None, Trans=None, hyp_rows=None, best=None, want_stats=False):
-    """-> T [4,4] f64 (device)  [, stats f64[16] = H(9), c0(3), c1(3), sum w]."""
+def refine(k0, k1, w, dist, T_in=None, Trans=None, hyp_rows=None, best=None, want_stats=False, w_f32=False):
+    """-> T [4,4] f64 (device)  [, stats f64[16] = H(9), c0(3), c1(3), sum w].  w_f32: float32 scores (see ransac_score): the weights are
+    normalised in float32 like the reference's scores / np.sum(scores) on a float32 array."""
     M = k0.shape[0]
     out = torch.empty((4, 4), dtype=torch.float64, device=k0.device)
     stats = torch.empty(16, dtype=torch.float64, device=k0.device) if want_stats else None
-    _check(lib().roreg_refine(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), M, _ptr(T_in, torch.float64), 4,
+    _check(lib().roreg_refine(_ptr(k0, torch.float64), _ptr(k1, torch.float64), _ptr(w, torch.float64), int(bool(w_f32)), M, _ptr(T_in, torch.float64), 4,
                               _ptr(Trans, torch.float64), _ptr(hyp_rows, torch.int64), _ptr(best, torch.int32), float(dist), _ptr(out),
                               _ptr(stats), _stream()), 'roreg_refine')
     return (out, stats) if want_stats else out

@@ -20,6 +20,7 @@ from . import distributed as D
 from .utils import RR_cal
 from .utils.r_eval import compute_R_diff
 from .utils.utils import make_non_exists_dir, transform_points, load_checkpoint
+from .test.estimator import pre_log_entry
 
 
 def build_engine(cfg):
@@ -45,29 +46,64 @@ def _feature_dir(cfg, dataset):
     return f'{cfg.output_cache_fn}/{name}/{cfg.backbone}_Input_Group_feature'
 
 
-def evaluate(cfg, datasets, engine, rank=0, world=1, seed=None):
+def inlier_ratio(cfg, result, keys0, keys1, gt):
+    """Inlier ratio of a pair's (top-scored) correspondences under the ground truth, test/evaluator.py:50-81 (host numpy, float64)."""
+    corr = result.matches.cpu().numpy() if torch.is_tensor(result.matches) else np.asarray(result.matches)
+    if corr.shape[0] == 0:
+        return 0.0
+    if cfg.RM and result.scores is not None:
+        num = max(result.scores.shape[0] * cfg.match_n, 10) if cfg.match_n < 0.999 else cfg.match_n
+        corr = corr[np.argsort(result.scores)[-int(num):]]
+    k0 = keys0[corr[:, 0]]; k1 = transform_points(keys1[corr[:, 1]], gt)
+    return float(np.mean(np.sqrt(np.sum(np.square(k0 - k1), axis=-1)) < cfg.tau_2))
+
+
+def scene_metrics(cfg, rows, gt_of):
+    """rows: [{'id0','id1','trans','ir'}] of ONE scene in pair-list order; gt_of(id0, id1) -> [3,4] or [4,4] ground truth.
+    -> (FMR, IR, RR(pointdsc), mean RRE, mean RTE of the successes) exactly as test/evaluator.py:50-101,111-129."""
+    ir_s, ok_s, re_s, te_s = [], [], [], []
+    for row in rows:
+        T = row['trans']; gt = gt_of(row['id0'], row['id1'])
+        ir_s.append(row['ir'])
+        if np.isfinite(T).all():
+            rd = compute_R_diff(T[0:3, 0:3], gt[0:3, 0:3]); td = np.sqrt(np.sum(np.square(T[0:3, -1] - gt[0:3, -1])))
+            good = bool(rd < 15 and td < 0.3)
+        else:
+            good = False
+        ok_s.append(1 if good else 0)
+        if good:
+            re_s.append(rd); te_s.append(td)
+    return (float(np.mean([1 if i > cfg.tau_1 else 0 for i in ir_s])), float(np.mean(ir_s)), float(np.mean(ok_s)),
+            float(np.mean(re_s)) if re_s else float('nan'), float(np.mean(te_s)) if te_s else float('nan'))
+
+
+def evaluate(cfg, datasets, engine, rank=0, world=1, seed=None, exchange=True):
     scenes = [s for s in datasets if s not in ('wholesetname', 'valscenes')]
     pair_counts = {s: len(datasets[s].pair_ids) for s in scenes}
     cloud_counts = {s: len(datasets[s].pc_ids) for s in scenes}
-    plan = D.shard_scenes(pair_counts, world, cloud_counts, pair_lists={s: datasets[s].pair_ids for s in scenes})
+    pair_lists = {s: datasets[s].pair_ids for s in scenes}
+    exchange = bool(exchange and world > 1 and hasattr(engine, 'cloud_from_eqv'))
+    plan = D.shard_scenes(pair_counts, world, cloud_counts, pair_lists=pair_lists, exchange=exchange)
+    transfers = D.exchange_plan(plan, pair_lists)[1] if exchange else []
+    inputs = {}
+
+    def scene_inputs(scene):
+        """(feats, keys, pair_ids, seeds) of a scene; the input features of the clouds this rank touches are read once"""
+        if scene not in inputs:
+            ds = datasets[scene]
+            used = sorted({int(i) for sc, a, b in plan[rank] if sc == scene for p in ds.pair_ids[a:b] for i in p} |
+                          {i for sc, i, src, dst in transfers if sc == scene and rank in (src, dst)})
+            fdir = _feature_dir(cfg, ds)
+            seeds = None if seed is None else [(int(seed) + zlib.crc32(f'{scene}:{p0}:{p1}'.encode())) % (2 ** 32) for p0, p1 in ds.pair_ids]
+            inputs[scene] = ({i: np.load(f'{fdir}/{i}.npy') for i in used}, {i: ds.get_kps(str(i)) for i in used}, ds.pair_ids, seeds)
+        return inputs[scene]
+
     rows = []
-    for scene, a, b in plan[rank]:
+    for scene, a, b, res in D.run_plan(engine, plan[rank], scene_inputs, transfers, rank, keynum=cfg.keynum, max_iter=cfg.max_iter, keep_matches=True):
         ds = datasets[scene]
-        pairs = ds.pair_ids[a:b]
-        pair_seeds = None if seed is None else [(int(seed) + zlib.crc32(f'{scene}:{p0}:{p1}'.encode())) % (2 ** 32) for p0, p1 in pairs]
-        used = sorted({int(i) for p in pairs for i in p})
-        fdir = _feature_dir(cfg, ds)
-        feats = {i: np.load(f'{fdir}/{i}.npy') for i in used}
-        keys = {i: ds.get_kps(str(i)) for i in used}
-        res = engine.run_scene(feats, keys, pairs, keynum=cfg.keynum, max_iter=cfg.max_iter, keep_matches=True, pair_seeds=pair_seeds)
+        keys = scene_inputs(scene)[1]
         for r in res:                                    # inlier ratio of the (top-scored) correspondences, evaluator.py:50-81
-            corr = r.matches.cpu().numpy()
-            if cfg.RM:
-                num = max(r.scores.shape[0] * cfg.match_n, 10) if cfg.match_n < 0.999 else cfg.match_n
-                corr = corr[np.argsort(r.scores)[-int(num):]]
-            gt = ds.get_transform(r.id0, r.id1)
-            k0 = keys[int(r.id0)][corr[:, 0]]; k1 = transform_points(keys[int(r.id1)][corr[:, 1]], gt)
-            r.ir = float(np.mean(np.sqrt(np.sum(np.square(k0 - k1), axis=-1)) < cfg.tau_2))
+            r.ir = inlier_ratio(cfg, r, keys[int(r.id0)], keys[int(r.id1)], ds.get_transform(r.id0, r.id1))
         rows.append(D.pack_rows(scenes.index(scene), res))
     table = D.gather_table(np.concatenate(rows, 0) if rows else np.zeros((0, D.ROW)))
     if rank != 0:
@@ -80,25 +116,13 @@ def evaluate(cfg, datasets, engine, rank=0, world=1, seed=None):
         ds = datasets[s]
         save_dir = f'{cfg.output_cache_fn}/{ds.name}/match_{cfg.keynum}/{cfg.ET}/{cfg.max_iter}iters'
         make_non_exists_dir(save_dir)
-        ir_s, ok_s, re_s, te_s = [], [], [], []
         with open(f'{save_dir}/pre.log', 'w') as w:
             for (a, b) in ds.pair_ids:
                 row = by_scene[s][(a, b)]
-                T = row['trans']
-                np.savez(f'{save_dir}/{a}-{b}.npz', trans=T, recalltime=row['recalltime'])
-                w.write(f'{int(a)}\t{int(b)}\t{len(ds.pc_ids)}\n')
-                for r in range(3):
-                    w.write(f'{T[r][0]}\t{T[r][1]}\t{T[r][2]}\t{T[r][3]}\n')
-                w.write(f'{0.0}\t{0.0}\t{0.0}\t{1.0}\n')
-                gt = ds.get_transform(a, b)
-                ir_s.append(row['ir'])
-                rd = compute_R_diff(T[0:3, 0:3], gt[0:3, 0:3]); td = np.sqrt(np.sum(np.square(T[0:3, -1] - gt[0:3, -1])))
-                good = bool(rd < 15 and td < 0.3)
-                ok_s.append(1 if good else 0)
-                if good:
-                    re_s.append(rd); te_s.append(td)
-        fmrs.append(np.mean([1 if i > cfg.tau_1 else 0 for i in ir_s])); irs.append(np.mean(ir_s))
-        rrs.append(np.mean(ok_s)); rres.append(np.mean(re_s) if re_s else np.nan); rtes.append(np.mean(te_s) if te_s else np.nan)
+                np.savez(f'{save_dir}/{a}-{b}.npz', trans=row['trans'], recalltime=row['recalltime'])
+                w.write(pre_log_entry(a, b, len(ds.pc_ids), row['trans']))
+        f, i, r, re, te = scene_metrics(cfg, [by_scene[s][p] for p in ds.pair_ids], ds.get_transform)
+        fmrs.append(f); irs.append(i); rrs.append(r); rres.append(re); rtes.append(te)
     out = {'fmr': float(np.mean(fmrs)), 'ir': float(np.mean(irs)), 'rr': float(np.mean(rrs)), 'rre': float(np.mean(rres)),
            'rte': float(np.mean(rtes)), 'pairs': int(table.shape[0])}
     if datasets['wholesetname'] == 'demo' or not all(os.path.exists(datasets[s].gt_dir[:datasets[s].gt_dir.rfind('.')] + '.info') for s in scenes):

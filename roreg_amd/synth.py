@@ -220,6 +220,25 @@ def make_ransac_case(seed, M=5000, H=1000, outlier=0.6, f32_scores=False, anchor
     return k0, k1, scores, Trans, hyp
 
 
+def make_ransac_tie_case(seed, M=3000, H=600, anchor=17):
+    """One-shot RANSAC inputs whose best hypotheses tie at float32 precision (the rotation-coherence matcher's score type): every score
+    is float32(0.75 + j 2^-16), j in 0..7, and every hypothesis is the true rotation with a millimetre-level translation jitter, so the
+    hypotheses' inlier sets differ by a handful of borderline correspondences and their score sums (~1500) by a few 2^-16 -- below the
+    float32 spacing there (1.2e-4).  Which hypothesis the reference's strict `>` scan keeps is then decided by the rounding of numpy's
+    PAIRWISE float32 sum and of its float32 division by M (test/estimator.py:381,433); a float64 accumulation picks another one.
+    Portable arithmetic only.  -> (k0 [M,3], k1 [M,3], scores float32 [M], Trans [H,3,4], hyp int64 [H] = arange)."""
+    rng = np.random.default_rng(int(seed))
+    T = tables()
+    R = T.R[anchor]; tgt = np.array([0.2, -0.4, 0.1])
+    k1 = rng.uniform(0, 3, (M, 3))
+    k0 = _rows_times_matrix(k1, R.T) + tgt + 0.045 * rng.standard_normal((M, 3))
+    scores = (0.75 + rng.integers(0, 8, M) * 2.0 ** -16).astype(np.float32)
+    Trans = np.zeros((H, 3, 4))
+    Trans[:, :, :3] = R
+    Trans[:, :, 3] = tgt + 1.5e-3 * rng.standard_normal((H, 3))
+    return k0, k1, scores, Trans, np.arange(H, dtype=np.int64)
+
+
 # ------------------------------------------------------------------------------------------------
 # benchmark-sized scenes generated on the device (bench.py: 433 clouds = 16.6 GB of group features would take minutes on the host)
 # ------------------------------------------------------------------------------------------------

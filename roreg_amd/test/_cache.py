@@ -14,21 +14,25 @@ _store = OrderedDict()
 _bytes = 0
 
 
-def load_device(path, dtype=torch.float32):
+def _insert(key, t):
+    """Add an entry and evict the least recently used ones down to the byte budget (the entry itself always stays)."""
     global _bytes
-    st = os.stat(path)
-    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, dtype)
-    t = _store.get(key)
-    if t is not None:
-        _store.move_to_end(key)
-        return t
-    t = torch.from_numpy(np.load(path)).to('cuda', dtype).contiguous()
     _store[key] = t
     _bytes += t.numel() * t.element_size()
     while _bytes > _MAX_BYTES and len(_store) > 1:
         _, old = _store.popitem(last=False)
         _bytes -= old.numel() * old.element_size()
     return t
+
+
+def load_device(path, dtype=torch.float32):
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, dtype)
+    t = _store.get(key)
+    if t is not None:
+        _store.move_to_end(key)
+        return t
+    return _insert(key, torch.from_numpy(np.load(path)).to('cuda', dtype).contiguous())
 
 
 def feat_dtype(cfg):
@@ -41,19 +45,17 @@ def feat_dtype(cfg):
 
 def load_coefs(path, dtype=torch.float32):
     """Group-Fourier coefficients (hip.feat_coefs) of the feature file `path`, cached like the file itself: the operand of the
-    irrep-domain Des2R, computed once per cloud instead of once per pair."""
-    global _bytes
+    irrep-domain Des2R, computed once per cloud instead of once per pair.  The transform's arithmetic depends on the matrix-core mode
+    (hip.GEMM_MODE), which is therefore part of the key."""
     from .. import hip
     st = os.stat(path)
-    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, 'coefs', dtype)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, 'coefs', hip.GEMM_MODE, dtype)
     t = _store.get(key)
     if t is not None:
         _store.move_to_end(key)
         return t
-    t = hip.feat_coefs(load_device(path, dtype))
-    _store[key] = t
-    _bytes += t.numel() * t.element_size()
-    return t
+    src = load_device(path, dtype)                  # (may itself evict; `src` keeps the tensor alive for the transform)
+    return _insert(key, hip.feat_coefs(src))
 
 
 def clear():

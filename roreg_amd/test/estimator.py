@@ -23,23 +23,30 @@ from . import _cache
 from .extractor import scene_feature_name
 
 
+def pre_log_entry(id0, id1, n_clouds, trans):
+    """One record of pre.log (the format utils/RR_cal.py:66-97 reads back): a header line `id0 <tab> id1 <tab> #clouds of the
+    scene`, then the four rows of the 4x4 estimate, tab-separated, every number in Python's shortest round-trip repr of the float64; the last
+    row is the constant `0.0 0.0 0.0 1.0`."""
+    rows = [[repr(float(v)) for v in trans[r][:4]] for r in range(3)] + [['0.0', '0.0', '0.0', '1.0']]
+    return '\t'.join([str(int(id0)), str(int(id1)), str(int(n_clouds))]) + '\n' + ''.join('\t'.join(r) + '\n' for r in rows)
+
+
 def R_pre_log(dataset, save_dir):
-    writer = open(f'{save_dir}/pre.log', 'w')
-    pair_num = int(len(dataset.pc_ids))
-    for pair in dataset.pair_ids:
-        pc0, pc1 = pair
-        ransac_result = np.load(f'{save_dir}/{pc0}-{pc1}.npz', allow_pickle=True)
-        transform_pr = ransac_result['trans']
-        writer.write(f'{int(pc0)}\t{int(pc1)}\t{pair_num}\n')
-        writer.write(f'{transform_pr[0][0]}\t{transform_pr[0][1]}\t{transform_pr[0][2]}\t{transform_pr[0][3]}\n')
-        writer.write(f'{transform_pr[1][0]}\t{transform_pr[1][1]}\t{transform_pr[1][2]}\t{transform_pr[1][3]}\n')
-        writer.write(f'{transform_pr[2][0]}\t{transform_pr[2][1]}\t{transform_pr[2][2]}\t{transform_pr[2][3]}\n')
-        writer.write(f'{0.0}\t{0.0}\t{0.0}\t{1.0}\n')
-    writer.close()
+    """pre.log of a scene from the per-pair result files {save_dir}/{id0}-{id1}.npz, in pair-list order (test/estimator.py:14-26)."""
+    with open(f'{save_dir}/pre.log', 'w') as out:
+        for id0, id1 in dataset.pair_ids:
+            estimate = np.load(f'{save_dir}/{id0}-{id1}.npz', allow_pickle=True)['trans']
+            out.write(pre_log_entry(id0, id1, len(dataset.pc_ids), estimate))
 
 
 def _dev64(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()
+
+
+def _is_f32(scores):
+    """True for the rotation-coherence matcher's float32 score arrays (test/matcher.py:210): the reference then sums and normalises them
+    in float32 (numpy's pairwise reduction), and the kernels follow (hip.ransac_score / hip.refine `w_f32`)."""
+    return getattr(scores, 'dtype', None) == np.float32
 
 
 def _select_top(scores, match_n):
@@ -56,13 +63,13 @@ def _kabsch_host(stats):
         return T
 
 
-def refine_twice(k0, k1, w, ird, T_in=None, Trans=None, hyp_rows=None, best=None):
+def refine_twice(k0, k1, w, ird, T_in=None, Trans=None, hyp_rows=None, best=None, w_f32=False):
     """The two refinements of estimator.py:438-439.  The M-sized reductions (inlier test, weighted centroids,
     3x3 cross-covariance) run on the device; the closing 3x3 SVD is the reference's own LAPACK call on the host,
     so that rank-deficient cases (<= 2 inliers) give the reference's value too."""
-    _, st = hip.refine(k0, k1, w, ird * 2.0, T_in=T_in, Trans=Trans, hyp_rows=hyp_rows, best=best, want_stats=True)
+    _, st = hip.refine(k0, k1, w, ird * 2.0, T_in=T_in, Trans=Trans, hyp_rows=hyp_rows, best=best, want_stats=True, w_f32=w_f32)
     T1 = _kabsch_host(st)
-    _, st = hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True)
+    _, st = hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True, w_f32=w_f32)
     return _kabsch_host(st)
 
 
@@ -71,7 +78,7 @@ class refiner:
         """Weighted Kabsch on the inliers of T at `inlinerdist` (estimator.py:53-72) -> [4,4] float64."""
         T = np.asarray(T, np.float64)
         T4 = np.zeros((4, 4)); T4[:T.shape[0], :] = T
-        _, st = hip.refine(_dev64(key_m0), _dev64(key_m1), _dev64(scores), inlinerdist, T_in=_dev64(T4), want_stats=True)
+        _, st = hip.refine(_dev64(key_m0), _dev64(key_m1), _dev64(scores), inlinerdist, T_in=_dev64(T4), want_stats=True, w_f32=_is_f32(scores))
         return _kabsch_host(st)
 
 
@@ -133,15 +140,16 @@ def dr_bins(Index):
     return counts, members, starts, prob / np.sum(prob)
 
 
-def yohoc_draws(Index, max_iter):
+def yohoc_draws(Index, max_iter, rng=None):
     """The draws of the YOHO-C loop (estimator.py:220-230) -> rows [H,3] of the correspondence list, or None when no rotation bin holds
     two correspondences (:214-216).  The loop's control flow depends only on the global generator and the bin statistics, never on
     the overlaps, so every hypothesis is drawn first (hip.yohoc_draw: the reference's generator calls, replayed) and all of them are
-    scored in one device launch."""
+    scored in one device launch.  rng=None: the process-global generator (the reference's); a RandomState: that stream, the global one
+    untouched."""
     counts, members, starts, prob = dr_bins(Index)
     if np.sum(prob) < 1e-5:
         return None
-    bins, picks = hip.yohoc_draw(prob, counts, max_iter)
+    bins, picks = hip.yohoc_draw(prob, counts, max_iter, rng=rng)
     return members[starts[bins][:, None] + picks]
 
 
@@ -169,7 +177,8 @@ class yohoc_ransac:
         return three_point_transforms(np.asarray(kps0_init)[None], np.asarray(kps1_init)[None])[0]          # 3*4
 
     def overlap_cal(self, key_m0, key_m1, T, scores):
-        ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist)
+        ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist,
+                                    w_f32=_is_f32(scores))
         return float(ov[0].item())
 
     def transdiff(self, gt, pre):
@@ -198,8 +207,8 @@ class yohoc_ransac:
             return 0
         k0 = _dev64(Keys_m0_init); k1 = _dev64(Keys_m1_init); w = _dev64(scores)
         Trans = _dev64(hyps)
-        _, best, _ = hip.ransac_score(k0, k1, w, Trans, self.inliner_dist)
-        T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=Trans, best=best)
+        _, best, _ = hip.ransac_score(k0, k1, w, Trans, self.inliner_dist, w_f32=_is_f32(scores))
+        T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=Trans, best=best, w_f32=_is_f32(scores))
         recall_time = int(best.item()) + 1                      # iter_ransac is 1-based when recorded
         np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T2, recalltime=recall_time)
 
@@ -285,7 +294,8 @@ class yohoo_ransac:
     def overlap_cal(self, key_m0, key_m1, T, scores):
         if len(key_m0) == 0:
             return float('nan')                                  # 0 / 0 in the reference (estimator.py:396-403)
-        ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist)
+        ov, _, _ = hip.ransac_score(_dev64(key_m0), _dev64(key_m1), _dev64(scores), _dev64(np.asarray(T)[None, :3, :]), self.inliner_dist,
+                                    w_f32=_is_f32(scores))
         return float(ov[0].item())
 
     def transdiff(self, gt, pre):
@@ -321,8 +331,8 @@ class yohoo_ransac:
             hyp = torch.from_numpy(np.ascontiguousarray(rows[index[0:max_iter]], np.int64)).cuda()
             w = _dev64(scores)
             TransD = _dev64(Trans)
-            _, best, _ = hip.ransac_score(k0, k1, w, TransD, self.inliner_dist, hyp_rows=hyp)
-            T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=TransD, hyp_rows=hyp, best=best)
+            _, best, _ = hip.ransac_score(k0, k1, w, TransD, self.inliner_dist, hyp_rows=hyp, w_f32=_is_f32(scores))
+            T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=TransD, hyp_rows=hyp, best=best, w_f32=_is_f32(scores))
             recall_time = max(int(best.item()), 0)
             np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T2, recalltime=recall_time)
         R_pre_log(dataset, Save_dir)

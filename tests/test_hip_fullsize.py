@@ -37,20 +37,53 @@ def test_full_ransac_masks_best_refine(tag, f32s):
     z = load_golden('full_ransac')
     k0, k1, sc, Tr, hyp = synth.make_ransac_case(int(z[f'{tag}_seed']), M=5000, H=1000, f32_scores=f32s)
     w = cu(sc.astype(np.float64))
-    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), w, cu(Tr), 0.1, hyp_rows=cu(hyp), want_mask=True)
+    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), w, cu(Tr), 0.1, hyp_rows=cu(hyp), want_mask=True, w_f32=f32s)
     want = np.unpackbits(z[f'{tag}_masks'], axis=1)[:, :5000].astype(bool)
     assert np.array_equal(mask.cpu().numpy().astype(bool), want)                      # 5,000,000 inlier decisions, bit-exact
     ovh = ov.cpu().numpy()
     if tag == 'ones':
         assert np.array_equal(ovh, z[f'{tag}_overlap'])
-    else:
-        assert np.abs(ovh - z[f'{tag}_overlap']).max() < 1e-6                          # the reference sums float32 scores in float32
+    else:                                                                              # the reference's float32 pairwise sums / float32 M, bit for bit
+        assert z[f'{tag}_overlap'].dtype == np.float32 and np.array_equal(ovh.astype(np.float32), z[f'{tag}_overlap'])
     assert int(best.item()) == int(z[f'{tag}_best'])
-    T1 = hip.refine(cu(k0), cu(k1), w, 0.2, Trans=cu(Tr), hyp_rows=cu(hyp), best=best)
-    T2 = hip.refine(cu(k0), cu(k1), w, 0.1, T_in=T1)
-    tol = 1e-9 if tag == 'ones' else 1e-6
+    T1 = hip.refine(cu(k0), cu(k1), w, 0.2, Trans=cu(Tr), hyp_rows=cu(hyp), best=best, w_f32=f32s)
+    T2 = hip.refine(cu(k0), cu(k1), w, 0.1, T_in=T1, w_f32=f32s)
+    tol = 1e-9
     assert np.abs(T1.cpu().numpy() - z[f'{tag}_refine1']).max() < tol
     assert np.abs(T2.cpu().numpy() - z[f'{tag}_refine2']).max() < tol
+
+
+def test_full_ransac_float32_ties_keep_the_references_winner():
+    """Float32 scores built to tie at float32 precision (synth.make_ransac_tie_case): the reference's winner (hypothesis 32 of 600) is
+    decided by numpy's pairwise float32 sum and float32 quotient; a float64 accumulation of the same weights would keep hypothesis 312.
+    Overlaps bit-exact as float32, same winner, same refinements -- through the per-pair entry points AND the batched estimator tail,
+    alone and next to a task with another M (the kernels' LDS compaction is per wave)."""
+    from roreg_amd import hip
+    z = load_golden('full_ransac_ties')
+    k0, k1, sc, Tr, hyp = synth.make_ransac_tie_case(int(z['seed']))
+    assert sc.dtype == np.float32 and int(z['best']) != int(z['best_of_float64_accumulation'])
+    w = cu(sc.astype(np.float64))
+    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), w, cu(Tr), 0.1, hyp_rows=cu(hyp), want_mask=True, w_f32=True)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), np.unpackbits(z['masks'], axis=1)[:, :k0.shape[0]].astype(bool))
+    assert np.array_equal(ov.cpu().numpy().astype(np.float32), z['overlap'])
+    assert int(best.item()) == int(z['best'])
+    ov64, best64, _ = hip.ransac_score(cu(k0), cu(k1), w, cu(Tr), 0.1, hyp_rows=cu(hyp))          # float64 accumulation: the other winner
+    assert int(best64.item()) == int(z['best_of_float64_accumulation'])
+    T1 = hip.refine(cu(k0), cu(k1), w, 0.2, Trans=cu(Tr), hyp_rows=cu(hyp), best=best, w_f32=True)
+    T2 = hip.refine(cu(k0), cu(k1), w, 0.1, T_in=T1, w_f32=True)
+    assert np.abs(T1.cpu().numpy() - z['refine1']).max() < 1e-9 and np.abs(T2.cpu().numpy() - z['refine2']).max() < 1e-9
+    # batched tail: identity matches (the keypoints are the matched ones already), a second, larger task beside it (M = 5000 > 4096)
+    ident = cu(np.stack([np.arange(k0.shape[0])] * 2, 1).astype(np.int64))
+    k0b, k1b, scb, Trb, hypb = synth.make_ransac_case(int(load_golden('full_ransac')['f32_seed']), M=5000, H=1000, f32_scores=True)
+    identb = cu(np.stack([np.arange(5000)] * 2, 1).astype(np.int64))
+    for tasks in ([(cu(k0), cu(k1), ident, w, cu(Tr), cu(hyp))],
+                  [(cu(k0b), cu(k1b), identb, cu(scb.astype(np.float64)), cu(Trb), cu(hypb)), (cu(k0), cu(k1), ident, w, cu(Tr), cu(hyp))]):
+        bb, T1b, _, T2b, _ = hip.ransac_batch(tasks, 0.1, w_f32=True)
+        assert int(bb[-1].item()) == int(z['best'])
+        assert np.abs(T1b[-1].cpu().numpy() - z['refine1']).max() < 1e-9 and np.abs(T2b[-1].cpu().numpy() - z['refine2']).max() < 1e-9
+        if len(tasks) == 2:
+            zf = load_golden('full_ransac')
+            assert int(bb[0].item()) == int(zf['f32_best']) and np.abs(T2b[0].cpu().numpy() - zf['f32_refine2']).max() < 1e-9
 
 
 # ---- matcher -> Des2R -> ET / Trans_pre -> RANSAC on a 5000-keypoint near-tie pair, stage by stage ------------------------------------

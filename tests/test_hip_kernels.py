@@ -289,6 +289,36 @@ def test_des2r_irrep_bound_with_exact_recheck_is_the_literal_argmax(group, scale
     assert torch.equal(gotb, wantb)
 
 
+def test_des2r_irrep_margin_on_largest_irrep_near_ties(group):
+    """Adversarial for the candidate margin of the irrep-domain Des2R (csrc/des2r.hip header): descriptors that live entirely in the
+    5-dimensional irrep (where sum |terms| of the irrep evaluation is largest relative to |d1||d2|: the entrywise-absolute representation
+    matrices reach spectral norm sqrt(5)) carrying TWO planted rotations whose correlations differ by 1e-6 .. 3e-4 of |d1||d2| -- the range
+    around the margin, where a too-small margin would drop the literal winner from the candidate set.  The index must be the literal
+    kernel's on every row."""
+    from roreg_amd import hip
+    from roreg_amd.fourier import group_fourier
+    gf = group_fourier()
+    F5 = gf.F[int(gf.offsets[4]):int(gf.offsets[5])]                              # [25, 60] rows of the d = 5 irrep
+    proj = (F5.T @ F5)                                                            # projector onto its isotypic subspace
+    rng = np.random.default_rng(31)
+    n = 4096
+    d2 = (rng.standard_normal((n, 32, 60)) @ proj).astype(np.float32)
+    d1 = np.zeros_like(d2)
+    a = rng.integers(0, 60, n); b = (a + 1 + rng.integers(0, 59, n)) % 60
+    gaps = 10.0 ** rng.uniform(-6.0, -3.5, n) * np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    for i in range(n):
+        d1[i][:, group.P[a[i]]] += d2[i]
+        tmp = np.zeros((32, 60), np.float32); tmp[:, group.P[b[i]]] = d2[i]
+        d1[i] += tmp * np.float32(1.0 + gaps[i])
+    for scale in (1.0, 1e-3, 37.0):
+        D1, D2 = cu(d1 * np.float32(scale)), cu(d2 * np.float32(scale))
+        want = hip.des2r(D1, D2)
+        got = hip.des2r(D1, D2, coefs1=hip.feat_coefs(D1), coefs0=hip.feat_coefs(D2))
+        assert torch.equal(got, want), int((got != want).sum())
+    picked = want.cpu().numpy()
+    assert np.mean((picked == a) | (picked == b)) > 0.99                          # the winner is one of the two planted rotations
+
+
 def test_des2r_recovers_planted_rotation(group):
     from roreg_amd import hip
     rng = np.random.default_rng(2)
@@ -320,17 +350,19 @@ def test_ransac_score_masks_bit_exact(tag):
     from roreg_amd import hip
     z = load_golden('ransac')
     k0, k1, sc, Tr = z[f'{tag}_k0'], z[f'{tag}_k1'], z[f'{tag}_scores'], z[f'{tag}_Trans']
-    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), cu(sc.astype(np.float64)), cu(Tr), 0.1, want_mask=True)
+    f32 = sc.dtype == np.float32                                  # the rotation-coherence matcher's scores: numpy's float32 reductions
+    ov, best, mask = hip.ransac_score(cu(k0), cu(k1), cu(sc.astype(np.float64)), cu(Tr), 0.1, want_mask=True, w_f32=f32)
     assert np.array_equal(mask.cpu().numpy().astype(bool), z[f'{tag}_masks'])
     ovh = ov.cpu().numpy()
     if tag == 'ones':
         assert np.array_equal(ovh, z[f'{tag}_overlap'])          # integer sums: exact
     else:
-        assert np.abs(ovh - z[f'{tag}_overlap']).max() < 1e-6    # reference sums these in float32
+        assert z[f'{tag}_overlap'].dtype == np.float32
+        assert np.array_equal(ovh.astype(np.float32), z[f'{tag}_overlap']) and np.array_equal(ovh.astype(np.float32).astype(np.float64), ovh)
     assert int(best.item()) == int(z[f'{tag}_best'])
-    T1 = hip.refine(cu(k0), cu(k1), cu(sc.astype(np.float64)), 0.2, Trans=cu(Tr), best=best)
-    T2 = hip.refine(cu(k0), cu(k1), cu(sc.astype(np.float64)), 0.1, T_in=T1)
-    tol = 1e-9 if tag == 'ones' else 1e-6
+    T1 = hip.refine(cu(k0), cu(k1), cu(sc.astype(np.float64)), 0.2, Trans=cu(Tr), best=best, w_f32=f32)
+    T2 = hip.refine(cu(k0), cu(k1), cu(sc.astype(np.float64)), 0.1, T_in=T1, w_f32=f32)
+    tol = 1e-9
     assert np.abs(T1.cpu().numpy() - z[f'{tag}_refine1']).max() < tol
     assert np.abs(T2.cpu().numpy() - z[f'{tag}_refine2']).max() < tol
 

@@ -113,6 +113,26 @@ def test_ransac_pieces_match_reference():
     assert np.allclose(r, z['single_refined'], atol=1e-12)
 
 
+def test_numpy_pairwise_model():
+    """The float32 reduction order the RANSAC kernels rebuild for float32 match scores (csrc/ransac.hip) IS numpy's: the written-out model
+    (oracle np_sum_f32_model: 8 strided partials + fixed tree per <= 128-element leaf, halving at multiples of 8, 8192-element chunks) equals
+    np.sum bit for bit at every length that matters, and the float32 quotient by a Python int stays float32 (test/estimator.py:381)."""
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 140)) + [255, 256, 257, 1000, 2500, 4095, 4096, 4097, 5000, 8191, 8192, 8193, 12345, 16384, 20000]:
+        a = rng.uniform(0.1, 1.0, n).astype(np.float32)
+        if n:
+            a[rng.integers(0, n)] *= np.float32(1000)
+        assert O.np_sum_f32_model(a) == np.sum(a), n
+    assert (np.sum(np.ones(3, np.float32)) / 5000).dtype == np.float32
+    z = load_golden('full_ransac_ties')
+    k0, k1, sc, Tr, hyp = synth.make_ransac_tie_case(int(z['seed']))
+    for h in (int(z['best']), int(z['best_of_float64_accumulation']), 0):
+        inl = np.where(O.inlier_mask(k0, k1, Tr[h], 0.1))[0]
+        assert np.float32(O.np_sum_f32_model(sc[inl]) / np.float32(sc.shape[0])) == z['overlap'][h] == O.overlap_cal(k0, k1, Tr[h], sc, 0.1)
+    ov = np.array([O.overlap_cal(k0, k1, Tr[h], sc, 0.1) for h in hyp])
+    assert np.array_equal(ov, z['overlap']) and int(np.argmax(ov)) == int(z['best']) != int(z['best_of_float64_accumulation'])
+
+
 def test_quat_and_rdiff_match_reference():
     z = load_golden('quat')
     for i in range(50):

@@ -4,7 +4,7 @@ Same rules as tools/gen_golden.py (build container only; the reference is import
 vectors are written).  The INPUTS of every case are rebuilt from a seed by roreg_amd/synth.py (portable arithmetic only), so the
 fixtures hold just the reference's small outputs: index lists, packed inlier masks, transforms and strided samples of the big tensors.
 
-    python tools/gen_golden_full.py [stages] [ransac] [match_ot] [pipeline]        (no argument = all; ~10 minutes on 8 cores)
+    python tools/gen_golden_full.py [stages] [ransac] [ransac_ties] [match_ot] [pipeline] [pipeline_rd_rm] [yohoc] [rd]        (no argument = all; ~10 minutes on 8 cores)
 """
 import os
 import shutil
@@ -67,6 +67,30 @@ def gen_ransac():
         out.update({f'{tag}_seed': np.int64(RANSAC_SEED + int(f32s)), f'{tag}_overlap': ov, f'{tag}_masks': np.packbits(masks, axis=1),
                     f'{tag}_best': np.int64(best), f'{tag}_refine1': r1, f'{tag}_refine2': r2})
     save('full_ransac', **out)
+
+
+def gen_ransac_ties():
+    """One-shot RANSAC of the reference on float32 scores that tie at float32 precision (synth.make_ransac_tie_case): the seed is searched
+    until the reference's winner (float32 pairwise sums, float32 quotient, strict `>`) differs from the winner of a float64 accumulation of
+    the same weights, so the fixture tells the two evaluation orders apart."""
+    rs = ref_est.yohoo_ransac(gg.make_cfg_like(gg.NS(ransac_ird=0.1, RM=True, match_n=0.5, output_cache_fn='/tmp', SO3_related_files=f'{REF}/utils/group_related')))
+    for seed in range(700, 760):
+        k0, k1, scores, Trans, hyp = synth.make_ransac_tie_case(seed)
+        ov = np.array([rs.overlap_cal(k0, k1, Trans[i], scores) for i in hyp])
+        assert ov.dtype == np.float32
+        masks = np.stack([np.sum(np.square(k0 - ref_utils.transform_points(k1, Trans[i])), -1) < 0.1 * 0.1 for i in hyp])
+        ov64 = np.array([scores[m].astype(np.float64).sum() / scores.shape[0] for m in masks])
+        best, best64 = int(np.argmax(ov)), int(np.argmax(ov64))
+        ties = int((ov == ov[best]).sum())
+        print('   seed', seed, 'best', best, 'float64-accumulation best', best64, 'hypotheses at the float32 maximum', ties)
+        if best != best64 and ties >= 2:
+            break
+    else:
+        raise SystemExit('no discriminating seed found')
+    r1 = rs.refiner.Refine_trans(k0, k1, Trans[hyp[best]], scores, inlinerdist=0.2)
+    r2 = rs.refiner.Refine_trans(k0, k1, r1, scores, inlinerdist=0.1)
+    save('full_ransac_ties', seed=np.int64(seed), overlap=ov, masks=np.packbits(masks, axis=1), best=np.int64(best),
+         best_of_float64_accumulation=np.int64(best64), refine1=r1, refine2=r2)
 
 
 def gen_match_ot():
@@ -164,7 +188,7 @@ def gen_rd():
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['ransac', 'stages', 'match_ot', 'pipeline', 'yohoc', 'rd']
+    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'yohoc', 'rd']
     for name in todo:
         print(name)
-        {'stages': gen_stages, 'ransac': gen_ransac, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
+        {'stages': gen_stages, 'ransac': gen_ransac, 'ransac_ties': gen_ransac_ties, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
