@@ -2,8 +2,12 @@
 """bench.py -- pair-registrations/sec of the RoReg hot path on MI355X.
 
     python bench.py [--gpus N --steps K --warmup W] [--workload 3dmatch-full | kitchen | chunk] [--gemm f16x2 | bf16x3 | f32]
-                    [--dtype fp32 | bf16] [--pair-lists banded | uniform]
+                    [--dtype fp32 | bf16] [--pair-lists banded | uniform] [--no-exchange]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: it starts N ranks of itself through
+torch.distributed.run (127.0.0.1 rendezvous) before anything touches a GPU, relays rank 0's JSON line and exits with the job's
+code.  Every rank checks that the world size it sees equals --gpus and fails otherwise.
 
 A "step" is one pass of the whole hot path (GF extractor on every cloud, mutual matcher, Des2R + ET local transforms, one-shot
 RANSAC + 2 refinements on every pair) over the workload, inputs resident in HBM before the timed region:
@@ -12,22 +16,30 @@ RANSAC + 2 refinements on every pair) over the workload, inputs resident in HBM 
            station counts [60,60,60,55,57,37,66,38] (dataops/dataset.py:152) = 433 clouds x 5000 keypoints and 1623 pairs (kitchen: 60 clouds,
            449 pairs; pair lists: the chain (i, i+1) plus pairs drawn with probability ~ exp(-|i-j|/8), --pair-lists uniform for uniformly
            drawn ones), random-init GF/ET weights of the reference's architecture.  With N ranks the pairs are sharded by
-           roreg_amd.distributed.shard_scenes (whole scenes first, the largest scene cut into pair ranges), no data-path collective,
+           roreg_amd.distributed.shard_scenes (whole scenes first, the scenes that must be cut into pair ranges); every cloud is extracted
+           by ONE rank and a cut scene's extractor outputs travel point to point (RCCL send/recv over xGMI) at the start of the step;
            ONE all_gather of the result table per step: STRONG scaling, the same command for every N.  At N = 1 the whole benchmark runs
            on one GPU (it fits: 16.6 GB of inputs); the kitchen scene alone (configs[1]) is timed inside the same steps and reported as
            `config.kitchen_scene`.
   kitchen: only the kitchen-like scene (60 clouds, 449 pairs), pairs sharded across the ranks.
   chunk  : round 1's 16-cloud / 60-pair scene chunk per rank (weak scaling), kept for comparison.
 
-The JSON line carries the roofline of the dominant kernel (the fp16x2 MFMA GEMMs of the group convolution in the irrep domain, HIP events
-on the launch stream inside the timed region), measured rooflines of the kernels north_star names (the descriptor distance matrix on the
-matrix cores, the RANSAC scoring kernel), the other matrix-core modes, and a CPU baseline (the numpy oracle, rank 0, bounded sample).
+The JSON line carries: the roofline of the dominant kernel (the fp16x2 MFMA GEMMs of the group convolution in the irrep domain, HIP events
+on the launch stream inside the timed region); measured rooflines of the kernels north_star names (descriptor distance matrix, RANSAC
+scoring, Des2R); `value_all_local_transforms` (the reference's per-pair work: the local transform of EVERY correspondence) on the same full
+workload; FMR / IR / RR over all ranks from the evaluator's metric code; a secondary leg on BASELINE configs[3]/[4]'s path (detector +
+rotation-coherence matcher at keynum 2500, float32 and bfloat16 descriptor storage) with the rooflines of its Sinkhorn and top-k kernels;
+and two CPU baselines on the host cores (the reference's own torch CPU operators on all threads = oracle/ref_torch.py, and the numpy
+oracle), rank 0, bounded samples.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 import torch
@@ -35,15 +47,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input MFMA peak (= the f32 vector FMA peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (no sparsity)
 PEAK_F64_VALU_TFLOPS = 78.6         # MI355X_MICROARCH.md: vector fp64
 PEAK_HBM_GBS = 8000.0
 N_KPTS = 5000
 OVERLAP = 0.6
+STUB = os.environ.get('ROREG_BENCH_ENGINE')          # tests only: 'module:factory' of a host-side stand-in engine (tests/_bench_stub.py)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -61,52 +74,82 @@ def parse():
                     'all cloud pairs (the worst case for cutting a scene across ranks); same pair and cloud counts, same single-GPU work')
     ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32', help='descriptor storage (BASELINE config 5: bf16 = group features stored and '
                     'streamed as bfloat16, float32 accumulation)')
-    return ap.parse_args()
+    ap.add_argument('--no-exchange', action='store_true', help='multi-rank: every rank extracts every cloud its pair ranges touch (round 2) instead of '
+                    'extracting each cloud once and shipping the extractor output of a cut scene over xGMI')
+    ap.add_argument('--all-steps', type=int, default=5, help='timed steps of the all-local-transforms figure (the reference\'s per-pair work)')
+    ap.add_argument('--master-port', type=int, default=0, help='launcher only: rendezvous port (0 = pick a free one)')
+    return ap.parse_args(argv)
+
+
+# ---- launcher ---------------------------------------------------------------------------------------------------------------------------
+def launch(args):
+    """--gpus N > 1 without a torch.distributed environment: start N ranks of this script (one process per GPU) through
+    torch.distributed.run.  Runs before any GPU call of this process -- a process that has initialised the GPU must never be replaced or
+    fork workers -- and the children are ordinary subprocesses; their exit code is ours."""
+    import socket
+    shared = bool(os.environ.get('ROREG_BENCH_SHARED_GPU')) or bool(STUB)
+    n_dev = torch.cuda.device_count()                       # (counting devices does not initialise the GPU)
+    if not shared and n_dev < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible (ROREG_BENCH_SHARED_GPU=1 --backend gloo runs every rank on GPU 0)', file=sys.stderr)
+        return 2
+    port = args.master_port
+    if not port:
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
+    return subprocess.call(cmd, env=env)
 
 
 # ---- workload ---------------------------------------------------------------------------------------------------------------------------
-def build_workload(args, rank, world):
+def build_workload(args, rank, world, device='cuda', exchange=True):
     """-> (scenes {name: (feats, keys, poses, pair_ids)} for the scenes this rank touches, plan [(scene, a, b)] of this rank, totals)."""
     from roreg_amd import synth
-    from roreg_amd.distributed import shard_scenes
+    from roreg_amd.distributed import shard_scenes, exchange_plan, extractions_per_rank
     if args.workload == 'chunk':
-        feats, keys, poses = synth.make_scene_device(1000 + rank, 16, args.kpts, OVERLAP)
+        feats, keys, poses = synth.make_scene_device(1000 + rank, 16, args.kpts, OVERLAP, device=device)
         pairs = [(str(a), str(b)) for a, b in synth.scene_pair_list(16, 60, 4242)]
-        return {'chunk': (feats, keys, poses, pairs)}, [('chunk', 0, len(pairs))], {'pairs': 60 * world, 'clouds': 16 * world, 'scaling': 'weak'}
+        return {'chunk': (feats, keys, poses, pairs)}, [('chunk', 0, len(pairs))], {'pairs': 60 * world, 'clouds': 16 * world, 'scaling': 'weak', 'transfers': [],
+                                                                                   'rows_per_rank': [60] * world}
     names = synth.THREEDMATCH_SCENES if args.workload == '3dmatch-full' else synth.THREEDMATCH_SCENES[:1]
     clouds = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(synth.THREEDMATCH_SCENES, synth.THREEDMATCH_PAIRS))
     loc = 8.0 if getattr(args, 'pair_lists', 'banded') == 'banded' else None
     lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + synth.THREEDMATCH_SCENES.index(s), locality=loc) for s in names}
-    plan = shard_scenes({s: npairs[s] for s in names}, world, {s: clouds[s] for s in names}, pair_lists=lists)
+    exchange = bool(exchange and world > 1)
+    plan = shard_scenes({s: npairs[s] for s in names}, world, {s: clouds[s] for s in names}, pair_lists=lists, exchange=exchange)
+    transfers = exchange_plan(plan, lists)[1] if exchange else []
     scenes = {}
-    for s in sorted({p[0] for p in plan[rank]}):
+    for s in sorted({p[0] for p in plan[rank]} | {t[0] for t in transfers if rank in (t[2], t[3])}):
         i = synth.THREEDMATCH_SCENES.index(s)
-        feats, keys, poses = synth.make_scene_device(500 + i, clouds[s], args.kpts, OVERLAP)
+        feats, keys, poses = synth.make_scene_device(500 + i, clouds[s], args.kpts, OVERLAP, device=device)
         scenes[s] = (feats, keys, poses, [(str(a), str(b)) for a, b in lists[s]])
     return scenes, plan[rank], {'pairs': sum(npairs[s] for s in names), 'clouds': sum(clouds[s] for s in names), 'scaling': 'strong',
-                                'plan': [[list(p) for p in r] for r in plan]}
+                                'plan': [[list(p) for p in r] for r in plan], 'transfers': transfers,
+                                'rows_per_rank': [sum(b - a for _, a, b in r) for r in plan],
+                                'extractions_per_rank': extractions_per_rank(plan, lists, exchange=exchange)}
 
 
-def cpu_baseline(cfg_nets, feats0, feats1):
+# ---- CPU baselines ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_numpy(cfg_nets, feats0, feats1):
     """Oracle (numpy port of the reference's algorithm) timed on a bounded sample (per-unit costs)."""
     from oracle import ref_numpy as O
     from roreg_amd.group import tables
     T = tables()
     gf_sd, et_sd = cfg_nets
-    threads = torch.get_num_threads()
     t = {}
-    nb = 1024
+    nb = 512
     x = feats0[:nb]
     t0 = time.perf_counter(); O.gf_forward(x, gf_sd, T.Nei); t['gf_per_kpt'] = (time.perf_counter() - t0) / nb
-    n = 3500
+    n = 2500
     e0 = feats0[:n]; e1 = feats1[:n]
     s = np.arange(n)
     t0 = time.perf_counter(); O.mutual_match(e0, e1, s, s); dt = time.perf_counter() - t0
     t['mutual_per_pair'] = dt * (feats0.shape[0] / n) ** 2                  # O(N^2)
-    nm = 1024
+    nm = 512
     d1 = feats1[:nm]; d0 = feats0[:nm]
     t0 = time.perf_counter(); dr = O.des2r(d1, d0, T.P); t['des2r_per_corr'] = (time.perf_counter() - t0) / nm
-    nb = 768
+    nb = 384
     batch = {'before_eqv0': feats1[:nb], 'before_eqv1': feats0[:nb], 'after_eqv0': feats1[:nb], 'after_eqv1': feats0[:nb], 'pre_idx': dr[:nb]}
     t0 = time.perf_counter(); O.et_forward(batch, et_sd, T.Nei, T.P); t['et_per_corr'] = (time.perf_counter() - t0) / nb
     M, H = 3000, 200
@@ -116,12 +159,57 @@ def cpu_baseline(cfg_nets, feats0, feats1):
     for h in range(H):
         O.overlap_cal(k0, k1, Tr[h], np.ones(M), 0.1)
     t['ransac_per_hyp'] = (time.perf_counter() - t0) / H
-    return t, threads
+    return t
 
 
-DTYPE_OF = {'f16x2': 'f32 (f32-accurate, NOT reduced precision: every f32 operand enters the fp16 matrix cores as hi+lo fp16 under a per-keypoint '
-                     'power-of-two block scale = 22 significant bits, 3 cross products, f32 accumulate; measured error <= the f32-input MFMA '
-                     'kernel\'s; results independent of batch composition and rank count); f64 estimator',
+def cpu_baseline_torch(cfg_nets, feats0, feats1):
+    """The reference's own torch CPU operators (oracle/ref_torch.py: conv2d on the gathered stencil tensor, batch_norm, einsum, the chunked
+    nearest-neighbour search) on ALL host threads, bounded samples (SURVEY 8d's CPU baseline) -> per-unit costs."""
+    from oracle import ref_torch as OT
+    from roreg_amd.group import tables
+    T = tables()
+    gf_sd, et_sd = cfg_nets
+    f0 = torch.from_numpy(feats0); f1 = torch.from_numpy(feats1)
+    t = {}
+    nb = 1250                                                               # the reference's bs_GF (test/extractor.py:51)
+    OT.gf_forward(f0[:64], gf_sd, T.Nei)                                    # (operator warm-up: oneDNN primitive creation)
+    t0 = time.perf_counter(); OT.gf_forward(f0[:nb], gf_sd, T.Nei); t['gf_per_kpt'] = (time.perf_counter() - t0) / nb
+    n = feats0.shape[0]
+    s = np.arange(n)
+    t0 = time.perf_counter(); OT.mutual_match(f0, f1, s, s); t['mutual_per_pair'] = time.perf_counter() - t0       # the full 5000 x 5000 search
+    nm = 1000
+    t0 = time.perf_counter(); dr = OT.des2r(f1[:nm], f0[:nm], T.P); t['des2r_per_corr'] = (time.perf_counter() - t0) / nm
+    nb = 1000                                                               # bs_ET (test/estimator.py:338)
+    batch = {'before_eqv0': f1[:nb], 'before_eqv1': f0[:nb], 'after_eqv0': f1[:nb], 'after_eqv1': f0[:nb], 'pre_idx': dr[:nb]}
+    OT.et_forward({k: v[:64] for k, v in batch.items()}, et_sd, T.Nei, T.P)
+    t0 = time.perf_counter(); OT.et_forward(batch, et_sd, T.Nei, T.P); t['et_per_corr'] = (time.perf_counter() - t0) / nb
+    M, H = 3000, 200
+    rng = np.random.default_rng(0)
+    k0 = rng.uniform(0, 3, (M, 3)); k1 = rng.uniform(0, 3, (M, 3)); Tr = rng.standard_normal((H, 3, 4))
+    t0 = time.perf_counter()
+    for h in range(H):
+        OT.overlap_cal(k0, k1, Tr[h], np.ones(M), 0.1)
+    t['ransac_per_hyp'] = (time.perf_counter() - t0) / H
+    return t
+
+
+def scale_baseline(t, M, clouds, pairs):
+    """per-unit host costs -> (pairs/s with the local transform of EVERY correspondence = the reference's work, pairs/s with only the drawn
+    hypotheses' = what the headline `value` does, components)."""
+    H = min(M, 1000)
+    per_cloud = t['gf_per_kpt'] * N_KPTS
+    tail = H * t['ransac_per_hyp'] * (M / 3000.0)
+    per_pair_all = t['mutual_per_pair'] + M * (t['des2r_per_corr'] + t['et_per_corr']) + tail
+    per_pair_drawn = t['mutual_per_pair'] + H * (t['des2r_per_corr'] + t['et_per_corr']) + tail
+    return (pairs / (clouds * per_cloud + pairs * per_pair_all), pairs / (clouds * per_cloud + pairs * per_pair_drawn),
+            {'gf_per_cloud': per_cloud, 'per_pair_all_local_transforms': per_pair_all, 'per_pair_drawn_hypotheses_only': per_pair_drawn})
+
+
+DTYPE_OF = {'f16x2': 'f32 (every f32 operand enters the fp16 matrix cores as hi + lo fp16 under a per-keypoint power-of-two block scale: <= 22 significant bits '
+                     'relative to a CONSERVATIVE per-keypoint bound -- the bound sits 2^4..2^9 above the keypoint\'s true coefficient maximum (config.'
+                     'f16x2_scale_headroom_bits), i.e. 13..18 bits relative to the data plus the lo piece\'s absolute floor of 2^-39 of the bound; 3 cross '
+                     'products, f32 accumulate; measured GEMM error 7e-7..9e-7 of the output scale vs 1.5e-6..2e-6 for the f32-input MFMA kernel; '
+                     'results independent of batch composition and rank count); f64 estimator',
             'bf16x3': 'f32 (f32-accurate: every f32 operand as 3 bf16 pieces = 24 bits, 6 cross products, f32 accumulate); f64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); f64 estimator'}
 MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}
@@ -129,6 +217,7 @@ KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2,4,1,1> (fragment-pipelined 8
                       'per-keypoint block scales: 3 fp16 MFMAs per product)',
              'bf16x3': 'irrep_gemm_split_kernel<32,3,2,1> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
              'f32': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, f32-input MFMA)'}
+TAG_OF = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
 
 
 def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
@@ -137,7 +226,8 @@ def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
     'f32': v_mfma_f32_32x32x2_f32, priced against the f32-input MFMA peak.  'bf16x3' / 'f16x2': every product is six bf16 / three fp16
     MFMAs, so 6x / 3x gemm_tflops are executed and priced against the dense bf16 = fp16 peak; the f32-equivalent rate is reported too.
     (In the reference's own 13-stencil form the same layer is 780/244 = 3.2x more flops: SURVEY 8d's per-keypoint figure.)"""
-    base = {'bound': 'mfma', 'unit': 'TFLOP/s', 'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch, 'traffic': traffic,
+    base = {'bound': 'mfma', 'unit': 'TFLOP/s', 'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch,
+            'traffic': None if traffic is None else traffic.get('bytes'), 'traffic_source': traffic,
             'algorithmic_bytes_per_launch': alg_bytes, 'f32_equivalent_gemm_tflops': gemm_tflops,
             'reference_stencil_form_equivalent_tflops': gemm_tflops * 780.0 / 244.0}
     if mode == 'f32':
@@ -160,166 +250,223 @@ def gemm_roofline(events, tagname):
     return (flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), ms, n_launch, (alg / n_launch if n_launch else None)
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the dominant kernel's source file: a PMC pass is only quoted for the source it was collected on."""
+    with open(os.path.join(ROOT, 'roreg_amd', 'csrc', 'fourier.hip'), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def measured_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_irrep_gemm_pmc.json) -- returned
+    only if that pass was collected on THIS kernel source (its `kernel_source_sha16` equals csrc/fourier.hip's hash now); otherwise None
+    with the reason, so a stale number is never printed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_irrep_gemm_pmc.json')))
+    if not files:
+        return None
+    j = json.load(open(files[-1]))
+    val = (j.get('hbm_bytes_per_launch') or {}).get(f'{args.workload}:{args.gemm}')
+    src = {'file': os.path.relpath(files[-1], ROOT), 'git_commit': j.get('git_commit'), 'kernel_source_sha16': j.get('kernel_source_sha16')}
+    if val is None:
+        return None
+    if j.get('kernel_source_sha16') != kernel_source_hash():
+        return {'bytes': None, **src, 'refused': f'the PMC pass was collected on another kernel source (now {kernel_source_hash()})'}
+    return {'bytes': val, **src}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch(args))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-    torch.cuda.set_device(0 if os.environ.get('ROREG_BENCH_SHARED_GPU') else local)
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)', file=sys.stderr)
+        sys.exit(3)
+    if STUB:
+        device = 'cpu'; dev_index = None; args.backend = 'gloo'
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+        dev_index = 0 if os.environ.get('ROREG_BENCH_SHARED_GPU') else local
+        torch.cuda.set_device(dev_index)
+        device = 'cuda'
+    sync = (lambda: None) if STUB else torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    coll_dev = 'cuda' if args.backend == 'nccl' else 'cpu'                 # device of the (tiny) collective payloads
+        kw = {'device_id': torch.device('cuda', dev_index)} if args.backend == 'nccl' else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    coll_dev = 'cuda' if (args.backend == 'nccl' and not STUB) else 'cpu'    # device of the (tiny) collective payloads
 
-    from roreg_amd import hip, synth
-    from roreg_amd.engine import RegistrationEngine
-    from roreg_amd.network import name2network
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[dev_index]) if args.backend == 'nccl' else dist.barrier()
+
+    from roreg_amd import distributed as D, synth
     from roreg_amd.parses.parses_test import default_config
-    from roreg_amd.utils.r_eval import compute_R_diff
-
     cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
-    gf = name2network['GF_test'](cfg); gf_sd = synth.seeded_state_dict(gf, 101)
-    et = name2network['ET_test'](cfg); et_sd = synth.seeded_state_dict(et, 202)
-    eng = RegistrationEngine(cfg, gf, et)
-    eng.set_gemm_mode(args.gemm)
-    if args.dtype == 'bf16':
-        eng.set_descriptor_dtype('bf16')
+    if STUB:
+        import importlib
+        mod, fn = STUB.split(':')
+        eng = getattr(importlib.import_module(mod), fn)(cfg)
+        hip = None
+    else:
+        from roreg_amd import hip
+        from roreg_amd.engine import RegistrationEngine
+        from roreg_amd.network import name2network
+        gf = name2network['GF_test'](cfg); gf_sd = synth.seeded_state_dict(gf, 101)
+        et = name2network['ET_test'](cfg); et_sd = synth.seeded_state_dict(et, 202)
+        eng = RegistrationEngine(cfg, gf, et)
+        eng.set_gemm_mode(args.gemm)
+        if args.dtype == 'bf16':
+            eng.set_descriptor_dtype('bf16')
 
-    scenes, my_plan, totals = build_workload(args, rank, world)            # inputs resident in HBM before timing
-    import zlib
+    scenes, my_plan, totals = build_workload(args, rank, world, device=device, exchange=not args.no_exchange)   # inputs resident in HBM before timing
+    transfers = totals['transfers']
     seeds = {s: [(7 + zlib.crc32(f'{s}:{a}:{b}'.encode())) % (2 ** 32) for a, b in scenes[s][3]] for s in scenes}
     kitchen = synth.THREEDMATCH_SCENES[0]
-    kitchen_whole = any(p == (kitchen, 0, synth.THREEDMATCH_PAIRS[0]) for p in my_plan)
+    kitchen_whole = any(p == (kitchen, 0, synth.THREEDMATCH_PAIRS[0]) for p in my_plan) and not any(t[0] == kitchen for t in transfers)
     kitchen_ms = []
+    scene_index = {s: i for i, s in enumerate(synth.THREEDMATCH_SCENES + ['chunk'])}
 
-    def run_range(s, a, b, **kw):
+    def scene_inputs(s):
         feats, keys, _, pairs = scenes[s]
-        return eng.run_scene(feats, keys, pairs[a:b], pair_seeds=seeds[s][a:b], **kw)
+        return feats, keys, pairs, seeds[s]
 
     def step(timed_kitchen=False, only=None, **kw):
-        rows = []
-        for (s, a, b) in my_plan:
-            if only is not None and s != only:
-                continue
-            if timed_kitchen and s == kitchen and kitchen_whole:
-                torch.cuda.synchronize(); tk = time.perf_counter()
-                res = run_range(s, a, b, **kw)
-                torch.cuda.synchronize(); kitchen_ms.append(1e3 * (time.perf_counter() - tk))
-            else:
-                res = run_range(s, a, b, **kw)
-            rows += [(s, r) for r in res]
-        table = torch.tensor([[float(r.id0), float(r.id1), r.n_match, r.recalltime] + r.trans.reshape(-1).tolist() for _, r in rows] or [[0.0] * 20],
-                             dtype=torch.float64, device=coll_dev)
-        if dist is not None:                                                  # the single result-table collective (RCCL/xGMI); ragged -> padded
-            n = torch.tensor([table.shape[0]], dtype=torch.int64, device=coll_dev)
-            ns = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(ns, n)
-            mx = max(int(x.item()) for x in ns)
-            pad = torch.zeros((mx, table.shape[1]), dtype=torch.float64, device=coll_dev); pad[:table.shape[0]] = table
-            out = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(out, pad)
-        return rows
+        """One pass of this rank's share + the step's single collective -> (this rank's rows [(scene, PairResult)], gathered table or None)."""
+        pieces = [p for p in my_plan if only is None or p[0] == only]
+        if timed_kitchen and kitchen_whole and only is None:                 # configs[1]: the kitchen scene alone, synchronised, inside the step
+            rest = [p for p in pieces if p[0] != kitchen]
+            sync(); tk = time.perf_counter()
+            done = D.run_plan(eng, [p for p in pieces if p[0] == kitchen], scene_inputs, [], rank, **kw)
+            sync(); kitchen_ms.append(1e3 * (time.perf_counter() - tk))
+            done += D.run_plan(eng, rest, scene_inputs, transfers, rank, **kw)
+        else:
+            done = D.run_plan(eng, pieces, scene_inputs, transfers if only is None else [], rank, **kw)
+        rows = [(s, r) for s, _, _, res in done for r in res]
+        table = None
+        if only is None:                                                      # the single result-table collective (RCCL over xGMI)
+            local_tab = np.concatenate([D.pack_rows(scene_index[s], res) for s, _, _, res in done] or [np.zeros((0, D.ROW))], 0)
+            table = D.gather_table(local_tab, device=coll_dev, counts=totals['rows_per_rank']) if dist is not None else local_tab
+        return rows, table
 
     def bracket(n, **kw):
         """n timed steps with the barrier + synchronise bracket on both sides; MAX over ranks."""
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
+        sync()
         t1 = time.perf_counter()
-        rows = None
+        out = None
         for _ in range(n):
-            rows = step(**kw)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+            out = step(**kw)
+        sync()
+        barrier()
         d = time.perf_counter() - t1
         if dist is not None:
             tt = torch.tensor([d], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
-        return d, rows
+        return d, out[0], out[1]
 
     for _ in range(args.warmup):
         step()
 
-    hip.PROFILE = []                                                         # per-launch HIP events of the group-conv GEMMs
-    hip.profile_enable(True)                                                 # library-side events: distance-matrix and RANSAC-scoring kernels
-    dt, rows = bracket(args.steps, timed_kitchen=True)
-    prof = hip.PROFILE; hip.PROFILE = None
-    mm_ms, mm_n = hip.profile_read('mm_tile'); rs_ms, rs_n = hip.profile_read('ransac_score')
-    d2_ms, d2_n = hip.profile_read('des2r'); ft_ms, ft_n = hip.profile_read('ft_nonlin')
-    hip.profile_enable(False)
+    if hip is not None:
+        hip.PROFILE = []                                                     # per-launch HIP events of the group-conv GEMMs
+        hip.profile_enable(True)                                             # library-side events: distance-matrix, RANSAC-scoring, Des2R kernels
+    dt, rows, table = bracket(args.steps, timed_kitchen=True)
+    prof = []
+    if hip is not None:
+        prof = hip.PROFILE; hip.PROFILE = None
+        mm_ms, mm_n = hip.profile_read('mm_tile'); rs_ms, rs_n = hip.profile_read('ransac_score')
+        d2_ms, d2_n = hip.profile_read('des2r'); ft_ms, ft_n = hip.profile_read('ft_nonlin')
+        hip.profile_enable(False)
     my_pairs = sum(b - a for _, a, b in my_plan)
-
-    # work terms of the named kernels on this rank, per step (from the result rows: M per pair; N = kpts; H = min(M, 1000))
     Ms = np.array([r.n_match for _, r in rows], np.float64)
     Hs = np.minimum(Ms, 1000.0)
 
-    # ---- secondary figures (outside the headline's timed region; kitchen scene only, so the default run stays short) ----
+    # ---- the reference's per-pair work on the SAME workload: the local transform of every correspondence (test/estimator.py:308-367) ----
     sec = {}
-    sec_scene = kitchen if kitchen in scenes else sorted(scenes)[0]
+    all_value = None
+    metrics = None
     if not args.no_secondary:
-        n_sec = 1
-        d_def, rows_def = bracket(n_sec, only=sec_scene)
-        n_sec_pairs = len(rows_def)
-        d_all, rows_all = bracket(n_sec, only=sec_scene, all_local_transforms=True)
-        same = all(np.array_equal(a.trans, b.trans, equal_nan=True) and a.recalltime == b.recalltime for (_, a), (_, b) in zip(rows_def, rows_all))
-        sec['value_all_local_transforms_on_secondary_scene'] = world * n_sec_pairs * n_sec / d_all if n_sec_pairs else None
-        sec['value_default_on_secondary_scene'] = world * n_sec_pairs * n_sec / d_def if n_sec_pairs else None
+        step(all_local_transforms=True)
+        d_all, rows_all, table_all = bracket(args.all_steps, all_local_transforms=True, keep_matches=True)
+        all_value = totals['pairs'] * args.all_steps / d_all
+        same = all(np.array_equal(a.trans, b.trans, equal_nan=True) and a.recalltime == b.recalltime for (_, a), (_, b) in zip(rows, rows_all))
+        if dist is not None:
+            ok = torch.tensor([1 if same else 0], dtype=torch.int64, device=coll_dev); dist.all_reduce(ok, op=dist.ReduceOp.MIN); same = bool(ok.item())
         sec['results_identical_to_all_local_transforms'] = bool(same)
+        # ---- FMR / IR / RR over ALL ranks (outside the timed regions; the evaluator's own metric code, test/evaluator.py:50-129) ----
+        from roreg_amd.run_distributed import inlier_ratio, scene_metrics
+        keys_host = {}
+        for s, r in rows_all:
+            for i in (int(r.id0), int(r.id1)):
+                if (s, i) not in keys_host:
+                    keys_host[(s, i)] = scenes[s][1][i].cpu().numpy()
+            r.ir = inlier_ratio(cfg, r, keys_host[(s, int(r.id0))], keys_host[(s, int(r.id1))], synth.pose_transform(scenes[s][2], r.id0, r.id1))
+        by_scene = {}
+        for s, r in rows_all:
+            by_scene.setdefault(s, []).append(r)
+        local_tab = np.concatenate([D.pack_rows(scene_index[s], rs) for s, rs in by_scene.items()] or [np.zeros((0, D.ROW))], 0)
+        full_tab = D.gather_table(local_tab, device=coll_dev) if dist is not None else local_tab
+        if rank == 0 and args.workload != 'chunk':
+            names = synth.THREEDMATCH_SCENES
+            per = {}
+            for row in D.unpack_rows(full_tab):
+                per.setdefault(names[row['scene']], []).append(row)
+            vals = []
+            for s in sorted(per, key=names.index):
+                # ground truth needs only the scene's poses: (group element, translation) per cloud from the scene's generator seed
+                poses = scenes[s][2] if s in scenes else synth.scene_poses(500 + names.index(s), synth.THREEDMATCH_CLOUDS[names.index(s)])
+                order = {(str(a), str(b)): q for q, (a, b) in enumerate(
+                    synth.scene_pair_list(synth.THREEDMATCH_CLOUDS[names.index(s)], synth.THREEDMATCH_PAIRS[names.index(s)], 900 + names.index(s),
+                                          locality=8.0 if args.pair_lists == 'banded' else None))}
+                rs = sorted(per[s], key=lambda r: order[(r['id0'], r['id1'])])
+                vals.append(scene_metrics(cfg, rs, lambda a, b: synth.pose_transform(poses, a, b)))
+            v = np.array(vals)
+            metrics = {'feature_matching_recall': float(v[:, 0].mean()), 'inlier_ratio': float(v[:, 1].mean()),
+                       'registration_recall_pointdsc': float(v[:, 2].mean()), 'rotation_error_deg': float(np.nanmean(v[:, 3])),
+                       'translation_error_m': float(np.nanmean(v[:, 4])), 'pairs': int(full_tab.shape[0]), 'scenes': len(vals),
+                       'note': 'synthetic scenes (tau_1 = 0.05, tau_2 = 0.1 m; RR = RRE < 15 deg and RTE < 0.3 m, scene means averaged like '
+                               'test/evaluator.py:111-129); RR(predator) needs the benchmark\'s gt.info covariances, which synthetic scenes do not have'}
+
+    # ---- secondary figures (outside the headline's timed region; kitchen scene only, so the default run stays short) ----
+    sec_scene = kitchen if kitchen in scenes else sorted(scenes)[0]
+    if not args.no_secondary and hip is not None:
+        n_sec = 1
+        d_def, rows_def, _ = bracket(n_sec, only=sec_scene)
+        n_sec_pairs = len(rows_def)
         sec['secondary_scene'] = sec_scene
         other = {}
         for mode in [m for m in ('f16x2', 'bf16x3', 'f32') if m != args.gemm]:
             eng.set_gemm_mode(mode)
             step(only=sec_scene)
             hip.PROFILE = []
-            d_o, rows_o = bracket(n_sec, only=sec_scene)
+            d_o, rows_o, _ = bracket(n_sec, only=sec_scene)
             pr = hip.PROFILE; hip.PROFILE = None
-            tag_of = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
-            ach, ms_o, nl_o, alg_o = gemm_roofline(pr, tag_of[mode])
+            ach, ms_o, nl_o, alg_o = gemm_roofline(pr, TAG_OF[mode])
             diffs = [float(np.abs(a.trans - b.trans).max()) for (_, a), (_, b) in zip(rows_def, rows_o) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()]
             other[mode] = {'dtype': DTYPE_OF[mode], 'value_on_secondary_scene': world * n_sec_pairs * n_sec / d_o if n_sec_pairs else None,
                            'ms_per_pass': 1e3 * d_o / n_sec, 'pairs_with_identical_transform_to_default': int(sum(1 for d in diffs if d == 0.0)),
                            'pairs_compared': len(diffs), 'max_abs_diff_of_transforms_vs_default': max(diffs or [0.0]),
                            'roofline': roofline_obj(mode, ach, ms_o, nl_o, None, alg_o)}
         eng.set_gemm_mode(args.gemm)
+        sec['value_default_on_secondary_scene'] = world * n_sec_pairs * n_sec / d_def if n_sec_pairs else None
         sec['other_gemm_modes'] = other
         eng.phase_ms = {}
         step(only=sec_scene)
         sec['phase_ms_one_synchronised_pass_of_secondary_scene'] = {k: round(v, 2) for k, v in eng.phase_ms.items()}
         eng.phase_ms = None
-        if args.workload != 'chunk' and world == 1:
-            # round 1's headline workload (16 clouds, 60 pairs: the benchmark's clouds:pairs ratio in one resident chunk), for continuity
-            cf, ck, _ = synth.make_scene_device(1000, 16, args.kpts, OVERLAP)
-            cp = [(str(a), str(b)) for a, b in synth.scene_pair_list(16, 60, 4242)]
-            for _ in range(2):
-                np.random.seed(7); eng.run_scene(cf, ck, cp)
-            torch.cuda.synchronize(); tc = time.perf_counter()
-            for _ in range(5):
-                np.random.seed(7); eng.run_scene(cf, ck, cp)
-            torch.cuda.synchronize()
-            sec['round1_chunk_workload_pairs_per_s'] = 60 * 5 / (time.perf_counter() - tc)
-            del cf, ck
+        if args.gemm == 'f16x2':
+            sec['f16x2_scale_headroom_bits'] = headroom_bits(eng, scenes[sec_scene][0][0])
+        if world == 1:
+            sec['rd_rm_leg'] = rd_rm_leg(args, cfg, gf, et)
 
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
-    tag_of = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
-    achieved, ms, n_launch, alg_bytes = gemm_roofline(prof, tag_of[args.gemm])
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r02_irrep_gemm_pmc.json')
-    if os.path.exists(pmc):                      # HBM bytes per launch from the rocprofv3 --pmc passes of this same command (same launch population)
-        j = json.load(open(pmc))
-        traffic = (j.get('hbm_bytes_per_launch') or {}).get(f'{args.workload}:{args.gemm}')
-
-    # ---- accuracy on the synthetic scenes (outside the timed region; the evaluator's own metric code) ----
-    rr = []
-    for s, r in rows:
-        gt = synth.pose_transform(scenes[s][2], r.id0, r.id1)
-        if np.isfinite(r.trans).all():
-            rd = compute_R_diff(r.trans[:3, :3], gt[:3, :3]); td = float(np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))))
-            rr.append(1 if (rd < 15 and td < 0.3) else 0)
-        else:
-            rr.append(0)
+    if hip is not None:
+        achieved, ms, n_launch, alg_bytes = gemm_roofline(prof, TAG_OF[args.gemm])
+        traffic = measured_traffic(args)
 
     if rank == 0:
         total_pairs = totals['pairs']
@@ -328,69 +475,159 @@ def main():
                               f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats); pairs sharded over the ranks by scene",
               'kitchen': f"3DMatch-kitchen-like scene: {totals['clouds']} clouds x {args.kpts} kpts, {total_pairs} pairs (mutual + yohoo, max_iter=1000)",
               'chunk': f"scene chunk per GPU: 16 clouds x {args.kpts} kpts, 60 pairs (mutual + yohoo, max_iter=1000)"}[args.workload]
-        mm_flop = float(np.sum(2.0 * args.kpts * args.kpts * 32)) * len(rows) * args.steps            # algorithmic: one N x N x 32 product per pair
-        rs_flop = float(np.sum(Hs * Ms * 27.0)) * args.steps
-        rs_bytes = float(np.sum(Ms * 56.0 + Hs * 96.0)) * args.steps
-        d2_bytes = float(np.sum(Hs * 15360.0)) * args.steps
+        devices = None
         out = {
             'metric': 'pair-registrations/sec', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': totals['scaling'],
-            'vs_baseline': None, 'dtype': DTYPE_OF[args.gemm] + ('' if args.dtype == 'fp32' else '; group features stored as bfloat16'), 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': ('stub' if STUB else DTYPE_OF[args.gemm] + ('' if args.dtype == 'fp32' else '; group features stored as bfloat16')),
+            'data': 'stub engine (host-side test of the launcher and the multi-rank control flow; no kernels ran)' if STUB else 'synthetic',
+            'value_all_local_transforms': all_value,
+            'accuracy': metrics,
             'config': {'workload': wl, 'pairs_per_step': total_pairs, 'clouds_per_step': totals['clouds'], 'parallelism': f'pairs-sharded x{world}',
                        'descriptor_dtype': args.dtype,
                        'pair_lists': ('chain (i, i+1) + pairs (i, j) drawn with probability ~ exp(-|i-j|/8): scan-sequence-like locality' if args.pair_lists == 'banded'
                                       else 'chain (i, i+1) + pairs drawn uniformly over all cloud pairs') if args.workload != 'chunk' else None,
                        'rank0_pairs_per_step': my_pairs, 'shard_plan': totals.get('plan'),
-                       'mean_matches_rank0': float(np.mean(Ms)) if len(Ms) else None, 'registration_recall_synthetic_rank0': float(np.mean(rr)) if rr else None,
-                       'local_transforms': 'only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M)',
+                       'cloud_extractions_per_rank': totals.get('extractions_per_rank'),
+                       'eqv_transfers_per_step': len(transfers), 'eqv_exchange': ('point-to-point send/recv of cut scenes\' extractor outputs (38.4 MB each), one grouped '
+                                                                                   'launch per step' if transfers else None),
+                       'mean_matches_rank0': float(np.mean(Ms)) if len(Ms) else None,
+                       'local_transforms': 'value: only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M, checked: '
+                                           'results_identical_to_all_local_transforms); value_all_local_transforms: every correspondence, as the reference '
+                                           f'computes them (same workload, {args.all_steps} timed steps)',
                        'kitchen_scene': ({'clouds': synth.THREEDMATCH_CLOUDS[0], 'pairs': synth.THREEDMATCH_PAIRS[0], 'ms_per_pass': float(np.mean(kitchen_ms)),
                                           'pairs_per_s': synth.THREEDMATCH_PAIRS[0] / (np.mean(kitchen_ms) * 1e-3),
                                           'note': 'BASELINE configs[1]: the kitchen scene alone, timed (synchronised) inside the same steps'} if kitchen_ms else None),
                        **sec},
-            'roofline': roofline_obj(args.gemm, achieved, ms, n_launch, traffic, alg_bytes),
+        }
+        if dist is not None:
+            out['config']['devices'] = 'every rank on GPU 0 (ROREG_BENCH_SHARED_GPU)' if os.environ.get('ROREG_BENCH_SHARED_GPU') else ('cpu (stub)' if STUB else list(range(world)))
+            out['config']['backend'] = args.backend
+        if hip is not None:
+            mm_flop = float(np.sum(2.0 * args.kpts * args.kpts * 32)) * len(rows) * args.steps            # algorithmic: one N x N x 32 product per pair
+            rs_flop = float(np.sum(Hs * Ms * 27.0)) * args.steps
+            rs_bytes = float(np.sum(Ms * 56.0 + Hs * 96.0)) * args.steps
+            d2_bytes = float(np.sum(Hs * 15360.0)) * args.steps
+            out['roofline'] = roofline_obj(args.gemm, achieved, ms, n_launch, traffic, alg_bytes)
             # the kernels north_star names, measured with HIP events on the launch stream in the same timed steps (rank 0)
-            'roofline_distance_gemm': None if not mm_n else {
+            out['roofline_distance_gemm'] = None if not mm_n else {
                 'kernel': 'mm_strip_kernel<false> + mm_strip_kernel<true> (5000 x 5000 x 32 descriptor distances of every pair of a scene, both search directions; '
                           'fp16 x 2 split MFMA bound under per-row scales + exact re-check; one workgroup per 128-row strip, column tiles streamed by LDS-DMA)',
                 'bound': 'mfma', 'unit': 'TFLOP/s', 'launch_pairs': mm_n, 'avg_ms': mm_ms / mm_n,
                 'algorithmic_tflops': mm_flop / (mm_ms * 1e-3) / 1e12, 'achieved': 6.0 * mm_flop / (mm_ms * 1e-3) / 1e12, 'peak': PEAK_BF16_MFMA_TFLOPS,
                 'frac': 6.0 * mm_flop / (mm_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                 'note': 'executed = 6 x algorithmic: two products (S.T^T in pass A for the row AND column minima, again in pass B for the candidate test) x '
-                        'three fp16 MFMAs per f32-accurate product (round 1: a third product T.S^T and six bf16 MFMAs each = 18 x, reported as 24 x).  With K = 32 '
-                        'the matrix cores are a small part of the kernel: the rest is the operand split and the min / candidate search over every one '
-                        'of the tile elements on the vector ALUs'},
-            'roofline_ransac': None if not rs_n else {
+                        'three fp16 MFMAs per f32-accurate product.  With K = 32 the matrix cores are a small part of the kernel: the rest is the operand '
+                        'split and the min / candidate search over every one of the tile elements on the vector ALUs'}
+            out['roofline_ransac'] = None if not rs_n else {
                 'kernel': 'ransac_score_batch_kernel (one wave per hypothesis over the pair\'s M correspondences, fp64, no FMA contraction: bit-exact masks)',
                 'bound': 'fp64-valu', 'unit': 'TFLOP/s', 'launches': rs_n, 'avg_ms': rs_ms / rs_n, 'achieved': rs_flop / (rs_ms * 1e-3) / 1e12,
                 'peak': PEAK_F64_VALU_TFLOPS, 'frac': rs_flop / (rs_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
                 'hbm': {'algorithmic_GBps': rs_bytes / (rs_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': rs_bytes / (rs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                        'note': 'M*56 + H*96 B per pair: the correspondences are re-read by every hypothesis from L2, the stage is not HBM-bound'}},
-            'roofline_des2r': None if not d2_n else {
+                        'note': 'M*56 + H*96 B per pair: the correspondences are re-read by every hypothesis from L2, the stage is not HBM-bound'}}
+            out['roofline_des2r'] = None if not d2_n else {
                 'kernel': 'des2r_irrep_batch_kernel (irrep-domain bound + exact re-check of near ties; M*15,360 algorithmic bytes)', 'bound': 'hbm', 'unit': 'GB/s', 'launches': d2_n, 'avg_ms': d2_ms / d2_n,
-                'achieved': d2_bytes / (d2_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': d2_bytes / (d2_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-            'transforms': None if not ft_n else {'kernel': 'ft_nonlin_kernel (all variants)', 'launches': ft_n, 'ms_per_step': ft_ms / args.steps},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            gf_np = {k: v.numpy() for k, v in gf_sd.items()}; et_np = {k: v.numpy() for k, v in et_sd.items()}
+                'achieved': d2_bytes / (d2_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'frac': d2_bytes / (d2_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            out['transforms'] = None if not ft_n else {'kernel': 'ft_nonlin_kernel (all variants)', 'launches': ft_n, 'ms_per_step': ft_ms / args.steps}
+        if hip is not None and not args.no_cpu_baseline and world == 1:
             s0 = sorted(scenes)[0]
-            t, threads = cpu_baseline((gf_np, et_np), scenes[s0][0][0].cpu().numpy(), scenes[s0][0][1].cpu().numpy())
-            M = float(np.mean(Ms)); H = min(M, 1000)
-            per_cloud = t['gf_per_kpt'] * args.kpts
-            tail = H * t['ransac_per_hyp'] * (M / 3000.0)
-            per_pair_all = t['mutual_per_pair'] + M * (t['des2r_per_corr'] + t['et_per_corr']) + tail          # the reference: every correspondence
-            per_pair_drawn = t['mutual_per_pair'] + H * (t['des2r_per_corr'] + t['et_per_corr']) + tail        # only the drawn hypotheses (what `value` does)
-            sec_all = totals['clouds'] * per_cloud + total_pairs * per_pair_all
-            sec_drawn = totals['clouds'] * per_cloud + total_pairs * per_pair_drawn
-            out['cpu_baseline'] = {'value': total_pairs / sec_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-                                   'sample': 'oracle/ref_numpy.py on this host: GF on 1024 kpts, mutual on 3500x3500 (scaled N^2), Des2R on 1024, '
-                                             'ET on 768 correspondences, RANSAC scoring on 200 hypotheses x 3000; scaled to the step workload with the '
-                                             'local transform of EVERY correspondence, as the reference computes it (pair with value_all_local_transforms)',
-                                   'value_if_only_drawn_hypotheses': total_pairs / sec_drawn,
-                                   'components_s': {'gf_per_cloud': per_cloud, 'per_pair_all_local_transforms': per_pair_all,
-                                                    'per_pair_drawn_hypotheses_only': per_pair_drawn}}
-        print(json.dumps(out))
+            f0 = scenes[s0][0][0].float().cpu().numpy(); f1 = scenes[s0][0][1].float().cpu().numpy()
+            M = float(np.mean(Ms))
+            threads = torch.get_num_threads()
+            t_t = cpu_baseline_torch((gf_sd, et_sd), f0, f1)
+            v_all, v_drawn, comp = scale_baseline(t_t, M, totals['clouds'], total_pairs)
+            out['cpu_baseline'] = {'value': v_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+                                   'sample': 'oracle/ref_torch.py (the reference\'s own torch CPU operators, torch.set_num_threads = all host threads) on this host: '
+                                             'GF on one bs_GF batch of 1250 kpts, mutual NN on the full 5000 x 5000 pair, Des2R on 1000 and ET on one bs_ET batch of '
+                                             '1000 correspondences, RANSAC scoring (numpy, as in the reference) on 200 hypotheses x 3000; scaled to the step workload '
+                                             'with the local transform of EVERY correspondence, as the reference computes it (pair with value_all_local_transforms)',
+                                   'value_if_only_drawn_hypotheses': v_drawn, 'components_s': comp}
+            t_n = cpu_baseline_numpy(({k: v.numpy() for k, v in gf_sd.items()}, {k: v.numpy() for k, v in et_sd.items()}), f0, f1)
+            v_all, v_drawn, comp = scale_baseline(t_n, M, totals['clouds'], total_pairs)
+            out['cpu_baseline_numpy_oracle'] = {'value': v_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+                                                'sample': 'oracle/ref_numpy.py (the parity oracle; BLAS-threaded matmuls, single-threaded gathers): GF on 512 kpts, '
+                                                          'mutual on 2500 x 2500 (scaled N^2), Des2R on 512, ET on 384 correspondences, RANSAC scoring on 200 x 3000',
+                                                'value_if_only_drawn_hypotheses': v_drawn, 'components_s': comp}
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        barrier()
         dist.destroy_process_group()
+
+
+def headroom_bits(eng, feats):
+    """How far the fp16 x 2 mode's per-keypoint block-scale BOUND sits above the keypoint's true coefficient maximum, per GEMM input of the
+    extractor, on one cloud: log2(bound / max|coef|) min / mean / max -- the bits of the 22 the conservative bound gives away."""
+    net = eng.gf.PartI_net
+    try:
+        rep = net._fourier.scale_headroom(feats.float())
+    except Exception as e:                                                  # diagnostics only
+        return {'error': f'{type(e).__name__}: {e}'}
+    return rep
+
+
+def rd_rm_leg(args, cfg0, gf, et):
+    """BASELINE configs[3] / [4] path on one low-overlap scene chunk: detector (RD) -> NMS sampling -> rotation-coherence matcher (RM) at keynum
+    2500 -> one-shot estimator on the top-`match_n` matches; float32 and bfloat16 descriptor storage.  Rooflines of the two kernels that dominate
+    Match_ot measured with the library's HIP-event brackets: the Sinkhorn iterations (HBM: one pass over every pair's (m+1) x (n+1) float32
+    coupling matrix per iteration) and roreg_topk_dot (f32 vector FMA: 2 x 32 x m x n per searched direction)."""
+    from roreg_amd import hip, synth
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+    n_clouds, n_pairs, overlap = 24, 100, 0.2
+    cfg = default_config(keynum=2500, max_iter=1000, ET='yohoo', RD=True, RM=True)
+    rd = name2network['RD_test'](cfg); rm = name2network['RM_test'](cfg)
+    weights = 'random-init'
+    gdir = os.path.join(ROOT, 'tests', 'golden')
+    if os.path.exists(f'{gdir}/weights_RD.npz') and os.path.exists(f'{gdir}/weights_RM.npz'):
+        rd.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(f'{gdir}/weights_RD.npz').items()})
+        rm.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(f'{gdir}/weights_RM.npz').items()})
+        weights = 'the reference\'s shipped RD / RM checkpoints (tests/golden/weights_R{D,M}.npz)'
+    else:
+        synth.seeded_state_dict(rd, 303); synth.seeded_state_dict(rm, 404)
+    feats, keys, poses = synth.make_scene_device(1400, n_clouds, args.kpts, overlap)
+    pairs = [(str(a), str(b)) for a, b in synth.scene_pair_list(n_clouds, n_pairs, 4343, locality=8.0)]
+    seeds = [(11 + zlib.crc32(f'lo:{a}:{b}'.encode())) % (2 ** 32) for a, b in pairs]
+    out = {'workload': f'{n_clouds} clouds x {args.kpts} kpts, {n_pairs} pairs, overlap {overlap} (3DLoMatch-like), --RD --RM --ET yohoo --keynum 2500 --match_n {cfg.match_n}',
+           'weights': weights}
+    for dtype in ('fp32', 'bf16'):
+        eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
+        eng.set_gemm_mode(args.gemm); eng.set_descriptor_dtype(dtype)
+        for _ in range(2):
+            res = eng.run_scene(feats, keys, pairs, pair_seeds=seeds)
+        hip.profile_enable(True); hip.WORK = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n_rep = 3
+        for _ in range(n_rep):
+            res = eng.run_scene(feats, keys, pairs, pair_seeds=seeds)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        sk_ms, sk_n = hip.profile_read('sinkhorn'); tk_ms, tk_n = hip.profile_read('topk_dot')
+        work = hip.WORK; hip.WORK = None; hip.profile_enable(False)
+        from roreg_amd.utils.r_eval import compute_R_diff
+        ok = []
+        for r in res:
+            gt = synth.pose_transform(poses, r.id0, r.id1)
+            ok.append(bool(np.isfinite(r.trans).all() and compute_R_diff(r.trans[:3, :3], gt[:3, :3]) < 15 and
+                           np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))) < 0.3))
+        leg = {'pairs_per_s': n_pairs * n_rep / dt, 'ms_per_pass': 1e3 * dt / n_rep, 'mean_matches': float(np.mean([r.n_match for r in res])),
+               'registration_recall_pointdsc': float(np.mean(ok))}
+        if sk_n:
+            gbs = work.get('sinkhorn_bytes', 0.0) / (sk_ms * 1e-3) / 1e9
+            leg['roofline_sinkhorn'] = {'kernel': 'ot_fused_pass_kernel + ot_col_merge_kernel (100 iterations per stacked group of pairs; row log-sum-exp and column sums from ONE '
+                                                  'read of the coupling matrix per iteration)', 'bound': 'hbm', 'unit': 'GB/s', 'launch_groups': sk_n, 'avg_ms': sk_ms / sk_n,
+                                        'achieved': gbs, 'peak': PEAK_HBM_GBS, 'frac': gbs / PEAK_HBM_GBS,
+                                        'algorithmic_bytes': 'iterations x sum over pairs of 4 (m+1)(n+1): the kernel\'s one pass per iteration; the reference\'s two '
+                                                             'logsumexp passes per iteration (SURVEY 8d: 200 (N+1)^2 4 B) would be twice this figure',
+                                        'note': 'a stacked group\'s matrices (32 pairs x 25 MB) exceed the 256 MB Infinity Cache: HBM-bound'}
+        if tk_n:
+            tf = work.get('topk_flop', 0.0) / (tk_ms * 1e-3) / 1e12
+            leg['roofline_topk_dot'] = {'kernel': 'topk_dot_kernel + topk_merge_kernel (k = 16 / 8 / 1 best dot products per row, never materialising the m x n score matrix; '
+                                                  'replaces score_mat + full argsort, network/rot_coh_match.py:8-12,34-45)', 'bound': 'valu-f32', 'unit': 'TFLOP/s', 'launches': tk_n,
+                                        'avg_ms': tk_ms / tk_n, 'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': tf / PEAK_F32_MFMA_TFLOPS,
+                                        'note': '2 x 32 x m x n flop per search on the f32 vector pipe (157.3 TFLOP/s FMA peak); the sorted k-list insertions are extra VALU work'}
+        out[dtype] = leg
+        del eng
+    return out
 
 
 if __name__ == '__main__':

@@ -420,7 +420,9 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
  * While enabled, the library brackets selected launches with HIP events recorded ON THE LAUNCH STREAM; roreg_profile_read synchronises
  * on them and returns the summed duration and the number of brackets of a slot:
  *   0 = the two mm_tile_kernel passes of roreg_mutual_match_batch (the descriptor distance matrix on the matrix cores),
- *   1 = ransac_score_batch_kernel of roreg_ransac_batch, 2 = des2r_batch_kernel of roreg_lt_prepare_batch, 3 = roreg_ft_nonlin.
+ *   1 = ransac_score_batch_kernel of roreg_ransac_batch, 2 = des2r_batch_kernel of roreg_lt_prepare_batch, 3 = roreg_ft_nonlin,
+ *   4 = the `iters` Sinkhorn iterations of roreg_sinkhorn_batch (one fused pass over every pair's coupling matrix + column merge each),
+ *   5 = roreg_topk_dot (slice search + merge).
  * roreg_profile_enable(1) clears earlier records; (0) stops recording. */
 int roreg_profile_enable(int on);
 int roreg_profile_read(int slot, double *total_ms, int *launches);

@@ -46,7 +46,7 @@ void launch_des2r_batch(const LtTask *tasks, int n_tasks, int max_n, int64_t *dr
 bool des2r_tables_ready();
 
 // Optional per-kernel timing (roreg_profile_enable): HIP events recorded on the launch stream around selected launches.
-enum ProfSlot { PROF_MM_TILE = 0, PROF_RANSAC_SCORE = 1, PROF_DES2R = 2, PROF_FT_NONLIN = 3, PROF_N = 4 };
+enum ProfSlot { PROF_MM_TILE = 0, PROF_RANSAC_SCORE = 1, PROF_DES2R = 2, PROF_FT_NONLIN = 3, PROF_SINKHORN = 4, PROF_TOPK = 5, PROF_N = 6 };
 bool prof_on();
 void prof_begin(int slot, hipStream_t s);
 void prof_end(int slot, hipStream_t s);

@@ -817,6 +817,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     int *pi = reinterpret_cast<int *>(ws + (size_t)slices * m * k);
     hipStream_t s = roreg::as_stream(stream);
     const int gm = (m + 255) / 256;
+    roreg::ProfScope prof(roreg::PROF_TOPK, s);
 #define RM_TOPK(KK)                                                                                                                  \
     hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
     hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
@@ -1062,6 +1063,8 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
     for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent
     const int nv = (ldz + 1023) / 1024;                  // float4 pieces of a row per thread
     const dim3 gp((max_m + 1 + OT_RB - 1) / OT_RB, n_seg), gm((max_n + 1 + 63) / 64, n_seg);
+    {
+    roreg::ProfScope prof(roreg::PROF_SINKHORN, s);      // (the iterations only: `iters` passes over every pair's coupling matrix)
     for (int it = 0; it < iters; ++it) {
         if (nv > 8) {                                    // rows beyond 8192 columns: the two-matrix passes
             hipLaunchKernelGGL(row_lse_kernel, dim3((max_m + 4) / 4, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, 0.f, 0.f, u, rows);
@@ -1075,6 +1078,7 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
         }
 #undef OT_PASS
         hipLaunchKernelGGL(ot_col_merge_kernel, gm, dim3(256), 0, s, part, pstride, ldz, v, cols, Z0T, ldt, u);
+    }
     }
     hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
     hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);

@@ -165,24 +165,30 @@ def unpack_rows(table):
     return out
 
 
-def gather_table(local, device=None):
-    """all_gather of ragged [n_r, ROW] float64 tables -> [sum n_r, ROW] on every rank (rank order)."""
+def gather_table(local, device=None, counts=None):
+    """all_gather of ragged [n_r, ROW] float64 tables -> [sum n_r, ROW] on every rank (rank order).
+    counts: the number of rows of every rank when it is known beforehand (it is: every rank derives the same shard plan) -- then this is
+    ONE collective; without it the sizes are exchanged first."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return np.asarray(local, np.float64).reshape(-1, ROW)
     world = dist.get_world_size()
     dev = device if device is not None else ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
-    n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        counts = [int(c.item()) for c in sizes]
+    elif len(local) != counts[dist.get_rank()]:
+        raise ValueError(f'gather_table: rank {dist.get_rank()} holds {len(local)} rows, the plan says {counts[dist.get_rank()]}')
     mx = max(max(counts), 1)
     buf = torch.zeros((mx, ROW), dtype=torch.float64, device=dev)
     if len(local):
         buf[:len(local)] = torch.as_tensor(np.asarray(local, np.float64), device=dev)
-    outs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf)
-    return np.concatenate([o[:c].cpu().numpy() for o, c in zip(outs, counts)], 0).reshape(-1, ROW)
+    out = torch.empty((world, mx, ROW), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, buf) if dist.get_backend() == 'nccl' else dist.all_gather(list(out.unbind(0)), buf)
+    out = out.cpu().numpy()
+    return np.concatenate([out[r, :c] for r, c in enumerate(counts)], 0).reshape(-1, ROW)
 
 
 # ---- cut scenes: every cloud is extracted once, its `eqv` travels point to point ------------------------------------------------------

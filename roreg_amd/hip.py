@@ -275,7 +275,11 @@ def _conv_wsplit2(layer):
 PROFILE = None
 
 
-PROFILE_SLOTS = {'mm_tile': 0, 'ransac_score': 1, 'des2r': 2, 'ft_nonlin': 3}
+# bench.py sets this to a dict to collect the algorithmic work of the profiled rotation-coherence-matcher kernels:
+# 'sinkhorn_bytes' (iterations x bytes of every pair's coupling matrix, ONE pass each), 'topk_flop' (2 x 32 x m x n per searched pair)
+WORK = None
+
+PROFILE_SLOTS = {'mm_tile': 0, 'ransac_score': 1, 'des2r': 2, 'ft_nonlin': 3, 'sinkhorn': 4, 'topk_dot': 5}
 
 
 def profile_enable(on=True):
@@ -859,6 +863,9 @@ def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
         seg = (None, None, 1, m, n)
     _check(lib().roreg_topk_dot(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, *seg, _stream()),
            'roreg_topk_dot')
+    if WORK is not None:
+        pairs = float(m) * n if segA is None else float(np.sum(np.diff(segA.host).astype(np.float64) * np.diff(segB.host)))
+        WORK['topk_flop'] = WORK.get('topk_flop', 0.0) + 2.0 * A.shape[1] * pairs
     return (idx, val) if want_val else idx
 
 
@@ -970,6 +977,9 @@ def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters):
                                       _ptr(seg_tgt.dev, torch.int32), seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, _ptr(cdev), seg_src.n,
                                       float(alpha), int(iters), _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, _stream()),
            'roreg_sinkhorn_batch')
+    if WORK is not None:
+        cells = float(np.sum((np.diff(seg_src.host).astype(np.float64) + 1) * (np.diff(seg_tgt.host) + 1)))
+        WORK['sinkhorn_bytes'] = WORK.get('sinkhorn_bytes', 0.0) + 4.0 * cells * int(iters)
     return m0, m1, s0, s1
 
 

@@ -120,6 +120,34 @@ class FourierGF:
         return ft(32, coef_in=T3, bias=self.l_out.bias, resid_spatial=x, spatial_out=True)
 
 
+    def scale_headroom(self, x):
+        """Diagnostics for the fp16 x 2 mode (bench.py `f16x2_scale_headroom_bits`): per GEMM input of the extractor, how many binades the
+        per-keypoint block-scale BOUND (row_bound / the previous GEMM's propagated next_bound) sits above the keypoint's true coefficient
+        maximum -- log2(bound / max|coef|), min / mean / max over the keypoints of x [B,32,60].  The hi + lo fp16 split resolves 22 bits
+        below the bound, so this is the precision the conservative bound gives away relative to the data."""
+        self._plan(); self._plan_bounds()
+        hip.ensure_fourier()
+        B = x.shape[0]
+        out = {}
+
+        def report(name, bound, coefs_f32, C):
+            actual = hip.pack_coefs_f16x2(coefs_f32, C, B)[1][:B]
+            bits = torch.log2(bound[:B].double() / actual.double().clamp_min(1e-300))
+            out[name] = {'min': round(float(bits.min()), 2), 'mean': round(float(bits.mean()), 2), 'max': round(float(bits.max()), 2)}
+        b0 = hip.row_bound(x)
+        report('gemm_32_256_input', b0, hip.ft_nonlin(B, 32, x_spatial=x, split=True), 32)
+        X0 = hip.ft_nonlin(B, 32, x_spatial=x, split='f16x2', out_bound=b0)
+        T0, b1 = hip.irrep_gemm(X0, None, 32, 256, B, f16x2=self.l_in.wsplit2, x_bound=b0, next_bound=self.nb_1)
+        report('gemm_256_512_input', b1, hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=True), 256)
+        X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split='f16x2', out_bound=b1)
+        T1, b2 = hip.irrep_gemm(X1, None, 256, 512, B, f16x2=self.l_1.wsplit2, x_bound=b1, next_bound=self.nb_2)
+        report('gemm_512_256_input', b2, hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split=True), 512)
+        X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split='f16x2', out_bound=b2)
+        T2, b3 = hip.irrep_gemm(X2, None, 512, 256, B, f16x2=self.l_2.wsplit2, x_bound=b2, next_bound=self.nb_3, add=T0)
+        report('gemm_256_32_input', b3, hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3, split=True), 256)
+        return out
+
+
 class FourierRD:
     """The detector's Residual_Comb_Conv(32, 64, 16) with its conv short cut (network/rot_detect.py:39, network/ops.py:22-64) in the
     irrep domain:

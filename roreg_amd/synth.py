@@ -306,6 +306,13 @@ def make_scene_device(seed, n_clouds, n_kpts=5000, overlap=0.6, feat_noise=0.05,
     return feats, keys, poses
 
 
+def scene_poses(seed, n_clouds):
+    """The poses [(group element, translation)] make_scene_device(seed, n_clouds, ...) gives its clouds -- they come from the numpy generator
+    alone, so a rank that does not hold a scene can still rebuild its ground truth (bench.py's accuracy figures on rank 0)."""
+    rng = np.random.default_rng(int(seed))
+    return [(0, np.zeros(3)) if c == 0 else (int(rng.integers(0, G)), rng.uniform(-0.5, 0.5, 3)) for c in range(n_clouds)]
+
+
 def pose_transform(poses, id0, id1):
     """[3,4] float64 ground truth x_0 = R x_1 + t of two clouds of a make_scene_device() scene."""
     R = tables().R

@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: the C-ABI surface, config defaults, dataset parsing, sharding + gloo gather."""
+import json
 import os
 import re
 import socket
@@ -347,6 +348,69 @@ def test_evaluate_does_not_depend_on_the_number_of_ranks(tmp_path):
     for k in one.files:
         if k != 'split':
             assert np.array_equal(one[k], two[k]), k
+
+
+def _bench_line(argv, env_extra, timeout=600):
+    env = dict(os.environ, OMP_NUM_THREADS='1', ROREG_BENCH_ENGINE='tests._bench_stub:make', PYTHONPATH=ROOT, **env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_starts_n_ranks_and_gathers_one_table():
+    """`python bench.py --gpus 3` with no torch.distributed environment must itself start 3 ranks (the driver's command line), print ONE
+    JSON line with n_gpus = 3, shard the pairs, ship the cut scene's extractor outputs between the ranks and gather one result table.
+    Host logic only: the engine is the stand-in of tests/_bench_stub.py over gloo.  The accuracy block (FMR / IR / RR over all ranks) and
+    the result table must not depend on the number of ranks nor on whether the exchange is used."""
+    args = ['--steps', '1', '--warmup', '1', '--kpts', '24', '--all-steps', '1']
+    one = _bench_line(args + ['--gpus', '1'], {})
+    assert one['n_gpus'] == 1 and one['config']['eqv_transfers_per_step'] == 0
+    two = _bench_line(args + ['--gpus', '3'], {})                            # (3 ranks: the smallest world size whose plan cuts a scene)
+    assert two['n_gpus'] == 3 and two['scaling'] == 'strong' and two['config']['pairs_per_step'] == 1623
+    assert two['config']['eqv_transfers_per_step'] > 0                       # a scene was cut and its clouds travelled
+    assert sum(two['config']['cloud_extractions_per_rank']) == 433           # every cloud extracted exactly once
+    assert len(two['config']['shard_plan']) == 3 and two['config']['backend'] == 'gloo'
+    assert two['accuracy'] == one['accuracy'] and one['accuracy']['pairs'] == 1623
+    plain = _bench_line(args + ['--gpus', '3', '--no-exchange'], {})
+    assert plain['config']['eqv_transfers_per_step'] == 0 and sum(plain['config']['cloud_extractions_per_rank']) > 433
+    assert plain['accuracy'] == one['accuracy']
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    env = dict(os.environ, ROREG_BENCH_ENGINE='tests._bench_stub:make', PYTHONPATH=ROOT, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--kpts', '24'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert p.returncode != 0 and b'--gpus 2' in p.stderr
+
+
+def test_exchange_plan_extracts_every_cloud_once():
+    """Cut scenes: with the extractor-output exchange the ranks of an 8-rank plan together extract exactly the benchmark's 433 clouds
+    (the reference extracts each cloud once, test/extractor.py:47), for both kinds of pair lists; without it 491 / 548.  Every transfer
+    goes from the cloud's owner to a rank whose ranges touch it, and the plan's modelled efficiency rises."""
+    from roreg_amd import synth
+    from roreg_amd.distributed import shard_scenes, exchange_plan, extractions_per_rank
+    names = synth.THREEDMATCH_SCENES
+    clouds = dict(zip(names, synth.THREEDMATCH_CLOUDS)); npairs = dict(zip(names, synth.THREEDMATCH_PAIRS))
+    cost1 = sum(npairs.values()) + 7.0 * sum(clouds.values())
+    for locality, floor in ((None, 0.93), (8.0, 0.95)):
+        lists = {s: synth.scene_pair_list(clouds[s], npairs[s], 900 + i, locality=locality) for i, s in enumerate(names)}
+        for world in (2, 4, 8):
+            plan = shard_scenes(npairs, world, clouds, pair_lists=lists, exchange=True)
+            owner, transfers = exchange_plan(plan, lists)
+            assert sum(extractions_per_rank(plan, lists)) == 433
+            touched = [{(s, int(i)) for s, a, b in r for pr in lists[s][a:b] for i in pr} for r in plan]
+            for s, i, src, dst in transfers:
+                assert src != dst and owner[(s, i)] == src and (s, i) in touched[src] and (s, i) in touched[dst]
+            need = {(c, r) for r in range(world) for c in touched[r] if owner.get(c, r) != r}
+            assert need == {((s, i), dst) for s, i, _, dst in transfers}         # exactly what is missing arrives, once
+            ex = extractions_per_rank(plan, lists)
+            loads = [sum(b - a for _, a, b in r) + 7.0 * ex[q] + 0.5 * sum(1 for t in transfers if t[3] == q) for q, r in enumerate(plan)]
+            if world == 8:
+                assert cost1 / (world * max(loads)) >= floor, (locality, cost1 / (world * max(loads)))
+        old = shard_scenes(npairs, 8, clouds, pair_lists=lists)
+        assert sum(extractions_per_rank(old, lists, exchange=False)) > 460
 
 
 def test_rr_cal_benchmark_matches_reference(tmp_path):

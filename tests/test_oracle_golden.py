@@ -113,6 +113,33 @@ def test_ransac_pieces_match_reference():
     assert np.allclose(r, z['single_refined'], atol=1e-12)
 
 
+def test_torch_restatement_matches_reference(group):
+    """oracle/ref_torch.py (the reference's own torch CPU operators, multi-threaded: bench.py's cpu_baseline) against the reference's
+    vectors: GF and ET outputs, Des2R indices, nearest neighbours and mutual matches."""
+    import torch
+    from oracle import ref_torch as OT
+    t = lambda sd: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    z = load_golden('gf_forward')
+    out = OT.gf_forward(torch.from_numpy(z['x']), t(seeded_sd('GF_test', int(z['seed']))), group.Nei)
+    assert np.abs(out['eqv'].numpy() - z['eqv']).max() < 1e-5 and np.abs(out['inv'].numpy() - z['inv']).max() < 1e-5
+    z = load_golden('et_forward')
+    batch = {k: torch.from_numpy(z[k]) for k in ['before_eqv0', 'before_eqv1', 'after_eqv0', 'after_eqv1', 'pre_idx']}
+    q = OT.et_forward(batch, t(seeded_sd('ET_test', int(z['seed']))), group.Nei, group.P)
+    assert np.abs(q.numpy() - z['quaternion']).max() < 1e-4
+    z = load_golden('des2r')
+    assert np.array_equal(OT.des2r(torch.from_numpy(z['d1']), torch.from_numpy(z['d2']), group.P).numpy(), z['idx'])
+    z = load_golden('pipeline_mutual_yohoo')
+    np.random.seed(1234)                                          # the matcher stage's generator calls (matcher.py:83-88), first pair
+    s0 = np.arange(z['yoho_0'].shape[0]); s1 = np.arange(z['yoho_1'].shape[0])
+    np.random.shuffle(s0); np.random.shuffle(s1)
+    keynum = int(z['keynum'])
+    got = OT.mutual_match(torch.from_numpy(z['yoho_0']), torch.from_numpy(z['yoho_1']), s0[:keynum], s1[:keynum])
+    assert np.array_equal(got, z['match_0_1'])
+    zr = load_golden('ransac')
+    for h in range(5):
+        assert OT.overlap_cal(zr['ones_k0'], zr['ones_k1'], zr['ones_Trans'][h], zr['ones_scores'], 0.1) == zr['ones_overlap'][h]
+
+
 def test_numpy_pairwise_model():
     """The float32 reduction order the RANSAC kernels rebuild for float32 match scores (csrc/ransac.hip) IS numpy's: the written-out model
     (oracle np_sum_f32_model: 8 strided partials + fixed tree per <= 128-element leaf, halving at multiples of 8, 8192-element chunks) equals
