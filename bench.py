@@ -206,8 +206,8 @@ def scale_baseline(t, M, clouds, pairs):
 
 
 DTYPE_OF = {'f16x2': 'f32 (every f32 operand enters the fp16 matrix cores as hi + lo fp16 under a per-keypoint power-of-two block scale: <= 22 significant bits '
-                     'relative to a CONSERVATIVE per-keypoint bound -- the bound sits 2^4..2^9 above the keypoint\'s true coefficient maximum (config.'
-                     'f16x2_scale_headroom_bits), i.e. 13..18 bits relative to the data plus the lo piece\'s absolute floor of 2^-39 of the bound; 3 cross '
+                     'relative to a CONSERVATIVE per-keypoint bound -- measured on the extractor: the bound sits 2^2..2^6 above the keypoint\'s true coefficient '
+                     'maximum (config.f16x2_scale_headroom_bits, this run), i.e. 16..20 bits relative to the data plus the lo piece\'s absolute floor of 2^-39 of the bound; 3 cross '
                      'products, f32 accumulate; measured GEMM error 7e-7..9e-7 of the output scale vs 1.5e-6..2e-6 for the f32-input MFMA kernel; '
                      'results independent of batch composition and rank count); f64 estimator',
             'bf16x3': 'f32 (f32-accurate: every f32 operand as 3 bf16 pieces = 24 bits, 6 cross products, f32 accumulate); f64 estimator',

@@ -179,9 +179,9 @@ def test_config4_low_overlap_with_detector_and_rotation_coherence_matcher(group)
 
 def test_config5_outdoor_scale_scene(group):
     """BASELINE config 5 shape (ETH-like: 30 m extent, 5 cm coordinate noise, ransac_ird 0.5 as README.md:175 prescribes) at 5000
-    keypoints through the engine at full float32 precision: every pair registers within the ETH success bounds and far inside them on
-    this noise level.  (The reduced-precision descriptor storage the config names is not offered: correspondence indices would no
-    longer be bit-exact)"""
+    keypoints through the engine with float32 descriptor storage: every pair registers within the ETH success bounds and far inside them
+    on this noise level.  (The bfloat16 descriptor storage the config names is `--dtype bf16`; the same scene in that storage type, with
+    parity defined on the rounded tensors, is tests/test_hip_bf16.py::test_config5_outdoor_scene_with_bf16_descriptors.)"""
     from roreg_amd.engine import RegistrationEngine
     from roreg_amd.network import name2network
     cfg = default_config(keynum=5000, max_iter=1000, ET='yohoo', ransac_ird=0.5)

@@ -184,9 +184,10 @@ def test_full_match_ot_stacked_path(rm_net):
 @pytest.mark.parametrize('mode', MODES)
 def test_full_pipeline_vs_reference(tmp_path, mode, monkeypatch):
     """GF -> mutual -> Des2R/ET -> one-shot RANSAC.  The extractor's output agrees with the reference's to 1e-5 (sampled rows); downstream,
-    correspondences are decided by float32 distances between those descriptors, so a different-but-equally-valid float32 evaluation may
-    flip a near tie: the bar is that almost all match rows are identical and the final transform agrees within 1e-4.  The per-mode counts are
-    printed (pytest -s) and recorded in DESIGN.md."""
+    correspondences are decided by float32 distances between those descriptors, so a different-but-equally-valid float32 evaluation COULD
+    flip a near tie -- it does not on this fixture: in every matrix-core mode all three match lists (9597 rows) are identical to the
+    reference's, every pair has the reference's recalltime and its transform to 1e-8, and the test asserts exactly that, so a regression
+    to "almost identical" fails."""
     from roreg_amd import hip
     from roreg_amd.test import name2extractor, name2matcher, name2estimator, _cache
     z = load_golden('full_pipeline')
@@ -218,7 +219,7 @@ def test_full_pipeline_vs_reference(tmp_path, mode, monkeypatch):
         same_rows += len(got & ref); total_rows += len(got | ref)
         identical_lists += int(np.array_equal(m, want))
     print(f'[{mode}] match rows identical to the reference: {same_rows}/{total_rows}; identical lists: {identical_lists}/3')
-    assert same_rows >= 0.999 * total_rows
+    assert same_rows == total_rows and identical_lists == len(ds.pair_ids), (mode, same_rows, total_rows, identical_lists)
     np.random.seed(4321)
     est = name2estimator['yohoo'](cfg)
     est.localT_extractor.network.gemm = mode
@@ -228,8 +229,78 @@ def test_full_pipeline_vs_reference(tmp_path, mode, monkeypatch):
         r = np.load(f'{md}/yohoo/1000iters/{a}-{b}.npz')
         d = np.abs(r['trans'] - z[f'trans_{a}_{b}']).max()
         exact += int(int(r['recalltime']) == int(z[f'recall_{a}_{b}']) and d < 1e-8)
-        assert d < 1e-4, (a, b, d)
+        assert int(r['recalltime']) == int(z[f'recall_{a}_{b}']) and d < 1e-8, (mode, a, b, int(r['recalltime']), int(z[f'recall_{a}_{b}']), d)
     print(f'[{mode}] pairs with the reference\'s recalltime and transform (1e-8): {exact}/3')
+
+
+# ---- BASELINE config 4's chain at full size against the reference's own end-to-end run ------------------------------------------------
+@pytest.mark.parametrize('tag', ['full_pipeline_rd_rm', 'full_pipeline_rd_rm_o60'])
+def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
+    """GF -> detector (shipped RD weights) -> rank scores -> NMS sampling of 2500 -> yoho_mat (shipped RM weights) -> one-shot RANSAC on the
+    best-scored half (test/detector.py:26-47, test/matcher.py:11-42,152-210, test/estimator.py:405-443) on a 5000-keypoint pair at 20 % overlap
+    (and one at 60 %), end to end from the input features, against the reference's run of the same chain.
+    The detector's saliency is a ~3e-3 standard deviation of 60 correlations of magnitude ~60, so float32 noise moves a few ranks (<= 30
+    places of 5000, test_full_detector_on_a_whole_cloud) -- which is why the chain is ALSO checked stage by stage on the reference's own
+    intermediate outputs, where every index list must be identical: NMS sample from the reference's ranks; matches from the reference's
+    samples; Des2R index, recalltime and transform from the reference's matches."""
+    from roreg_amd import hip
+    from roreg_amd.test import name2extractor, name2detector, name2matcher, name2estimator, _cache
+    from roreg_amd.test.matcher import NMS_sample
+    z = load_golden(tag)
+    root = str(tmp_path)
+    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=2500,
+                         bs_GF=1250, bs_ET=1000, ET='yohoo', RD=True, RM=True, match_n=0.5)
+    _write_ckpts(root, cfg)
+    for d in ['RD', 'RM']:
+        os.makedirs(f'{root}/ckpt/{d}', exist_ok=True)
+        torch.save({'best_para': 0, 'network_state_dict': {k: torch.from_numpy(v) for k, v in load_golden(f'weights_{d}').items()}}, f'{root}/ckpt/{d}/model_best.pth')
+    ds = synth.make_scene(int(z['scene_seed']), n_clouds=2, n_kpts=5000, overlap=float(z['overlap']), coord_noise=0.005, name='synth/scene0', portable=True)
+    ds.write_inputs(cfg.output_cache_fn)
+    base = f'{cfg.output_cache_fn}/{ds.name}'
+    md = f'{base}/match_2500'
+    _cache.clear()
+    # ---- end to end from the input features ----
+    name2extractor['yoho_des'](cfg).run(ds)
+    for pc in ds.pc_ids:
+        assert np.abs(np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')[::250] - z[f'yoho_sample_{pc}']).max() < 1e-5
+    name2detector['yoho_det'](cfg).run(ds)
+    moved, same_nms = [], []
+    for pc in ds.pc_ids:
+        det = np.load(f'{base}/det_score/{pc}.npy')
+        moved.append(np.abs(np.rint(det * 5000) - z[f'det_rank_{pc}']).max())
+        mine = NMS_sample(2500, 5).sample(ds.get_kps(pc), det)
+        same_nms.append(len(set(mine.tolist()) & set(z[f'nms_{pc}'].astype(np.int64).tolist())))
+    np.random.seed(1234)
+    name2matcher['yoho_mat'](cfg).run(ds, 2500)
+    np.random.seed(4321)
+    name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
+    m = np.load(f'{md}/0-1.npy'); want_m = z['match_0_1'].astype(np.int64)
+    r = np.load(f'{md}/yohoo/1000iters/0-1.npz')
+    rows_same = len({tuple(x) for x in m} & {tuple(x) for x in want_m})
+    e2e_identical = np.array_equal(m, want_m) and int(r['recalltime']) == int(z['recall_0_1'])
+    print(f'[{tag}] end to end: detector ranks moved <= {max(moved):.0f} places; NMS samples shared {same_nms} of 2500; match rows shared {rows_same} of '
+          f'{len(want_m)} (mine {len(m)}); recalltime {int(r["recalltime"])} vs {int(z["recall_0_1"])}; |dT| {np.abs(r["trans"] - z["trans_0_1"]).max():.2e}')
+    assert max(moved) <= 30 and min(same_nms) >= 2450
+    if e2e_identical:
+        assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
+    # ---- stage by stage on the reference's intermediate outputs: every index list identical ----
+    for pc in ds.pc_ids:
+        ranks = z[f'det_rank_{pc}'].astype(np.float64) / 5000.0
+        np.save(f'{base}/det_score/{pc}.npy', ranks.astype(np.float32))
+        assert np.array_equal(NMS_sample(2500, 5).sample(ds.get_kps(pc), ranks.astype(np.float32)), z[f'nms_{pc}'].astype(np.int64)), pc
+    np.random.seed(1234)
+    name2matcher['yoho_mat'](cfg).run(ds, 2500)
+    m = np.load(f'{md}/0-1.npy'); sc = np.load(f'{md}/scores/0-1.npy')
+    assert np.array_equal(m, want_m)
+    assert sc.dtype == np.float32 and np.abs(sc - z['mscore_0_1']).max() < 1e-4
+    np.save(f'{md}/scores/0-1.npy', z['mscore_0_1'])                       # the estimator's top-`match_n` selection: the reference's own scores
+    np.random.seed(4321)
+    name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
+    assert np.array_equal(np.load(f'{md}/DR_index/0-1.npy'), z['dr_0_1'].astype(np.int64))
+    assert np.abs(np.load(f'{md}/Trans_pre/0-1.npy')[::16] - z['transpre_sample_0_1']).max() < 2e-4
+    r = np.load(f'{md}/yohoo/1000iters/0-1.npz')
+    assert int(r['recalltime']) == int(z['recall_0_1'])
+    assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
 
 
 # ---- the rotation-bin estimator and the detector at full size ---------------------------------------------------------------------------

@@ -150,6 +150,50 @@ def gen_pipeline():
         shutil.rmtree(root, ignore_errors=True)
 
 
+def gen_pipeline_rd_rm(tag='full_pipeline_rd_rm', overlap=0.2, seed=PIPE_SEED + 7):
+    """BASELINE config 4's chain in the reference, end to end at full size on a LOW-OVERLAP pair (20 % shared keypoints; a second fixture
+    `_o60` at 60 %, where the trained matcher finds enough correct correspondences on synthetic descriptors to register the pair): GF (seeded
+    weights) -> detector (shipped RD weights) -> rank scores -> NMS sampling of 2500 keypoints -> yoho_mat (shipped RM weights) -> one-shot
+    RANSAC on the top-`match_n` = 0.5 matches (test/detector.py:26-47, test/matcher.py:11-42,152-210, test/estimator.py:405-443).
+    Stored: the detector's rank order, both NMS samples, matches + scores, DR_index, a strided sample of Trans_pre, the result."""
+    root = tempfile.mkdtemp(prefix='golden_full_')
+    try:
+        cfg = gg.make_cfg(root, RD=True, RM=True, keynum=2500, match_n=0.5)
+        cfg.bs_GF = 250; cfg.bs_ET = 500
+        ds = synth.make_scene(seed, n_clouds=2, n_kpts=5000, overlap=overlap, coord_noise=0.005, name='synth/scene0', portable=True)
+        ds.write_inputs(cfg.output_cache_fn)
+        name2extractor['yoho_des'](cfg).run(ds)
+        gg.name2detector['yoho_det'](cfg).run(ds)
+        np.random.seed(1234)
+        mat = name2matcher['yoho_mat'](cfg)
+        mat.run(ds, 2500)
+        np.random.seed(4321)
+        name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
+        base = f'{cfg.output_cache_fn}/{ds.name}'
+        out = {'scene_seed': np.int64(seed), 'overlap': np.float64(overlap)}
+        RefNMS = gg.ref_mat.NMS_sample                                # the reference's sampler, to store the two samples it drew
+        for pc in ds.pc_ids:
+            det = np.load(f'{base}/det_score/{pc}.npy')
+            out[f'det_rank_{pc}'] = _i16(np.rint(det * det.shape[0]))
+            out[f'nms_{pc}'] = _i16(RefNMS(2500, 5).sample(ds.get_kps(pc), det))
+            y = np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')
+            out[f'yoho_sample_{pc}'] = y[::250].copy()
+        md = f'{base}/match_2500'
+        for a, b in ds.pair_ids:
+            out[f'match_{a}_{b}'] = _i16(np.load(f'{md}/{a}-{b}.npy'))
+            out[f'mscore_{a}_{b}'] = np.load(f'{md}/scores/{a}-{b}.npy')
+            out[f'dr_{a}_{b}'] = np.load(f'{md}/DR_index/{a}-{b}.npy').astype(np.int8)
+            out[f'transpre_sample_{a}_{b}'] = np.load(f'{md}/Trans_pre/{a}-{b}.npy')[::16].copy()
+            r = np.load(f'{md}/yohoo/1000iters/{a}-{b}.npz', allow_pickle=True)
+            out[f'trans_{a}_{b}'] = r['trans']; out[f'recall_{a}_{b}'] = np.int64(r['recalltime'])
+            gt = ds.get_transform(a, b)
+            print('   pair', a, b, 'matches', out[f'match_{a}_{b}'].shape[0], 'score dtype', out[f'mscore_{a}_{b}'].dtype, 'recalltime', int(r['recalltime']),
+                  'RRE', gg.ref_reval.compute_R_diff(gt[:3, :3], r['trans'][:3, :3]), 'RTE', float(np.linalg.norm(gt[:3, 3] - r['trans'][:3, 3])))
+        save(tag, **out)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def gen_yohoc():
     """The rotation-bin estimator (test/estimator.py:173-241, run without its Pool like tools/gen_golden.py does) on the matches and
     DR_index of the full-size near-tie pair (inputs = arrays of full_stages.npz + the seed-rebuilt keypoints)."""
@@ -188,7 +232,7 @@ def gen_rd():
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'yohoc', 'rd']
+    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'pipeline_rd_rm', 'pipeline_rd_rm_o60', 'yohoc', 'rd']
     for name in todo:
         print(name)
-        {'stages': gen_stages, 'ransac': gen_ransac, 'ransac_ties': gen_ransac_ties, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
+        {'stages': gen_stages, 'ransac': gen_ransac, 'ransac_ties': gen_ransac_ties, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'pipeline_rd_rm': gen_pipeline_rd_rm, 'pipeline_rd_rm_o60': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60', 0.6, PIPE_SEED + 8), 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
