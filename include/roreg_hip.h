@@ -24,7 +24,7 @@ extern "C" {
 /* Version of THIS header.  It is bumped whenever an existing entry point changes its argument list or a shared struct its size
  * (2: round 2's per-keypoint block scales -- roreg_gf_finalize, roreg_inv_descriptor, roreg_et_gather, roreg_dense_split/_f16x2,
  * roreg_lt_prepare_batch, roreg_group_conv_f16x2, roreg_lt_task 80 -> 96 bytes; 3: round 3 -- roreg_ransac_score / roreg_refine /
- * roreg_ransac_batch take `w_f32`, the scores' storage type).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
 #define ROREG_ABI_VERSION 3
 int roreg_abi_version(void);
@@ -63,7 +63,11 @@ int roreg_group_conv(const float *x, const float *wpack, const float *bias,
  * Cout % 256 == 0, no residual.  wsplit: bf16 bits, layout [3 planes][KS][Cin/16][2 k-octets][Cout][8 channels]
  * (plane p of W[o, 16*(c/16) + 8*h + e, k]; the pieces are round-to-nearest-even of the exact remainders). */
 int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
-                           float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
+                           float *out, const int32_t *gather,
+                           const int32_t *lds_order /* nullable device int32 [Lin]: LDS slot of every input column (distinct values in [0, lds_stride); < 0 for a
+                           column no output gathers) -- an execution hint that spreads the gathered operand reads over the LDS banks
+                           (tools/lds_perm_search.py); results do not depend on it */, int lds_stride,
+                           int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
 
 /* Dense layer on row-major activations with the same f32-accurate 3 x bf16 split:
  *   out[b][o] = bias[o] + sum_k W[o][k] * act_k(x[b][k]) (+ residual[b][o]),  act_k(v) = max(v*scale[k] + shift[k], 0) or identity (scale NULL).
@@ -82,7 +86,8 @@ int roreg_dense_split(const float *x, const void *wsplit, const float *bias, con
  * above with two planes hi, lo of fp16 bits).  out_rowmax_dev (nullable, [B], zeroed by the caller) receives max |out[b]| for the next layer. */
 int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *bn_scale, const float *bn_shift,
                            float act_smax, float act_tmax, const float *in_rowmax_dev, float *out, float *out_rowmax_dev,
-                           const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
+                           const int32_t *gather, const int32_t *lds_order /* as roreg_group_conv_split */, int lds_stride,
+                           int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
 int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
                       float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, int residual_stride, float *out,
                       float *out_rowmax_dev, int B, int K, int O, void *stream);

@@ -199,8 +199,25 @@ __device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &
     }
 }
 
+// Which column of the wave's 128 the accumulator block t holds in lane j (the MFMA B operand's lane):
+//   INTERLEAVED (round 3): 4 j + t -- a lane's four blocks are four ADJACENT output columns, so the epilogue stores (and reads the residual)
+//   16 bytes per instruction: 32 global_store_dwordx4 per wave instead of 128 global_store_dword (the epilogue is issue-bound: it took 8-12 k
+//   cycles per 256 x 256 tile, 5.4 % of the kernel).  The B-fragment LDS slot of column n makes both sides conflict-free: block t's 32
+//   columns sit in 32 consecutive slots rotated by 4 t (16-lane ds_read_b128 groups read 16 consecutive slots; the 8-lane ds_write_b128
+//   groups of the staging -- 8 consecutive columns = 4 blocks x 2 lanes -- hit bank quads q, q+4, q+8, q+12, q+1, ...: all distinct).
+//   BLOCKED (rounds 1-2; the opt-in ping-pong kernel): t * 32 + j, slot n ^ ((n >> 3) & 1).
+// The arithmetic per output element is the same either way (same K order, same MFMA sequence): results are bitwise identical.
+template <bool INTERLEAVED>
+__device__ __forceinline__ int wave_col(int t, int j) { return INTERLEAVED ? 4 * j + t : t * 32 + j; }
+template <bool INTERLEAVED>
+__device__ __forceinline__ int col_slot(int n /* column inside the 256-column tile */) {
+    if constexpr (!INTERLEAVED) return n ^ ((n >> 3) & 1);
+    const int t = n & 3, q = (n & 127) >> 2;
+    return (n & ~127) | (t * 32 + ((q + 4 * t) & 31));
+}
+
 // Epilogue shared by the fp16 x 2 / bf16 x 3 GEMM kernels: rescale, optional residual, store, optional bound propagation.
-template <int NP, int WO>
+template <int NP, int WO, bool INTERLEAVED = true>
 __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int ncol_wave, f32x16 (&acc)[2][4],
                                                     char *smem) {
     constexpr int NCOL = 256, OT = WO * 64, NT = WO * 128;
@@ -221,7 +238,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
     if constexpr (NP == 2) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = n0 + ncol_wave + t * 32 + j;
+            const int n = n0 + ncol_wave + wave_col<INTERLEAVED>(t, j);
             if (n < N) oscale[t] = ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(n, dirr)]) + p.w_exp));
         }
         if (want_bound) {                                        // (the LDS tiles are dead: the loop ended with a barrier)
@@ -246,28 +263,41 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {                 // four accumulator rows at a time: their 16 residual loads go out together
+                for (int rq = 0; rq < 4; ++rq) {                 // four accumulator rows at a time: their residual loads go out together
                     float res[4][4];
                     if constexpr (decltype(has_add)::value) {
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr)
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const unsigned roff = (unsigned)(ot * 32 + rr + 8 * rq + 4 * h) * un;
+                            if constexpr (INTERLEAVED) {
+                                const float4 q = *reinterpret_cast<const float4 *>(ab + roff + 4u * (unsigned)j);
+                                res[rr][0] = q.x; res[rr][1] = q.y; res[rr][2] = q.z; res[rr][3] = q.w;
+                            } else {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) res[rr][t] = ab[(unsigned)(ot * 32 + rr + 8 * rq + 4 * h) * un + (unsigned)j + t * 32];
+                                for (int t = 0; t < 4; ++t) res[rr][t] = ab[roff + (unsigned)j + t * 32];
+                            }
+                        }
                     }
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int r = rq * 4 + rr;
                         const int rl = ot * 32 + rr + 8 * rq + 4 * h;          // row inside the wave's 64
-                        const unsigned off = (unsigned)rl * un + (unsigned)j;
                         float ur = 0.f, vr = 0.f;
                         if constexpr (decltype(has_bound)::value) { ur = su[wo * 64 + rl]; vr = sv[wo * 64 + rl]; }
+                        float o4[4];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             float o = acc[ot][t][r];
                             if constexpr (NP == 2) o *= oscale[t];
                             if constexpr (decltype(has_add)::value) o += res[rr][t];
-                            ob[off + t * 32] = o;
+                            o4[t] = o;
                             if constexpr (decltype(has_bound)::value) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr));
+                        }
+                        if constexpr (INTERLEAVED) {
+                            *reinterpret_cast<float4 *>(ob + (unsigned)rl * un + 4u * (unsigned)j) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) ob[(unsigned)rl * un + (unsigned)j + t * 32] = o4[t];
                         }
                     }
                 }
@@ -286,7 +316,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
                 if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int n = n0 + ncol_wave + t * 32 + j;
+                    const int n = n0 + ncol_wave + wave_col<INTERLEAVED>(t, j);
                     if (n >= N) continue;
                     float o = acc[ot][t][r];
                     if constexpr (NP == 2) o *= oscale[t];
@@ -301,7 +331,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float bm = fmaxf(bmax[t], __shfl_xor(bmax[t], 32));
-                if (h == 0) atomicMax(cm + ncol_wave + t * 32 + j, __float_as_uint(bm));      // non-negative floats order like their bit patterns
+                if (h == 0) atomicMax(cm + ncol_wave + wave_col<INTERLEAVED>(t, j), __float_as_uint(bm));      // non-negative floats order like their bit patterns
             }
             __syncthreads();
             for (int i = tid; i < NCOL; i += NT) {
@@ -358,8 +388,9 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
     // staging patch of this thread: columns n0 + 2*pp, +1 (clamped inside the matrix: out-of-range columns are never stored),
-    // k-octet po of the step.  Column n lives in fragment slot n ^ ((n >> 3) & 1): conflict-free for the 8-lane groups of
-    // ds_write_b128 (even columns of 8 neighbouring threads) and for the 16-lane groups of ds_read_b128.
+    // k-octet po of the step.  Column n lives in fragment slot col_slot(n) (see wave_col / col_slot above): conflict-free for the 8-lane
+    // groups of ds_write_b128 (8 neighbouring columns, or the even / odd columns of 8 neighbouring threads) and for the 16-lane groups of
+    // ds_read_b128.
     const int pp = tid % (NCOL / CPT), po = tid / (NCOL / CPT);
     int ncol = n0 + CPT * pp;
     if (ncol > N - CPT) ncol = N - CPT;
@@ -373,7 +404,7 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     };
     int slot[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) { const int n = CPT * pp + c; slot[c] = po * NCOL + (n ^ ((n >> 3) & 1)); }
+    for (int c = 0; c < CPT; ++c) slot[c] = po * NCOL + col_slot<true>(CPT * pp + c);
     auto convert_store = [&](int buf, const xpatch (&xr)[8]) {
         frag *dst = xs + buf * XBUF;
 #pragma unroll
@@ -410,7 +441,7 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     // fragment slots this lane reads in the MFMA phase
     int xslot[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const int n = ncol_wave + t * 32 + j; xslot[t] = h * NCOL + (n ^ ((n >> 3) & 1)); }
+    for (int t = 0; t < 4; ++t) xslot[t] = h * NCOL + col_slot<true>(ncol_wave + wave_col<true>(t, j));
     const int aslot = h * OT + wo * 64 + j;
 
     auto step = [&](int ks, int buf, xpatch (&xr_load)[8], const xpatch (&xr_use)[8]) {
@@ -737,7 +768,7 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p,
     if (k + 1 < nsteps) step(k + 1, R0, R2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_split_epilogue<2, 4>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
+    gemm_split_epilogue<2, 4, false>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

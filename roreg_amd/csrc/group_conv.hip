@@ -256,6 +256,13 @@ struct GCSplitParams {
     const int32_t *gather;
     int B, Cin, Cout, CoutPad, Lin, Lout, ncols, gt_bytes, nkp_max;
     SplitScale sc;
+    // LDS slot order of the activation slab: input column c of keypoint kp lives at fragment slot kp * S + order[c] (order[c] < 0: column c
+    // is never gathered and is not staged).  order == null: the natural order, S = Lin.  The gathered B-operand reads of a 16-lane
+    // ds_read_b128 group hit bank quad (kp * S + order[gather[j][k]]) % 16; with the natural order of the ET trunk's 13-of-45 stencil 3.2
+    // lanes of a group collide on average (65 % of the kernel's LDS cycles were bank conflicts); tools/lds_perm_search.py finds an order
+    // with 1.97.  Pure data movement: results are bitwise unchanged.
+    const int32_t *order;
+    int S;
 };
 
 __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
@@ -273,8 +280,8 @@ template <int KS, int NP>
 __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams p) {
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *gt = reinterpret_cast<int *>(smem);
-    frag *slab = reinterpret_cast<frag *>(smem + p.gt_bytes);            // [NP planes][2 k-octets][nkp_max][Lin]
+    int *gt = reinterpret_cast<int *>(smem);                             // [Lout * KS] slot of every gathered column, then [Lin] slot of every input column
+    frag *slab = reinterpret_cast<frag *>(smem + p.gt_bytes);            // [NP planes][2 k-octets][nkp_max][S slots]
     constexpr int OT = 256, NCOL = 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -286,9 +293,12 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     const int b_first = col0 / Lout;
     const int col_last = min(col0 + NCOL, p.ncols) - 1;
     const int nkp = col_last / Lout - b_first + 1;
-    const int plane_stride = 2 * p.nkp_max * Lin, h_stride = p.nkp_max * Lin;     // in 16-byte fragments
+    const int S = p.S;
+    const int plane_stride = 2 * p.nkp_max * S, h_stride = p.nkp_max * S;         // in 16-byte fragments
+    int *slot_of = gt + Lout * KS;
 
-    for (int i = tid; i < Lout * KS; i += 256) gt[i] = p.gather[i];
+    for (int i = tid; i < Lout * KS; i += 256) gt[i] = p.order ? p.order[p.gather[i]] : p.gather[i];
+    for (int i = tid; i < Lin; i += 256) slot_of[i] = p.order ? p.order[i] : i;
 
     int rowbase[4], gi[4], bcol[4];
     bool valid[4];
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
         const int b = nn / Lout;
         gi[t] = nn - b * Lout;
         bcol[t] = b;
-        rowbase[t] = h * h_stride + (b - b_first) * Lin;
+        rowbase[t] = h * h_stride + (b - b_first) * S;
     }
 
     f32x16 acc[2][4];
@@ -343,6 +353,8 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
         for (int i = tid; i < items; i += 256) {
             const int col = i % Lin, r = i / Lin;
             const int ho = r & 1, kp = r >> 1;
+            const int sl = slot_of[col];
+            if (sl < 0) continue;                                                    // a column no output gathers (padding)
             const float *src = raw + (kp * 16 + 8 * ho) * Lin + col;
             float v[8];
 #pragma unroll
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.bn_scale[c0 + 8 * ho + e], p.bn_shift[c0 + 8 * ho + e]), 0.f);
             }
-            frag *dst = slab + ho * h_stride + kp * Lin + col;
+            frag *dst = slab + ho * h_stride + kp * S + sl;
             if constexpr (NP == 3) {
                 bf16x8 b1, b2, b3;
                 gc_split3(v, b1, b2, b3);
@@ -822,7 +834,7 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
 
 template <int NP>
 static int launch_conv_split(GCSplitParams p, hipStream_t s) {
-    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.Lin * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4;     // gather table, fragment slab, raw chunk
+    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4;       // slot tables, fragment slab, raw chunk
     ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
     auto kern = group_conv_split_kernel<13, NP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -834,7 +846,8 @@ static int launch_conv_split(GCSplitParams p, hipStream_t s) {
 }
 
 static int conv_split_common(int np, const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
-                             float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, SplitScale sc, void *stream) {
+                             float *out, const int32_t *gather, const int32_t *lds_order, int lds_stride, int B, int Cin, int Cout, int Lin, int Lout,
+                             int KS, SplitScale sc, void *stream) {
     if (B == 0) return 0;
     ROREG_REQUIRE(x && wsplit && bias && out && gather && B > 0, "roreg_group_conv_split: bad arguments");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv_split: bn_scale/bn_shift must come together");
@@ -844,7 +857,9 @@ static int conv_split_common(int np, const float *x, const void *wsplit, const f
     GCSplitParams p;
     p.x = x; p.ws = wsplit; p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.out = out;
     p.gather = gather; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = Cout; p.Lin = Lin; p.Lout = Lout; p.ncols = B * Lout;
-    p.gt_bytes = round_up(Lout * KS * 4, 16);
+    ROREG_REQUIRE(!lds_order || (lds_stride >= 1 && lds_stride <= 64), "roreg_group_conv_split: lds_stride %d out of range", lds_stride);
+    p.order = lds_order; p.S = lds_order ? lds_stride : Lin;
+    p.gt_bytes = round_up((Lout * KS + Lin) * 4, 16);
     p.nkp_max = (128 - 1) / Lout + 2;
     if (p.nkp_max > B) p.nkp_max = B;
     p.sc = sc;
@@ -852,17 +867,19 @@ static int conv_split_common(int np, const float *x, const void *wsplit, const f
 }
 
 extern "C" int roreg_group_conv_split(const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
-                                      float *out, const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+                                      float *out, const int32_t *gather, const int32_t *lds_order, int lds_stride, int B, int Cin, int Cout, int Lin,
+                                      int Lout, int KS, void *stream) {
     SplitScale sc = {nullptr, 1.f, 0.f, 0, nullptr};
-    return conv_split_common(3, x, wsplit, bias, bn_scale, bn_shift, out, gather, B, Cin, Cout, Lin, Lout, KS, sc, stream);
+    return conv_split_common(3, x, wsplit, bias, bn_scale, bn_shift, out, gather, lds_order, lds_stride, B, Cin, Cout, Lin, Lout, KS, sc, stream);
 }
 
 extern "C" int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *bn_scale, const float *bn_shift,
                                       float act_smax, float act_tmax, const float *in_rowmax_dev, float *out, float *out_rowmax_dev,
-                                      const int32_t *gather, int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+                                      const int32_t *gather, const int32_t *lds_order, int lds_stride, int B, int Cin, int Cout, int Lin, int Lout,
+                                      int KS, void *stream) {
     ROREG_REQUIRE(in_rowmax_dev, "roreg_group_conv_f16x2: in_rowmax_dev is required");
     SplitScale sc = {in_rowmax_dev, act_smax, act_tmax, w_exp, out_rowmax_dev};
-    return conv_split_common(2, x, wsplit2, bias, bn_scale, bn_shift, out, gather, B, Cin, Cout, Lin, Lout, KS, sc, stream);
+    return conv_split_common(2, x, wsplit2, bias, bn_scale, bn_shift, out, gather, lds_order, lds_stride, B, Cin, Cout, Lin, Lout, KS, sc, stream);
 }
 
 template <int NP>

@@ -13,7 +13,8 @@ import torch
 
 from .group import tables
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libroreg_hip.so')
+# ROREG_HIP_LIB: another build of the same library (A/B measurements of kernel variants, tools/gemm_ab.sh); default: the in-tree build
+_LIB_PATH = os.environ.get('ROREG_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libroreg_hip.so')
 
 # How the irrep-domain GEMMs and transforms feed the matrix cores:
 #   'f16x2' (default): every f32 operand as hi + lo fp16 with power-of-two block scaling (22 significant bits), products hi.hi + hi.lo +
@@ -41,8 +42,8 @@ PROTOTYPES = {
     'roreg_group_conv_pack_weights': (c_int, [_P, c_int, c_int, c_int, _P]),
     'roreg_group_conv_workspace_size': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
-    'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    'roreg_group_conv_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_group_conv_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'roreg_dense_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, c_int, _P, c_int, _P]),
@@ -307,10 +308,12 @@ def full_gather():
     return gather_table('nei60', tables().Nei)
 
 
-def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False, in_rowmax=None, want_rowmax=False):
+def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False, in_rowmax=None, want_rowmax=False, lds_order=None):
     """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32.  split: use the 3 x bf16 split kernel (f32-accurate) where its shape constraints hold;
     with in_rowmax (device float32 [B], tracked max |x[b]| per row) the fp16 x 2 kernel, whose block scale is per row (a row's result does
-    not depend on the other rows of the batch); it can also return the tracked per-row max |out[b]| (want_rowmax)."""
+    not depend on the other rows of the batch); it can also return the tracked per-row max |out[b]| (want_rowmax).
+    lds_order: optional (device int32 [Lin] slot table, stride) -- the split kernels' LDS slot order of the input columns (an execution hint
+    against bank conflicts of the gathered reads, tools/lds_perm_search.py; results do not depend on it)."""
     ensure_tables()
     B, Cin, Lin = x.shape
     assert Cin == layer.Cin, (Cin, layer.Cin)
@@ -320,6 +323,9 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
     split_ok = residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0
+    order_t, order_s = (None, 0) if lds_order is None else lds_order
+    if order_t is not None and (order_t.numel() != Lin or not 1 <= int(order_s) <= 64):
+        raise HipError(f'group_conv: lds_order must hold one slot per input column ({Lin}) and a stride in 1..64')
     if in_rowmax is not None:
         if not split_ok:
             raise HipError('group_conv: the fp16 x 2 kernel does not support this shape')
@@ -329,12 +335,12 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
         amax = torch.zeros(B, dtype=torch.float32, device=x.device) if want_rowmax else None
         _check(lib().roreg_group_conv_f16x2(_ptr(x, torch.float32), _ptr(w2), w_exp, _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift), smax, tmax,
                                             _ptr(in_rowmax, torch.float32), _ptr(out, torch.float32), _ptr(amax), _ptr(gather, torch.int32),
-                                            B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv_f16x2')
+                                            _ptr(order_t, torch.int32), order_s, B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()), 'roreg_group_conv_f16x2')
         return (out, amax) if want_rowmax else out
     if split and split_ok:
         _check(lib().roreg_group_conv_split(_ptr(x, torch.float32), _ptr(_conv_wsplit(layer)), _ptr(layer.bias), _ptr(layer.scale), _ptr(layer.shift),
-                                            _ptr(out, torch.float32), _ptr(gather, torch.int32), B, Cin, layer.Cout, Lin, Lout, layer.KS, _stream()),
-               'roreg_group_conv_split')
+                                            _ptr(out, torch.float32), _ptr(gather, torch.int32), _ptr(order_t, torch.int32), order_s, B, Cin, layer.Cout, Lin, Lout,
+                                            layer.KS, _stream()), 'roreg_group_conv_split')
         return out
     ws_n = lib().roreg_group_conv_workspace_size(B, Cin, layer.Cout, Lin, Lout, layer.KS)
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device) if ws_n else None

@@ -77,6 +77,20 @@ class ET_test(nn.Module):
 
     LIVE_PAD = 48          # the 45 live columns of Conv_init's output are stored with a 16-byte-friendly stride
 
+    # LDS slot order of the 45 live input columns for the trunk's 13-column stencil convolution (hip.group_conv lds_order): found by
+    # tools/lds_perm_search.py for THIS gather table (mean serialisation of the gathered 16-lane ds_read_b128 groups 1.95 instead of 3.21
+    # with the natural order at stride 48, where 65 % of the kernel's LDS cycles were bank conflicts).  An execution hint only.
+    _LDS_ORDER_45 = (32, 12, 28, 30, 42, 35, 15, 40, 17, 39, 29, 22, 26, 4, 11, 18, 6, 9, 33, 24, 8, 2, 7, 1, 14, 34, 37, 27, 13, 38, 20, 25, 10, 21, 43, 16,
+                     36, 0, 19, 5, 41, 3, 31, 23, 44)
+
+    @classmethod
+    def _trunk_lds_order(cls):
+        """(device int32 [LIVE_PAD] slot table, stride 45): the padding columns 45..47 are never gathered (-1)."""
+        order = np.full(cls.LIVE_PAD, -1, np.int32)
+        order[:45] = cls._LDS_ORDER_45
+        assert sorted(order[:45].tolist()) == list(range(45))
+        return hip.gather_table('et_lds_order', order), 45
+
     @staticmethod
     def _pruned_gathers():
         T = tables()
@@ -142,7 +156,7 @@ class ET_test(nn.Module):
                     h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split='f16x2',
                                           want_rowmax=True)                                                          # [B,256,48]
                     del T0
-                    m, am = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True)                                  # [B,512,13]
+                    m, am = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True, lds_order=self._trunk_lds_order())   # [B,512,13]
                     d_out, d0, d1, d2 = self._dense_plans()
                     # identity short cut = column g = 0 of h, read in place (element (b, o) at stride LIVE_PAD from h[0, 0, p0])
                     t, at = hip.dense_split(m.view(B, -1), d_out, residual=h[:, :, p0:], residual_stride=self.LIVE_PAD, in_rowmax=am, want_rowmax=True)   # [B,256]
@@ -156,7 +170,8 @@ class ET_test(nn.Module):
                 del T0
             else:
                 h = self.Conv_init(x, gather=ga)                               # [B,256,45]
-            m = res._b_in(h, gather=gb, split=self.gemm != 'f32')              # [B,512,13]
+            m = res._b_in(h, gather=gb, split=self.gemm != 'f32',
+                          lds_order=self._trunk_lds_order() if (self.fourier_init and self.gemm != 'f32') else None)       # [B,512,13]
             sc = h[:, :, p0:p0 + 1].contiguous()                               # identity short cut at g=0
             if self.gemm != 'f32':                                             # trunk tail + head as dense split layers
                 d_out, d0, d1, d2 = self._dense_plans()

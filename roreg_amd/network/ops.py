@@ -33,8 +33,9 @@ class _PlannedConv(nn.Module):
             self._plan_key = key
         return self._plan
 
-    def forward(self, x, gather=None, residual=None, split=False, in_rowmax=None, want_rowmax=False):
-        return hip.group_conv(x, self.plan(), gather=gather, residual=residual, split=split, in_rowmax=in_rowmax, want_rowmax=want_rowmax)
+    def forward(self, x, gather=None, residual=None, split=False, in_rowmax=None, want_rowmax=False, lds_order=None):
+        return hip.group_conv(x, self.plan(), gather=gather, residual=residual, split=split, in_rowmax=in_rowmax, want_rowmax=want_rowmax,
+                              lds_order=lds_order)
 
 
 class Comb_Conv(_PlannedConv):

@@ -112,6 +112,16 @@ def test_group_conv_split_is_f32_accurate(group):
     e32 = np.abs(y32 - ref).max() / s; esp = np.abs(ysp - ref).max() / s; e16 = np.abs(y16 - ref).max() / s
     assert e32 < 2e-6 and esp < 2e-6 and e16 < 2e-6, (e32, esp, e16)
     assert esp < 3 * e32 + 2e-7 and e16 < 3 * e32 + 2e-7, (e32, esp, e16)
+    # the LDS slot order of the input columns (hip.group_conv lds_order, tools/lds_perm_search.py) is an execution hint: any injective
+    # order at any stride gives bitwise the same output, in both split modes, also on a launch of several column tiles
+    big = torch.from_numpy((rng.standard_normal((700, C, Lin)) * np.exp(rng.standard_normal((700, C, 1)))).astype(np.float32)).cuda()
+    bmax = big.abs().amax((1, 2))
+    want_sp = hip.group_conv(big, layer, gather=gd, split=True); want_16 = hip.group_conv(big, layer, gather=gd, in_rowmax=bmax)
+    for stride in (45, 48, 53, 64):
+        order = np.full(Lin, -1, np.int32); order[:45] = rng.permutation(stride)[:45]
+        od = (torch.from_numpy(order).cuda(), stride)
+        assert torch.equal(hip.group_conv(big, layer, gather=gd, split=True, lds_order=od), want_sp), stride
+        assert torch.equal(hip.group_conv(big, layer, gather=gd, in_rowmax=bmax, lds_order=od), want_16), stride
 
 
 def test_dense_split_is_f32_accurate():
