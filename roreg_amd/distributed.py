@@ -297,17 +297,36 @@ def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, 
     importing = {s for s, _, _, _ in recvs}
     order = sorted(range(len(pieces)), key=lambda q: (pieces[q][0] in importing, q))
     out = [None] * len(pieces)
+
+    def run_group(qs):
+        """the pieces `qs` through the engine: software-pipelined over the scenes when it offers run_scenes(), else one after the other"""
+        jobs = []
+        for q in qs:
+            s, a, b = pieces[q]
+            feats, keys, pairs, seeds = scene_inputs(s)
+            ready = cache.setdefault(s, {}) if s in shared else None
+            jobs.append((feats, keys, pairs[a:b], dict(pair_seeds=None if seeds is None else seeds[a:b], ready=ready, **run_kw)))
+        # (two ranges of ONE cut scene on this rank share `ready`: the second must see the clouds the first extracted -> not pipelined together)
+        scenes_of = [pieces[q][0] for q in qs]
+        if hasattr(engine, 'run_scenes') and len(set(scenes_of)) == len(scenes_of):
+            res = engine.run_scenes(jobs)
+        else:
+            res = [engine.run_scene(f, k, p, **kw) for f, k, p, kw in jobs]
+        for q, r in zip(qs, res):
+            out[q] = (pieces[q][0], pieces[q][1], pieces[q][2], r)
+
+    first = [q for q in order if pieces[q][0] not in importing]
+    last = [q for q in order if pieces[q][0] in importing]
     waited = not recvs
-    for q in order:
-        s, a, b = pieces[q]
-        feats, keys, pairs, seeds = scene_inputs(s)
-        if s in importing and not waited:
+    if first:
+        run_group(first)
+    if last:
+        if not waited:
             for (sc, i), eqv in ex.wait().items():
                 f, k = scene_inputs(sc)[:2]
                 cache.setdefault(sc, {})[i] = engine.cloud_from_eqv(f[i], eqv, k[i])
             waited = True
-        ready = cache.setdefault(s, {}) if s in shared else None
-        out[q] = (s, a, b, engine.run_scene(feats, keys, pairs[a:b], pair_seeds=None if seeds is None else seeds[a:b], ready=ready, **run_kw))
+        run_group(last)
     if ex is not None and not waited:                              # a rank that only sends: its sends complete before the step ends
         ex.wait()
     return out

@@ -126,6 +126,7 @@ class RegistrationEngine:
         self.extract_rows = int(os.environ.get('ROREG_EXTRACT_ROWS', 65536))    # keypoints per extractor launch (activations: ~370 KB per keypoint at peak)
         self.lt_rows = int(os.environ.get('ROREG_LT_ROWS', 131072))                  # correspondences per pass of the ET network (local_transforms_many)
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
+        self._side = None           # side stream of run_scenes' downloads
 
     def _mark(self, name, t0):
         """Diagnostics: with phase_ms set, synchronise and add the wall time since t0 to phase `name`; returns the new t0."""
@@ -501,9 +502,81 @@ class RegistrationEngine:
         return rt, w_all, skipped
 
     # ---- whole scene -----------------------------------------------------------------------------------------
-    def run_scene(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None,
-                  writer=None, ready=None):
-        """feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
+    def run_scene(self, feats, keys, pair_ids, **kw):
+        """One scene, synchronously (see _scene_steps for the arguments): the scene's two host synchronisations are plain blocking downloads."""
+        g = self._scene_steps(feats, keys, pair_ids, **kw)
+        try:
+            req = next(g)
+            while True:
+                req = g.send([t.cpu().numpy() for t in req])
+        except StopIteration as done:
+            return done.value
+
+    def run_scenes(self, jobs):
+        """Several scenes (or pair ranges), software-pipelined on the one stream: jobs = [(feats, keys, pair_ids, kwargs)] -> [[PairResult]].
+        A scene synchronises with the host twice -- for the match counts (the hypothesis order needs every pair's M) and for the result
+        table -- and between a download and the next launch the host shuffles, builds task tables and uploads: ~5 ms per scene with the GPU
+        idle when the scenes run one after the other (3 % of a step, profiles/r02_bench_gpu_idle.txt).  Here scene i + 1's extraction and
+        matcher are enqueued BEFORE the host waits for scene i's counts, and scene i's estimator before it waits for scene i - 1's results;
+        every download goes through a side stream ordered by an event behind its producer, so it does not wait for the kernels queued
+        after it.  Needs per-pair generator streams (pair_seeds: the host-side draws then do not depend on the order scenes are
+        prepared in); without them -- the reference's single global stream -- the scenes run one after the other.  Results are
+        bitwise those of run_scene()."""
+        import os
+        if (len(jobs) < 2 or self.phase_ms is not None or any(kw.get('pair_seeds') is None for _, _, _, kw in jobs)
+                or os.environ.get('ROREG_NO_PIPELINE')):                     # (the switch is for A/B measurements)
+            return [self.run_scene(f, k, p, **kw) for f, k, p, kw in jobs]
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+
+        def download(tensors):
+            """start the device -> pinned-host copies of `tensors` on the side stream, behind everything enqueued so far"""
+            ready = torch.cuda.Event(); ready.record()
+            hosts = []
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                for t in tensors:
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    t.record_stream(side)
+                    hosts.append(h)
+                done = torch.cuda.Event(); done.record(side)
+            return hosts, done
+
+        out = [None] * len(jobs)
+        active = []                                                  # [index, generator, pinned hosts, event], oldest first
+
+        def advance(slot):
+            i, g, hosts, done = slot
+            done.synchronize()
+            try:
+                req = g.send([h.numpy() for h in hosts])
+            except StopIteration as fin:
+                out[i] = fin.value
+                return None
+            return [i, g, *download(req)]
+
+        for i in range(len(jobs)):
+            older = active
+            f, k, p, kw = jobs[i]                                    # the next scene's first stage is enqueued ...
+            g = self._scene_steps(f, k, p, **kw)
+            newest = []
+            try:
+                newest = [[i, g, *download(next(g))]]
+            except StopIteration as fin:
+                out[i] = fin.value
+            # ... before the host waits for anything of the scenes already in flight, each of which then moves one stage on (oldest first)
+            active = [n for n in (advance(slot) for slot in older) if n is not None] + newest
+        while active:
+            active = [n for n in (advance(slot) for slot in active) if n is not None]
+        return out
+
+    def _scene_steps(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None,
+                     writer=None, ready=None):
+        """Generator behind run_scene / run_scenes: yields the device tensors it needs on the host at each of the scene's two synchronisation
+        points and is sent their numpy copies; returns [PairResult].
+        feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
         pair_seeds: optional one integer per pair -- the pair's keypoint sampling draws from a generator stream of its own,
         RandomState(seed) (the stream np.random.seed(seed) would start), and its hypothesis draws from RandomState(seed + 1), so a pair's
         result is a function of the pair alone (whatever other pairs this call processes: the multi-GPU driver's rank-count
@@ -564,7 +637,7 @@ class RegistrationEngine:
                 d1 = flat_dev[o:o + len(s1)]; o += len(s1)
                 tasks.append((c0.inv, c1.inv, d0, d1))
             mbuf, cnt = hip.mutual_match_batch(tasks)
-            counts = cnt.cpu().numpy()                                       # the one sync of the matcher stage
+            counts = (yield [cnt])[0]                                        # the one sync of the matcher stage
             full = [(clouds[int(a)], clouds[int(b)], mbuf[q, :int(M)]) for q, ((a, b), M) in enumerate(zip(pair_ids, counts))]
             all_scores = [None] * len(full)
         if writer is not None:
@@ -583,9 +656,8 @@ class RegistrationEngine:
         f32_scores = any(sc is not None and sc.dtype == np.float32 for sc in all_scores)      # the rotation-coherence matcher's (matcher.py:210)
         best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird, w_f32=f32_scores)
         t0 = self._mark('ransac_issue', t0)
-        T_host = T2_d.cpu().numpy()                                         # the one sync of the estimator stage
-        best_host = best_d.cpu().numpy()
-        st_host = torch.stack([st1_d, st2_d], 1).cpu().numpy()
+        T_host, best_host, st_host = yield [T2_d, best_d, torch.stack([st1_d, st2_d], 1)]       # the one sync of the estimator stage
+        T_host = np.array(T_host)                                           # (the driver's buffers may be read-only / pinned views)
         # The device closes each refinement with its own 3x3 SVD.  When a cross-covariance is rank-deficient
         # (<= 2 inliers: a failed registration) U V^T is not unique and the reference's value is LAPACK's; redo
         # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.

@@ -203,6 +203,36 @@ def test_engine_writer_files_equal_the_stage_classes_files(tmp_path, RD, RM, ET)
             assert np.abs(r.trans - want['trans']).max() < 1e-10
 
 
+@pytest.mark.parametrize('kind', ['mutual+yohoo', 'mutual+yohoc', 'rd+rm+yohoo'])
+def test_run_scenes_pipelined_equals_one_scene_at_a_time(kind):
+    """engine.run_scenes (the next scene's extraction and matcher enqueued before the host waits for this scene's match counts; downloads on
+    a side stream) gives bitwise the results of run_scene scene by scene, for every estimator / matcher combination (per-pair seeds)."""
+    import zlib
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    RD = RM = kind.startswith('rd')
+    cfg = default_config(keynum=96, max_iter=300, ET='yohoc' if kind.endswith('yohoc') else 'yohoo', RD=RD, RM=RM)
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    rd = rm = None
+    if RD:
+        rd = name2network['RD_test'](cfg); rd.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RD').items()})
+        rm = name2network['RM_test'](cfg); rm.load_state_dict({k: torch.from_numpy(v) for k, v in load_golden('weights_RM').items()})
+    eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
+    jobs = []
+    for q, n_clouds in enumerate((4, 3, 5, 2)):
+        ds = synth.make_scene(40 + q, n_clouds=n_clouds, n_kpts=128 + 16 * q, overlap=0.6)
+        seeds = [zlib.crc32(f'{q}:{a}:{b}'.encode()) for a, b in ds.pair_ids]
+        jobs.append((ds.feats, [ds.get_kps(i) for i in ds.pc_ids], ds.pair_ids, dict(keynum=96, max_iter=300, keep_matches=True, pair_seeds=seeds)))
+    one = [eng.run_scene(f, k, p, **kw) for f, k, p, kw in jobs]
+    piped = eng.run_scenes(jobs)
+    assert [len(r) for r in piped] == [len(r) for r in one]
+    for ra, rb in zip(one, piped):
+        for a, b in zip(ra, rb):
+            assert (a.id0, a.id1, a.n_match, a.recalltime) == (b.id0, b.id1, b.n_match, b.recalltime)
+            assert np.array_equal(a.trans, b.trans, equal_nan=True) and torch.equal(a.matches, b.matches)
+
+
 def test_engine_yohoc_equals_file_coupled_stages(tmp_path):
     """The rotation-bin estimator inside the device-resident engine against the file-coupled yohoc stages on the same
     generator stream: same matches, same winning try, same transform."""

@@ -33,7 +33,11 @@ def main():
              '#   python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --gemm <mode>',
              '# per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE tallies a wide coalesced read at half',
              '# its bytes, MI355X_MICROARCH.md section HBM -- see the calibration line of each mode).']
-    res = {'hbm_bytes_per_launch': {}, 'detail': {}}
+    import hashlib, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # bench.py quotes `roofline.traffic` from this file only while csrc/fourier.hip still hashes to kernel_source_sha16
+    res = {'hbm_bytes_per_launch': {}, 'detail': {}, 'git_commit': os.environ.get('ROREG_GIT_COMMIT'),
+           'kernel_source_sha16': hashlib.sha256(open(os.path.join(here, 'roreg_amd', 'csrc', 'fourier.hip'), 'rb').read()).hexdigest()[:16]}
     for spec in sys.argv[3:]:
         mode, d = spec.split('=')
         gm = mode.split(':')[-1]
