@@ -15,9 +15,10 @@ import torch
 ROW = 21     # scene, id0, id1, n_match, recalltime, trans[0:15] (row-major 4x4 without the final 1), inlier ratio
 
 
-def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=7.0, tolerance=1.02, pair_lists=None, exchange=False, recv_cost=0.5):
-    """pair_counts: {scene: n_pairs}; cloud_counts: {scene: n_clouds}.  Extracting a cloud costs about `cloud_cost` pair-units (measured:
-    ~380 clouds/s against ~2800 pairs/s of the per-pair stages) and is paid again by every rank that holds a slice of the scene --
+def shard_scenes(pair_counts, world_size, cloud_counts=None, cloud_cost=9.0, tolerance=1.02, pair_lists=None, exchange=False, recv_cost=1.0):
+    """pair_counts: {scene: n_pairs}; cloud_counts: {scene: n_clouds}.  Extracting a cloud costs about `cloud_cost` pair-units (round 3: a
+    least-squares fit of the per-rank times of tools/scaling_estimate.py at N = 1, 2, 4, 8 gives 0.29 ms per pair, 2.65 ms per extracted
+    cloud, 0.1-0.4 ms per received cloud: ratios 9 and ~1; rounds 1-2 used 7) and is paid again by every rank that holds a slice of the scene --
     but only for the clouds the slice touches: with pair_lists = {scene: [(id0, id1), ...]} the cost of a range is exact, otherwise
     every slice is charged the whole scene.
     exchange=True (needs pair_lists): a cloud is extracted by ONE rank only -- the one whose range holds the first pair of the scene's
@@ -273,7 +274,7 @@ class EqvExchange:
         return out
 
 
-def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, **run_kw):
+def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, min_jobs=4, min_pairs=48, **run_kw):
     """One pass of this rank's share of a shard plan.  pieces [(scene, a, b)]; scene_inputs(scene) -> (feats, keys, pair_ids, pair_seeds or
     None) with feats / keys indexable by int cloud id; transfers: exchange_plan()'s list (empty: every rank extracts what it touches).
     Order: (0) the clouds this rank owns and others need are extracted and sent, the receives are posted; (1) the scenes this rank
@@ -298,35 +299,50 @@ def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, 
     order = sorted(range(len(pieces)), key=lambda q: (pieces[q][0] in importing, q))
     out = [None] * len(pieces)
 
-    def run_group(qs):
-        """the pieces `qs` through the engine: software-pipelined over the scenes when it offers run_scenes(), else one after the other"""
-        jobs = []
-        for q in qs:
-            s, a, b = pieces[q]
-            feats, keys, pairs, seeds = scene_inputs(s)
-            ready = cache.setdefault(s, {}) if s in shared else None
-            jobs.append((feats, keys, pairs[a:b], dict(pair_seeds=None if seeds is None else seeds[a:b], ready=ready, **run_kw)))
-        # (two ranges of ONE cut scene on this rank share `ready`: the second must see the clouds the first extracted -> not pipelined together)
-        scenes_of = [pieces[q][0] for q in qs]
-        if hasattr(engine, 'run_scenes') and len(set(scenes_of)) == len(scenes_of):
-            res = engine.run_scenes(jobs)
-        else:
-            res = [engine.run_scene(f, k, p, **kw) for f, k, p, kw in jobs]
-        for q, r in zip(qs, res):
-            out[q] = (pieces[q][0], pieces[q][1], pieces[q][2], r)
+    # One software pipeline over all of this rank's jobs (engine.run_scenes), the ranges that use received clouds last: their jobs are
+    # created lazily, so the wait for the transfers (a stream-ordered wait under nccl) is enqueued only when the pipeline reaches them --
+    # behind the whole scenes' kernels -- and the pipeline does not drain in between.  A rank that holds only one or two scenes (8 ranks on
+    # 8 scenes) has nothing to hide a scene's two host synchronisations behind, so its pair ranges are halved (down to `min_pairs`) until
+    # `min_jobs` jobs are in flight: the halves of a scene share one cloud cache -- the second finds the clouds the first extracted (the
+    # cache is filled when the first half's extraction is ENQUEUED, and the stream orders the kernels) -- and every pair's result is
+    # independent of the batch it is computed in, so the results are bitwise those of the unsplit range.
+    jobs = []                                                      # [piece index, a, b, cloud cache]
+    for q in order:
+        s, a, b = pieces[q]
+        jobs.append([q, a, b, cache.setdefault(s, {}) if s in shared else None])
+    pipelined = hasattr(engine, 'run_scenes') and all(scene_inputs(pieces[q][0])[3] is not None for q in order)
+    if pipelined:
+        while len(jobs) < min_jobs:
+            k = max(range(len(jobs)), key=lambda i: jobs[i][2] - jobs[i][1])
+            q, a, b, rd = jobs[k]
+            if b - a < 2 * min_pairs:
+                break
+            rd = {} if rd is None else rd
+            mid = (a + b) // 2
+            jobs[k:k + 1] = [[q, a, mid, rd], [q, mid, b, rd]]
+    state = {'waited': not recvs}
 
-    first = [q for q in order if pieces[q][0] not in importing]
-    last = [q for q in order if pieces[q][0] in importing]
-    waited = not recvs
-    if first:
-        run_group(first)
-    if last:
-        if not waited:
+    def call_of(job):
+        q, a, b, rd = job
+        s = pieces[q][0]
+        if s in importing and not state['waited']:
             for (sc, i), eqv in ex.wait().items():
                 f, k = scene_inputs(sc)[:2]
                 cache.setdefault(sc, {})[i] = engine.cloud_from_eqv(f[i], eqv, k[i])
-            waited = True
-        run_group(last)
+            state['waited'] = True
+        feats, keys, pairs, seeds = scene_inputs(s)
+        return feats, keys, pairs[a:b], dict(pair_seeds=None if seeds is None else seeds[a:b], ready=rd, **run_kw)
+
+    if pipelined:
+        res = engine.run_scenes([(lambda job=job: call_of(job)) for job in jobs])
+    else:
+        res = []
+        for job in jobs:
+            f, k, p, kw = call_of(job)
+            res.append(engine.run_scene(f, k, p, **kw))
+    for q in order:
+        out[q] = (pieces[q][0], pieces[q][1], pieces[q][2], [r for (qq, _, _, _), rs in zip(jobs, res) if qq == q for r in rs])
+    waited = state['waited']
     if ex is not None and not waited:                              # a rank that only sends: its sends complete before the step ends
         ex.wait()
     return out

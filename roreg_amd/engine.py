@@ -513,7 +513,9 @@ class RegistrationEngine:
             return done.value
 
     def run_scenes(self, jobs):
-        """Several scenes (or pair ranges), software-pipelined on the one stream: jobs = [(feats, keys, pair_ids, kwargs)] -> [[PairResult]].
+        """Several scenes (or pair ranges), software-pipelined on the one stream: jobs = [(feats, keys, pair_ids, kwargs)] -> [[PairResult]];
+        a job may also be a callable returning that tuple, evaluated when the pipeline reaches it (distributed.run_plan: the jobs that
+        first have to wait for received clouds).
         A scene synchronises with the host twice -- for the match counts (the hypothesis order needs every pair's M) and for the result
         table -- and between a download and the next launch the host shuffles, builds task tables and uploads: ~5 ms per scene with the GPU
         idle when the scenes run one after the other (3 % of a step, profiles/r02_bench_gpu_idle.txt).  Here scene i + 1's extraction and
@@ -523,9 +525,10 @@ class RegistrationEngine:
         prepared in); without them -- the reference's single global stream -- the scenes run one after the other.  Results are
         bitwise those of run_scene()."""
         import os
-        if (len(jobs) < 2 or self.phase_ms is not None or any(kw.get('pair_seeds') is None for _, _, _, kw in jobs)
+        materialise = lambda job: job() if callable(job) else job
+        if (len(jobs) < 2 or self.phase_ms is not None or any(not callable(j) and j[3].get('pair_seeds') is None for j in jobs)
                 or os.environ.get('ROREG_NO_PIPELINE')):                     # (the switch is for A/B measurements)
-            return [self.run_scene(f, k, p, **kw) for f, k, p, kw in jobs]
+            return [self.run_scene(f, k, p, **kw) for f, k, p, kw in map(materialise, jobs)]
         if self._side is None:
             self._side = torch.cuda.Stream()
         side = self._side
@@ -559,7 +562,7 @@ class RegistrationEngine:
 
         for i in range(len(jobs)):
             older = active
-            f, k, p, kw = jobs[i]                                    # the next scene's first stage is enqueued ...
+            f, k, p, kw = materialise(jobs[i])                       # the next scene's first stage is enqueued ...
             g = self._scene_steps(f, k, p, **kw)
             newest = []
             try:

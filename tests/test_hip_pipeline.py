@@ -233,6 +233,33 @@ def test_run_scenes_pipelined_equals_one_scene_at_a_time(kind):
             assert np.array_equal(a.trans, b.trans, equal_nan=True) and torch.equal(a.matches, b.matches)
 
 
+def test_run_plan_splits_a_lone_scene_without_changing_results():
+    """distributed.run_plan on a rank that holds ONE scene: the pair list is halved into four jobs that share the scene's cloud cache and
+    are pipelined (so the scene's host synchronisations hide behind its own other half); results bitwise those of engine.run_scene on the
+    whole list, in the list's order."""
+    import zlib
+    from roreg_amd import distributed as D
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    cfg = default_config(keynum=128, max_iter=300, ET='yohoo')
+    gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
+    et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
+    eng = RegistrationEngine(cfg, gf, et)
+    ds = synth.make_scene(9, n_clouds=9, n_kpts=160, overlap=0.6)                    # 36 pairs
+    keys = [ds.get_kps(i) for i in ds.pc_ids]
+    seeds = [zlib.crc32(f'{a}:{b}'.encode()) for a, b in ds.pair_ids]
+    want = eng.run_scene(ds.feats, keys, ds.pair_ids, keynum=128, max_iter=300, keep_matches=True, pair_seeds=seeds)
+    calls = []
+    orig = eng.run_scenes
+    eng.run_scenes = lambda jobs: (calls.append([len((j() if callable(j) else j)[2]) for j in jobs]), orig(jobs))[1]
+    got = D.run_plan(eng, [('s', 0, len(ds.pair_ids))], lambda s: (ds.feats, keys, ds.pair_ids, seeds), min_jobs=4, min_pairs=4,
+                     keynum=128, max_iter=300, keep_matches=True)
+    assert calls == [[9, 9, 9, 9]] and len(got) == 1 and got[0][:3] == ('s', 0, 36)
+    for a, b in zip(want, got[0][3]):
+        assert (a.id0, a.id1, a.n_match, a.recalltime) == (b.id0, b.id1, b.n_match, b.recalltime)
+        assert np.array_equal(a.trans, b.trans, equal_nan=True) and torch.equal(a.matches, b.matches)
+
+
 def test_engine_yohoc_equals_file_coupled_stages(tmp_path):
     """The rotation-bin estimator inside the device-resident engine against the file-coupled yohoc stages on the same
     generator stream: same matches, same winning try, same transform."""
