@@ -274,11 +274,14 @@ class EqvExchange:
         return out
 
 
-def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, min_jobs=4, min_pairs=48, **run_kw):
+def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, min_jobs=None, min_pairs=48, **run_kw):
     """One pass of this rank's share of a shard plan.  pieces [(scene, a, b)]; scene_inputs(scene) -> (feats, keys, pair_ids, pair_seeds or
     None) with feats / keys indexable by int cloud id; transfers: exchange_plan()'s list (empty: every rank extracts what it touches).
     Order: (0) the clouds this rank owns and others need are extracted and sent, the receives are posted; (1) the scenes this rank
     holds without imports; (2) the pair ranges that wait for imported clouds.  -> [(scene, a, b, [PairResult])] in `pieces` order."""
+    if min_jobs is None:
+        import os
+        min_jobs = int(os.environ.get('ROREG_PLAN_MIN_JOBS', 4))   # (the switch is for A/B measurements)
     sends = [t for t in transfers if t[2] == rank]
     recvs = [t for t in transfers if t[3] == rank]
     cache = {}                                                     # scene -> {cloud: CloudState}: exported, imported, reused across ranges

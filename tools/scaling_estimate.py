@@ -4,7 +4,7 @@ estimated efficiency = T(1) / (N * max_r T(r)).  With the extractor-output excha
 clouds it would RECEIVE are handed to it by a stand-in exchange object from copies extracted outside the timed region (the transfer itself
 -- 38.4 MB per cloud over xGMI beside the rank's whole scenes -- and the result-table all_gather of ~0.3 MB are not modelled); it still
 pays for rebuilding the received clouds' derivatives.
-Usage: python tools/scaling_estimate.py [steps] [uniform|banded] [--no-exchange]"""
+Usage: python tools/scaling_estimate.py [steps] [uniform|banded] [--no-exchange] [--worlds=1,2,4,8]"""
 import sys, time, types, zlib
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -32,7 +32,8 @@ class HandedOver:
 
 
 t1 = None
-for world in (1, 2, 4, 8):
+worlds = [int(x) for x in next((a.split('=')[1] for a in sys.argv if a.startswith('--worlds=')), '1,2,4,8').split(',')]
+for world in worlds:
     times, pairs, clouds = [], [], []
     for rank in range(world):
         scenes, plan, totals = bench.build_workload(args, rank, world, exchange=exchange)
@@ -57,5 +58,6 @@ for world in (1, 2, 4, 8):
         torch.cuda.empty_cache()
     if world == 1:
         t1 = times[0]
+    t1 = t1 if t1 is not None else float('nan')
     print(f'N={world} ({"exchange" if exchange else "replicated extraction"}): per-rank step time {["%.0f" % (1e3 * x) for x in times]} ms, pairs {pairs}, clouds extracted {clouds} '
           f'(sum {sum(clouds)});  throughput {1623 / max(times):.0f} pairs/s,  efficiency {t1 / (world * max(times)):.3f}', flush=True)
