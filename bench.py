@@ -95,9 +95,8 @@ def launch(args):
     port = args.master_port
     if not port:
         s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    argv = [a for a in sys.argv[1:]]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + argv
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
     return subprocess.call(cmd, env=env)
 
@@ -474,7 +473,6 @@ def main():
                               f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats); pairs sharded over the ranks by scene",
               'kitchen': f"3DMatch-kitchen-like scene: {totals['clouds']} clouds x {args.kpts} kpts, {total_pairs} pairs (mutual + yohoo, max_iter=1000)",
               'chunk': f"scene chunk per GPU: 16 clouds x {args.kpts} kpts, 60 pairs (mutual + yohoo, max_iter=1000)"}[args.workload]
-        devices = None
         out = {
             'metric': 'pair-registrations/sec', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': totals['scaling'],

@@ -281,7 +281,7 @@ def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, 
     holds without imports; (2) the pair ranges that wait for imported clouds.  -> [(scene, a, b, [PairResult])] in `pieces` order."""
     if min_jobs is None:
         import os
-        min_jobs = int(os.environ.get('ROREG_PLAN_MIN_JOBS', 4))   # (the switch is for A/B measurements)
+        min_jobs = int(os.environ.get('ROREG_PLAN_MIN_JOBS', 2))   # (the switch is for A/B measurements: 1 / 2 / 4 measured alike, profiles/r03_split_ab.txt)
     sends = [t for t in transfers if t[2] == rank]
     recvs = [t for t in transfers if t[3] == rank]
     cache = {}                                                     # scene -> {cloud: CloudState}: exported, imported, reused across ranges
@@ -306,7 +306,7 @@ def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, 
     # created lazily, so the wait for the transfers (a stream-ordered wait under nccl) is enqueued only when the pipeline reaches them --
     # behind the whole scenes' kernels -- and the pipeline does not drain in between.  A rank that holds only one or two scenes (8 ranks on
     # 8 scenes) has nothing to hide a scene's two host synchronisations behind, so its pair ranges are halved (down to `min_pairs`) until
-    # `min_jobs` jobs are in flight: the halves of a scene share one cloud cache -- the second finds the clouds the first extracted (the
+    # `min_jobs` jobs are in flight (default 2: a lone scene becomes two jobs): the halves of a scene share one cloud cache -- the second finds the clouds the first extracted (the
     # cache is filled when the first half's extraction is ENQUEUED, and the stream orders the kernels) -- and every pair's result is
     # independent of the batch it is computed in, so the results are bitwise those of the unsplit range.
     jobs = []                                                      # [piece index, a, b, cloud cache]

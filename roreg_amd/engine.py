@@ -14,7 +14,6 @@ import numpy as np
 import torch
 
 from . import hip
-from .group import tables
 
 
 @dataclass

@@ -187,6 +187,13 @@ def test_yohoc_sampling_replays_the_reference_generator_calls():
         assert np.array_equal(tail, np.random.rand(3))                      # generator advanced by exactly the same amount
         assert np.array_equal(bins, np.array(want_bins))
         assert np.array_equal(members[starts[bins][:, None] + picks], np.array(want_idx).reshape(-1, 3))
+        # the engine's per-pair streams: a private RandomState(seed) gives the draws np.random.seed(seed) gives, ends in the same state,
+        # and leaves the process-global generator untouched
+        np.random.seed(4242); before = np.random.get_state()[1].copy()
+        own = np.random.RandomState(trial)
+        bins_p, picks_p = hip.yohoc_draw(prob_v, counts, max_iter, rng=own)
+        assert np.array_equal(bins_p, bins) and np.array_equal(picks_p, picks) and np.array_equal(own.rand(3), tail)
+        assert np.array_equal(np.random.get_state()[1], before)
     # stacked Kabsch == per-triple Kabsch (same LAPACK call per matrix), including repeated points
     K0 = rng.uniform(0, 3, (500, 3)); K1 = K0[:, [1, 2, 0]] + rng.normal(0, 0.01, (500, 3))
     idx = rng.integers(0, 500, (300, 3)); idx[::7, 1] = idx[::7, 0]; idx[::13] = idx[::13, :1]

@@ -7,7 +7,7 @@ pays for rebuilding the received clouds' derivatives.
 Usage: python tools/scaling_estimate.py [steps] [uniform|banded] [--no-exchange] [--worlds=1,2,4,8]"""
 import sys, time, types, zlib
 sys.path.insert(0, '.')
-import numpy as np, torch
+import torch
 import bench
 from roreg_amd import distributed as D, synth
 from roreg_amd.engine import RegistrationEngine
