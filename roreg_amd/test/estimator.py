@@ -8,8 +8,6 @@
 
 Files: match_{k}/DR_index/{a}-{b}.npy [M] int64, match_{k}/Trans_pre/{a}-{b}.npy [M,3,4] f64,
 match_{k}/{yohoo|yohoc}/{it}iters/{a}-{b}.npz {trans [4,4] f64, recalltime}, .../pre.log."""
-import os
-
 import numpy as np
 import torch
 from tqdm import tqdm
@@ -18,9 +16,9 @@ from .. import hip
 from ..group import tables
 from ..network import name2network
 from ..utils.r_eval import compute_R_diff
-from ..utils.utils import make_non_exists_dir, load_checkpoint
 from . import _cache
-from .extractor import scene_feature_name
+from .extractor import restore_weights
+from ._files import SceneFiles
 
 
 def pre_log_entry(id0, id1, n_clouds, trans):
@@ -39,8 +37,20 @@ def R_pre_log(dataset, save_dir):
             out.write(pre_log_entry(id0, id1, len(dataset.pc_ids), estimate))
 
 
+def pose_errors(gt, pre):
+    """(rotation error in degrees, translation error = Euclidean distance of the translation columns) between two rigid transforms given
+    as 3x4 / 4x4 matrices -- the pair the estimators' `transdiff` methods return (test/estimator.py:155-158, 384-387)."""
+    gt, pre = np.asarray(gt), np.asarray(pre)
+    shift = gt[:3, 3] - pre[:3, 3]
+    return compute_R_diff(gt[:3, :3], pre[:3, :3]), np.sqrt(np.sum(np.square(shift)))
+
+
 def _dev64(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()
+
+
+def _dev_i64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.int64)).cuda()
 
 
 def _is_f32(scores):
@@ -94,22 +104,17 @@ class extractor_dr_index:
         return self.Batch_Des2R_torch(des1_eqv[None], des2_eqv[None])[0]
 
     def Rindex(self, dataset, keynum):
-        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        Save_dir = f'{match_dir}/DR_index'
-        make_non_exists_dir(Save_dir)
-        datasetname = scene_feature_name(dataset)
-        Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        files = SceneFiles(self.cfg, dataset, keynum)
+        files.make('DR_index')
         print(f'extract the drindex of the matches on {dataset.name}')
-        for pair in tqdm(dataset.pair_ids):
-            id0, id1 = pair
-            match_pps = torch.from_numpy(np.load(f'{match_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
-            ft = _cache.feat_dtype(self.cfg)
-            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy', ft)
-            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy', ft)
+        ft = _cache.feat_dtype(self.cfg)
+        for id0, id1 in tqdm(dataset.pair_ids):
+            rows = _dev_i64(files.load_matches(id0, id1))
+            path0, path1 = files.feature(id0), files.feature(id1)
             # irrep-domain bound + exact re-check of near ties: the literal arg-max with ~10x fewer operations (coefficients cached per cloud)
-            pre_idxs = hip.des2r(feats1, feats0, rows1=match_pps[:, 1].contiguous(), rows0=match_pps[:, 0].contiguous(),
-                                 coefs1=_cache.load_coefs(f'{Feature_dir}/{id1}.npy', ft), coefs0=_cache.load_coefs(f'{Feature_dir}/{id0}.npy', ft))
-            np.save(f'{Save_dir}/{id0}-{id1}.npy', pre_idxs.cpu().numpy())
+            anchors = hip.des2r(_cache.load_device(path1, ft), _cache.load_device(path0, ft), rows1=rows[:, 1].contiguous(), rows0=rows[:, 0].contiguous(),
+                                coefs1=_cache.load_coefs(path1, ft), coefs0=_cache.load_coefs(path0, ft))
+            np.save(files.dr_index(id0, id1), anchors.cpu().numpy())
 
 
 def three_point_transforms(kps0, kps1):
@@ -182,46 +187,36 @@ class yohoc_ransac:
         return float(ov[0].item())
 
     def transdiff(self, gt, pre):
-        Rdiff = compute_R_diff(gt[0:3:, 0:3], pre[0:3:, 0:3])
-        tdiff = np.sqrt(np.sum(np.square(gt[0:3, 3] - pre[0:3, 3])))
-        return Rdiff, tdiff
+        return pose_errors(gt, pre)
 
     def ransac_once(self, dataset, keynum, max_iter, pair):
-        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        Index_dir = f'{match_dir}/DR_index'
-        Save_dir = f'{match_dir}/yohoc/{max_iter}iters'
+        files = SceneFiles(self.cfg, dataset, keynum)
         id0, id1 = pair
-        Keys0 = dataset.get_kps(id0)
-        Keys1 = dataset.get_kps(id1)
-        scores = np.load(f'{match_dir}/scores/{id0}-{id1}.npy')
-        pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
-        Keys_m0_init = Keys0[pps[:, 0]]
-        Keys_m1_init = Keys1[pps[:, 1]]
-        sample_index = np.arange(pps.shape[0])
-        if self.cfg.RM:
-            sample_index = _select_top(scores, self.cfg.match_n)
-        Index = np.load(f'{Index_dir}/{id0}-{id1}.npy')[sample_index]
-        hyps = yohoc_hypotheses(Index, Keys_m0_init[sample_index], Keys_m1_init[sample_index], max_iter)
-        if hyps is None:
-            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=np.random.rand(4, 4), center=np.ones([6, 3]), recalltime=50000)
+        out = files.result('yohoc', max_iter, id0, id1)
+        scores = files.load_scores(id0, id1)
+        pps = files.load_matches(id0, id1)
+        pts0 = dataset.get_kps(id0)[pps[:, 0]]                     # the matched keypoints, all M of them (scored against)
+        pts1 = dataset.get_kps(id1)[pps[:, 1]]
+        drawn_from = _select_top(scores, self.cfg.match_n) if self.cfg.RM else np.arange(pps.shape[0])
+        anchors = np.load(files.dr_index(id0, id1))[drawn_from]
+        hyps = yohoc_hypotheses(anchors, pts0[drawn_from], pts1[drawn_from], max_iter)
+        if hyps is None:                                           # no rotation bin with two correspondences (estimator.py:214-218)
+            np.savez(out, trans=np.random.rand(4, 4), center=np.ones([6, 3]), recalltime=50000)
             return 0
-        k0 = _dev64(Keys_m0_init); k1 = _dev64(Keys_m1_init); w = _dev64(scores)
-        Trans = _dev64(hyps)
+        k0, k1, w, Trans = _dev64(pts0), _dev64(pts1), _dev64(scores), _dev64(hyps)
         _, best, _ = hip.ransac_score(k0, k1, w, Trans, self.inliner_dist, w_f32=_is_f32(scores))
         T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=Trans, best=best, w_f32=_is_f32(scores))
-        recall_time = int(best.item()) + 1                      # iter_ransac is 1-based when recorded
-        np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T2, recalltime=recall_time)
+        np.savez(out, trans=T2, recalltime=int(best.item()) + 1)   # the try count is 1-based when recorded (:241)
 
     def ransac(self, dataset, keynum, max_iter=1000):
-        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        Save_dir = f'{match_dir}/yohoc/{max_iter}iters'
-        make_non_exists_dir(Save_dir)
+        files = SceneFiles(self.cfg, dataset, keynum)
+        files.make(files.result_dir('yohoc', max_iter))
         print(f'Ransac with YOHO-C on {dataset.name}:')
         # the reference forks one process per pair (Pool(len(pair_ids)), estimator.py:258-262); hypothesis scoring is a
         # single kernel launch per pair here, so the pairs simply run in order on the device
         for pair in tqdm(dataset.pair_ids):
             self.ransac_once(dataset, keynum, max_iter, pair)
-        R_pre_log(dataset, Save_dir)
+        R_pre_log(dataset, files.result_dir('yohoc', max_iter))
         print('Done')
 
 
@@ -244,42 +239,32 @@ class extractor_localtrans():
         self.test_batch_size = self.cfg.bs_ET
 
     def _load_model(self):
-        if os.path.exists(self.best_model_fn):
-            checkpoint = load_checkpoint(self.best_model_fn)
-            self.network.load_state_dict(checkpoint['network_state_dict'], strict=False)
-        else:
-            raise ValueError("No model exists")
+        restore_weights(self.network, self.best_model_fn, strict=False)      # (the reference loads this checkpoint non-strictly, estimator.py:289)
 
     def Rt_pre(self, dataset, keynum):
         self._load_model()
         self.network.eval()
-        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        DRindex_dir = f'{match_dir}/DR_index'
-        Save_dir = f'{match_dir}/Trans_pre'
-        make_non_exists_dir(Save_dir)
-        datasetname = scene_feature_name(dataset)
-        FCGF_dir = f'{self.cfg.output_cache_fn}/{datasetname}/{self.cfg.backbone}_Input_Group_feature'
-        YOMO_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        files = SceneFiles(self.cfg, dataset, keynum)
+        files.make('Trans_pre')
         print(f'Extracting the local transformation on each correspondence of {dataset.name}')
-        for pair in tqdm(dataset.pair_ids):
-            id0, id1 = pair
-            pps = torch.from_numpy(np.load(f'{match_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
+        ft = _cache.feat_dtype(self.cfg)
+        step = self.test_batch_size
+        for id0, id1 in tqdm(dataset.pair_ids):
+            pps = _dev_i64(files.load_matches(id0, id1))
             rows0 = pps[:, 0].contiguous(); rows1 = pps[:, 1].contiguous()
-            ft = _cache.feat_dtype(self.cfg)
-            f0_in = _cache.load_device(f'{FCGF_dir}/{id0}.npy', ft); f1_in = _cache.load_device(f'{FCGF_dir}/{id1}.npy', ft)
-            f0_out = _cache.load_device(f'{YOMO_dir}/{id0}.npy', ft); f1_out = _cache.load_device(f'{YOMO_dir}/{id1}.npy', ft)
-            Index_pre = torch.from_numpy(np.load(f'{DRindex_dir}/{id0}-{id1}.npy').astype(np.int64)).cuda()
+            f0_in = _cache.load_device(files.input_feature(id0), ft); f1_in = _cache.load_device(files.input_feature(id1), ft)
+            f0_out = _cache.load_device(files.feature(id0), ft); f1_out = _cache.load_device(files.feature(id1), ft)
+            anchors = _dev_i64(np.load(files.dr_index(id0, id1)))
             keys0 = _dev64(dataset.get_kps(id0)); keys1 = _dev64(dataset.get_kps(id1))
             outs = []
-            for start in range(0, pps.shape[0], self.test_batch_size):
-                sl = slice(start, start + self.test_batch_size)
-                # feats1 is the "before rotation" side: it is the one permuted by the anchor (estimator.py:293-306)
-                x = hip.et_gather(f0_in, f1_in, f0_out, f1_out, Index_pre[sl].contiguous(), rows0=rows0[sl].contiguous(), rows1=rows1[sl].contiguous())
+            for start in range(0, pps.shape[0], step):
+                a, r0, r1 = (t[start:start + step].contiguous() for t in (anchors, rows0, rows1))
+                # cloud 1 is the "before rotation" side: it is the one permuted by the anchor (estimator.py:293-306)
+                x = hip.et_gather(f0_in, f1_in, f0_out, f1_out, a, rows0=r0, rows1=r1)
                 with torch.no_grad():
                     q = self.network.trunk_and_head(x)
-                outs.append(hip.quat_to_trans(q, Index_pre[sl].contiguous(), keys0, keys1, rows0=rows0[sl].contiguous(), rows1=rows1[sl].contiguous()))
-            Trans = torch.cat(outs, 0).cpu().numpy() if outs else np.zeros((0, 3, 4))
-            np.save(f'{Save_dir}/{id0}-{id1}.npy', Trans)
+                outs.append(hip.quat_to_trans(q, a, keys0, keys1, rows0=r0, rows1=r1))
+            np.save(files.trans_pre(id0, id1), torch.cat(outs, 0).cpu().numpy() if outs else np.zeros((0, 3, 4)))
 
 
 class yohoo_ransac:
@@ -299,43 +284,35 @@ class yohoo_ransac:
         return float(ov[0].item())
 
     def transdiff(self, gt, pre):
-        Rdiff = compute_R_diff(gt[0:3:, 0:3], pre[0:3:, 0:3])
-        tdiff = np.sqrt(np.sum(np.square(gt[0:3, 3] - pre[0:3, 3])))
-        return Rdiff, tdiff
+        return pose_errors(gt, pre)
 
     def ransac(self, dataset, keynum, max_iter=1000):
-        match_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        Trans_dir = f'{match_dir}/Trans_pre'
-        Save_dir = f'{match_dir}/yohoo/{max_iter}iters'
-        make_non_exists_dir(Save_dir)
+        files = SceneFiles(self.cfg, dataset, keynum)
+        files.make(files.result_dir('yohoo', max_iter))
         print(f'Ransac with YOHO-O on {dataset.name}:')
-        for pair in tqdm(dataset.pair_ids):
-            id0, id1 = pair
-            Keys0 = dataset.get_kps(id0)
-            Keys1 = dataset.get_kps(id1)
-            scores = np.load(f'{match_dir}/scores/{id0}-{id1}.npy')
-            pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
+        for id0, id1 in tqdm(dataset.pair_ids):
+            out = files.result('yohoo', max_iter, id0, id1)
+            scores = files.load_scores(id0, id1)
+            pps = files.load_matches(id0, id1)
             if pps.shape[0] == 0:
                 # an empty match list (the reference's matcher crashes before writing one, matcher.py:98-107): the engine's result for
                 # such a pair -- no hypothesis, no inlier, NaN transform, recalltime 0 -- so the two supported paths agree
                 T = np.full((4, 4), np.nan); T[3] = [0.0, 0.0, 0.0, 1.0]
-                np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T, recalltime=0)
+                np.savez(out, trans=T, recalltime=0)
                 continue
-            k0 = _dev64(Keys0[pps[:, 0]]); k1 = _dev64(Keys1[pps[:, 1]])
-            Trans = np.load(f'{Trans_dir}/{id0}-{id1}.npy')
-            rows = np.arange(Trans.shape[0])
-            if self.cfg.RM:
-                rows = _select_top(scores, self.cfg.match_n)           # hypotheses only from the best-scored matches
-            index = np.arange(rows.shape[0])
-            np.random.shuffle(index)                                    # estimator.py:423-425
-            hyp = torch.from_numpy(np.ascontiguousarray(rows[index[0:max_iter]], np.int64)).cuda()
-            w = _dev64(scores)
-            TransD = _dev64(Trans)
+            k0 = _dev64(dataset.get_kps(id0)[pps[:, 0]]); k1 = _dev64(dataset.get_kps(id1)[pps[:, 1]])
+            Trans = np.load(files.trans_pre(id0, id1))
+            # hypotheses: the local transforms of all matches, or of the best-scored share of them with --RM (:415-421), in the order of
+            # one shuffle of the process-global generator, the first max_iter of them (:423-425)
+            rows = _select_top(scores, self.cfg.match_n) if self.cfg.RM else np.arange(Trans.shape[0])
+            order = np.arange(rows.shape[0])
+            np.random.shuffle(order)
+            hyp = _dev_i64(rows[order[0:max_iter]])
+            w, TransD = _dev64(scores), _dev64(Trans)
             _, best, _ = hip.ransac_score(k0, k1, w, TransD, self.inliner_dist, hyp_rows=hyp, w_f32=_is_f32(scores))
             T2 = refine_twice(k0, k1, w, self.inliner_dist, Trans=TransD, hyp_rows=hyp, best=best, w_f32=_is_f32(scores))
-            recall_time = max(int(best.item()), 0)
-            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=T2, recalltime=recall_time)
-        R_pre_log(dataset, Save_dir)
+            np.savez(out, trans=T2, recalltime=max(int(best.item()), 0))
+        R_pre_log(dataset, files.result_dir('yohoo', max_iter))
 
 
 class yohoo:

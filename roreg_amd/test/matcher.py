@@ -5,8 +5,6 @@
   yoho_mat(cfg).run(dataset,keynum)      -- rotation-coherence matcher (Match_ot)
 
 Outputs: match_{keynum}/{id0}-{id1}.npy [M,2] int64 (col0 -> pc0, col1 -> pc1) and scores/{id0}-{id1}.npy."""
-import os
-
 import numpy as np
 import torch
 import tqdm
@@ -14,9 +12,10 @@ import tqdm
 from .. import hip
 from ..network import name2network
 from ..utils.knn_search import knn_module
-from ..utils.utils import make_non_exists_dir, to_cuda, load_checkpoint
+from ..utils.utils import to_cuda
 from . import _cache
-from .extractor import scene_feature_name
+from ._files import SceneFiles
+from .extractor import restore_weights
 
 
 class NMS_sample():
@@ -52,21 +51,18 @@ class NMS_sample():
         return chosen
 
 
-def _sample_pair(cfg, sampler, dataset, datasetname, id0, id1, n0, n1, keynum):
-    """Keypoint sampling of one pair; identical global-RNG consumption to matcher.py:75-88."""
+def _sample_pair(cfg, sampler, dataset, files, id0, id1, n0, n1, keynum):
+    """Keypoint sampling of one pair -> (rows of cloud 0, rows of cloud 1): NMS on the detector's rank scores with --RD, else the first
+    `keynum` of a shuffle of each cloud's rows -- two shuffles per pair on the process-global generator, cloud 0 first, exactly the
+    reference's consumption (matcher.py:75-88)."""
     if cfg.RD:
-        det_scores0 = np.load(f'{cfg.output_cache_fn}/{datasetname}/det_score/{id0}.npy')
-        det_scores1 = np.load(f'{cfg.output_cache_fn}/{datasetname}/det_score/{id1}.npy')
-        sample0 = sampler.sample(dataset.get_kps(id0), det_scores0)
-        sample1 = sampler.sample(dataset.get_kps(id1), det_scores1)
-    else:
-        sample0 = np.arange(n0)
-        sample1 = np.arange(n1)
-        np.random.shuffle(sample0)
-        np.random.shuffle(sample1)
-        sample0 = sample0[0:keynum]
-        sample1 = sample1[0:keynum]
-    return sample0, sample1
+        return tuple(sampler.sample(dataset.get_kps(pc), np.load(files.det_score(pc))) for pc in (id0, id1))
+    drawn = []
+    for n in (n0, n1):
+        rows = np.arange(n)
+        np.random.shuffle(rows)
+        drawn.append(rows[0:keynum])
+    return tuple(drawn)
 
 
 class mutual():
@@ -77,26 +73,21 @@ class mutual():
     def run(self, dataset, keynum=5000):
         self.sampler = NMS_sample(keynum, 5)
         print(f'Matching the keypoints with mutual on {dataset.name}')
-        Save_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        make_non_exists_dir(Save_dir)
-        Save_score_dir = f'{Save_dir}/scores'
-        make_non_exists_dir(Save_score_dir)
-        datasetname = scene_feature_name(dataset)
-        Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
-        for pair in tqdm.tqdm(dataset.pair_ids):
-            id0, id1 = pair
-            ft = _cache.feat_dtype(self.cfg)
-            eqv0 = _cache.load_device(f'{Feature_dir}/{id0}.npy', ft)   # N*32*60, HBM-resident across pairs
-            eqv1 = _cache.load_device(f'{Feature_dir}/{id1}.npy', ft)
+        files = SceneFiles(self.cfg, dataset, keynum)
+        files.make('scores')
+        ft = _cache.feat_dtype(self.cfg)
+        for id0, id1 in tqdm.tqdm(dataset.pair_ids):
+            eqv0 = _cache.load_device(files.feature(id0), ft)            # N*32*60, HBM-resident across pairs
+            eqv1 = _cache.load_device(files.feature(id1), ft)
             inv0 = hip.inv_descriptor(eqv0)                               # mean over g, / (norm + 1e-5)  (matcher.py:69-72)
             inv1 = hip.inv_descriptor(eqv1)
-            sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, eqv0.shape[0], eqv1.shape[0], keynum)
+            sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, files, id0, id1, eqv0.shape[0], eqv1.shape[0], keynum)
             s0 = torch.from_numpy(np.ascontiguousarray(sample0, np.int64)).cuda()
             s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
             buf, cnt = hip.mutual_match_batch([(inv0, inv1, s0, s1)])       # both NN directions + the mutual check (matcher.py:90-107)
-            match_pps = buf[0, :int(cnt.item())].cpu().numpy()
-            np.save(f'{Save_dir}/{id0}-{id1}.npy', match_pps)
-            np.save(f'{Save_score_dir}/{id0}-{id1}.npy', np.ones(match_pps.shape[0]))
+            found = buf[0, :int(cnt.item())].cpu().numpy()
+            np.save(files.matches(id0, id1), found)
+            np.save(files.scores(id0, id1), np.ones(found.shape[0]))     # (float64 ones, matcher.py:109)
 
 
 class yoho_mat():
@@ -108,73 +99,58 @@ class yoho_mat():
         self._load_model()
 
     def _load_model(self):
-        if os.path.exists(self.best_model_fn):
-            checkpoint = load_checkpoint(self.best_model_fn)
-            self.network.load_state_dict(checkpoint['network_state_dict'], strict=True)
-        else:
-            raise ValueError("No model exists")
+        restore_weights(self.network, self.best_model_fn, strict=True)
 
     def get_ot_match(self, batch):
+        """The network on one pair's batch dict -> (pairs [M,2] = (source row, its mutual match) for the matched source rows in increasing
+        order, or None when fewer than three rows are matched; their matching scores; matching_scores0; matching_scores1), all host arrays
+        (matcher.py:131-150)."""
         self.network.eval()
         with torch.no_grad():
-            result = self.network(to_cuda(batch))
-        matches0 = result['matches0'][0].cpu().numpy()
-        scores = result['matching_scores0'][0].cpu().numpy()
-        scores0 = scores
-        scores1 = result['matching_scores1'][0].cpu().numpy()
-        valid = np.where(matches0 != -1)[0]
-        score_ms = scores[valid]
-        if valid.shape[0] < 3:
-            pairs = None
-        else:
-            pairs = np.stack([valid, matches0[valid]], 1)
-        return pairs, np.array(score_ms), scores0, scores1
+            out = self.network(to_cuda(batch))
+        partner, scores0, scores1 = (out[k][0].cpu().numpy() for k in ('matches0', 'matching_scores0', 'matching_scores1'))
+        matched = np.where(partner != -1)[0]
+        pairs = np.stack([matched, partner[matched]], 1) if matched.shape[0] >= 3 else None
+        return pairs, np.array(scores0[matched]), scores0, scores1
 
     def run(self, dataset, keynum=2500):
         self.sampler = NMS_sample(keynum, 5)
-        Save_dir = f'{self.cfg.output_cache_fn}/{dataset.name}/match_{keynum}'
-        make_non_exists_dir(Save_dir)
-        Save_score_dir = f'{Save_dir}/scores'
-        make_non_exists_dir(Save_score_dir)
-        datasetname = scene_feature_name(dataset)
-        Feature_dir = f'{self.cfg.output_cache_fn}/{datasetname}/YOHO_Output_Group_feature'
+        files = SceneFiles(self.cfg, dataset, keynum)
+        files.make('scores')
         print(f'Matching the keypoints with rotation coherence matcher on {dataset.name}')
         # The reference runs the network pair by pair (matcher.py:187-206); one pair's 2500 points leave most of the chip idle, so the
         # sampled points of a group of pairs are stacked and go through the network in one pass with segmented per-pair operations
         # (Match_ot.match_many: bitwise the per-pair forward).  Sampling order (and its generator calls) is the reference's.
         self.network.eval()
         group, pend = int(getattr(self.cfg, 'rm_group', 16)), []
+        ft = _cache.feat_dtype(self.cfg)
 
         def flush():
             if not pend:
                 return
             with torch.no_grad():
                 outs = self.network.match_many([q[2] for q in pend])
-            m0_all = torch.cat([m for m, _ in outs]).cpu().numpy(); sc_all = torch.cat([x for _, x in outs]).cpu().numpy()
+            partner_all = torch.cat([m for m, _ in outs]).cpu().numpy(); score_all = torch.cat([x for _, x in outs]).cpu().numpy()
             o = 0
             for (id0, id1, _, sample0, sample1), (m, _) in zip(pend, outs):
                 n = int(m.shape[0])
-                matches0, sc = m0_all[o:o + n], sc_all[o:o + n]; o += n
-                valid = np.where(matches0 != -1)[0]
-                if valid.shape[0] < 3:
+                partner, sc = partner_all[o:o + n], score_all[o:o + n]; o += n
+                matched = np.where(partner != -1)[0]
+                if matched.shape[0] < 3:
                     # the reference crashes here (np.ones(1,2) is a TypeError, matcher.py:200-202); documented
                     # divergence: emit the single dummy correspondence it evidently intended
-                    matches = np.ones((1, 2), np.int64)
-                    scores = np.ones(1, np.float32)
+                    src_rows, tgt_rows, scores = np.ones(1, np.int64), np.ones(1, np.int64), np.ones(1, np.float32)
                 else:
-                    matches = np.stack([valid, matches0[valid]], 1)
-                    scores = sc[valid]
-                matches_in_former = np.concatenate([sample0[matches[:, 1]][:, None], sample1[matches[:, 0]][:, None]], axis=1)
-                np.save(f'{Save_dir}/{id0}-{id1}.npy', matches_in_former)
-                np.save(f'{Save_score_dir}/{id0}-{id1}.npy', scores)
+                    src_rows, tgt_rows, scores = matched, partner[matched], sc[matched]
+                # the network's source side is cloud 1, its target side cloud 0: column 0 of the file indexes cloud 0 (matcher.py:204-206)
+                np.save(files.matches(id0, id1), np.stack([sample0[tgt_rows], sample1[src_rows]], 1))
+                np.save(files.scores(id0, id1), scores)
             pend.clear()
 
-        for pair in tqdm.tqdm(dataset.pair_ids):
-            id0, id1 = pair
-            ft = _cache.feat_dtype(self.cfg)
-            feats0 = _cache.load_device(f'{Feature_dir}/{id0}.npy', ft)
-            feats1 = _cache.load_device(f'{Feature_dir}/{id1}.npy', ft)
-            sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, datasetname, id0, id1, feats0.shape[0], feats1.shape[0], keynum)
+        for id0, id1 in tqdm.tqdm(dataset.pair_ids):
+            feats0 = _cache.load_device(files.feature(id0), ft)
+            feats1 = _cache.load_device(files.feature(id1), ft)
+            sample0, sample1 = _sample_pair(self.cfg, self.sampler, dataset, files, id0, id1, feats0.shape[0], feats1.shape[0], keynum)
             s0 = torch.from_numpy(np.ascontiguousarray(sample0, np.int64)).cuda()
             s1 = torch.from_numpy(np.ascontiguousarray(sample1, np.int64)).cuda()
             keys0 = dataset.get_kps(id0)[sample0]
