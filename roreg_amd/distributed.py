@@ -186,9 +186,9 @@ def gather_table(local, device=None, counts=None):
     buf = torch.zeros((mx, ROW), dtype=torch.float64, device=dev)
     if len(local):
         buf[:len(local)] = torch.as_tensor(np.asarray(local, np.float64), device=dev)
-    out = torch.empty((world, mx, ROW), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(out, buf) if dist.get_backend() == 'nccl' else dist.all_gather(list(out.unbind(0)), buf)
-    out = out.cpu().numpy()
+    out = torch.empty((world * mx, ROW), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, buf)                         # (one call path for nccl and gloo: the CPU tests exercise it)
+    out = out.view(world, mx, ROW).cpu().numpy()
     return np.concatenate([out[r, :c] for r, c in enumerate(counts)], 0).reshape(-1, ROW)
 
 
