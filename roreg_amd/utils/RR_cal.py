@@ -3,7 +3,6 @@
 `nibabel.quaternions.mat2quat` (RR_cal.py:61) is restated through quaternion_from_matrix: both build the same
 symmetric 4x4 K matrix and return the eigenvector of its largest eigenvalue with w >= 0."""
 import os
-from collections import defaultdict
 
 import numpy as np
 
@@ -27,12 +26,10 @@ def translation_error(t1, t2):
 
 
 def computeTransformationErr(trans, info):
-    t = trans[:3, 3]
-    r = trans[:3, :3]
-    q = mat2quat(r)
-    er = np.concatenate([t, q[1:]], axis=0)
-    p = er.reshape(1, 6) @ info @ er.reshape(6, 1) / info[0, 0]
-    return p.item()
+    """Redwood's information-weighted pose error of a relative transform: e = (translation, vector part of the rotation's unit quaternion),
+    e^T info e / info[0, 0]  (RR_cal.py:47-65)."""
+    e = np.concatenate([trans[:3, 3], mat2quat(trans[:3, :3])[1:]], axis=0)
+    return (e.reshape(1, 6) @ info @ e.reshape(6, 1) / info[0, 0]).item()
 
 
 def read_trajectory(filename, dim=4):
@@ -106,56 +103,54 @@ def evaluate_registration(num_fragment, result, result_pairs, gt_pairs, gt, gt_i
     return tally['good'] * 1.0 / seen, tally['good'] * 1.0 / n_gt, flags, errors
 
 
+# result.txt, block per scene and closing block (text contract of RR_cal.py:332-397, including its missing line break after the first
+# "Mean precision" and the upper-case F of the RTE lines)
+_SCENE_TEXT = ("{name}\t {prec:.3f}\t {rec:.3f}\t {re_med:.3f}\t {te_med:.3f}\t {n:3d}\n"
+               "Mean precision: {prec:.3f}Registration Recall: {rec:.3f}\n"
+               "Mean median RRE: {re_mean:.3f}: +- {re_med:.3f}\n"
+               "Mean median RTE: {te_mean:.3F}: +- {te_med:.3f}\n")
+_TOTAL_TEXT = ("Mean precision: {prec_mean:.3f}: +- {prec_std:.3f}\n"
+               "Weighted precision: {prec_w:.3f}\n"
+               "Registration Recall: {rec_mean:.3f}: +- {rec_std:.3f}\n"
+               "Mean median RRE: {re_mean:.3f}: +- {re_std:.3f}\n"
+               "Mean median RTE: {te_mean:.3F}: +- {te_std:.3f}\n")
+
+
+def _scene_recall(cfg, dataset, keynum, max_iter, yoho_sign, nonconsecutive):
+    """One scene of the Redwood protocol from its pre.log, gt.log and gt.info -> dict of the per-scene figures (RR_cal.py:338-386)."""
+    gt_stem = dataset.gt_dir[:dataset.gt_dir.rfind('.')]
+    gt_pairs, gt_traj = read_trajectory(f'{gt_stem}.log')
+    n_fragments, gt_cov = read_trajectory_info(f'{gt_stem}.info')
+    est_pairs, est_traj = read_pre_trajectory(f'{cfg.output_cache_fn}/{dataset.name}/match_{keynum}/{yoho_sign}/{max_iter}iters/pre.log')
+    n_valid = sum(1 for i, j, _ in gt_pairs if not nonconsecutive or abs(int(i) - int(j)) > 1)
+    prec, rec, flags, errors = evaluate_registration(n_fragments, est_traj, est_pairs, gt_pairs, gt_traj, gt_cov, err2=cfg.tau_3,
+                                                     nonconsecutive=nonconsecutive)
+    gt_of_est = extract_corresponding_trajectors(est_pairs, gt_pairs, gt_traj)
+    hit = np.array(flags) == 0
+    re = rotation_error(gt_of_est[:, 0:3, 0:3], est_traj[:, 0:3, 0:3])[hit]
+    te = translation_error(gt_of_est[:, 0:3, 3:4], est_traj[:, 0:3, 3:4])[hit]
+    if re.shape[0] == 0:                                           # no success in the scene: the reference's placeholders
+        re = np.ones([n_valid]) * 180
+    if te.shape[0] == 0:
+        te = np.ones([n_valid])
+    return {'name': dataset.name, 'prec': prec, 'rec': rec, 'n': int(n_valid), 'flags': flags, 'errors': errors,
+            're_mean': np.mean(re), 're_med': np.median(re), 'te_mean': np.mean(te), 'te_med': np.median(te)}
+
+
 def benchmark(cfg, datasets, keynum, max_iter, yoho_sign='YOHO_O'):
-    """RR_cal.py:321-398: scene-mean registration recall + Eval_results/.../result.txt."""
-    c_flags, c_errors = {}, {}
-    re_per_scene, te_per_scene = defaultdict(list), defaultdict(list)
-    precision, recall, n_valids = [], [], []
+    """Registration recall of a whole test set under the Redwood / Predator protocol (RR_cal.py:321-398): the scene mean of the per-scene
+    recalls; writes Eval_results/{yoho_sign}_RR/{max_iter}iters/result.txt.  -> (recall, {scene: flags}, {scene: errors})."""
     wholesetname = datasets['wholesetname']
-    nonconsecutive = wholesetname != 'WHU-TLS'
     result_dir = f'{cfg.output_cache_fn}/{wholesetname}/Eval_results/{yoho_sign}_RR/{max_iter}iters'
     os.makedirs(result_dir, exist_ok=True)
-    f = open(f'{result_dir}/result.txt', 'w')
-    f.write("Scene\t prec.\t rec.\t re\t te\t samples\t\n")
-    for scene, dataset in datasets.items():
-        if scene == 'wholesetname':
-            continue
-        pre_dir = f'{cfg.output_cache_fn}/{dataset.name}/match_{keynum}/{yoho_sign}/{max_iter}iters'
-        gt_dir = dataset.gt_dir[0:str.rfind(dataset.gt_dir, '.')]
-        gt_pairs, gt_traj = read_trajectory(f'{gt_dir}.log')
-        n_valid = 0
-        for ele in gt_pairs:
-            n_valid += (abs(int(ele[0]) - int(ele[1])) > 1) if nonconsecutive else 1
-        n_valids.append(n_valid)
-        n_fragments, gt_traj_cov = read_trajectory_info(f'{gt_dir}.info')
-        est_pairs, est_traj = read_pre_trajectory(os.path.join(pre_dir, 'pre.log'))
-        temp_precision, temp_recall, c_flag, c_error = evaluate_registration(
-            n_fragments, est_traj, est_pairs, gt_pairs, gt_traj, gt_traj_cov, err2=cfg.tau_3, nonconsecutive=nonconsecutive)
-        c_flags[dataset.name] = c_flag
-        c_errors[dataset.name] = c_error
-        ext_gt_traj = extract_corresponding_trajectors(est_pairs, gt_pairs, gt_traj)
-        ok = np.array(c_flag) == 0
-        re = rotation_error(ext_gt_traj[:, 0:3, 0:3], est_traj[:, 0:3, 0:3])[ok]
-        te = translation_error(ext_gt_traj[:, 0:3, 3:4], est_traj[:, 0:3, 3:4])[ok]
-        if re.shape[0] == 0:
-            re = np.ones([n_valid]) * 180
-        if te.shape[0] == 0:
-            te = np.ones([n_valid])
-        for name, fn in [('mean', np.mean), ('median', np.median), ('min', np.min), ('max', np.max)]:
-            re_per_scene[name].append(fn(re)); te_per_scene[name].append(fn(te))
-        precision.append(temp_precision)
-        recall.append(temp_recall)
-        f.write("{}\t {:.3f}\t {:.3f}\t {:.3f}\t {:.3f}\t {:3d}\n".format(dataset.name, temp_precision, temp_recall, np.median(re), np.median(te), n_valid))
-        f.write("Mean precision: {:.3f}".format(temp_precision))
-        f.write("Registration Recall: {:.3f}\n".format(temp_recall))
-        f.write("Mean median RRE: {:.3f}: +- {:.3f}\n".format(np.mean(re), np.median(re)))
-        f.write("Mean median RTE: {:.3F}: +- {:.3f}\n".format(np.mean(te), np.median(te)))
-    weighted_precision = (np.array(n_valids) * np.array(precision)).sum() / np.sum(n_valids)
-    Registration_Recall = np.mean(np.array(recall))
-    f.write("Mean precision: {:.3f}: +- {:.3f}\n".format(np.mean(precision), np.std(precision)))
-    f.write("Weighted precision: {:.3f}\n".format(weighted_precision))
-    f.write("Registration Recall: {:.3f}: +- {:.3f}\n".format(Registration_Recall, np.std(np.array(recall))))
-    f.write("Mean median RRE: {:.3f}: +- {:.3f}\n".format(np.mean(re_per_scene['median']), np.std(re_per_scene['median'])))
-    f.write("Mean median RTE: {:.3F}: +- {:.3f}\n".format(np.mean(te_per_scene['median']), np.std(te_per_scene['median'])))
-    f.close()
-    return Registration_Recall, c_flags, c_errors
+    scenes = [_scene_recall(cfg, ds, keynum, max_iter, yoho_sign, nonconsecutive=wholesetname != 'WHU-TLS')
+              for key, ds in datasets.items() if key != 'wholesetname']
+    prec = np.array([sc['prec'] for sc in scenes]); rec = np.array([sc['rec'] for sc in scenes]); n = np.array([sc['n'] for sc in scenes])
+    re_med = [sc['re_med'] for sc in scenes]; te_med = [sc['te_med'] for sc in scenes]
+    with open(f'{result_dir}/result.txt', 'w') as out:
+        out.write("Scene\t prec.\t rec.\t re\t te\t samples\t\n")
+        for sc in scenes:
+            out.write(_SCENE_TEXT.format(**sc))
+        out.write(_TOTAL_TEXT.format(prec_mean=np.mean(prec), prec_std=np.std(prec), prec_w=(n * prec).sum() / np.sum(n), rec_mean=np.mean(rec),
+                                     rec_std=np.std(rec), re_mean=np.mean(re_med), re_std=np.std(re_med), te_mean=np.mean(te_med), te_std=np.std(te_med)))
+    return np.mean(rec), {sc['name']: sc['flags'] for sc in scenes}, {sc['name']: sc['errors'] for sc in scenes}
