@@ -24,7 +24,8 @@ extern "C" {
 /* Version of THIS header.  It is bumped whenever an existing entry point changes its argument list or a shared struct its size
  * (2: round 2's per-keypoint block scales -- roreg_gf_finalize, roreg_inv_descriptor, roreg_et_gather, roreg_dense_split/_f16x2,
  * roreg_lt_prepare_batch, roreg_group_conv_f16x2, roreg_lt_task 80 -> 96 bytes; 3: round 3 -- roreg_ransac_score / roreg_refine /
- * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order; roreg_ft_nonlin /
+ * roreg_irrep_gemm_f16x2 take the plane-layout flags).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
 #define ROREG_ABI_VERSION 3
 int roreg_abi_version(void);
@@ -403,7 +404,13 @@ int roreg_irrep_gemm_split(const float *const *X, float *const *Out, const float
 int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
                            const float *x_bound_dev, int w_exp, const float *next_u_dev, const float *next_v_dev, float *out_bound_dev,
                            int C, int O, int B, const int32_t *tiles_dev, int n_tiles,
-                           int tile_m /* 128 | 256 (O % 256 == 0): the m-tile the list was built with; 256 = 8-wave workgroups */, void *stream);
+                           int tile_m /* 128 | 256 (O % 256 == 0): the m-tile the list was built with; 256 = 8-wave workgroups */,
+                           int x_planes /* X[rho] is in HALF-BLOCK layout (roreg_ft_nonlin out_planes): row pitch and 32-column blocks of the word layout, but every
+                           128-byte block holds its 32 fp16 hi values followed by its 32 lo values (each half in the column order 0, 16, 1, 17, ...) instead of 32
+                           words hi | lo << 16; the
+                           activations then reach LDS by LDS-DMA and the matrix cores through transposing LDS reads, no register staging
+                           (needs tile_m = 256); results are
+                           bitwise those of the word layout */, void *stream);
 /* bound_out[b] (b < round_up(B,32); 0 for pad keypoints) = sqrt(60) max_{c,g} |act(x[b,c,g])| >= every coefficient of FT(act(x[b])), act =
  * ReLU(bn_scale_c x + bn_shift_c) or the identity (bn NULL): the x_bound of a layer whose input is a group-domain tensor [B,C,60]. */
 int roreg_row_bound(const void *x_spatial, int x_bf16 /* x is bfloat16 instead of float32 */, const float *bn_scale, const float *bn_shift,
@@ -419,6 +426,7 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                     float *out_rowmax /* optional, with out_spatial: [B], zeroed by the caller; receives max |out_spatial[b]| per keypoint (the block
                                          scale of roreg_group_conv_f16x2) */,
                     int spatial_bf16 /* x_spatial / resid_spatial point to bfloat16 tensors (BASELINE config 5: group features stored as bf16) */,
+                    int out_planes /* split = 2, Xin -> Xout: write Xout in the HALF-BLOCK layout roreg_irrep_gemm_f16x2(x_planes = 1) consumes */,
                     void *stream);
 
 /* Optional kernel timing for bench.py's measured rooflines (no reference counterpart: the reference has no profiler hooks).

@@ -206,23 +206,28 @@ __device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &
 //   columns sit in 32 consecutive slots rotated by 4 t (16-lane ds_read_b128 groups read 16 consecutive slots; the 8-lane ds_write_b128
 //   groups of the staging -- 8 consecutive columns = 4 blocks x 2 lanes -- hit bank quads q, q+4, q+8, q+12, q+1, ...: all distinct).
 //   BLOCKED (rounds 1-2; the opt-in ping-pong kernel): t * 32 + j, slot n ^ ((n >> 3) & 1).
+//   PAIRED (the LDS-DMA kernel): t * 32 + j / 2 + 16 (j % 2) -- the order in which ft_nonlin's half-block layout holds a 32-column block
+//   (16-bit position e = column e / 2 + 16 (e % 2): its 32-bit words pair columns w and w + 16, see ft_nonlin_kernel's store).
 // The arithmetic per output element is the same either way (same K order, same MFMA sequence): results are bitwise identical.
-template <bool INTERLEAVED>
-__device__ __forceinline__ int wave_col(int t, int j) { return INTERLEAVED ? 4 * j + t : t * 32 + j; }
-template <bool INTERLEAVED>
+enum : int { COLS_BLOCKED = 0, COLS_INTERLEAVED = 1, COLS_PAIRED = 2 };
+template <int MODE>
+__device__ __forceinline__ int wave_col(int t, int j) { return MODE == COLS_INTERLEAVED ? 4 * j + t : MODE == COLS_PAIRED ? t * 32 + (j >> 1) + 16 * (j & 1) : t * 32 + j; }
+template <int MODE>
 __device__ __forceinline__ int col_slot(int n /* column inside the 256-column tile */) {
-    if constexpr (!INTERLEAVED) return n ^ ((n >> 3) & 1);
+    static_assert(MODE != COLS_PAIRED, "the LDS-DMA kernel does not stage through fragment slots");
+    if constexpr (MODE == COLS_BLOCKED) return n ^ ((n >> 3) & 1);
     const int t = n & 3, q = (n & 127) >> 2;
     return (n & ~127) | (t * 32 + ((q + 4 * t) & 31));
 }
 
 // Epilogue shared by the fp16 x 2 / bf16 x 3 GEMM kernels: rescale, optional residual, store, optional bound propagation.
-template <int NP, int WO, bool INTERLEAVED = true>
+template <int NP, int WO, int COLS = COLS_INTERLEAVED>
 __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int ncol_wave, f32x16 (&acc)[2][4],
                                                     char *smem) {
     constexpr int NCOL = 256, OT = WO * 64, NT = WO * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
+    const unsigned jc = (unsigned)wave_col<COLS == COLS_PAIRED ? COLS_PAIRED : COLS_BLOCKED>(0, j);      // this lane's column inside a 32-column block (scalar-store modes)
     const int M = p.M[irr], N = p.N[irr];
     const int dirr = kIrrDim[irr];
     float *__restrict__ Out = p.Out[irr];
@@ -238,7 +243,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
     if constexpr (NP == 2) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = n0 + ncol_wave + wave_col<INTERLEAVED>(t, j);
+            const int n = n0 + ncol_wave + wave_col<COLS>(t, j);
             if (n < N) oscale[t] = ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(n, dirr)]) + p.w_exp));
         }
         if (want_bound) {                                        // (the LDS tiles are dead: the loop ended with a barrier)
@@ -269,12 +274,12 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const unsigned roff = (unsigned)(ot * 32 + rr + 8 * rq + 4 * h) * un;
-                            if constexpr (INTERLEAVED) {
+                            if constexpr (COLS == COLS_INTERLEAVED) {
                                 const float4 q = *reinterpret_cast<const float4 *>(ab + roff + 4u * (unsigned)j);
                                 res[rr][0] = q.x; res[rr][1] = q.y; res[rr][2] = q.z; res[rr][3] = q.w;
                             } else {
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) res[rr][t] = ab[roff + (unsigned)j + t * 32];
+                                for (int t = 0; t < 4; ++t) res[rr][t] = ab[roff + jc + t * 32];
                             }
                         }
                     }
@@ -293,11 +298,11 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
                             o4[t] = o;
                             if constexpr (decltype(has_bound)::value) bmax[t] = fmaxf(bmax[t], fmaf(ur, fabsf(o), vr));
                         }
-                        if constexpr (INTERLEAVED) {
+                        if constexpr (COLS == COLS_INTERLEAVED) {
                             *reinterpret_cast<float4 *>(ob + (unsigned)rl * un + 4u * (unsigned)j) = make_float4(o4[0], o4[1], o4[2], o4[3]);
                         } else {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) ob[(unsigned)rl * un + (unsigned)j + t * 32] = o4[t];
+                            for (int t = 0; t < 4; ++t) ob[(unsigned)rl * un + jc + t * 32] = o4[t];
                         }
                     }
                 }
@@ -316,7 +321,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
                 if constexpr (NP == 2) { if (want_bound) { ur = su[row]; vr = sv[row]; } }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int n = n0 + ncol_wave + wave_col<INTERLEAVED>(t, j);
+                    const int n = n0 + ncol_wave + wave_col<COLS>(t, j);
                     if (n >= N) continue;
                     float o = acc[ot][t][r];
                     if constexpr (NP == 2) o *= oscale[t];
@@ -331,7 +336,7 @@ __device__ __forceinline__ void gemm_split_epilogue(const GemmSplitDescs &p, int
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float bm = fmaxf(bmax[t], __shfl_xor(bmax[t], 32));
-                if (h == 0) atomicMax(cm + ncol_wave + wave_col<INTERLEAVED>(t, j), __float_as_uint(bm));      // non-negative floats order like their bit patterns
+                if (h == 0) atomicMax(cm + ncol_wave + wave_col<COLS>(t, j), __float_as_uint(bm));      // non-negative floats order like their bit patterns
             }
             __syncthreads();
             for (int i = tid; i < NCOL; i += NT) {
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     };
     int slot[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) slot[c] = po * NCOL + col_slot<true>(CPT * pp + c);
+    for (int c = 0; c < CPT; ++c) slot[c] = po * NCOL + col_slot<COLS_INTERLEAVED>(CPT * pp + c);
     auto convert_store = [&](int buf, const xpatch (&xr)[8]) {
         frag *dst = xs + buf * XBUF;
 #pragma unroll
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
     // fragment slots this lane reads in the MFMA phase
     int xslot[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) xslot[t] = h * NCOL + col_slot<true>(ncol_wave + wave_col<true>(t, j));
+    for (int t = 0; t < 4; ++t) xslot[t] = h * NCOL + col_slot<COLS_INTERLEAVED>(ncol_wave + wave_col<COLS_INTERLEAVED>(t, j));
     const int aslot = h * OT + wo * 64 + j;
 
     auto step = [&](int ks, int buf, xpatch (&xr_load)[8], const xpatch (&xr_use)[8]) {
@@ -625,6 +630,153 @@ __global__ __launch_bounds__(WO * 128, 2) void irrep_gemm_split_kernel(GemmSplit
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// fp16 x 2 GEMM, 256 x 256 tile, 8 waves, with the ACTIVATIONS delivered by LDS-DMA (round 3; the review's "X by LDS-DMA in fragment order").
+// ft_nonlin writes the operand in HALF-BLOCK layout (NonlinParams::out_planes): the row pitch and the 32-column blocks of the word layout, but
+// inside a block the 32 fp16 hi values first, then the 32 lo values, each half in the order 0, 16, 1, 17, ... (the transform then stores
+// consecutive words from consecutive lanes, as in the word layout, and a GEMM tile still reads 1 KB per k row; the column an MFMA lane holds
+// is wave_col<COLS_PAIRED>).  A 16-byte LDS-DMA piece is then 8 consecutive columns of one k row of one plane; the pieces of a K16 step are laid out
+// in LDS as [k / 4][column panel of 16][4 rows][16 columns] (a 128-byte block per (k quad, panel)), which is exactly what gfx950's transposing
+// ds_read_b64_tr_b16 turns into MFMA B fragments: a 16-lane group reads one block and every lane receives the 4 k values of its column; two
+// such reads (k quads 2h and 2h + 1) are the lane's 8-value fragment.  Both sides are conflict-free (the DMA writes lane-linear; the four
+// groups of a read cover 2 x 256 contiguous bytes).  No activation passes through a VGPR: per K16 step and wave 2 + 2 DMA instructions
+// instead of 2 + 8 loads, no byte permutes, no ds_write.  The weights, the MFMA order per accumulator and the epilogue are those of
+// irrep_gemm_split_kernel<.., 2, 4, .., 1> with the BLOCKED column mapping, so the results are bitwise the same.
+// Stages: weights double-buffered as before (DMA one step ahead); activations in THREE stages, DMA two steps ahead (they stream from
+// HBM, the weights from L2): at the end of step k `s_waitcnt vmcnt(2)` leaves only the two activation pieces of step k + 3 in flight.
+template <int BIG>
+__global__ __launch_bounds__(512, 2) void irrep_gemm_xdma_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+    using frag = f16x8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCOL = 256, OT = 256;
+    constexpr int XIMG = 16 * NCOL * 2, XSTAGE = 2 * XIMG;       // bytes: one plane's K16 x 256 image; both planes
+    constexpr int ABUF = 2 * 2 * OT;                             // weight fragments per stage
+    char *xs = smem;                                             // [3 stages][2 planes][XIMG]
+    frag *as = reinterpret_cast<frag *>(smem + 3 * XSTAGE);      // [2 stages][2 planes][2 k-octets][256 m]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
+    if (irr < 0) return;
+    const frag *__restrict__ W = reinterpret_cast<const frag *>(p.W[irr]);
+    const int K = p.K[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
+    const int wo = w % 4, wb = w / 4;
+    const int n0 = nt * NCOL;
+    const int ncol_wave = wb * 128;
+    const int nsteps = K / 16;                                   // even (C % 32 == 0)
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    // ---- activation DMA: wave w issues pieces m = 2w, 2w + 1 of the 16 KB step (8 KB per plane = 8 instructions of 64 pieces) ----
+    const int x_plane = w >> 2;
+    const char *xsrc[2];
+    int xdst[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int mm = (2 * w + i2) & 7;
+        const int pi = mm * 64 + lane;                           // 16-byte piece inside the plane's image: block beta = pi / 8
+        const int beta = pi >> 3, r = (pi & 7) >> 1, half = pi & 1;
+        const int k = 4 * (beta >> 4) + r;
+        int col = n0 + 16 * (beta & 15) + 8 * half;
+        if (col > N - 8) col = N - 8;                            // (columns beyond N are never stored)
+        xsrc[i2] = reinterpret_cast<const char *>(p.X[irr]) + (size_t)k * N * 4 + (col >> 5) * 128 + x_plane * 64 + (col & 31) * 2;
+        xdst[i2] = x_plane * XIMG + mm * 1024;
+    }
+    const size_t xstep = (size_t)16 * N * 4;                     // bytes between K16 steps
+    auto dma_x = [&](int i2, int kstep, int stage) {
+        const char *q = xsrc[i2] + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * xstep;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)q,
+                                         (__attribute__((address_space(3))) void *)(xs + stage * XSTAGE + xdst[i2]), 16, 0, 0);
+    };
+    // ---- weight DMA, as in irrep_gemm_split_kernel ----
+    const frag *wsrc = W + (size_t)(tid / OT) * Mpad + mt * OT + (tid % OT);
+    auto dma_w = [&](int sp, int kstep, int buf) {
+        const frag *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q + sp * split_stride),
+                                         (__attribute__((address_space(3))) void *)(as + buf * ABUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+    };
+    const int aslot = h * OT + wo * 64 + j;
+    // transposing fragment read: this lane's address inside a stage's plane-0 image for column block t = 0, k quad 2h
+    const unsigned xlane = (unsigned)(uintptr_t)xs + (unsigned)((2 * h * 16 + wb * 8 + ((lane >> 4) & 1)) * 128 + (lane & 15) * 8);
+    frag aA[2][2], aB[2][2], b[4][2];
+    auto read_a = [&](int buf, frag (&a)[2][2]) {
+        const frag *at = as + buf * ABUF + aslot;
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) a[ot][sp] = at[sp * (2 * OT) + ot * 32];
+    };
+    // (inline assembly: through the builtin the compiler guards every transposing read with s_waitcnt vmcnt(0) -- it cannot tell the read from
+    //  the LDS-DMA pieces in flight -- which would expose the DMA latency four times per step; the explicit waits below cover the real
+    //  dependences: a fragment is read after the barrier that follows its pieces' landing, and used after the next end-of-step wait, whose
+    //  asm statement takes the fragment registers as operands so that no use can be scheduled above it)
+    auto read_b = [&](unsigned stage_off, auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned a = xlane + stage_off;
+        unsigned long long q[4];
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q[0]) : "v"(a), "n"(t * 256));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q[1]) : "v"(a), "n"(t * 256 + 2048));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q[2]) : "v"(a), "n"(XIMG + t * 256));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q[3]) : "v"(a), "n"(XIMG + t * 256 + 2048));
+        struct Pair { unsigned long long lo, hi; };
+        b[t][0] = __builtin_bit_cast(frag, Pair{q[0], q[1]});
+        b[t][1] = __builtin_bit_cast(frag, Pair{q[2], q[3]});
+    };
+#define ROREG_WAIT_FRAGS(waits)                                                                                                          \
+    asm volatile(waits : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]) \
+                 :: "memory")
+    // One step = 24 MFMAs per wave in 12 pairs with the step's memory operations BETWEEN the pairs (see irrep_gemm_split_kernel's step2).
+    auto step = [&](int ks, int wbuf, unsigned xs_next /* stage of step ks + 1 */, int xs_fill /* stage of step ks (free), receives step ks + 3 */,
+                    const frag (&a)[2][2], frag (&an)[2][2]) {
+        const frag *aq = as + (wbuf ^ 1) * ABUF + aslot;
+        auto mm = [&](int t, int i) {                            // pair i of column block t: 0 = lo.hi, 1 = hi.lo, 2 = hi.hi (both row blocks)
+            const f16x8 bb = b[t][i == 1 ? 1 : 0];
+            const int ai = i == 0 ? 1 : 0;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][ai], bb, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][ai], bb, acc[1][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rb = [&](auto tc) { read_b(xs_next, tc); __builtin_amdgcn_sched_barrier(0); };
+        auto ra = [&](int ot) { an[ot][0] = aq[ot * 32]; an[ot][1] = aq[2 * OT + ot * 32]; __builtin_amdgcn_sched_barrier(0); };
+        using std::integral_constant;
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0, 0); dma_w(0, ks + 2, wbuf); __builtin_amdgcn_sched_barrier(0);
+        mm(0, 1); dma_w(1, ks + 2, wbuf); __builtin_amdgcn_sched_barrier(0);
+        mm(0, 2); rb(integral_constant<int, 0>{});
+        mm(1, 0); ra(0); mm(1, 1); ra(1); mm(1, 2); rb(integral_constant<int, 1>{});
+        mm(2, 0); dma_x(0, ks + 3, xs_fill); __builtin_amdgcn_sched_barrier(0);
+        mm(2, 1); dma_x(1, ks + 3, xs_fill); __builtin_amdgcn_sched_barrier(0);
+        mm(2, 2); rb(integral_constant<int, 2>{});
+        mm(3, 0); mm(3, 1); mm(3, 2); rb(integral_constant<int, 3>{});
+        // in issue order the step's two activation pieces are the newest: vmcnt(2) = this step's weights and the previous step's
+        // activations (needed by the next step's fragment reads) have landed; lgkmcnt(0) = this wave's fragment reads are done
+        ROREG_WAIT_FRAGS("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier");
+    };
+    dma_x(0, 0, 0); dma_x(1, 0, 0); dma_x(0, 1, 1); dma_x(1, 1, 1); dma_x(0, 2, 2); dma_x(1, 2, 2);
+    dma_w(0, 0, 0); dma_w(1, 0, 0); dma_w(0, 1, 1); dma_w(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    read_a(0, aA);
+    read_b(0u, std::integral_constant<int, 0>{}); read_b(0u, std::integral_constant<int, 1>{});
+    read_b(0u, std::integral_constant<int, 2>{}); read_b(0u, std::integral_constant<int, 3>{});
+    ROREG_WAIT_FRAGS("s_waitcnt lgkmcnt(0)\n\ts_barrier");                      // stage 0 (weights and activations) is overwritten from step 0 on
+    int cur = 0;                                                 // activation stage of step ks
+    for (int ks = 0; ks < nsteps; ks += 2) {
+        const int n1 = cur == 2 ? 0 : cur + 1, n2 = n1 == 2 ? 0 : n1 + 1;
+        step(ks, 0, (unsigned)(n1 * XSTAGE), cur, aA, aB);
+        step(ks + 1, 1, (unsigned)(n2 * XSTAGE), n1, aB, aA);
+        cur = n2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              // the clamped look-ahead pieces still target LDS the epilogue reuses
+#undef ROREG_WAIT_FRAGS
+    gemm_split_epilogue<2, 4, COLS_PAIRED>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // fp16 x 2 GEMM, 256 x 256 tile, 8 waves, "ping-pong" schedule.  The two waves that share a SIMD (w and w + 4: the two column halves of
 // the tile) alternate roles inside every K16 step instead of both interleaving matrix and memory work: after the step's barrier group 0
 // issues its 24 MFMAs back to back from fragment REGISTERS while group 1 does its LDS/VMEM work (fragment reads, staging of a later
@@ -768,7 +920,7 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p,
     if (k + 1 < nsteps) step(k + 1, R0, R2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_split_epilogue<2, 4, false>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
+    gemm_split_epilogue<2, 4, COLS_BLOCKED>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -789,6 +941,8 @@ struct NonlinParams {
     float *out_rowmax;           // optional, group-domain output: per-keypoint max |value written| [B] (zeroed by the caller; atomic max), the
                                  // block scale of the fp16 x 2 convolution that consumes the tensor
     int x_bf16;                  // the group-domain input / residual tensors are bfloat16 instead of float32
+    int out_planes;              // SPLIT = 2 coefficient output in HALF-BLOCK layout (see irrep_gemm_xdma_kernel): every 32-column block of a row holds
+                                 // its 32 fp16 hi values (order 0, 16, 1, 17, ...), then its 32 lo values, instead of 32 words hi | lo << 16
     float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
@@ -1127,6 +1281,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
                     if (lane < ROREG_G) p.out_spatial[((size_t)(b0 + bl) * C + c) * ROREG_G + lane] = tb[bl * 65 + lane];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (PACK_OUT && p.out_planes) {
+                // Half-block layout for the LDS-DMA GEMM: every 32-column block of a row (128 bytes in either layout) holds 16 words of fp16
+                // hi values, then 16 words of lo values; word w pairs the block's columns w and w + 16.  The two lanes of a pair (jn, jn + 16:
+                // the same coefficient of two keypoints) exchange their hi | lo << 16 words with one v_permlane16_swap; the lower lane
+                // stores hi(w) | hi(w + 16) << 16 at word w, the upper lane lo(w) | lo(w + 16) << 16 at word 16 + w: ONE 4-byte store per lane
+                // and coefficient to consecutive addresses, exactly the word layout's access pattern.
+                const int tb = tbi;
+                const unsigned sel = (jn & 16) ? 0x07060302u : 0x05040100u;    // v_perm(S0 = column w + 16, S1 = column w): the lo or the hi halves
+                unsigned *xw = reinterpret_cast<unsigned *>(p.Xout);
+                static_for<32>([&](auto ic) {
+                    constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
+                    constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
+                    if constexpr (q0 < ROREG_G) {
+                        const unsigned own = __float_as_uint(o[t][r]);
+                        // swaps the odd 16-lane rows of the first operand with the even rows of the second: [0] = the pair's lower lane's
+                        // word, [1] = the upper lane's word, in both lanes of the pair
+                        const auto pr = __builtin_amdgcn_permlane16_swap(own, own, false, false);
+                        const unsigned word = __builtin_amdgcn_perm(pr[1], pr[0], sel);
+                        if constexpr (q1 < ROREG_G) xw[OFF_OF(q0, q1, c, tb) + jn] = word;
+                        else {
+                            unsigned *dst = h ? reinterpret_cast<unsigned *>(p.dump + lane) : xw + OFF_Q(q0, c, tb) + jn;
+                            *dst = word;
+                        }
+                    }
+                });
             } else {
                 const int tb = tbi;                           // pad keypoints (b >= B) get zeros: the buffers stay fully defined
                 static_for<32>([&](auto ic) {
@@ -1349,7 +1528,7 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
 template <int NP, int WO>
 static int launch_gemm_split(const char *what, const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit,
                              const float *xbound, int w_exp, const float *nb_u, const float *nb_v, float *out_bound, int C, int O, int B,
-                             const int32_t *tiles_dev, int n_tiles, void *stream) {
+                             const int32_t *tiles_dev, int n_tiles, void *stream, int x_planes = 0) {
     static const int dims[5] = {1, 3, 3, 4, 5};
     GemmSplitDescs p;
     for (int r = 0; r < 5; ++r) {
@@ -1360,6 +1539,22 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
     p.xbound = xbound; p.w_exp = w_exp; p.nb_u = nb_u; p.nb_v = nb_v; p.out_bound = out_bound; p.O = O;
     constexpr int CT = 32;
     const size_t lds = 2 * (NP * 2 * 256 + NP * (WO * 64) * 2) * 16;     // two buffers of (activation planes + weight fragments) of a K16 step
+    if (x_planes) {
+        if constexpr (NP == 2 && WO == 4) {
+            // activations in half-block layout (ft_nonlin out_planes), delivered by LDS-DMA: irrep_gemm_xdma_kernel
+            const size_t lds_x = 3 * (2 * 16 * 256 * 2) + 2 * (2 * 2 * 256) * 16;      // three activation stages + two weight stages = 80 KB
+            auto kx = (long long)C * O == 256ll * 512 ? irrep_gemm_xdma_kernel<1> : irrep_gemm_xdma_kernel<0>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x);
+            if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
+            hipLaunchKernelGGL(kx, dim3(n_tiles), dim3(512), lds_x, roreg::as_stream(stream), p, tiles_dev);
+            hipError_t e2 = hipGetLastError();
+            if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
+            return 0;
+        } else {
+            roreg::set_error("%s: the half-block layout needs the fp16 x 2 kernel with tile_m = 256", what);
+            return 2;
+        }
+    }
     if constexpr (NP == 2 && WO == 4) {
         // opt-in (ROREG_GEMM_PP=1): measured 13.4 vs 12.7 ms per launch against the interleaved kernel on the same box (round 2) -- neither
         // the unbroken MFMA stream nor operands two steps deep in flight pay: the kernel is limited by the power the chip may draw
@@ -1396,15 +1591,16 @@ extern "C" int roreg_irrep_gemm_split(const float *const *X, float *const *Out, 
 
 extern "C" int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit2,
                                       const float *x_bound_dev, int w_exp, const float *next_u_dev, const float *next_v_dev, float *out_bound_dev,
-                                      int C, int O, int B, const int32_t *tiles_dev, int n_tiles, int tile_m, void *stream) {
+                                      int C, int O, int B, const int32_t *tiles_dev, int n_tiles, int tile_m, int x_planes, void *stream) {
     ROREG_REQUIRE(X && Out && Wsplit2 && tiles_dev && C > 0 && O > 0 && B > 0 && n_tiles > 0, "roreg_irrep_gemm_f16x2: bad arguments");
+    ROREG_REQUIRE(!x_planes || tile_m == 256, "roreg_irrep_gemm_f16x2: x_planes needs tile_m = 256");
     ROREG_REQUIRE(C % 32 == 0 && B % 32 == 0, "roreg_irrep_gemm_f16x2: C %% 32 and B %% 32 must be 0 (got %d, %d)", C, B);
     ROREG_REQUIRE(x_bound_dev, "roreg_irrep_gemm_f16x2: x_bound_dev (the per-keypoint bound the activations were split under) is required");
     ROREG_REQUIRE(!out_bound_dev || (next_u_dev && next_v_dev), "roreg_irrep_gemm_f16x2: out_bound_dev needs next_u_dev / next_v_dev");
     ROREG_REQUIRE(tile_m == 128 || tile_m == 256, "roreg_irrep_gemm_f16x2: tile_m must be 128 or 256 (the value the tile list was built with)");
     if (tile_m == 256)
         return launch_gemm_split<2, 4>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_bound_dev, w_exp, next_u_dev, next_v_dev, out_bound_dev, C, O, B,
-                                       tiles_dev, n_tiles, stream);
+                                       tiles_dev, n_tiles, stream, x_planes);
     return launch_gemm_split<2, 2>("roreg_irrep_gemm_f16x2", X, Out, Add, Wsplit2, x_bound_dev, w_exp, next_u_dev, next_v_dev, out_bound_dev, C, O, B,
                                    tiles_dev, n_tiles, stream);
 }
@@ -1444,7 +1640,7 @@ extern "C" int roreg_row_bound(const void *x_spatial, int x_bf16, const float *b
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
                                const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, const float *out_bound, float *out_rowmax,
-                               int spatial_bf16, void *stream) {
+                               int spatial_bf16, int out_planes, void *stream) {
     ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin: roreg_set_fourier_tables has not been called");
     ROREG_REQUIRE((Xin != nullptr) != (x_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xin / x_spatial");
     ROREG_REQUIRE((Xout != nullptr) != (out_spatial != nullptr), "roreg_ft_nonlin: exactly one of Xout / out_spatial");
@@ -1460,6 +1656,8 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_bound = out_bound; p.out_rowmax = out_rowmax; p.x_bf16 = spatial_bf16;
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
+    p.out_planes = out_planes;
+    ROREG_REQUIRE(!out_planes || (split == 2 && Xin && Xout), "roreg_ft_nonlin: out_planes is a layout of the fp16 x 2 coefficient -> coefficient pass");
     const long long n_tiles = (long long)C * p.tiles_per_c;
     hipStream_t s = roreg::as_stream(stream);
     roreg::ProfScope prof(roreg::PROF_FT_NONLIN, s);

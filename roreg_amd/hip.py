@@ -28,6 +28,8 @@ if GEMM_MODE == 'split':
     GEMM_MODE = 'bf16x3'
 if GEMM_MODE not in GEMM_MODES:
     raise ValueError(f"ROREG_GEMM must be one of {GEMM_MODES}, got {GEMM_MODE!r}")
+# ROREG_GEMM_XDMA=1: the fp16 x 2 GEMMs of the extractor's two big layers take their activations in half-block layout by LDS-DMA (A/B switch)
+XDMA = os.environ.get('ROREG_GEMM_XDMA', '0') == '1'
 ABI_VERSION = 3          # == ROREG_ABI_VERSION of include/roreg_hip.h; lib() refuses a library that reports another one
 _lib = None
 _tables_uploaded = False
@@ -95,9 +97,9 @@ PROTOTYPES = {
     'roreg_irrep_gemm_tiles_m': (c_size_t, [c_int, c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'roreg_irrep_gemm_split': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
-    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     'roreg_row_bound': (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P]),
-    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
 }
 
 
@@ -1029,13 +1031,14 @@ def coef_views(buf, C, B):
 _tile_cache = {}
 
 
-def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound=None, next_bound=None):
+def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound=None, next_bound=None, x_planes=False):
     """coefficients [60*C*Bp] -> [60*O*Bp] through the five per-irrep GEMMs (Bp = coef_pitch(B): the GEMMs run on the padded width).
     split: the five 3xbf16-split weight tensors (f32-accurate GEMM on the bf16 matrix cores) or None for the f32-input MFMA kernel.
     add: optional coefficient buffer [60*O*Bp] summed onto the result in the epilogue (residual short cut in the irrep domain).
     f16x2 = (five fp16x2 weight tensors, w_exp): X_buf holds the fp16 hi/lo words ft_nonlin(split='f16x2', out_bound=x_bound) wrote under the
     per-keypoint bound x_bound [Bp]; next_bound = (u [O], v [O]) (NextBound of the following nonlinearity) additionally returns the
-    per-keypoint bound [Bp] of the NEXT transform's coefficients: -> (out, bound)."""
+    per-keypoint bound [Bp] of the NEXT transform's coefficients: -> (out, bound).
+    x_planes: X_buf is in the half-block layout (ft_nonlin(..., planes=True): per 32-column block 32 fp16 hi values, then 32 lo values, columns in the order 0, 16, 1, 17, ...): the activations reach LDS by LDS-DMA; O % 256 == 0 only."""
     Bp = coef_pitch(B)
     if X_buf.numel() != 60 * C * Bp or (add is not None and add.numel() != 60 * O * Bp):
         raise HipError(f'irrep_gemm: coefficient buffers must hold 60*C*{Bp} floats (B={B} padded to the 32-keypoint pitch)')
@@ -1066,7 +1069,7 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound
             bound_out = torch.zeros(Bp, dtype=torch.float32, device=X_buf.device)
         _check(lib().roreg_irrep_gemm_f16x2(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(wl), _ptr(x_bound, torch.float32), int(w_exp),
                                             _ptr(nu, torch.float32), _ptr(nv, torch.float32), _ptr(bound_out), C, O, Bp,
-                                            _ptr(t, torch.int32), int(t.shape[0]), tile_m, _stream()), 'roreg_irrep_gemm_f16x2')
+                                            _ptr(t, torch.int32), int(t.shape[0]), tile_m, 1 if x_planes else 0, _stream()), 'roreg_irrep_gemm_f16x2')
     elif split is not None:
         _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]),
                                             _stream()), 'roreg_irrep_gemm_split')
@@ -1124,6 +1127,15 @@ def pack_coefs_f16x2(X_buf, C, B, bound=None):
     return out, bound
 
 
+def words_to_planes(X_words, C, B):
+    """The fp16 hi/lo word layout -> the half-block layout of ft_nonlin(planes=True) (test helper, torch ops): every 32-column block of a row
+    holds its 32 hi values (16 bit each, in the column order 0, 16, 1, 17, ...: word w pairs columns w and w + 16), then its 32 lo values in
+    the same order, in the 128 bytes the 32 words occupied."""
+    w = X_words.contiguous().view(torch.int32).view(-1, 2, 16)                        # [block][column // 16][column % 16]
+    hi = (w & 0xffff).to(torch.int16).transpose(1, 2); lo = (w >> 16).to(torch.int16).transpose(1, 2)         # [block][w][pair member]
+    return torch.cat([hi.reshape(-1, 32), lo.reshape(-1, 32)], 1).contiguous().view(torch.float32).view(-1)
+
+
 def unpack_coefs_f16x2(X_words, bound, C, B):
     """Inverse of the split: fp16 hi/lo words + per-keypoint bound -> float32 coefficients (hi + lo) * 2^-e.  Test helper."""
     Bp = coef_pitch(B)
@@ -1153,7 +1165,7 @@ def next_bound(bn, bias, bias2=None):
 
 
 def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None, resid_spatial=None, spatial_out=False,
-              g_map=None, Lout=60, Lvalid=60, split=False, out_bound=None, want_rowmax=False):
+              g_map=None, Lout=60, Lvalid=60, split=False, out_bound=None, want_rowmax=False, planes=False):
     """split='f16x2' with coefficient output: out_bound [Bp] (row_bound() or the producing GEMM's propagated bound) is required and the
     result holds fp16 hi/lo words for irrep_gemm(f16x2=...) instead of floats.  want_rowmax (group-domain output): also return the
     per-keypoint max |out[b]| [B] (the block scale of the fp16 x 2 convolution that follows)."""
@@ -1177,7 +1189,7 @@ def ft_nonlin(B, C, coef_in=None, x_spatial=None, bias=None, bias2=None, bn=None
     _check(lib().roreg_ft_nonlin(_ptr(coef_in, torch.float32), xs, _ptr(bias),
                                  _ptr(bias2), _ptr(scale), _ptr(shift), rs, xout, osp,
                                  _ptr(g_map, torch.int32), int(Lout), int(Lvalid), B, C, 2 if split == 'f16x2' else (1 if split else 0),
-                                 _ptr(out_bound, torch.float32), _ptr(amax), bf_x or bf_r, _stream()), 'roreg_ft_nonlin')
+                                 _ptr(out_bound, torch.float32), _ptr(amax), bf_x or bf_r, 1 if planes else 0, _stream()), 'roreg_ft_nonlin')
     return (out, amax) if want_rowmax else out
 
 

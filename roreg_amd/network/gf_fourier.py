@@ -87,12 +87,14 @@ class FourierGF:
             X0 = hip.ft_nonlin(B, 32, x_spatial=x, split=sp, out_bound=b0)
             T0, b1 = hip.irrep_gemm(X0, None, 32, 256, B, f16x2=self.l_in.wsplit2, x_bound=b0, next_bound=self.nb_1)
             del X0
-            X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=sp, out_bound=b1)
-            T1, b2 = hip.irrep_gemm(X1, None, 256, 512, B, f16x2=self.l_1.wsplit2, x_bound=b1, next_bound=self.nb_2)
+            # the two big layers' operands in half-block (hi | lo per 32 columns) layout: their activations reach LDS by LDS-DMA (hip.XDMA; csrc/fourier.hip irrep_gemm_xdma_kernel)
+            xd = hip.XDMA
+            X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=sp, out_bound=b1, planes=xd)
+            T1, b2 = hip.irrep_gemm(X1, None, 256, 512, B, f16x2=self.l_1.wsplit2, x_bound=b1, next_bound=self.nb_2, x_planes=xd)
             del X1
-            X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split=sp, out_bound=b2)
+            X2 = hip.ft_nonlin(B, 512, coef_in=T1, bias=self.l_1.bias, bn=self.bn_2, split=sp, out_bound=b2, planes=xd)
             del T1
-            T2, b3 = hip.irrep_gemm(X2, None, 512, 256, B, f16x2=self.l_2.wsplit2, x_bound=b2, next_bound=self.nb_3, add=T0)   # + identity short cut
+            T2, b3 = hip.irrep_gemm(X2, None, 512, 256, B, f16x2=self.l_2.wsplit2, x_bound=b2, next_bound=self.nb_3, add=T0, x_planes=xd)   # + identity short cut
             del X2, T0
             X3 = hip.ft_nonlin(B, 256, coef_in=T2, bias=self.l_2.bias, bias2=self.l_in.bias, bn=self.bn_3, split=sp, out_bound=b3)
             del T2

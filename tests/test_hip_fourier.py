@@ -241,6 +241,35 @@ def test_f16x2_block_scale_survives_outliers(group):
     assert err['f16'] < 3 * err['f32'] + 1e-7 and err['f16'] < 4e-6, err
 
 
+@pytest.mark.parametrize('C,Oc', [(256, 512), (512, 256)])
+@pytest.mark.parametrize('B', [40, 256, 1000])
+def test_plane_layout_gemm_is_bitwise_the_word_layout_gemm(group, C, Oc, B):
+    """ft_nonlin(planes=True) writes exactly the bits of the word layout, re-arranged into hi / lo planes, and the GEMM fed from the planes
+    by LDS-DMA (irrep_gemm_xdma_kernel) returns bit for bit what the word-layout kernel returns -- coefficients, the residual add and the
+    propagated bound -- for a batch below one column tile, an exact multiple, and a ragged one."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(100 * B + C)
+    torch.manual_seed(C)
+    L = _Layer(torch.nn.Conv2d(C, Oc, (1, 13)))
+    x = torch.from_numpy((rng.standard_normal((B, C, 60)) * np.exp(rng.standard_normal((B, C, 1)))).astype(np.float32)).cuda()
+    T = hip.ft_nonlin(B, C, x_spatial=x)                                             # float32 coefficients, pad keypoints zero
+    bias = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda()
+    bn = (torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda(), torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda())
+    Y = hip.ft_nonlin(B, C, coef_in=T, bias=bias, bn=bn, split=True)
+    yb = 1.01 * hip.pack_coefs_f16x2(Y, C, B)[1]
+    Xw = hip.ft_nonlin(B, C, coef_in=T, bias=bias, bn=bn, split='f16x2', out_bound=yb)
+    Xp = hip.ft_nonlin(B, C, coef_in=T, bias=bias, bn=bn, split='f16x2', out_bound=yb, planes=True)
+    assert torch.equal(Xp.view(torch.int32), hip.words_to_planes(Xw, C, B).view(torch.int32))
+    bn2 = (torch.from_numpy(rng.uniform(0.5, 1.5, Oc).astype(np.float32)).cuda(), torch.from_numpy(rng.standard_normal(Oc).astype(np.float32)).cuda())
+    nb = hip.next_bound(bn2, L.bias)
+    add = torch.from_numpy(rng.standard_normal(hip.coef_size(Oc, B)).astype(np.float32)).cuda()
+    for kw in ({}, {'add': add}):
+        Tw, bw = hip.irrep_gemm(Xw, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, **kw)
+        Tp, bp = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=True, **kw)
+        assert torch.equal(Tw.view(torch.int32), Tp.view(torch.int32)) and torch.equal(bw.view(torch.int32), bp.view(torch.int32))
+
+
 def test_gemm_bound_propagation(group):
     """The bound a GEMM epilogue hands to the next transform really bounds that transform's coefficients, per keypoint, and is not
     absurdly loose (the split keeps full accuracy while bound / max <= ~2^11)."""

@@ -33,15 +33,17 @@ def coefs(kind):
 for kind in ('random', 'ones', 'zeros', 'random'):
     L = layer(kind)
     Xp, xb = hip.pack_coefs_f16x2(coefs(kind), C, B)
+    if hip.XDMA:
+        Xp = hip.words_to_planes(Xp, C, B)
     t_end = time.perf_counter() + 1.5                       # let the power management settle on this operand class
     while time.perf_counter() < t_end:
-        hip.irrep_gemm(Xp, L.wpack, C, O, B, f16x2=L.wsplit2, x_bound=xb)
+        hip.irrep_gemm(Xp, L.wpack, C, O, B, f16x2=L.wsplit2, x_bound=xb, x_planes=hip.XDMA)
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 20
     e0.record()
     for _ in range(n):
-        hip.irrep_gemm(Xp, L.wpack, C, O, B, f16x2=L.wsplit2, x_bound=xb)
+        hip.irrep_gemm(Xp, L.wpack, C, O, B, f16x2=L.wsplit2, x_bound=xb, x_planes=hip.XDMA)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print(f'operands={kind:7s} B={B}: {ms:.3f} ms / launch   {2.0 * 244 * C * O * B / ms / 1e9:.1f} TFLOP/s real   {3 * 2.0 * 244 * C * O * B / ms / 1e9:.1f} TFLOP/s executed', flush=True)
