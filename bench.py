@@ -212,9 +212,11 @@ DTYPE_OF = {'f16x2': 'f32 (every f32 operand enters the fp16 matrix cores as hi 
             'bf16x3': 'f32 (f32-accurate: every f32 operand as 3 bf16 pieces = 24 bits, 6 cross products, f32 accumulate); f64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); f64 estimator'}
 MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}
-KERNEL_OF = {'f16x2': 'irrep_gemm_split_kernel<32,2,4,1,1> (fragment-pipelined 8-wave loop; GF 256->512 / 512->256 in the irrep domain, fp16 x 2 operands pre-split by ft_nonlin under '
-                      'per-keypoint block scales: 3 fp16 MFMAs per product)',
+KERNEL_OF = {'f16x2': 'irrep_gemm_xdma_kernel<1> (8-wave 256 x 256 tile, activations global -> LDS by DMA and LDS -> fragments by transposing reads; GF 256->512 / 512->256 in the '
+                      'irrep domain, fp16 x 2 operands pre-split by ft_nonlin under per-keypoint block scales: 3 fp16 MFMAs per product)',
              'bf16x3': 'irrep_gemm_split_kernel<32,3,2,1> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
+             'f16x2-words': 'irrep_gemm_split_kernel<32,2,4,1,1> (ROREG_GEMM_XDMA=0: fragment-pipelined 8-wave loop with the activations staged through registers; GF 256->512 / '
+                            '512->256 in the irrep domain, fp16 x 2 operands pre-split by ft_nonlin under per-keypoint block scales: 3 fp16 MFMAs per product)',
              'f32': 'irrep_gemm_kernel<32> (GF 256->512 / 512->256 in the irrep domain, f32-input MFMA)'}
 TAG_OF = {'f32': 'irrep_gemm', 'bf16x3': 'irrep_gemm_split', 'f16x2': 'irrep_gemm_f16x2'}
 
@@ -233,7 +235,8 @@ def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
         base.update({'kernel': KERNEL_OF[mode], 'achieved': gemm_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': gemm_tflops / PEAK_F32_MFMA_TFLOPS})
     else:
         k = MFMAS_PER_PRODUCT[mode]
-        base.update({'kernel': KERNEL_OF[mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
+        from roreg_amd import hip
+        base.update({'kernel': KERNEL_OF['f16x2-words' if mode == 'f16x2' and not hip.XDMA else mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
     return base
 
 

@@ -426,7 +426,7 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                     float *out_rowmax /* optional, with out_spatial: [B], zeroed by the caller; receives max |out_spatial[b]| per keypoint (the block
                                          scale of roreg_group_conv_f16x2) */,
                     int spatial_bf16 /* x_spatial / resid_spatial point to bfloat16 tensors (BASELINE config 5: group features stored as bf16) */,
-                    int out_planes /* split = 2, Xin -> Xout: write Xout in the HALF-BLOCK layout roreg_irrep_gemm_f16x2(x_planes = 1) consumes */,
+                    int out_planes /* split = 2 with Xout: write Xout in the HALF-BLOCK layout roreg_irrep_gemm_f16x2(x_planes = 1) consumes */,
                     void *stream);
 
 /* Optional kernel timing for bench.py's measured rooflines (no reference counterpart: the reference has no profiler hooks).

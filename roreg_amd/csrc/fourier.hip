@@ -969,6 +969,49 @@ constexpr QRows make_qrows() {
 }
 constexpr QRows kQ = make_qrows();
 
+// Which coefficient the forward transform produces in which MFMA output row.  The two half-waves of one store instruction hold output rows
+// m and m + 4; the assignment of coefficients to rows is free (it only permutes the rows of the forward table), so the 32 row pairs are filled
+// such that a pair's two addresses differ by a WAVE-UNIFORM amount:
+//   24 pairs (rho, i, l), (rho, i + 1, l)   : neighbouring 128-byte blocks of one row segment -> the instruction covers 256 contiguous bytes,
+//    4 pairs (rho, 0, l), (rho, 0, l + 1)   : the same block of two consecutive rows (d odd: rows of 3 / 5 blocks leave one over),
+//    4 pairs (rho, 0, l_last), none         : the last left-over of the d = 1, 3, 3, 5 irreps with one of the four unused rows 60..63.
+// Every store is then (scalar row base) + (one of three per-lane byte offsets fixed for the whole kernel) + immediate: no per-access vector
+// address arithmetic (with rows in (rho, i, l) order every access needed a 64-bit select and add: the kernel is issue-bound at its occupancy
+// and address arithmetic was a third of its instructions).  The INVERSE transform keeps its K slots in (rho, i, l) order: permuting them
+// would change the order of its float32 sums, i.e. the low bits of every feature.
+struct PairSlots {
+    int qa[32], qb[32];          // canonical coefficient index off_rho + i*d + l of the two members; qb = 64: none
+    int row[32];                 // row id of member a: 0 | 1..3 | 4..6 | 7..10 | 11..15  (rho, l)
+    int i[32];                   // block of member a inside its row segment
+    int kind[32];                // 0: member b is the next block; 1: member b is the same block of the next row; 2: no member b
+    int d[32];
+    int row_alpha[16], row_d[16];         // a row's first coefficient-row index off_rho + l*d, and its irrep dimension
+};
+constexpr PairSlots make_pair_slots() {
+    PairSlots t{};
+    const int dims[NIRR] = {1, 3, 3, 4, 5};
+    int off = 0, s = 0, row0 = 0;
+    for (int r = 0; r < NIRR; ++r) {
+        const int d = dims[r];
+        for (int l = 0; l < d; ++l) {
+            t.row_alpha[row0 + l] = off + l * d; t.row_d[row0 + l] = d;
+            for (int i = d % 2; i < d; i += 2, ++s) {
+                t.qa[s] = off + i * d + l; t.qb[s] = off + (i + 1) * d + l; t.row[s] = row0 + l; t.i[s] = i; t.kind[s] = 0; t.d[s] = d;
+            }
+        }
+        if (d % 2)
+            for (int l = 0; l < d; l += 2, ++s) {
+                t.qa[s] = off + l; t.row[s] = row0 + l; t.i[s] = 0; t.d[s] = d;
+                if (l + 1 < d) { t.qb[s] = off + l + 1; t.kind[s] = 1; } else { t.qb[s] = 64; t.kind[s] = 2; }
+            }
+        off += d * d; row0 += d;
+    }
+    return t;
+}
+constexpr PairSlots kPS = make_pair_slots();
+// coefficient produced in row m = 32 t + (r & 3) + 8 (r >> 2) + 4 h of the forward transform (pair slot t*16 + r); >= 60: none
+constexpr int slot_out_q(int m) { const int mm = m & 31, s = (m >> 5) * 16 + (mm & 3) + 4 * (mm >> 3); return (mm & 4) ? kPS.qb[s] : kPS.qa[s]; }
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
@@ -1026,6 +1069,19 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
     const size_t hmask = (size_t)0 - (size_t)h;                  // all ones for the second half-wave
 #define OFF_Q(Q, c, tb) ((size_t)(kQ.alpha[Q] * C + (c) * kQ.d[Q]) * Bp + (size_t)(tb) * (32 * kQ.d[Q]) + kQ.i[Q] * 32)
 #define OFF_OF(Q0, Q1, c, tb) (OFF_Q(Q0, c, tb) + ((OFF_Q(Q1, c, tb) - OFF_Q(Q0, c, tb)) & hmask))   // arithmetic select (mask, not a quarter-rate multiply): one load, no exec-masked pair
+    // Pair-slot addressing of the stores (kPS): byte address = buffer + 4 * row_off(row, c, tb) [scalar] + 128 * i [immediate] + lane offset [one of three VGPRs]
+    const unsigned lane_next = (unsigned)lane * 4u;                                                     // second half-wave: the next 128-byte block
+    const unsigned lane_row3 = (unsigned)jn * 4u + (h ? 12u * (unsigned)C * (unsigned)p.Bp : 0u);       // ... the same block one row down, d = 3
+    const unsigned lane_row5 = (unsigned)jn * 4u + (h ? 20u * (unsigned)C * (unsigned)p.Bp : 0u);       // ... d = 5   (< 2^32: checked by the launcher)
+    auto row_off = [&](auto rc, int c, int tb) -> size_t {        // float offset of row `rc` (see PairSlots::row) of channel c, keypoint tile tb: wave-uniform
+        constexpr int R = decltype(rc)::value;
+        return ((size_t)(kPS.row_alpha[R] * C) + (size_t)(c * kPS.row_d[R])) * Bp + (size_t)tb * (32 * kPS.row_d[R]);
+    };
+    auto slot_ptr = [&](auto sc, const void *buf, int c, int tb) -> const char * {      // address of pair slot `sc`'s two members for this lane
+        constexpr int S = decltype(sc)::value;
+        const char *rb = reinterpret_cast<const char *>(buf) + 4 * row_off(std::integral_constant<int, kPS.row[S]>{}, c, tb) + 128 * kPS.i[S];
+        return rb + (kPS.kind[S] == 1 ? (kPS.d[S] == 3 ? lane_row3 : lane_row5) : lane_next);
+    };
 
     // software pipeline: the 30 coefficient rows of the NEXT column tile are requested before the 124 MFMAs of the current one
     constexpr int NCV = IN_SPATIAL ? 32 : (SPLIT != 0 ? 32 : 30);
@@ -1273,7 +1329,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int qq = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int qq = h ? kPS.qb[t * 16 + r] : kPS.qa[t * 16 + r];      // canonical coefficient index of this lane's row (64: none)
                         if (qq < ROREG_G) tb[jn * 65 + qq] = o[t][r];
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1289,36 +1345,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 // and coefficient to consecutive addresses, exactly the word layout's access pattern.
                 const int tb = tbi;
                 const unsigned sel = (jn & 16) ? 0x07060302u : 0x05040100u;    // v_perm(S0 = column w + 16, S1 = column w): the lo or the hi halves
-                unsigned *xw = reinterpret_cast<unsigned *>(p.Xout);
                 static_for<32>([&](auto ic) {
-                    constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
-                    constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
-                    if constexpr (q0 < ROREG_G) {
-                        const unsigned own = __float_as_uint(o[t][r]);
-                        // swaps the odd 16-lane rows of the first operand with the even rows of the second: [0] = the pair's lower lane's
-                        // word, [1] = the upper lane's word, in both lanes of the pair
-                        const auto pr = __builtin_amdgcn_permlane16_swap(own, own, false, false);
-                        const unsigned word = __builtin_amdgcn_perm(pr[1], pr[0], sel);
-                        if constexpr (q1 < ROREG_G) xw[OFF_OF(q0, q1, c, tb) + jn] = word;
-                        else {
-                            unsigned *dst = h ? reinterpret_cast<unsigned *>(p.dump + lane) : xw + OFF_Q(q0, c, tb) + jn;
-                            *dst = word;
-                        }
-                    }
+                    constexpr int S = decltype(ic)::value, t = S / 16, r = S % 16;          // pair slot S = registers o[t][r] of the two half-waves
+                    const unsigned own = __float_as_uint(o[t][r]);
+                    // swaps the odd 16-lane rows of the first operand with the even rows of the second: [0] = the pair's lower lane's
+                    // word, [1] = the upper lane's word, in both lanes of the pair
+                    const auto pr = __builtin_amdgcn_permlane16_swap(own, own, false, false);
+                    const unsigned word = __builtin_amdgcn_perm(pr[1], pr[0], sel);
+                    unsigned *dst = reinterpret_cast<unsigned *>(const_cast<char *>(slot_ptr(ic, p.Xout, c, tb)));
+                    if (kPS.kind[S] != 2 || h == 0) *dst = word;          // (no member b: the second half-wave is masked off, the store is still issued)
                 });
             } else {
                 const int tb = tbi;                           // pad keypoints (b >= B) get zeros: the buffers stay fully defined
                 static_for<32>([&](auto ic) {
-                    constexpr int t = decltype(ic)::value / 16, r = decltype(ic)::value % 16;
-                    constexpr int q0 = t * 32 + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;          // this lane's coefficient is q0 + 4*h
-                    if constexpr (q0 < ROREG_G) {
-                        if constexpr (q1 < ROREG_G) p.Xout[OFF_OF(q0, q1, c, tb) + jn] = o[t][r];
-                        else {      // q1 does not exist: the second half-wave stores into a dump row instead of branching around the store,
-                                    // so every tile issues the same 32 stores and the pipeline's vmcnt bookkeeping stays exact
-                            float *dst = h ? p.dump + lane : p.Xout + OFF_Q(q0, c, tb) + jn;
-                            *dst = o[t][r];
-                        }
-                    }
+                    constexpr int S = decltype(ic)::value, t = S / 16, r = S % 16;
+                    float *dst = reinterpret_cast<float *>(const_cast<char *>(slot_ptr(ic, p.Xout, c, tb)));
+                    if (kPS.kind[S] != 2 || h == 0) *dst = o[t][r];
                 });
             }
         }
@@ -1349,7 +1391,7 @@ float *g_dump = nullptr;
 extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)], orthonormal */) {
     ROREG_REQUIRE(F_host, "roreg_set_fourier_tables: null table");
     // A1[s][tile][lane] = F[q = 2s + (lane>>5)][g = tile*32 + (lane&31)]   (inverse transform: x(g) = sum_q F[q][g] coef[q])
-    // A2[(t,r)][tile][lane] = F[q' = tile*32 + (lane&31)][g = t*32 + (r&3) + 8(r>>2) + 4(lane>>5)]
+    // A2[(t,r)][tile][lane] = F[q' = slot_out_q(tile*32 + (lane&31))][g = t*32 + (r&3) + 8(r>>2) + 4(lane>>5)]
     static float A1[30 * 2 * 64], A2[32 * 2 * 64];
     for (int s = 0; s < 30; ++s)
         for (int tile = 0; tile < 2; ++tile)
@@ -1361,7 +1403,7 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
         for (int r = 0; r < 16; ++r)
             for (int tile = 0; tile < 2; ++tile)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int qq = tile * 32 + (lane & 31), g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int qq = slot_out_q(tile * 32 + (lane & 31)), g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     A2[((t * 16 + r) * 2 + tile) * 64 + lane] = (qq < 60 && g < 60) ? F_host[qq * 60 + g] : 0.f;
                 }
     if (!g_A1) {
@@ -1376,7 +1418,7 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
     }
     // the same tables as 3 x bf16 split fragments of the K=16 MFMA: [step st][tile][plane][lane][e]
     //   A1s: F[q = 16 st + 8 h + e][g = tile*32 + j]                                  (inverse)
-    //   A2s: F[q' = tile*32 + j][g = 32 (st>>1) + (r&3) + 8 (r>>2) + 4 h], r = 8 (st&1) + e   (forward; K order = accumulator registers)
+    //   A2s: F[q' = slot_out_q(tile*32 + j)][g = 32 (st>>1) + (r&3) + 8 (r>>2) + 4 h], r = 8 (st&1) + e   (forward; K order = accumulator registers)
     static uint16_t A1s[4 * 2 * 3 * 64 * 8], A2s[4 * 2 * 3 * 64 * 8];
     auto split3_host = [](float x, uint16_t out[3]) {                  // round-to-nearest-even pieces of the exact remainders
         float rem = x;
@@ -1397,7 +1439,7 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
                     const int j = lane & 31, h = lane >> 5;
                     const int q1 = 16 * st + 8 * h + e, g1 = tile * 32 + j;
                     const float f1 = (q1 < 60 && g1 < 60) ? F_host[q1 * 60 + g1] : 0.f;
-                    const int r = 8 * (st & 1) + e, q2 = tile * 32 + j, g2 = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int r = 8 * (st & 1) + e, q2 = slot_out_q(tile * 32 + j), g2 = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float f2 = (q2 < 60 && g2 < 60) ? F_host[q2 * 60 + g2] : 0.f;
                     uint16_t p1[3], p2[3];
                     split3_host(f1, p1); split3_host(f2, p2);
@@ -1436,7 +1478,7 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
                     const int j = lane & 31, h = lane >> 5;
                     const int q1 = 16 * st + 8 * h + e, g1 = tile * 32 + j;
                     const float f1 = (q1 < 60 && g1 < 60) ? std::ldexp(F_host[q1 * 60 + g1], g_f_exp) : 0.f;
-                    const int r = 8 * (st & 1) + e, q2 = tile * 32 + j, g2 = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int r = 8 * (st & 1) + e, q2 = slot_out_q(tile * 32 + j), g2 = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float f2 = (q2 < 60 && g2 < 60) ? std::ldexp(F_host[q2 * 60 + g2], g_f_exp) : 0.f;
                     const uint16_t h1 = f2h(f1), h2 = f2h(f2);
                     const size_t hi_at = ((((size_t)st * 2 + tile) * 2 + 0) * 64 + lane) * 8 + e, lo_at = hi_at + 64 * 8;
@@ -1637,6 +1679,21 @@ extern "C" int roreg_row_bound(const void *x_spatial, int x_bf16, const float *b
     return 0;
 }
 
+// The transform kernels are persistent: every wave walks tiles wave, wave + n_waves, ...  The grid is a whole number of "rounds" of what the
+// chip holds at once (occupancy differs per variant: 2-3 workgroups per SIMD row), so that no round runs part-filled.
+template <void (*KERN)(NonlinParams)>
+static void launch_ft(const NonlinParams &p, long long n_tiles, hipStream_t s) {
+    static const int resident = [] {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERN, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return per_cu * cus;
+    }();
+    static const int rounds = [] { const char *e = getenv("ROREG_FT_ROUNDS"); const int r = e ? atoi(e) : 0; return r > 0 ? r : 4; }();
+    const long long want = (n_tiles + 3) / 4, cap = (long long)resident * rounds;
+    hipLaunchKernelGGL(KERN, dim3((unsigned)(want > cap ? cap : want)), dim3(256), 0, s, p);
+}
+
 extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const float *bias, const float *bias2,
                                const float *bn_scale, const float *bn_shift, const float *resid_spatial, float *Xout, float *out_spatial,
                                const int32_t *g_map, int Lout, int Lvalid, int B, int C, int split, const float *out_bound, float *out_rowmax,
@@ -1657,7 +1714,8 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     p.out_planes = out_planes;
-    ROREG_REQUIRE(!out_planes || (split == 2 && Xin && Xout), "roreg_ft_nonlin: out_planes is a layout of the fp16 x 2 coefficient -> coefficient pass");
+    ROREG_REQUIRE((unsigned long long)C * p.Bp * 20ull < (1ull << 32), "roreg_ft_nonlin: C * round_up(B, 32) must stay below 2^32 / 20 (32-bit lane offsets)");
+    ROREG_REQUIRE(!out_planes || (split == 2 && Xout), "roreg_ft_nonlin: out_planes is a layout of the fp16 x 2 coefficient output");
     const long long n_tiles = (long long)C * p.tiles_per_c;
     hipStream_t s = roreg::as_stream(stream);
     roreg::ProfScope prof(roreg::PROF_FT_NONLIN, s);
@@ -1666,21 +1724,20 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     ROREG_REQUIRE(split != 2 || out_sp || out_bound, "roreg_ft_nonlin: split = 2 writes the coefficients as fp16 hi/lo pairs and needs out_bound");
     ROREG_REQUIRE(!spatial_bf16 || in_sp || resid_spatial, "roreg_ft_nonlin: spatial_bf16 refers to x_spatial / resid_spatial");
     ROREG_REQUIRE(!out_rowmax || out_sp, "roreg_ft_nonlin: out_rowmax goes with a group-domain output");
-    auto grid_for = [&](int nw, long long cap) { long long b = (n_tiles + nw - 1) / nw; return dim3((unsigned)(b > cap ? cap : b)); };
     ROREG_REQUIRE(split >= 0 && split <= 2, "roreg_ft_nonlin: split must be 0 (f32 MFMA), 1 (bf16 x 3) or 2 (fp16 x 2)");
     if (split == 2) {
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 2, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, 2, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 2, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        if (in_sp) launch_ft<ft_nonlin_kernel<true, false, 2, 4, 1>>(p, n_tiles, s);
+        else if (!out_sp) launch_ft<ft_nonlin_kernel<false, false, 2, 4, 1>>(p, n_tiles, s);
+        else launch_ft<ft_nonlin_kernel<false, true, 2, 4, 1>>(p, n_tiles, s);
     } else if (split == 1) {
         // (6-wave workgroups at 3 waves per SIMD -- <.., 6, 3>, 384 threads, 139 VGPRs -- measured SLOWER: 4.6 vs 4.0 ms at C=512, B=65000)
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 3, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, 3, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 3, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        if (in_sp) launch_ft<ft_nonlin_kernel<true, false, 3, 4, 1>>(p, n_tiles, s);
+        else if (!out_sp) launch_ft<ft_nonlin_kernel<false, false, 3, 4, 1>>(p, n_tiles, s);
+        else launch_ft<ft_nonlin_kernel<false, true, 3, 4, 1>>(p, n_tiles, s);
     } else {
-        if (in_sp) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else if (!out_sp) hipLaunchKernelGGL((ft_nonlin_kernel<false, false, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((ft_nonlin_kernel<false, true, 0, 4, 1>), grid_for(4, 2048), dim3(256), 0, s, p);
+        if (in_sp) launch_ft<ft_nonlin_kernel<true, false, 0, 4, 1>>(p, n_tiles, s);
+        else if (!out_sp) launch_ft<ft_nonlin_kernel<false, false, 0, 4, 1>>(p, n_tiles, s);
+        else launch_ft<ft_nonlin_kernel<false, true, 0, 4, 1>>(p, n_tiles, s);
     }
     ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
     return 0;
@@ -1698,12 +1755,10 @@ extern "C" int roreg_feat_coefs(const void *x, int x_bf16, float *out, int B, in
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
-    const long long blocks = (n_tiles + 3) / 4;
-    const dim3 grid((unsigned)(blocks > 2048 ? 2048 : blocks));
     hipStream_t s = roreg::as_stream(stream);
-    if (split == 2) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 2, 4, 1, true>), grid, dim3(256), 0, s, p);
-    else if (split == 1) hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 3, 4, 1, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((ft_nonlin_kernel<true, false, 0, 4, 1, true>), grid, dim3(256), 0, s, p);
+    if (split == 2) launch_ft<ft_nonlin_kernel<true, false, 2, 4, 1, true>>(p, n_tiles, s);
+    else if (split == 1) launch_ft<ft_nonlin_kernel<true, false, 3, 4, 1, true>>(p, n_tiles, s);
+    else launch_ft<ft_nonlin_kernel<true, false, 0, 4, 1, true>>(p, n_tiles, s);
     ROREG_CHECK_LAUNCH("roreg_feat_coefs");
     return 0;
 }

@@ -28,8 +28,10 @@ if GEMM_MODE == 'split':
     GEMM_MODE = 'bf16x3'
 if GEMM_MODE not in GEMM_MODES:
     raise ValueError(f"ROREG_GEMM must be one of {GEMM_MODES}, got {GEMM_MODE!r}")
-# ROREG_GEMM_XDMA=1: the fp16 x 2 GEMMs of the extractor's two big layers take their activations in half-block layout by LDS-DMA (A/B switch)
-XDMA = os.environ.get('ROREG_GEMM_XDMA', '0') == '1'
+# The fp16 x 2 GEMMs with 256-row tiles and a transform as producer (the extractor's two big layers, ET's Conv_init) take their activations in
+# half-block layout by LDS-DMA (csrc/fourier.hip irrep_gemm_xdma_kernel); ROREG_GEMM_XDMA=0: the word layout + register staging (A/B switch,
+# bitwise the same results)
+XDMA = os.environ.get('ROREG_GEMM_XDMA', '1') == '1'
 ABI_VERSION = 3          # == ROREG_ABI_VERSION of include/roreg_hip.h; lib() refuses a library that reports another one
 _lib = None
 _tables_uploaded = False

@@ -63,12 +63,14 @@ def main():
                     cal = (rows, known, f)
         if cal:
             lines.append(f'calibration: gf_finalize on {cal[0]} keypoints reads {cal[1]:.0f} KiB; FETCH_SIZE reports {cal[2]:.0f} KiB -> factor {cal[1] / cal[2]:.3f}')
-        kern = 'irrep_gemm_kernel' if gm == 'f32' else 'irrep_gemm_split_kernel'
-        def big_tag(name):          # irrep_gemm_split_kernel<CT, NP, WO, BIG[, PIPE]>: the fourth template argument
-            m = re.search(r'irrep_gemm_split_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name)
+        kern = 'irrep_gemm_kernel' if gm == 'f32' else 'irrep_gemm_'
+        def big_tag(name):          # irrep_gemm_split_kernel<CT, NP, WO, BIG[, PIPE]> (fourth template argument) or irrep_gemm_xdma_kernel<BIG>
+            m = re.search(r'irrep_gemm_split_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name) or re.search(r'irrep_gemm_xdma_kernel<\s*(\d+)', name)
             return bool(m) and m.group(1) == '1'
         tagged = (lambda k: k[1] >= 4000000) if gm == 'f32' else (lambda k: big_tag(k[0]))
         big = [k for k in agg if k[0].startswith(kern) and tagged(k) and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]]
+        if gm != 'f32' and big:
+            kern = sorted({k[0].split('<')[0] for k in big})[-1]
         if big:
             nf = sum(len(agg[k]['FETCH_SIZE']) for k in big); nw = sum(len(agg[k]['WRITE_SIZE']) for k in big)
             f_kib = sum(sum(agg[k]['FETCH_SIZE']) for k in big) / nf
