@@ -363,6 +363,7 @@ def main():
             d = float(tt.item())
         return d, out[0], out[1]
 
+    barrier()            # the group's first call involves every rank (the warm-up's send/recv batch involves only those that cut a scene)
     for _ in range(args.warmup):
         step()
 

@@ -154,7 +154,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        # a world-wide collective before anything else: the extractor-output exchange is a batched send/recv that only SOME ranks take part
+        # in, and a group's first call must involve all of its ranks (torch.distributed.batch_isend_irecv)
+        dist.barrier(device_ids=[local])
     datasets = get_dataset_name(cfg.testset, cfg.origin_data_dir)
     evaluate(cfg, datasets, build_engine(cfg), rank, world, cfg.seed)
     if world > 1:
