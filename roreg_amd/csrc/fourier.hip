@@ -943,7 +943,6 @@ struct NonlinParams {
     int x_bf16;                  // the group-domain input / residual tensors are bfloat16 instead of float32
     int out_planes;              // SPLIT = 2 coefficient output in HALF-BLOCK layout (see irrep_gemm_xdma_kernel): every 32-column block of a row holds
                                  // its 32 fp16 hi values (order 0, 16, 1, 17, ...), then its 32 lo values, instead of 32 words hi | lo << 16
-    float *dump;                 // 64 floats nobody reads (target of the half-wave stores of the non-existent coefficients 60..63)
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
 
@@ -1384,7 +1383,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
 float *g_A1 = nullptr, *g_A2 = nullptr;
 uint16_t *g_A1s = nullptr, *g_A2s = nullptr, *g_A1h = nullptr, *g_A2h = nullptr;
 int g_f_exp = 0;
-float *g_dump = nullptr;
 
 }  // namespace
 
@@ -1449,7 +1447,7 @@ extern "C" int roreg_set_fourier_tables(const float *F_host /* [60 (q)][60 (g)],
                     }
                 }
     if (!g_A1s) {
-        if (hipMalloc(&g_A1s, sizeof(A1s)) != hipSuccess || hipMalloc(&g_A2s, sizeof(A2s)) != hipSuccess || hipMalloc(&g_dump, 64 * sizeof(float)) != hipSuccess) {
+        if (hipMalloc(&g_A1s, sizeof(A1s)) != hipSuccess || hipMalloc(&g_A2s, sizeof(A2s)) != hipSuccess) {
             roreg::set_error("roreg_set_fourier_tables: hipMalloc failed");
             return 1;
         }
@@ -1710,7 +1708,7 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
     p.x_spatial = x_spatial; p.r_spatial = resid_spatial; p.out_spatial = out_spatial;
     p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
     p.bias = bias; p.bias2 = bias2; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
-    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump; p.out_bound = out_bound; p.out_rowmax = out_rowmax; p.x_bf16 = spatial_bf16;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.out_bound = out_bound; p.out_rowmax = out_rowmax; p.x_bf16 = spatial_bf16;
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     p.out_planes = out_planes;
@@ -1751,7 +1749,7 @@ extern "C" int roreg_feat_coefs(const void *x, int x_bf16, float *out, int B, in
     memset(&p, 0, sizeof(p));
     p.x_spatial = reinterpret_cast<const float *>(x); p.x_bf16 = x_bf16; p.out_spatial = out;
     p.Lout = ROREG_G; p.Lvalid = ROREG_G; p.A1 = g_A1; p.A2 = g_A2;
-    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s); p.dump = g_dump;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s);
     p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
     p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
     const long long n_tiles = (long long)C * p.tiles_per_c;
