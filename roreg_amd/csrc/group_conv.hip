@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     const int plane_stride = 2 * p.nkp_max * S, h_stride = p.nkp_max * S;         // in 16-byte fragments
     int *slot_of = gt + Lout * KS;
 
+    const bool has_bn = p.bn_scale != nullptr;
     for (int i = tid; i < Lout * KS; i += 256) gt[i] = p.order ? p.order[p.gather[i]] : p.gather[i];
     for (int i = tid; i < Lin; i += 256) slot_of[i] = p.order ? p.order[i] : i;
 
@@ -321,7 +322,6 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
-    const bool has_bn = p.bn_scale != nullptr;
     float oscale[4] = {1.f, 1.f, 1.f, 1.f};
     if constexpr (NP == 2) {
 #pragma unroll
@@ -336,6 +336,13 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     // form loaded each k-octet with eight dependent global loads, one item after the other: 12-16 us of exposed latency per chunk against
     // 4 us of MFMAs -- the kernel ran at 42 % matrix-pipe duty, independent of the operands, i.e. stall-bound, not power-bound.)
     float *raw = reinterpret_cast<float *>(slab + (size_t)NP * plane_stride);       // [nkp_max][16][Lin]
+    // BatchNorm parameters of all input channels and the block scale of this tile's keypoints, staged ONCE: convert() runs between two
+    // barriers of every chunk, and with these as global loads every one of its 4-5 iterations per thread exposed two L2 round trips
+    // (the ISA showed s_waitcnt vmcnt(0) twice per iteration) -- more time per chunk than the chunk's MFMAs.
+    float *bn_s = raw + (size_t)p.nkp_max * 16 * Lin, *bn_h = bn_s + p.Cin, *kp_scale = bn_h + p.Cin;       // [Cin], [Cin], [nkp_max]
+    for (int i = tid; i < p.Cin; i += 256) { bn_s[i] = has_bn ? p.bn_scale[i] : 1.f; bn_h[i] = has_bn ? p.bn_shift[i] : 0.f; }
+    if constexpr (NP == 2)
+        for (int i = tid; i < nkp; i += 256) kp_scale[i] = ldexpf(1.f, row_scale_exp(p.sc, b_first + i));
     const int pieces = nkp * 4 * Lin;                                                // 16-byte pieces of a chunk
     auto issue_raw = [&](int c0) {
         for (int base = w * 64; base < pieces; base += 256) {                        // (wave-uniform trip count)
@@ -360,8 +367,11 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = src[e * Lin];
             if (has_bn) {
+                const float4 *sc4 = reinterpret_cast<const float4 *>(bn_s + c0 + 8 * ho), *sh4 = reinterpret_cast<const float4 *>(bn_h + c0 + 8 * ho);
+                const float4 s0 = sc4[0], s1 = sc4[1], h0 = sh4[0], h1 = sh4[1];
+                const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.bn_scale[c0 + 8 * ho + e], p.bn_shift[c0 + 8 * ho + e]), 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
             }
             frag *dst = slab + ho * h_stride + kp * S + sl;
             if constexpr (NP == 3) {
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                 dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
             } else {
                 f16x8 hi, lo;
-                gc_split2(v, ldexpf(1.f, row_scale_exp(p.sc, b_first + kp)), hi, lo);
+                gc_split2(v, kp_scale[kp], hi, lo);
                 dst[0] = hi; dst[plane_stride] = lo;
             }
         }
@@ -379,6 +389,9 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                                 // (also orders the gather-table fill)
     convert(0);
+    int gix0[4];                                                                     // slot of every column block's first gathered column: the same for all chunks
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gix0[t] = gt[gi[t] * KS];
 
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
         __syncthreads();                                                             // the slab of this chunk is complete, the raw buffer is free
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
         int gix[2][4];
         frag fb[2][NP];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) gix[0][t] = gt[gi[t] * KS];
+        for (int t = 0; t < 4; ++t) gix[0][t] = gix0[t];
         auto read_frags = [&](int slot, int t, int set) {
             const frag *bp = slab + rowbase[t] + slot;
 #pragma unroll
@@ -834,7 +847,8 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
 
 template <int NP>
 static int launch_conv_split(GCSplitParams p, hipStream_t s) {
-    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4;       // slot tables, fragment slab, raw chunk
+    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4        // slot tables, fragment slab, raw chunk,
+                       + (size_t)(2 * p.Cin + p.nkp_max) * 4;                                                                // BatchNorm parameters, keypoint scales
     ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
     auto kern = group_conv_split_kernel<13, NP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

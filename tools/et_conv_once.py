@@ -10,6 +10,9 @@ et = name2network['ET_test'](cfg); et.load_state_dict(synth.seeded_state_dict(et
 res = et.PartII_SO3_Conv_layers[0]
 ga, gb, gc, p0, gmap = et._pruned_gathers()
 B = 32000
+torch.manual_seed(0)
 h = torch.randn(B, 256, 48, device='cuda'); ah = h.abs().amax(dim=(1, 2)).contiguous()
-for _ in range(6): res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True)
+for _ in range(6): out = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True)
 torch.cuda.synchronize()
+import hashlib
+print('checksum', [hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest()[:16] for t in (out if isinstance(out, tuple) else (out,))])
