@@ -1247,8 +1247,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             // keypoint's contiguous row of Lout floats instead of 64 scattered dwords
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int b0 = tbi * 32;
-            for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
-                if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
+            if (b0 + 32 <= B) {
+                // interior tile: eight rows per group -- their LDS reads go out together instead of one exposed LDS round trip per row
+                // (the rolled loop below waits lgkmcnt(0) 32 times per tile)
+                float *ob = p.out_spatial + ((size_t)b0 * C + c) * p.Lout + lane;
+                const size_t ostep = (size_t)C * p.Lout;
+#pragma unroll
+                for (int g8 = 0; g8 < 4; ++g8) {
+                    float tv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tv[q] = tb[(g8 * 8 + q) * 65 + lane];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (lane < p.Lout) ob[(size_t)(g8 * 8 + q) * ostep] = lane < p.Lvalid ? tv[q] : 0.f;
+                }
+            } else {
+                for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
+                    if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (p.out_rowmax) {
                 // every lane issues the atomic (no branch around a VMEM operation in the pipelined loop): both half-waves hold their
@@ -1333,8 +1349,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const int b0 = tbi * 32;
-                for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
-                    if (lane < ROREG_G) p.out_spatial[((size_t)(b0 + bl) * C + c) * ROREG_G + lane] = tb[bl * 65 + lane];
+                if (b0 + 32 <= B) {
+                    float *ob = p.out_spatial + ((size_t)b0 * C + c) * ROREG_G + lane;
+                    const size_t ostep = (size_t)C * ROREG_G;
+#pragma unroll
+                    for (int g8 = 0; g8 < 4; ++g8) {
+                        float tv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) tv[q] = tb[(g8 * 8 + q) * 65 + lane];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (lane < ROREG_G) ob[(size_t)(g8 * 8 + q) * ostep] = tv[q];
+                    }
+                } else {
+                    for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
+                        if (lane < ROREG_G) p.out_spatial[((size_t)(b0 + bl) * C + c) * ROREG_G + lane] = tb[bl * 65 + lane];
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else if (PACK_OUT && p.out_planes) {
                 // Half-block layout for the LDS-DMA GEMM: every 32-column block of a row (128 bytes in either layout) holds 16 words of fp16

@@ -666,24 +666,54 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(DenseParams p) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) wmax[rt][r] = 0.f;
+    if (b0 + TB <= p.B && o0 + TO <= p.O) {
+        // interior tile: no per-element range branches, and the 16 residual loads (and row scales) of a 32-row block go out together -- in the
+        // generic body below every element is a branch with its own load and s_waitcnt vmcnt(0): 128 exposed L2 round trips per thread,
+        // several times the K loop of the 1x1 layers.  Same arithmetic: (acc * scale + bias) + residual.
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int o = o0 + wc * 128 + t * 32 + j;
-        if (o >= p.O) continue;
-        const float bo = p.bias[o];
+        for (int rt = 0; rt < 2; ++rt) {
+            float sc16[16];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int r = 0; r < 16; ++r) sc16[r] = NP == 2 ? so[wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 1.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int b = b0 + row;
-                if (b < p.B) {
-                    float v = (NP == 2 ? acc[rt][t][r] * so[row] : acc[rt][t][r]) + bo;
-                    if (p.res) v += p.res[((size_t)b * p.O + o) * p.res_stride];
-                    p.out[(size_t)b * p.O + o] = v;
+            for (int t = 0; t < 4; ++t) {
+                const int o = o0 + wc * 128 + t * 32 + j;
+                const float bo = p.bias[o];
+                const size_t base = (size_t)(b0 + wr * 64 + rt * 32 + 4 * h) * p.O + o;
+                float rv[16];
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = p.res[(base + (size_t)((r & 3) + 8 * (r >> 2)) * p.O) * p.res_stride];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (NP == 2 ? acc[rt][t][r] * sc16[r] : acc[rt][t][r]) + bo;
+                    if (p.res) v += rv[r];
+                    p.out[base + (size_t)((r & 3) + 8 * (r >> 2)) * p.O] = v;
                     wmax[rt][r] = fmaxf(wmax[rt][r], fabsf(v));
                 }
             }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o = o0 + wc * 128 + t * 32 + j;
+            if (o >= p.O) continue;
+            const float bo = p.bias[o];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int b = b0 + row;
+                    if (b < p.B) {
+                        float v = (NP == 2 ? acc[rt][t][r] * so[row] : acc[rt][t][r]) + bo;
+                        if (p.res) v += p.res[((size_t)b * p.O + o) * p.res_stride];
+                        p.out[(size_t)b * p.O + o] = v;
+                        wmax[rt][r] = fmaxf(wmax[rt][r], fabsf(v));
+                    }
+                }
+        }
     }
     if constexpr (NP == 2) {
         if (p.sc.out_rowmax) {
