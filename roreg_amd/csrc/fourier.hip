@@ -1099,11 +1099,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             // tile's keypoint i; process() transposes through the wave's LDS buffer.  (Lane = keypoint reads -- 64 addresses 30 KB apart per
             // instruction -- ran at 2.7 TB/s.)
             const int b0 = tb * 32;
-            static_for<32>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const size_t src = ((size_t)(b0 + i < B ? b0 + i : B - 1) * C + c) * ROREG_G;
-                dst[i] = lane < ROREG_G ? ld_sp(p.x_spatial, src + lane) : 0.f;
-            });
+            // (bfloat16 storage: the raw 16 bits are loaded here and widened where the tile is consumed -- with the conversion at the load the
+            //  compiler put s_waitcnt vmcnt(0) behind every one of the 32 row loads, i.e. the prefetch was 32 serialised round trips)
+            if (p.x_bf16) {
+                const unsigned short *xs16 = reinterpret_cast<const unsigned short *>(p.x_spatial);
+                static_for<32>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const size_t src = ((size_t)(b0 + i < B ? b0 + i : B - 1) * C + c) * ROREG_G;
+                    dst[i] = __uint_as_float(lane < ROREG_G ? (unsigned)xs16[src + lane] : 0u);
+                });
+            } else {
+                static_for<32>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const size_t src = ((size_t)(b0 + i < B ? b0 + i : B - 1) * C + c) * ROREG_G;
+                    dst[i] = lane < ROREG_G ? p.x_spatial[src + lane] : 0.f;
+                });
+            }
         } else if constexpr (SPLIT != 0) {
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
@@ -1164,7 +1175,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             __builtin_amdgcn_sched_barrier(0);
             float *ti = sT + (threadIdx.x >> 6) * (32 * 65);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) ti[i * 65 + lane] = cv[i];
+            for (int i = 0; i < 32; ++i) ti[i * 65 + lane] = p.x_bf16 ? __uint_as_float(__float_as_uint(cv[i]) << 16) : cv[i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the buffer is this wave's own: no barrier)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
