@@ -1236,6 +1236,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         const bool bn = p.bn_scale != nullptr;
         const float sc = sScale[c], sh = sShift[c];
         const bool has_rs = OUT_SPATIAL && p.r_spatial;
+        // Without BatchNorm, column map and tracked maximum the residual is simply added to what is written: it is then read in the store
+        // loop below, one keypoint's contiguous row per load (lane = group element), eight rows at a time -- not here with lane = keypoint,
+        // 64 scattered dwords per load and an s_waitcnt vmcnt(0) per element (32 serialised round trips per tile, which also drained the
+        // next tile's prefetch).  (v + bias) + residual either way.
+        const bool rs_late = has_rs && !bn && !p.g_map && !p.out_rowmax;
         const size_t rs = ((size_t)bb * C + c) * ROREG_G;
         float *tb = (OUT_SPATIAL || OUT_ROWS) ? sT + (threadIdx.x >> 6) * (32 * 65) : nullptr;      // this wave's [32 keypoints][65] transpose buffer
 #pragma unroll
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             for (int r = 0; r < 16; ++r) {
                 const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float x = v[t][r] + bsum;
-                if (OUT_SPATIAL && has_rs && g < ROREG_G) x += ld_sp(p.r_spatial, rs + g);
+                if (OUT_SPATIAL && has_rs && !rs_late && g < ROREG_G) x += ld_sp(p.r_spatial, rs + g);
                 if (bn) x = fmaxf(fmaf(x, sc, sh), 0.f);
                 if (g >= ROREG_G || !valid) x = 0.f;          // pad keypoints carry zeros through the forward transform: their coefficients are exact 0
                 v[t][r] = x;
@@ -1263,18 +1268,37 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 // (the rolled loop below waits lgkmcnt(0) 32 times per tile)
                 float *ob = p.out_spatial + ((size_t)b0 * C + c) * p.Lout + lane;
                 const size_t ostep = (size_t)C * p.Lout;
+                const size_t rb = ((size_t)b0 * C + c) * ROREG_G + (lane < ROREG_G ? lane : 0), rstep = (size_t)C * ROREG_G;
+                const unsigned short *r16 = reinterpret_cast<const unsigned short *>(p.r_spatial);
 #pragma unroll
                 for (int g8 = 0; g8 < 4; ++g8) {
-                    float tv[8];
+                    float tv[8], rv[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) tv[q] = tb[(g8 * 8 + q) * 65 + lane];
+                    if (rs_late) {                       // (the storage type is tested once per group, not per load: see load_coefs)
+                        if (p.x_bf16) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) rv[q] = __uint_as_float((unsigned)r16[rb + (size_t)(g8 * 8 + q) * rstep]);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) tv[q] += __uint_as_float(__float_as_uint(rv[q]) << 16);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) rv[q] = p.r_spatial[rb + (size_t)(g8 * 8 + q) * rstep];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) tv[q] += rv[q];
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         if (lane < p.Lout) ob[(size_t)(g8 * 8 + q) * ostep] = lane < p.Lvalid ? tv[q] : 0.f;
                 }
             } else {
                 for (int bl = 0; bl < 32 && b0 + bl < B; ++bl)
-                    if (lane < p.Lout) p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tb[bl * 65 + lane] : 0.f;
+                    if (lane < p.Lout) {
+                        float tv = tb[bl * 65 + lane];
+                        if (rs_late && lane < ROREG_G) tv += ld_sp(p.r_spatial, ((size_t)(b0 + bl) * C + c) * ROREG_G + lane);
+                        p.out_spatial[((size_t)(b0 + bl) * C + c) * p.Lout + lane] = lane < p.Lvalid ? tv : 0.f;
+                    }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (p.out_rowmax) {
