@@ -78,6 +78,10 @@ def parse(argv=None):
                     'extracting each cloud once and shipping the extractor output of a cut scene over xGMI')
     ap.add_argument('--all-steps', type=int, default=5, help='timed steps of the all-local-transforms figure (the reference\'s per-pair work)')
     ap.add_argument('--master-port', type=int, default=0, help='launcher only: rendezvous port (0 = pick a free one)')
+    ap.add_argument('--force-collectives', action='store_true', help='N = 1: initialise the process group (nccl = RCCL, one rank) anyway, run the result '
+                    'table\'s all_gather every step and ship the extractor outputs of 4 clouds from the rank to itself through the grouped send/recv: a '
+                    'single GPU then executes the whole multi-GPU code path (ROREG_FORCE_COLLECTIVES=1 does the same)')
+    ap.add_argument('--bf16x3-steps', type=int, default=2, help='timed steps of the strictly 24-bit matrix-core mode on the full workload (0 = skip)')
     return ap.parse_args(argv)
 
 
@@ -236,7 +240,7 @@ def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
     else:
         k = MFMAS_PER_PRODUCT[mode]
         from roreg_amd import hip
-        base.update({'kernel': KERNEL_OF['f16x2-words' if mode == 'f16x2' and not hip.XDMA else mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
+        base.update({'kernel': KERNEL_OF['f16x2-words' if mode == 'f16x2' and not hip.use_planes(512) else mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
     return base
 
 
@@ -258,10 +262,14 @@ def kernel_source_hash():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def measured_traffic(args):
+PMC_DEFAULT_CONDITIONS = {'kpts': 5000, 'dtype': 'fp32', 'gpus': 1, 'pair_lists': 'banded', 'xdma': True}
+
+
+def measured_traffic(args, world=1):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_irrep_gemm_pmc.json) -- returned
-    only if that pass was collected on THIS kernel source (its `kernel_source_sha16` equals csrc/fourier.hip's hash now); otherwise None
-    with the reason, so a stale number is never printed."""
+    only if that pass was collected on THIS kernel source (its `kernel_source_sha16` equals csrc/fourier.hip's hash now) AND under this
+    run's conditions (keypoints per cloud, descriptor storage type, rank count, pair lists, the LDS-DMA kernel switch: they decide the
+    launch sizes and which kernel runs); otherwise None with the reason, so a number is never printed for a run it was not measured on."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_irrep_gemm_pmc.json')))
     if not files:
@@ -273,7 +281,13 @@ def measured_traffic(args):
         return None
     if j.get('kernel_source_sha16') != kernel_source_hash():
         return {'bytes': None, **src, 'refused': f'the PMC pass was collected on another kernel source (now {kernel_source_hash()})'}
-    return {'bytes': val, **src}
+    from roreg_amd import hip
+    now = {'kpts': args.kpts, 'dtype': args.dtype, 'gpus': world, 'pair_lists': args.pair_lists, 'xdma': hip.use_planes(512)}
+    then = dict(PMC_DEFAULT_CONDITIONS, **(j.get('conditions') or {}))
+    diff = {k: (then.get(k), now[k]) for k in now if then.get(k) != now[k]}
+    if diff:
+        return {'bytes': None, **src, 'refused': f'the PMC pass was collected under other conditions (then, now): {diff}'}
+    return {'bytes': val, **src, 'conditions': then}
 
 
 def main():
@@ -292,19 +306,22 @@ def main():
         torch.cuda.set_device(dev_index)
         device = 'cuda'
     sync = (lambda: None) if STUB else torch.cuda.synchronize
+    from roreg_amd import distributed as D
+    if args.force_collectives:
+        os.environ['ROREG_FORCE_COLLECTIVES'] = '1'
+    forced = D.forced()
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        kw = {'device_id': torch.device('cuda', dev_index)} if args.backend == 'nccl' else {}
-        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    if world > 1 or forced:
+        dist = D.init_collectives(args.backend, rank, world, dev_index)      # init_process_group + the group's first barrier, under the hang watchdog
     coll_dev = 'cuda' if (args.backend == 'nccl' and not STUB) else 'cpu'    # device of the (tiny) collective payloads
+    step_timeout = D.collective_timeout(180.0)                               # a step is ~1.5 s; the first one also builds RCCL's peer connections
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[dev_index]) if args.backend == 'nccl' else dist.barrier()
+            with D.watchdog(step_timeout, 'barrier'):
+                dist.barrier(device_ids=[dev_index]) if args.backend == 'nccl' else dist.barrier()
 
-    from roreg_amd import distributed as D, synth
+    from roreg_amd import synth
     from roreg_amd.parses.parses_test import default_config
     cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
     if STUB:
@@ -325,6 +342,9 @@ def main():
 
     scenes, my_plan, totals = build_workload(args, rank, world, device=device, exchange=not args.no_exchange)   # inputs resident in HBM before timing
     transfers = totals['transfers']
+    if forced and world == 1 and args.workload != 'chunk':
+        transfers = D.self_transfers(my_plan, {s: scenes[s][3] for s in scenes}, rank=0, n_clouds=4)
+    moved = {}                                                               # eqv bytes this rank sent / received, all steps
     seeds = {s: [(7 + zlib.crc32(f'{s}:{a}:{b}'.encode())) % (2 ** 32) for a, b in scenes[s][3]] for s in scenes}
     kitchen = synth.THREEDMATCH_SCENES[0]
     kitchen_whole = any(p == (kitchen, 0, synth.THREEDMATCH_PAIRS[0]) for p in my_plan) and not any(t[0] == kitchen for t in transfers)
@@ -338,12 +358,13 @@ def main():
     def step(only=None, **kw):
         """One pass of this rank's share + the step's single collective -> (this rank's rows [(scene, PairResult)], gathered table or None)."""
         pieces = [p for p in my_plan if only is None or p[0] == only]
-        done = D.run_plan(eng, pieces, scene_inputs, transfers if only is None else [], rank, **kw)
-        rows = [(s, r) for s, _, _, res in done for r in res]
-        table = None
-        if only is None:                                                      # the single result-table collective (RCCL over xGMI)
-            local_tab = np.concatenate([D.pack_rows(scene_index[s], res) for s, _, _, res in done] or [np.zeros((0, D.ROW))], 0)
-            table = D.gather_table(local_tab, device=coll_dev, counts=totals['rows_per_rank']) if dist is not None else local_tab
+        with D.watchdog(step_timeout if dist is not None else 0.0, 'one step (exchange, kernels, gather)'):
+            done = D.run_plan(eng, pieces, scene_inputs, transfers if only is None else [], rank, stats=moved, **kw)
+            rows = [(s, r) for s, _, _, res in done for r in res]
+            table = None
+            if only is None:                                                  # the single result-table collective (RCCL over xGMI)
+                local_tab = np.concatenate([D.pack_rows(scene_index[s], res) for s, _, _, res in done] or [np.zeros((0, D.ROW))], 0)
+                table = D.gather_table(local_tab, device=coll_dev, counts=totals['rows_per_rank']) if dist is not None else local_tab
         return rows, table
 
     def bracket(n, **kw):
@@ -370,7 +391,9 @@ def main():
     if hip is not None:
         hip.PROFILE = []                                                     # per-launch HIP events of the group-conv GEMMs
         hip.profile_enable(True)                                             # library-side events: distance-matrix, RANSAC-scoring, Des2R kernels
+    moved.clear()
     dt, rows, table = bracket(args.steps)
+    moved_timed = dict(moved)
     prof = []
     if hip is not None:
         prof = hip.PROFILE; hip.PROFILE = None
@@ -427,6 +450,15 @@ def main():
                        'note': 'synthetic scenes (tau_1 = 0.05, tau_2 = 0.1 m; RR = RRE < 15 deg and RTE < 0.3 m, scene means averaged like '
                                'test/evaluator.py:111-129); RR(predator) needs the benchmark\'s gt.info covariances, which synthetic scenes do not have'}
 
+    # ---- the strictly 24-bit matrix-core mode on the SAME full workload (the default f16x2 is 22 bits under a per-keypoint bound) ----
+    bf16x3_value = None
+    if not args.no_secondary and hip is not None and args.gemm == 'f16x2' and args.bf16x3_steps > 0:
+        eng.set_gemm_mode('bf16x3')
+        step()
+        d_b, _, _ = bracket(args.bf16x3_steps)
+        bf16x3_value = totals['pairs'] * args.bf16x3_steps / d_b
+        eng.set_gemm_mode(args.gemm)
+
     # ---- secondary figures (outside the headline's timed region; kitchen scene only, so the default run stays short) ----
     sec_scene = kitchen if kitchen in scenes else sorted(scenes)[0]
     if not args.no_secondary and kitchen_whole:                               # BASELINE configs[1]: the kitchen scene alone on this GPU
@@ -464,11 +496,18 @@ def main():
             sec['f16x2_scale_headroom_bits'] = headroom_bits(eng, scenes[sec_scene][0][0])
         if world == 1:
             sec['rd_rm_leg'] = rd_rm_leg(args, cfg, gf, et)
+            sec['rd_rm_leg_pairs_per_s'] = sec['rd_rm_leg'].get('fp32', {}).get('pairs_per_s')
+            sec['rd_rm_leg_pairs_per_s_bf16'] = sec['rd_rm_leg'].get('bf16', {}).get('pairs_per_s')
 
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
     if hip is not None:
         achieved, ms, n_launch, alg_bytes = gemm_roofline(prof, TAG_OF[args.gemm])
-        traffic = measured_traffic(args)
+        traffic = measured_traffic(args, world)
+
+    eqv_moved = float(moved_timed.get('eqv_bytes_sent', 0))
+    if dist is not None:
+        tt = torch.tensor([eqv_moved], dtype=torch.float64, device=coll_dev); dist.all_reduce(tt); eqv_moved = float(tt.item())
+    eqv_moved /= max(args.steps, 1)
 
     if rank == 0:
         total_pairs = totals['pairs']
@@ -484,13 +523,23 @@ def main():
             'data': 'stub engine (host-side test of the launcher and the multi-rank control flow; no kernels ran)' if STUB else 'synthetic',
             'value_all_local_transforms': all_value,
             'accuracy': metrics,
+            'value_bf16x3': bf16x3_value,
             'config': {'workload': wl, 'pairs_per_step': total_pairs, 'clouds_per_step': totals['clouds'], 'parallelism': f'pairs-sharded x{world}',
                        'descriptor_dtype': args.dtype,
+                       # scalars repeated here because a record that keeps only the contract's keys keeps `config`'s scalars:
+                       'value_all_local_transforms': all_value,            # the reference's per-pair work (every correspondence's local transform)
+                       'value_bf16x3': bf16x3_value,                        # same workload, strictly 24-bit operands (3 x bf16) in the matrix cores
+                       'fmr': None if metrics is None else metrics['feature_matching_recall'],
+                       'ir': None if metrics is None else metrics['inlier_ratio'],
+                       'rr': None if metrics is None else metrics['registration_recall_pointdsc'],
+                       'eqv_bytes_moved_per_step': eqv_moved,              # extractor outputs sent rank to rank (sum over ranks), timed steps
+                       'forced_collectives': bool(forced and world == 1),
                        'pair_lists': ('chain (i, i+1) + pairs (i, j) drawn with probability ~ exp(-|i-j|/8): scan-sequence-like locality' if args.pair_lists == 'banded'
                                       else 'chain (i, i+1) + pairs drawn uniformly over all cloud pairs') if args.workload != 'chunk' else None,
                        'rank0_pairs_per_step': my_pairs, 'shard_plan': totals.get('plan'),
                        'cloud_extractions_per_rank': totals.get('extractions_per_rank'),
-                       'eqv_transfers_per_step': len(transfers), 'eqv_exchange': ('point-to-point send/recv of cut scenes\' extractor outputs (38.4 MB each), one grouped '
+                       'eqv_transfers_per_step': len(transfers), 'result_table_bytes_gathered_per_step': (total_pairs * D.ROW * 8 if dist is not None else 0),
+                       'eqv_exchange': ('point-to-point send/recv of cut scenes\' extractor outputs (38.4 MB each), one grouped '
                                                                                    'launch per step' if transfers else None),
                        'mean_matches_rank0': float(np.mean(Ms)) if len(Ms) else None,
                        'local_transforms': 'value: only the <=1000 hypotheses one-shot RANSAC draws per pair (results identical to evaluating all M, checked: '
@@ -537,15 +586,15 @@ def main():
             threads = torch.get_num_threads()
             t_t = cpu_baseline_torch((gf_sd, et_sd), f0, f1)
             v_all, v_drawn, comp = scale_baseline(t_t, M, totals['clouds'], total_pairs)
-            out['cpu_baseline'] = {'value': v_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-                                   'sample': 'oracle/ref_torch.py (the reference\'s own torch CPU operators, torch.set_num_threads = all host threads) on this host: '
+            out['cpu_baseline'] = {'value': v_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'sampled': True,
+                                   'sample': 'SAMPLED, not a timed step (per-unit costs on bounded samples, scaled to the workload): ' 'oracle/ref_torch.py (the reference\'s own torch CPU operators, torch.set_num_threads = all host threads) on this host: '
                                              'GF on one bs_GF batch of 1250 kpts, mutual NN on the full 5000 x 5000 pair, Des2R on 1000 and ET on one bs_ET batch of '
                                              '1000 correspondences, RANSAC scoring (numpy, as in the reference) on 200 hypotheses x 3000; scaled to the step workload '
                                              'with the local transform of EVERY correspondence, as the reference computes it (pair with value_all_local_transforms)',
                                    'value_if_only_drawn_hypotheses': v_drawn, 'components_s': comp}
             t_n = cpu_baseline_numpy(({k: v.numpy() for k, v in gf_sd.items()}, {k: v.numpy() for k, v in et_sd.items()}), f0, f1)
             v_all, v_drawn, comp = scale_baseline(t_n, M, totals['clouds'], total_pairs)
-            out['cpu_baseline_numpy_oracle'] = {'value': v_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            out['cpu_baseline_numpy_oracle'] = {'value': v_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'sampled': True,
                                                 'sample': 'oracle/ref_numpy.py (the parity oracle; BLAS-threaded matmuls, single-threaded gathers): GF on 512 kpts, '
                                                           'mutual on 2500 x 2500 (scaled N^2), Des2R on 512, ET on 384 correspondences, RANSAC scoring on 200 x 3000',
                                                 'value_if_only_drawn_hypotheses': v_drawn, 'components_s': comp}

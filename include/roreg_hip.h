@@ -25,9 +25,10 @@ extern "C" {
  * (2: round 2's per-keypoint block scales -- roreg_gf_finalize, roreg_inv_descriptor, roreg_et_gather, roreg_dense_split/_f16x2,
  * roreg_lt_prepare_batch, roreg_group_conv_f16x2, roreg_lt_task 80 -> 96 bytes; 3: round 3 -- roreg_ransac_score / roreg_refine /
  * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order; roreg_ft_nonlin /
- * roreg_irrep_gemm_f16x2 take the plane-layout flags).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * roreg_irrep_gemm_f16x2 take the plane-layout flags; 4: round 4 -- additions only (roreg_nn_search_ex / roreg_knn_search_ex / roreg_pdist and the entries marked "v4"),
+ * bumped so that a binding can rely on them).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
-#define ROREG_ABI_VERSION 3
+#define ROREG_ABI_VERSION 4
 int roreg_abi_version(void);
 const char *roreg_last_error(void);
 
@@ -118,6 +119,17 @@ int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
                     const float *tgt, const int64_t *tgt_rows, int n, int F,
                     int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream);
 
+/* v4: roreg_nn_search with the distance type of modified_knn_matcher.find_nn_gpu (utils/knn_search.py:26-66): squared = 0 is 'L2' (the
+ * function above), squared = 1 is 'SquareL2' = sum_f (s_f-t_f)^2 itself (no 1e-7, no root; find_nn_gpu's own default): the first minimum of
+ * THAT value wins, which may differ from the 'L2' winner where two roots round to the same float. */
+int roreg_nn_search_ex(const float *src, const int64_t *src_rows, int m,
+                       const float *tgt, const int64_t *tgt_rows, int n, int F, int squared,
+                       int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream);
+
+/* v4: the whole distance matrix out[i*n+j] of modified_knn_matcher.pdist (utils/knn_search.py:17-24), A [m,F], B [n,F], any F >= 1;
+ * squared as above. */
+int roreg_pdist(const float *A, int m, const float *B, int n, int F, int squared, float *out, void *stream);
+
 /* The mutual matcher for a batch of pairs (test/matcher.py:90-107 for every pair of a scene), on the matrix cores and bit-exact:
  * approximate squared distances |s|^2+|t|^2-2s.t as 3 x bf16 split MFMAs give row / column minima; every entry within a proven margin
  * of its row (column) minimum is re-evaluated with the literal formula of roreg_nn_search and merged "first minimum wins"
@@ -141,6 +153,11 @@ size_t roreg_knn_search_workspace(int m, int n);
 int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k,
                      int64_t *idx_out, void *workspace /* roreg_knn_search_workspace bytes: targets are scanned in slices that fill the chip;
                      NULL = one thread per source scans everything */, size_t workspace_bytes, void *stream);
+
+/* v4: roreg_knn_search with the distance type (squared as in roreg_nn_search_ex) and, optionally, the k distances (dist_out f32 [m,k] or
+ * NULL): modified_knn_matcher.find_knn_gpu (utils/knn_search.py:68-103). */
+int roreg_knn_search_ex(const float *src, int m, const float *tgt, int n, int F, int k, int squared, int64_t *idx_out, float *dist_out,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* roreg_knn_search for several clouds per launch: the point lists are stacked, seg_src / seg_tgt are DEVICE int32 [n_seg+1] row
  * offsets, a source only sees the targets of its own segment; idx_out int64 [m_total,k] holds indices LOCAL to the segment (the NMS

@@ -138,23 +138,31 @@ def et_forward(batch, sd, Nei, P):
 # ====================================================================================================
 # nearest neighbours, NMS, mutual matching
 # ====================================================================================================
-def pdist_l2(S, T):
-    """knn_search.py:17-20 with the fixed accumulation order of this oracle.  S [m,f], T [n,f] -> [m,n]."""
+def pdist(S, T, dist_type='L2'):
+    """modified_knn_matcher.pdist (knn_search.py:17-24) with the fixed accumulation order of this oracle.  S [m,f], T [n,f] -> [m,n]."""
     S = S.astype(f32); T = T.astype(f32)
     acc = np.zeros((S.shape[0], T.shape[0]), f32)
     for f in range(S.shape[1]):
         d = S[:, f][:, None] - T[:, f][None, :]
         acc = acc + d * d
+    if dist_type == 'SquareL2':
+        return acc
+    if dist_type != 'L2':
+        raise NotImplementedError('Not implemented')
     return np.sqrt(acc + f32(1e-7))
 
 
-def knn(target, source, k=1, chunk=500):
-    """knn_module.KNN(k)(target_F[1,f,n], source_F[1,f,m]) on [n,f],[m,f] arrays (knn_search.py:138-162).
-    Returns (d, idx): k==1 -> [m],[m];  k>=2 -> idx [m,k] ordered by increasing distance."""
+def pdist_l2(S, T):
+    return pdist(S, T, 'L2')
+
+
+def knn(target, source, k=1, chunk=500, dist_type='L2'):
+    """knn_module.KNN(k)(target_F[1,f,n], source_F[1,f,m]) on [n,f],[m,f] arrays (knn_search.py:138-162) = find_nn_gpu / find_knn_gpu
+    (:26-103) on (source, target).  Returns (d, idx): k==1 -> [m],[m];  k>=2 -> [m,k],[m,k] ordered by increasing distance."""
     m = source.shape[0]
     ds, ids = [], []
     for s in range(0, m, chunk):
-        D = pdist_l2(source[s:s + chunk], target)
+        D = pdist(source[s:s + chunk], target, dist_type)
         if k < 2:
             i = D.argmin(1)
             ds.append(D[np.arange(D.shape[0]), i]); ids.append(i)
@@ -162,6 +170,16 @@ def knn(target, source, k=1, chunk=500):
             i = np.argsort(D, axis=1, kind='stable')[:, :k]       # topk(-d): ascending d, first index on ties
             ds.append(np.take_along_axis(D, i, 1)); ids.append(i)
     return np.concatenate(ds, 0), np.concatenate(ids, 0).astype(np.int64)
+
+
+def find_corr(F0, F1, mutual=True):
+    """modified_knn_matcher.find_corr without subsampling (knn_search.py:105-136): 'SquareL2' (mutual) nearest neighbours."""
+    _, nn01 = knn(F1, F0, 1, dist_type='SquareL2')
+    if not mutual:
+        return np.arange(F0.shape[0]), nn01
+    _, nn10 = knn(F0, F1, 1, dist_type='SquareL2')
+    keep = [i for i in range(len(nn01)) if nn10[nn01[i]] == i]
+    return np.array(keep, np.int64), nn01[keep]
 
 
 def nms_sample(keys, scores, num, k=5):

@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *p, un
     if (i < n) p[i] = v;
 }
 
-template <int F>
+// SQ: dist_type 'SquareL2' (utils/knn_search.py:21-22): the key is the squared distance itself (no 1e-7, no root), so two targets whose
+// roots round to the same float are still told apart by their radicands.
+template <int F, bool SQ>
 __global__ __launch_bounds__(256) void nn_search_kernel(const float *__restrict__ src, const int64_t *__restrict__ src_rows, int m,
                                                         const float *__restrict__ tgt, const int64_t *__restrict__ tgt_rows, int n,
                                                         int slice, unsigned long long *__restrict__ packed) {
@@ -47,6 +49,10 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float *__restrict_
         for (int f = 0; f < F; ++f) {
             const float d = __fsub_rn(s[f], t[f]);
             acc = __fadd_rn(acc, __fmul_rn(d, d));
+        }
+        if (SQ) {
+            if (acc < best_d) { best_d = acc; best_j = j; }
+            continue;
         }
         const float x = __fadd_rn(acc, 1e-7f);
         if (x < best_x) {                      // sqrt is monotone: only a smaller radicand can give a smaller d
@@ -71,9 +77,9 @@ __global__ __launch_bounds__(256) void nn_unpack_kernel(const unsigned long long
 }
 
 // k nearest with k <= 8: each thread keeps a sorted list; full scan (used for F=3 NMS neighbourhoods).
-template <int F>
+template <int F, bool SQ>
 __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict__ src, int m, const float *__restrict__ tgt, int n,
-                                                         int k, int64_t *__restrict__ idx_out) {
+                                                         int k, int64_t *__restrict__ idx_out, float *__restrict__ dist_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ii = i < m ? i : m - 1;
     float s[F];
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
             const float d = __fsub_rn(s[f], t[f]);
             acc = __fadd_rn(acc, __fmul_rn(d, d));
         }
-        float d = sqrtf(__fadd_rn(acc, 1e-7f));
+        float d = SQ ? acc : sqrtf(__fadd_rn(acc, 1e-7f));
         int dj = j;
         // insertion into the sorted list; strict '<' keeps the earlier index ahead on ties
 #pragma unroll
@@ -103,14 +109,17 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
         }
     }
     if (i < m)
-        for (int q = 0; q < k; ++q) idx_out[(size_t)i * k + q] = bj[q];
+        for (int q = 0; q < k; ++q) {
+            idx_out[(size_t)i * k + q] = bj[q];
+            if (dist_out) dist_out[(size_t)i * k + q] = bd[q];
+        }
 }
 
 // the same scan over one slice of the targets (grid.y slices fill the chip: one thread per source alone is 20 workgroups at m = 5000);
 // per-slice sorted lists go to a workspace and are merged in slice order = index order, so ties still resolve to the first index
 // Segments (several clouds per launch, blockIdx.z = cloud): seg_src / seg_tgt [P+1] are row offsets into the stacked point lists, a
 // source only sees the targets of its own segment and the indices written are LOCAL to the segment.  seg_src == nullptr: one search.
-template <int F>
+template <int F, bool SQ>
 __global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict__ src, int m, const float *__restrict__ tgt, int n, int k, int slice,
                                                         float *__restrict__ pd, int *__restrict__ pj, const int *__restrict__ seg_src,
                                                         const int *__restrict__ seg_tgt, int m_total) {
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict_
             const float d = __fsub_rn(s[f], t[f]);
             acc = __fadd_rn(acc, __fmul_rn(d, d));
         }
-        float d = sqrtf(__fadd_rn(acc, 1e-7f));
+        float d = SQ ? acc : sqrtf(__fadd_rn(acc, 1e-7f));
         int dj = j;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict_
 }
 
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float *__restrict__ pd, const int *__restrict__ pj, int m, int slices, int k,
-                                                        int64_t *__restrict__ idx_out) {
+                                                        int64_t *__restrict__ idx_out, float *__restrict__ dist_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     float bd[8];
@@ -184,7 +193,26 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float *__restrict_
             }
         }
     }
-    for (int q = 0; q < k; ++q) idx_out[(size_t)i * k + q] = bj[q];
+    for (int q = 0; q < k; ++q) {
+        idx_out[(size_t)i * k + q] = bj[q];
+        if (dist_out) dist_out[(size_t)i * k + q] = bd[q];
+    }
+}
+
+// The full distance matrix of modified_knn_matcher.pdist (utils/knn_search.py:17-24), any feature width: one thread per entry, sources along
+// threadIdx.y (their rows are re-read from L1), targets along threadIdx.x (coalesced stores).
+template <bool SQ>
+__global__ __launch_bounds__(256) void pdist_kernel(const float *__restrict__ A, int m, const float *__restrict__ B, int n, int F, float *__restrict__ out) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= m || j >= n) return;
+    const float *a = A + (size_t)i * F, *b = B + (size_t)j * F;
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float d = __fsub_rn(a[f], b[f]);
+        acc = __fadd_rn(acc, __fmul_rn(d, d));
+    }
+    out[(size_t)i * n + j] = SQ ? acc : sqrtf(__fadd_rn(acc, 1e-7f));
 }
 
 // mutual check + ordered compaction by a single workgroup (m <= a few thousand)
@@ -231,12 +259,11 @@ __global__ __launch_bounds__(1024) void mutual_kernel(const int64_t *__restrict_
 
 }  // namespace
 
-extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m, const float *tgt, const int64_t *tgt_rows,
-                               int n, int F, int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream) {
+extern "C" int roreg_nn_search_ex(const float *src, const int64_t *src_rows, int m, const float *tgt, const int64_t *tgt_rows,
+                                  int n, int F, int squared, int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream) {
     if (m == 0) return 0;
     ROREG_REQUIRE(src && tgt && idx_out && scratch && m > 0 && n > 0, "roreg_nn_search: bad arguments");
     ROREG_REQUIRE(F == 32 || F == 3, "roreg_nn_search: F must be 32 or 3 (got %d)", F);
-    if (m == 0) return 0;
     hipStream_t s = roreg::as_stream(stream);
     unsigned long long *g_packed = reinterpret_cast<unsigned long long *>(scratch);
     hipLaunchKernelGGL(fill_u64_kernel, dim3((m + 255) / 256), dim3(256), 0, s, g_packed, ~0ull, m);
@@ -245,12 +272,27 @@ extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m,
     if (slices > n) slices = n;
     const int slice = (n + slices - 1) / slices;
     slices = (n + slice - 1) / slice;
-    if (F == 32)
-        hipLaunchKernelGGL(nn_search_kernel<32>, dim3(gx, slices), dim3(256), 0, s, src, src_rows, m, tgt, tgt_rows, n, slice, g_packed);
-    else
-        hipLaunchKernelGGL(nn_search_kernel<3>, dim3(gx, slices), dim3(256), 0, s, src, src_rows, m, tgt, tgt_rows, n, slice, g_packed);
+#define ROREG_NN(F_, SQ_) hipLaunchKernelGGL((nn_search_kernel<F_, SQ_>), dim3(gx, slices), dim3(256), 0, s, src, src_rows, m, tgt, tgt_rows, n, slice, g_packed)
+    if (F == 32) { if (squared) ROREG_NN(32, true); else ROREG_NN(32, false); }
+    else { if (squared) ROREG_NN(3, true); else ROREG_NN(3, false); }
+#undef ROREG_NN
     hipLaunchKernelGGL(nn_unpack_kernel, dim3((m + 255) / 256), dim3(256), 0, s, g_packed, m, idx_out, dist_out);
     ROREG_CHECK_LAUNCH("roreg_nn_search");
+    return 0;
+}
+
+extern "C" int roreg_nn_search(const float *src, const int64_t *src_rows, int m, const float *tgt, const int64_t *tgt_rows,
+                               int n, int F, int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream) {
+    return roreg_nn_search_ex(src, src_rows, m, tgt, tgt_rows, n, F, 0, idx_out, dist_out, scratch, stream);
+}
+
+extern "C" int roreg_pdist(const float *A, int m, const float *B, int n, int F, int squared, float *out, void *stream) {
+    if (m == 0 || n == 0) return 0;
+    ROREG_REQUIRE(A && B && out && m > 0 && n > 0 && F > 0, "roreg_pdist: bad arguments");
+    const dim3 grid((n + 63) / 64, (m + 3) / 4);
+    if (squared) hipLaunchKernelGGL(pdist_kernel<true>, grid, dim3(256), 0, roreg::as_stream(stream), A, m, B, n, F, out);
+    else hipLaunchKernelGGL(pdist_kernel<false>, grid, dim3(256), 0, roreg::as_stream(stream), A, m, B, n, F, out);
+    ROREG_CHECK_LAUNCH("roreg_pdist");
     return 0;
 }
 
@@ -266,8 +308,8 @@ extern "C" size_t roreg_knn_search_workspace(int m, int n) {
     return slices > 1 ? (size_t)slices * m * 8 * (sizeof(float) + sizeof(int)) : 0;
 }
 
-extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k, int64_t *idx_out, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+extern "C" int roreg_knn_search_ex(const float *src, int m, const float *tgt, int n, int F, int k, int squared, int64_t *idx_out, float *dist_out,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
     if (m == 0) return 0;
     ROREG_REQUIRE(src && tgt && idx_out && m > 0 && n > 0, "roreg_knn_search: bad arguments");
     ROREG_REQUIRE(k >= 1 && k <= 8 && k <= n, "roreg_knn_search: k must be in 1..min(8,n) (got %d)", k);
@@ -275,20 +317,30 @@ extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n
     hipStream_t s = roreg::as_stream(stream);
     const int slices = knn_slices(m, n);
     const size_t need = roreg_knn_search_workspace(m, n);
+    const int *none = nullptr;
     if (slices > 1 && workspace && workspace_bytes >= need) {
         float *pd = reinterpret_cast<float *>(workspace);
         int *pj = reinterpret_cast<int *>(pd + (size_t)slices * m * 8);
         const int slice = (n + slices - 1) / slices;
         const dim3 grid((m + 255) / 256, (n + slice - 1) / slice);
-        if (F == 3) hipLaunchKernelGGL(knn_slice_kernel<3>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj, (const int *)nullptr, (const int *)nullptr, m);
-        else hipLaunchKernelGGL(knn_slice_kernel<32>, grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj, (const int *)nullptr, (const int *)nullptr, m);
-        hipLaunchKernelGGL(knn_merge_kernel, dim3((m + 255) / 256), dim3(256), 0, s, pd, pj, m, (int)grid.y, k, idx_out);
+#define ROREG_KS(F_, SQ_) hipLaunchKernelGGL((knn_slice_kernel<F_, SQ_>), grid, dim3(256), 0, s, src, m, tgt, n, k, slice, pd, pj, none, none, m)
+        if (F == 3) { if (squared) ROREG_KS(3, true); else ROREG_KS(3, false); }
+        else { if (squared) ROREG_KS(32, true); else ROREG_KS(32, false); }
+#undef ROREG_KS
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((m + 255) / 256), dim3(256), 0, s, pd, pj, m, (int)grid.y, k, idx_out, dist_out);
     } else {                                           // no workspace: the single-pass scan (one thread per source)
-        if (F == 3) hipLaunchKernelGGL(knn_search_kernel<3>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
-        else hipLaunchKernelGGL(knn_search_kernel<32>, dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out);
+#define ROREG_K1(F_, SQ_) hipLaunchKernelGGL((knn_search_kernel<F_, SQ_>), dim3((m + 255) / 256), dim3(256), 0, s, src, m, tgt, n, k, idx_out, dist_out)
+        if (F == 3) { if (squared) ROREG_K1(3, true); else ROREG_K1(3, false); }
+        else { if (squared) ROREG_K1(32, true); else ROREG_K1(32, false); }
+#undef ROREG_K1
     }
     ROREG_CHECK_LAUNCH("roreg_knn_search");
     return 0;
+}
+
+extern "C" int roreg_knn_search(const float *src, int m, const float *tgt, int n, int F, int k, int64_t *idx_out, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    return roreg_knn_search_ex(src, m, tgt, n, F, k, 0, idx_out, nullptr, workspace, workspace_bytes, stream);
 }
 extern "C" size_t roreg_knn_search_seg_workspace(long long m_total, int n_seg, int max_m, int max_n) {
     const int gx = (max_m + 255) / 256;
@@ -314,9 +366,9 @@ extern "C" int roreg_knn_search_seg(const float *src, const float *tgt, const in
     float *pd = reinterpret_cast<float *>(workspace);
     int *pj = reinterpret_cast<int *>(pd + (size_t)slices * m_total * 8);
     const dim3 grid(gx, slices, n_seg);
-    if (F == 3) hipLaunchKernelGGL(knn_slice_kernel<3>, grid, dim3(256), 0, s, src, 0, tgt, 0, k, 0, pd, pj, seg_src, seg_tgt, (int)m_total);
-    else hipLaunchKernelGGL(knn_slice_kernel<32>, grid, dim3(256), 0, s, src, 0, tgt, 0, k, 0, pd, pj, seg_src, seg_tgt, (int)m_total);
-    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, pd, pj, (int)m_total, slices, k, idx_out);
+    if (F == 3) hipLaunchKernelGGL((knn_slice_kernel<3, false>), grid, dim3(256), 0, s, src, 0, tgt, 0, k, 0, pd, pj, seg_src, seg_tgt, (int)m_total);
+    else hipLaunchKernelGGL((knn_slice_kernel<32, false>), grid, dim3(256), 0, s, src, 0, tgt, 0, k, 0, pd, pj, seg_src, seg_tgt, (int)m_total);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, pd, pj, (int)m_total, slices, k, idx_out, (float *)nullptr);
     ROREG_CHECK_LAUNCH("roreg_knn_search_seg");
     return 0;
 }

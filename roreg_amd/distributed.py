@@ -166,28 +166,99 @@ def unpack_rows(table):
     return out
 
 
-def gather_table(local, device=None, counts=None):
+def forced():
+    """ROREG_FORCE_COLLECTIVES=1 (bench.py --force-collectives): a one-rank job still issues every collective and sends the extractor outputs of
+    a few clouds to itself, so that a single GPU executes the RCCL code path (the all_gather of the table, the grouped send/recv)."""
+    import os
+    return os.environ.get('ROREG_FORCE_COLLECTIVES', '0') not in ('', '0')
+
+
+class watchdog:
+    """`with watchdog(seconds, 'what'):` -- if the block has not finished after `seconds`, every thread's stack is written to stderr and the
+    process ends with status 1 (faulthandler's own C thread: it needs neither the GIL nor a live Python main thread, so it also fires
+    while the host is stuck inside a collective or a stream synchronisation behind one).  A hung rank then fails the whole job
+    (torch.distributed.run tears the other ranks down) instead of holding the node.  Nothing is re-executed and nothing forks.
+    Blocks may nest: leaving the inner one re-arms the outer one with the time it has left.  seconds <= 0 disables."""
+    _stack = []
+
+    def __init__(self, seconds, what=''):
+        self.seconds, self.what = float(seconds), what
+
+    @staticmethod
+    def _arm(deadline, what):
+        import faulthandler, sys, time
+        left = max(deadline - time.monotonic(), 0.05)
+        sys.stderr.flush()
+        faulthandler.dump_traceback_later(left, exit=True)
+
+    def __enter__(self):
+        import time
+        if self.seconds > 0:
+            self.deadline = time.monotonic() + self.seconds
+            watchdog._stack.append((self.deadline, self.what))
+            self._arm(self.deadline, self.what)
+        return self
+
+    def __exit__(self, *exc):
+        import faulthandler
+        if self.seconds > 0:
+            watchdog._stack.pop()
+            faulthandler.cancel_dump_traceback_later()
+            if watchdog._stack:
+                self._arm(*watchdog._stack[-1])
+        return False
+
+
+def collective_timeout(default=60.0):
+    import os
+    return float(os.environ.get('ROREG_COLLECTIVE_TIMEOUT_S', default))
+
+
+def init_collectives(backend, rank, world, dev_index=None, timeout_s=None):
+    """init_process_group + the group's first world-wide collective (a barrier), under the hang watchdog.  backend 'nccl' = RCCL: the group
+    is bound to this rank's GPU (`device_id`), the barrier names it (`device_ids`).  The extractor-output exchange is a batched send/recv in
+    which only SOME ranks take part, and a group's first call must involve all of its ranks -- hence the barrier here.
+    Works at world size 1 too (forced collectives on a single GPU)."""
+    import datetime, os, socket
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if 'MASTER_PORT' not in os.environ:
+        if world != 1:
+            raise RuntimeError('init_collectives: MASTER_PORT is not set (start the ranks with torch.distributed.run)')
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s.getsockname()[1]); s.close()
+    t = collective_timeout(120.0) if timeout_s is None else timeout_s
+    with watchdog(t, 'init_process_group + first barrier'):
+        kw = {'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(t, 30.0) * 4), **kw)
+        dist.barrier(device_ids=[dev_index]) if backend == 'nccl' else dist.barrier()
+    return dist
+
+
+def gather_table(local, device=None, counts=None, force=None, group=None):
     """all_gather of ragged [n_r, ROW] float64 tables -> [sum n_r, ROW] on every rank (rank order).
     counts: the number of rows of every rank when it is known beforehand (it is: every rank derives the same shard plan) -- then this is
-    ONE collective; without it the sizes are exchanged first."""
+    ONE collective; without it the sizes are exchanged first.
+    A one-rank group returns `local` without a collective unless force (default: forced()) -- then the same calls run with one rank."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    force = forced() if force is None else force
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return np.asarray(local, np.float64).reshape(-1, ROW)
-    world = dist.get_world_size()
-    dev = device if device is not None else ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else ('cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
     if counts is None:
         n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
         sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, n)
+        dist.all_gather(sizes, n, group=group)
         counts = [int(c.item()) for c in sizes]
-    elif len(local) != counts[dist.get_rank()]:
-        raise ValueError(f'gather_table: rank {dist.get_rank()} holds {len(local)} rows, the plan says {counts[dist.get_rank()]}')
+    elif len(local) != counts[rank]:
+        raise ValueError(f'gather_table: rank {rank} holds {len(local)} rows, the plan says {counts[rank]}')
     mx = max(max(counts), 1)
     buf = torch.zeros((mx, ROW), dtype=torch.float64, device=dev)
     if len(local):
         buf[:len(local)] = torch.as_tensor(np.asarray(local, np.float64), device=dev)
     out = torch.empty((world * mx, ROW), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(out, buf)                         # (one call path for nccl and gloo: the CPU tests exercise it)
+    dist.all_gather_into_tensor(out, buf, group=group)            # (one call path for nccl and gloo: the CPU tests exercise it)
     out = out.view(world, mx, ROW).cpu().numpy()
     return np.concatenate([out[r, :c] for r, c in enumerate(counts)], 0).reshape(-1, ROW)
 
@@ -234,13 +305,16 @@ class EqvExchange:
     """The point-to-point exchange of extractor outputs at the start of a step: one torch.distributed.batch_isend_irecv (backend nccl = RCCL:
     one grouped launch, device buffers, xGMI peer-to-peer; the sends read `eqv` on the stream it was produced on, the transfer itself runs on
     the communicator's stream beside this rank's whole scenes).  Under gloo (CPU tests; the shared-GPU control-flow check) the payload is
-    staged through host memory."""
+    staged through host memory.  A transfer whose source and destination are the same rank (forced collectives on one GPU) is a send AND a
+    receive of that rank inside the one group."""
 
-    def __init__(self, rank, device_payloads=None):
+    def __init__(self, rank, device_payloads=None, group=None):
         import torch.distributed as dist
         self.rank = rank
-        self.on_device = (dist.get_backend() == 'nccl') if device_payloads is None else device_payloads
+        self.group = group
+        self.on_device = (dist.get_backend(group) == 'nccl') if device_payloads is None else device_payloads
         self.works, self.landed = [], []
+        self.bytes_sent = self.bytes_received = 0
 
     def start(self, transfers, get_eqv, alloc):
         """transfers: the canonical list (all ranks'); get_eqv(scene, cloud) -> the tensor to send; alloc(scene, cloud) -> the tensor to
@@ -248,16 +322,23 @@ class EqvExchange:
         import torch.distributed as dist
         ops, keep = [], []
         for tag, (s, i, src, dst) in enumerate(transfers):
+            if src == dst == self.rank and not self.on_device:       # (gloo has no pair to itself: a host-staged self-transfer is the staging copy alone)
+                t = get_eqv(s, i); buf = alloc(s, i)
+                self.landed.append(((s, i), buf, t.cpu()))
+                self.bytes_sent += t.numel() * t.element_size(); self.bytes_received += buf.numel() * buf.element_size()
+                continue
             if src == self.rank:
                 t = get_eqv(s, i)
                 t = t if self.on_device else t.cpu()
                 keep.append(t)
-                ops.append(dist.P2POp(dist.isend, t, dst, tag=tag))
-            elif dst == self.rank:
+                self.bytes_sent += t.numel() * t.element_size()
+                ops.append(dist.P2POp(dist.isend, t, dst, group=self.group, tag=tag))
+            if dst == self.rank:
                 buf = alloc(s, i)
                 stage = buf if self.on_device else torch.empty(buf.shape, dtype=buf.dtype)
                 self.landed.append(((s, i), buf, stage))
-                ops.append(dist.P2POp(dist.irecv, stage, src, tag=tag))
+                self.bytes_received += buf.numel() * buf.element_size()
+                ops.append(dist.P2POp(dist.irecv, stage, src, group=self.group, tag=tag))
         self.keep = keep
         self.works = dist.batch_isend_irecv(ops) if ops else []
 
@@ -274,11 +355,29 @@ class EqvExchange:
         return out
 
 
-def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, min_jobs=None, min_pairs=48, **run_kw):
+def self_transfers(pieces, pair_lists, rank=0, n_clouds=4):
+    """Forced collectives on one rank: the first `n_clouds` clouds of the LAST scene of `pieces` are 'shipped' from this rank to itself
+    (extract -> isend -> irecv -> rebuild the derivatives), which drives run_plan's whole exchange branch with a one-rank group."""
+    if not pieces:
+        return []
+    s, a, b = pieces[-1]
+    ids = []
+    for pr in pair_lists[s][a:b]:
+        for i in pr:
+            if int(i) not in ids:
+                ids.append(int(i))
+    return [(s, i, rank, rank) for i in sorted(ids[:n_clouds])]
+
+
+def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, min_jobs=None, min_pairs=48, stats=None, seeded=None, **run_kw):
     """One pass of this rank's share of a shard plan.  pieces [(scene, a, b)]; scene_inputs(scene) -> (feats, keys, pair_ids, pair_seeds or
     None) with feats / keys indexable by int cloud id; transfers: exchange_plan()'s list (empty: every rank extracts what it touches).
     Order: (0) the clouds this rank owns and others need are extracted and sent, the receives are posted; (1) the scenes this rank
-    holds without imports; (2) the pair ranges that wait for imported clouds.  -> [(scene, a, b, [PairResult])] in `pieces` order."""
+    holds without imports; (2) the pair ranges that wait for imported clouds.  -> [(scene, a, b, [PairResult])] in `pieces` order.
+    stats (a dict, optional) receives 'eqv_bytes_sent' / 'eqv_bytes_received' of this pass.
+    seeded: whether scene_inputs() hands out per-pair seeds (the condition for software-pipelining the jobs); None = ask scene_inputs for
+    every piece up front (fine when that is cheap; a driver whose scene_inputs reads files passes the flag instead, so that a scene's
+    inputs are touched only when the pipeline reaches it)."""
     if min_jobs is None:
         import os
         min_jobs = int(os.environ.get('ROREG_PLAN_MIN_JOBS', 2))   # (the switch is for A/B measurements: 1 / 2 / 4 measured alike, profiles/r03_split_ab.txt)
@@ -313,7 +412,9 @@ def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, 
     for q in order:
         s, a, b = pieces[q]
         jobs.append([q, a, b, cache.setdefault(s, {}) if s in shared else None])
-    pipelined = hasattr(engine, 'run_scenes') and all(scene_inputs(pieces[q][0])[3] is not None for q in order)
+    if seeded is None:
+        seeded = all(scene_inputs(pieces[q][0])[3] is not None for q in order)
+    pipelined = hasattr(engine, 'run_scenes') and bool(seeded)
     if pipelined:
         while len(jobs) < min_jobs:
             k = max(range(len(jobs)), key=lambda i: jobs[i][2] - jobs[i][1])
@@ -348,4 +449,7 @@ def run_plan(engine, pieces, scene_inputs, transfers=(), rank=0, exchange=None, 
     waited = state['waited']
     if ex is not None and not waited:                              # a rank that only sends: its sends complete before the step ends
         ex.wait()
+    if stats is not None:
+        stats['eqv_bytes_sent'] = stats.get('eqv_bytes_sent', 0) + (ex.bytes_sent if ex is not None else 0)
+        stats['eqv_bytes_received'] = stats.get('eqv_bytes_received', 0) + (ex.bytes_received if ex is not None else 0)
     return out

@@ -32,7 +32,13 @@ if GEMM_MODE not in GEMM_MODES:
 # half-block layout by LDS-DMA (csrc/fourier.hip irrep_gemm_xdma_kernel); ROREG_GEMM_XDMA=0: the word layout + register staging (A/B switch,
 # bitwise the same results)
 XDMA = os.environ.get('ROREG_GEMM_XDMA', '1') == '1'
-ABI_VERSION = 3          # == ROREG_ABI_VERSION of include/roreg_hip.h; lib() refuses a library that reports another one
+
+
+def use_planes(O):
+    """Whether the fp16 x 2 GEMM with O output channels takes its activations in the half-block layout (LDS-DMA kernel): decided HERE for
+    both ft_nonlin(planes=) and irrep_gemm(x_planes=) -- the kernel needs the 256-row tile (O % 256 == 0, not ROREG_TILE_M128)."""
+    return bool(XDMA and O % 256 == 0 and not os.environ.get('ROREG_TILE_M128'))
+ABI_VERSION = 4          # == ROREG_ABI_VERSION of include/roreg_hip.h; lib() refuses a library that reports another one
 _lib = None
 _tables_uploaded = False
 
@@ -54,8 +60,11 @@ PROTOTYPES = {
     'roreg_det_score': (c_int, [_P, _P, c_int, _P]),
     'roreg_inv_descriptor': (c_int, [_P, c_int, _P, c_int, _P]),
     'roreg_nn_search': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    'roreg_nn_search_ex': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    'roreg_pdist': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
     'roreg_knn_search_workspace': (c_size_t, [c_int, c_int]),
     'roreg_knn_search': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    'roreg_knn_search_ex': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     'roreg_knn_search_seg_workspace': (c_size_t, [ctypes.c_longlong, c_int, c_int, c_int]),
     'roreg_knn_search_seg': (c_int, [_P, _P, _P, _P, c_int, ctypes.c_longlong, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     'roreg_mutual_matches': (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
@@ -312,6 +321,27 @@ def full_gather():
     return gather_table('nei60', tables().Nei)
 
 
+_lds_order_ok = set()
+
+
+def _check_lds_order(order_t, stride, gather, Lin):
+    """The contract of roreg_group_conv_{split,f16x2}'s lds_order, enforced once per (table, gather) pair on the host: every input column the
+    gather table reads has a slot in [0, stride), and no two of them share one (the kernel uses order[gather[i]] as an LDS address
+    unchecked: a -1, a slot >= stride or a duplicate would alias or overrun LDS silently)."""
+    key = (order_t.data_ptr(), int(stride), gather.data_ptr())
+    if key in _lds_order_ok:
+        return
+    if order_t.numel() != Lin or not 1 <= int(stride) <= 64:
+        raise HipError(f'group_conv: lds_order must hold one slot per input column ({Lin}) and a stride in 1..64')
+    o = order_t.cpu().numpy(); cols = np.unique(gather.cpu().numpy())
+    if cols.min() < 0 or cols.max() >= Lin:
+        raise HipError('group_conv: the gather table reads a column outside the input')
+    slots = o[cols]
+    if slots.min() < 0 or slots.max() >= stride or np.unique(slots).size != slots.size:
+        raise HipError(f'group_conv: lds_order must give the {cols.size} gathered columns distinct slots in [0, {stride})')
+    _lds_order_ok.add(key)
+
+
 def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=False, in_rowmax=None, want_rowmax=False, lds_order=None):
     """x [B,Cin,Lin] f32 -> [B,Cout,Lout] f32.  split: use the 3 x bf16 split kernel (f32-accurate) where its shape constraints hold;
     with in_rowmax (device float32 [B], tracked max |x[b]| per row) the fp16 x 2 kernel, whose block scale is per row (a row's result does
@@ -328,8 +358,8 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
     split_ok = residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0
     order_t, order_s = (None, 0) if lds_order is None else lds_order
-    if order_t is not None and (order_t.numel() != Lin or not 1 <= int(order_s) <= 64):
-        raise HipError(f'group_conv: lds_order must hold one slot per input column ({Lin}) and a stride in 1..64')
+    if order_t is not None:
+        _check_lds_order(order_t, order_s, gather, Lin)
     if in_rowmax is not None:
         if not split_ok:
             raise HipError('group_conv: the fp16 x 2 kernel does not support this shape')
@@ -388,27 +418,40 @@ def inv_descriptor(eqv):
     return out
 
 
-def nn_search(src, tgt, src_rows=None, tgt_rows=None, want_dist=False):
-    """nearest target for every source.  src [*,F], tgt [*,F] f32; optional int64 row lists."""
+def nn_search(src, tgt, src_rows=None, tgt_rows=None, want_dist=False, squared=False):
+    """nearest target for every source.  src [*,F], tgt [*,F] f32; optional int64 row lists.  squared: dist_type 'SquareL2'."""
     F = src.shape[1]
     m = int(src_rows.shape[0]) if src_rows is not None else int(src.shape[0])
     n = int(tgt_rows.shape[0]) if tgt_rows is not None else int(tgt.shape[0])
     idx = torch.empty(m, dtype=torch.int64, device=src.device)
     dist = torch.empty(m, dtype=torch.float32, device=src.device) if want_dist else None
     scratch = torch.empty(max(m, 1), dtype=torch.int64, device=src.device)
-    _check(lib().roreg_nn_search(_ptr(src, torch.float32), _ptr(src_rows, torch.int64), m, _ptr(tgt, torch.float32),
-                                 _ptr(tgt_rows, torch.int64), n, F, _ptr(idx), _ptr(dist), _ptr(scratch), _stream()), 'roreg_nn_search')
+    _check(lib().roreg_nn_search_ex(_ptr(src, torch.float32), _ptr(src_rows, torch.int64), m, _ptr(tgt, torch.float32),
+                                    _ptr(tgt_rows, torch.int64), n, F, 1 if squared else 0, _ptr(idx), _ptr(dist), _ptr(scratch), _stream()), 'roreg_nn_search')
     return (idx, dist) if want_dist else idx
 
 
-def knn_search(src, tgt, k):
+def knn_search(src, tgt, k, want_dist=False, squared=False):
     m, F = src.shape
     n = tgt.shape[0]
     idx = torch.empty((m, k), dtype=torch.int64, device=src.device)
+    dist = torch.empty((m, k), dtype=torch.float32, device=src.device) if want_dist else None
     ws_n = lib().roreg_knn_search_workspace(m, n)
     ws = torch.empty(ws_n // 4, dtype=torch.int32, device=src.device) if ws_n else None
-    _check(lib().roreg_knn_search(_ptr(src, torch.float32), m, _ptr(tgt, torch.float32), n, F, k, _ptr(idx), _ptr(ws), ws_n, _stream()), 'roreg_knn_search')
-    return idx
+    _check(lib().roreg_knn_search_ex(_ptr(src, torch.float32), m, _ptr(tgt, torch.float32), n, F, k, 1 if squared else 0, _ptr(idx), _ptr(dist),
+                                     _ptr(ws), ws_n, _stream()), 'roreg_knn_search')
+    return (idx, dist) if want_dist else idx
+
+
+def pdist(A, B, squared=False):
+    """[m,F] x [n,F] f32 -> the [m,n] distance matrix of modified_knn_matcher.pdist (utils/knn_search.py:17-24)."""
+    m, F = A.shape
+    n = B.shape[0]
+    if B.shape[1] != F:
+        raise HipError(f'pdist: feature widths differ ({F} vs {B.shape[1]})')
+    out = torch.empty((m, n), dtype=torch.float32, device=A.device)
+    _check(lib().roreg_pdist(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, F, 1 if squared else 0, _ptr(out), _stream()), 'roreg_pdist')
+    return out
 
 
 def knn_search_seg(pts, seg, k):

@@ -150,8 +150,8 @@ class ET_test(nn.Module):
                     # row's own bound (hip.row_bound), every later kernel tracks max |output row| on the device as the next kernel's scale,
                     # so a correspondence's quaternion does not depend on which other correspondences share the batch
                     b0 = x_bound if x_bound is not None else hip.row_bound(x, bn=bn)
-                    X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', out_bound=b0, planes=hip.XDMA)      # half-block layout: LDS-DMA GEMM
-                    T0 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0, x_planes=hip.XDMA)
+                    X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', out_bound=b0, planes=hip.use_planes(256))      # half-block layout: LDS-DMA GEMM
+                    T0 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0, x_planes=hip.use_planes(256))
                     del X0
                     h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split='f16x2',
                                           want_rowmax=True)                                                          # [B,256,48]

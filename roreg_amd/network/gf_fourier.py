@@ -88,7 +88,7 @@ class FourierGF:
             T0, b1 = hip.irrep_gemm(X0, None, 32, 256, B, f16x2=self.l_in.wsplit2, x_bound=b0, next_bound=self.nb_1)
             del X0
             # the two big layers' operands in half-block (hi | lo per 32 columns) layout: their activations reach LDS by LDS-DMA (hip.XDMA; csrc/fourier.hip irrep_gemm_xdma_kernel)
-            xd = hip.XDMA
+            xd = hip.use_planes(512) and hip.use_planes(256)
             X1 = hip.ft_nonlin(B, 256, coef_in=T0, bias=self.l_in.bias, bn=self.bn_1, split=sp, out_bound=b1, planes=xd)
             T1, b2 = hip.irrep_gemm(X1, None, 256, 512, B, f16x2=self.l_1.wsplit2, x_bound=b1, next_bound=self.nb_2, x_planes=xd)
             del X1

@@ -87,25 +87,41 @@ def evaluate(cfg, datasets, engine, rank=0, world=1, seed=None, exchange=True):
     transfers = D.exchange_plan(plan, pair_lists)[1] if exchange else []
     inputs = {}
 
+    class LazyFeats:
+        """{cloud id: [N,32,60] float32} of one scene, memory-mapped on access and never held: a cloud's file is read when the engine uploads it
+        (once per extraction), under the kernels of the scenes already in flight; the host keeps no copy (the page cache does)."""
+
+        def __init__(self, fdir, used):
+            self.fdir, self.used = fdir, set(used)
+
+        def __getitem__(self, i):
+            if int(i) not in self.used:
+                raise KeyError(i)
+            return np.load(f'{self.fdir}/{int(i)}.npy', mmap_mode='r')
+
+        def __contains__(self, i):
+            return int(i) in self.used
+
     def scene_inputs(scene):
-        """(feats, keys, pair_ids, seeds) of a scene; the input features of the clouds this rank touches are read once"""
+        """(feats, keys, pair_ids, seeds) of a scene: keypoints (small) are read once, input features stay on disk until they are uploaded"""
         if scene not in inputs:
             ds = datasets[scene]
             used = sorted({int(i) for sc, a, b in plan[rank] if sc == scene for p in ds.pair_ids[a:b] for i in p} |
                           {i for sc, i, src, dst in transfers if sc == scene and rank in (src, dst)})
-            fdir = _feature_dir(cfg, ds)
             seeds = None if seed is None else [(int(seed) + zlib.crc32(f'{scene}:{p0}:{p1}'.encode())) % (2 ** 32) for p0, p1 in ds.pair_ids]
-            inputs[scene] = ({i: np.load(f'{fdir}/{i}.npy') for i in used}, {i: ds.get_kps(str(i)) for i in used}, ds.pair_ids, seeds)
+            inputs[scene] = (LazyFeats(_feature_dir(cfg, ds), used), {i: ds.get_kps(str(i)) for i in used}, ds.pair_ids, seeds)
         return inputs[scene]
 
     rows = []
-    for scene, a, b, res in D.run_plan(engine, plan[rank], scene_inputs, transfers, rank, keynum=cfg.keynum, max_iter=cfg.max_iter, keep_matches=True):
+    for scene, a, b, res in D.run_plan(engine, plan[rank], scene_inputs, transfers, rank, seeded=seed is not None,
+                                       keynum=cfg.keynum, max_iter=cfg.max_iter, keep_matches=True):
         ds = datasets[scene]
         keys = scene_inputs(scene)[1]
         for r in res:                                    # inlier ratio of the (top-scored) correspondences, evaluator.py:50-81
             r.ir = inlier_ratio(cfg, r, keys[int(r.id0)], keys[int(r.id1)], ds.get_transform(r.id0, r.id1))
         rows.append(D.pack_rows(scenes.index(scene), res))
-    table = D.gather_table(np.concatenate(rows, 0) if rows else np.zeros((0, D.ROW)))
+    with D.watchdog(D.collective_timeout(600.0), 'gather of the result table'):     # (waits for the slowest rank's whole share)
+        table = D.gather_table(np.concatenate(rows, 0) if rows else np.zeros((0, D.ROW)))
     if rank != 0:
         return None
     by_scene = {s: {} for s in scenes}
@@ -151,16 +167,11 @@ def main():
     cfg, _ = parser.parse_known_args()
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
-        # a world-wide collective before anything else: the extractor-output exchange is a batched send/recv that only SOME ranks take part
-        # in, and a group's first call must involve all of its ranks (torch.distributed.batch_isend_irecv)
-        dist.barrier(device_ids=[local])
+    if world > 1 or D.forced():
+        D.init_collectives('nccl', rank, world, local)
     datasets = get_dataset_name(cfg.testset, cfg.origin_data_dir)
     evaluate(cfg, datasets, build_engine(cfg), rank, world, cfg.seed)
-    if world > 1:
+    if world > 1 or D.forced():
         import torch.distributed as dist
         dist.destroy_process_group()
 

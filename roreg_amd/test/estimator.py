@@ -241,6 +241,14 @@ class extractor_localtrans():
     def _load_model(self):
         restore_weights(self.network, self.best_model_fn, strict=False)      # (the reference loads this checkpoint non-strictly, estimator.py:289)
 
+    def batch_create(self, feats0_fcgf, feats1_fcgf, feats0_yomo, feats1_yomo, index_pre, start, end):
+        """The ET network's input dictionary for correspondences [start, end) of gathered host arrays (test/estimator.py:293-306; note the
+        exchange: cloud 1 is the `*_eqv0` side, the one the anchor permutes).  Rt_pre() itself gathers on the device (roreg_et_gather)
+        and never builds this dictionary; the method is here for callers that feed ET_test.forward() the reference's way."""
+        cut = lambda a: torch.from_numpy(np.ascontiguousarray(a[start:end], dtype=np.float32))
+        return {'before_eqv0': cut(feats1_fcgf), 'before_eqv1': cut(feats0_fcgf), 'after_eqv0': cut(feats1_yomo), 'after_eqv1': cut(feats0_yomo),
+                'pre_idx': torch.from_numpy(np.ascontiguousarray(index_pre[start:end]).astype(np.int64))}
+
     def Rt_pre(self, dataset, keynum):
         self._load_model()
         self.network.eval()

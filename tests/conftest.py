@@ -51,3 +51,19 @@ if os.environ.get('ROREG_POISON_EMPTY'):
 
     _torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
     _torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
+
+def canon_knn(d, i):
+    """Rows of a k-nearest list re-ordered by (distance, index): torch.topk (the reference's find_knn_gpu, utils/knn_search.py:84) returns
+    exactly tied entries in an unspecified order, ours in index order -- the lists are compared in this canonical order."""
+    d = np.asarray(d); i = np.asarray(i)
+    order = np.lexsort((i, d), axis=-1)
+    return np.take_along_axis(d, order, -1), np.take_along_axis(i, order, -1)
+
+
+def same_knn_up_to_duplicates(i, ri, targets):
+    """k-nearest index lists (canonical order) equal except where the two name byte-identical target rows (an exact tie at the list's
+    k-th place: which duplicate makes the list is torch.topk's unspecified choice in the reference)."""
+    i = np.asarray(i); ri = np.asarray(ri)
+    bad = i != ri
+    return bool(np.array_equal(targets[i[bad]], targets[ri[bad]])), int(bad.sum())

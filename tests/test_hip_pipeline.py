@@ -425,6 +425,21 @@ def test_evaluate_world_1_equals_world_2_on_device(tmp_path):
             assert np.array_equal(one[k], two[k]), k
 
 
+def test_rccl_path_on_one_gpu_forced_collectives(tmp_path):
+    """The RCCL code path executed on the one GPU there is (tests/_nccl_worker.py, a fresh process): init_process_group('nccl', world_size 1,
+    device_id) + barrier(device_ids); gather_table's device float64 all_gather_into_tensor; EqvExchange's batch_isend_irecv with device
+    payloads sent from the rank to itself -- payload still being produced by queued kernels when the send is issued, receive buffer
+    poisoned with NaN, consumer enqueued behind wait() with no host synchronisation; run_plan with the real engine through that exchange:
+    table, received `eqv` and every pair's result bitwise equal to the plain pass and to the gloo-staged exchange.  Every section runs
+    under the hang watchdog (status 1 instead of a hung box)."""
+    from test_host_logic import run_forced_collectives
+    rc, log = run_forced_collectives('nccl', tmp_path / 'forced.npz', timeout=600)
+    assert rc == 0 and 'ok' in log, log
+    z = np.load(tmp_path / 'forced.npz')
+    assert z['table'].shape == (37, 21) and int(z['raw_exchange_bytes']) == 5000 * 32 * 60 * 4
+    assert z['rows'].shape == (25, 20) and np.isfinite(z['rows']).all()
+
+
 def test_config3_full_benchmark_shape_through_the_distributed_driver(tmp_path):
     """BASELINE config 3's shape on one GPU: 8 scenes with the 3DMatch station counts [60,60,60,55,57,37,66,38] (dataops/dataset.py:152) =
     433 clouds and 1623 pairs through run_distributed.evaluate (shard plan, engine, result table, metrics), at 256 keypoints per cloud so

@@ -24,7 +24,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(L, name), f'{name} declared in roreg_hip.h but not exported'
         assert name in hip.PROTOTYPES, f'{name} has no ctypes prototype'
     assert sorted(hip.PROTOTYPES) == declared
-    assert L.roreg_abi_version() == hip.ABI_VERSION == 3
+    assert L.roreg_abi_version() == hip.ABI_VERSION == 4
     assert int(re.search(r'#define\s+ROREG_ABI_VERSION\s+(\d+)', header).group(1)) == hip.ABI_VERSION
     # pure host entry points work without a GPU
     assert L.roreg_group_conv_packed_size(256, 512, 13) == 13 * 256 * 512
@@ -356,6 +356,52 @@ def test_evaluate_does_not_depend_on_the_number_of_ranks(tmp_path):
     for k in one.files:
         if k != 'split':
             assert np.array_equal(one[k], two[k]), k
+
+
+def test_batch_create_matches_reference():
+    """extractor_localtrans.batch_create (test/estimator.py:293-306): slices, float32 / int64 casts and the 0 <-> 1 exchange."""
+    from roreg_amd.test.estimator import extractor_localtrans
+    z = np.load(os.path.join(GOLDEN, 'batch_create.npz'))
+    ex = extractor_localtrans.__new__(extractor_localtrans)
+    b = ex.batch_create(z['f0_fcgf'], z['f1_fcgf'], z['f0_yomo'], z['f1_yomo'], z['index_pre'], 2, 7)
+    assert sorted(b) == ['after_eqv0', 'after_eqv1', 'before_eqv0', 'before_eqv1', 'pre_idx']
+    for k, v in b.items():
+        assert str(v.dtype) == ('torch.int64' if k == 'pre_idx' else 'torch.float32') and np.array_equal(v.numpy(), z[k]), k
+
+
+def run_forced_collectives(backend, out, timeout=300, extra=()):
+    """tests/_nccl_worker.py in a fresh process -> (return code, output)."""
+    worker = os.path.join(ROOT, 'tests', '_nccl_worker.py')
+    env = dict(os.environ, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env.pop('MASTER_PORT', None)
+    p = subprocess.run([sys.executable, worker, ROOT, backend, str(out), *extra], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=timeout)
+    return p.returncode, p.stdout.decode()
+
+
+def test_forced_collectives_on_one_rank_gloo(tmp_path):
+    """ROREG_FORCE_COLLECTIVES: a one-rank group still runs the table's all_gather (with and without the plan's row counts) and drives
+    run_plan's whole exchange branch with transfers from the rank to itself; the results are bitwise those of the plain pass.  Host
+    control flow over gloo with the stub engine; the same worker runs the RCCL path on the GPU (tests/test_hip_pipeline.py)."""
+    rc, log = run_forced_collectives('gloo', tmp_path / 'forced.npz')
+    assert rc == 0 and 'ok' in log, log
+    z = np.load(tmp_path / 'forced.npz')
+    assert z['table'].shape == (37, 21) and z['rows'].shape[1] == 20
+
+
+def test_watchdog_ends_a_hung_process_with_status_1(tmp_path):
+    """distributed.watchdog: a block that does not return in time ends the process (status 1, stacks on stderr) -- and leaves a block that
+    does return alone, nested blocks included."""
+    rc, log = run_forced_collectives('gloo', tmp_path / 'x.npz', extra=('hang',), timeout=60)
+    assert rc == 1 and 'Timeout' in log and 'did not fire' not in log, log
+    from roreg_amd.distributed import watchdog
+    import time
+    with watchdog(5.0, 'outer'):
+        with watchdog(0.5, 'inner'):
+            pass
+        time.sleep(0.8)                                      # the inner block's timer must be gone; the outer one re-armed with its own deadline
+    with watchdog(0.0, 'disabled'):
+        pass
+    time.sleep(0.2)
 
 
 def _bench_line(argv, env_extra, timeout=600):

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, canon_knn, same_knn_up_to_duplicates
 from oracle import ref_numpy as O
 from roreg_amd import synth
 
@@ -69,6 +69,34 @@ def test_knn_matches_reference():
         assert np.abs(d - z[f'{tag}_d'].reshape(-1)).max() < 1e-6
     _, idx5 = O.knn(z['k5_keys'], z['k5_keys'], 5)
     assert np.array_equal(idx5, z['k5_idx'][0].T)
+
+
+def test_knn_api_matches_reference():
+    """pdist / find_nn_gpu / find_knn_gpu / find_corr in both distance types (utils/knn_search.py:17-136), incl. duplicated targets and
+    near-duplicates whose roots may round together."""
+    z = load_golden('knn_api')
+    A, B = z['A'], z['B']
+    for dt in ('L2', 'SquareL2'):
+        D = O.pdist(A[:40], B, dt)
+        assert np.abs(D - z[f'pdist_{dt}']).max() < 1e-6
+        d, i = O.knn(B, A, 1, dist_type=dt)
+        assert np.array_equal(i, z[f'nn_i_{dt}']) and np.abs(d - z[f'nn_d_{dt}']).max() < 1e-6
+        assert np.array_equal(i, z[f'call1_i_{dt}'].reshape(-1))
+        d, i = O.knn(B, A, 5, dist_type=dt)
+        rd, ri = canon_knn(z[f'knn_d_{dt}'][:, 0, :], z[f'knn_i_{dt}'])        # (exact ties: torch.topk's order is unspecified)
+        ok, n_dup = same_knn_up_to_duplicates(i, ri, B)
+        assert ok and n_dup < 40 and np.abs(d - rd).max() < 1e-6
+        assert np.array_equal(ri, canon_knn(z[f'call5_d_{dt}'][0, :, 0, :].T, z[f'call5_i_{dt}'][0].T)[1])
+        assert z[f'call5_d_{dt}'].shape == (1, 5, 1, A.shape[0])
+    assert np.array_equal(z['nn_i_only'], z['nn_i_SquareL2'])
+    _, i = O.knn(z['K'], z['K'], 5, dist_type='SquareL2')
+    assert np.array_equal(i, z['knn3_i'])                         # (no exact ties among random coordinates: the order is the reference's)
+    i0, i1 = O.find_corr(A, B, mutual=False)
+    assert np.array_equal(i0, z['corr_nm_i0']) and np.array_equal(i1, z['corr_nm_i1'])
+    np.random.seed(77)                                            # find_corr's subsampling: two np.random.choice calls, then the mutual check
+    s0 = np.random.choice(len(A), 256, replace=False); s1 = np.random.choice(len(B), 256, replace=False)
+    k0, k1 = O.find_corr(A[s0], B[s1], mutual=True)
+    assert np.array_equal(s0[k0], z['corr_i0']) and np.array_equal(s1[k1], z['corr_i1'])
 
 
 def test_nms_matches_reference():

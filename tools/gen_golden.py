@@ -146,6 +146,47 @@ def gen_knn():
     save('knn', **out)
 
 
+def gen_knn_api():
+    """The other public methods of modified_knn_matcher (utils/knn_search.py:17-136) and batch_create (test/estimator.py:293-306)."""
+    rng = np.random.default_rng(19)
+    out = {}
+    M = knn_module.KNN(5)
+    A = rng.standard_normal((301, 32)).astype(np.float32); A /= np.linalg.norm(A, axis=1, keepdims=True)
+    B = rng.standard_normal((450, 32)).astype(np.float32); B /= np.linalg.norm(B, axis=1, keepdims=True)
+    B[100:164] = A[:64]                                           # exact hits (distance 0 / sqrt(1e-7)) ...
+    B[200:264] = A[:64]                                           # ... twice: first-index ties
+    B[300:332] = A[:32] + np.float32(3e-5) * rng.standard_normal((32, 32)).astype(np.float32)   # roots that may round together
+    tA, tB = torch.from_numpy(A), torch.from_numpy(B)
+    out.update(A=A, B=B)
+    for dt in ('L2', 'SquareL2'):
+        out[f'pdist_{dt}'] = M.pdist(tA[:40], tB, dist_type=dt).numpy()
+        d, i = M.find_nn_gpu(tA, tB, nn_max_n=128, dist_type=dt)
+        out[f'nn_d_{dt}'] = d.numpy(); out[f'nn_i_{dt}'] = i.numpy()
+        d, i = M.find_knn_gpu(tA, tB, nn_max_n=128, dist_type=dt)
+        out[f'knn_d_{dt}'] = d.numpy(); out[f'knn_i_{dt}'] = i.numpy()
+        d, i = M(tB.T[None], tA.T[None], dist_type=dt)            # __call__(target [1,f,n], source [1,f,m])
+        out[f'call5_d_{dt}'] = d.numpy(); out[f'call5_i_{dt}'] = i.numpy()
+        d, i = knn_module.KNN(1)(tB.T[None], tA.T[None], dist_type=dt)
+        out[f'call1_d_{dt}'] = d.numpy(); out[f'call1_i_{dt}'] = i.numpy()
+    out['nn_i_only'] = M.find_nn_gpu(tA, tB, return_distance=False).numpy()
+    K = rng.uniform(0, 3, (500, 3)).astype(np.float32)
+    d, i = M.find_knn_gpu(torch.from_numpy(K), torch.from_numpy(K))
+    out.update(K=K, knn3_d=d.numpy(), knn3_i=i.numpy())
+    np.random.seed(77)
+    i0, i1 = M.find_corr(tA, tB, subsample_size=256, mutual=True)
+    out.update(corr_i0=i0, corr_i1=i1)
+    np.random.seed(78)
+    i0, i1 = M.find_corr(tA, tB, subsample_size=-1, mutual=False)
+    out.update(corr_nm_i0=i0, corr_nm_i1=i1)
+    save('knn_api', **out)
+    # batch_create: a pure re-labelling of slices (NB the 0/1 exchange)
+    ex = ref_est.extractor_localtrans.__new__(ref_est.extractor_localtrans)
+    f = [rng.standard_normal((9, 4, 6)) for _ in range(4)]        # float64 on purpose: the method casts to float32
+    idx = rng.integers(0, 60, 9)
+    b = ex.batch_create(f[0], f[1], f[2], f[3], idx, 2, 7)
+    save('batch_create', f0_fcgf=f[0], f1_fcgf=f[1], f0_yomo=f[2], f1_yomo=f[3], index_pre=idx, **{k: v.numpy() for k, v in b.items()})
+
+
 def gen_nms():
     rng = np.random.default_rng(10)
     out = {}
@@ -382,6 +423,10 @@ def gen_rr_cal():
 
 
 def main():
+    if len(sys.argv) > 1:                                          # python tools/gen_golden.py knn_api ... : only the named fixtures
+        for name in sys.argv[1:]:
+            print(name); globals()[f'gen_{name}']()
+        return
     root = tempfile.mkdtemp(prefix='golden_cfg_')
     try:
         cfg = make_cfg(root)
@@ -389,6 +434,7 @@ def main():
         print('gf'); gen_gf(cfg)
         print('rd'); gen_rd(cfg)
         print('knn'); gen_knn()
+        print('knn_api'); gen_knn_api()
         print('nms'); gen_nms()
         print('des2r'); gen_des2r(cfg)
         print('et'); gen_et(cfg)

@@ -37,6 +37,9 @@ def main():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # bench.py quotes `roofline.traffic` from this file only while csrc/fourier.hip still hashes to kernel_source_sha16
     res = {'hbm_bytes_per_launch': {}, 'detail': {}, 'git_commit': os.environ.get('ROREG_GIT_COMMIT'),
+           # the conditions of the profiled command (bench.py refuses to quote the figure for a run under other ones); ROREG_PMC_CONDITIONS = JSON overrides
+           'conditions': dict({'kpts': 5000, 'dtype': 'fp32', 'gpus': 1, 'pair_lists': 'banded', 'xdma': os.environ.get('ROREG_GEMM_XDMA', '1') != '0'},
+                              **json.loads(os.environ.get('ROREG_PMC_CONDITIONS', '{}'))),
            'kernel_source_sha16': hashlib.sha256(open(os.path.join(here, 'roreg_amd', 'csrc', 'fourier.hip'), 'rb').read()).hexdigest()[:16]}
     for spec in sys.argv[3:]:
         mode, d = spec.split('=')
