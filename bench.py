@@ -295,6 +295,11 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch(args))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    # stdout carries ONE line, the JSON record: everything else this process or its libraries write to file descriptor 1 (RCCL prints a version
+    # banner there when a communicator is created) goes to stderr; the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     if world != args.gpus:
         print(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)', file=sys.stderr)
         sys.exit(3)
@@ -598,7 +603,7 @@ def main():
                                                 'sample': 'oracle/ref_numpy.py (the parity oracle; BLAS-threaded matmuls, single-threaded gathers): GF on 512 kpts, '
                                                           'mutual on 2500 x 2500 (scaled N^2), Des2R on 512, ET on 384 correspondences, RANSAC scoring on 200 x 3000',
                                                 'value_if_only_drawn_hypotheses': v_drawn, 'components_s': comp}
-        print(json.dumps(out), flush=True)
+        record_out.write(json.dumps(out) + '\n'); record_out.flush()
     if dist is not None:
         barrier()
         dist.destroy_process_group()

@@ -99,12 +99,17 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
         }
         float d = SQ ? acc : sqrtf(__fadd_rn(acc, 1e-7f));
         int dj = j;
-        // insertion into the sorted list; strict '<' keeps the earlier index ahead on ties
+        // insertion into the sorted list: the new entry goes in front of the first strictly larger one (an equal distance keeps the earlier
+        // index ahead), and from there on every entry moves down one place -- unconditionally: an entry pushed down must not be
+        // compared again, or it would slip behind a later entry of the SAME distance (round 4: exactly tied neighbours came out in
+        // reverse index order whenever a closer point was found after them)
+        bool ins = false;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (q < k && d < bd[q]) {
+            if (q < k && (ins || d < bd[q])) {
                 const float td = bd[q]; const int tj = bj[q];
                 bd[q] = d; bj[q] = dj; d = td; dj = tj;
+                ins = true;
             }
         }
     }
@@ -153,11 +158,13 @@ __global__ __launch_bounds__(256) void knn_slice_kernel(const float *__restrict_
         }
         float d = SQ ? acc : sqrtf(__fadd_rn(acc, 1e-7f));
         int dj = j;
+        bool ins = false;                                          // (see knn_search_kernel: entries pushed down are not compared again)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (q < k && d < bd[q]) {
+            if (q < k && (ins || d < bd[q])) {
                 const float td = bd[q]; const int tj = bj[q];
                 bd[q] = d; bj[q] = dj; d = td; dj = tj;
+                ins = true;
             }
         }
     }
@@ -184,11 +191,13 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float *__restrict_
             float d = vd[c];
             int dj = vj[c];
             if (dj < 0) break;
+            bool ins = false;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (q < k && d < bd[q]) {
+                if (q < k && (ins || d < bd[q])) {
                     const float td = bd[q]; const int tj = bj[q];
                     bd[q] = d; bj[q] = dj; d = td; dj = tj;
+                    ins = true;
                 }
             }
         }
