@@ -380,6 +380,18 @@ int roreg_sinkhorn_batch(const float *src_final, const float *tgt_final, const i
                          int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                          void *stream);
 
+/* v4: roreg_sinkhorn_batch with the choice of how the iterations see the coupling matrix.  recompute = 0: the function above (the matrix is
+ * materialised and read once per iteration: 4 (m+1)(n+1) bytes per pair and iteration from HBM).  recompute = 1: the iterations never read
+ * a matrix -- every pass recomputes the scores <s_i, t_j> on the matrix cores from the L2-resident descriptors (fp16 hi + lo operands, f32
+ * accumulate; potentials, dustbins and padding ride in one more MFMA) and only exponentiates and adds (csrc/ot_flash.hip); same read-outs
+ * (indices identical on the tests, scores to 1e-6).  The matrix is still built once per pair for the read-out.
+ * ws: roreg_sinkhorn_batch2_workspace_size floats. */
+size_t roreg_sinkhorn_batch2_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n);
+int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                          const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                          int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                          int recompute, void *stream);
+
 /* ---- group-Fourier evaluation of the group convolution (csrc/fourier.hip, roreg_amd/fourier.py) ---------------
  * In the basis of the five real irreps (d = 1,3,3,4,5) the 13-stencil group conv is one dense GEMM per irrep,
  *   Out_rho [d*O][d*B] = W_rho [d*O][d*C] . X_rho [d*C][d*B]      (row-major, keypoints fastest),

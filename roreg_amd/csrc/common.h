@@ -56,6 +56,11 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(slot, s); }
 };
 
+// Sinkhorn iterations without a materialised coupling matrix (csrc/ot_flash.hip): potentials (natural log) of every pair to u_out / v_out
+size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n);
+int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
+                        int max_m, int max_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s);
+
 #define ROREG_CHECK_LAUNCH(name)                                                     \
     do {                                                                             \
         hipError_t e__ = hipGetLastError();                                          \

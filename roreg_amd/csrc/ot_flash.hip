@@ -1,0 +1,326 @@
+// Sinkhorn iterations that never read a coupling matrix: every pass recomputes the scores on the matrix cores.
+//
+// The log-domain Sinkhorn of the rotation-coherence matcher (network/rot_coh_match.py:285-314) alternates
+//     u = log_mu - LSE_j(Z + v),      v = log_nu - LSE_i(Z + u)
+// 100 times over the (m+1) x (n+1) coupling matrix Z = [[<s_i, t_j>, alpha], [alpha, alpha]] (alpha = the dustbin score).  Materialised,
+// that is 25 MB per pair at keynum 2500, read once per iteration by the fused pass of rm.hip: 2.5 GB per pair, HBM-bound at ~5.3 TB/s
+// (0.48 ms per pair; the 256 MB Infinity Cache reads no faster than HBM: profiles/r04_mall_rate.txt).  But Z has rank 32 + 2: here a
+// wavefront owns 32 rows (their descriptors sit in registers as MFMA fragments), streams the other cloud's descriptors -- 395 KB per
+// pair, L2-resident -- in 32-column tiles, and gets
+//     acc[i][j] = log2(e) (Z[i][j] + u[i] + v[j])
+// straight out of the matrix cores: the descriptors as fp16 hi + lo pieces (three cross products per 16-wide k step, f32 accumulate:
+// the f32-accurate product of the GEMM kernels), and ONE more MFMA whose k slots carry the potentials (three fp16 pieces each, against
+// constant ones), the dustbin row and column (alpha against indicator slots) and the padding (-60000 in a potential slot: its exponential
+// is exactly 0).  The vector pipe then only exponentiates and adds: S_i = sum_j 2^acc_ij, and
+//     u_new[i] = u[i] + log_mu[i] - log S_i
+// -- the same update written with the CURRENT potentials as the stabiliser instead of the row maximum: after a column update every
+// column of exp(Z + u + v) sums to nu_j <= 1, so no term overflows, and a row's terms cannot all underflow unless its potential moves by
+// e^87 in one iteration (then the update kernel evaluates that row exactly in the log domain from the float32 descriptors).  The very
+// first row pass has no previous normalisation to lean on: its stabiliser is minus the row's maximum score, from one extra max-only pass.
+// The column update is the same kernel with the two sides exchanged.  Partial sums over column chunks simply add (a common stabiliser),
+// so the grid is (row tiles / 4, chunks, pairs) and fills the chip whatever the pair count.
+//
+// Per element and iteration: 2 x (7/1024 MFMA + v_exp_f32 + v_add_f32) against one 4-byte HBM read + ~10 vector instructions before.
+// The read-out (arg-max of Z + u + v over rows and columns) still runs on a matrix built once per pair (rm.hip).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int OF_F = 32;                  // descriptor width
+constexpr int OF_PLANES = 5;              // fragment planes of a 32-row tile: hi k0-15, hi k16-31, extras, lo k0-15, lo k16-31
+constexpr int OF_TILE_HALFS = OF_PLANES * 64 * 8;
+constexpr float OF_PAD = -60000.0f;       // potential of a padding row / column (fp16-representable; 2^-60000 = 0)
+constexpr float OF_LO_SCALE = 4096.0f;    // third pieces travel as x 2^12 against a 2^-12 slot: never an fp16 subnormal
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+
+struct Side {                             // one side (source rows or target columns) of one pass
+    const float *desc;                    // [total, 32] float32 descriptors, all pairs
+    const int *seg;                       // [n_seg + 1] offsets
+    _Float16 *frag;                       // fragments, per pair `frag_stride` halfs
+    float *pot;                           // potentials in log2 units, per pair `pot_stride`
+    float *part;                          // partial sums [NCH][pot_stride] per pair
+    size_t frag_stride, pot_stride;
+    const float *consts;                  // per pair (normc, log of the OTHER side's length): natural logs (roreg_sinkhorn_batch_consts)
+};
+
+__device__ __forceinline__ void split3(float x, _Float16 &h, _Float16 &m, _Float16 &l) {
+    h = (_Float16)x;
+    const float r = x - (float)h;
+    m = (_Float16)r;
+    l = (_Float16)((r - (float)m) * OF_LO_SCALE);
+}
+
+__global__ __launch_bounds__(256) void of_absmax_kernel(Side a, Side b, unsigned *__restrict__ amax) {
+    const int pair = blockIdx.y >> 1, side = blockIdx.y & 1;
+    const Side &s = side ? b : a;
+    const int r0 = s.seg[pair], len = s.seg[pair + 1] - r0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < len * OF_F) v = fabsf(s.desc[(size_t)r0 * OF_F + i]);
+    if (!(v < __builtin_inff())) v = 0.f;                       // non-finite descriptors do not steer the scale (their scores are NaN anyway)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(&amax[pair * 2 + side], __float_as_uint(v));
+}
+
+// Power-of-two balance of the two sides' magnitudes (exact, the product is unchanged): both maxima end up near the geometric mean, far
+// inside fp16's range unless the scores themselves are beyond 2^28.
+__device__ __forceinline__ int balance_exp(const unsigned *amax, int pair) {
+    const float as = __uint_as_float(amax[pair * 2]) * LOG2E, at = __uint_as_float(amax[pair * 2 + 1]);
+    if (!(as > 0.f) || !(at > 0.f)) return 0;
+    int es, et;
+    (void)frexpf(as, &es); (void)frexpf(at, &et);
+    return (et - es) / 2;
+}
+
+// Fragment order of v_mfma_f32_32x32x16_f16 (A and B alike): lane l carries row (l % 32), k = 8 (l / 32) + e.  One workgroup per
+// (tile, side, pair); thread (plane, lane) writes its 8 halfs.
+__global__ __launch_bounds__(320) void of_prep_kernel(Side a, Side b, const unsigned *__restrict__ amax, float alpha) {
+    const int pair = blockIdx.z, side = blockIdx.y, t = blockIdx.x;
+    const Side &s = side ? b : a;
+    const int r0 = s.seg[pair], len = s.seg[pair + 1] - r0;            // rows 0..len-1 are points, row len is the dustbin
+    if (t * 32 > len) return;
+    const int p = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int i = t * 32 + (l & 31), kg = l >> 5;
+    const int e0 = balance_exp(amax, pair);
+    const float c = side ? ldexpf(1.0f, -e0) : ldexpf(LOG2E, e0);
+    f16x8 out;
+    if (p != 2) {
+        const int ks = p < 2 ? p : p - 3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = 0.f;
+            if (i < len) x = s.desc[(size_t)(r0 + i) * OF_F + ks * 16 + kg * 8 + e] * c;
+            const _Float16 h = (_Float16)x;
+            out[e] = p < 2 ? h : (_Float16)(x - (float)h);
+        }
+    } else {
+        _Float16 ah, am, al;
+        split3(alpha * LOG2E, ah, am, al);
+        const _Float16 one = (_Float16)1.0f, tiny = (_Float16)(1.0f / OF_LO_SCALE), zero = (_Float16)0.0f;
+        const bool valid = i <= len, dust = i == len;
+        _Float16 sl[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sl[q] = zero;
+        if (side == 0) {          // rows: own potential pieces | constants against v's pieces | "any valid row" x dustbin column | "dustbin row" x point columns
+            sl[0] = valid ? zero : (_Float16)OF_PAD;
+            sl[3] = one; sl[4] = one; sl[5] = tiny;
+            if (valid) { sl[6] = one; sl[7] = one; sl[8] = tiny; }
+            if (dust) { sl[9] = one; sl[10] = one; sl[11] = tiny; }
+        } else {                  // columns: constants against u's pieces | own potential pieces | alpha on the dustbin column | alpha on the point columns
+            sl[0] = one; sl[1] = one; sl[2] = tiny;
+            sl[3] = valid ? zero : (_Float16)OF_PAD;
+            if (dust) { sl[6] = ah; sl[7] = am; sl[8] = al; }
+            if (i < len) { sl[9] = ah; sl[10] = am; sl[11] = al; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = sl[kg * 8 + e];
+    }
+    *reinterpret_cast<f16x8 *>(s.frag + pair * s.frag_stride + ((size_t)(t * OF_PLANES + p) * 64 + l) * 8) = out;
+    if (p == 0 && l < 32) s.pot[pair * s.pot_stride + i] = 0.f;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+// reductions over the 32 lanes of each half of the wave (the 32 columns of an accumulator row); the result is valid in lanes 16..31 (first
+// half) and 48..63 (second half)
+__device__ __forceinline__ float half_sum(float x) {
+    x += dpp_mov<0xB1, 0xf>(x);                 // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E, 0xf>(x);                 // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141, 0xf>(x);                // row_half_mirror
+    x += dpp_mov<0x140, 0xf>(x);                // row_mirror: every lane of a 16-lane row holds the row's sum
+    const float t = dpp_mov<0x142, 0xa>(x);     // row_bcast:15 -> rows 1 and 3 receive the previous row's sum
+    return ((threadIdx.x >> 4) & 1) ? x + t : x;
+}
+__device__ __forceinline__ float half_max(float x) {
+    x = fmaxf(x, dpp_mov<0xB1, 0xf>(x));
+    x = fmaxf(x, dpp_mov<0x4E, 0xf>(x));
+    x = fmaxf(x, dpp_mov<0x141, 0xf>(x));
+    x = fmaxf(x, dpp_mov<0x140, 0xf>(x));
+    return fmaxf(x, dpp_mov<0x142, 0xa>(x));    // (rows 0 and 2 see their own value again: harmless for a maximum)
+}
+
+// One pass: for the 32 rows of side A that this wave owns, part[chunk][row] = sum (MAXP: max) over the chunk's columns of 2^acc (acc).
+// Wave w of a workgroup owns row tile 4 blockIdx.x + w; the four waves stream the same column tiles (their fragment loads meet in L1).
+template <bool MAXP>
+__global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
+    const int pair = blockIdx.z, chunk = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int lenA = a.seg[pair + 1] - a.seg[pair], lenB = b.seg[pair + 1] - b.seg[pair];
+    const int tilesA = lenA / 32 + 1, tilesB = lenB / 32 + 1;              // (len + 1 rows: the dustbin)
+    const int tA = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tA >= tilesA) return;
+    const int cht = (tilesB + nch - 1) / nch;
+    const int tb0 = chunk * cht, tb1 = min(tb0 + cht, tilesB);
+    const f16x8 *fa = reinterpret_cast<const f16x8 *>(a.frag + pair * a.frag_stride) + (size_t)tA * OF_PLANES * 64 + lane;
+    const f16x8 *fb = reinterpret_cast<const f16x8 *>(b.frag + pair * b.frag_stride) + lane;
+    f16x8 A[OF_PLANES];
+#pragma unroll
+    for (int p = 0; p < OF_PLANES; ++p) A[p] = fa[p * 64];
+    float red[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[r] = MAXP ? -__builtin_inff() : 0.f;
+    f16x8 B[OF_PLANES], Bn[OF_PLANES];
+    if (tb0 < tb1) {
+#pragma unroll
+        for (int p = 0; p < OF_PLANES; ++p) B[p] = fb[((size_t)tb0 * OF_PLANES + p) * 64];
+    }
+    for (int tb = tb0; tb < tb1; ++tb) {
+        const int tn = tb + 1 < tb1 ? tb + 1 : tb;                        // (the last round re-reads its own tile: branch-free prefetch)
+#pragma unroll
+        for (int p = 0; p < OF_PLANES; ++p) Bn[p] = fb[((size_t)tn * OF_PLANES + p) * 64];
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[3], B[0], acc, 0, 0, 0);      // lo . hi
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[4], B[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[3], acc, 0, 0, 0);      // hi . lo
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc, 0, 0, 0);      // hi . hi
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[2], B[2], acc, 0, 0, 0);      // potentials, dustbins, padding
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (MAXP) red[r] = fmaxf(red[r], acc[r]);
+            else red[r] += __builtin_amdgcn_exp2f(acc[r]);
+        }
+#pragma unroll
+        for (int p = 0; p < OF_PLANES; ++p) B[p] = Bn[p];
+    }
+    // accumulator register r of lane l is row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
+    float *out = a.part + pair * (a.pot_stride * nch) + (size_t)chunk * a.pot_stride + tA * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = MAXP ? half_max(red[r]) : half_sum(red[r]);
+        if ((lane & 31) == 31) out[8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = v;
+    }
+}
+
+// pot[i] <- -max (MAXP: the first row pass's stabiliser)  or  pot[i] + log2(mu_i) - log2(sum of the chunks' partial sums); the three fp16
+// pieces of the new potential go into the extras plane of side A's fragments.  A sum outside (1e-35, 1e35) (every term underflowed, or
+// non-finite input) is replaced by the exact log-domain evaluation of that row from the float32 descriptors.
+template <bool MAXP>
+__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int slot0, float alpha, const unsigned *__restrict__ amax) {
+    const int pair = blockIdx.y;
+    const int ra = a.seg[pair], lenA = a.seg[pair + 1] - ra;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > lenA) return;
+    const float *part = a.part + pair * (a.pot_stride * nch) + i;
+    float *pot = a.pot + pair * a.pot_stride;
+    float np;
+    if (MAXP) {
+        float mx = -__builtin_inff();
+        for (int c = 0; c < nch; ++c) mx = fmaxf(mx, part[(size_t)c * a.pot_stride]);
+        np = mx > -__builtin_inff() && mx < __builtin_inff() ? -mx : 0.f;
+    } else {
+        float S = 0.f;
+        for (int c = 0; c < nch; ++c) S += part[(size_t)c * a.pot_stride];
+        const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
+        if (S > 1e-35f && S < 1e35f) {
+            np = pot[i] + (lmu - __log2f(S));
+        } else {                                                  // exact: log2-sum-exp2 of (Z' + potB) over the other side, float32 descriptors
+            const int rb = b.seg[pair], lenB = b.seg[pair + 1] - rb;
+            const float *potB = b.pot + pair * b.pot_stride;
+            const float al = alpha * LOG2E;
+            float d[OF_F];
+#pragma unroll
+            for (int f = 0; f < OF_F; ++f) d[f] = i < lenA ? a.desc[(size_t)(ra + i) * OF_F + f] * LOG2E : 0.f;
+            float mx = -__builtin_inff();
+            for (int rep = 0; rep < 2; ++rep) {
+                float sum = 0.f;
+                for (int j = 0; j <= lenB; ++j) {
+                    float x = al;
+                    if (i < lenA && j < lenB) {
+                        x = 0.f;
+                        const float *t = b.desc + (size_t)(rb + j) * OF_F;
+#pragma unroll
+                        for (int f = 0; f < OF_F; ++f) x = fmaf(d[f], t[f], x);
+                    }
+                    x += potB[j];
+                    if (rep == 0) mx = fmaxf(mx, x);
+                    else sum += __builtin_amdgcn_exp2f(x - mx);
+                }
+                if (rep == 1) np = lmu - (mx + __log2f(sum));
+            }
+        }
+    }
+    pot[i] = np;
+    _Float16 h, m, l;
+    split3(np, h, m, l);
+    _Float16 *dst = a.frag + pair * a.frag_stride + ((size_t)((i >> 5) * OF_PLANES + 2) * 64 + (i & 31)) * 8 + slot0;
+    dst[0] = h; dst[1] = m; dst[2] = l;
+}
+
+__global__ __launch_bounds__(256) void of_export_kernel(Side a, float *__restrict__ out, size_t out_stride) {
+    const int pair = blockIdx.y;
+    const int len = a.seg[pair + 1] - a.seg[pair];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i <= len) out[pair * out_stride + i] = a.pot[pair * a.pot_stride + i] * LN2;
+}
+
+__host__ __device__ inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+namespace roreg {
+
+static int ot_flash_chunks(int n_seg, int max_m, int max_n) {
+    const int ta = (max_m / 32 + 1 + 3) / 4, tb = (max_n / 32 + 1 + 3) / 4;
+    const int wg = (ta < tb ? ta : tb) * n_seg;
+    int nch = (2048 + wg - 1) / wg;                   // ~8 workgroups per CU in flight or queued
+    if (nch > 8) nch = 8;
+    return nch < 1 ? 1 : nch;
+}
+
+// bytes of workspace of ot_flash_iterations (16-byte aligned pieces): per pair the two sides' fragments, potentials and chunk partials
+size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
+    const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
+    const size_t per_pair = (ta + tb) * OF_TILE_HALFS * sizeof(_Float16) + (ta + tb) * 32 * sizeof(float) * (1 + 8);
+    return (size_t)n_seg * per_pair + round_up((size_t)n_seg * 2 * sizeof(unsigned), 16) + 256;
+}
+
+// `iters` Sinkhorn iterations for every pair; the potentials (natural log, u[0..m], v[0..n]) are written to u_out + pair * uv_stride and
+// v_out + pair * uv_stride.  seg_* are DEVICE offset arrays, consts the device array of roreg_sinkhorn_batch_consts.
+int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
+                        int max_m, int max_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s) {
+    const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
+    const int nch = ot_flash_chunks(n_seg, max_m, max_n);
+    char *p = reinterpret_cast<char *>(ws);
+    p = reinterpret_cast<char *>(round_up(reinterpret_cast<uintptr_t>(p), 16));
+    Side A, B;
+    A.desc = src; A.seg = seg_src; A.consts = consts;
+    B.desc = tgt; B.seg = seg_tgt; B.consts = consts + 2 * n_seg;
+    A.frag_stride = ta * OF_TILE_HALFS; B.frag_stride = tb * OF_TILE_HALFS;
+    A.pot_stride = ta * 32; B.pot_stride = tb * 32;
+    A.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * A.frag_stride * sizeof(_Float16);
+    B.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * B.frag_stride * sizeof(_Float16);
+    A.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * sizeof(float);
+    B.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * sizeof(float);
+    A.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * 8 * sizeof(float);
+    B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * 8 * sizeof(float);
+    unsigned *amax = reinterpret_cast<unsigned *>(p);
+    (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
+    const int mx = max_m > max_n ? max_m : max_n;
+    hipLaunchKernelGGL(of_absmax_kernel, dim3((mx * OF_F + 255) / 256, 2 * n_seg), dim3(256), 0, s, A, B, amax);
+    hipLaunchKernelGGL(of_prep_kernel, dim3((unsigned)(ta > tb ? ta : tb), 2, n_seg), dim3(320), 0, s, A, B, amax, alpha);
+    const dim3 gA((unsigned)((ta + 3) / 4), nch, n_seg), gB((unsigned)((tb + 3) / 4), nch, n_seg);
+    const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);
+    if (iters > 0) {
+        hipLaunchKernelGGL(of_pass_kernel<true>, gA, dim3(256), 0, s, A, B, nch);
+        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
+    }
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(of_pass_kernel<false>, gA, dim3(256), 0, s, A, B, nch);
+        hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
+        hipLaunchKernelGGL(of_pass_kernel<false>, gB, dim3(256), 0, s, B, A, nch);
+        hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nch, 3, alpha, amax);
+    }
+    hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride);
+    hipLaunchKernelGGL(of_export_kernel, uB, dim3(256), 0, s, B, v_out, uv_stride);
+    return 0;
+}
+
+}  // namespace roreg

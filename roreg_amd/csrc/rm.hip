@@ -1027,10 +1027,16 @@ extern "C" int roreg_sinkhorn_batch_consts(const int32_t *seg_src_host, const in
     return 0;
 }
 
-extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
-                                    const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
-                                    int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
-                                    void *stream) {
+static size_t ot_flash_floats(int n_seg, int max_m, int max_n) { return (roreg::ot_flash_workspace_bytes(n_seg, max_m, max_n) + 3) / 4 + 8; }
+
+extern "C" size_t roreg_sinkhorn_batch2_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n) {
+    return roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, total_m, total_n) + ot_flash_floats(n_seg, max_m, max_n);
+}
+
+static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                               const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                               int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                               int recompute, void *stream) {
     ROREG_REQUIRE(src_final && tgt_final && seg_src && seg_tgt && seg_src_host && seg_tgt_host && consts && n_seg > 0 && iters >= 0 && ws &&
                       matches0 && matches1 && mscores0 && mscores1, "roreg_sinkhorn_batch: bad arguments");
     int max_m = 0, max_n = 0;
@@ -1041,7 +1047,8 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
         if (n > max_n) max_n = n;
     }
     const long long tm = seg_src_host[n_seg], tn = seg_tgt_host[n_seg];
-    ROREG_REQUIRE(ws_floats >= roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, tm, tn), "roreg_sinkhorn_batch: workspace too small");
+    const size_t base_floats = roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, tm, tn);
+    ROREG_REQUIRE(ws_floats >= base_floats + (recompute ? ot_flash_floats(n_seg, max_m, max_n) : 0), "roreg_sinkhorn_batch: workspace too small");
     hipStream_t s = roreg::as_stream(stream);
     const int ldz = (max_n + 4) & ~3, ldt = (max_m + 4) & ~3;
     const size_t slab = ot_slab(max_m, max_n);
@@ -1060,25 +1067,33 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
                        tgt_final, 0, alpha, rpb, Z0, ldz, seg_src, seg_tgt, slab);
     hipLaunchKernelGGL(ot_build_kernel, dim3((max_m + 1 + 255) / 256, (max_n + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, tgt_final, 0,
                        src_final, 0, alpha, rpb, Z0T, ldt, seg_tgt, seg_src, slab);
-    for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent
-    const int nv = (ldz + 1023) / 1024;                  // float4 pieces of a row per thread
-    const dim3 gp((max_m + 1 + OT_RB - 1) / OT_RB, n_seg), gm((max_n + 1 + 63) / 64, n_seg);
-    {
-    roreg::ProfScope prof(roreg::PROF_SINKHORN, s);      // (the iterations only: `iters` passes over every pair's coupling matrix)
-    for (int it = 0; it < iters; ++it) {
-        if (nv > 8) {                                    // rows beyond 8192 columns: the two-matrix passes
-            hipLaunchKernelGGL(row_lse_kernel, dim3((max_m + 4) / 4, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, 0.f, 0.f, u, rows);
-            hipLaunchKernelGGL(row_lse_kernel, dim3((max_n + 4) / 4, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, 0.f, 0.f, v, cols);
-            continue;
-        }
+    if (recompute) {
+        // the iterations never touch Z0 / Z0T: every pass recomputes the scores on the matrix cores (csrc/ot_flash.hip); the two matrices
+        // above only serve the read-out below
+        roreg::ProfScope prof(roreg::PROF_SINKHORN, s);
+        if (roreg::ot_flash_iterations(src_final, tgt_final, seg_src, seg_tgt, consts, n_seg, max_m, max_n, alpha, iters, u, v, slab,
+                                       ws + base_floats, s) != 0) return 1;
+    } else {
+        for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent
+        const int nv = (ldz + 1023) / 1024;                  // float4 pieces of a row per thread
+        const dim3 gp((max_m + 1 + OT_RB - 1) / OT_RB, n_seg), gm((max_n + 1 + 63) / 64, n_seg);
+        {
+        roreg::ProfScope prof(roreg::PROF_SINKHORN, s);      // (the iterations only: `iters` passes over every pair's coupling matrix)
+        for (int it = 0; it < iters; ++it) {
+            if (nv > 8) {                                    // rows beyond 8192 columns: the two-matrix passes
+                hipLaunchKernelGGL(row_lse_kernel, dim3((max_m + 4) / 4, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, 0.f, 0.f, u, rows);
+                hipLaunchKernelGGL(row_lse_kernel, dim3((max_n + 4) / 4, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, 0.f, 0.f, v, cols);
+                continue;
+            }
 #define OT_PASS(NV) hipLaunchKernelGGL(ot_fused_pass_kernel<NV>, gp, dim3(256), 0, s, Z0, ldz, v, u, part, pstride, rows)
-        switch (nv) {
-        case 1: OT_PASS(1); break; case 2: OT_PASS(2); break; case 3: OT_PASS(3); break; case 4: OT_PASS(4); break;
-        case 5: OT_PASS(5); break; case 6: OT_PASS(6); break; case 7: OT_PASS(7); break; default: OT_PASS(8); break;
-        }
+            switch (nv) {
+            case 1: OT_PASS(1); break; case 2: OT_PASS(2); break; case 3: OT_PASS(3); break; case 4: OT_PASS(4); break;
+            case 5: OT_PASS(5); break; case 6: OT_PASS(6); break; case 7: OT_PASS(7); break; default: OT_PASS(8); break;
+            }
 #undef OT_PASS
-        hipLaunchKernelGGL(ot_col_merge_kernel, gm, dim3(256), 0, s, part, pstride, ldz, v, cols, Z0T, ldt, u);
-    }
+            hipLaunchKernelGGL(ot_col_merge_kernel, gm, dim3(256), 0, s, part, pstride, ldz, v, cols, Z0T, ldt, u);
+        }
+        }
     }
     hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
     hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);
@@ -1087,4 +1102,20 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
                        mscores1, seg_src, seg_tgt);
     ROREG_CHECK_LAUNCH("roreg_sinkhorn_batch");
     return 0;
+}
+
+extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                                    const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                                    int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                                    void *stream) {
+    return sinkhorn_batch_impl(src_final, tgt_final, seg_src, seg_tgt, seg_src_host, seg_tgt_host, consts, n_seg, alpha, iters, matches0, matches1,
+                               mscores0, mscores1, ws, ws_floats, 0, stream);
+}
+
+extern "C" int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                                     const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                                     int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                                     int recompute, void *stream) {
+    return sinkhorn_batch_impl(src_final, tgt_final, seg_src, seg_tgt, seg_src_host, seg_tgt_host, consts, n_seg, alpha, iters, matches0, matches1,
+                               mscores0, mscores1, ws, ws_floats, recompute, stream);
 }

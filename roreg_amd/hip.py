@@ -93,6 +93,8 @@ PROTOTYPES = {
     'roreg_sinkhorn_batch_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong]),
     'roreg_sinkhorn_batch_consts': (c_int, [_P, _P, c_int, _P]),
     'roreg_sinkhorn_batch': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'roreg_sinkhorn_batch2_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong]),
+    'roreg_sinkhorn_batch2': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'roreg_linear': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_instnorm_stats': (c_int, [_P, c_int, c_int, c_float, _P, _P, _P, c_int, c_int, _P]),
     'roreg_mlp_tail': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
@@ -1014,9 +1016,15 @@ def sinkhorn(src_final, tgt_final, alpha, iters):
     return Z, m0, m1, s0, s1
 
 
-def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters):
+# Sinkhorn iterations of the stacked matcher path: 1 = recompute the scores on the matrix cores in every pass (csrc/ot_flash.hip, default);
+# ROREG_OT_RECOMPUTE=0 = read the materialised coupling matrix once per iteration (rounds 1-3; A/B switch)
+OT_RECOMPUTE = os.environ.get('ROREG_OT_RECOMPUTE', '1') == '1'
+
+
+def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters, recompute=None):
     """Sinkhorn + mutual read-out of several pairs (descriptors concatenated by seg_src / seg_tgt) ->
-    (matches0 [sum m] local indices or -1, matches1 [sum n], mscores0, mscores1)."""
+    (matches0 [sum m] local indices or -1, matches1 [sum n], mscores0, mscores1).  recompute: None = OT_RECOMPUTE."""
+    recompute = OT_RECOMPUTE if recompute is None else bool(recompute)
     dev = src_final.device
     tm, tn = seg_src.total, seg_tgt.total
     m0 = torch.empty(tm, dtype=torch.int64, device=dev); m1 = torch.empty(tn, dtype=torch.int64, device=dev)
@@ -1024,15 +1032,18 @@ def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters):
     consts = np.empty(4 * seg_src.n, np.float32)
     _check(lib().roreg_sinkhorn_batch_consts(seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, seg_src.n, consts.ctypes.data), 'roreg_sinkhorn_batch_consts')
     cdev = upload(consts)
-    wsn = lib().roreg_sinkhorn_batch_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
+    wsn = lib().roreg_sinkhorn_batch2_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
     ws = torch.empty(wsn, dtype=torch.float32, device=dev)
-    _check(lib().roreg_sinkhorn_batch(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
-                                      _ptr(seg_tgt.dev, torch.int32), seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, _ptr(cdev), seg_src.n,
-                                      float(alpha), int(iters), _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, _stream()),
-           'roreg_sinkhorn_batch')
+    _check(lib().roreg_sinkhorn_batch2(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
+                                       _ptr(seg_tgt.dev, torch.int32), seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, _ptr(cdev), seg_src.n,
+                                       float(alpha), int(iters), _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, 1 if recompute else 0, _stream()),
+           'roreg_sinkhorn_batch2')
     if WORK is not None:
         cells = float(np.sum((np.diff(seg_src.host).astype(np.float64) + 1) * (np.diff(seg_tgt.host) + 1)))
         WORK['sinkhorn_bytes'] = WORK.get('sinkhorn_bytes', 0.0) + 4.0 * cells * int(iters)
+        WORK['sinkhorn_cells'] = WORK.get('sinkhorn_cells', 0.0) + cells * int(iters)
+        WORK['sinkhorn_pairs'] = WORK.get('sinkhorn_pairs', 0) + seg_src.n
+        WORK['sinkhorn_recompute'] = bool(recompute)
     return m0, m1, s0, s1
 
 

@@ -142,9 +142,11 @@ def test_sinkhorn_and_readout():
         assert (w0 >= 0).sum() >= min(m, n) // 2 - 2
 
 
-def test_sinkhorn_batch_with_widely_spread_scores():
+@pytest.mark.parametrize('recompute', [True, False])
+def test_sinkhorn_batch_with_widely_spread_scores(recompute):
     """Final descriptors whose scores spread over several hundred: whole columns underflow in the one-pass (linear-domain column sums)
-    iteration of the stacked Sinkhorn; the exact log-domain fallback for those columns keeps it equal to the one-pair path."""
+    iteration of the stacked Sinkhorn; the exact log-domain fallback for those columns keeps it equal to the one-pair path.  Both ways
+    of running the iterations: scores recomputed on the matrix cores in every pass (default), or the materialised matrix re-read."""
     from roreg_amd import hip
     rng = np.random.default_rng(17)
     m, n = 300, 260
@@ -156,11 +158,64 @@ def test_sinkhorn_batch_with_widely_spread_scores():
     s, t = cu(src), cu(tgt)
     Z, m0, m1, s0, s1 = hip.sinkhorn(s, t, 1.0, 100)
     seg_s = hip.Segments([m, m]); seg_t = hip.Segments([n, n])
-    b0, b1, bs0, bs1 = hip.sinkhorn_batch(torch.cat([s, s]), torch.cat([t, t]), seg_s, seg_t, 1.0, 100)
+    b0, b1, bs0, bs1 = hip.sinkhorn_batch(torch.cat([s, s]), torch.cat([t, t]), seg_s, seg_t, 1.0, 100, recompute=recompute)
     assert float(Z.max() - Z.min()) > 200 and bool(torch.isfinite(Z).all())
     for k in range(2):
         assert torch.equal(b0[k * m:(k + 1) * m], m0) and torch.equal(b1[k * n:(k + 1) * n], m1)
         assert float((bs0[k * m:(k + 1) * m] - s0).abs().max()) < 1e-4 and float((bs1[k * n:(k + 1) * n] - s1).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('iters', [100, 1, 0])
+def test_sinkhorn_recomputed_on_the_matrix_cores_equals_the_materialised_iterations(iters):
+    """The stacked Sinkhorn whose passes recompute <s_i, t_j> with fp16 hi + lo MFMAs (csrc/ot_flash.hip) against (a) the same call reading the
+    materialised matrix, (b) the one-pair kernel, (c) the oracle's log-domain iteration: ragged pairs in ONE call, sizes on and around the
+    32-row tile (3 x 5, 31 x 32, 32 x 31, 33 x 64 ...), descriptors from 0.02 to several units (low pieces in fp16's subnormal range, scores up to
+    ~60), after 100, 1 and 0 iterations.  Matches identical, matching scores to 2e-5 (absolute; they are probabilities)."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(23)
+    sizes = [(3, 5), (31, 32), (32, 31), (33, 64), (200, 173), (64, 300), (1, 1), (97, 1)]
+    S, T = [], []
+    for q, (m, n) in enumerate(sizes):
+        scale = [0.5, 0.02, 2.0, 0.05, 0.5, 1.0, 0.5, 0.5][q]
+        s = rng.standard_normal((m, 32)).astype(np.float32) * scale; t = rng.standard_normal((n, 32)).astype(np.float32) * scale
+        k = min(m, n) // 2
+        t[:k] = s[:k] * 3                                     # planted strong matches
+        S.append(s); T.append(t)
+    seg_s = hip.Segments([m for m, _ in sizes]); seg_t = hip.Segments([n for _, n in sizes])
+    cs, ct = cu(np.concatenate(S)), cu(np.concatenate(T))
+    a0, a1, as0, as1 = hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, iters, recompute=True)
+    b0, b1, bs0, bs1 = hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, iters, recompute=False)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    assert float((as0 - bs0).abs().max()) < 2e-5 and float((as1 - bs1).abs().max()) < 2e-5
+    o0 = o1 = 0
+    for (m, n), s, t in zip(sizes, S, T):
+        Z, m0, m1, s0, s1 = hip.sinkhorn(cu(s), cu(t), 1.5, iters)
+        assert torch.equal(a0[o0:o0 + m], m0) and torch.equal(a1[o1:o1 + n], m1)
+        assert float((as0[o0:o0 + m] - s0).abs().max()) < 2e-5
+        want = MO.log_sinkhorn((s @ t.T).astype(np.float32), np.float32(1.5), iters)
+        w0, w1, ws0, ws1 = MO.readout(want)
+        if iters == 100:
+            assert np.array_equal(a0[o0:o0 + m].cpu().numpy(), w0) and np.array_equal(a1[o1:o1 + n].cpu().numpy(), w1)
+            assert np.abs(as0[o0:o0 + m].cpu().numpy() - ws0).max() < 2e-5
+        o0 += m; o1 += n
+
+
+def test_sinkhorn_recomputed_survives_non_finite_and_huge_descriptors():
+    """No fault and no hang on NaN / inf / 1e6-sized descriptors (the fp16 operands overflow: those pairs' results are meaningless, as the
+    reference's would be); a healthy pair stacked beside them is unaffected."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(5)
+    good_s = rng.standard_normal((70, 32)).astype(np.float32); good_t = rng.standard_normal((90, 32)).astype(np.float32)
+    good_t[:30] = good_s[:30] * 2
+    bad_s = good_s.copy(); bad_s[3, 5] = np.nan; bad_s[9, 1] = np.inf
+    huge_s = good_s * 1e6
+    seg_s = hip.Segments([70, 70, 70]); seg_t = hip.Segments([90, 90, 90])
+    cs = cu(np.concatenate([good_s, bad_s, huge_s])); ct = cu(np.concatenate([good_t, good_t, good_t]))
+    a0, a1, as0, as1 = hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.0, 100, recompute=True)
+    torch.cuda.synchronize()
+    Z, m0, m1, s0, s1 = hip.sinkhorn(cu(good_s), cu(good_t), 1.0, 100)
+    assert torch.equal(a0[:70], m0) and torch.equal(a1[:90], m1) and float((as0[:70] - s0).abs().max()) < 2e-5
+    assert int(a0.min()) >= -1 and int(a0.max()) < 90
 
 
 def test_match_ot_forward_vs_reference_golden(rm):
