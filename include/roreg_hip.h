@@ -297,6 +297,13 @@ int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_tasks, long lon
                        int32_t *best_out, double *T1_out, double *stats1_out, double *T2_out, double *stats2_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* v4: one more refinement at `dist`, from the given transforms T_in [n_sel][16], of the tasks sel_dev[0..n_sel) (device int32) of an EARLIER
+ * roreg_ransac_batch call: tasks_dev, total_M and workspace are that call's (its workspace still holds the gathered keypoints).  T_out /
+ * stats_out [n_sel][16] as roreg_refine.  One launch for all of them: the engine's second refinement of the pairs whose first one had a
+ * rank-deficient covariance and was closed by host LAPACK (test/estimator.py:53-72 per pair). */
+int roreg_refine_batch(const roreg_ransac_task *tasks_dev, const int32_t *sel_dev, int n_sel, long long total_M, const double *T_in,
+                       double dist, int w_f32, double *T_out, double *stats_out, const void *workspace, void *stream);
+
 /* Seeded shuffles, HOST function (no device work): for every job j, `np.random.seed(seeds[j])` followed by, for each of its per_job lists
  * (sizes int32 [n_jobs][per_job]), `idx = np.arange(n); np.random.shuffle(idx); idx[:take]` -- numpy's legacy MT19937 stream and its
  * Fisher-Yates shuffle, replayed bit for bit.  out int64 [n_jobs][per_job][take] (-1 beyond a list's length).  Replaces the per-pair

@@ -515,17 +515,20 @@ template <bool F32W>
 __global__ __launch_bounds__(256) void refine_batch_kernel(const RansacTask *__restrict__ tasks, const double *__restrict__ k0_all,
                                                            const double *__restrict__ k1_all, const double *__restrict__ T_in_all,
                                                            const int32_t *__restrict__ best_all, double thr2,
-                                                           double *__restrict__ T_out_all, double *__restrict__ stats_all) {
+                                                           double *__restrict__ T_out_all, double *__restrict__ stats_all,
+                                                           const int32_t *__restrict__ sel) {
     __shared__ float npbuf[F32W ? NP_CHUNK : 1];
     __shared__ NpSumScratch npsc;
-    const RansacTask t = tasks[blockIdx.x];
+    // sel: the launch refines the tasks sel[0..grid) only (T_in / outputs are indexed by the position in sel); nullptr = every task
+    const int ti = sel ? sel[blockIdx.x] : (int)blockIdx.x;
+    const RansacTask t = tasks[ti];
     if (F32W && t.w)
         refine_body<true>(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, T_in_all ? T_in_all + (size_t)blockIdx.x * 16 : nullptr, 4, t.Trans,
-                          t.hyp_rows, T_in_all ? nullptr : best_all + blockIdx.x, thr2, T_out_all + (size_t)blockIdx.x * 16,
+                          t.hyp_rows, T_in_all ? nullptr : best_all + ti, thr2, T_out_all + (size_t)blockIdx.x * 16,
                           stats_all + (size_t)blockIdx.x * 16, npbuf, &npsc);
     else
     refine_body<false>(k0_all + t.koff * 3, k1_all + t.koff * 3, t.w, t.M, T_in_all ? T_in_all + (size_t)blockIdx.x * 16 : nullptr, 4, t.Trans,
-                t.hyp_rows, T_in_all ? nullptr : best_all + blockIdx.x, thr2, T_out_all + (size_t)blockIdx.x * 16,
+                t.hyp_rows, T_in_all ? nullptr : best_all + ti, thr2, T_out_all + (size_t)blockIdx.x * 16,
                 stats_all + (size_t)blockIdx.x * 16);
 }
 
@@ -595,15 +598,34 @@ extern "C" int roreg_ransac_batch(const roreg_ransac_task *tasks_dev, int n_task
     hipLaunchKernelGGL(first_best_batch_kernel, dim3(n_tasks), dim3(256), 0, s, tasks, pitch_h, overlap, best_out);
     if (w_f32) {
         hipLaunchKernelGGL(refine_batch_kernel<true>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
-                           (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);
+                           (2.0 * ird) * (2.0 * ird), T1_out, stats1_out, (const int32_t *)nullptr);
         hipLaunchKernelGGL(refine_batch_kernel<true>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)T1_out, (const int32_t *)nullptr,
-                           ird * ird, T2_out, stats2_out);
+                           ird * ird, T2_out, stats2_out, (const int32_t *)nullptr);
     } else {
         hipLaunchKernelGGL(refine_batch_kernel<false>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)nullptr, best_out,
-                           (2.0 * ird) * (2.0 * ird), T1_out, stats1_out);
+                           (2.0 * ird) * (2.0 * ird), T1_out, stats1_out, (const int32_t *)nullptr);
         hipLaunchKernelGGL(refine_batch_kernel<false>, dim3(n_tasks), dim3(256), 0, s, tasks, k0, k1, (const double *)T1_out, (const int32_t *)nullptr,
-                           ird * ird, T2_out, stats2_out);
+                           ird * ird, T2_out, stats2_out, (const int32_t *)nullptr);
     }
     ROREG_CHECK_LAUNCH("roreg_ransac_batch");
+    return 0;
+}
+
+// One more refinement (from given transforms) of SOME tasks of an earlier roreg_ransac_batch, in one launch: the engine's second pass over
+// the rank-deficient pairs, whose first refinement was closed on the host (LAPACK's choice of U V^T for a rank <= 2 covariance).
+extern "C" int roreg_refine_batch(const roreg_ransac_task *tasks_dev, const int32_t *sel_dev, int n_sel, long long total_M, const double *T_in,
+                                  double dist, int w_f32, double *T_out, double *stats_out, const void *workspace, void *stream) {
+    if (n_sel == 0) return 0;
+    ROREG_REQUIRE(tasks_dev && sel_dev && T_in && T_out && stats_out && workspace && n_sel > 0 && total_M >= 0, "roreg_refine_batch: bad arguments");
+    hipStream_t s = roreg::as_stream(stream);
+    const RansacTask *tasks = reinterpret_cast<const RansacTask *>(tasks_dev);
+    const double *k0 = reinterpret_cast<const double *>(workspace), *k1 = k0 + (size_t)total_M * 3;
+    if (w_f32)
+        hipLaunchKernelGGL(refine_batch_kernel<true>, dim3(n_sel), dim3(256), 0, s, tasks, k0, k1, T_in, (const int32_t *)nullptr, dist * dist, T_out,
+                           stats_out, sel_dev);
+    else
+        hipLaunchKernelGGL(refine_batch_kernel<false>, dim3(n_sel), dim3(256), 0, s, tasks, k0, k1, T_in, (const int32_t *)nullptr, dist * dist, T_out,
+                           stats_out, sel_dev);
+    ROREG_CHECK_LAUNCH("roreg_refine_batch");
     return 0;
 }

@@ -656,7 +656,7 @@ class RegistrationEngine:
         t0 = self._mark('local_transforms', t0)
         ird = float(self.cfg.ransac_ird)
         f32_scores = any(sc is not None and sc.dtype == np.float32 for sc in all_scores)      # the rotation-coherence matcher's (matcher.py:210)
-        best_d, T1_d, st1_d, T2_d, st2_d = hip.ransac_batch(rt, ird, w_f32=f32_scores)
+        best_d, T1_d, st1_d, T2_d, st2_d, rctx = hip.ransac_batch(rt, ird, w_f32=f32_scores, keep=True)
         t0 = self._mark('ransac_issue', t0)
         T_host, best_host, st_host = yield [T2_d, best_d, torch.stack([st1_d, st2_d], 1)]       # the one sync of the estimator stage
         T_host = np.array(T_host)                                           # (the driver's buffers may be read-only / pinned views)
@@ -666,15 +666,9 @@ class RegistrationEngine:
         from .test.estimator import _kabsch_host, _dev64
         deficient = hip.stats_rank_deficient_many(st_host).any(axis=1) if len(full) else np.zeros(0, bool)       # [pairs, 2 refinements]
         redo = [i for i in range(len(full)) if i not in skipped and deficient[i]]
-        pending = []
-        for i in redo:                                                      # all second refinements are enqueued before the one download
-            c0, c1, matches = full[i]
-            k0 = hip.gather_rows_f64(c0.keys, matches[:, 0].contiguous()); k1 = hip.gather_rows_f64(c1.keys, matches[:, 1].contiguous())
-            w = w_all[i] if w_all[i] is not None else torch.ones(matches.shape[0], dtype=torch.float64, device='cuda')
-            T1 = _kabsch_host(st_host[i, 0])
-            pending.append(hip.refine(k0, k1, w, ird, T_in=_dev64(T1), want_stats=True, w_f32=f32_scores and w_all[i] is not None)[1])
-        if pending:
-            st_redo = torch.stack(pending).cpu().numpy()
+        if redo:                                                            # their second refinements in ONE launch, one download
+            T1s = np.stack([_kabsch_host(st_host[i, 0]) for i in redo])
+            st_redo = hip.refine_batch(rctx, redo, T1s, ird)[1].cpu().numpy()
             for i, st in zip(redo, st_redo):
                 T_host[i] = _kabsch_host(st)
         local = full

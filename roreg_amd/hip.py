@@ -84,6 +84,7 @@ PROTOTYPES = {
     'roreg_lt_finish_batch': (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_ransac_batch_workspace': (c_size_t, [c_int, ctypes.c_longlong, c_int]),
     'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'roreg_refine_batch': (c_int, [_P, _P, c_int, ctypes.c_longlong, _P, ctypes.c_double, c_int, _P, _P, _P, _P]),
     'roreg_yohoc_draw': (c_int, [_P, ctypes.c_longlong, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
@@ -613,18 +614,19 @@ _RANSAC_TASK = np.dtype([('keys0', np.uint64), ('keys1', np.uint64), ('matches',
                          ('hyp_rows', np.uint64), ('M', np.int32), ('H', np.int32), ('koff', np.int64)])
 
 
-def ransac_batch(tasks, ird, w_f32=False):
+def ransac_batch(tasks, ird, w_f32=False, keep=False):
     """tasks: [(keys0 [*,3] f64, keys1 [*,3] f64, matches [M,2] int64, w [M] f64 or None, Trans [*,3,4] f64, hyp_rows int64 [H] or None)]
     (device tensors).  One-shot RANSAC + the two refinements of every task in five launches ->
     (best int32 [n], T1 [n,4,4], stats1 [n,16], T2 [n,4,4], stats2 [n,16]) device tensors.
-    w_f32: the tasks' weights are float32 scores (widened to f64 for the upload): numpy's float32 reductions, see ransac_score."""
+    w_f32: the tasks' weights are float32 scores (widened to f64 for the upload): numpy's float32 reductions, see ransac_score.
+    keep: also return the call's context (task table, gathered keypoints) for refine_batch()."""
     n = len(tasks)
     dev = tasks[0][0].device if n else torch.device('cuda')
     best = torch.empty(n, dtype=torch.int32, device=dev)
     T1 = torch.empty((n, 4, 4), dtype=torch.float64, device=dev); T2 = torch.empty_like(T1)
     st1 = torch.empty((n, 16), dtype=torch.float64, device=dev); st2 = torch.empty_like(st1)
     if n == 0:
-        return best, T1, st1, T2, st2
+        return (best, T1, st1, T2, st2, None) if keep else (best, T1, st1, T2, st2)
     table = np.zeros(n, _RANSAC_TASK)
     koff = 0
     for i, (k0, k1, m, w, Tr, hr) in enumerate(tasks):
@@ -643,7 +645,25 @@ def ransac_batch(tasks, ird, w_f32=False):
     ws = torch.empty(max(ws_n, 8) // 8, dtype=torch.float64, device=dev)
     _check(lib().roreg_ransac_batch(_ptr(tdev), n, koff, max(max_M, 1), max_H, float(ird), int(bool(w_f32)), _ptr(best), _ptr(T1), _ptr(st1), _ptr(T2), _ptr(st2),
                                     _ptr(ws), ws_n, _stream()), 'roreg_ransac_batch')
+    if keep:
+        return best, T1, st1, T2, st2, (tdev, ws, koff, bool(w_f32), tasks)
     return best, T1, st1, T2, st2
+
+
+def refine_batch(ctx, sel, T_in, dist):
+    """One more refinement at `dist` of the tasks `sel` (host ints) of ransac_batch(keep=True)'s context, from T_in [len(sel),4,4] f64 (host or
+    device) -> (T [len(sel),4,4], stats [len(sel),16]) device tensors, one launch."""
+    tdev, ws, total_M, w_f32, _tasks = ctx
+    n = len(sel)
+    dev = ws.device
+    T = torch.empty((n, 4, 4), dtype=torch.float64, device=dev); st = torch.empty((n, 16), dtype=torch.float64, device=dev)
+    if n == 0:
+        return T, st
+    sel_dev = upload(np.ascontiguousarray(sel, np.int32))
+    Tin = T_in if torch.is_tensor(T_in) else upload(np.ascontiguousarray(T_in, np.float64))
+    _check(lib().roreg_refine_batch(_ptr(tdev), _ptr(sel_dev, torch.int32), n, total_M, _ptr(Tin, torch.float64), float(dist), int(w_f32), _ptr(T), _ptr(st),
+                                    _ptr(ws), _stream()), 'roreg_refine_batch')
+    return T, st
 
 
 _MATCH_TASK = np.dtype([('desc0', np.uint64), ('desc1', np.uint64), ('rows0', np.uint64), ('rows1', np.uint64), ('m0', np.int32), ('m1', np.int32)])

@@ -491,6 +491,22 @@ def test_ransac_batch_equals_per_pair_calls():
         for got, want in ((T1[q], a1), (st1[q], s1), (T2[q], a2), (st2[q], s2)):
             assert np.array_equal(got.reshape(-1), want.cpu().numpy().reshape(-1), equal_nan=True), q
     assert hip.ransac_batch([], ird)[0].numel() == 0
+    # one more refinement of SOME tasks from given transforms in one launch (the engine's pass over rank-deficient pairs) == per-pair calls,
+    # float64 and float32-score arithmetic
+    for w_f32 in (False, True):
+        out = hip.ransac_batch(tasks, ird, w_f32=w_f32, keep=True)
+        ctx = out[5]
+        sel = [3, 0, 4, 2]
+        Tin = rng.standard_normal((len(sel), 4, 4)) * 0.01 + np.asarray(T1)[sel]
+        Tb, sb = hip.refine_batch(ctx, sel, Tin, ird)
+        for pos, q in enumerate(sel):
+            d, M = per_pair[q]
+            k0 = hip.gather_rows_f64(d['k0'], d['m'][:, 0].contiguous()); k1 = hip.gather_rows_f64(d['k1'], d['m'][:, 1].contiguous())
+            w = d['w'] if d['w'] is not None else torch.ones(M, dtype=torch.float64, device='cuda')
+            a, st = hip.refine(k0, k1, w, ird, T_in=cu(Tin[pos]), want_stats=True, w_f32=w_f32 and d['w'] is not None)
+            assert np.array_equal(Tb[pos].cpu().numpy().reshape(-1), a.cpu().numpy().reshape(-1), equal_nan=True), (w_f32, q)
+            assert np.array_equal(sb[pos].cpu().numpy(), st.cpu().numpy().reshape(-1), equal_nan=True), (w_f32, q)
+    assert hip.refine_batch(ctx, [], np.zeros((0, 4, 4)), ird)[0].shape == (0, 4, 4)
 
 
 def test_lt_batch_equals_per_pair_calls(group):
