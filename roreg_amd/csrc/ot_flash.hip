@@ -23,6 +23,7 @@
 // Per element and iteration: 2 x (7/1024 MFMA + v_exp_f32 + v_add_f32) against one 4-byte HBM read + ~10 vector instructions before.
 // The read-out (arg-max of Z + u + v over rows and columns) still runs on a matrix built once per pair (rm.hip).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -145,26 +146,35 @@ __device__ __forceinline__ float half_max(float x) {
     return fmaxf(x, dpp_mov<0x142, 0xa>(x));    // (rows 0 and 2 see their own value again: harmless for a maximum)
 }
 
-// One pass: for the 32 rows of side A that this wave owns, part[chunk][row] = sum (MAXP: max) over the chunk's columns of 2^acc (acc).
-// Wave w of a workgroup owns row tile 4 blockIdx.x + w; the four waves stream the same column tiles (their fragment loads meet in L1).
-template <bool MAXP>
+// One pass: for the R x 32 rows of side A that this wave owns, part[chunk][row] = sum (MAXP: max) over the chunk's columns of 2^acc (acc).
+// Wave w of a workgroup owns row tiles R (4 blockIdx.x + w) .. + R - 1; the four waves stream the same column tiles (their fragment loads
+// meet in L1).  R = 2: every column fragment fetched serves two accumulator tiles, whose MFMA chains interleave (round 4: with R = 1 and
+// ten-tile chunks the kernel ran at 0.34 MFMA-busy, bound by the dependent chain and by wave start-up, the max-only pass as slow as the
+// exponentiating one).
+template <bool MAXP, int R>
 __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int lenA = a.seg[pair + 1] - a.seg[pair], lenB = b.seg[pair + 1] - b.seg[pair];
     const int tilesA = lenA / 32 + 1, tilesB = lenB / 32 + 1;              // (len + 1 rows: the dustbin)
-    const int tA = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tA >= tilesA) return;
+    const int tA0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (tA0 >= tilesA) return;
     const int cht = (tilesB + nch - 1) / nch;
     const int tb0 = chunk * cht, tb1 = min(tb0 + cht, tilesB);
-    const f16x8 *fa = reinterpret_cast<const f16x8 *>(a.frag + pair * a.frag_stride) + (size_t)tA * OF_PLANES * 64 + lane;
     const f16x8 *fb = reinterpret_cast<const f16x8 *>(b.frag + pair * b.frag_stride) + lane;
-    f16x8 A[OF_PLANES];
+    f16x8 A[R][OF_PLANES];
 #pragma unroll
-    for (int p = 0; p < OF_PLANES; ++p) A[p] = fa[p * 64];
-    float red[16];
+    for (int q = 0; q < R; ++q) {
+        const int tA = min(tA0 + q, tilesA - 1);                           // (an odd tile count: the last wave's second tile repeats its first, not stored)
+        const f16x8 *fa = reinterpret_cast<const f16x8 *>(a.frag + pair * a.frag_stride) + (size_t)tA * OF_PLANES * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[r] = MAXP ? -__builtin_inff() : 0.f;
+        for (int p = 0; p < OF_PLANES; ++p) A[q][p] = fa[p * 64];
+    }
+    float red[R][16];
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[q][r] = MAXP ? -__builtin_inff() : 0.f;
     f16x8 B[OF_PLANES], Bn[OF_PLANES];
     if (tb0 < tb1) {
 #pragma unroll
@@ -174,28 +184,36 @@ __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
         const int tn = tb + 1 < tb1 ? tb + 1 : tb;                        // (the last round re-reads its own tile: branch-free prefetch)
 #pragma unroll
         for (int p = 0; p < OF_PLANES; ++p) Bn[p] = fb[((size_t)tn * OF_PLANES + p) * 64];
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[3], B[0], acc, 0, 0, 0);      // lo . hi
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[4], B[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[3], acc, 0, 0, 0);      // hi . lo
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[4], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc, 0, 0, 0);      // hi . hi
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[2], B[2], acc, 0, 0, 0);      // potentials, dustbins, padding
+        f32x16 acc[R];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (MAXP) red[r] = fmaxf(red[r], acc[r]);
-            else red[r] += __builtin_amdgcn_exp2f(acc[r]);
-        }
+        for (int q = 0; q < R; ++q) acc[q] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // small terms first; the R accumulators' chains alternate so that consecutive MFMAs are independent
+#define OF_STEP(PA, PB) _Pragma("unroll") for (int q = 0; q < R; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[q][PA], B[PB], acc[q], 0, 0, 0)
+        OF_STEP(3, 0); OF_STEP(4, 1);          // lo . hi
+        OF_STEP(0, 3); OF_STEP(1, 4);          // hi . lo
+        OF_STEP(0, 0); OF_STEP(1, 1);          // hi . hi
+        OF_STEP(2, 2);                         // potentials, dustbins, padding
+#undef OF_STEP
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (MAXP) red[q][r] = fmaxf(red[q][r], acc[q][r]);
+                else red[q][r] += __builtin_amdgcn_exp2f(acc[q][r]);
+            }
 #pragma unroll
         for (int p = 0; p < OF_PLANES; ++p) B[p] = Bn[p];
     }
     // accumulator register r of lane l is row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
-    float *out = a.part + pair * (a.pot_stride * nch) + (size_t)chunk * a.pot_stride + tA * 32;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v = MAXP ? half_max(red[r]) : half_sum(red[r]);
-        if ((lane & 31) == 31) out[8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = v;
+    for (int q = 0; q < R; ++q) {
+        if (tA0 + q >= tilesA) break;
+        float *out = a.part + pair * (a.pot_stride * nch) + (size_t)chunk * a.pot_stride + (tA0 + q) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = MAXP ? half_max(red[q][r]) : half_sum(red[q][r]);
+            if ((lane & 31) == 31) out[8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = v;
+        }
     }
 }
 
@@ -267,10 +285,17 @@ __host__ __device__ inline size_t round_up(size_t x, size_t a) { return (x + a -
 
 namespace roreg {
 
+constexpr int OF_R = 2;                                // row tiles per wave
+
+// Column chunks per row block: enough workgroups for ~4 waves per SIMD in ONE residency (1024 SIMDs), no more -- a wave that owns only a few
+// column tiles spends its life starting up.  ROREG_OT_NCH overrides (measurements).
 static int ot_flash_chunks(int n_seg, int max_m, int max_n) {
-    const int ta = (max_m / 32 + 1 + 3) / 4, tb = (max_n / 32 + 1 + 3) / 4;
+    static const int forced = getenv("ROREG_OT_NCH") ? atoi(getenv("ROREG_OT_NCH")) : 0;
+    const int ta = (max_m / 32 + 1 + 4 * OF_R - 1) / (4 * OF_R), tb = (max_n / 32 + 1 + 4 * OF_R - 1) / (4 * OF_R);
     const int wg = (ta < tb ? ta : tb) * n_seg;
-    int nch = (2048 + wg - 1) / wg;                   // ~8 workgroups per CU in flight or queued
+    int nch = forced > 0 ? forced : (1024 + wg - 1) / wg;
+    const int tiles = (max_m < max_n ? max_m : max_n) / 32 + 1;
+    if (nch > tiles) nch = tiles;
     if (nch > 8) nch = 8;
     return nch < 1 ? 1 : nch;
 }
@@ -306,16 +331,16 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     const int mx = max_m > max_n ? max_m : max_n;
     hipLaunchKernelGGL(of_absmax_kernel, dim3((mx * OF_F + 255) / 256, 2 * n_seg), dim3(256), 0, s, A, B, amax);
     hipLaunchKernelGGL(of_prep_kernel, dim3((unsigned)(ta > tb ? ta : tb), 2, n_seg), dim3(320), 0, s, A, B, amax, alpha);
-    const dim3 gA((unsigned)((ta + 3) / 4), nch, n_seg), gB((unsigned)((tb + 3) / 4), nch, n_seg);
+    const dim3 gA((unsigned)((ta + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg), gB((unsigned)((tb + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg);
     const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);
     if (iters > 0) {
-        hipLaunchKernelGGL(of_pass_kernel<true>, gA, dim3(256), 0, s, A, B, nch);
+        hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch);
         hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
     }
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(of_pass_kernel<false>, gA, dim3(256), 0, s, A, B, nch);
+        hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
         hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
-        hipLaunchKernelGGL(of_pass_kernel<false>, gB, dim3(256), 0, s, B, A, nch);
+        hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);
         hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nch, 3, alpha, amax);
     }
     hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride);

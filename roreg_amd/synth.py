@@ -140,6 +140,27 @@ def make_scene(seed, n_clouds=2, n_kpts=256, overlap=0.6, feat_noise=0.05, coord
     return SynthScene(name, kps, feats, poses, pair_ids)
 
 
+def config1_pair():
+    """BASELINE configs[0] / SURVEY 8(d) "config 1", the plumbing case, as one fixed recipe: np.random.seed(0) and torch.manual_seed(0) streams
+    (private generator objects: the process-global ones are untouched); N = 256; feats0 = randn(N,32,60) float32; keys0 uniform in [0,3]^3
+    float64; cloud 1 = cloud 0 seen from the pose (group element 7, t = (0.3, -0.2, 0.5)) with its rows permuted and
+    feats1 = feats0[:, :, P[7]] + 0.05 randn.  -> SynthScene with the pair ('0', '1'); its ground truth is T(0 <- 1) = [R_7 | t]."""
+    import torch
+    rs = np.random.RandomState(0)
+    gen = torch.Generator().manual_seed(0)
+    T = tables()
+    N, g, t = 256, 7, np.array([0.3, -0.2, 0.5])
+    feats0 = torch.randn(N, 32, G, generator=gen).numpy()
+    noise = torch.randn(N, 32, G, generator=gen).numpy()
+    keys0 = rs.uniform(0.0, 3.0, (N, 3))
+    perm = rs.permutation(N)
+    keys1 = np.ascontiguousarray(((keys0 - t) @ T.R[g])[perm])
+    feats1 = np.ascontiguousarray((feats0[:, :, T.P[g]] + np.float32(0.05) * noise)[perm].astype(np.float32))
+    ds = SynthScene('synth/config1', [keys0, keys1], [feats0, feats1], [(0, np.zeros(3)), (g, t)], [(0, 1)])
+    ds.perm = perm
+    return ds
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size parity cases (tests/golden/full_*.npz store only the reference's small outputs; the inputs are rebuilt here from the seed)
 # ------------------------------------------------------------------------------------------------

@@ -217,6 +217,43 @@ def test_split_bf16_gemm_is_f32_accurate(group):
     assert esp < 3 * e32 + 1e-7 and e16 < 3 * e32 + 1e-7, (e32, esp, e16)
 
 
+@pytest.mark.parametrize('span_bits', [12, 8])
+def test_f16x2_small_channels_beside_large_ones_keep_their_own_accuracy(group, span_bits):
+    """PER-ELEMENT accuracy under the per-keypoint block scale (the other accuracy tests take a maximum over the whole output tensor): in
+    every keypoint half of the input channels are 2^span times smaller than the other half, and the weights are block diagonal, so half of
+    the OUTPUT channels are 2^span times smaller than the others and depend on the small inputs alone.  Their errors, measured against
+    float64 relative to THEIR OWN magnitude, must stay at the f32-input kernel's level (<= 3 x): the fp16 hi + lo split is relative to the
+    keypoint's bound, which the large channels set."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    rng = np.random.default_rng(40 + span_bits)
+    B, C, Oc = 96, 256, 512
+    conv = torch.nn.Conv2d(C, Oc, (1, 13))
+    with torch.no_grad():
+        conv.weight[:Oc // 2, C // 2:] = 0.0; conv.weight[Oc // 2:, :C // 2] = 0.0; conv.bias.zero_()
+    L = _Layer(conv)
+    x = rng.standard_normal((B, C, 60)).astype(np.float32)
+    x[:, :C // 2] *= np.float32(2.0 ** -span_bits)                                   # the small half, in the SAME keypoints as the large half
+    xd = torch.from_numpy(x).cuda()
+    X = hip.ft_nonlin(B, C, x_spatial=xd)
+    xb = hip.row_bound(xd)
+    Xp = hip.ft_nonlin(B, C, x_spatial=xd, split='f16x2', out_bound=xb)
+    T32 = hip.irrep_gemm(X, L.wpack, C, Oc, B)
+    Tsp = hip.irrep_gemm(X, L.wpack, C, Oc, B, split=L.wsplit)
+    T16 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb)
+    ref = np.einsum('ock,bcgk->bog', conv.weight.detach().double().numpy()[:, :, 0, :], x.astype(np.float64)[:, :, group.Nei])
+    small = ref[:, :Oc // 2]
+    assert np.abs(small).max() < 2.0 ** (3 - span_bits) * np.abs(ref[:, Oc // 2:]).max()
+    err = {}
+    for name, T in (('f32', T32), ('bf16x3', Tsp), ('f16x2', T16)):
+        y = hip.ft_nonlin(B, Oc, coef_in=T, bias=L.bias, spatial_out=True).double().cpu().numpy()
+        err[name] = (float(np.abs(y[:, :Oc // 2] - small).max() / np.abs(small).max()), float(np.abs(y[:, Oc // 2:] - ref[:, Oc // 2:]).max() / np.abs(ref[:, Oc // 2:]).max()))
+    print(f'span 2^{span_bits}: (small-channel, large-channel) errors relative to their own scale: {err}')
+    assert err['f32'][0] < 4e-6, err
+    assert err['f16x2'][0] < 3 * err['f32'][0] + 1e-7 and err['f16x2'][1] < 3 * err['f32'][1] + 1e-7, err
+    assert err['bf16x3'][0] < 3 * err['f32'][0] + 1e-7, err
+
+
 def test_f16x2_block_scale_survives_outliers(group):
     """One coefficient 10^4 times larger than the rest sets the block scale of ITS keypoint in the fp16 x 2 GEMM; the keypoint's other columns
     must keep their accuracy (the hi/lo split keeps 22 bits within ~11 binades of the bound), and other keypoints are not affected at all."""

@@ -90,7 +90,8 @@ def test_full_ransac_float32_ties_keep_the_references_winner():
 @pytest.mark.parametrize('mode', MODES)
 def test_full_stages_neartie_pair(tmp_path, mode, monkeypatch):
     """Exact duplicates and thousands of near ties among 5000 x 5000 descriptors: the mutual matches, the Des2R indices and the
-    RANSAC result equal the reference's bit for bit; Trans_pre within 2e-4 in every matrix-core mode."""
+    RANSAC result equal the reference's bit for bit; Trans_pre: rotations within 1e-4, translations within 1e-4 x (1 + lever arm) (t = key0 -
+    key1 R^T carries the rotation's error times |key1|), in every matrix-core mode."""
     from roreg_amd import hip
     from roreg_amd.test import name2matcher, name2estimator, _cache
     z = load_golden('full_stages')
@@ -116,7 +117,9 @@ def test_full_stages_neartie_pair(tmp_path, mode, monkeypatch):
     assert np.array_equal(np.load(f'{md}/DR_index/0-1.npy'), z['dr'].astype(np.int64))
     est.localT_extractor.Rt_pre(ds, 5000)
     T = np.load(f'{md}/Trans_pre/0-1.npy')
-    assert T.shape == z['transpre'].shape and np.abs(T - z['transpre']).max() < 2e-4
+    assert T.shape == z['transpre'].shape and np.abs(T[:, :, :3] - z['transpre'][:, :, :3]).max() < 1e-4
+    lever = float(np.abs(ds.get_kps('1')).sum(1).max())
+    assert np.abs(T[:, :, 3] - z['transpre'][:, :, 3]).max() < 1e-4 * (1.0 + lever), lever
     np.save(f'{md}/Trans_pre/0-1.npy', z['transpre'])                                   # identical inputs for the RANSAC stage
     np.random.seed(4321)
     est.ransacer.ransac(ds, 5000, 1000)
@@ -280,7 +283,17 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     e2e_identical = np.array_equal(m, want_m) and int(r['recalltime']) == int(z['recall_0_1'])
     print(f'[{tag}] end to end: detector ranks moved <= {max(moved):.0f} places; NMS samples shared {same_nms} of 2500; match rows shared {rows_same} of '
           f'{len(want_m)} (mine {len(m)}); recalltime {int(r["recalltime"])} vs {int(z["recall_0_1"])}; |dT| {np.abs(r["trans"] - z["trans_0_1"]).max():.2e}')
-    assert max(moved) <= 30 and min(same_nms) >= 2450
+    assert max(moved) <= 30 and min(same_nms) >= 2495             # measured: <= 15 places; at most ONE of the 2500 sampled keypoints differs
+    if tag.endswith('_o60'):
+        # the pair that registers (60 % overlap): the whole chain stays on the reference's track from the input features -- both NMS samples,
+        # every one of the 212 match rows, the recalltime and the transform
+        assert same_nms == [2500, 2500] and e2e_identical and len(m) == len(want_m) == 212
+        assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
+    else:
+        # the 20 % pair is a FAILED registration in the reference too (175 matches, a one-inlier winner); one keypoint of 2500 flips at the NMS
+        # boundary on float32 detector noise and the matcher's context is global: measured 150 of the reference's 175 rows shared.  The floor
+        # below is what "no worse than that" means; stage by stage (below) everything is identical.
+        assert rows_same >= 140 and abs(len(m) - len(want_m)) <= 15, (rows_same, len(m), len(want_m))
     if e2e_identical:
         assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
     # ---- stage by stage on the reference's intermediate outputs: every index list identical ----
@@ -297,7 +310,13 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     np.random.seed(4321)
     name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
     assert np.array_equal(np.load(f'{md}/DR_index/0-1.npy'), z['dr_0_1'].astype(np.int64))
-    assert np.abs(np.load(f'{md}/Trans_pre/0-1.npy')[::16] - z['transpre_sample_0_1']).max() < 2e-4
+    tp = np.load(f'{md}/Trans_pre/0-1.npy')[::16]; tw = z['transpre_sample_0_1']
+    # local transforms: the rotation (ET quaternion -> R, float32 in the reference) to 1e-4; the translation t = key0 - key1 R^T (estimator.py:362)
+    # carries the rotation's error times the keypoint's lever arm (|key1| up to 5.2 m in this scene), hence 1e-4 x (1 + lever arm) <= 2e-4 x 3.1
+    assert np.abs(tp[:, :, :3] - tw[:, :, :3]).max() < 1e-4
+    lever = float(np.abs(ds.get_kps('1')).sum(1).max())
+    assert np.abs(tp[:, :, 3] - tw[:, :, 3]).max() < 1e-4 * (1.0 + lever)
+    print(f'[{tag}] Trans_pre: |dR| {np.abs(tp[:, :, :3] - tw[:, :, :3]).max():.2e}, |dt| {np.abs(tp[:, :, 3] - tw[:, :, 3]).max():.2e}, lever arm {lever:.2f}')
     r = np.load(f'{md}/yohoo/1000iters/0-1.npz')
     assert int(r['recalltime']) == int(z['recall_0_1'])
     assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4

@@ -186,7 +186,9 @@ def test_sinkhorn_recomputed_on_the_matrix_cores_equals_the_materialised_iterati
     cs, ct = cu(np.concatenate(S)), cu(np.concatenate(T))
     a0, a1, as0, as1 = hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, iters, recompute=True)
     b0, b1, bs0, bs1 = hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, iters, recompute=False)
-    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    bad0 = torch.nonzero(a0 != b0).flatten().tolist(); bad1 = torch.nonzero(a1 != b1).flatten().tolist()
+    assert not bad0 and not bad1, (bad0[:8], bad1[:8], a0[bad0[:8]].tolist(), b0[bad0[:8]].tolist(), as0[bad0[:8]].tolist(), bs0[bad0[:8]].tolist(),
+                                   seg_s.host.tolist(), seg_t.host.tolist())
     assert float((as0 - bs0).abs().max()) < 5e-5 and float((as1 - bs1).abs().max()) < 5e-5
     o0 = o1 = 0
     for (m, n), s, t in zip(sizes, S, T):

@@ -300,12 +300,24 @@ def gen_quat():
 
 
 # ====================================================================================================
-def run_pipeline(tag, RD, RM, ET, keynum, n_kpts=128, n_clouds=3, seed=5, match_n=0.5, keep_yoho=True):
+def gen_config1():
+    """SURVEY 8(d) config 1 (N = 256, g = 7, t = (0.3, -0.2, 0.5)) through the reference's mutual matcher + yohoo estimator; the inputs are rebuilt
+    from the recipe (roreg_amd.synth.config1_pair), only their checksum and the reference's outputs are stored."""
+    import hashlib
+    ds = synth.config1_pair()
+    h = hashlib.sha256()
+    for a in ds.feats + ds._kps:
+        h.update(np.ascontiguousarray(a).tobytes())
+    run_pipeline('config1', RD=False, RM=False, ET='yohoo', keynum=256, n_kpts=256, n_clouds=2, keep_yoho='sample', ds=ds,
+                 extra={'inputs_sha256': np.frombuffer(h.hexdigest().encode(), np.uint8)})
+
+
+def run_pipeline(tag, RD, RM, ET, keynum, n_kpts=128, n_clouds=3, seed=5, match_n=0.5, keep_yoho=True, ds=None, extra=None):
     """End-to-end reference run on a small synthetic scene; captures every inter-stage file."""
     root = tempfile.mkdtemp(prefix='golden_')
     try:
         cfg = make_cfg(root, RD=RD, RM=RM, ET=ET, keynum=keynum, match_n=match_n)
-        ds = synth.make_scene(seed, n_clouds=n_clouds, n_kpts=n_kpts, overlap=0.6, name='synth/scene0')
+        ds = synth.make_scene(seed, n_clouds=n_clouds, n_kpts=n_kpts, overlap=0.6, name='synth/scene0') if ds is None else ds
         ds.write_inputs(cfg.output_cache_fn)
         out = {'n_kpts': np.int64(n_kpts), 'n_clouds': np.int64(n_clouds), 'scene_seed': np.int64(seed),
                'keynum': np.int64(keynum), 'RD': np.bool_(RD), 'RM': np.bool_(RM), 'match_n': np.float64(match_n)}
@@ -319,7 +331,9 @@ def run_pipeline(tag, RD, RM, ET, keynum, n_kpts=128, n_clouds=3, seed=5, match_
         base = f'{cfg.output_cache_fn}/{ds.name}'
         for pc in ds.pc_ids:
             y = np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')
-            if keep_yoho:
+            if keep_yoho == 'sample':
+                out[f'yoho_sample_{pc}'] = y[::8]
+            elif keep_yoho:
                 out[f'yoho_{pc}'] = y
             else:   # same scene + same GF weights as the first pipeline: stored once there
                 first = np.load(os.path.join(OUT, 'pipeline_mutual_yohoo.npz'))
@@ -342,6 +356,7 @@ def run_pipeline(tag, RD, RM, ET, keynum, n_kpts=128, n_clouds=3, seed=5, match_
         fmr, ir = ev.fmr_ir_scene(ds)
         rr, rre, rte = ev.rr_scene(ds)
         out.update(fmr=np.float64(fmr), ir=np.float64(ir), rr=np.float64(rr), rre=np.float64(rre), rte=np.float64(rte))
+        out.update(extra or {})
         save(f'pipeline_{tag}', **out)
     finally:
         shutil.rmtree(root, ignore_errors=True)
