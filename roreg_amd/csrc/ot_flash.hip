@@ -148,10 +148,14 @@ __device__ __forceinline__ float half_max(float x) {
 
 // One pass: for the R x 32 rows of side A that this wave owns, part[chunk][row] = sum (MAXP: max) over the chunk's columns of 2^acc (acc).
 // Wave w of a workgroup owns row tiles R (4 blockIdx.x + w) .. + R - 1; the four waves stream the same column tiles (their fragment loads
-// meet in L1).  R = 2: every column fragment fetched serves two accumulator tiles, whose MFMA chains interleave (round 4: with R = 1 and
-// ten-tile chunks the kernel ran at 0.34 MFMA-busy, bound by the dependent chain and by wave start-up, the max-only pass as slow as the
-// exponentiating one).
-template <bool MAXP, int R>
+// meet in L1).  R = 2: every column fragment fetched serves two accumulator tiles, whose MFMA chains alternate.
+// Software pipeline (round 4; measured by ablation on 30 stacked 2500 x 2500 pairs: of 58 us per pass the 14 MFMAs of a trip accounted for
+// 34, the exponentials 11, the fragment loads 10 -- all in series, because a wavefront issues in order and the loop was "14 MFMAs, then 32
+// exponentials"): the MFMAs of column tile t + 1 are issued INTERLEAVED with the exponentials of tile t (two accumulator sets, ping-pong
+// over two tiles per trip so that nothing is copied; sched_group_barrier prescribes one MFMA, three transcendentals, two vector adds, ...),
+// so the vector pipe works in the matrix pipe's shadow; the fragments of tile t + 2 are in flight meanwhile.  The file is compiled with
+// -amdgpu-mfma-vgpr-form: accumulators in VGPRs, no v_accvgpr_read per element.
+template <bool MAXP, int R, int VAR = 0>     // VAR: ablations for measurements only (ROREG_OT_VARIANT): 1 = no exponentials, 2 = no MFMAs, 3 = no column loads in the loop
 __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -175,34 +179,70 @@ __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
     for (int q = 0; q < R; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[q][r] = MAXP ? -__builtin_inff() : 0.f;
-    f16x8 B[OF_PLANES], Bn[OF_PLANES];
-    if (tb0 < tb1) {
+    auto load_b = [&](int tb, f16x8 (&dst)[OF_PLANES]) {
+        if (VAR == 3) return;
+        const f16x8 *src = fb + (size_t)min(tb, tb1 - 1) * OF_PLANES * 64;   // (past the chunk: a valid tile, never used)
 #pragma unroll
-        for (int p = 0; p < OF_PLANES; ++p) B[p] = fb[((size_t)tb0 * OF_PLANES + p) * 64];
-    }
-    for (int tb = tb0; tb < tb1; ++tb) {
-        const int tn = tb + 1 < tb1 ? tb + 1 : tb;                        // (the last round re-reads its own tile: branch-free prefetch)
-#pragma unroll
-        for (int p = 0; p < OF_PLANES; ++p) Bn[p] = fb[((size_t)tn * OF_PLANES + p) * 64];
-        f32x16 acc[R];
+        for (int p = 0; p < OF_PLANES; ++p) dst[p] = src[p * 64];
+    };
+    // the 7 R MFMAs of one column tile: small terms first; the R accumulators' chains alternate (consecutive MFMAs are independent)
+    auto mm = [&](const f16x8 (&B)[OF_PLANES], f32x16 (&acc)[R]) {
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // small terms first; the R accumulators' chains alternate so that consecutive MFMAs are independent
-#define OF_STEP(PA, PB) _Pragma("unroll") for (int q = 0; q < R; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[q][PA], B[PB], acc[q], 0, 0, 0)
+#define OF_STEP(PA, PB) _Pragma("unroll") for (int q = 0; q < R; ++q) { if (VAR != 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[q][PA], B[PB], acc[q], 0, 0, 0); else acc[q][PA] += (float)B[PB][q]; }
         OF_STEP(3, 0); OF_STEP(4, 1);          // lo . hi
         OF_STEP(0, 3); OF_STEP(1, 4);          // hi . lo
         OF_STEP(0, 0); OF_STEP(1, 1);          // hi . hi
         OF_STEP(2, 2);                         // potentials, dustbins, padding
 #undef OF_STEP
+    };
+    auto fold = [&](const f32x16 (&acc)[R]) {
 #pragma unroll
         for (int q = 0; q < R; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (MAXP) red[q][r] = fmaxf(red[q][r], acc[q][r]);
+                else if (VAR == 1) red[q][r] += acc[q][r];
                 else red[q][r] += __builtin_amdgcn_exp2f(acc[q][r]);
             }
+    };
+    auto interleave = [&]() {                  // one MFMA, then a few transcendentals and vector adds in its shadow, 7 R times
 #pragma unroll
-        for (int p = 0; p < OF_PLANES; ++p) B[p] = Bn[p];
+        for (int g = 0; g < 7 * R; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, MAXP ? 0 : (16 * R + 7 * R - 1) / (7 * R), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (16 * R + 7 * R - 1) / (7 * R), 0);
+        }
+    };
+    f16x8 B0[OF_PLANES], B1[OF_PLANES];
+    f32x16 accA[R], accB[R];
+    if (tb0 < tb1) {
+        if (VAR == 3) {
+#pragma unroll
+            for (int p = 0; p < OF_PLANES; ++p) { B0[p] = A[0][p]; B1[p] = A[R - 1][(p + 1) % OF_PLANES]; }
+        }
+        load_b(tb0, B0);
+        load_b(tb0 + 1, B1);
+        mm(B0, accA);
+        int tb = tb0;
+        for (; tb + 2 < tb1; tb += 2) {        // entering a trip: accA = tile tb (issued), B1 = fragments of tile tb + 1
+            load_b(tb + 2, B0);
+            mm(B1, accB); fold(accA);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(tb + 3, B1);
+            mm(B0, accA); fold(accB);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tb + 1 < tb1) {
+            mm(B1, accB); fold(accA);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            fold(accB);
+        } else {
+            fold(accA);
+        }
     }
     // accumulator register r of lane l is row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
 #pragma unroll
@@ -338,6 +378,24 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
         hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
     }
     for (int it = 0; it < iters; ++it) {
+        static const int variant = getenv("ROREG_OT_VARIANT") ? atoi(getenv("ROREG_OT_VARIANT")) : 0;
+        if (variant == 1) {
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 1>), gA, dim3(256), 0, s, A, B, nch);
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 1>), gB, dim3(256), 0, s, B, A, nch);
+            continue;
+        } else if (variant == 2) {
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 2>), gA, dim3(256), 0, s, A, B, nch);
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 2>), gB, dim3(256), 0, s, B, A, nch);
+            continue;
+        } else if (variant == 3) {
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 3>), gA, dim3(256), 0, s, A, B, nch);
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 3>), gB, dim3(256), 0, s, B, A, nch);
+            continue;
+        } else if (variant == 4) {                       // passes only (no update launches)
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);
+            continue;
+        }
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
         hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);

@@ -83,6 +83,51 @@ def test_stages_mutual_yohoo_stagewise(tmp_path):
     assert got.shape == want.shape and np.abs(got - want).max() < 1e-8
 
 
+def test_config1_recipe_end_to_end_on_the_device(tmp_path):
+    """BASELINE configs[0] / SURVEY 8(d) config 1 with its exact recipe (N = 256, group element 7, t = (0.3, -0.2, 0.5)) through the stage
+    classes END TO END (no stage is fed the reference's intermediates) and through the device-resident engine: the reference's 256 matches,
+    Des2R indices, recalltime and transform (1e-7, = the ground truth), FMR = IR = RR = 1."""
+    from roreg_amd.network import name2network
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.test import name2extractor, name2matcher, name2estimator, _cache
+    z = load_golden('pipeline_config1')
+    root = str(tmp_path)
+    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=256, ET='yohoo')
+    nets = {}
+    for kind, d, seed in [('GF_test', 'GF', 101), ('ET_test', 'ET', 202)]:
+        net = name2network[kind](cfg)
+        synth.seeded_state_dict(net, seed)
+        os.makedirs(f'{root}/ckpt/{d}', exist_ok=True)
+        torch.save({'best_para': 0, 'network_state_dict': net.state_dict()}, f'{root}/ckpt/{d}/model_best.pth')
+        nets[d] = net
+    ds = synth.config1_pair()
+    ds.write_inputs(cfg.output_cache_fn)
+    _cache.clear()
+    name2extractor['yoho_des'](cfg).run(ds)
+    base = f'{cfg.output_cache_fn}/{ds.name}'
+    for pc in ds.pc_ids:
+        assert np.abs(np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')[::8] - z[f'yoho_sample_{pc}']).max() < 1e-5
+    np.random.seed(1234)
+    name2matcher['matmul'](cfg).run(ds, 256)
+    md = f'{base}/match_256'
+    m = np.load(f'{md}/0-1.npy')
+    assert np.array_equal(m, z['match_0_1']) and np.array_equal(ds.perm[m[:, 1]], m[:, 0])
+    np.random.seed(4321)
+    name2estimator['yohoo'](cfg).run(ds, 256, 1000)
+    assert np.array_equal(np.load(f'{md}/DR_index/0-1.npy'), z['dr_0_1'])
+    tp = np.load(f'{md}/Trans_pre/0-1.npy')
+    assert np.abs(tp[:, :, :3] - z['transpre_0_1'][:, :, :3]).max() < 1e-4 and np.abs(tp - z['transpre_0_1']).max() < 4e-4
+    r = np.load(f'{md}/yohoo/1000iters/0-1.npz')
+    gt = np.eye(4); gt[:3] = ds.get_transform('0', '1').astype(np.float64)
+    assert int(r['recalltime']) == int(z['recall_0_1'])
+    assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-7 and np.abs(r['trans'] - gt).max() < 1e-6
+    # the device-resident engine on the same pair (the reference's global generator calls in the reference's order)
+    eng = RegistrationEngine(cfg, nets['GF'], nets['ET'])
+    np.random.seed(1234)
+    res = eng.run_scene({0: ds.feats[0], 1: ds.feats[1]}, {0: ds.get_kps('0'), 1: ds.get_kps('1')}, ds.pair_ids, keynum=256, max_iter=1000, keep_matches=True)
+    assert res[0].n_match == 256 and np.abs(res[0].trans - gt).max() < 1e-6
+
+
 def test_stages_rd_mutual_yohoc_stagewise(tmp_path):
     from roreg_amd.test import name2detector, name2matcher, name2estimator
     z = load_golden('pipeline_rd_mutual_yohoc')

@@ -246,6 +246,44 @@ def test_pipeline_mutual_yohoo_stagewise(group):
     assert txt.encode() == z['pre_log'].tobytes()
 
 
+def test_config1_recipe_end_to_end(group):
+    """BASELINE configs[0] = SURVEY 8(d) config 1, the CPU plumbing case, with its exact recipe (roreg_amd.synth.config1_pair: N = 256, group
+    element 7, t = (0.3, -0.2, 0.5)): the oracle chained END TO END from the input features -- extractor, mutual matcher, Des2R, ET, local
+    transforms, one-shot RANSAC -- reproduces the reference's run (256 / 256 matches, every one correct; index lists identical; the recovered
+    transform equals the ground truth to 1e-7)."""
+    import hashlib
+    z = load_golden('pipeline_config1')
+    ds = synth.config1_pair()
+    h = hashlib.sha256()
+    for a in ds.feats + ds._kps:
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest().encode() == z['inputs_sha256'].tobytes(), 'the recipe no longer rebuilds the inputs the reference was run on'
+    gf_sd = seeded_sd('GF_test', 101); et_sd = seeded_sd('ET_test', 202)
+    eqv = [O.gf_forward(f, gf_sd, group.Nei)['eqv'] for f in ds.feats]
+    for pc in (0, 1):
+        assert np.abs(eqv[pc][::8] - z[f'yoho_sample_{pc}']).max() < 1e-5
+    np.random.seed(1234)
+    s0 = np.arange(256); s1 = np.arange(256)
+    np.random.shuffle(s0); np.random.shuffle(s1)
+    m = O.mutual_match(eqv[0], eqv[1], s0[:256], s1[:256])
+    assert np.array_equal(m, z['match_0_1']) and m.shape == (256, 2)
+    assert np.array_equal(ds.perm[m[:, 1]], m[:, 0])              # cloud 1's row j is cloud 0's row perm[j]: every match is a true correspondence
+    dr = O.des2r(eqv[1][m[:, 1]], eqv[0][m[:, 0]], group.P)
+    assert np.array_equal(dr, z['dr_0_1'])
+    batch = {'before_eqv0': ds.feats[1][m[:, 1]], 'before_eqv1': ds.feats[0][m[:, 0]], 'after_eqv0': eqv[1][m[:, 1]], 'after_eqv1': eqv[0][m[:, 0]],
+             'pre_idx': dr}
+    q = O.et_forward(batch, et_sd, group.Nei, group.P)
+    k0 = ds.get_kps('0')[m[:, 0]]; k1 = ds.get_kps('1')[m[:, 1]]
+    Tr = O.rt_pre(q, dr, group.R.astype(np.float32), k0, k1)
+    assert np.abs(Tr[:, :, :3] - z['transpre_0_1'][:, :, :3]).max() < 1e-4 and np.abs(Tr - z['transpre_0_1']).max() < 4e-4
+    np.random.seed(4321)
+    T, rec, _ = O.yohoo_ransac(k0, k1, z['mscore_0_1'], Tr, 0.1, 1000, False, 0.5, np.random.shuffle)
+    assert rec == int(z['recall_0_1'])
+    gt = np.eye(4); gt[:3] = ds.get_transform('0', '1').astype(np.float64)
+    assert np.abs(T - z['trans_0_1']).max() < 1e-7 and np.abs(T - gt).max() < 1e-6 and np.abs(z['trans_0_1'] - gt).max() < 1e-6
+    assert float(z['fmr']) == float(z['ir']) == float(z['rr']) == 1.0
+
+
 def test_pipeline_rd_mutual_yohoc_stagewise(group):
     z = load_golden('pipeline_rd_mutual_yohoc')
     y = load_golden('pipeline_mutual_yohoo')
