@@ -503,6 +503,7 @@ def main():
             sec['rd_rm_leg'] = rd_rm_leg(args, cfg, gf, et)
             sec['rd_rm_leg_pairs_per_s'] = sec['rd_rm_leg'].get('fp32', {}).get('pairs_per_s')
             sec['rd_rm_leg_pairs_per_s_bf16'] = sec['rd_rm_leg'].get('bf16', {}).get('pairs_per_s')
+            sec['rd_rm_leg_sinkhorn_ms_per_pair'] = (sec['rd_rm_leg'].get('fp32', {}).get('roofline_sinkhorn') or {}).get('ms_per_pair')
 
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
     if hip is not None:
@@ -666,10 +667,27 @@ def rd_rm_leg(args, cfg0, gf, et):
                            np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))) < 0.3))
         leg = {'pairs_per_s': n_pairs * n_rep / dt, 'ms_per_pass': 1e3 * dt / n_rep, 'mean_matches': float(np.mean([r.n_match for r in res])),
                'registration_recall_pointdsc': float(np.mean(ok))}
-        if sk_n:
+        if sk_n and work.get('sinkhorn_recompute'):
+            # the iterations recompute the scores on the matrix cores (csrc/ot_flash.hip): per element and iteration two passes of seven K = 16
+            # fp16 MFMAs (224 flop each way) + one v_exp_f32 + one add each; no coupling matrix is read
+            cells = work.get('sinkhorn_cells', 0.0)
+            tf = cells * 448.0 / (sk_ms * 1e-3) / 1e12
+            ex = cells * 2.0 / (sk_ms * 1e-3)
+            leg['roofline_sinkhorn'] = {'kernel': 'of_pass_kernel + of_update_kernel (100 iterations per stacked group of pairs: every pass recomputes <s_i, t_j> + potentials + dustbins '
+                                                  'with seven fp16 MFMAs per 32 x 32 tile and exponentiates; the coupling matrix is never read)', 'bound': 'mfma', 'unit': 'TFLOP/s',
+                                        'launch_groups': sk_n, 'avg_ms': sk_ms / sk_n, 'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1),
+                                        'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': tf / PEAK_BF16_MFMA_TFLOPS,
+                                        'exponentials_per_s': ex, 'exponential_peak_per_s': 256 * 4 * 16 / 4 * 2.4e9,
+                                        'exponential_frac': ex / (256 * 4 * 16 / 4 * 2.4e9),
+                                        'hbm_bytes_not_read': work.get('sinkhorn_bytes', 0.0),
+                                        'note': 'executed MFMA flop = 448 per matrix element and iteration (three fp16 cross products x K = 32, one K = 16 block of potentials / '
+                                                'dustbins, two passes); the materialised iteration (ROREG_OT_RECOMPUTE=0) read 4 (m+1)(n+1) bytes per pair and iteration from HBM '
+                                                'instead: 0.57 of HBM peak, 0.43-0.49 ms per pair at keynum 2500'}
+        elif sk_n:
             gbs = work.get('sinkhorn_bytes', 0.0) / (sk_ms * 1e-3) / 1e9
             leg['roofline_sinkhorn'] = {'kernel': 'ot_fused_pass_kernel + ot_col_merge_kernel (100 iterations per stacked group of pairs; row log-sum-exp and column sums from ONE '
                                                   'read of the coupling matrix per iteration)', 'bound': 'hbm', 'unit': 'GB/s', 'launch_groups': sk_n, 'avg_ms': sk_ms / sk_n,
+                                        'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1),
                                         'achieved': gbs, 'peak': PEAK_HBM_GBS, 'frac': gbs / PEAK_HBM_GBS,
                                         'algorithmic_bytes': 'iterations x sum over pairs of 4 (m+1)(n+1): the kernel\'s one pass per iteration; the reference\'s two '
                                                              'logsumexp passes per iteration (SURVEY 8d: 200 (N+1)^2 4 B) would be twice this figure',

@@ -58,10 +58,13 @@ __global__ __launch_bounds__(256) void of_absmax_kernel(Side a, Side b, unsigned
     const int pair = blockIdx.y >> 1, side = blockIdx.y & 1;
     const Side &s = side ? b : a;
     const int r0 = s.seg[pair], len = s.seg[pair + 1] - r0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(s.desc + (size_t)r0 * OF_F);       // rows are 128 bytes: 16-byte aligned
     float v = 0.f;
-    if (i < len * OF_F) v = fabsf(s.desc[(size_t)r0 * OF_F + i]);
-    if (!(v < __builtin_inff())) v = 0.f;                       // non-finite descriptors do not steer the scale (their scores are NaN anyway)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < len * (OF_F / 4); i += gridDim.x * 256) {
+        const float4 x = src[i];
+        const float m4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+        if (m4 < __builtin_inff()) v = fmaxf(v, m4);             // non-finite descriptors do not steer the scale (their scores are NaN anyway)
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(&amax[pair * 2 + side], __float_as_uint(v));
@@ -368,8 +371,7 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * 8 * sizeof(float);
     unsigned *amax = reinterpret_cast<unsigned *>(p);
     (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
-    const int mx = max_m > max_n ? max_m : max_n;
-    hipLaunchKernelGGL(of_absmax_kernel, dim3((mx * OF_F + 255) / 256, 2 * n_seg), dim3(256), 0, s, A, B, amax);
+    hipLaunchKernelGGL(of_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, amax);      // 8 workgroups per (pair, side): 32 atomics each
     hipLaunchKernelGGL(of_prep_kernel, dim3((unsigned)(ta > tb ? ta : tb), 2, n_seg), dim3(320), 0, s, A, B, amax, alpha);
     const dim3 gA((unsigned)((ta + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg), gB((unsigned)((tb + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg);
     const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);

@@ -192,11 +192,20 @@ def test_sinkhorn_recomputed_on_the_matrix_cores_equals_the_materialised_iterati
         want = MO.log_sinkhorn((s @ t.T).astype(np.float32), np.float32(1.5), iters)
         assert np.abs(Z.cpu().numpy() - want).max() < 1e-4 * max(1.0, np.abs(want).max() / 20), (q, iters)
         w0, w1, ws0, ws1 = MO.readout(want)
-        for name, (g0, g1, gs0) in (('recomputed', (a0, a1, as0)), ('materialised', (b0, b1, bs0))):
-            assert torch.equal(g0[o0:o0 + m], m0) and torch.equal(g1[o1:o1 + n], m1), (name, q, (m, n), iters, g0[o0:o0 + m].tolist(), m0.tolist())
-            assert float((gs0[o0:o0 + m] - s0).abs().max()) < 5e-5, (name, q, iters)
-            assert np.array_equal(g0[o0:o0 + m].cpu().numpy(), w0) and np.array_equal(g1[o1:o1 + n].cpu().numpy(), w1), (name, q, iters)
-            assert np.abs(gs0[o0:o0 + m].cpu().numpy() - ws0).max() < 5e-5, (name, q, iters)
+        # After ONE iteration a column's two best rows can tie to the last bit (the oracle itself then disagrees with a float64 evaluation):
+        # rows / columns are compared where the oracle's arg-max is decided by more than 1e-3 on both sides of the mutual check.
+        P = want[:m, :n]
+        gap = lambda A: (np.sort(A, 1)[:, -1] - np.sort(A, 1)[:, -2]) if A.shape[1] > 1 else np.full(A.shape[0], np.inf)
+        row_ok, col_ok = gap(P) > 1e-3, gap(P.T) > 1e-3
+        keep0 = row_ok & col_ok[P.argmax(1)]; keep1 = col_ok & row_ok[P.argmax(0)]
+        if iters != 1:
+            assert keep0.all() and keep1.all(), (q, iters)
+        for name, (g0, g1, gs0) in (('recomputed', (a0, a1, as0)), ('materialised', (b0, b1, bs0)), ('literal', (None, None, None))):
+            h0 = (m0 if g0 is None else g0[o0:o0 + m]).cpu().numpy(); h1 = (m1 if g1 is None else g1[o1:o1 + n]).cpu().numpy()
+            hs = (s0 if gs0 is None else gs0[o0:o0 + m]).cpu().numpy()
+            assert np.array_equal(h0[keep0], w0[keep0]) and np.array_equal(h1[keep1], w1[keep1]), (name, q, (m, n), iters, h0.tolist(), w0.tolist())
+            sure = keep0 & (h0 == w0)
+            assert np.abs(hs[sure] - ws0[sure]).max(initial=0.0) < 5e-5, (name, q, iters)
         o0 += m; o1 += n
 
 
