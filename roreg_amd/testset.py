@@ -21,16 +21,20 @@ def assemble_group_features(backbone, points, keypoints, group_dir=None):
     T = tables(group_dir)
     pts = np.asarray(points, np.float64)
     kps = np.asarray(keypoints, np.float64)
-    cols = []
+    # the 60 rotated keypoint sets in ONE upload (host float64 products rounded to float32 exactly as testset.py:80-81 does; 3.6 MB at 5000
+    # keypoints); the group feature is assembled in place on the device and downloaded once
+    kps_all = hip.upload(np.stack([(kps @ T.R[g].T).astype(np.float32) for g in range(60)]))            # [60,N,3]
+    out = None
     for g in range(60):
         xyz_g = (pts @ T.R[g].T).astype(np.float32)                      # testset.py:43
-        kps_g = torch.from_numpy((kps @ T.R[g].T).astype(np.float32)).cuda().contiguous()      # testset.py:80-81
-        xyz_down, feats = backbone(xyz_g)
-        xyz_down = torch.as_tensor(xyz_down, dtype=torch.float32).cuda().contiguous()
-        feats = torch.as_tensor(feats, dtype=torch.float32).cuda()
-        nn = hip.nn_search(kps_g, xyz_down)                               # nearest down-sampled point of every keypoint
-        cols.append(feats[nn])                                            # [N,F]
-    return torch.stack(cols, dim=-1).cpu().numpy()                        # [N,F,60]
+        xyz_down, feats = backbone(xyz_g)                                 # the plug-in decides where its outputs live; device tensors are used as they are
+        xyz_down = torch.as_tensor(xyz_down, dtype=torch.float32).to('cuda', non_blocking=True).contiguous()
+        feats = torch.as_tensor(feats, dtype=torch.float32).to('cuda', non_blocking=True)
+        if out is None:
+            out = torch.empty((kps.shape[0], feats.shape[1], 60), dtype=torch.float32, device='cuda')
+        nn = hip.nn_search(kps_all[g], xyz_down)                          # nearest down-sampled point of every keypoint (KNN(1), testset.py:170-172)
+        out[:, :, g] = feats[nn]                                          # [N,F] into group column g
+    return out.cpu().numpy()                                              # [N,F,60]
 
 
 def write_group_features(backbone, dataset, output_cache_fn, backbone_name='FCGF', group_dir=None):
