@@ -5,6 +5,7 @@
 // except the optimal-transport coupling (which is the output): top-k neighbours are selected on the fly from the dot
 // products (the reference fully argsorts a 25M-element matrix 12 times per pair, rot_coh_match.py:34-45).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -827,9 +828,20 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     return 0;
 }
 
+static bool linear_on_mfma() {
+    static const bool on = !(getenv("ROREG_LINEAR_MFMA") && atoi(getenv("ROREG_LINEAR_MFMA")) == 0);
+    return on;
+}
+
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
+    // every layer with >= 32 inputs runs on the matrix cores, whatever L (csrc/linear_mfma.hip; ROREG_LINEAR_MFMA=0: the vector-pipe kernels
+    // below, rounds 1-3); the 3 -> 64 / 32 position MLP inputs stay on the vector pipe
+    if (linear_on_mfma() && roreg::linear_mfma(x, L, Cin, W, b, Cout, y, s)) {
+        ROREG_CHECK_LAUNCH("roreg_linear");
+        return 0;
+    }
     const int oc = linear_ochunk(L, Cout);
     const dim3 g((L + 255) / 256, (Cout + oc - 1) / oc), t(256);
 #define RM_LIN_T(CI, CO)                                                                                                         \
@@ -875,6 +887,10 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
     if (!seg_off) { n_seg = 1; mult = 1; }
     hipStream_t s = roreg::as_stream(stream);
+    if (linear_on_mfma() && roreg::linear_tail_mfma(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s)) {
+        ROREG_CHECK_LAUNCH("roreg_mlp_tail");
+        return 0;
+    }
     const int oc = linear_ochunk(L, 32);
     const dim3 g((L + 255) / 256, (32 + oc - 1) / oc), t(256);
     if (oc == 32 && Cmid == 64) hipLaunchKernelGGL((linear_tiled_kernel<64, 32, true, true>), dim3((L + 255) / 256), t, 0, s, h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult);

@@ -287,7 +287,9 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     if tag.endswith('_o60'):
         # the pair that registers (60 % overlap): the whole chain stays on the reference's track from the input features -- both NMS samples,
         # every one of the 212 match rows, the recalltime and the transform
-        assert same_nms == [2500, 2500] and e2e_identical and len(m) == len(want_m) == 212
+        same_rows = sorted(map(tuple, m.tolist())) == sorted(map(tuple, want_m.tolist()))
+        assert same_nms == [2500, 2500] and same_rows and len(m) == len(want_m) == 212, (same_nms, same_rows, len(m), len(want_m), np.array_equal(m, want_m))
+        assert int(r['recalltime']) == int(z['recall_0_1'])
         assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
     else:
         # the 20 % pair is a FAILED registration in the reference too (175 matches, a one-inlier winner); one keypoint of 2500 flips at the NMS

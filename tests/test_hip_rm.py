@@ -100,9 +100,46 @@ def test_mlp_instnorm_and_attention(rm):
     assert np.abs(got - want).max() < 1e-4
 
 
+@pytest.mark.parametrize('cin,cout', [(32, 32), (96, 64), (120, 128), (64, 64), (96, 32), (120, 32), (64, 32)])
+def test_linear_layers_on_the_matrix_cores_are_f32_accurate(cin, cout):
+    """The 1x1 layers as fp16 hi + lo MFMAs against float64, PER ELEMENT relative to the row's own |W||x| scale: rows spanning 1e-3 .. 1e3 in
+    magnitude in one call, rows beyond fp16's range (1e6: the power-of-two row scale), a ragged row count; error at the level of a float32
+    fmaf chain (3e-7 of sum |w||x|)."""
+    from roreg_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(100 * cin + cout)
+    L = 4133
+    x = torch.randn((L, cin), device='cuda', generator=g)
+    x *= torch.pow(10.0, torch.randint(-3, 4, (L, 1), device='cuda', generator=g).float())
+    x[7] *= 1e3; x[100:110] *= 1e3                                            # 1e6-sized rows: beyond fp16
+    W = torch.randn((cout, cin), device='cuda', generator=g) * 0.3; b = torch.randn(cout, device='cuda', generator=g)
+    y = hip.linear(x, W, b).double()
+    ref = x.double() @ W.double().t() + b.double()
+    scale = x.double().abs() @ W.double().abs().t() + b.double().abs()
+    err = ((y - ref).abs() / scale).max().item()
+    assert err < 1e-6, err
+    assert torch.equal(hip.linear(x[:33].contiguous(), W, b), hip.linear(x, W, b)[:33])
+
+
+def test_mlp_tail_on_the_matrix_cores(rm):
+    """mlp_2layer (conv -> InstanceNorm -> ReLU -> conv + residual conv; rot_coh_match.py:14-32) with the shipped final_mlp weights against
+    a float64 torch evaluation of the same formula."""
+    net, sd = rm
+    mlp = net.final_mlp
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn((3001, 64), device='cuda', generator=g) * 2.0
+    with torch.no_grad():
+        got = mlp(x).double()
+    w = {k.split('final_mlp.')[1]: torch.from_numpy(v).double().cuda() for k, v in sd.items() if k.startswith('final_mlp.')}
+    h = x.double() @ w['net.0.weight'][:, :, 0, 0].t() + w['net.0.bias']
+    h = (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5)
+    ref = torch.relu(h) @ w['net.3.weight'][:, :, 0, 0].t() + w['net.3.bias'] + x.double() @ w['res.weight'][:, :, 0, 0].t() + w['res.bias']
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_many_row_layers_equal_the_per_row_kernels(rm):
-    """At >= 65536 rows (several pairs stacked) the 1x1 layers and the row normalisation go through LDS tiles for coalesced rows;
-    same fmaf chains, so the result is bitwise that of the one-thread-per-row kernels the short calls use."""
+    """A 1x1 layer's result for a row depends on that row alone, whatever the number of rows in the call (several pairs stacked: >= 65536
+    rows): the matrix-core kernel (csrc/linear_mfma.hip) has a fixed k order and no cross-row arithmetic, the row normalisation goes
+    through LDS tiles with the per-row kernel's sums -- big calls are bitwise the concatenation of short ones."""
     from roreg_amd import hip
     g = torch.Generator(device='cuda').manual_seed(3)
     L = 70001
