@@ -340,7 +340,8 @@ int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t 
                    float *ws, size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream);
 
 /* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
- * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119). */
+ * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119).  Layers with >= 32 inputs run on the matrix cores (fp16 hi + lo operands,
+ * f32 accumulate: float32-accurate; csrc/linear_mfma.hip), one kernel for every L: a row's result depends on that row alone. */
 int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
 
 /* InstanceNorm2d(affine=False) statistics of h [L,C] over all L positions -> mean_rstd [2C] = mean, 1/sqrt(var_biased+eps).

@@ -6,11 +6,13 @@
 // chain per (row, output) on the vector pipe: 16 TFLOP/s and 0.8 TB/s at 1.28 M x 96 -> 64, bound by neither (15 % of BASELINE configs[3]'s
 // path, profiles/r04_rd_rm_config_flash_kernel_trace.txt).  Here a wavefront owns 32 rows: their inputs are read once (32 B per lane and k
 // step: lane l holds row l % 32, k = 8 (l / 32) + e -- v_mfma_f32_32x32x16_f16's A fragment), normalised if asked, split into fp16 hi + lo
-// (22 bits; f32 accumulate; the three cross products of the GEMM kernels), and multiplied with the weight fragments the workgroup split
-// once into LDS.  A row's result depends on that row alone (fixed k order, no cross-row arithmetic, the optional power-of-two row scale is
-// taken from the row's own maximum): the same kernel serves every L, so a pair's result does not depend on how many pairs are stacked.
-// fp16 range: rows whose largest |input| reaches 2^13 are scaled down by an exact power of two (and the result back); smaller inputs are
-// used as they are -- gfx950's fp16 MFMA honours subnormal operands (tools/probe/mfma_f16_denorm.hip).
+// and multiplied with the weight fragments the workgroup split once into LDS: ALL FOUR cross products (hi.hi, hi.lo, lo.hi, lo.lo), f32
+// accumulate.  Every row is scaled by an exact power of two that puts its largest |input| in [2^13, 2^14) (the weights likewise, one
+// scale per tensor), so each operand keeps 22 bits relative to its row's / the tensor's maximum and the result is at the level of a
+// float32 fmaf chain (measured <= 5e-7 of sum |w||x| per element).  That level matters: the layers feed top-k neighbour selections, and a
+// coarser product (three cross products on unscaled rows: 1.2e-6) flipped one neighbour at keynum 2500 and moved the log-couplings by 2e-3.
+// A row's result depends on that row alone (fixed k order, no cross-row arithmetic, its own scale): the same kernel serves every L, so a
+// pair's result does not depend on how many pairs are stacked.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,6 +38,21 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
     extern __shared__ __attribute__((aligned(16))) char lm_smem[];
     f16x8 *wf = reinterpret_cast<f16x8 *>(lm_smem);                         // [2 planes][KS][NT][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // ---- the weights' power-of-two scale (one per tensor): max |W| -> [2^13, 2^14) ----
+    __shared__ float wmax_s[4];
+    float wm = 0.f;
+    for (int f = tid; f < CIN * COUT; f += 256) {
+        const float a = fabsf(W[f]);
+        if (a < __builtin_inff()) wm = fmaxf(wm, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+    if (lane == 0) wmax_s[w] = wm;
+    __syncthreads();
+    wm = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
+    int ew = 0;
+    if (wm > 0.f) { (void)frexpf(wm, &ew); ew = 14 - ew; }                  // wm 2^ew in [2^13, 2^14)
+    const float wscale = ldexpf(1.f, ew), wback = ldexpf(1.f, -ew);
     // ---- the workgroup's weight fragments, once: B fragment of (k step, output tile): lane l holds output l % 32, k = 16 ks + 8 (l / 32) + e ----
     for (int f = tid; f < KS * NT * 64; f += 256) {
         const int l = f & 63, nt = (f >> 6) % NT, ks = f / (64 * NT);
@@ -43,7 +60,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
         f16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = k0 + e < CIN ? W[(size_t)o * CIN + k0 + e] : 0.f;
+            const float v = k0 + e < CIN ? W[(size_t)o * CIN + k0 + e] * wscale : 0.f;
             const _Float16 h = (_Float16)v;
             hi[e] = h; lo[e] = (_Float16)(v - (float)h);
         }
@@ -80,13 +97,16 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[ks][e]));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));                                  // the row's maximum (its two k halves sit 32 lanes apart)
-        float down = 1.f, up = 1.f;
-        if (mx >= 8192.f && mx < __builtin_inff()) {                          // (non-finite rows: NaN / inf results either way)
+        float down = 1.f, up = wback;
+        if (mx > 0.f && mx < __builtin_inff()) {                              // (all-zero rows need no scale; non-finite rows: NaN / inf results either way)
             int ex;
             (void)frexpf(mx, &ex);                                            // mx = f 2^ex, f in [0.5, 1)
-            down = ldexpf(1.f, 13 - ex); up = ldexpf(1.f, ex - 13);
+            ex = ex < -100 ? -100 : ex;                                       // (denormal-sized rows: keep the factors finite)
+            down = ldexpf(1.f, 14 - ex); up = ldexpf(wback, ex - 14);
         }
-        const bool any_scaled = __ballot(down != 1.f) != 0ull;
+        float upr[16];                                                        // the factor of each accumulator register's row (lane rr holds row rr's)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) upr[r] = __shfl(up, 8 * (r >> 2) + 4 * kg + (r & 3));
         f16x8 ah[KS], al[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -103,6 +123,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const f16x8 bh = wf[(size_t)(ks * NT + nt) * 64 + lane], bl = wf[(size_t)((KS + ks) * NT + nt) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc, 0, 0, 0);
@@ -113,9 +134,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = 8 * (r >> 2) + 4 * kg + (r & 3);
-                float val = acc[r];
-                if (any_scaled) val *= __shfl(up, rr);                       // (wave-uniform branch; the row's factor lives in lane rr)
-                val += bias;
+                const float val = acc[r] * upr[r] + bias;                   // exact power-of-two rescale, then the bias
                 if (row0 + rr < L) {
                     float *yo = y + (size_t)(row0 + rr) * COUT + o;
                     *yo = ACCUM ? *yo + val : val;

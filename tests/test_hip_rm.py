@@ -104,7 +104,7 @@ def test_mlp_instnorm_and_attention(rm):
 def test_linear_layers_on_the_matrix_cores_are_f32_accurate(cin, cout):
     """The 1x1 layers as fp16 hi + lo MFMAs against float64, PER ELEMENT relative to the row's own |W||x| scale: rows spanning 1e-3 .. 1e3 in
     magnitude in one call, rows beyond fp16's range (1e6: the power-of-two row scale), a ragged row count; error at the level of a float32
-    fmaf chain (3e-7 of sum |w||x|)."""
+    fmaf chain (<= 6e-7 of sum |w||x| per element)."""
     from roreg_amd import hip
     g = torch.Generator(device='cuda').manual_seed(100 * cin + cout)
     L = 4133
@@ -116,7 +116,7 @@ def test_linear_layers_on_the_matrix_cores_are_f32_accurate(cin, cout):
     ref = x.double() @ W.double().t() + b.double()
     scale = x.double().abs() @ W.double().abs().t() + b.double().abs()
     err = ((y - ref).abs() / scale).max().item()
-    assert err < 1e-6, err
+    assert err < 6e-7, err
     assert torch.equal(hip.linear(x[:33].contiguous(), W, b), hip.linear(x, W, b)[:33])
 
 
