@@ -340,9 +340,12 @@ int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t 
                    float *ws, size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream);
 
 /* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
- * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119).  Layers with >= 32 inputs run on the matrix cores (fp16 hi + lo operands,
- * f32 accumulate: float32-accurate; csrc/linear_mfma.hip), one kernel for every L: a row's result depends on that row alone. */
+ * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119): one float32 fmaf chain per (row, output), inputs ascending, starting from the bias. */
 int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
+/* v4: the same layer on the matrix cores for Cin >= 32 (other shapes: roreg_linear): fp16 hi + lo operands under exact per-row / per-tensor
+ * power-of-two scales, all four cross products, f32 accumulate (<= 6e-7 of sum |w||x| per element: the level of the fmaf chain, other
+ * rounding); one kernel for every L, a row's result depends on that row alone.  csrc/linear_mfma.hip; used by the stacked matcher. */
+int roreg_linear_mfma(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
 
 /* InstanceNorm2d(affine=False) statistics of h [L,C] over all L positions -> mean_rstd [2C] = mean, 1/sqrt(var_biased+eps).
  * ws: 2*C*256 doubles.  (rot_coh_match.py:19,68)   With segments (seg_off in points, `mult` rows of h per point): one statistic
@@ -353,6 +356,9 @@ int roreg_instnorm_stats(const float *h, int L, int C, float eps, float *mean_rs
 /* y [L,32] += W2 relu((h - mean) * rstd) + b2  (closing conv of mlp_2layer / Contextnorm; y already holds the residual conv);
  * with segments every row uses the statistics of its pair. */
 int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2 /* [32,Cmid] */, const float *b2,
+                   float *y, const int32_t *seg_off, int n_seg, int mult, void *stream);
+/* v4: roreg_mlp_tail on the matrix cores (as roreg_linear_mfma; the normalisation + ReLU are applied while the operand is split). */
+int roreg_mlp_tail_mfma(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2 /* [32,Cmid] */, const float *b2,
                    float *y, const int32_t *seg_off, int n_seg, int mult, void *stream);
 
 /* ctx [L,120] = [R [L,60] | max over the points of the row's pair of R]  (Self_attention_block's ambiguity context,

@@ -828,20 +828,34 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     return 0;
 }
 
-static bool linear_on_mfma() {
-    static const bool on = !(getenv("ROREG_LINEAR_MFMA") && atoi(getenv("ROREG_LINEAR_MFMA")) == 0);
-    return on;
+// The same layers on the matrix cores (csrc/linear_mfma.hip): layers with >= 32 inputs; the 3 -> 64 / 32 position-MLP inputs fall through to
+// the vector-pipe kernel.
+extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream);
+extern "C" int roreg_linear_mfma(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
+    ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear_mfma: bad arguments");
+    if (roreg::linear_mfma(x, L, Cin, W, b, Cout, y, roreg::as_stream(stream))) {
+        ROREG_CHECK_LAUNCH("roreg_linear_mfma");
+        return 0;
+    }
+    return roreg_linear(x, L, Cin, W, b, Cout, y, stream);
+}
+
+extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y,
+                              const int32_t *seg_off, int n_seg, int mult, void *stream);
+extern "C" int roreg_mlp_tail_mfma(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y,
+                                   const int32_t *seg_off, int n_seg, int mult, void *stream) {
+    ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail_mfma: bad arguments");
+    if (!seg_off) { n_seg = 1; mult = 1; }
+    if (roreg::linear_tail_mfma(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, roreg::as_stream(stream))) {
+        ROREG_CHECK_LAUNCH("roreg_mlp_tail_mfma");
+        return 0;
+    }
+    return roreg_mlp_tail(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, stream);
 }
 
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
-    // every layer with >= 32 inputs runs on the matrix cores, whatever L (csrc/linear_mfma.hip; ROREG_LINEAR_MFMA=0: the vector-pipe kernels
-    // below, rounds 1-3); the 3 -> 64 / 32 position MLP inputs stay on the vector pipe
-    if (linear_on_mfma() && roreg::linear_mfma(x, L, Cin, W, b, Cout, y, s)) {
-        ROREG_CHECK_LAUNCH("roreg_linear");
-        return 0;
-    }
     const int oc = linear_ochunk(L, Cout);
     const dim3 g((L + 255) / 256, (Cout + oc - 1) / oc), t(256);
 #define RM_LIN_T(CI, CO)                                                                                                         \
@@ -887,10 +901,6 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
     if (!seg_off) { n_seg = 1; mult = 1; }
     hipStream_t s = roreg::as_stream(stream);
-    if (linear_on_mfma() && roreg::linear_tail_mfma(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s)) {
-        ROREG_CHECK_LAUNCH("roreg_mlp_tail");
-        return 0;
-    }
     const int oc = linear_ochunk(L, 32);
     const dim3 g((L + 255) / 256, (32 + oc - 1) / oc), t(256);
     if (oc == 32 && Cmid == 64) hipLaunchKernelGGL((linear_tiled_kernel<64, 32, true, true>), dim3((L + 255) / 256), t, 0, s, h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult);

@@ -97,8 +97,10 @@ PROTOTYPES = {
     'roreg_sinkhorn_batch2_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong]),
     'roreg_sinkhorn_batch2': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'roreg_linear': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
+    'roreg_linear_mfma': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_instnorm_stats': (c_int, [_P, c_int, c_int, c_float, _P, _P, _P, c_int, c_int, _P]),
     'roreg_mlp_tail': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'roreg_mlp_tail_mfma': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'roreg_knn_attention': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'roreg_rm_elementwise': (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     'roreg_sinkhorn_workspace_size': (c_size_t, [c_int, c_int]),
@@ -944,12 +946,37 @@ def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
     return (idx, val) if want_val else idx
 
 
+# The matcher's 1x1 layers: False = one float32 fmaf chain per (row, output) on the vector pipe (Match_ot.forward(): the arithmetic that keeps the
+# log-couplings within 1e-4 of the reference's at keynum 2500 -- a different rounding, equally accurate, flips a top-k neighbour on that fixture);
+# True = fp16 hi + lo MFMAs (csrc/linear_mfma.hip; the stacked matcher, which returns matches and scores only).  Set by matrix_core_layers().
+LINEAR_MFMA = False
+
+
+class matrix_core_layers:
+    """`with hip.matrix_core_layers():` -- linear() / mlp_instnorm() inside the block run on the matrix cores."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global LINEAR_MFMA
+        self.prev = LINEAR_MFMA
+        LINEAR_MFMA = self.on
+        return self
+
+    def __exit__(self, *exc):
+        global LINEAR_MFMA
+        LINEAR_MFMA = self.prev
+        return False
+
+
 def linear(x, W, b):
     """x [L,Cin] -> [L,Cout]; W [Cout,Cin], b [Cout] device float32."""
     L, Cin = x.shape
     Cout = W.shape[0]
     y = torch.empty((L, Cout), dtype=torch.float32, device=x.device)
-    _check(lib().roreg_linear(_ptr(x, torch.float32), L, Cin, _ptr(W, torch.float32), _ptr(b, torch.float32), Cout, _ptr(y), _stream()), 'roreg_linear')
+    fn = lib().roreg_linear_mfma if LINEAR_MFMA else lib().roreg_linear
+    _check(fn(_ptr(x, torch.float32), L, Cin, _ptr(W, torch.float32), _ptr(b, torch.float32), Cout, _ptr(y), _stream()), 'roreg_linear')
     return y
 
 
@@ -968,7 +995,8 @@ def mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=1e-5, seg=None):
     ws = torch.empty(n_seg * 2 * C * 256, dtype=torch.float64, device=x.device)
     _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), *sg, _stream()), 'roreg_instnorm_stats')
     y = linear(x, Wr, br)
-    _check(lib().roreg_mlp_tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), *sg, _stream()), 'roreg_mlp_tail')
+    tail = lib().roreg_mlp_tail_mfma if LINEAR_MFMA else lib().roreg_mlp_tail
+    _check(tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), *sg, _stream()), 'roreg_mlp_tail')
     return y
 
 

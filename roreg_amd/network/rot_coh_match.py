@@ -9,6 +9,7 @@ forward(batch) with feats0 [1,m,32,60], feats1 [1,n,32,60], keys0 [1,m,3], keys1
 scores [1,m+1,n+1], matches0 [1,m], matches1 [1,n] (int64, -1 = unmatched), matching_scores0/1, source_final /
 target_final [1,32,m,1]; 'scores_other' (training-only supervision, never read at test time, rot_coh_match.py:355-358)
 is computed on demand."""
+import os
 from copy import deepcopy
 
 import torch
@@ -198,17 +199,19 @@ class Match_ot(nn.Module):
     def match_stacked(self, source_eqv, target_eqv, source_keys, target_keys, seg_s, seg_t):
         """match_many on already stacked tensors: the pairs' points are concatenated (hip.Segments seg_s / seg_t give the row ranges);
         every per-pair operation of the graph (neighbour search, InstanceNorm statistics, the context maximum, Sinkhorn) is
-        segmented.  The network part is the arithmetic of forward() bit for bit; the stacked Sinkhorn reads the coupling matrix once per
-        iteration and associates the column sums differently (include/roreg_hip.h: matches identical, scores to rounding; a column whose
-        couplings all underflow in that pass is evaluated exactly in the log domain, like forward() does for every column)."""
+        segmented.  This is the throughput path: the 1x1 layers run on the matrix cores (hip.matrix_core_layers: float32-accurate, another
+        rounding than forward()'s fmaf chains; ROREG_LINEAR_MFMA=0 keeps forward()'s kernels) and the Sinkhorn iterations recompute the scores
+        instead of reading a coupling matrix (hip.sinkhorn_batch).  A pair's result does not depend on which pairs are stacked beside it.
+        Against forward() pair by pair: matches identical on the tests (incl. the reference's keynum-2500 golden), scores to 2e-5."""
         source_eqv = source_eqv.contiguous(); target_eqv = target_eqv.contiguous()
         source_coor = (source_keys / self.coor_norm_step).contiguous()
         target_coor = (target_keys / self.coor_norm_step).contiguous()
         source_inv = hip.mean_over_group(source_eqv)
         target_inv = hip.mean_over_group(target_eqv)
-        sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t)
-        source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]), seg=seg_s)
-        target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]), seg=seg_t)
+        with hip.matrix_core_layers(os.environ.get('ROREG_LINEAR_MFMA', '1') != '0'):
+            sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t)
+            source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]), seg=seg_s)
+            target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]), seg=seg_t)
         m0, _, s0, _ = hip.sinkhorn_batch(source_final, target_final, seg_s, seg_t, self._alpha_value(), self.ot_layer.iters)
         o = seg_s.host
         return [(m0[o[i]:o[i + 1]], s0[o[i]:o[i + 1]]) for i in range(seg_s.n)]
