@@ -35,6 +35,7 @@ constexpr int OF_PLANES = 5;              // fragment planes of a 32-row tile: h
 constexpr int OF_TILE_HALFS = OF_PLANES * 64 * 8;
 constexpr float OF_PAD = -60000.0f;       // potential of a padding row / column (fp16-representable; 2^-60000 = 0)
 constexpr float OF_LO_SCALE = 4096.0f;    // third pieces travel as x 2^12 against a 2^-12 slot: never an fp16 subnormal
+constexpr int OF_CHT = 16;                // column tiles per chunk (512 columns): the unit of a row's partial sums
 constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
 
 struct Side {                             // one side (source rows or target columns) of one pass
@@ -166,8 +167,7 @@ __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
     const int tilesA = lenA / 32 + 1, tilesB = lenB / 32 + 1;              // (len + 1 rows: the dustbin)
     const int tA0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (tA0 >= tilesA) return;
-    const int cht = (tilesB + nch - 1) / nch;
-    const int tb0 = chunk * cht, tb1 = min(tb0 + cht, tilesB);
+    const int tb0 = chunk * OF_CHT, tb1 = min(tb0 + OF_CHT, tilesB);          // chunks of a FIXED number of column tiles: a pair's sums associate the same way whatever is stacked beside it
     const f16x8 *fb = reinterpret_cast<const f16x8 *>(b.frag + pair * b.frag_stride) + lane;
     f16x8 A[R][OF_PLANES];
 #pragma unroll
@@ -270,15 +270,16 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i > lenA) return;
     const float *part = a.part + pair * (a.pot_stride * nch) + i;
+    const int nch_pair = ((b.seg[pair + 1] - b.seg[pair]) / 32 + 1 + OF_CHT - 1) / OF_CHT;      // the chunks this pair's other side really has
     float *pot = a.pot + pair * a.pot_stride;
     float np;
     if (MAXP) {
         float mx = -__builtin_inff();
-        for (int c = 0; c < nch; ++c) mx = fmaxf(mx, part[(size_t)c * a.pot_stride]);
+        for (int c = 0; c < nch_pair; ++c) mx = fmaxf(mx, part[(size_t)c * a.pot_stride]);
         np = mx > -__builtin_inff() && mx < __builtin_inff() ? -mx : 0.f;
     } else {
         float S = 0.f;
-        for (int c = 0; c < nch; ++c) S += part[(size_t)c * a.pot_stride];
+        for (int c = 0; c < nch_pair; ++c) S += part[(size_t)c * a.pot_stride];
         const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
         if (S > 1e-35f && S < 1e35f) {
             np = pot[i] + (lmu - __log2f(S));
@@ -330,23 +331,18 @@ namespace roreg {
 
 constexpr int OF_R = 2;                                // row tiles per wave
 
-// Column chunks per row block: enough workgroups for ~4 waves per SIMD in ONE residency (1024 SIMDs), no more -- a wave that owns only a few
-// column tiles spends its life starting up.  ROREG_OT_NCH overrides (measurements).
-static int ot_flash_chunks(int n_seg, int max_m, int max_n) {
-    static const int forced = getenv("ROREG_OT_NCH") ? atoi(getenv("ROREG_OT_NCH")) : 0;
-    const int ta = (max_m / 32 + 1 + 4 * OF_R - 1) / (4 * OF_R), tb = (max_n / 32 + 1 + 4 * OF_R - 1) / (4 * OF_R);
-    const int wg = (ta < tb ? ta : tb) * n_seg;
-    int nch = forced > 0 ? forced : (1024 + wg - 1) / wg;
-    const int tiles = (max_m < max_n ? max_m : max_n) / 32 + 1;
-    if (nch > tiles) nch = tiles;
-    if (nch > 8) nch = 8;
-    return nch < 1 ? 1 : nch;
+// Column chunks per row block: ceil(tiles / OF_CHT) of the larger side -- fixed by the pair sizes alone (a wave that owns only a few column
+// tiles spends its life starting up; 16 tiles per chunk and two row tiles per wave gave the best time on 30 stacked 2500-point pairs).
+static int ot_flash_chunks(int max_m, int max_n) {
+    const int tiles = (max_m > max_n ? max_m : max_n) / 32 + 1;
+    return (tiles + OF_CHT - 1) / OF_CHT;
 }
 
 // bytes of workspace of ot_flash_iterations (16-byte aligned pieces): per pair the two sides' fragments, potentials and chunk partials
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
     const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
-    const size_t per_pair = (ta + tb) * OF_TILE_HALFS * sizeof(_Float16) + (ta + tb) * 32 * sizeof(float) * (1 + 8);
+    const size_t nch = ot_flash_chunks(max_m, max_n);
+    const size_t per_pair = (ta + tb) * OF_TILE_HALFS * sizeof(_Float16) + (ta + tb) * 32 * sizeof(float) * (1 + nch);
     return (size_t)n_seg * per_pair + round_up((size_t)n_seg * 2 * sizeof(unsigned), 16) + 256;
 }
 
@@ -355,7 +351,7 @@ size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
 int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
                         int max_m, int max_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s) {
     const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
-    const int nch = ot_flash_chunks(n_seg, max_m, max_n);
+    const int nch = ot_flash_chunks(max_m, max_n);
     char *p = reinterpret_cast<char *>(ws);
     p = reinterpret_cast<char *>(round_up(reinterpret_cast<uintptr_t>(p), 16));
     Side A, B;
@@ -367,8 +363,8 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     B.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * B.frag_stride * sizeof(_Float16);
     A.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * sizeof(float);
     B.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * sizeof(float);
-    A.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * 8 * sizeof(float);
-    B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * 8 * sizeof(float);
+    A.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * nch * sizeof(float);
+    B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * nch * sizeof(float);
     unsigned *amax = reinterpret_cast<unsigned *>(p);
     (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
     hipLaunchKernelGGL(of_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, amax);      // 8 workgroups per (pair, side): 32 atomics each
