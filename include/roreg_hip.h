@@ -188,6 +188,13 @@ int roreg_des2r(const float *feats1, const int64_t *rows1, const float *feats0, 
 int roreg_group_corr(const float *perm_feats, const int64_t *perm_rows, const float *bcast_feats, const int64_t *bcast_rows,
                      int M, int transpose_table, int64_t *idx_out, float *cor_out, void *stream);
 
+/* v4: all 60 correlations of roreg_group_corr as ONE [60 x 32] . [32 x 60] float32 matrix product per point on the matrix cores (C[p,g] = sum_f
+ * A[f,p] B[f,g]) + the 60 coset sums cor[a] = sum_g C[T[a,g], g]: the permutation addresses the result instead of every multiply-add
+ * (csrc/corr_mfma.hip; HBM-bound instead of LDS-bound).  The literal kernel's function in another summation order (float32 throughout,
+ * ~1e-6 |A||B| apart): for the correlation as a FEATURE (the stacked matcher's R_indicator); no arg-max. */
+int roreg_group_corr_mfma(const float *perm_feats, const int64_t *perm_rows, const float *bcast_feats, const int64_t *bcast_rows, int M,
+                          int transpose_table, float *cor_out, void *stream);
+
 /* The same arg-max (test/estimator.py:85-89, bit for bit) with 10x fewer operations: the 60 correlations are first BOUNDED in the irrep
  * domain of the icosahedral group -- cor[a] = sum_rho sum_ij rho(a)[j][i] (sum_f X2_f(rho) X1_f(rho)^T)[i][j], sum_d d^3 = 244
  * multiply-adds per channel instead of 3600, from per-keypoint coefficients computed once per cloud (roreg_feat_coefs) -- and only the

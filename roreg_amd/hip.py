@@ -73,6 +73,7 @@ PROTOTYPES = {
     'roreg_des2r': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
     'roreg_set_des2r_tables': (c_int, [c_int, _P, _P, _P, _P]),
     'roreg_group_corr_irrep': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    'roreg_group_corr_mfma': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     'roreg_des2r_irrep': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     'roreg_des2r_recheck_count': (c_int, [c_int, _P]),
     'roreg_feat_coefs': (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
@@ -908,6 +909,10 @@ def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpo
                                             _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(cor), _stream()), 'roreg_group_corr_irrep')
         return cor
     cor = torch.empty((M, 60), dtype=torch.float32, device=perm_feats.device)
+    if LINEAR_MFMA and not want_idx:             # (inside matrix_core_layers(): the stacked matcher) one 60 x 32 x 60 product per point + coset sums
+        _check(lib().roreg_group_corr_mfma(_ptr(perm_feats, torch.float32), _ptr(perm_rows, torch.int64), _ptr(bcast_feats, torch.float32),
+                                           _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(cor), _stream()), 'roreg_group_corr_mfma')
+        return cor
     idx = torch.empty(M, dtype=torch.int64, device=perm_feats.device) if want_idx else None
     _check(lib().roreg_group_corr(_ptr(perm_feats, torch.float32), _ptr(perm_rows, torch.int64), _ptr(bcast_feats, torch.float32),
                                   _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(idx), _ptr(cor), _stream()), 'roreg_group_corr')
