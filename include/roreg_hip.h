@@ -345,12 +345,6 @@ int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int wid
 size_t roreg_topk_dot_workspace_size(int m, int n, int k);
 int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t *idx_out, float *val_out /* optional [m,k] */,
                    float *ws, size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream);
-/* v4: roreg_topk_dot with the 32-wide dot products on the matrix cores: fp16 hi + lo operands under one exact power-of-two scale per pair and
- * side, all four cross products, f32 accumulate (<= 6e-7 of sum |a||b| per score: the level of the float32 fmaf chain, another rounding),
- * each source's sorted k-list spread over the lanes of a half-wave (an insertion is a ballot and a one-lane shift), exact ties in index order.  The stacked matcher's neighbour search.  ws: roreg_topk_dot_mfma_workspace_size floats. */
-size_t roreg_topk_dot_mfma_workspace_size(int m, int n, int k, int n_seg, int max_m, int max_n);
-int roreg_topk_dot_mfma(const float *A, int m, const float *B, int n, int k, int64_t *idx_out, float *val_out /* optional [m,k] */,
-                        float *ws, size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream);
 
 /* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
  * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119): one float32 fmaf chain per (row, output), inputs ascending, starting from the bias. */

@@ -86,153 +86,6 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 }
 
-// ---- the same search on the matrix cores (round 4) --------------------------------------------------------------------------------------
-// The vector-pipe kernel above spends 32 fmas per (source, target) pair: 0.19 of the f32 vector peak, 5 % of BASELINE configs[3]'s path.  Here
-// the scores of a 32 x 32 (source x target) tile come out of 8 fp16 MFMAs (hi + lo operands under one power-of-two scale per pair and side,
-// all four cross products, f32 accumulate: the float32-accurate product of csrc/linear_mfma.hip).  The selection is the other half of the
-// story: with one sorted list per LANE (64 sources per wavefront) almost every candidate makes some lane insert, so the whole wave walks the
-// k-deep insertion for nearly every candidate -- in the kernel above and in a first matrix-core version alike (k = 16: 594 us vs 358 us,
-// NOTES.md).  Here a source's list is spread over the 32 LANES of a half-wave (entry t in lane t) and accumulator register r of a half-wave
-// holds the 32 scores of ONE source: one compare + ballot per register tests 2 x 32 candidates against their sources' thresholds, and an
-// insertion is a ballot / popcount for the position and a one-lane shift -- a dozen instructions, executed only for candidates that really
-// enter a list (K ln(n / K) per source).  Same partial-list layout and merge kernel as above.
-// Another rounding of the same products (<= 6e-7 of sum |a||b|): the stacked matcher's search; exact ties (duplicated points) keep index order.
-typedef float tk_f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 tk_f16x8 __attribute__((ext_vector_type(8)));
-constexpr int TK_PLANES = 4;                       // hi k0-15, hi k16-31, lo k0-15, lo k16-31
-constexpr int TK_TILE_HALFS = TK_PLANES * 64 * 8;
-
-__global__ __launch_bounds__(256) void tk_absmax_kernel(const float *__restrict__ A, const float *__restrict__ B, const int *__restrict__ segA,
-                                                        const int *__restrict__ segB, int m, int n, unsigned *__restrict__ amax) {
-    const int pair = blockIdx.y >> 1, side = blockIdx.y & 1;
-    const int *seg = side ? segB : segA;
-    const int r0 = seg ? seg[pair] : 0, len = seg ? seg[pair + 1] - r0 : (side ? n : m);
-    const float4 *src = reinterpret_cast<const float4 *>((side ? B : A) + (size_t)r0 * RM_F);
-    float v = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < len * (RM_F / 4); i += gridDim.x * 256) {
-        const float4 x = src[i];
-        const float m4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
-        if (m4 < __builtin_inff()) v = fmaxf(v, m4);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(&amax[pair * 2 + side], __float_as_uint(v));
-}
-
-__device__ __forceinline__ int tk_scale_exp(unsigned bits) {                   // e with max 2^e in [2^13, 2^14); 0 for an all-zero / non-finite side
-    const float mx = __uint_as_float(bits);
-    if (!(mx > 0.f) || !(mx < __builtin_inff())) return 0;
-    int ex;
-    (void)frexpf(mx, &ex);
-    return 14 - ex;
-}
-
-// fragments of v_mfma_f32_32x32x16_f16 (A and B alike): lane l carries row l % 32, k = 8 (l / 32) + e; one workgroup per (tile, side, pair)
-__global__ __launch_bounds__(256) void tk_prep_kernel(const float *__restrict__ A, const float *__restrict__ B, const int *__restrict__ segA,
-                                                      const int *__restrict__ segB, int m, int n, const unsigned *__restrict__ amax,
-                                                      _Float16 *__restrict__ fragA, _Float16 *__restrict__ fragB, size_t strideA, size_t strideB) {
-    const int pair = blockIdx.z, side = blockIdx.y, t = blockIdx.x;
-    const int *seg = side ? segB : segA;
-    const int r0 = seg ? seg[pair] : 0, len = seg ? seg[pair + 1] - r0 : (side ? n : m);
-    if (t * 32 >= len) return;
-    const float *X = (side ? B : A) + (size_t)r0 * RM_F;
-    const int p = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int i = t * 32 + (l & 31), k0 = (p & 1) * 16 + (l >> 5) * 8;
-    const float c = ldexpf(1.f, tk_scale_exp(amax[pair * 2 + side]));
-    tk_f16x8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = i < len ? X[(size_t)i * RM_F + k0 + e] * c : 0.f;
-        const _Float16 h = (_Float16)x;
-        out[e] = p < 2 ? h : (_Float16)(x - (float)h);
-    }
-    _Float16 *dst = (side ? fragB + pair * strideB : fragA + pair * strideA);
-    *reinterpret_cast<tk_f16x8 *>(dst + ((size_t)(t * TK_PLANES + p) * 64 + l) * 8) = out;
-}
-
-template <int K>
-__global__ __launch_bounds__(256) void topk_mfma_kernel(const _Float16 *__restrict__ fragA, const _Float16 *__restrict__ fragB, size_t strideA,
-                                                        size_t strideB, const int *__restrict__ segA, const int *__restrict__ segB, int m, int n,
-                                                        int slices, const unsigned *__restrict__ amax, float *__restrict__ pv, int *__restrict__ pi) {
-    static_assert(K <= 32, "a list lives in the 32 lanes of a half-wave");
-    const int pair = blockIdx.z;
-    const int a0 = segA ? segA[pair] : 0, mp = segA ? segA[pair + 1] - a0 : m;
-    const int b0 = segA ? segB[pair] : 0, np_ = segA ? segB[pair + 1] - b0 : n;
-    const int lane = threadIdx.x & 63, kh = lane >> 5, t = lane & 31;
-    const int tA = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tA * 32 >= mp || np_ <= 0) return;
-    const int tilesB = (np_ + 31) / 32;
-    const int tps = (tilesB + slices - 1) / slices;                         // target tiles per slice
-    const int tb0 = blockIdx.y * tps, tb1 = min(tb0 + tps, tilesB);
-    const tk_f16x8 *fa = reinterpret_cast<const tk_f16x8 *>(fragA + pair * strideA) + (size_t)tA * TK_PLANES * 64 + lane;
-    const tk_f16x8 *fb = reinterpret_cast<const tk_f16x8 *>(fragB + pair * strideB) + lane;
-    tk_f16x8 S[TK_PLANES];
-#pragma unroll
-    for (int p = 0; p < TK_PLANES; ++p) S[p] = fa[p * 64];
-    // list r of this half-wave = the K best of source 8 (r / 4) + 4 kh + r % 4 of the tile: entry t in lane t (t < K), thr = entry K - 1
-    float lv[16], thr[16];
-    int li[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { lv[r] = -__builtin_inff(); li[r] = 0x7fffffff; thr[r] = -__builtin_inff(); }
-    tk_f16x8 T[TK_PLANES], Tn[TK_PLANES];
-    if (tb0 < tb1) {
-#pragma unroll
-        for (int p = 0; p < TK_PLANES; ++p) T[p] = fb[((size_t)tb0 * TK_PLANES + p) * 64];
-    }
-    for (int tb = tb0; tb < tb1; ++tb) {
-        const int tn = tb + 1 < tb1 ? tb + 1 : tb;
-#pragma unroll
-        for (int p = 0; p < TK_PLANES; ++p) Tn[p] = fb[((size_t)tn * TK_PLANES + p) * 64];
-        tk_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // rows = sources (A operand), columns = targets (B operand): register r of a half-wave = 32 targets of ONE source
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[2], T[2], acc, 0, 0, 0);      // lo . lo
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[3], T[3], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[2], T[0], acc, 0, 0, 0);      // lo . hi
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[3], T[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[0], T[2], acc, 0, 0, 0);      // hi . lo
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[1], T[3], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[0], T[0], acc, 0, 0, 0);      // hi . hi
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(S[1], T[1], acc, 0, 0, 0);
-        const bool valid = tb * 32 + t < np_;                               // (the last tile's padding columns never enter a list)
-        const int jbase = b0 + tb * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = valid ? acc[r] : -__builtin_inff();
-            unsigned long long cand = __ballot(v > thr[r]);
-            while (cand) {                                                  // ascending lane = ascending target index within a half
-                const int bl = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                const int hb = bl >> 5;
-                const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), bl));
-                const float ct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr[r]), hb * 32));
-                if (!(cv > ct)) continue;                                   // an earlier insertion of this round raised the threshold
-                const int cj = jbase + (bl & 31);
-                const bool mine = kh == hb;
-                const int pos = __popcll(__ballot(mine && (lv[r] > cv || (lv[r] == cv && li[r] < cj))));     // entries that stay ahead
-                const float up_v = __shfl_up(lv[r], 1);
-                const int up_i = __shfl_up(li[r], 1);
-                if (mine && t > pos && t < K) { lv[r] = up_v; li[r] = up_i; }
-                if (mine && t == pos) { lv[r] = cv; li[r] = cj; }
-                const float nt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv[r]), hb * 32 + K - 1));
-                if (mine) thr[r] = nt;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < TK_PLANES; ++p) T[p] = Tn[p];
-    }
-    if (t < K) {
-        const float back = ldexpf(1.f, -(tk_scale_exp(amax[pair * 2]) + tk_scale_exp(amax[pair * 2 + 1])));      // exact: powers of two
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = tA * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-            if (i < mp) {
-                pv[((size_t)blockIdx.y * m + a0 + i) * K + t] = lv[r] * back;
-                pi[((size_t)blockIdx.y * m + a0 + i) * K + t] = li[r];
-            }
-        }
-    }
-}
-
 // segment of row r in offsets off[0..n_seg] (off[n_seg] = total): the last s with off[s] <= r
 __device__ __forceinline__ int seg_of(const int *__restrict__ off, int n_seg, int r) {
     int lo = 0, hi = n_seg - 1;
@@ -978,56 +831,6 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
 // The same layers on the matrix cores (csrc/linear_mfma.hip): layers with >= 32 inputs; the 3 -> 64 / 32 position-MLP inputs fall through to
 // the vector-pipe kernel.
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream);
-static int topk_mfma_slices(int n_seg, int max_m, int max_n) {
-    const int wgs = ((max_m + 31) / 32 + 3) / 4 * n_seg;
-    int slices = (1024 + wgs - 1) / wgs;                                     // ~4 workgroups per CU
-    const int tiles = (max_n + 31) / 32;
-    if (slices > tiles) slices = tiles;
-    if (slices > 16) slices = 16;
-    return slices < 1 ? 1 : slices;
-}
-
-extern "C" size_t roreg_topk_dot_mfma_workspace_size(int m, int n, int k, int n_seg, int max_m, int max_n) {
-    if (n_seg < 1) { n_seg = 1; max_m = m; max_n = n; }
-    const size_t lists = (size_t)16 * m * k * 2;                            // partial lists of up to 16 slices: floats + ints
-    const size_t frags = (size_t)n_seg * (((size_t)max_m + 31) / 32 + ((size_t)max_n + 31) / 32) * TK_TILE_HALFS / 2;     // halfs -> floats
-    return lists + frags + (size_t)2 * n_seg + 64;
-}
-
-extern "C" int roreg_topk_dot_mfma(const float *A, int m, const float *B, int n, int k, int64_t *idx_out, float *val_out, float *ws,
-                                   size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream) {
-    ROREG_REQUIRE(A && B && idx_out && ws && m > 0 && n > 0, "roreg_topk_dot_mfma: bad arguments");
-    ROREG_REQUIRE(k == 16 || k == 8 || k == 1, "roreg_topk_dot_mfma: k must be 16, 8 or 1 (got %d)", k);
-    ROREG_REQUIRE((segA == nullptr) == (segB == nullptr), "roreg_topk_dot_mfma: both segment tables or none");
-    if (!segA) { n_seg = 1; max_m = m; max_n = n; }
-    ROREG_REQUIRE(n_seg > 0 && max_m > 0 && max_n > 0 && max_m <= m && max_n <= n, "roreg_topk_dot_mfma: bad segment description");
-    ROREG_REQUIRE(segA || k <= n, "roreg_topk_dot_mfma: k > n");
-    ROREG_REQUIRE(ws_floats >= roreg_topk_dot_mfma_workspace_size(m, n, k, n_seg, max_m, max_n), "roreg_topk_dot_mfma: workspace too small");
-    const int slices = topk_mfma_slices(n_seg, max_m, max_n);
-    const size_t tA = ((size_t)max_m + 31) / 32, tB = ((size_t)max_n + 31) / 32;
-    float *pv = ws;
-    int *pi = reinterpret_cast<int *>(ws + (size_t)slices * m * k);
-    _Float16 *fragA = reinterpret_cast<_Float16 *>(ws + (size_t)16 * m * k * 2);
-    _Float16 *fragB = fragA + (size_t)n_seg * tA * TK_TILE_HALFS;
-    unsigned *amax = reinterpret_cast<unsigned *>(fragB + (size_t)n_seg * tB * TK_TILE_HALFS);
-    hipStream_t s = roreg::as_stream(stream);
-    roreg::ProfScope prof(roreg::PROF_TOPK, s);
-    (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
-    hipLaunchKernelGGL(tk_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, segA, segB, m, n, amax);
-    hipLaunchKernelGGL(tk_prep_kernel, dim3((unsigned)(tA > tB ? tA : tB), 2, n_seg), dim3(256), 0, s, A, B, segA, segB, m, n, amax, fragA, fragB,
-                       tA * TK_TILE_HALFS, tB * TK_TILE_HALFS);
-    const dim3 grid((unsigned)((tA + 3) / 4), slices, n_seg);
-    const int gm = (m + 255) / 256;
-#define RM_TOPKM(KK)                                                                                                                 \
-    hipLaunchKernelGGL(topk_mfma_kernel<KK>, grid, dim3(256), 0, s, fragA, fragB, tA * TK_TILE_HALFS, tB * TK_TILE_HALFS, segA, segB, m, n, slices, \
-                       amax, pv, pi);                                                                                                \
-    hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
-    if (k == 16) { RM_TOPKM(16) } else if (k == 8) { RM_TOPKM(8) } else { RM_TOPKM(1) }
-#undef RM_TOPKM
-    ROREG_CHECK_LAUNCH("roreg_topk_dot_mfma");
-    return 0;
-}
-
 extern "C" int roreg_linear_mfma(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear_mfma: bad arguments");
     if (roreg::linear_mfma(x, L, Cin, W, b, Cout, y, roreg::as_stream(stream))) {

@@ -91,8 +91,6 @@ PROTOTYPES = {
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'roreg_topk_dot_workspace_size': (c_size_t, [c_int, c_int, c_int]),
     'roreg_topk_dot': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P, _P, c_int, c_int, c_int, _P]),
-    'roreg_topk_dot_mfma': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P, _P, c_int, c_int, c_int, _P]),
-    'roreg_topk_dot_mfma_workspace_size': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'roreg_context_colmax': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P]),
     'roreg_sinkhorn_batch_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong]),
     'roreg_sinkhorn_batch_consts': (c_int, [_P, _P, c_int, _P]),
@@ -937,27 +935,19 @@ def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
     m, n = A.shape[0], B.shape[0]
     idx = torch.empty((m, k), dtype=torch.int64, device=A.device)
     val = torch.empty((m, k), dtype=torch.float32, device=A.device) if want_val else None
+    wsn = lib().roreg_topk_dot_workspace_size(m, n, k)
+    ws = torch.empty(wsn, dtype=torch.float32, device=A.device)
     if segA is not None:
         if segB.min < k:
             raise HipError(f'topk_dot: a pair has fewer than k={k} targets')
         seg = (_ptr(segA.dev, torch.int32), _ptr(segB.dev, torch.int32), segA.n, segA.max, segB.max)
     else:
         seg = (None, None, 1, m, n)
-    mfma = bool(LINEAR_MFMA and TOPK_MFMA)       # (inside matrix_core_layers(): the stacked matcher) scores from the matrix cores, lists across lanes
-    if mfma:
-        wsn = lib().roreg_topk_dot_mfma_workspace_size(m, n, k, seg[2], seg[3], seg[4])
-        ws = torch.empty(wsn, dtype=torch.float32, device=A.device)
-        _check(lib().roreg_topk_dot_mfma(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, *seg, _stream()),
-               'roreg_topk_dot_mfma')
-    else:
-        wsn = lib().roreg_topk_dot_workspace_size(m, n, k)
-        ws = torch.empty(wsn, dtype=torch.float32, device=A.device)
-        _check(lib().roreg_topk_dot(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, *seg, _stream()),
-               'roreg_topk_dot')
+    _check(lib().roreg_topk_dot(_ptr(A, torch.float32), m, _ptr(B, torch.float32), n, k, _ptr(idx), _ptr(val), _ptr(ws), wsn, *seg, _stream()),
+           'roreg_topk_dot')
     if WORK is not None:
         pairs = float(m) * n if segA is None else float(np.sum(np.diff(segA.host).astype(np.float64) * np.diff(segB.host)))
         WORK['topk_flop'] = WORK.get('topk_flop', 0.0) + 2.0 * A.shape[1] * pairs
-        WORK['topk_mfma'] = mfma
     return (idx, val) if want_val else idx
 
 
@@ -965,7 +955,6 @@ def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
 # log-couplings within 1e-4 of the reference's at keynum 2500 -- a different rounding, equally accurate, flips a top-k neighbour on that fixture);
 # True = fp16 hi + lo MFMAs (csrc/linear_mfma.hip; the stacked matcher, which returns matches and scores only).  Set by matrix_core_layers().
 LINEAR_MFMA = False
-TOPK_MFMA = os.environ.get('ROREG_TOPK_MFMA', '1') != '0'      # A/B switch of the matrix-core neighbour search inside matrix_core_layers()
 
 
 class matrix_core_layers:
