@@ -67,7 +67,7 @@ profile)
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench_$tag -- python3 bench.py --steps 2 --warmup 1 $ARGS > $OUT/bench_line_under_kernel_trace_$tag.json 2> $OUT/kt_bench_$tag.err
   db=$(find $OUT/kt_bench_$tag -name '*.db' | head -1)
   python3 tools/rocprof_summary.py $db $OUT/bench_kernel_trace_$tag.txt > /dev/null
-  python3 tools/rocprof_gaps.py $db > $OUT/bench_gpu_idle_$tag.txt 2>&1
+  python3 tools/rocprof_gaps.py $db 3.1 > $OUT/bench_gpu_idle_$tag.txt 2>&1       # (the two timed steps: the last ~3.1 s of the trace)
   rm -rf $OUT/kt_bench_$tag
   i=0; rm -rf $OUT/pmc_bench_$tag
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
