@@ -226,7 +226,8 @@ def init_collectives(backend, rank, world, dev_index=None, timeout_s=None):
         if world != 1:
             raise RuntimeError('init_collectives: MASTER_PORT is not set (start the ranks with torch.distributed.run)')
         s = socket.socket(); s.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s.getsockname()[1]); s.close()
-    t = collective_timeout(120.0) if timeout_s is None else timeout_s
+    # generous: the ranks of a fresh box import torch at different speeds (minutes apart in the worst case) before they meet here
+    t = collective_timeout(600.0) if timeout_s is None else timeout_s
     with watchdog(t, 'init_process_group + first barrier'):
         kw = {'device_id': torch.device('cuda', dev_index)} if backend == 'nccl' else {}
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(t, 30.0) * 4), **kw)
