@@ -79,9 +79,19 @@ profile)
   head -30 $OUT/bench_kernel_trace_$tag.txt | cut -c1-220 ;;
 final)
   python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
-  timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_final.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest_gpu_final.log
-  timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2> $OUT/bench_final.err; echo "bench rc $?"
-  timeout 900 python bench.py --force-collectives --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_forced_final.json 2> $OUT/bench_forced_final.err; echo "forced rc $?" ;;
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_final.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest_gpu_final.log
+  timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2> $OUT/bench_final.err; echo "bench rc $? lines $(wc -l < $OUT/bench_final.json)"
+  timeout 900 python bench.py --force-collectives --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_forced_final.json 2> $OUT/bench_forced_final.err; echo "forced rc $? lines $(wc -l < $OUT/bench_forced_final.json)"
+  ROREG_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 3 --backend gloo --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_shared3_final.json 2> $OUT/bench_shared3_final.err; echo "shared3 rc $? lines $(wc -l < $OUT/bench_shared3_final.json)"
+  python3 - <<'PY'
+import json
+j=json.load(open('gpurun_out/r04/bench_final.json')); f=json.load(open('gpurun_out/r04/bench_forced_final.json')); k=json.load(open('gpurun_out/r04/bench_shared3_final.json'))
+c=j['config']
+print('final', j['value'], j['ms_per_step'], j['value_all_local_transforms'], j.get('value_bf16x3'), j['roofline']['frac'], j['roofline']['traffic'], c.get('rd_rm_leg_pairs_per_s'), c.get('rd_rm_leg_sinkhorn_ms_per_pair'), c.get('rr'))
+print('forced', f['value'], f['config']['forced_collectives'], f['config']['eqv_bytes_moved_per_step'], f['config'].get('backend'))
+print('shared3', k['n_gpus'], k['value'], k['config']['eqv_transfers_per_step'], k['config']['cloud_extractions_per_rank'], k['accuracy'] == j['accuracy'])
+PY
+  ;;
 *) echo "unknown sub-command $cmd"; exit 2 ;;
 esac
 du -sh $OUT | tail -1
