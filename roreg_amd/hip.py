@@ -909,7 +909,7 @@ def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpo
                                             _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(cor), _stream()), 'roreg_group_corr_irrep')
         return cor
     cor = torch.empty((M, 60), dtype=torch.float32, device=perm_feats.device)
-    if LINEAR_MFMA and not want_idx:             # (inside matrix_core_layers(): the stacked matcher) one 60 x 32 x 60 product per point + coset sums
+    if MATRIX_CORE_LAYERS and not want_idx:             # (inside matrix_core_layers(): the stacked matcher) one 60 x 32 x 60 product per point + coset sums
         _check(lib().roreg_group_corr_mfma(_ptr(perm_feats, torch.float32), _ptr(perm_rows, torch.int64), _ptr(bcast_feats, torch.float32),
                                            _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(cor), _stream()), 'roreg_group_corr_mfma')
         return cor
@@ -951,27 +951,28 @@ def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
     return (idx, val) if want_val else idx
 
 
-# The matcher's 1x1 layers: False = one float32 fmaf chain per (row, output) on the vector pipe (Match_ot.forward(): the arithmetic that keeps the
-# log-couplings within 1e-4 of the reference's at keynum 2500 -- a different rounding, equally accurate, flips a top-k neighbour on that fixture);
-# True = fp16 hi + lo MFMAs (csrc/linear_mfma.hip; the stacked matcher, which returns matches and scores only).  Set by matrix_core_layers().
-LINEAR_MFMA = False
+# The matcher's 1x1 layers and R_indicator: False = one float32 fmaf chain per (row, output) / the literal gathered correlation on the vector
+# pipe (Match_ot.forward(): the arithmetic that keeps the log-couplings within 1e-4 of the reference's at keynum 2500 -- a different rounding,
+# equally accurate, flips a top-k neighbour on that fixture); True = fp16 hi + lo MFMAs (csrc/linear_mfma.hip) and one float32 MFMA product per
+# point (csrc/corr_mfma.hip): the stacked matcher, which returns matches and scores only.  Set by matrix_core_layers().
+MATRIX_CORE_LAYERS = False
 
 
 class matrix_core_layers:
-    """`with hip.matrix_core_layers():` -- linear() / mlp_instnorm() inside the block run on the matrix cores."""
+    """`with hip.matrix_core_layers():` -- linear() / mlp_instnorm() / group_corr() inside the block run on the matrix cores."""
 
     def __init__(self, on=True):
         self.on = bool(on)
 
     def __enter__(self):
-        global LINEAR_MFMA
-        self.prev = LINEAR_MFMA
-        LINEAR_MFMA = self.on
+        global MATRIX_CORE_LAYERS
+        self.prev = MATRIX_CORE_LAYERS
+        MATRIX_CORE_LAYERS = self.on
         return self
 
     def __exit__(self, *exc):
-        global LINEAR_MFMA
-        LINEAR_MFMA = self.prev
+        global MATRIX_CORE_LAYERS
+        MATRIX_CORE_LAYERS = self.prev
         return False
 
 
@@ -980,7 +981,7 @@ def linear(x, W, b):
     L, Cin = x.shape
     Cout = W.shape[0]
     y = torch.empty((L, Cout), dtype=torch.float32, device=x.device)
-    fn = lib().roreg_linear_mfma if LINEAR_MFMA else lib().roreg_linear
+    fn = lib().roreg_linear_mfma if MATRIX_CORE_LAYERS else lib().roreg_linear
     _check(fn(_ptr(x, torch.float32), L, Cin, _ptr(W, torch.float32), _ptr(b, torch.float32), Cout, _ptr(y), _stream()), 'roreg_linear')
     return y
 
@@ -1000,7 +1001,7 @@ def mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=1e-5, seg=None):
     ws = torch.empty(n_seg * 2 * C * 256, dtype=torch.float64, device=x.device)
     _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), *sg, _stream()), 'roreg_instnorm_stats')
     y = linear(x, Wr, br)
-    tail = lib().roreg_mlp_tail_mfma if LINEAR_MFMA else lib().roreg_mlp_tail
+    tail = lib().roreg_mlp_tail_mfma if MATRIX_CORE_LAYERS else lib().roreg_mlp_tail
     _check(tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), *sg, _stream()), 'roreg_mlp_tail')
     return y
 

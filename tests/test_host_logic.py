@@ -408,8 +408,8 @@ def _bench_line(argv, env_extra, timeout=600):
     env = dict(os.environ, OMP_NUM_THREADS='1', ROREG_BENCH_ENGINE='tests._bench_stub:make', PYTHONPATH=ROOT, **env_extra)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
-    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{'), p.stdout.decode()[-2000:]       # stdout carries the record and NOTHING else
     return json.loads(lines[0])
 
 
@@ -430,6 +430,10 @@ def test_bench_launcher_starts_n_ranks_and_gathers_one_table():
     plain = _bench_line(args + ['--gpus', '3', '--no-exchange'], {})
     assert plain['config']['eqv_transfers_per_step'] == 0 and sum(plain['config']['cloud_extractions_per_rank']) > 433
     assert plain['accuracy'] == one['accuracy']
+    eight = _bench_line(args + ['--gpus', '8'], {})                          # the driver's largest launch: every scene cut, 85 transfers
+    assert eight['n_gpus'] == 8 and sum(eight['config']['cloud_extractions_per_rank']) == 433 and eight['accuracy'] == one['accuracy']
+    assert eight['config']['eqv_bytes_moved_per_step'] == eight['config']['eqv_transfers_per_step'] * 24 * 32 * 60 * 4
+    assert eight['config']['result_table_bytes_gathered_per_step'] == 1623 * 21 * 8
 
 
 def test_bench_refuses_a_world_size_other_than_gpus():
