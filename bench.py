@@ -233,6 +233,8 @@ def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
     (In the reference's own 13-stencil form the same layer is 780/244 = 3.2x more flops: SURVEY 8d's per-keypoint figure.)"""
     base = {'bound': 'mfma', 'unit': 'TFLOP/s', 'avg_launch_ms': ms / max(n_launch, 1), 'launches': n_launch,
             'traffic': None if traffic is None else traffic.get('bytes'), 'traffic_source': traffic,
+            'mfma_busy_fraction': None if traffic is None else traffic.get('mfma_busy_fraction'),      # SQ_VALU_MFMA_BUSY_CYCLES of the same PMC pass
+            'traffic_over_algorithmic': (traffic.get('bytes') / alg_bytes) if (traffic and traffic.get('bytes') and alg_bytes) else None,
             'algorithmic_bytes_per_launch': alg_bytes, 'f32_equivalent_gemm_tflops': gemm_tflops,
             'reference_stencil_form_equivalent_tflops': gemm_tflops * 780.0 / 244.0}
     if mode == 'f32':
@@ -287,7 +289,8 @@ def measured_traffic(args, world=1):
     diff = {k: (then.get(k), now[k]) for k in now if then.get(k) != now[k]}
     if diff:
         return {'bytes': None, **src, 'refused': f'the PMC pass was collected under other conditions (then, now): {diff}'}
-    return {'bytes': val, **src, 'conditions': then}
+    det = (j.get('detail') or {}).get(f'{args.workload}:{args.gemm}') or {}
+    return {'bytes': val, **src, 'conditions': then, 'mfma_busy_fraction': det.get('mfma_busy_fraction')}
 
 
 def main():
