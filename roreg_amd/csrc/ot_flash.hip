@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
 // pieces of the new potential go into the extras plane of side A's fragments.  A sum outside (1e-35, 1e35) (every term underflowed, or
 // non-finite input) is replaced by the exact log-domain evaluation of that row from the float32 descriptors.
 template <bool MAXP>
-__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int slot0, float alpha, const unsigned *__restrict__ amax) {
+__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int slot0, float alpha) {
     const int pair = blockIdx.y;
     const int ra = a.seg[pair], lenA = a.seg[pair + 1] - ra;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -373,7 +373,7 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);
     if (iters > 0) {
         hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch);
-        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
+        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, 0, alpha);
     }
     for (int it = 0; it < iters; ++it) {
         static const int variant = getenv("ROREG_OT_VARIANT") ? atoi(getenv("ROREG_OT_VARIANT")) : 0;
@@ -395,9 +395,9 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
             continue;
         }
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
-        hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, 0, alpha, amax);
+        hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, 0, alpha);
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);
-        hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nch, 3, alpha, amax);
+        hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nch, 3, alpha);
     }
     hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride);
     hipLaunchKernelGGL(of_export_kernel, uB, dim3(256), 0, s, B, v_out, uv_stride);
