@@ -327,6 +327,17 @@ int roreg_mt_shuffle_prefix(const uint32_t *seeds, int n_jobs, const int32_t *si
 int roreg_yohoc_draw(const uint32_t *words, long long n_words, const double *cdf, const int32_t *bin_size, int max_iter, int max_tries,
                      int32_t *bin_out, int64_t *pick_out, int32_t *n_hyp_out, long long *words_used);
 
+/* v4: row gathers of several (source, row list) pairs in ONE launch -- task t copies rows[0..n) of src (row_bytes each, a multiple of 8) to
+ * consecutive rows of dst; tasks_dev is a DEVICE array, max_n >= every n.  The stacked matcher's per-pair sample gathers
+ * (feats[sample], keys[sample]: test/matcher.py:187-197 for every pair of a group). */
+typedef struct {
+    const void *src;
+    const int64_t *rows;
+    void *dst;
+    int32_t n, pad_;
+} roreg_gather_task;
+int roreg_gather_rows_batch(const roreg_gather_task *tasks_dev, int n_tasks, int max_n, int row_bytes, void *stream);
+
 /* Gather rows: out[i] = src[rows[i]] for f64 [.,3] keypoints (estimator.py:407-408). */
 int roreg_gather_rows_f64(const double *src, const int64_t *rows, int M, int width, double *out, void *stream);
 

@@ -289,7 +289,37 @@ __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double *__re
     out[i] = src[(size_t)rows[r] * width + c];
 }
 
+// Row gathers of several (source tensor, row list) pairs in ONE launch: task t copies rows[0..n) of its source (row_bytes each, a multiple
+// of 8) to consecutive rows of its destination.  blockIdx.y = task; a workgroup moves whole rows in 8-byte pieces.
+struct GatherTask { const void *src; const int64_t *rows; void *dst; int32_t n, pad_; };
+__global__ __launch_bounds__(256) void gather_rows_batch_kernel(const GatherTask *__restrict__ tasks, int row_words /* 8-byte words per row */,
+                                                                int rows_per_block) {
+    const GatherTask t = tasks[blockIdx.y];
+    const int r0 = blockIdx.x * rows_per_block;
+    if (r0 >= t.n) return;
+    const int r1 = min(r0 + rows_per_block, t.n);
+    const uint2 *src = reinterpret_cast<const uint2 *>(t.src);
+    uint2 *dst = reinterpret_cast<uint2 *>(t.dst);
+    for (int r = r0; r < r1; ++r) {
+        const uint2 *s = src + (size_t)t.rows[r] * row_words;
+        uint2 *d = dst + (size_t)r * row_words;
+        for (int i = threadIdx.x; i < row_words; i += 256) d[i] = s[i];
+    }
+}
+
 }  // namespace
+
+extern "C" int roreg_gather_rows_batch(const roreg_gather_task *tasks_dev, int n_tasks, int max_n, int row_bytes, void *stream) {
+    if (n_tasks == 0 || max_n == 0) return 0;
+    ROREG_REQUIRE(tasks_dev && n_tasks > 0 && max_n > 0 && row_bytes > 0 && row_bytes % 8 == 0, "roreg_gather_rows_batch: bad arguments (row_bytes must be a multiple of 8)");
+    static_assert(sizeof(roreg_gather_task) == sizeof(GatherTask), "roreg_gather_task layout");
+    const int row_words = row_bytes / 8;
+    const int rpb = row_words >= 256 ? 4 : (row_words >= 32 ? 32 : 256);      // long rows: a few per workgroup; short rows: many
+    hipLaunchKernelGGL(gather_rows_batch_kernel, dim3((max_n + rpb - 1) / rpb, n_tasks), dim3(256), 0, roreg::as_stream(stream),
+                       reinterpret_cast<const GatherTask *>(tasks_dev), row_words, rpb);
+    ROREG_CHECK_LAUNCH("roreg_gather_rows_batch");
+    return 0;
+}
 
 extern "C" int roreg_gf_finalize(const float *eqv_raw, void *eqv, int eqv_bf16, float *inv, int B, void *stream) {
     if (B == 0) return 0;

@@ -331,12 +331,14 @@ class RegistrationEngine:
             seg_s = hip.Segments([len(jobs[q][3]) for q in range(i, j)]); seg_t = hip.Segments([len(jobs[q][2]) for q in range(i, j)])
             se = torch.empty((seg_s.total, 32, 60), dtype=self.feat_dtype, device='cuda'); te = torch.empty((seg_t.total, 32, 60), dtype=self.feat_dtype, device='cuda')
             sk = torch.empty((seg_s.total, 3), dtype=torch.float64, device='cuda'); tk = torch.empty((seg_t.total, 3), dtype=torch.float64, device='cuda')
+            gf, gk = [], []                                                 # the group's sample gathers: two launches (features, keypoints) instead of four per pair
             for q in range(i, j):
                 c0, c1 = jobs[q][0], jobs[q][1]
                 d0, d1 = rows[q]
                 a, b = seg_s.host[q - i], seg_t.host[q - i]
-                torch.index_select(c1.eqv, 0, d1, out=se[a:a + d1.shape[0]]); torch.index_select(c1.keys, 0, d1, out=sk[a:a + d1.shape[0]])
-                torch.index_select(c0.eqv, 0, d0, out=te[b:b + d0.shape[0]]); torch.index_select(c0.keys, 0, d0, out=tk[b:b + d0.shape[0]])
+                gf += [(c1.eqv, d1, se[a:a + d1.shape[0]]), (c0.eqv, d0, te[b:b + d0.shape[0]])]
+                gk += [(c1.keys, d1, sk[a:a + d1.shape[0]]), (c0.keys, d0, tk[b:b + d0.shape[0]])]
+            hip.gather_rows_batch(gf); hip.gather_rows_batch(gk)
             with torch.no_grad():
                 issued += self.rm.match_stacked(se.float(), te.float(), sk.float(), tk.float(), seg_s, seg_t)   # (bf16 rows: lossless up-cast)
             i = j

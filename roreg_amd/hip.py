@@ -87,6 +87,7 @@ PROTOTYPES = {
     'roreg_ransac_batch': (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, c_double, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'roreg_refine_batch': (c_int, [_P, _P, c_int, ctypes.c_longlong, _P, ctypes.c_double, c_int, _P, _P, _P, _P]),
     'roreg_yohoc_draw': (c_int, [_P, ctypes.c_longlong, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    'roreg_gather_rows_batch': (c_int, [_P, c_int, c_int, c_int, _P]),
     'roreg_gather_rows_f64': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'roreg_group_corr': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'roreg_topk_dot_workspace_size': (c_size_t, [c_int, c_int, c_int]),
@@ -883,6 +884,25 @@ def mt_shuffle_prefix(seeds, sizes, take, n_threads=None):
         _check(lib().roreg_mt_shuffle_prefix(c_void_p(seeds.ctypes.data), seeds.shape[0], c_void_p(sizes.ctypes.data), sizes.shape[1], int(take),
                                              c_void_p(out.ctypes.data), int(nt)), 'roreg_mt_shuffle_prefix')
     return out
+
+
+_GATHER_TASK = np.dtype([('src', np.uint64), ('rows', np.uint64), ('dst', np.uint64), ('n', np.int32), ('pad', np.int32)])
+
+
+def gather_rows_batch(tasks):
+    """tasks [(src [*, ...] contiguous device tensor, rows int64 device [n], dst [n, ...] contiguous device tensor of src's dtype and row
+    shape)]: dst[i] = src[rows[i]] for every task, ONE launch (all tasks must have the same row size in bytes, a multiple of 8)."""
+    if not tasks:
+        return
+    row_bytes = int(tasks[0][0][0].numel() * tasks[0][0].element_size())
+    table = np.zeros(len(tasks), _GATHER_TASK)
+    for i, (src, rows, dst) in enumerate(tasks):
+        _ptr(src); _ptr(rows, torch.int64); _ptr(dst)
+        if src.dtype != dst.dtype or int(src[0].numel() * src.element_size()) != row_bytes or dst.shape[0] != rows.shape[0]:
+            raise HipError('gather_rows_batch: tasks must share the row size, and dst must hold one row per index')
+        table[i] = (src.data_ptr(), rows.data_ptr(), dst.data_ptr(), int(rows.shape[0]), 0)
+    tdev = upload(table.view(np.uint8).reshape(len(tasks), _GATHER_TASK.itemsize))
+    _check(lib().roreg_gather_rows_batch(_ptr(tdev), len(tasks), int(table['n'].max()), row_bytes, _stream()), 'roreg_gather_rows_batch')
 
 
 def gather_rows_f64(src, rows):

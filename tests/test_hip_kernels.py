@@ -509,6 +509,24 @@ def test_ransac_batch_equals_per_pair_calls():
     assert hip.refine_batch(ctx, [], np.zeros((0, 4, 4)), ird)[0].shape == (0, 4, 4)
 
 
+def test_gather_rows_batch_equals_index_select():
+    """Several (tensor, row list) gathers in one launch: float32 / bfloat16 [*,32,60] feature rows and float64 [*,3] keypoint rows, ragged
+    counts incl. an empty task, repeated and unordered indices -- bitwise torch.index_select."""
+    from roreg_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for dtype, shape in ((torch.float32, (32, 60)), (torch.bfloat16, (32, 60)), (torch.float64, (3,))):
+        srcs = [torch.randn((n,) + shape, device='cuda', generator=g, dtype=torch.float32).to(dtype) for n in (700, 64, 1300)]
+        rows = [torch.randint(0, s.shape[0], (k,), device='cuda', generator=g) for s, k in zip(srcs, (513, 0, 2500))]
+        out = torch.zeros((sum(r.shape[0] for r in rows),) + shape, device='cuda', dtype=dtype)
+        tasks, o = [], 0
+        for s, r in zip(srcs, rows):
+            tasks.append((s, r, out[o:o + r.shape[0]])); o += r.shape[0]
+        hip.gather_rows_batch(tasks)
+        want = torch.cat([torch.index_select(s, 0, r) for s, r in zip(srcs, rows)])
+        assert torch.equal(out, want), dtype
+    hip.gather_rows_batch([])
+
+
 def test_lt_batch_equals_per_pair_calls(group):
     """Batched Des2R + ET-input assembly + quaternion->transform against the per-pair entry points: ragged n, hypothesis
     selections given / all matches, an empty task."""
