@@ -38,11 +38,11 @@ def use_planes(O):
     """Whether the fp16 x 2 GEMM with O output channels takes its activations in the half-block layout (LDS-DMA kernel): decided HERE for
     both ft_nonlin(planes=) and irrep_gemm(x_planes=) -- the kernel needs the 256-row tile (O % 256 == 0, not ROREG_TILE_M128)."""
     return bool(XDMA and O % 256 == 0 and not os.environ.get('ROREG_TILE_M128'))
-from ._abi import ABI_VERSION
 _lib = None
 _tables_uploaded = False
 
-from ._abi import PROTOTYPES, _P           # the C-ABI as data: prototypes and task-struct layouts (roreg_amd/_abi.py)
+# the C-ABI as data: version, ctypes prototypes and the numpy layouts of the task structs (roreg_amd/_abi.py)
+from ._abi import ABI_VERSION, PROTOTYPES, _P, _LT_TASK, _RANSAC_TASK, _MATCH_TASK, _GATHER_TASK
 
 
 class HipError(RuntimeError):
@@ -410,7 +410,6 @@ def mutual_matches(nn01, nn10, sample0=None, sample1=None):
     return out, cnt
 
 
-from ._abi import _LT_TASK
 
 
 class LtBatch:
@@ -536,7 +535,6 @@ def yohoc_draw(prob, bin_size, max_iter, max_tries=50000, rng=None):
     return bins[:n_hyp.value].copy(), picks[:n_hyp.value].copy()
 
 
-from ._abi import _RANSAC_TASK
 
 
 def ransac_batch(tasks, ird, w_f32=False, keep=False):
@@ -591,7 +589,6 @@ def refine_batch(ctx, sel, T_in, dist):
     return T, st
 
 
-from ._abi import _MATCH_TASK
 
 
 def mutual_match_batch(tasks):
@@ -807,7 +804,6 @@ def mt_shuffle_prefix(seeds, sizes, take, n_threads=None):
     return out
 
 
-from ._abi import _GATHER_TASK
 
 
 def gather_rows_batch(tasks):
