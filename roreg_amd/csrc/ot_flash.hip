@@ -24,6 +24,7 @@
 // The read-out (arg-max of Z + u + v over rows and columns) still runs on a matrix built once per pair (rm.hip).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(320) void of_prep_kernel(Side a, Side b, const unsi
     const int pair = blockIdx.z, side = blockIdx.y, t = blockIdx.x;
     const Side &s = side ? b : a;
     const int r0 = s.seg[pair], len = s.seg[pair + 1] - r0;            // rows 0..len-1 are points, row len is the dustbin
-    if (t * 32 > len) return;
+    if (t > len / 32 + 1) return;                                     // (tile len / 32 + 1 is the PAD tile: all rows invalid; of_iter_kernel reads it for tiles a pair does not have)
     const int p = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int i = t * 32 + (l & 31), kg = l >> 5;
     const int e0 = balance_exp(amax, pair);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(320) void of_prep_kernel(Side a, Side b, const unsi
         for (int e = 0; e < 8; ++e) out[e] = sl[kg * 8 + e];
     }
     *reinterpret_cast<f16x8 *>(s.frag + pair * s.frag_stride + ((size_t)(t * OF_PLANES + p) * 64 + l) * 8) = out;
-    if (p == 0 && l < 32) s.pot[pair * s.pot_stride + i] = 0.f;
+    if (p == 0 && l < 32 && t <= len / 32) s.pot[pair * s.pot_stride + i] = 0.f;
 }
 
 template <int CTRL, int ROW_MASK>
@@ -260,17 +261,55 @@ __global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch) {
     }
 }
 
-// pot[i] <- -max (MAXP: the first row pass's stabiliser)  or  pot[i] + log2(mu_i) - log2(sum of the chunks' partial sums); the three fp16
-// pieces of the new potential go into the extras plane of side A's fragments.  A sum outside (1e-35, 1e35) (every term underflowed, or
-// non-finite input) is replaced by the exact log-domain evaluation of that row from the float32 descriptors.
-template <bool MAXP>
-__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int slot0, float alpha) {
-    const int pair = blockIdx.y;
+// Exact log2-sum-exp2 of (Z' + potB) over the other side for row i of side A, from the float32 descriptors: lmu minus it is the row's new
+// potential.  Only rows whose sum of exponentials left (1e-35, 1e35) come here (every term underflowed, or non-finite input).
+__device__ float exact_potential(const Side &a, const Side &b, int pair, int i, float alpha, float lmu) {
     const int ra = a.seg[pair], lenA = a.seg[pair + 1] - ra;
+    const int rb = b.seg[pair], lenB = b.seg[pair + 1] - rb;
+    const float *potB = b.pot + pair * b.pot_stride;
+    const float al = alpha * LOG2E;
+    float d[OF_F];
+#pragma unroll
+    for (int f = 0; f < OF_F; ++f) d[f] = i < lenA ? a.desc[(size_t)(ra + i) * OF_F + f] * LOG2E : 0.f;
+    float mx = -__builtin_inff(), np = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {
+        float sum = 0.f;
+        for (int j = 0; j <= lenB; ++j) {
+            float x = al;
+            if (i < lenA && j < lenB) {
+                x = 0.f;
+                const float *t = b.desc + (size_t)(rb + j) * OF_F;
+#pragma unroll
+                for (int f = 0; f < OF_F; ++f) x = fmaf(d[f], t[f], x);
+            }
+            x += potB[j];
+            if (rep == 0) mx = fmaxf(mx, x);
+            else sum += __builtin_amdgcn_exp2f(x - mx);
+        }
+        if (rep == 1) np = lmu - (mx + __log2f(sum));
+    }
+    return np;
+}
+
+__device__ __forceinline__ void store_pieces(const Side &a, int pair, int i, float np, int slot0) {
+    _Float16 h, m, l;
+    split3(np, h, m, l);
+    _Float16 *dst = a.frag + pair * a.frag_stride + ((size_t)((i >> 5) * OF_PLANES + 2) * 64 + (i & 31)) * 8 + slot0;
+    dst[0] = h; dst[1] = m; dst[2] = l;
+}
+
+// pot[i] <- -max (MAXP: the first row pass's stabiliser)  or  pot[i] + log2(mu_i) - log2(sum of the partial sums); the three fp16
+// pieces of the new potential go into the extras plane of side A's fragments.  A sum outside (1e-35, 1e35) is replaced by the exact
+// log-domain evaluation of that row.  `cht` = tiles of the OTHER side per partial sum (OF_CHT for of_pass_kernel's chunks, 1 for the row
+// strips of of_iter_kernel), `nch` = partial sums allocated per row.
+template <bool MAXP>
+__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int cht, int slot0, float alpha) {
+    const int pair = blockIdx.y;
+    const int lenA = a.seg[pair + 1] - a.seg[pair];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i > lenA) return;
     const float *part = a.part + pair * (a.pot_stride * nch) + i;
-    const int nch_pair = ((b.seg[pair + 1] - b.seg[pair]) / 32 + 1 + OF_CHT - 1) / OF_CHT;      // the chunks this pair's other side really has
+    const int nch_pair = ((b.seg[pair + 1] - b.seg[pair]) / 32 + 1 + cht - 1) / cht;      // the partial sums this pair's other side really has
     float *pot = a.pot + pair * a.pot_stride;
     float np;
     if (MAXP) {
@@ -278,42 +317,196 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
         for (int c = 0; c < nch_pair; ++c) mx = fmaxf(mx, part[(size_t)c * a.pot_stride]);
         np = mx > -__builtin_inff() && mx < __builtin_inff() ? -mx : 0.f;
     } else {
-        float S = 0.f;
-        for (int c = 0; c < nch_pair; ++c) S += part[(size_t)c * a.pot_stride];
+        float S = 0.f;                                            // partial sums added in order; 16 independent loads in flight at a time
+        for (int c0 = 0; c0 < nch_pair; c0 += 16) {                // (of_iter_kernel leaves up to 80 of them per column)
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = c0 + q < nch_pair ? __builtin_nontemporal_load(part + (size_t)(c0 + q) * a.pot_stride) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) if (c0 + q < nch_pair) S += v[q];
+        }
         const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
-        if (S > 1e-35f && S < 1e35f) {
-            np = pot[i] + (lmu - __log2f(S));
-        } else {                                                  // exact: log2-sum-exp2 of (Z' + potB) over the other side, float32 descriptors
-            const int rb = b.seg[pair], lenB = b.seg[pair + 1] - rb;
-            const float *potB = b.pot + pair * b.pot_stride;
-            const float al = alpha * LOG2E;
-            float d[OF_F];
+        if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
+        else np = exact_potential(a, b, pair, i, alpha, lmu);
+    }
+    pot[i] = np;
+    store_pieces(a, pair, i, np, slot0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One WHOLE iteration per launch (+ the column update): the exponentials of a 32-row strip stay in registers between the row sums and
+// the column sums, so the scores are recomputed once per iteration instead of twice.
+//     E_ij = 2^(Z'_ij + u_i + v_j)         (7 MFMAs per 32 x 32 tile + one v_exp_f32 per element, as in of_pass_kernel)
+//     S_i = sum_j E_ij,   u_i += log2 mu_i - log2 S_i,   f_i = 2^(u_new - u_old)
+//     C_j(strip) = sum_{i in strip} E_ij f_i            (= the strip's part of sum_i 2^(Z' + u_new + v): one fma per element)
+// A workgroup of eight wavefronts owns the strip (one row tile of side A); wave w owns the column tiles w, w + 8, ..., NT <= 10 of them
+// (NT from the group's longest target cloud; tiles beyond a pair's own are the PAD tile of_prep_kernel writes behind the pair's last
+// one: padding potentials, exponentials exactly 0, so the code has no branches and every sum the same association whatever NT is):
+// 160 accumulator registers per lane hold the wave's part of E (2 waves per SIMD, <= 256 VGPRs).  The strip's column sums go to
+// part[strip][column] of side B and of_update_kernel adds the strips in order (cht = 1): fixed association, independent of what is
+// stacked beside the pair.  Rows beyond the dustbin have E = 0 and are not updated.  A row whose sum left (1e-35, 1e35) -- every term
+// underflowed, or non-finite input -- makes the workgroup redo its strip with the row maxima as stabilisers (mode 1 = max_j acc,
+// mode 2 = E = 2^(acc - M_i), f_i = mu_i / S_i).  Valid for <= 80 column tiles (2559 target points).
+constexpr int OF_FW = 8, OF_FT = 10;
+template <int NT, int VAR = 0>       // VAR: ablations for measurements only (ROREG_OT_FVAR): 1 no exponentials, 2 no MFMAs, 3 no fragment loads in the loop, 5 no row update
+__global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts) {
+    const int pair = blockIdx.y, tA = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (w in a scalar register: tile addresses are scalar)
+    const int lenA = a.seg[pair + 1] - a.seg[pair], lenB = b.seg[pair + 1] - b.seg[pair];
+    const int tilesA = lenA / 32 + 1, tilesB = lenB / 32 + 1;
+    if (tA >= tilesA) return;
+    __shared__ float s_part[OF_FW][32];
+    __shared__ float s_np[32];
+    // the row this lane updates (both halves of every wave: row tA * 32 + lane % 32); its potential and log-marginal are fetched now
+    const int i_row = tA * 32 + (lane & 31);
+    const bool row_valid = i_row <= lenA;
+    float *pot = a.pot + pair * a.pot_stride;
+    float old = 0.f, lmu = 0.f;
+    if (row_valid) {
+        old = pot[i_row];
+        lmu = (i_row == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
+    }
+    const f16x8 *fb = reinterpret_cast<const f16x8 *>(b.frag + pair * b.frag_stride);
+    f16x8 A[OF_PLANES];
+    {
+        const f16x8 *fa = reinterpret_cast<const f16x8 *>(a.frag + pair * a.frag_stride) + (size_t)tA * OF_PLANES * 64 + lane;
 #pragma unroll
-            for (int f = 0; f < OF_F; ++f) d[f] = i < lenA ? a.desc[(size_t)(ra + i) * OF_F + f] * LOG2E : 0.f;
-            float mx = -__builtin_inff();
-            for (int rep = 0; rep < 2; ++rep) {
-                float sum = 0.f;
-                for (int j = 0; j <= lenB; ++j) {
-                    float x = al;
-                    if (i < lenA && j < lenB) {
-                        x = 0.f;
-                        const float *t = b.desc + (size_t)(rb + j) * OF_F;
+        for (int p = 0; p < OF_PLANES; ++p) A[p] = fa[p * 64];
+    }
+    f32x16 E[NT];
+    float red[16];
+    f16x8 B[OF_PLANES];
+    auto load_plane = [&](int k, int p) {                          // plane p of the wave's k-th tile (scalar base + the lane's offset)
+        if (VAR == 3 && k > 0) return;
+        const f16x8 *src = fb + (size_t)min(w + OF_FW * k, tilesB) * OF_PLANES * 64;
+        B[p] = src[p * 64 + lane];
+    };
+    // A tile's chain of 7 MFMAs.  Order: each fragment plane of B in consecutive links, so that its registers can be reloaded for the NEXT tile
+    // right behind its last use -- one fragment buffer, and every plane is requested 5-7 links before the chain that needs it.
+    constexpr int PA[7] = {3, 0, 4, 1, 0, 1, 2}, PB[7] = {0, 0, 1, 1, 3, 4, 2};     // lo.hi, hi.hi (k 0-15); lo.hi, hi.hi (k 16-31); hi.lo; hi.lo; potentials
+    constexpr int FREE[7] = {-1, 0, -1, 1, 3, 4, 2};                               // the plane whose last use link g is
+    auto link = [&](int g, f32x16 &acc) {
+        if (VAR == 2) { acc[g] = (float)B[PB[g]][0] + (float)A[PA[g]][1]; return; }
+        if (g == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[0]], B[PB[0]], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[g]], B[PB[g]], acc, 0, 0, 0);
+    };
+    auto phase1 = [&](auto mode_c) {
+        constexpr int mode = decltype(mode_c)::value;
 #pragma unroll
-                        for (int f = 0; f < OF_F; ++f) x = fmaf(d[f], t[f], x);
-                    }
-                    x += potB[j];
-                    if (rep == 0) mx = fmaxf(mx, x);
-                    else sum += __builtin_amdgcn_exp2f(x - mx);
+        for (int r = 0; r < 16; ++r) red[r] = mode == 1 ? -__builtin_inff() : 0.f;
+        auto post = [&](int k, int r0, int r1) {                   // the vector-pipe part of tile k, accumulator registers r0 .. r1 - 1
+#pragma unroll
+            for (int r = r0; r < r1; ++r) {
+                if (mode == 0) {                                   // (inline assembly: the exponential replaces its operand IN PLACE -- no second copy of a tile's 16 registers)
+                    float x = E[k][r];
+                    if (VAR != 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+                    else x = fabsf(x) * 1e-4f + 1e-4f;
+                    E[k][r] = x;
+                    red[r] += x;
+                } else if (mode == 1) {
+                    red[r] = fmaxf(red[r], E[k][r]);
+                } else {                                           // (the maxima from LDS per use: this path is rare, registers are not)
+                    E[k][r] = __builtin_amdgcn_exp2f(E[k][r] - s_np[8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)]);
+                    red[r] += E[k][r];
                 }
-                if (rep == 1) np = lmu - (mx + __log2f(sum));
+            }
+        };
+        // Software pipeline: the links of tile k + 1's chain are issued INTERLEAVED with the exponentials and adds of tile k -- a wavefront
+        // issues in order, so the vector work has to sit between the links to run in their shadow.
+#pragma unroll
+        for (int p = 0; p < OF_PLANES; ++p) load_plane(0, p);
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            link(g, E[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NT > 1 && FREE[g] >= 0) load_plane(1, FREE[g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            if (k + 1 < NT) {
+#pragma unroll
+                for (int g = 0; g < 7; ++g) {
+                    link(g, E[k + 1 < NT ? k + 1 : k]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 2 < NT && FREE[g] >= 0) load_plane(k + 2, FREE[g]);
+                    post(k, (16 * g) / 7, (16 * (g + 1)) / 7);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // the last tile's chain has just been issued, and the in-place exponentials are inline assembly: the compiler's hazard
+                // recogniser does not see them as readers of the MFMA result (no hardware interlock): 18 wait states by hand
+                if (mode == 0) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 3"); __builtin_amdgcn_sched_barrier(0); }
+                post(k, 0, 16);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = mode == 1 ? half_max(red[r]) : half_sum(red[r]);
+            if ((lane & 31) == 31) s_part[w][8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = v;
+        }
+        __syncthreads();
+    };
+    using std::integral_constant;
+    phase1(integral_constant<int, 0>{});
+    // ---- the strip's row update: every wave evaluates it for itself (same LDS data, same result: no second barrier); wave 0 stores it ----
+    float frow = 0.f;                                              // f of row lane % 32
+    bool redo = false;
+    if (VAR == 5) {
+        frow = row_valid ? 1.f : 0.f;
+    } else {
+        float S = 0.f;
+#pragma unroll
+        for (int q = 0; q < OF_FW; ++q) S += s_part[q][lane & 31];
+        const bool ok = S > 1e-35f && S < 1e35f;
+        redo = __any(row_valid && !ok);                            // (identical in all eight waves)
+        if (!redo && row_valid) {
+            const float np = old + (lmu - __log2f(S));             // u + log2 mu - log2 sum_j 2^(Z' + u + v)
+            frow = __builtin_amdgcn_exp2f(np - old);               // E f = 2^(Z' + u_new + v)
+            if (threadIdx.x < 32) {
+                pot[i_row] = np;
+                store_pieces(a, pair, i_row, np, 0);
             }
         }
     }
-    pot[i] = np;
-    _Float16 h, m, l;
-    split3(np, h, m, l);
-    _Float16 *dst = a.frag + pair * a.frag_stride + ((size_t)((i >> 5) * OF_PLANES + 2) * 64 + (i & 31)) * 8 + slot0;
-    dst[0] = h; dst[1] = m; dst[2] = l;
+    if (redo) {                                                    // rare: stabilised evaluation of the whole strip
+        __syncthreads();                                           // (s_part is rewritten)
+        phase1(integral_constant<int, 1>{});
+        if (threadIdx.x < 32) {
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int q = 0; q < OF_FW; ++q) mx = fmaxf(mx, s_part[q][threadIdx.x]);
+            s_np[threadIdx.x] = mx > -__builtin_inff() && mx < __builtin_inff() ? mx : 0.f;
+        }
+        __syncthreads();
+        phase1(integral_constant<int, 2>{});
+        float S = 0.f;
+#pragma unroll
+        for (int q = 0; q < OF_FW; ++q) S += s_part[q][lane & 31];
+        if (row_valid) {
+            const float m = s_np[lane & 31];
+            const float np = old + ((lmu - m) - __log2f(S));
+            frow = __builtin_amdgcn_exp2f((np - old) + m);         // = mu_i / S_i: E f = 2^(Z' + u_new + v)
+            if (threadIdx.x < 32) {
+                pot[i_row] = np;
+                store_pieces(a, pair, i_row, np, 0);
+            }
+        }
+    }
+    // ---- phase 2: the strip's part of the column sums ----
+    float f[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) f[r] = __shfl(frow, 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3));
+    float *out = b.part + pair * (b.pot_stride * nparts) + (size_t)tA * b.pot_stride;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int t = w + OF_FW * k;
+        float c = E[k][0] * f[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) c = fmaf(E[k][r], f[r], c);
+        c += __shfl_xor(c, 32);
+        if (t < tilesB && lane < 32) out[t * 32 + lane] = c;
+    }
 }
 
 __global__ __launch_bounds__(256) void of_export_kernel(Side a, float *__restrict__ out, size_t out_stride) {
@@ -338,11 +531,19 @@ static int ot_flash_chunks(int max_m, int max_n) {
     return (tiles + OF_CHT - 1) / OF_CHT;
 }
 
+// The whole-iteration kernel holds a strip's exponentials in registers: at most OF_FW * OF_FT column tiles.  ROREG_OT_FUSED=0 keeps the
+// two-pass form (measurements).
+static bool ot_flash_fused(int max_n) {
+    static const bool on = !(getenv("ROREG_OT_FUSED") && atoi(getenv("ROREG_OT_FUSED")) == 0);
+    return on && max_n / 32 + 1 <= OF_FW * OF_FT;
+}
+
 // bytes of workspace of ot_flash_iterations (16-byte aligned pieces): per pair the two sides' fragments, potentials and chunk partials
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
     const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
     const size_t nch = ot_flash_chunks(max_m, max_n);
-    const size_t per_pair = (ta + tb) * OF_TILE_HALFS * sizeof(_Float16) + (ta + tb) * 32 * sizeof(float) * (1 + nch);
+    const size_t nparts = ot_flash_fused(max_n) && ta > nch ? ta : nch;           // side B's partial sums: one per row strip in the fused iteration
+    const size_t per_pair = (ta + tb + 2) * OF_TILE_HALFS * sizeof(_Float16) + (ta + tb) * 32 * sizeof(float) + (ta * nch + tb * nparts) * 32 * sizeof(float);
     return (size_t)n_seg * per_pair + round_up((size_t)n_seg * 2 * sizeof(unsigned), 16) + 256;
 }
 
@@ -357,26 +558,28 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     Side A, B;
     A.desc = src; A.seg = seg_src; A.consts = consts;
     B.desc = tgt; B.seg = seg_tgt; B.consts = consts + 2 * n_seg;
-    A.frag_stride = ta * OF_TILE_HALFS; B.frag_stride = tb * OF_TILE_HALFS;
+    A.frag_stride = (ta + 1) * OF_TILE_HALFS; B.frag_stride = (tb + 1) * OF_TILE_HALFS;      // (+ the pad tile)
     A.pot_stride = ta * 32; B.pot_stride = tb * 32;
     A.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * A.frag_stride * sizeof(_Float16);
     B.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * B.frag_stride * sizeof(_Float16);
     A.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * sizeof(float);
     B.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * sizeof(float);
+    static const int variant = getenv("ROREG_OT_VARIANT") ? atoi(getenv("ROREG_OT_VARIANT")) : 0;
+    const bool fused = ot_flash_fused(max_n) && variant == 0;
+    const int nparts = fused && (int)ta > nch ? (int)ta : nch;
     A.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * nch * sizeof(float);
-    B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * nch * sizeof(float);
+    B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * nparts * sizeof(float);
     unsigned *amax = reinterpret_cast<unsigned *>(p);
     (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
     hipLaunchKernelGGL(of_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, amax);      // 8 workgroups per (pair, side): 32 atomics each
-    hipLaunchKernelGGL(of_prep_kernel, dim3((unsigned)(ta > tb ? ta : tb), 2, n_seg), dim3(320), 0, s, A, B, amax, alpha);
+    hipLaunchKernelGGL(of_prep_kernel, dim3((unsigned)(ta > tb ? ta : tb) + 1, 2, n_seg), dim3(320), 0, s, A, B, amax, alpha);
     const dim3 gA((unsigned)((ta + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg), gB((unsigned)((tb + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg);
     const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);
     if (iters > 0) {
         hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch);
-        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, 0, alpha);
+        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha);
     }
     for (int it = 0; it < iters; ++it) {
-        static const int variant = getenv("ROREG_OT_VARIANT") ? atoi(getenv("ROREG_OT_VARIANT")) : 0;
         if (variant == 1) {
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 1>), gA, dim3(256), 0, s, A, B, nch);
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 1>), gB, dim3(256), 0, s, B, A, nch);
@@ -389,15 +592,26 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 3>), gA, dim3(256), 0, s, A, B, nch);
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R, 3>), gB, dim3(256), 0, s, B, A, nch);
             continue;
+        } else if (fused) {                            // the row update and the strips' column sums in one launch; then the column update
+            static const int fvar = getenv("ROREG_OT_FVAR") ? atoi(getenv("ROREG_OT_FVAR")) : 0;
+            using Kern = void (*)(Side, Side, int);
+            static const Kern by_nt[OF_FT] = {of_iter_kernel<1>, of_iter_kernel<2>, of_iter_kernel<3>, of_iter_kernel<4>, of_iter_kernel<5>,
+                                              of_iter_kernel<6>, of_iter_kernel<7>, of_iter_kernel<8>, of_iter_kernel<9>, of_iter_kernel<10>};
+            const int nt = (int)(tb + OF_FW - 1) / OF_FW;                   // column tiles per wave
+            Kern kern = by_nt[nt - 1];
+            if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 3 ? of_iter_kernel<OF_FT, 3> : of_iter_kernel<OF_FT, 5>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts);
+            hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, 1, 3, alpha);
+            continue;
         } else if (variant == 4) {                       // passes only (no update launches)
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);
             continue;
         }
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
-        hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, 0, alpha);
+        hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha);
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);
-        hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nch, 3, alpha);
+        hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, OF_CHT, 3, alpha);
     }
     hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride);
     hipLaunchKernelGGL(of_export_kernel, uB, dim3(256), 0, s, B, v_out, uv_stride);
