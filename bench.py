@@ -671,21 +671,28 @@ def rd_rm_leg(args, cfg0, gf, et):
         leg = {'pairs_per_s': n_pairs * n_rep / dt, 'ms_per_pass': 1e3 * dt / n_rep, 'mean_matches': float(np.mean([r.n_match for r in res])),
                'registration_recall_pointdsc': float(np.mean(ok))}
         if sk_n and work.get('sinkhorn_recompute'):
-            # the iterations recompute the scores on the matrix cores (csrc/ot_flash.hip): per element and iteration two passes of seven K = 16
-            # fp16 MFMAs (224 flop each way) + one v_exp_f32 + one add each; no coupling matrix is read
+            # the iterations recompute the scores on the matrix cores (csrc/ot_flash.hip).  One recomputation per element and iteration
+            # (of_iter_kernel: seven K = 16 fp16 MFMAs = 224 flop, one v_exp_f32, one add, one fma; a 32-row strip's exponentials stay in registers
+            # between the row sums and the column sums) unless ROREG_OT_FUSED=0 or a target cloud exceeds 2559 points (two passes: twice that).
+            # No coupling matrix is read; what the fused kernel moves instead is 5 bytes of L2-resident fragments per element and iteration,
+            # and that traffic is what bounds it (measured: fetching every fragment twice costs +50-67 %).
             cells = work.get('sinkhorn_cells', 0.0)
-            tf = cells * 448.0 / (sk_ms * 1e-3) / 1e12
-            ex = cells * 2.0 / (sk_ms * 1e-3)
-            leg['roofline_sinkhorn'] = {'kernel': 'of_pass_kernel + of_update_kernel (100 iterations per stacked group of pairs: every pass recomputes <s_i, t_j> + potentials + dustbins '
-                                                  'with seven fp16 MFMAs per 32 x 32 tile and exponentiates; the coupling matrix is never read)', 'bound': 'mfma', 'unit': 'TFLOP/s',
+            fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and cfg.keynum <= 2559
+            per_cell = 224.0 if fused else 448.0
+            tf = cells * per_cell / (sk_ms * 1e-3) / 1e12
+            ex = cells * (1.0 if fused else 2.0) / (sk_ms * 1e-3)
+            leg['roofline_sinkhorn'] = {'kernel': ('of_iter_kernel + of_update_kernel (one recomputation per iteration)' if fused else 'of_pass_kernel + of_update_kernel (two passes per iteration)') +
+                                                  ': 100 iterations per stacked group of pairs; <s_i, t_j> + potentials + dustbins from seven fp16 MFMAs per 32 x 32 tile, then exponentiated; '
+                                                  'the coupling matrix is never read', 'bound': 'l2-fragment-traffic' if fused else 'mfma', 'unit': 'TFLOP/s',
                                         'launch_groups': sk_n, 'avg_ms': sk_ms / sk_n, 'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1),
                                         'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': tf / PEAK_BF16_MFMA_TFLOPS,
-                                        'exponentials_per_s': ex, 'exponential_peak_per_s': 256 * 4 * 16 / 4 * 2.4e9,
-                                        'exponential_frac': ex / (256 * 4 * 16 / 4 * 2.4e9),
+                                        'executed_mfma_flop_per_element_and_iteration': per_cell,
+                                        'exponentials_per_s': ex, 'exponential_peak_per_s': 256 * 4 * 16 / 2 * 2.4e9,
+                                        'exponential_frac': ex / (256 * 4 * 16 / 2 * 2.4e9),
+                                        'l2_fragment_bytes_per_s': cells * 5.0 / (sk_ms * 1e-3) if fused else None,
                                         'hbm_bytes_not_read': work.get('sinkhorn_bytes', 0.0),
-                                        'note': 'executed MFMA flop = 448 per matrix element and iteration (three fp16 cross products x K = 32, one K = 16 block of potentials / '
-                                                'dustbins, two passes); the materialised iteration (ROREG_OT_RECOMPUTE=0) read 4 (m+1)(n+1) bytes per pair and iteration from HBM '
-                                                'instead: 0.57 of HBM peak, 0.43-0.49 ms per pair at keynum 2500'}
+                                        'note': 'v_exp_f32 issues at half rate on gfx950 (SQ_ACTIVE_INST_VALU, profiles/r04_sinkhorn_fused_pmc.txt); the materialised iteration '
+                                                '(ROREG_OT_RECOMPUTE=0) read 4 (m+1)(n+1) bytes per pair and iteration from HBM instead: 0.57 of HBM peak, 0.57-0.59 ms per pair at keynum 2500'}
         elif sk_n:
             gbs = work.get('sinkhorn_bytes', 0.0) / (sk_ms * 1e-3) / 1e9
             leg['roofline_sinkhorn'] = {'kernel': 'ot_fused_pass_kernel + ot_col_merge_kernel (100 iterations per stacked group of pairs; row log-sum-exp and column sums from ONE '

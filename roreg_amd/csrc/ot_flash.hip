@@ -22,6 +22,11 @@
 //
 // Per element and iteration: 2 x (7/1024 MFMA + v_exp_f32 + v_add_f32) against one 4-byte HBM read + ~10 vector instructions before.
 // The read-out (arg-max of Z + u + v over rows and columns) still runs on a matrix built once per pair (rm.hip).
+//
+// Two forms of the iteration.  of_pass_kernel + of_update_kernel, twice per iteration (rows, then columns): any size.  of_iter_kernel
+// (target clouds of <= 2559 points -- every shipped configuration): ONE recomputation per iteration, a 32-row strip's exponentials stay in
+// registers between its row sums and its share of the column sums (details at the kernel).  A group of pairs takes one form or the
+// other as a whole (by its longest target cloud); within a form every sum associates independently of what is stacked beside a pair.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -135,11 +140,15 @@ __device__ __forceinline__ float dpp_mov(float x) {
 }
 // reductions over the 32 lanes of each half of the wave (the 32 columns of an accumulator row); the result is valid in lanes 16..31 (first
 // half) and 48..63 (second half)
+template <int CTRL>
+__device__ __forceinline__ float dpp_all(float x) {     // every lane has a source under these controls: old = 0 + bound_ctrl lets the compiler fold the move into the add (v_add_f32_dpp)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float half_sum(float x) {
-    x += dpp_mov<0xB1, 0xf>(x);                 // quad_perm [1,0,3,2]
-    x += dpp_mov<0x4E, 0xf>(x);                 // quad_perm [2,3,0,1]
-    x += dpp_mov<0x141, 0xf>(x);                // row_half_mirror
-    x += dpp_mov<0x140, 0xf>(x);                // row_mirror: every lane of a 16-lane row holds the row's sum
+    x += dpp_all<0xB1>(x);                      // quad_perm [1,0,3,2]
+    x += dpp_all<0x4E>(x);                      // quad_perm [2,3,0,1]
+    x += dpp_all<0x141>(x);                     // row_half_mirror
+    x += dpp_all<0x140>(x);                     // row_mirror: every lane of a 16-lane row holds the row's sum
     const float t = dpp_mov<0x142, 0xa>(x);     // row_bcast:15 -> rows 1 and 3 receive the previous row's sum
     return ((threadIdx.x >> 4) & 1) ? x + t : x;
 }
@@ -317,13 +326,13 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
         for (int c = 0; c < nch_pair; ++c) mx = fmaxf(mx, part[(size_t)c * a.pot_stride]);
         np = mx > -__builtin_inff() && mx < __builtin_inff() ? -mx : 0.f;
     } else {
-        float S = 0.f;                                            // partial sums added in order; 16 independent loads in flight at a time
-        for (int c0 = 0; c0 < nch_pair; c0 += 16) {                // (of_iter_kernel leaves up to 80 of them per column)
-            float v[16];
+        float S = 0.f;                                            // partial sums added in order; 40 independent loads in flight at a time (the launch is
+        for (int c0 = 0; c0 < nch_pair; c0 += 40) {                //  one small workgroup per CU: latency-bound; of_iter_kernel leaves up to 80 per column)
+            float v[40];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = c0 + q < nch_pair ? __builtin_nontemporal_load(part + (size_t)(c0 + q) * a.pot_stride) : 0.f;
+            for (int q = 0; q < 40; ++q) v[q] = c0 + q < nch_pair ? __builtin_nontemporal_load(part + (size_t)(c0 + q) * a.pot_stride) : 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) if (c0 + q < nch_pair) S += v[q];
+            for (int q = 0; q < 40; ++q) if (c0 + q < nch_pair) S += v[q];
         }
         const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
         if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
 // underflowed, or non-finite input -- makes the workgroup redo its strip with the row maxima as stabilisers (mode 1 = max_j acc,
 // mode 2 = E = 2^(acc - M_i), f_i = mu_i / S_i).  Valid for <= 80 column tiles (2559 target points).
 constexpr int OF_FW = 8, OF_FT = 10;
-template <int NT, int VAR = 0>       // VAR: ablations for measurements only (ROREG_OT_FVAR): 1 no exponentials, 2 no MFMAs, 3 no fragment loads in the loop, 5 no row update
+template <int NT, int VAR = 0>       // VAR: ablations for measurements only (ROREG_OT_FVAR): 1 no exponentials, 2 no MFMAs, 4 every fragment fetched twice, 5 no row update
 __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts) {
     const int pair = blockIdx.y, tA = blockIdx.x;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (w in a scalar register: tile addresses are scalar)
@@ -377,9 +386,13 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
     float red[16];
     f16x8 B[OF_PLANES];
     auto load_plane = [&](int k, int p) {                          // plane p of the wave's k-th tile (scalar base + the lane's offset)
-        if (VAR == 3 && k > 0) return;
         const f16x8 *src = fb + (size_t)min(w + OF_FW * k, tilesB) * OF_PLANES * 64;
         B[p] = src[p * 64 + lane];
+        if (VAR == 4) {                                            // (measurement only: the same traffic twice -- a second fetch of another tile's plane, result unused)
+            const f16x8 *src2 = fb + (size_t)min(w + OF_FW * ((k + 3) % NT), tilesB) * OF_PLANES * 64;
+            f16x8 dummy = src2[p * 64 + lane];
+            asm volatile("" :: "v"(dummy));
+        }
     };
     // A tile's chain of 7 MFMAs.  Order: each fragment plane of B in consecutive links, so that its registers can be reloaded for the NEXT tile
     // right behind its last use -- one fragment buffer, and every plane is requested 5-7 links before the chain that needs it.
@@ -599,7 +612,7 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
                                               of_iter_kernel<6>, of_iter_kernel<7>, of_iter_kernel<8>, of_iter_kernel<9>, of_iter_kernel<10>};
             const int nt = (int)(tb + OF_FW - 1) / OF_FW;                   // column tiles per wave
             Kern kern = by_nt[nt - 1];
-            if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 3 ? of_iter_kernel<OF_FT, 3> : of_iter_kernel<OF_FT, 5>;
+            if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : of_iter_kernel<OF_FT, 5>;
             hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts);
             hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, 1, 3, alpha);
             continue;

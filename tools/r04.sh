@@ -5,6 +5,7 @@
 #   bash tools/r04.sh config4 [tag]                        -> kernel trace + PMC passes of BASELINE configs[3]'s path (RD + RM + yohoo, 16 clouds / 60 pairs)
 #   bash tools/r04.sh bench [tag] [extra bench args]       -> the driver's bench command -> gpurun_out/r04/bench_<tag>.json
 #   bash tools/r04.sh profile [tag]                        -> kernel trace + PMC passes of the bench command (profiles/r04_*)
+#   bash tools/r04.sh ot [tag]                             -> kernel trace + PMC passes of 30 stacked 2500 x 2500 Sinkhorn problems (tools/time_sinkhorn.py)
 #   bash tools/r04.sh final                                -> build, smoke, full gpu suite, bench, forced bench
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/r04; mkdir -p $OUT
@@ -32,6 +33,18 @@ pmc() {  # pmc <name> <python args...>: one pass per counter group -> $OUT/<name
 }
 
 case $cmd in
+ot)
+  tag=${1:-ot}
+  kt sinkhorn_$tag tools/time_sinkhorn.py 2500 30
+  grep -E "of_|ot_fused|calls" $OUT/sinkhorn_${tag}_kernel_trace.txt | cut -c1-150
+  rm -rf $OUT/pmc_sk; i=0
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_sk/g$i -- python3 tools/time_sinkhorn.py 2500 30 > $OUT/pmc_sk_g$i.log 2>&1 || tail -3 $OUT/pmc_sk_g$i.log
+  done
+  python3 tools/pmc_kernel_means.py $OUT/pmc_sk > $OUT/sinkhorn_${tag}_pmc.txt
+  grep -E "of_iter|of_update|ot_fused" -A14 $OUT/sinkhorn_${tag}_pmc.txt | head -80
+  rm -rf $OUT/pmc_sk ;;
 tests)
   tag=$(echo "$1" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40)
   timeout 2400 python -m pytest tests -m gpu -x -q -k "$1" > $OUT/pytest_$tag.log 2>&1; echo "pytest rc $?"; tail -5 $OUT/pytest_$tag.log ;;
