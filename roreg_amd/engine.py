@@ -323,11 +323,16 @@ class RegistrationEngine:
         rows, o = [], 0
         for _, _, s0, s1 in jobs:
             rows.append((flat_dev[o:o + len(s0)], flat_dev[o + len(s0):o + len(s0) + len(s1)])); o += len(s0) + len(s1)
+        # groups of at most max_points stacked points, EVEN in size (100 pairs of 2500 points: 4 x 25, not 32 + 32 + 32 + 4 -- a group of four
+        # leaves most of the chip idle; a pair's results do not depend on what is stacked beside it)
+        size = [max(len(s0), len(s1)) for _, _, s0, s1 in jobs]
+        n_groups = max(1, -(-sum(size) // max_points))
+        target = sum(size) / n_groups
         issued, i = [], 0
         while i < len(jobs):
             j, pts = i, 0
-            while j < len(jobs) and (j == i or pts + max(len(jobs[j][2]), len(jobs[j][3])) <= max_points):
-                pts += max(len(jobs[j][2]), len(jobs[j][3])); j += 1
+            while j < len(jobs) and (j == i or (pts + size[j] <= max_points and pts + size[j] / 2 <= target)):
+                pts += size[j]; j += 1
             seg_s = hip.Segments([len(jobs[q][3]) for q in range(i, j)]); seg_t = hip.Segments([len(jobs[q][2]) for q in range(i, j)])
             se = torch.empty((seg_s.total, 32, 60), dtype=self.feat_dtype, device='cuda'); te = torch.empty((seg_t.total, 32, 60), dtype=self.feat_dtype, device='cuda')
             sk = torch.empty((seg_s.total, 3), dtype=torch.float64, device='cuda'); tk = torch.empty((seg_t.total, 3), dtype=torch.float64, device='cuda')
