@@ -282,6 +282,51 @@ def test_sinkhorn_recomputed_on_the_matrix_cores_equals_the_materialised_iterati
         o0 += m; o1 += n
 
 
+def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
+    """of_iter_kernel (one recomputation per iteration, csrc/ot_flash.hip) over its template range: 1 ... 10 column tiles per wave, ragged
+    pairs in one call (tiles a pair does not have read the pad tile).  (a) A pair's matches AND scores are bitwise the same stacked and
+    alone -- alone the kernel is another instantiation (tiles per wave follow the call's longest target cloud), so this is the
+    association-independence the kernel promises; (b) against the materialised iteration: matches identical where the arg-max is decided,
+    scores to 5e-5; (c) a call with a target cloud above 2559 points takes the two-pass form and meets the same bar."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(41)
+    sizes = [(2500, 2500), (700, 1200), (1200, 700), (20, 300), (2500, 90)]
+    S, T = [], []
+    for m, n in sizes:
+        s = rng.standard_normal((m, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((n, 32)).astype(np.float32) * 0.5
+        k = min(m, n) // 2
+        t[:k] = s[:k] * 3 + rng.standard_normal((k, 32)).astype(np.float32) * 0.05
+        S.append(s); T.append(t)
+
+    def run(idx, recompute):
+        seg_s = hip.Segments([sizes[q][0] for q in idx]); seg_t = hip.Segments([sizes[q][1] for q in idx])
+        out = hip.sinkhorn_batch(cu(np.concatenate([S[q] for q in idx])), cu(np.concatenate([T[q] for q in idx])), seg_s, seg_t, 1.5, 100, recompute=recompute)
+        return [x.cpu().numpy() for x in out], seg_s.host, seg_t.host
+
+    (a0, a1, as0, as1), hs, ht = run(range(len(sizes)), True)
+    (b0, b1, bs0, bs1), _, _ = run(range(len(sizes)), False)
+    for q, (m, n) in enumerate(sizes):
+        (c0, c1, cs0, cs1), _, _ = run([q], True)
+        o0, o1 = hs[q], ht[q]
+        assert np.array_equal(a0[o0:o0 + m], c0) and np.array_equal(a1[o1:o1 + n], c1), (q, 'matches stacked vs alone')
+        assert np.array_equal(as0[o0:o0 + m], cs0) and np.array_equal(as1[o1:o1 + n], cs1), (q, 'scores stacked vs alone')
+        same = a0[o0:o0 + m] == b0[o0:o0 + m]
+        assert same.mean() > 0.995 and (a0[o0:o0 + m] >= 0).sum() >= min(m, n) // 2 - 5, (q, same.mean())          # (near-ties may fall either way between two arithmetics)
+        assert np.abs(as0[o0:o0 + m][same] - bs0[o0:o0 + m][same]).max() < 5e-5, q
+    # (c) one target cloud of 2600 points: the whole call runs of_pass_kernel twice per iteration
+    s = rng.standard_normal((300, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((2600, 32)).astype(np.float32) * 0.5
+    t[:150] = s[:150] * 3
+    seg_s = hip.Segments([300, sizes[1][0]]); seg_t = hip.Segments([2600, sizes[1][1]])
+    cs, ct = cu(np.concatenate([s, S[1]])), cu(np.concatenate([t, T[1]]))
+    d = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=True)]
+    e = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=False)]
+    same = d[0] == e[0]
+    assert same.mean() > 0.995 and (d[0][:300] >= 0).sum() >= 145 and np.abs(d[2][same] - e[2][same]).max() < 5e-5
+    # the 700 x 1200 pair, whichever form ran it: same matches, scores to 2e-5
+    m, n = sizes[1]
+    assert (d[0][300:] == a0[hs[1]:hs[1] + m]).mean() > 0.995 and np.abs(d[2][300:] - as0[hs[1]:hs[1] + m])[d[0][300:] == a0[hs[1]:hs[1] + m]].max() < 2e-5
+
+
 def test_sinkhorn_recomputed_survives_non_finite_and_huge_descriptors():
     """No fault and no hang on NaN / inf / 1e6-sized descriptors (the fp16 operands overflow: those pairs' results are meaningless, as the
     reference's would be); a healthy pair stacked beside them is unaffected."""
