@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
             for (int r = r0; r < r1; ++r) {
                 if (mode == 0) {                                   // (inline assembly: the exponential replaces its operand IN PLACE -- no second copy of a tile's 16 registers)
                     float x = E[k][r];
-                    if (VAR != 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+                    if (VAR != 1) asm volatile("v_exp_f32 %0, %0\n\ts_nop 0" : "+v"(x));      // (+ the wait state a VALU reader of a transcendental's result needs on gfx940+: the hazard recogniser does not look inside)
                     else x = fabsf(x) * 1e-4f + 1e-4f;
                     E[k][r] = x;
                     red[r] += x;
