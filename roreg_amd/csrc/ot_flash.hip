@@ -408,6 +408,9 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[r] = mode == 1 ? -__builtin_inff() : 0.f;
         auto post = [&](int k, int r0, int r1) {                   // the vector-pipe part of tile k, accumulator registers r0 .. r1 - 1
+            // (tile k's chain ended one link ago: 8 passes + the next link's issue slot = 9 wait states, the hazard table wants 11 between an
+            //  8-pass MFMA and a VALU reader of its result, and the compiler does not count an inline-assembly reader)
+            if (mode == 0 && r0 == 0) asm volatile("s_nop 3");
 #pragma unroll
             for (int r = r0; r < r1; ++r) {
                 if (mode == 0) {                                   // (inline assembly: the exponential replaces its operand IN PLACE -- no second copy of a tile's 16 registers)
