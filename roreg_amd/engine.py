@@ -10,6 +10,8 @@ the result table.
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 import torch
 
@@ -119,9 +121,11 @@ class RegistrationEngine:
         self.rd = rd_net            # detector_eqv_test (needed when cfg.RD)
         self.rm = rm_net            # Match_ot (needed when cfg.RM)
         hip.ensure_tables()
-        self.rm_max_points = 80000  # points per side stacked into one pass of the rotation-coherence matcher (32 pairs at keynum 2500)
+        # points per side stacked into one pass of the rotation-coherence matcher: 104 pairs at keynum 2500 (~6 GB of Sinkhorn read-out matrices and
+        # activations).  Measured on BASELINE configs[3]'s chunk (24 clouds / 100 pairs, one box): 80,000 -> 572-591 pairs/s, 160,000 -> 609-616,
+        # 260,000 -> 629-633: every kernel of the matcher fills the chip better, the Sinkhorn iterations drop from 0.37 to 0.32 ms per pair
+        self.rm_max_points = int(os.environ.get('ROREG_RM_MAX_POINTS', 260000))
         self.feat_dtype = torch.bfloat16 if getattr(cfg, 'dtype', 'fp32') == 'bf16' else torch.float32
-        import os
         self.extract_rows = int(os.environ.get('ROREG_EXTRACT_ROWS', 65536))    # keypoints per extractor launch (activations: ~370 KB per keypoint at peak)
         self.lt_rows = int(os.environ.get('ROREG_LT_ROWS', 131072))                  # correspondences per pass of the ET network (local_transforms_many)
         self.phase_ms = None        # set to {} to collect synchronised wall times per phase of run_scene (diagnostics only)
