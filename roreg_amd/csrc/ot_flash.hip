@@ -342,6 +342,41 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
     store_pieces(a, pair, i, np, slot0);
 }
 
+// The column update behind of_iter_kernel: up to 80 strip sums per column.  of_update_kernel (one thread per column) spends its time waiting
+// for them -- 24 MB per 30 pairs just written by other XCDs, ~300 small workgroups on the chip -- so here FOUR waves share a block of 64
+// columns, wave q adds the q-th quarter of the strips (in order), and wave 0 adds the four quarter sums ((q0 + q1) + (q2 + q3)): four
+// times the loads in flight, the association a function of the pair's own strip count alone.
+__global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int nparts, float alpha) {
+    const int pair = blockIdx.y;
+    const int lenA = a.seg[pair + 1] - a.seg[pair];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 > lenA) return;
+    __shared__ float s_q[4][64];
+    const int n = (b.seg[pair + 1] - b.seg[pair]) / 32 + 1;            // the strips this pair really has
+    const int per = (n + 3) / 4, c0 = q * per, c1 = min(c0 + per, n);
+    float S = 0.f;
+    if (i <= lenA) {
+        const float *part = a.part + pair * (a.pot_stride * nparts) + i;
+        float v[20];                                                  // (per <= 20: at most 80 strips)
+#pragma unroll
+        for (int k = 0; k < 20; ++k) v[k] = c0 + k < c1 ? __builtin_nontemporal_load(part + (size_t)(c0 + k) * a.pot_stride) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) if (c0 + k < c1) S += v[k];
+    }
+    s_q[q][lane] = S;
+    __syncthreads();
+    if (q != 0 || i > lenA) return;
+    S = (s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]);
+    float *pot = a.pot + pair * a.pot_stride;
+    const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
+    float np;
+    if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
+    else np = exact_potential(a, b, pair, i, alpha, lmu);
+    pot[i] = np;
+    store_pieces(a, pair, i, np, 3);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // One WHOLE iteration per launch (+ the column update): the exponentials of a 32-row strip stay in registers between the row sums and
 // the column sums, so the scores are recomputed once per iteration instead of twice.
@@ -617,7 +652,7 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
             Kern kern = by_nt[nt - 1];
             if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : of_iter_kernel<OF_FT, 5>;
             hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts);
-            hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, 1, 3, alpha);
+            hipLaunchKernelGGL(of_update_cols_kernel, dim3((max_n + 64) / 64, n_seg), dim3(256), 0, s, B, A, nparts, alpha);
             continue;
         } else if (variant == 4) {                       // passes only (no update launches)
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
