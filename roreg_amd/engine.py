@@ -113,6 +113,24 @@ class StageFileWriter:
             raise self.error
 
 
+def even_groups(sizes, cap):
+    """Consecutive groups [(i, j)] of `sizes` whose sums stay <= cap (a single item above the cap is a group of its own), EVEN in size:
+    100 pairs of 2500 points under a cap of 80,000 are 4 x 25, not 32 + 32 + 32 + 4 -- a small last group leaves most of the chip idle, and
+    a pair's results do not depend on what is stacked beside it."""
+    sizes = [int(x) for x in sizes]
+    if not sizes:
+        return []
+    n_groups = max(1, -(-sum(sizes) // int(cap)))
+    target = sum(sizes) / n_groups
+    out, i = [], 0
+    while i < len(sizes):
+        j, pts = i, 0
+        while j < len(sizes) and (j == i or (pts + sizes[j] <= cap and pts + sizes[j] / 2 <= target)):
+            pts += sizes[j]; j += 1
+        out.append((i, j)); i = j
+    return out
+
+
 class RegistrationEngine:
     def __init__(self, cfg, gf_net, et_net, rd_net=None, rm_net=None):
         self.cfg = cfg
@@ -327,16 +345,8 @@ class RegistrationEngine:
         rows, o = [], 0
         for _, _, s0, s1 in jobs:
             rows.append((flat_dev[o:o + len(s0)], flat_dev[o + len(s0):o + len(s0) + len(s1)])); o += len(s0) + len(s1)
-        # groups of at most max_points stacked points, EVEN in size (100 pairs of 2500 points: 4 x 25, not 32 + 32 + 32 + 4 -- a group of four
-        # leaves most of the chip idle; a pair's results do not depend on what is stacked beside it)
-        size = [max(len(s0), len(s1)) for _, _, s0, s1 in jobs]
-        n_groups = max(1, -(-sum(size) // max_points))
-        target = sum(size) / n_groups
-        issued, i = [], 0
-        while i < len(jobs):
-            j, pts = i, 0
-            while j < len(jobs) and (j == i or (pts + size[j] <= max_points and pts + size[j] / 2 <= target)):
-                pts += size[j]; j += 1
+        issued = []
+        for i, j in even_groups([max(len(s0), len(s1)) for _, _, s0, s1 in jobs], max_points):
             seg_s = hip.Segments([len(jobs[q][3]) for q in range(i, j)]); seg_t = hip.Segments([len(jobs[q][2]) for q in range(i, j)])
             se = torch.empty((seg_s.total, 32, 60), dtype=self.feat_dtype, device='cuda'); te = torch.empty((seg_t.total, 32, 60), dtype=self.feat_dtype, device='cuda')
             sk = torch.empty((seg_s.total, 3), dtype=torch.float64, device='cuda'); tk = torch.empty((seg_t.total, 3), dtype=torch.float64, device='cuda')
@@ -350,7 +360,6 @@ class RegistrationEngine:
             hip.gather_rows_batch(gf); hip.gather_rows_batch(gk)
             with torch.no_grad():
                 issued += self.rm.match_stacked(se.float(), te.float(), sk.float(), tk.float(), seg_s, seg_t)   # (bf16 rows: lossless up-cast)
-            i = j
         m0_all = torch.cat([m for m, _ in issued]).cpu().numpy()            # the one sync of the matcher stage
         sc_all = torch.cat([s for _, s in issued]).cpu().numpy()
         out, o = [], 0

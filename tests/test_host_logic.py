@@ -490,3 +490,22 @@ def test_rr_cal_benchmark_matches_reference(tmp_path):
     assert np.abs(np.array(errors['synth/scene0']) - z['errors']).max() < 1e-9
     got = (tmp_path / 'cache' / 'synth' / 'Eval_results' / 'yohoo_RR' / '1000iters' / 'result.txt').read_text()
     assert got == z['result_txt'].tobytes().decode()
+
+
+def test_even_groups_of_the_stacked_matcher():
+    """engine.even_groups: consecutive, covering, capped (a lone item above the cap is its own group), and even -- the cut that replaced
+    32 + 32 + 32 + 4 by 4 x 25."""
+    from roreg_amd.engine import even_groups
+    assert even_groups([], 10) == []
+    assert even_groups([2500] * 100, 80000) == [(0, 25), (25, 50), (50, 75), (75, 100)]
+    assert even_groups([2500] * 100, 260000) == [(0, 100)]
+    assert even_groups([2500] * 33, 80000) == [(0, 17), (17, 33)]
+    assert even_groups([2500, 100, 90000, 2500, 2500], 80000) == [(0, 2), (2, 3), (3, 5)]
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        sizes = rng.integers(1, 3000, size=int(rng.integers(1, 60))).tolist()
+        cap = int(rng.integers(500, 20000))
+        g = even_groups(sizes, cap)
+        assert g[0][0] == 0 and g[-1][1] == len(sizes) and all(a[1] == b[0] for a, b in zip(g, g[1:])) and all(i < j for i, j in g)
+        assert all(sum(sizes[i:j]) <= cap or j - i == 1 for i, j in g)
+
