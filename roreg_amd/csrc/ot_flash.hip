@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int
 // (NT from the group's longest target cloud; tiles beyond a pair's own are the PAD tile of_prep_kernel writes behind the pair's last
 // one: padding potentials, exponentials exactly 0, so the code has no branches and every sum the same association whatever NT is):
 // 160 accumulator registers per lane hold the wave's part of E (2 waves per SIMD, <= 256 VGPRs).  The strip's column sums go to
-// part[strip][column] of side B and of_update_kernel adds the strips in order (cht = 1): fixed association, independent of what is
+// part[strip][column] of side B and of_update_cols_kernel adds the strips in a fixed order: an association independent of what is
 // stacked beside the pair.  Rows beyond the dustbin have E = 0 and are not updated.  A row whose sum left (1e-35, 1e35) -- every term
 // underflowed, or non-finite input -- makes the workgroup redo its strip with the row maxima as stabilisers (mode 1 = max_j acc,
 // mode 2 = E = 2^(acc - M_i), f_i = mu_i / S_i).  Valid for <= 80 column tiles (2559 target points).
