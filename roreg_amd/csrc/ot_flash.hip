@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int
 // underflowed, or non-finite input -- makes the workgroup redo its strip with the row maxima as stabilisers (mode 1 = max_j acc,
 // mode 2 = E = 2^(acc - M_i), f_i = mu_i / S_i).  Valid for <= 80 column tiles (2559 target points).
 constexpr int OF_FW = 8, OF_FT = 10;
-template <int NT, int VAR = 0>       // VAR: ablations for measurements only (ROREG_OT_FVAR): 1 no exponentials, 2 no MFMAs, 4 every fragment fetched twice, 5 no row update
+template <int NT, int VAR = 0>       // VAR: ablations for measurements only (ROREG_OT_FVAR): 1 no exponentials, 2 no MFMAs, 4 every fragment fetched twice, 5 no row update; 6 (tests) every strip through the stabilised redo
 __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts) {
     const int pair = blockIdx.y, tA = blockIdx.x;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (w in a scalar register: tile addresses are scalar)
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
 #pragma unroll
         for (int q = 0; q < OF_FW; ++q) S += s_part[q][lane & 31];
         const bool ok = S > 1e-35f && S < 1e35f;
-        redo = __any(row_valid && !ok);                            // (identical in all eight waves)
+        redo = VAR == 6 || __any(row_valid && !ok);                // (identical in all eight waves; VAR 6: the stabilised redo for EVERY strip -- tests only)
         if (!redo && row_valid) {
             const float np = old + (lmu - __log2f(S));             // u + log2 mu - log2 sum_j 2^(Z' + u + v)
             frow = __builtin_amdgcn_exp2f(np - old);               // E f = 2^(Z' + u_new + v)
@@ -650,7 +650,7 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
                                               of_iter_kernel<6>, of_iter_kernel<7>, of_iter_kernel<8>, of_iter_kernel<9>, of_iter_kernel<10>};
             const int nt = (int)(tb + OF_FW - 1) / OF_FW;                   // column tiles per wave
             Kern kern = by_nt[nt - 1];
-            if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : of_iter_kernel<OF_FT, 5>;
+            if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : fvar == 6 ? of_iter_kernel<OF_FT, 6> : of_iter_kernel<OF_FT, 5>;
             hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts);
             hipLaunchKernelGGL(of_update_cols_kernel, dim3((max_n + 64) / 64, n_seg), dim3(256), 0, s, B, A, nparts, alpha);
             continue;

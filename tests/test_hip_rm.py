@@ -327,6 +327,34 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
     assert (d[0][300:] == a0[hs[1]:hs[1] + m]).mean() > 0.995 and np.abs(d[2][300:] - as0[hs[1]:hs[1] + m])[d[0][300:] == a0[hs[1]:hs[1] + m]].max() < 2e-5
 
 
+def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path):
+    """of_iter_kernel redoes a strip with the row maxima as stabilisers when a row's sum leaves (1e-35, 1e35) -- which finite, sanely scaled
+    input never provokes.  ROREG_OT_FVAR=6 (read once per process: a child process) sends EVERY strip through that path: same matches,
+    scores to 2e-5 against the normal path."""
+    import subprocess, sys
+    from roreg_amd import hip
+    rng = np.random.default_rng(43)
+    m = n = 2500                                                   # (10 column tiles per wave: the instantiation the switch covers)
+    s = rng.standard_normal((m, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((n, 32)).astype(np.float32) * 0.5
+    t[:1000] = s[:1000] * 3 + rng.standard_normal((1000, 32)).astype(np.float32) * 0.05
+    np.savez(tmp_path / 'in.npz', s=s, t=t)
+    code = ("import numpy as np, torch, sys\n"
+            "from roreg_amd import hip\n"
+            "z = np.load(sys.argv[1]); s = torch.from_numpy(z['s']).cuda(); t = torch.from_numpy(z['t']).cuda()\n"
+            "seg_s = hip.Segments([s.shape[0]]); seg_t = hip.Segments([t.shape[0]])\n"
+            "a0, a1, as0, as1 = hip.sinkhorn_batch(s, t, seg_s, seg_t, 1.5, 100, recompute=True)\n"
+            "np.savez(sys.argv[2], a0=a0.cpu().numpy(), a1=a1.cpu().numpy(), as0=as0.cpu().numpy(), as1=as1.cpu().numpy())\n")
+    env = dict(os.environ, ROREG_OT_FVAR='6', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / 'out.npz')
+    seg = hip.Segments([m])
+    a0, a1, as0, as1 = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(s), cu(t), seg, hip.Segments([n]), 1.5, 100, recompute=True)]
+    same = z['a0'] == a0
+    assert same.mean() > 0.998 and (a0 >= 0).sum() >= 990, same.mean()
+    assert np.abs(z['as0'][same] - as0[same]).max() < 2e-5 and np.abs(z['as1'][z['a1'] == a1] - as1[z['a1'] == a1]).max() < 2e-5
+
+
 def test_sinkhorn_recomputed_survives_non_finite_and_huge_descriptors():
     """No fault and no hang on NaN / inf / 1e6-sized descriptors (the fp16 operands overflow: those pairs' results are meaningless, as the
     reference's would be); a healthy pair stacked beside them is unaffected."""
