@@ -1119,8 +1119,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
             static_for<32>([&](auto ic) {                     // slot st*8+e holds coefficient q = 16 st + 8 h + e
                 constexpr int st = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
                 constexpr int q0 = 16 * st + e, q1 = 16 * st + 8 + e;
-                if constexpr (q1 < ROREG_G) dst[st * 8 + e] = p.Xin[OFF_OF(q0, q1, c, tb) + jn];
-                else dst[st * 8 + e] = p.Xin[OFF_Q(q0, c, tb) + jn];      // q1 does not exist: the second half-wave's copy is zeroed at use
+                // (streamed once: non-temporal loads and stores -- the transforms' time 310.1 -> 307.2 ms per step on one box; the same hint on the
+                //  GEMM epilogue's stores and residual loads changed nothing)
+                if constexpr (q1 < ROREG_G) dst[st * 8 + e] = __builtin_nontemporal_load(p.Xin + OFF_OF(q0, q1, c, tb) + jn);
+                else dst[st * 8 + e] = __builtin_nontemporal_load(p.Xin + OFF_Q(q0, c, tb) + jn);      // q1 does not exist: the second half-wave's copy is zeroed at use
             });
         } else {
             static_for<30>([&](auto ic) {
@@ -1417,14 +1419,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                     const auto pr = __builtin_amdgcn_permlane16_swap(own, own, false, false);
                     const unsigned word = __builtin_amdgcn_perm(pr[1], pr[0], sel);
                     unsigned *dst = reinterpret_cast<unsigned *>(const_cast<char *>(slot_ptr(ic, p.Xout, c, tb)));
-                    if (kPS.kind[S] != 2 || h == 0) *dst = word;          // (no member b: the second half-wave is masked off, the store is still issued)
+                    if (kPS.kind[S] != 2 || h == 0) __builtin_nontemporal_store(word, dst);          // (no member b: the second half-wave is masked off, the store is still issued)
                 });
             } else {
                 const int tb = tbi;                           // pad keypoints (b >= B) get zeros: the buffers stay fully defined
                 static_for<32>([&](auto ic) {
                     constexpr int S = decltype(ic)::value, t = S / 16, r = S % 16;
                     float *dst = reinterpret_cast<float *>(const_cast<char *>(slot_ptr(ic, p.Xout, c, tb)));
-                    if (kPS.kind[S] != 2 || h == 0) *dst = o[t][r];
+                    if (kPS.kind[S] != 2 || h == 0) __builtin_nontemporal_store(o[t][r], dst);
                 });
             }
         }
