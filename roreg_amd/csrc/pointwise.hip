@@ -172,10 +172,10 @@ __device__ __forceinline__ void et_gather_body(const void *__restrict__ before0_
         const int c = i / ROREG_G, g = i - c * ROREG_G;
         const int pg = c * ROREG_G + perm[g];
         const float v0 = (float)s_b1[pg], v1 = (float)s_b0[i], v2 = (float)s_a1[pg], v3 = (float)s_a0[i];
-        dst[i] = v0;
-        dst[ROREG_F * ROREG_G + i] = v1;
-        dst[2 * ROREG_F * ROREG_G + i] = v2;
-        dst[3 * ROREG_F * ROREG_G + i] = v3;
+        __builtin_nontemporal_store(v0, dst + i);                  // (streamed: ET's first transform reads the row after gigabytes of other rows)
+        __builtin_nontemporal_store(v1, dst + ROREG_F * ROREG_G + i);
+        __builtin_nontemporal_store(v2, dst + 2 * ROREG_F * ROREG_G + i);
+        __builtin_nontemporal_store(v3, dst + 3 * ROREG_F * ROREG_G + i);
         if (bound_row) {       // the row's bound for the fp16 x 2 split of FT(ReLU(BN(x))): what roreg_row_bound computes, without re-reading x
             mx = fmaxf(mx, fmaxf(fmaf(v0, bn_scale[c], bn_shift[c]), 0.f));
             mx = fmaxf(mx, fmaxf(fmaf(v1, bn_scale[ROREG_F + c], bn_shift[ROREG_F + c]), 0.f));
