@@ -216,8 +216,10 @@ DTYPE_OF = {'f16x2': 'f32 (every f32 operand enters the fp16 matrix cores as hi 
             'bf16x3': 'f32 (f32-accurate: every f32 operand as 3 bf16 pieces = 24 bits, 6 cross products, f32 accumulate); f64 estimator',
             'f32': 'f32 (f32-input MFMA, f32 accumulate); f64 estimator'}
 MFMAS_PER_PRODUCT = {'f16x2': 3, 'bf16x3': 6}
-KERNEL_OF = {'f16x2': 'irrep_gemm_xdma_kernel<1> (8-wave 256 x 256 tile, activations global -> LDS by DMA and LDS -> fragments by transposing reads; GF 256->512 / 512->256 in the '
+KERNEL_OF = {'f16x2': 'irrep_gemm_xdma16_kernel<1> (8-wave 256 x 256 tile, v_mfma_f32_16x16x32_f16 on K = 32 steps, activations and weights global -> LDS by DMA into rings '
+                      'that take the whole LDS, LDS -> fragments by transposing reads, epilogue through LDS with 16-byte stores; GF 256->512 / 512->256 in the '
                       'irrep domain, fp16 x 2 operands pre-split by ft_nonlin under per-keypoint block scales: 3 fp16 MFMAs per product)',
+             'f16x2-mfma32': 'irrep_gemm_xdma_kernel<1> (ROREG_GEMM_MFMA16=0: the same operands and LDS images under v_mfma_f32_32x32x16_f16, K = 16 steps; bitwise the register-staged kernel)',
              'bf16x3': 'irrep_gemm_split_kernel<32,3,2,1> (GF 256->512 / 512->256 in the irrep domain, 3 x bf16 split operands: 6 bf16 MFMAs per product)',
              'f16x2-words': 'irrep_gemm_split_kernel<32,2,4,1,1> (ROREG_GEMM_XDMA=0: fragment-pipelined 8-wave loop with the activations staged through registers; GF 256->512 / '
                             '512->256 in the irrep domain, fp16 x 2 operands pre-split by ft_nonlin under per-keypoint block scales: 3 fp16 MFMAs per product)',
@@ -242,7 +244,7 @@ def roofline_obj(mode, gemm_tflops, ms, n_launch, traffic, alg_bytes):
     else:
         k = MFMAS_PER_PRODUCT[mode]
         from roreg_amd import hip
-        base.update({'kernel': KERNEL_OF['f16x2-words' if mode == 'f16x2' and not hip.use_planes(512) else mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
+        base.update({'kernel': KERNEL_OF[('f16x2-words' if not hip.use_planes(512) else 'f16x2' if hip.MFMA16 else 'f16x2-mfma32') if mode == 'f16x2' else mode], 'achieved': k * gemm_tflops, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': k * gemm_tflops / PEAK_BF16_MFMA_TFLOPS})
     return base
 
 
@@ -264,7 +266,7 @@ def kernel_source_hash():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-PMC_DEFAULT_CONDITIONS = {'kpts': 5000, 'dtype': 'fp32', 'gpus': 1, 'pair_lists': 'banded', 'xdma': True}
+PMC_DEFAULT_CONDITIONS = {'kpts': 5000, 'dtype': 'fp32', 'gpus': 1, 'pair_lists': 'banded', 'xdma': True, 'mfma16': True}
 
 
 def measured_traffic(args, world=1):
@@ -284,7 +286,7 @@ def measured_traffic(args, world=1):
     if j.get('kernel_source_sha16') != kernel_source_hash():
         return {'bytes': None, **src, 'refused': f'the PMC pass was collected on another kernel source (now {kernel_source_hash()})'}
     from roreg_amd import hip
-    now = {'kpts': args.kpts, 'dtype': args.dtype, 'gpus': world, 'pair_lists': args.pair_lists, 'xdma': hip.use_planes(512)}
+    now = {'kpts': args.kpts, 'dtype': args.dtype, 'gpus': world, 'pair_lists': args.pair_lists, 'xdma': hip.use_planes(512), 'mfma16': bool(hip.MFMA16)}
     then = dict(PMC_DEFAULT_CONDITIONS, **(j.get('conditions') or {}))
     diff = {k: (then.get(k), now[k]) for k in now if then.get(k) != now[k]}
     if diff:

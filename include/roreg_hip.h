@@ -470,8 +470,8 @@ int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float
                            128-byte block holds its 32 fp16 hi values followed by its 32 lo values (each half in the column order 0, 16, 1, 17, ...) instead of 32
                            words hi | lo << 16; the
                            activations then reach LDS by LDS-DMA and the matrix cores through transposing LDS reads, no register staging
-                           (needs tile_m = 256); results are
-                           bitwise those of the word layout */, void *stream);
+                           (needs tile_m = 256); x_planes = 1: 32x32x16 MFMAs, results bitwise those of the word layout; x_planes = 2 (round 4): the same
+                           operands and LDS images under v_mfma_f32_16x16x32_f16 (K = 32 per step: ~4 % faster, the same error bound, last bits differ) */, void *stream);
 /* bound_out[b] (b < round_up(B,32); 0 for pad keypoints) = sqrt(60) max_{c,g} |act(x[b,c,g])| >= every coefficient of FT(act(x[b])), act =
  * ReLU(bn_scale_c x + bn_shift_c) or the identity (bn NULL): the x_bound of a layer whose input is a group-domain tensor [B,C,60]. */
 int roreg_row_bound(const void *x_spatial, int x_bf16 /* x is bfloat16 instead of float32 */, const float *bn_scale, const float *bn_shift,

@@ -57,7 +57,8 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound
     f16x2 = (five fp16x2 weight tensors, w_exp): X_buf holds the fp16 hi/lo words ft_nonlin(split='f16x2', out_bound=x_bound) wrote under the
     per-keypoint bound x_bound [Bp]; next_bound = (u [O], v [O]) (NextBound of the following nonlinearity) additionally returns the
     per-keypoint bound [Bp] of the NEXT transform's coefficients: -> (out, bound).
-    x_planes: X_buf is in the half-block layout (ft_nonlin(..., planes=True): per 32-column block 32 fp16 hi values, then 32 lo values, columns in the order 0, 16, 1, 17, ...): the activations reach LDS by LDS-DMA; O % 256 == 0 only."""
+    x_planes: X_buf is in the half-block layout (ft_nonlin(..., planes=True): per 32-column block 32 fp16 hi values, then 32 lo values, columns in the order 0, 16, 1, 17, ...): the activations reach LDS by LDS-DMA; O % 256 == 0 only.  True: the kernel hip.MFMA16 selects
+    (default: 16x16x32 MFMAs); the integers 1 / 2 name the 32x32x16 / 16x16x32 kernel (tests)."""
     Bp = coef_pitch(B)
     if X_buf.numel() != 60 * C * Bp or (add is not None and add.numel() != 60 * O * Bp):
         raise HipError(f'irrep_gemm: coefficient buffers must hold 60*C*{Bp} floats (B={B} padded to the 32-keypoint pitch)')
@@ -88,7 +89,7 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound
             bound_out = torch.zeros(Bp, dtype=torch.float32, device=X_buf.device)
         _check(lib().roreg_irrep_gemm_f16x2(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(wl), _ptr(x_bound, torch.float32), int(w_exp),
                                             _ptr(nu, torch.float32), _ptr(nv, torch.float32), _ptr(bound_out), C, O, Bp,
-                                            _ptr(t, torch.int32), int(t.shape[0]), tile_m, 1 if x_planes else 0, _stream()), 'roreg_irrep_gemm_f16x2')
+                                            _ptr(t, torch.int32), int(t.shape[0]), tile_m, (int(x_planes) if x_planes in (1, 2) and x_planes is not True else (2 if _core.MFMA16 else 1)) if x_planes else 0, _stream()), 'roreg_irrep_gemm_f16x2')
     elif split is not None:
         _check(lib().roreg_irrep_gemm_split(_ptr_array(xv), _ptr_array(ov), av, _ptr_array(split), C, O, Bp, _ptr(t, torch.int32), int(t.shape[0]),
                                             _stream()), 'roreg_irrep_gemm_split')

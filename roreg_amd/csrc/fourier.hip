@@ -776,6 +776,246 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma_kernel(GemmSplitDescs 
     gemm_split_epilogue<2, 4, COLS_PAIRED>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
 }
 
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f);      // (defined with the transforms below)
+
+// Epilogue of irrep_gemm_xdma16_kernel: accumulator block (rb, cb), register r of lane (j = l % 16, q = l / 16) = tile row
+// wo * 64 + 16 rb + 4 q + r, position 16 cb + j of the wave's 128 columns (position p of a 32-column block = column p / 2 + 16 (p % 2)).
+// A lane's 16 columns per row block are scattered (32-byte runs): stored from the accumulators directly the epilogue cost 2.5 x the
+// other kernel's (2.6 ms of a 12.0 ms launch).  So every wave passes its tile through LDS, 16 rows x 128 columns at a time (the rings are
+// dead): scalar writes in accumulator order, then 16-byte reads along the rows -- lane l % 32 owns FOUR ADJACENT columns, l / 32 the row
+// parity -- and everything else happens on that side: rescale by the columns' (keypoints') and the weights' power of two, optional
+// residual (16-byte loads), 16-byte stores (1 KB per instruction: two rows x 512 contiguous bytes), optional bound of the next
+// transform (max over the rows of u_o |T| + v_o per column, merged per keypoint with atomic max: order-independent).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int wb, f32x4_t (&acc)[4][8], char *smem) {
+    constexpr int NCOL = 256, OT = 256, NT = 512, P = 132;      // P: row pitch of a wave's LDS tile in floats
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int M = p.M[irr], N = p.N[irr];
+    const int dirr = kIrrDim[irr];
+    float *__restrict__ Out = p.Out[irr];
+    const float *__restrict__ Add = p.Add[irr];
+    const bool want_bound = p.out_bound != nullptr;
+    float *su = reinterpret_cast<float *>(smem), *sv = su + OT;
+    unsigned *cm = reinterpret_cast<unsigned *>(sv + OT);
+    float *buf = reinterpret_cast<float *>(smem + 4096) + w * (16 * P);
+    int cw[8];                                                   // write side: the column (inside the wave's 128) of block cb in this lane
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        const int pp = (cb & 1) * 16 + j;
+        cw[cb] = (cb >> 1) * 32 + (pp >> 1) + 16 * (pp & 1);
+    }
+    const int rl = lane & 31, rr = lane >> 5;                    // read side: columns 4 rl .. 4 rl + 3, row parity rr
+    const int ncol = n0 + wb * 128 + 4 * rl;                     // (N % 32 == 0: the four columns are inside or outside together)
+    const bool col_ok = ncol < N;
+    float osc[4], bm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        osc[e] = col_ok ? ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(ncol + e, dirr)]) + p.w_exp)) : 1.f;
+        bm[e] = 0.f;
+    }
+    if (want_bound) {                                            // (the LDS rings are dead: the loop ended with a barrier)
+        for (int i = tid; i < OT; i += NT) {
+            const int m = mt * OT + i;
+            su[i] = m < M ? p.nb_u[m % p.O] : 0.f; sv[i] = m < M ? p.nb_v[m % p.O] : 0.f;
+        }
+        for (int i = tid; i < NCOL; i += NT) cm[i] = 0u;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[(4 * q + r) * P + cw[cb]] = acc[rb][cb][r];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row_l = 2 * it + rr;
+            const int row = wo * 64 + rb * 16 + row_l;
+            const int m = mt * OT + row;
+            const f32x4_t v = *reinterpret_cast<const f32x4_t *>(buf + row_l * P + 4 * rl);
+            if (m < M && col_ok) {
+                f32x4_t o = {v[0] * osc[0], v[1] * osc[1], v[2] * osc[2], v[3] * osc[3]};
+                const size_t off = (size_t)m * N + ncol;
+                if (Add) { const f32x4_t ad = *reinterpret_cast<const f32x4_t *>(Add + off); o = o + ad; }
+                *reinterpret_cast<f32x4_t *>(Out + off) = o;
+                if (want_bound) {
+                    const float ur = su[row], vr = sv[row];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bm[e] = fmaxf(bm[e], fmaf(ur, fabsf(o[e]), vr));
+                }
+            }
+        }
+    }
+    if (want_bound) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = fmaxf(bm[e], __shfl_xor(bm[e], 32));
+            if (rr == 0) atomicMax(cm + wb * 128 + 4 * rl + e, __float_as_uint(x));      // non-negative floats order like their bit patterns
+        }
+        __syncthreads();
+        for (int i = tid; i < NCOL; i += NT) {
+            const int n = n0 + i;
+            if (n < N) atomicMax(reinterpret_cast<unsigned *>(p.out_bound) + column_keypoint(n, dirr), cm[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_16x16x32_f16 (round 4).  Measured with a speed probe first (NOTES.md): two 16x16x32 MFMAs in place of every
+// 32x32x16 make the big layers 4.6 % faster on real operands -- an accumulator register is read and written once per 32 k instead of once per
+// 16, and on this power-limited part that is clock.  What changes against irrep_gemm_xdma_kernel:
+//   * a reduction step is K = 32 = two K16 stages of the SAME LDS images (same DMA pieces, same layouts): lane (j = l % 16, q = l / 16)
+//     carries row / column j and the k octet q of the 32, i.e. octet q % 2 of stage q / 2 -- for the weights a ds_read_b128 at a per-lane
+//     stage offset, for the activations the same two transposing reads per plane (k quads 2 (q % 2), + 1) in stage q / 2;
+//   * the wave's 64 x 128 tile is 4 x 8 blocks of 16 x 16: 96 MFMAs per step, column block by column block (12 each: the three products of
+//     the four row blocks, consecutive MFMAs independent); the NEXT column block's fragments are read under the current one's MFMAs, the
+//     next step's weight fragments one per column block, the DMA pieces of the step after next one per column block;
+//   * rings: activations 6 K16 stages (the step in use, the next one landed -- so that its first column block can be read before the
+//     step's barrier --, the one after in flight), weights 4 (the step in use sits in registers): 96 + 64 KB = the whole LDS;
+//   * accumulator block (rb, cb), register r of lane (j, q) = row 16 rb + 4 q + r, column (position) 16 cb + j of the wave's 128; a
+//     position p of a 32-column block is column p / 2 + 16 (p % 2) (ft_nonlin's half-block layout), as in the other kernel;
+//   * a k octet's 8 products are summed inside one MFMA in both kernels, but 32 k now meet in one instruction: results differ from the
+//     32x32x16 kernel's in the last bits (same error bound), so "bitwise the register-staged kernel" no longer holds for this one.
+template <int BIG>
+__global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+    using frag = f16x8;
+    using f32x4 = f32x4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCOL = 256, OT = 256;
+    constexpr int XIMG = 16 * NCOL * 2, XSTAGE = 2 * XIMG;       // bytes: one plane's K16 x 256 image; both planes
+    constexpr int ABUF = 2 * 2 * OT;                             // weight fragments per K16 stage
+    constexpr int NXS = 6, NWS = 4;
+    char *xs = smem;                                             // [6 stages][2 planes][XIMG]
+    frag *as = reinterpret_cast<frag *>(smem + NXS * XSTAGE);    // [4 stages][2 planes][2 k-octets][256 m]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
+    if (irr < 0) return;
+    const frag *__restrict__ W = reinterpret_cast<const frag *>(p.W[irr]);
+    const int K = p.K[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
+    const int wo = w % 4, wb = w / 4;
+    const int n0 = nt * NCOL;
+    const int nsteps = K / 16, nss = K / 32;                     // K % 32 == 0 (C % 32 == 0)
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- DMA, exactly the other kernel's pieces: per K16 step wave w issues activation pieces 2w, 2w + 1 and two weight pieces ----
+    const int x_plane = w >> 2;
+    const char *xsrc[2];
+    int xdst[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int mm = (2 * w + i2) & 7;
+        const int pi = mm * 64 + lane;
+        const int beta = pi >> 3, r = (pi & 7) >> 1, half = pi & 1;
+        const int k = 4 * (beta >> 4) + r;
+        int col = n0 + 16 * (beta & 15) + 8 * half;
+        if (col > N - 8) col = N - 8;
+        xsrc[i2] = reinterpret_cast<const char *>(p.X[irr]) + (size_t)k * N * 4 + (col >> 5) * 128 + x_plane * 64 + (col & 31) * 2;
+        xdst[i2] = x_plane * XIMG + mm * 1024;
+    }
+    const size_t xstep = (size_t)16 * N * 4;
+    auto dma_x = [&](int i2, int kstep) {
+        const char *src = xsrc[i2] + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * xstep;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(xs + (kstep % NXS) * XSTAGE + xdst[i2]), 16, 0, 0);
+    };
+    const frag *wsrc = W + (size_t)(tid / OT) * Mpad + mt * OT + (tid % OT);
+    auto dma_w = [&](int sp, int kstep) {
+        const frag *src = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + sp * split_stride),
+                                         (__attribute__((address_space(3))) void *)(as + (kstep % NWS) * ABUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+    };
+    // ---- fragment addresses ----
+    // weights of step S: stage (2 S + q / 2) % 4, octet q % 2, row wo * 64 + rb * 16 + j
+    const int a_lane = (q >> 1) * ABUF + (q & 1) * OT + wo * 64 + j;               // + (S % 2) * 2 * ABUF + plane * 2 * OT + rb * 16
+    // activations of step S: stage (2 S) % 6 + q / 2, k quads 2 (q % 2) and + 1, panel wb * 8 + cb, position j
+    const unsigned x_lane = (unsigned)(uintptr_t)xs + (unsigned)((q >> 1) * XSTAGE + ((2 * (q & 1)) * 16 + wb * 8) * 128 + j * 8);     // + (S % 3) * 2 * XSTAGE + plane * XIMG + cb * 128 (+ 2048)
+    frag aA[4][2], aB[4][2];
+    frag b0[2], b1[2];
+    auto read_a = [&](int S, auto rb_c, auto pl_c, frag (&a)[4][2]) {
+        constexpr int rb = decltype(rb_c)::value, pl = decltype(pl_c)::value;
+        a[rb][pl] = as[(S & 1) * 2 * ABUF + a_lane + pl * (2 * OT) + rb * 16];
+    };
+    // (inline assembly, as in the other kernel: through the builtin the compiler would guard every transposing read with vmcnt(0) against
+    //  the LDS-DMA in flight; the explicit waits carry the real dependences)
+    auto read_b = [&](unsigned xoff, auto cb_c, frag (&b)[2]) {
+        constexpr int cb = decltype(cb_c)::value;
+        const unsigned a = x_lane + xoff;
+        unsigned long long u[4];
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[0]) : "v"(a), "n"(cb * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[1]) : "v"(a), "n"(cb * 128 + 2048));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[2]) : "v"(a), "n"(XIMG + cb * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[3]) : "v"(a), "n"(XIMG + cb * 128 + 2048));
+        struct Pair { unsigned long long lo, hi; };
+        b[0] = __builtin_bit_cast(frag, Pair{u[0], u[1]});
+        b[1] = __builtin_bit_cast(frag, Pair{u[2], u[3]});
+    };
+#define ROREG_PIN_B(waits, B) asm volatile(waits : "+v"(B[0]), "+v"(B[1]) :: "memory")
+    using std::integral_constant;
+    // One K32 step S.  a = this step's weight fragments (registers); an receives step S + 1's.  Who may touch what, and when:
+    //   * column blocks 0-3 request the WEIGHTS of step S + 2 into the weight stages of step S (whose fragments were read during step S - 1),
+    //     column blocks 4-7 the ACTIVATIONS of step S + 2 into the activation stages of step S - 1;
+    //   * the one barrier of the step sits in front of column block 7, behind s_waitcnt vmcnt(3): in issue order only the three activation
+    //     pieces of blocks 4-6 may be in flight, so this step's weight pieces and everything older (the activations of step S + 1) have landed;
+    //   * behind it column block 7 reads step S + 1's first column block, and step S + 1 reads its weight fragments; in front of it lie all
+    //     reads of this step's activation stages (the last: block 7's fragments, requested in block 6) and of step S + 1's weight stages
+    //     (the eight fragments of `an`, column blocks 0-6) -- the stages the next step's DMA overwrites.
+    auto step = [&](int S, const frag (&a)[4][2], frag (&an)[4][2]) {
+        const unsigned xoff = (unsigned)((S % 3) * 2 * XSTAGE), xoff_next = (unsigned)(((S + 1) % 3) * 2 * XSTAGE);
+        static_for<8>([&](auto cb_c) {
+            constexpr int cb = decltype(cb_c)::value;
+            frag (&bc)[2] = (cb & 1) ? b1 : b0;
+            frag (&bn)[2] = (cb & 1) ? b0 : b1;
+            if constexpr (cb == 7) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+            ROREG_PIN_B("s_waitcnt lgkmcnt(0)", bc);                                  // this column block's fragments (requested one block ago)
+            auto mm = [&](int i) {                                                     // product i of the four row blocks: 0 = lo.hi, 1 = hi.lo, 2 = hi.hi
+                const frag bb = bc[i == 1 ? 1 : 0];
+                const int ai = i == 0 ? 1 : 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rb][ai], bb, acc[rb][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            // the NEXT column block's fragments are requested first: this block's twelve MFMAs cover the LDS round trip
+            if constexpr (cb < 7) read_b(xoff, integral_constant<int, cb + 1>{}, bn);
+            else read_b(xoff_next, integral_constant<int, 0>{}, bn);                                      // ... of the next step (landed: behind the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0);
+            if constexpr (cb < 4) dma_w(cb & 1, 2 * (S + 2) + (cb >> 1));
+            else dma_x(cb & 1, 2 * (S + 2) + ((cb - 4) >> 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1);
+            if constexpr (cb == 0) { read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 0>{}, an); read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 1>{}, an); }
+            else if constexpr (cb < 7) read_a(S + 1, integral_constant<int, (cb + 1) / 2>{}, integral_constant<int, (cb + 1) % 2>{}, an);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(2);
+        });
+    };
+    // ---- prologue: steps 0 and 1 (K16 stages 0-3) requested, landed; the weight fragments of step 0 and the first column block into registers ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { dma_x(0, ks); dma_x(1, ks); dma_w(0, ks); dma_w(1, ks); }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    static_for<8>([&](auto c) { read_a(0, integral_constant<int, decltype(c)::value / 2>{}, integral_constant<int, decltype(c)::value % 2>{}, aA); });
+    read_b(0u, integral_constant<int, 0>{}, b0);
+    // (the first step's DMA pieces target stages 4, 5 of the activations -- never used -- and stages 0, 1 of the weights, whose fragments
+    //  every wave must have read first)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int S = 0; S < nss; S += 2) {
+        step(S, aA, aB);
+        if (S + 1 < nss) step(S + 1, aB, aA);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the clamped look-ahead pieces still target LDS the epilogue reuses
+#undef ROREG_PIN_B
+    gemm_split_epilogue16(p, irr, mt, n0, wo, wb, acc, smem);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fp16 x 2 GEMM, 256 x 256 tile, 8 waves, "ping-pong" schedule.  The two waves that share a SIMD (w and w + 4: the two column halves of
 // the tile) alternate roles inside every K16 step instead of both interleaving matrix and memory work: after the step's barrier group 0
@@ -1650,10 +1890,14 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
         if constexpr (NP == 2 && WO == 4) {
             // activations in half-block layout (ft_nonlin out_planes), delivered by LDS-DMA: irrep_gemm_xdma_kernel
             const size_t lds_x = 3 * (2 * 16 * 256 * 2) + 2 * (2 * 2 * 256) * 16;      // three activation stages + two weight stages = 80 KB
-            auto kx = (long long)C * O == 256ll * 512 ? irrep_gemm_xdma_kernel<1> : irrep_gemm_xdma_kernel<0>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x);
+            // x_planes == 2: the 16x16x32 kernel (K = 32 steps, the whole LDS as rings); 1: the 32x32x16 kernel (bitwise the register-staged one)
+            const bool mfma16 = x_planes == 2;
+            const size_t lds_use = mfma16 ? (size_t)(6 + 4) * 16384 : lds_x;
+            auto kx = mfma16 ? ((long long)C * O == 256ll * 512 ? irrep_gemm_xdma16_kernel<1> : irrep_gemm_xdma16_kernel<0>)
+                             : ((long long)C * O == 256ll * 512 ? irrep_gemm_xdma_kernel<1> : irrep_gemm_xdma_kernel<0>);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
             if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
-            hipLaunchKernelGGL(kx, dim3(n_tiles), dim3(512), lds_x, roreg::as_stream(stream), p, tiles_dev);
+            hipLaunchKernelGGL(kx, dim3(n_tiles), dim3(512), lds_use, roreg::as_stream(stream), p, tiles_dev);
             hipError_t e2 = hipGetLastError();
             if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
             return 0;

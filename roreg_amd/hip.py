@@ -32,6 +32,8 @@ if GEMM_MODE not in GEMM_MODES:
 # half-block layout by LDS-DMA (csrc/fourier.hip irrep_gemm_xdma_kernel); ROREG_GEMM_XDMA=0: the word layout + register staging (A/B switch,
 # bitwise the same results)
 XDMA = os.environ.get('ROREG_GEMM_XDMA', '1') == '1'
+# ... and with v_mfma_f32_16x16x32_f16 (K = 32 per step; ROREG_GEMM_MFMA16=0: the 32x32x16 LDS-DMA kernel, bitwise the register-staged one)
+MFMA16 = os.environ.get('ROREG_GEMM_MFMA16', '1') == '1'
 
 
 def use_planes(O):

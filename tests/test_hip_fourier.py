@@ -280,7 +280,7 @@ def test_f16x2_block_scale_survives_outliers(group):
 
 @pytest.mark.parametrize('C,Oc', [(256, 512), (512, 256)])
 @pytest.mark.parametrize('B', [40, 256, 1000])
-def test_plane_layout_gemm_is_bitwise_the_word_layout_gemm(group, C, Oc, B):
+def test_plane_layout_gemm_is_bitwise_the_word_layout_gemm(group, C, Oc, B):      # (+ the 16x16x32 kernel against both, to rounding)
     """ft_nonlin(planes=True) writes exactly the bits of the word layout, re-arranged into hi / lo planes, and the GEMM fed from the planes
     by LDS-DMA (irrep_gemm_xdma_kernel) returns bit for bit what the word-layout kernel returns -- coefficients, the residual add and the
     propagated bound -- for a batch below one column tile, an exact multiple, and a ragged one."""
@@ -303,8 +303,14 @@ def test_plane_layout_gemm_is_bitwise_the_word_layout_gemm(group, C, Oc, B):
     add = torch.from_numpy(rng.standard_normal(hip.coef_size(Oc, B)).astype(np.float32)).cuda()
     for kw in ({}, {'add': add}):
         Tw, bw = hip.irrep_gemm(Xw, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, **kw)
-        Tp, bp = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=True, **kw)
+        Tp, bp = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=1, **kw)      # 32x32x16 MFMAs: the same sums in the same order
         assert torch.equal(Tw.view(torch.int32), Tp.view(torch.int32)) and torch.equal(bw.view(torch.int32), bp.view(torch.int32))
+        # the 16x16x32 kernel (the default): 32 k per MFMA instead of 16 -- the same operands, another association of the f32 sums:
+        # coefficients to 2e-6 of the tensor's scale (the f16x2 GEMM's own error is 7e-7..9e-7 of it), the propagated bound to 1e-5
+        T16, b16 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=2, **kw)
+        assert float((T16 - Tw).abs().max()) <= 2e-6 * float(Tw.abs().max()), float((T16 - Tw).abs().max()) / float(Tw.abs().max())
+        assert float(((b16 - bw).abs() / bw.abs().clamp_min(1e-30)).max()) <= 1e-5
+        assert torch.equal(T16.view(torch.int32), hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=True, **kw)[0].view(torch.int32)) == hip.MFMA16
 
 
 def test_gemm_bound_propagation(group):

@@ -38,7 +38,7 @@ def main():
     # bench.py quotes `roofline.traffic` from this file only while csrc/fourier.hip still hashes to kernel_source_sha16
     res = {'hbm_bytes_per_launch': {}, 'detail': {}, 'git_commit': os.environ.get('ROREG_GIT_COMMIT'),
            # the conditions of the profiled command (bench.py refuses to quote the figure for a run under other ones); ROREG_PMC_CONDITIONS = JSON overrides
-           'conditions': dict({'kpts': 5000, 'dtype': 'fp32', 'gpus': 1, 'pair_lists': 'banded', 'xdma': os.environ.get('ROREG_GEMM_XDMA', '1') != '0'},
+           'conditions': dict({'kpts': 5000, 'dtype': 'fp32', 'gpus': 1, 'pair_lists': 'banded', 'xdma': os.environ.get('ROREG_GEMM_XDMA', '1') != '0', 'mfma16': os.environ.get('ROREG_GEMM_MFMA16', '1') != '0'},
                               **json.loads(os.environ.get('ROREG_PMC_CONDITIONS', '{}'))),
            'kernel_source_sha16': hashlib.sha256(open(os.path.join(here, 'roreg_amd', 'csrc', 'fourier.hip'), 'rb').read()).hexdigest()[:16]}
     for spec in sys.argv[3:]:
@@ -67,8 +67,8 @@ def main():
         if cal:
             lines.append(f'calibration: gf_finalize on {cal[0]} keypoints reads {cal[1]:.0f} KiB; FETCH_SIZE reports {cal[2]:.0f} KiB -> factor {cal[1] / cal[2]:.3f}')
         kern = 'irrep_gemm_kernel' if gm == 'f32' else 'irrep_gemm_'
-        def big_tag(name):          # irrep_gemm_split_kernel<CT, NP, WO, BIG[, PIPE]> (fourth template argument) or irrep_gemm_xdma_kernel<BIG>
-            m = re.search(r'irrep_gemm_split_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name) or re.search(r'irrep_gemm_xdma_kernel<\s*(\d+)', name)
+        def big_tag(name):          # irrep_gemm_split_kernel<CT, NP, WO, BIG[, PIPE]> (fourth template argument) or irrep_gemm_xdma_kernel<BIG> / irrep_gemm_xdma16_kernel<BIG>
+            m = re.search(r'irrep_gemm_split_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name) or re.search(r'irrep_gemm_xdma(?:16)?_kernel<\s*(\d+)', name)
             return bool(m) and m.group(1) == '1'
         tagged = (lambda k: k[1] >= 4000000) if gm == 'f32' else (lambda k: big_tag(k[0]))
         big = [k for k in agg if k[0].startswith(kern) and tagged(k) and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]]
