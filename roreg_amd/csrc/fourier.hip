@@ -788,7 +788,7 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f);    
 // transform (max over the rows of u_o |T| + v_o per column, merged per keypoint with atomic max: order-independent).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int wb, f32x4_t (&acc)[4][8], char *smem) {
-    constexpr int NCOL = 256, OT = 256, NT = 512, P = 132;      // P: row pitch of a wave's LDS tile in floats
+    constexpr int NCOL = 256, OT = 256, NT = 512, P = 192;      // P: row pitch of a wave's LDS tile in floats (a multiple of the 64 banks: the row's bank shift is rowpad alone)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int M = p.M[irr], N = p.N[irr];
@@ -805,6 +805,9 @@ __device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, i
         const int pp = (cb & 1) * 16 + j;
         cw[cb] = (cb >> 1) * 32 + (pp >> 1) + 16 * (pp & 1);
     }
+    // a write instruction's 64 lanes: 16 columns {c .. c + 7, c + 16 .. c + 23} x the 4 row groups q -- shifted by 0, 8, 32, 40 floats per
+    // group they cover the 64 banks exactly once
+    const int rowpad_w = 8 * (q & 1) + 32 * (q >> 1);
     const int rl = lane & 31, rr = lane >> 5;                    // read side: columns 4 rl .. 4 rl + 3, row parity rr
     const int ncol = n0 + wb * 128 + 4 * rl;                     // (N % 32 == 0: the four columns are inside or outside together)
     const bool col_ok = ncol < N;
@@ -827,13 +830,13 @@ __device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, i
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf[(4 * q + r) * P + cw[cb]] = acc[rb][cb][r];
+            for (int r = 0; r < 4; ++r) buf[(4 * q + r) * P + rowpad_w + cw[cb]] = acc[rb][cb][r];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row_l = 2 * it + rr;
             const int row = wo * 64 + rb * 16 + row_l;
             const int m = mt * OT + row;
-            const f32x4_t v = *reinterpret_cast<const f32x4_t *>(buf + row_l * P + 4 * rl);
+            const f32x4_t v = *reinterpret_cast<const f32x4_t *>(buf + row_l * P + 8 * ((row_l >> 2) & 1) + 32 * ((row_l >> 3) & 1) + 4 * rl);
             if (m < M && col_ok) {
                 f32x4_t o = {v[0] * osc[0], v[1] * osc[1], v[2] * osc[2], v[3] * osc[3]};
                 const size_t off = (size_t)m * N + ncol;
@@ -986,15 +989,15 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
             // the NEXT column block's fragments are requested first: this block's twelve MFMAs cover the LDS round trip
             if constexpr (cb < 7) read_b(xoff, integral_constant<int, cb + 1>{}, bn);
             else read_b(xoff_next, integral_constant<int, 0>{}, bn);                                      // ... of the next step (landed: behind the barrier)
+            // ... and so is the next step's weight fragment of this block (the wait at the top of the next block covers both)
+            if constexpr (cb == 0) { read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 0>{}, an); read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 1>{}, an); }
+            else if constexpr (cb < 7) read_a(S + 1, integral_constant<int, (cb + 1) / 2>{}, integral_constant<int, (cb + 1) % 2>{}, an);
             __builtin_amdgcn_sched_barrier(0);
             mm(0);
             if constexpr (cb < 4) dma_w(cb & 1, 2 * (S + 2) + (cb >> 1));
             else dma_x(cb & 1, 2 * (S + 2) + ((cb - 4) >> 1));
             __builtin_amdgcn_sched_barrier(0);
             mm(1);
-            if constexpr (cb == 0) { read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 0>{}, an); read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 1>{}, an); }
-            else if constexpr (cb < 7) read_a(S + 1, integral_constant<int, (cb + 1) / 2>{}, integral_constant<int, (cb + 1) % 2>{}, an);
-            __builtin_amdgcn_sched_barrier(0);
             mm(2);
         });
     };
