@@ -918,7 +918,10 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
         const int pi = mm * 64 + lane;
         const int beta = pi >> 3, r = (pi & 7) >> 1, half = pi & 1;
         const int k = 4 * (beta >> 4) + r;
-        int col = n0 + 16 * (beta & 15) + 8 * half;
+        // (k quads 2 and 3 hold panel P at block position P ^ 1: the four 16-lane groups of a fragment read then touch both 128-byte bank
+        //  halves -- groups q and q + 1 read k quads 0 and 2 of the same panel, 4 KB apart = the same banks: measured 0.36 conflict cycles
+        //  per active LDS cycle without the swap, none in the 32x32x16 kernel, whose paired groups read neighbouring panels)
+        int col = n0 + 16 * ((beta & 15) ^ ((beta >> 5) & 1)) + 8 * half;
         if (col > N - 8) col = N - 8;
         xsrc[i2] = reinterpret_cast<const char *>(p.X[irr]) + (size_t)k * N * 4 + (col >> 5) * 128 + x_plane * 64 + (col & 31) * 2;
         xdst[i2] = x_plane * XIMG + mm * 1024;
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(xs + (kstep % NXS) * XSTAGE + xdst[i2]), 16, 0, 0);
     };
-    const frag *wsrc = W + (size_t)(tid / OT) * Mpad + mt * OT + (tid % OT);
+    const frag *wsrc = W + (size_t)(tid / OT) * Mpad + mt * OT + ((tid % OT) ^ (8 * (tid / OT)));      // (octet 1: row m at slot m ^ 8, for the same reason)
     auto dma_w = [&](int sp, int kstep) {
         const frag *src = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + sp * split_stride),
@@ -937,9 +940,10 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
     };
     // ---- fragment addresses ----
     // weights of step S: stage (2 S + q / 2) % 4, octet q % 2, row wo * 64 + rb * 16 + j
-    const int a_lane = (q >> 1) * ABUF + (q & 1) * OT + wo * 64 + j;               // + (S % 2) * 2 * ABUF + plane * 2 * OT + rb * 16
+    const int a_lane = (q >> 1) * ABUF + (q & 1) * OT + wo * 64 + (j ^ (8 * (q & 1)));      // + (S % 2) * 2 * ABUF + plane * 2 * OT + rb * 16
     // activations of step S: stage (2 S) % 6 + q / 2, k quads 2 (q % 2) and + 1, panel wb * 8 + cb, position j
     const unsigned x_lane = (unsigned)(uintptr_t)xs + (unsigned)((q >> 1) * XSTAGE + ((2 * (q & 1)) * 16 + wb * 8) * 128 + j * 8);     // + (S % 3) * 2 * XSTAGE + plane * XIMG + cb * 128 (+ 2048)
+    const unsigned x_swap = (q & 1) ? 128u : 0u;                 // k quads 2, 3: panel P sits at position P ^ 1 (+ 128 bytes for even column blocks, - 128 for odd ones)
     frag aA[4][2], aB[4][2];
     frag b0[2], b1[2];
     auto read_a = [&](int S, auto rb_c, auto pl_c, frag (&a)[4][2]) {
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
     //  the LDS-DMA in flight; the explicit waits carry the real dependences)
     auto read_b = [&](unsigned xoff, auto cb_c, frag (&b)[2]) {
         constexpr int cb = decltype(cb_c)::value;
-        const unsigned a = x_lane + xoff;
+        const unsigned a = (cb & 1) ? x_lane + xoff - x_swap : x_lane + xoff + x_swap;
         unsigned long long u[4];
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[0]) : "v"(a), "n"(cb * 128));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[1]) : "v"(a), "n"(cb * 128 + 2048));
