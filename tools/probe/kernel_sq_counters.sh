@@ -1,5 +1,5 @@
 # SQ wait / issue / LDS counters of one kernel (three rocprofv3 --pmc passes).  Usage on the GPU box:
-#   bash tools/kernel_sq_counters.sh <kernel-name-substring> <script.py> [args]
+#   bash tools/probe/kernel_sq_counters.sh <kernel-name-substring> <script.py> [args]
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 K=$1; shift
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3

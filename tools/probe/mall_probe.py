@@ -1,6 +1,6 @@
 """Does a coefficient tensor written by one kernel and read by the next come from the 256 MB Infinity Cache when the working set is small?
 ft_nonlin (coefficient -> coefficient, 512 channels) on B keypoints, (a) back to back on the same buffers (input last written by the
-previous call's neighbour), (b) with 2 GB of unrelated traffic in between.  Usage: python tools/mall_probe.py"""
+previous call's neighbour), (b) with 2 GB of unrelated traffic in between.  Usage: python tools/probe/mall_probe.py"""
 import sys, time
 sys.path.insert(0, '.')
 import torch

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/pmc_gemm.sh  -> per-kernel PMC averages of tools/time_gemm.py (both GEMM kernels)
+# usage (GPU box): bash tools/probe/pmc_gemm.sh  -> per-kernel PMC averages of tools/time_gemm.py (both GEMM kernels)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcg

@@ -1,4 +1,4 @@
-# usage (on the GPU box): bash tools/profile_all.sh   -> gpurun_out/final/{kt_<mode>.txt, pmc.txt, pmc.json}
+# usage (on the GPU box): bash tools/probe/profile_all.sh   -> gpurun_out/final/{kt_<mode>.txt, pmc.txt, pmc.json}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final

@@ -1,4 +1,4 @@
-# usage (on the GPU box): bash tools/profile_bench.sh <tag> [bench args...]   -> gpurun_out/kt_<tag>.txt
+# usage (on the GPU box): bash tools/probe/profile_bench.sh <tag> [bench args...]   -> gpurun_out/kt_<tag>.txt
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
