@@ -59,7 +59,7 @@ struct ProfScope {
 // Sinkhorn iterations without a materialised coupling matrix (csrc/ot_flash.hip): potentials (natural log) of every pair to u_out / v_out
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n);
 int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
-                        int max_m, int max_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s);
+                        int max_m, int max_n, int min_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s);
 
 // the matcher's 1x1 layers on the matrix cores (csrc/linear_mfma.hip): true = shape served, launch issued
 bool linear_mfma(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);

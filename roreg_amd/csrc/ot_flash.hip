@@ -23,10 +23,12 @@
 // Per element and iteration: 2 x (7/1024 MFMA + v_exp_f32 + v_add_f32) against one 4-byte HBM read + ~10 vector instructions before.
 // The read-out (arg-max of Z + u + v over rows and columns) still runs on a matrix built once per pair (rm.hip).
 //
-// Two forms of the iteration.  of_pass_kernel + of_update_kernel, twice per iteration (rows, then columns): any size.  of_iter_kernel
-// (target clouds of <= 2559 points -- every shipped configuration): ONE recomputation per iteration, a 32-row strip's exponentials stay in
-// registers between its row sums and its share of the column sums (details at the kernel).  A group of pairs takes one form or the
-// other as a whole (by its longest target cloud); within a form every sum associates independently of what is stacked beside a pair.
+// Two forms of the iteration.  of_pass_kernel + of_update_kernel, twice per iteration (rows, then columns): any size.  of_iter_kernel /
+// of_iter_coop_kernel: ONE recomputation per iteration, a 32-row strip's exponentials stay in registers between its row sums and its
+// share of the column sums -- one workgroup per strip up to 2559 target points (yoho_mat's default keynum 2500), two cooperating
+// workgroups up to 5119 (`Test.py --keynum 5000`, test/evaluator.py:20,46); details at the kernels.  Which of the two a pair takes depends
+// on its own target length, and every sum associates independently of what is stacked beside a pair; only a group with a target cloud
+// beyond 5119 points takes the two-pass form as a whole.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -49,6 +51,7 @@ struct Side {                             // one side (source rows or target col
     const int *seg;                       // [n_seg + 1] offsets
     _Float16 *frag;                       // fragments, per pair `frag_stride` halfs
     float *pot;                           // potentials in log2 units, per pair `pot_stride`
+    float *pot2;                          // the fused iteration's second buffer of ROW potentials (it reads one, writes the other: see of_iter_body)
     float *part;                          // partial sums [NCH][pot_stride] per pair
     size_t frag_stride, pot_stride;
     const float *consts;                  // per pair (normc, log of the OTHER side's length): natural logs (roreg_sinkhorn_batch_consts)
@@ -342,10 +345,11 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
     store_pieces(a, pair, i, np, slot0);
 }
 
-// The column update behind of_iter_kernel: up to 80 strip sums per column.  of_update_kernel (one thread per column) spends its time waiting
-// for them -- 24 MB per 30 pairs just written by other XCDs, ~300 small workgroups on the chip -- so here FOUR waves share a block of 64
-// columns, wave q adds the q-th quarter of the strips (in order), and wave 0 adds the four quarter sums ((q0 + q1) + (q2 + q3)): four
-// times the loads in flight, the association a function of the pair's own strip count alone.
+// The column update behind of_iter_kernel: one strip sum per 32 source rows and column (79 at keynum 2500, 157 at 5000).  of_update_kernel
+// (one thread per column) spends its time waiting for them -- 24 MB per 30 pairs just written by other XCDs, ~300 small workgroups on the
+// chip -- so here FOUR waves share a block of 64 columns, wave q adds the q-th quarter of the strips (in order, 20 loads in flight at a
+// time), and wave 0 adds the four quarter sums ((q0 + q1) + (q2 + q3)): four times the loads in flight, the association a function of
+// the pair's own strip count alone.
 __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int nparts, float alpha) {
     const int pair = blockIdx.y;
     const int lenA = a.seg[pair + 1] - a.seg[pair];
@@ -358,11 +362,13 @@ __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int
     float S = 0.f;
     if (i <= lenA) {
         const float *part = a.part + pair * (a.pot_stride * nparts) + i;
-        float v[20];                                                  // (per <= 20: at most 80 strips)
+        for (int cb = c0; cb < c1; cb += 20) {                        // (wave-uniform trip count; one trip up to 80 strips)
+            float v[20];
 #pragma unroll
-        for (int k = 0; k < 20; ++k) v[k] = c0 + k < c1 ? __builtin_nontemporal_load(part + (size_t)(c0 + k) * a.pot_stride) : 0.f;
+            for (int k = 0; k < 20; ++k) v[k] = cb + k < c1 ? __builtin_nontemporal_load(part + (size_t)(cb + k) * a.pot_stride) : 0.f;
 #pragma unroll
-        for (int k = 0; k < 20; ++k) if (c0 + k < c1) S += v[k];
+            for (int k = 0; k < 20; ++k) if (cb + k < c1) S += v[k];
+        }
     }
     s_q[q][lane] = S;
     __syncthreads();
@@ -383,48 +389,78 @@ __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int
 //     E_ij = 2^(Z'_ij + u_i + v_j)         (7 MFMAs per 32 x 32 tile + one v_exp_f32 per element, as in of_pass_kernel)
 //     S_i = sum_j E_ij,   u_i += log2 mu_i - log2 S_i,   f_i = 2^(u_new - u_old)
 //     C_j(strip) = sum_{i in strip} E_ij f_i            (= the strip's part of sum_i 2^(Z' + u_new + v): one fma per element)
-// A workgroup of eight wavefronts owns the strip (one row tile of side A); wave w owns the column tiles w, w + 8, ..., NT <= 10 of them
-// (NT from the group's longest target cloud; tiles beyond a pair's own are the PAD tile of_prep_kernel writes behind the pair's last
-// one: padding potentials, exponentials exactly 0, so the code has no branches and every sum the same association whatever NT is):
-// 160 accumulator registers per lane hold the wave's part of E (2 waves per SIMD, <= 256 VGPRs).  The strip's column sums go to
-// part[strip][column] of side B and of_update_cols_kernel adds the strips in a fixed order: an association independent of what is
-// stacked beside the pair.  Rows beyond the dustbin have E = 0 and are not updated.  A row whose sum left (1e-35, 1e35) -- every term
-// underflowed, or non-finite input -- makes the workgroup redo its strip with the row maxima as stabilisers (mode 1 = max_j acc,
-// mode 2 = E = 2^(acc - M_i), f_i = mu_i / S_i).  Valid for <= 80 column tiles (2559 target points).
-constexpr int OF_FW = 8, OF_FT = 10;
-template <int NT, int VAR = 0>       // VAR: ablations for measurements only (ROREG_OT_FVAR): 1 no exponentials, 2 no MFMAs, 4 every fragment fetched twice, 5 no row update; 6 (tests) every strip through the stabilised redo
-__global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts) {
-    const int pair = blockIdx.y, tA = blockIdx.x;
+// A workgroup of eight wavefronts owns the strip (one row tile of side A) and OF_HALF = 80 column tiles; wave w owns the column tiles
+// w, w + 8, ..., NT <= 10 of them (NT from the group's longest target cloud; tiles beyond a pair's own are the PAD tile of_prep_kernel
+// writes behind the pair's last one: padding potentials, exponentials exactly 0, so the code has no branches and every sum the same
+// association whatever NT is): 160 accumulator registers per lane hold the wave's part of E (2 waves per SIMD, <= 256 VGPRs) -- a compute
+// unit's register file holds 32 rows x 2560 columns and no more.  The strip's column sums go to part[strip][column] of side B and
+// of_update_cols_kernel adds the strips in a fixed order: an association independent of what is stacked beside the pair.  Rows beyond the
+// dustbin have E = 0 and are not updated.  A row whose sum left (1e-35, 1e35) -- every term underflowed, or non-finite input -- makes the
+// workgroup redo its strip with the row maxima as stabilisers (mode 1 = max_j acc, mode 2 = E = 2^(acc - M_i), f_i = mu_i / S_i).
+//
+// Target clouds of 2560 .. 5119 points (keynum 5000: 157 tiles): TWO workgroups per strip (of_iter_kernel<NT1, true>), half 0 owns column
+// tiles 0 .. 79 (exactly the single-workgroup layout), half 1 the tiles 80 + w + 8 k (NT1 per wave).  A row's sum is
+// S_i = S_i(half 0) + S_i(half 1): each half publishes its 32 partial sums as 8-byte (value, token) words -- one relaxed device-scope
+// atomic store per row, the token names (iteration, stage), so a value and its validity arrive together and nothing is ever reset -- and
+// polls the partner's words.  Both halves then evaluate the same row update (half 0 stores it).  The two workgroups sit next to each other
+// in one XCD's dispatch order (linear workgroup ids L and L + 8), so the partner of a resident workgroup is resident or next in line.  The
+// wait is BOUNDED all the same: after OF_SPIN_LIMIT polls a workgroup computes the partner's sums itself (a plain loop that repeats the
+// partner's operations in the partner's order: bitwise the same sums) -- slower, never wrong, never stuck.
+// Which form a pair takes depends on its OWN target length only (both kernels run over a mixed group, each skipping the other's pairs).
+constexpr int OF_FW = 8, OF_FT = 10, OF_HALF = OF_FW * OF_FT;
+constexpr int OF_SPIN_LIMIT = 1 << 15;
+
+struct Xchg {                              // (value, token) words of the cooperating halves: [unit][half][32]
+    unsigned long long *words;
+    int token0;                            // 4 * iteration + 1: stage s of this launch publishes token0 + s
+};
+
+// VAR: measurements / tests only.  ROREG_OT_FVAR: 1 no exponentials, 2 no MFMAs, 4 every fragment fetched twice, 5 no row update;
+// 6 (tests) every strip through the stabilised redo; 7 (tests) the cooperating halves never see each other (always the bounded wait's fallback)
+template <int NT, int NT_OTHER, bool COOP, int VAR>
+__device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int nparts, int parity, int pair, int tA, int hb, unsigned long long *xw, int token0) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (w in a scalar register: tile addresses are scalar)
     const int lenA = a.seg[pair + 1] - a.seg[pair], lenB = b.seg[pair + 1] - b.seg[pair];
-    const int tilesA = lenA / 32 + 1, tilesB = lenB / 32 + 1;
-    if (tA >= tilesA) return;
+    const int tilesB = lenB / 32 + 1;
     __shared__ float s_part[OF_FW][32];
     __shared__ float s_np[32];
+    __shared__ float s_x[32];
+    __shared__ int s_timeout;
     // the row this lane updates (both halves of every wave: row tA * 32 + lane % 32); its potential and log-marginal are fetched now
+    // The row potentials are DOUBLE-BUFFERED (read `parity`, write the other) and their fp16 pieces are rebuilt here from the float
+    // (split3 of the same number: the bits store_pieces would have left in the extras plane) instead of being read back from the
+    // fragments: nothing a workgroup reads is written during the launch, so the two halves of a strip may run at any distance in time.
     const int i_row = tA * 32 + (lane & 31);
     const bool row_valid = i_row <= lenA;
-    float *pot = a.pot + pair * a.pot_stride;
+    const float *pot_in = (parity ? a.pot2 : a.pot) + pair * a.pot_stride;
+    float *pot = (parity ? a.pot : a.pot2) + pair * a.pot_stride;
     float old = 0.f, lmu = 0.f;
     if (row_valid) {
-        old = pot[i_row];
+        old = pot_in[i_row];
         lmu = (i_row == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
     }
     const f16x8 *fb = reinterpret_cast<const f16x8 *>(b.frag + pair * b.frag_stride);
+    const int t_own = hb * OF_HALF, t_other = (1 - hb) * OF_HALF;
     f16x8 A[OF_PLANES];
     {
         const f16x8 *fa = reinterpret_cast<const f16x8 *>(a.frag + pair * a.frag_stride) + (size_t)tA * OF_PLANES * 64 + lane;
 #pragma unroll
         for (int p = 0; p < OF_PLANES; ++p) A[p] = fa[p * 64];
+        if (lane < 32 && row_valid) {                              // (lanes 0..31 carry k slots 0..7 of row `lane`; slots 0..2 = the row's potential; padding rows keep OF_PAD)
+            _Float16 h, m, l;
+            split3(old, h, m, l);
+            A[2][0] = h; A[2][1] = m; A[2][2] = l;
+        }
     }
     f32x16 E[NT];
     float red[16];
     f16x8 B[OF_PLANES];
     auto load_plane = [&](int k, int p) {                          // plane p of the wave's k-th tile (scalar base + the lane's offset)
-        const f16x8 *src = fb + (size_t)min(w + OF_FW * k, tilesB) * OF_PLANES * 64;
+        if (VAR == 8 && (k & 1)) return;                           // (measurement only: every other tile re-uses the previous tile's fragments -- half the traffic, wrong sums)
+        const f16x8 *src = fb + (size_t)min(t_own + w + OF_FW * k, tilesB) * OF_PLANES * 64;
         B[p] = src[p * 64 + lane];
         if (VAR == 4) {                                            // (measurement only: the same traffic twice -- a second fetch of another tile's plane, result unused)
-            const f16x8 *src2 = fb + (size_t)min(w + OF_FW * ((k + 3) % NT), tilesB) * OF_PLANES * 64;
+            const f16x8 *src2 = fb + (size_t)min(t_own + w + OF_FW * ((k + 3) % NT), tilesB) * OF_PLANES * 64;
             f16x8 dummy = src2[p * 64 + lane];
             asm volatile("" :: "v"(dummy));
         }
@@ -437,6 +473,14 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
         if (VAR == 2) { acc[g] = (float)B[PB[g]][0] + (float)A[PA[g]][1]; return; }
         if (g == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[0]], B[PB[0]], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[g]], B[PB[g]], acc, 0, 0, 0);
+    };
+    auto reduce_to_lds = [&](bool is_max) {                        // red[] -> s_part[w][row]; ends behind a barrier
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = is_max ? half_max(red[r]) : half_sum(red[r]);
+            if ((lane & 31) == 31) s_part[w][8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = v;
+        }
+        __syncthreads();
     };
     auto phase1 = [&](auto mode_c) {
         constexpr int mode = decltype(mode_c)::value;
@@ -491,14 +535,81 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
                 post(k, 0, 16);
             }
         }
+        reduce_to_lds(mode == 1);
+    };
+    // The PARTNER's phase 1 (its sums only, nothing kept) as a plain rolled loop: the same operations on the same operands in the same
+    // order as the partner's pipelined code, so s_part receives bitwise the partner's values.  One accumulator tile and one fragment plane
+    // at a time beside the strip's own E (which stays where it is): the registers phase 1's fragment buffer and sums have just vacated.
+    auto partner_sums = [&](int mode) {
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = mode == 1 ? -__builtin_inff() : 0.f;
+#pragma unroll 1
+        for (int k = 0; k < NT_OTHER; ++k) {
+            const f16x8 *src = fb + (size_t)min(t_other + w + OF_FW * k, tilesB) * OF_PLANES * 64 + lane;
+            f32x16 acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 7; ++g) {
+                const f16x8 bo = src[PB[g] * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[PA[g]], bo, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (mode == 0) pr[r] += __builtin_amdgcn_exp2f(acc[r]);
+                else if (mode == 1) pr[r] = fmaxf(pr[r], acc[r]);
+                else pr[r] += __builtin_amdgcn_exp2f(acc[r] - s_np[8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)]);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = mode == 1 ? half_max(red[r]) : half_sum(red[r]);
+            const float v = mode == 1 ? half_max(pr[r]) : half_sum(pr[r]);
             if ((lane & 31) == 31) s_part[w][8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = v;
         }
         __syncthreads();
     };
     using std::integral_constant;
+    // this half's value of row lane % 32 (sum or maximum over its eight waves; s_part is complete behind phase1's barrier), and -- two
+    // cooperating halves -- the partner's: published / polled by wave 0, handed to the other waves through LDS.  Returns the strip's value.
+    auto combine = [&](auto mode_c, int stage) -> float {
+        constexpr int mode = decltype(mode_c)::value;
+        float own = mode == 1 ? -__builtin_inff() : 0.f;
+#pragma unroll
+        for (int q = 0; q < OF_FW; ++q) own = mode == 1 ? fmaxf(own, s_part[q][lane & 31]) : own + s_part[q][lane & 31];
+        if (!COOP) return own;
+        const unsigned token = (unsigned)(token0 + stage);
+        if (w == 0) {
+            unsigned long long *mine = xw + hb * 32 + (lane & 31), *theirs = xw + (1 - hb) * 32 + (lane & 31);
+            if (lane < 32) __hip_atomic_store(mine, ((unsigned long long)token << 32) | __float_as_uint(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long v = 0;
+            bool got = false;
+            if (VAR != 7) {
+                for (int spin = 0; spin < OF_SPIN_LIMIT; ++spin) {
+                    if (!got) v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    got = (unsigned)(v >> 32) == token;
+                    if (__all(got)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            const bool timeout = !__all(got);
+            if (lane < 32) s_x[lane] = __uint_as_float((unsigned)v);
+            if (lane == 0) s_timeout = timeout ? 1 : 0;
+        }
+        __syncthreads();
+        const bool timeout = s_timeout != 0;                       // (uniform over the workgroup)
+        float other;
+        if (!timeout) {
+            other = s_x[lane & 31];
+            __syncthreads();                                       // (s_x / s_timeout are rewritten by the next stage)
+        } else {                                                   // the partner did not answer in time: its sums are computed here
+            partner_sums(mode);
+            other = mode == 1 ? -__builtin_inff() : 0.f;
+#pragma unroll
+            for (int q = 0; q < OF_FW; ++q) other = mode == 1 ? fmaxf(other, s_part[q][lane & 31]) : other + s_part[q][lane & 31];
+            __syncthreads();
+        }
+        const float h0 = hb == 0 ? own : other, h1 = hb == 0 ? other : own;      // the same association in both halves
+        return mode == 1 ? fmaxf(h0, h1) : h0 + h1;
+    };
     phase1(integral_constant<int, 0>{});
     // ---- the strip's row update: every wave evaluates it for itself (same LDS data, same result: no second barrier); wave 0 stores it ----
     float frow = 0.f;                                              // f of row lane % 32
@@ -506,42 +617,29 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
     if (VAR == 5) {
         frow = row_valid ? 1.f : 0.f;
     } else {
-        float S = 0.f;
-#pragma unroll
-        for (int q = 0; q < OF_FW; ++q) S += s_part[q][lane & 31];
+        const float S = combine(integral_constant<int, 0>{}, 0);
         const bool ok = S > 1e-35f && S < 1e35f;
-        redo = VAR == 6 || __any(row_valid && !ok);                // (identical in all eight waves; VAR 6: the stabilised redo for EVERY strip -- tests only)
+        redo = VAR == 6 || __any(row_valid && !ok);                // (identical in all waves of both halves; VAR 6: the stabilised redo for EVERY strip -- tests only)
         if (!redo && row_valid) {
             const float np = old + (lmu - __log2f(S));             // u + log2 mu - log2 sum_j 2^(Z' + u + v)
             frow = __builtin_amdgcn_exp2f(np - old);               // E f = 2^(Z' + u_new + v)
-            if (threadIdx.x < 32) {
-                pot[i_row] = np;
-                store_pieces(a, pair, i_row, np, 0);
-            }
+            if (threadIdx.x < 32 && hb == 0) pot[i_row] = np;
         }
     }
     if (redo) {                                                    // rare: stabilised evaluation of the whole strip
         __syncthreads();                                           // (s_part is rewritten)
         phase1(integral_constant<int, 1>{});
-        if (threadIdx.x < 32) {
-            float mx = -__builtin_inff();
-#pragma unroll
-            for (int q = 0; q < OF_FW; ++q) mx = fmaxf(mx, s_part[q][threadIdx.x]);
-            s_np[threadIdx.x] = mx > -__builtin_inff() && mx < __builtin_inff() ? mx : 0.f;
-        }
+        const float mxs = combine(integral_constant<int, 1>{}, 1);
+        __syncthreads();
+        if (threadIdx.x < 32) s_np[threadIdx.x] = mxs > -__builtin_inff() && mxs < __builtin_inff() ? mxs : 0.f;
         __syncthreads();
         phase1(integral_constant<int, 2>{});
-        float S = 0.f;
-#pragma unroll
-        for (int q = 0; q < OF_FW; ++q) S += s_part[q][lane & 31];
+        const float S = combine(integral_constant<int, 2>{}, 2);
         if (row_valid) {
             const float m = s_np[lane & 31];
             const float np = old + ((lmu - m) - __log2f(S));
             frow = __builtin_amdgcn_exp2f((np - old) + m);         // = mu_i / S_i: E f = 2^(Z' + u_new + v)
-            if (threadIdx.x < 32) {
-                pot[i_row] = np;
-                store_pieces(a, pair, i_row, np, 0);
-            }
+            if (threadIdx.x < 32 && hb == 0) pot[i_row] = np;
         }
     }
     // ---- phase 2: the strip's part of the column sums ----
@@ -551,13 +649,38 @@ __global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int
     float *out = b.part + pair * (b.pot_stride * nparts) + (size_t)tA * b.pot_stride;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        const int t = w + OF_FW * k;
+        const int t = t_own + w + OF_FW * k;
         float c = E[k][0] * f[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) c = fmaf(E[k][r], f[r], c);
         c += __shfl_xor(c, 32);
         if (t < tilesB && lane < 32) out[t * 32 + lane] = c;
     }
+}
+
+// one workgroup per strip: pairs whose target cloud has at most OF_HALF column tiles (others are left to the cooperating kernel)
+template <int NT, int VAR = 0>
+__global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts, int parity) {
+    const int pair = blockIdx.y, tA = blockIdx.x;
+    const int tilesA = (a.seg[pair + 1] - a.seg[pair]) / 32 + 1, tilesB = (b.seg[pair + 1] - b.seg[pair]) / 32 + 1;
+    if (tA >= tilesA || tilesB > OF_HALF) return;
+    of_iter_body<NT, 0, false, VAR>(a, b, nparts, parity, pair, tA, 0, nullptr, 0);
+}
+
+// two workgroups per strip: pairs with OF_HALF < column tiles <= 2 OF_HALF.  Linear workgroup id L -> XCD L % 8, position L / 8 in that
+// XCD's dispatch order; positions 2 s and 2 s + 1 are the two halves of unit 8 s + XCD (unit = pair * ta + strip).
+template <int NT1, int VAR = 0>
+__global__ __launch_bounds__(64 * OF_FW) void of_iter_coop_kernel(Side a, Side b, int nparts, int parity, int ta, int units, Xchg x) {
+    const int L = blockIdx.x, pos = L >> 3;
+    const int unit = (pos >> 1) * 8 + (L & 7), hb = pos & 1;
+    if (unit >= units) return;
+    const int pair = unit / ta, tA = unit - pair * ta;
+    const int tilesA = (a.seg[pair + 1] - a.seg[pair]) / 32 + 1, tilesB = (b.seg[pair + 1] - b.seg[pair]) / 32 + 1;
+    if (tA >= tilesA || tilesB <= OF_HALF) return;
+    unsigned long long *xw = x.words + (size_t)unit * 64;
+    if (NT1 == OF_FT) of_iter_body<OF_FT, OF_FT, true, VAR>(a, b, nparts, parity, pair, tA, hb, xw, x.token0);      // (one body for both halves)
+    else if (hb == 0) of_iter_body<OF_FT, NT1, true, VAR>(a, b, nparts, parity, pair, tA, 0, xw, x.token0);
+    else of_iter_body<NT1, OF_FT, true, VAR>(a, b, nparts, parity, pair, tA, 1, xw, x.token0);
 }
 
 __global__ __launch_bounds__(256) void of_export_kernel(Side a, float *__restrict__ out, size_t out_stride) {
@@ -582,26 +705,31 @@ static int ot_flash_chunks(int max_m, int max_n) {
     return (tiles + OF_CHT - 1) / OF_CHT;
 }
 
-// The whole-iteration kernel holds a strip's exponentials in registers: at most OF_FW * OF_FT column tiles.  ROREG_OT_FUSED=0 keeps the
-// two-pass form (measurements).
+// The whole-iteration kernels hold a strip's exponentials in registers: at most OF_HALF column tiles per workgroup, one or two
+// workgroups per strip -- target clouds up to 2 * 2560 - 1 points.  Longer ones (no shipped configuration) take the two-pass form for the
+// whole group.  ROREG_OT_FUSED=0 keeps the two-pass form (measurements); ROREG_OT_COOP=0 keeps it beyond 2559 points.
 static bool ot_flash_fused(int max_n) {
     static const bool on = !(getenv("ROREG_OT_FUSED") && atoi(getenv("ROREG_OT_FUSED")) == 0);
-    return on && max_n / 32 + 1 <= OF_FW * OF_FT;
+    static const bool coop = !(getenv("ROREG_OT_COOP") && atoi(getenv("ROREG_OT_COOP")) == 0);
+    return on && max_n / 32 + 1 <= (coop ? 2 : 1) * OF_HALF;
 }
 
 // bytes of workspace of ot_flash_iterations (16-byte aligned pieces): per pair the two sides' fragments, potentials and chunk partials
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
     const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
     const size_t nch = ot_flash_chunks(max_m, max_n);
-    const size_t nparts = ot_flash_fused(max_n) && ta > nch ? ta : nch;           // side B's partial sums: one per row strip in the fused iteration
-    const size_t per_pair = (ta + tb + 2) * OF_TILE_HALFS * sizeof(_Float16) + (ta + tb) * 32 * sizeof(float) + (ta * nch + tb * nparts) * 32 * sizeof(float);
+    const bool fused = ot_flash_fused(max_n);
+    const size_t nparts = fused && ta > nch ? ta : nch;                          // side B's partial sums: one per row strip in the fused iteration
+    const size_t per_pair = (ta + tb + 2) * OF_TILE_HALFS * sizeof(_Float16) + (2 * ta + tb) * 32 * sizeof(float) + (ta * nch + tb * nparts) * 32 * sizeof(float)
+                            + (fused && tb > (size_t)OF_HALF ? ta * 64 * sizeof(unsigned long long) : 0);     // + the cooperating halves' words
     return (size_t)n_seg * per_pair + round_up((size_t)n_seg * 2 * sizeof(unsigned), 16) + 256;
 }
 
 // `iters` Sinkhorn iterations for every pair; the potentials (natural log, u[0..m], v[0..n]) are written to u_out + pair * uv_stride and
-// v_out + pair * uv_stride.  seg_* are DEVICE offset arrays, consts the device array of roreg_sinkhorn_batch_consts.
+// v_out + pair * uv_stride.  seg_* are DEVICE offset arrays, consts the device array of roreg_sinkhorn_batch_consts.  min_n = the shortest
+// target cloud of the group (which of the two fused kernels have work).
 int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
-                        int max_m, int max_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s) {
+                        int max_m, int max_n, int min_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s) {
     const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
     const int nch = ot_flash_chunks(max_m, max_n);
     char *p = reinterpret_cast<char *>(ws);
@@ -614,14 +742,20 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     A.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * A.frag_stride * sizeof(_Float16);
     B.frag = reinterpret_cast<_Float16 *>(p); p += (size_t)n_seg * B.frag_stride * sizeof(_Float16);
     A.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * sizeof(float);
+    A.pot2 = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * sizeof(float);
     B.pot = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * sizeof(float);
+    B.pot2 = nullptr;
     static const int variant = getenv("ROREG_OT_VARIANT") ? atoi(getenv("ROREG_OT_VARIANT")) : 0;
     const bool fused = ot_flash_fused(max_n) && variant == 0;
+    const bool coop = fused && (int)tb > OF_HALF, single = fused && min_n / 32 + 1 <= OF_HALF;
     const int nparts = fused && (int)ta > nch ? (int)ta : nch;
     A.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * nch * sizeof(float);
     B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * nparts * sizeof(float);
-    unsigned *amax = reinterpret_cast<unsigned *>(p);
+    unsigned *amax = reinterpret_cast<unsigned *>(p); p += round_up((size_t)n_seg * 2 * sizeof(unsigned), 16);
+    Xchg X = {reinterpret_cast<unsigned long long *>(p), 0};
+    const int units = n_seg * (int)ta;
     (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
+    if (coop) (void)hipMemsetAsync(X.words, 0, (size_t)units * 64 * sizeof(unsigned long long), s);       // token 0 = nothing published
     hipLaunchKernelGGL(of_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, amax);      // 8 workgroups per (pair, side): 32 atomics each
     hipLaunchKernelGGL(of_prep_kernel, dim3((unsigned)(ta > tb ? ta : tb) + 1, 2, n_seg), dim3(320), 0, s, A, B, amax, alpha);
     const dim3 gA((unsigned)((ta + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg), gB((unsigned)((tb + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg);
@@ -645,14 +779,28 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
             continue;
         } else if (fused) {                            // the row update and the strips' column sums in one launch; then the column update
             static const int fvar = getenv("ROREG_OT_FVAR") ? atoi(getenv("ROREG_OT_FVAR")) : 0;
-            using Kern = void (*)(Side, Side, int);
-            static const Kern by_nt[OF_FT] = {of_iter_kernel<1>, of_iter_kernel<2>, of_iter_kernel<3>, of_iter_kernel<4>, of_iter_kernel<5>,
-                                              of_iter_kernel<6>, of_iter_kernel<7>, of_iter_kernel<8>, of_iter_kernel<9>, of_iter_kernel<10>};
-            const int nt = (int)(tb + OF_FW - 1) / OF_FW;                   // column tiles per wave
-            Kern kern = by_nt[nt - 1];
-            if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : fvar == 6 ? of_iter_kernel<OF_FT, 6> : of_iter_kernel<OF_FT, 5>;
-            hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts);
-            hipLaunchKernelGGL(of_update_cols_kernel, dim3((max_n + 64) / 64, n_seg), dim3(256), 0, s, B, A, nparts, alpha);
+            if (single) {                              // pairs with <= OF_HALF column tiles
+                using Kern = void (*)(Side, Side, int, int);
+                static const Kern by_nt[OF_FT] = {of_iter_kernel<1>, of_iter_kernel<2>, of_iter_kernel<3>, of_iter_kernel<4>, of_iter_kernel<5>,
+                                                  of_iter_kernel<6>, of_iter_kernel<7>, of_iter_kernel<8>, of_iter_kernel<9>, of_iter_kernel<10>};
+                const int nt = coop ? OF_FT : (int)(tb + OF_FW - 1) / OF_FW;        // column tiles per wave
+                Kern kern = by_nt[nt - 1];
+                if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : fvar == 6 ? of_iter_kernel<OF_FT, 6> : fvar == 5 ? of_iter_kernel<OF_FT, 5> : fvar == 8 ? of_iter_kernel<OF_FT, 8> : kern;
+                hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts, it & 1);
+            }
+            if (coop) {                                // pairs with more: two workgroups per strip
+                using Kern = void (*)(Side, Side, int, int, int, int, Xchg);
+                static const Kern by_nt[OF_FT / 2] = {of_iter_coop_kernel<2>, of_iter_coop_kernel<4>, of_iter_coop_kernel<6>, of_iter_coop_kernel<8>, of_iter_coop_kernel<10>};
+                const int nt1 = (int)(tb - OF_HALF + OF_FW - 1) / OF_FW;            // the second half's column tiles per wave (instantiated for even counts)
+                Kern kern = by_nt[(nt1 - 1) / 2];
+                if (fvar == 6) kern = of_iter_coop_kernel<OF_FT, 6>;              // (tests: a full-length second half)
+                if (fvar == 7) kern = of_iter_coop_kernel<OF_FT, 7>;
+                X.token0 = 4 * it + 1;
+                hipLaunchKernelGGL(kern, dim3(2 * (unsigned)round_up(units, 8)), dim3(64 * OF_FW), 0, s, A, B, nparts, it & 1, (int)ta, units, X);
+            }
+            Side Anew = A;                             // (the column update's exact fall-back reads the row potentials just written)
+            Anew.pot = (it & 1) ? A.pot : A.pot2;
+            hipLaunchKernelGGL(of_update_cols_kernel, dim3((max_n + 64) / 64, n_seg), dim3(256), 0, s, B, Anew, nparts, alpha);
             continue;
         } else if (variant == 4) {                       // passes only (no update launches)
             hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch);
@@ -664,7 +812,9 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
         hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nch);
         hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, OF_CHT, 3, alpha);
     }
-    hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride);
+    Side Aend = A;
+    if (fused && (iters & 1)) Aend.pot = A.pot2;
+    hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, Aend, u_out, uv_stride);
     hipLaunchKernelGGL(of_export_kernel, uB, dim3(256), 0, s, B, v_out, uv_stride);
     return 0;
 }

@@ -1065,12 +1065,13 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
                                int recompute, void *stream) {
     ROREG_REQUIRE(src_final && tgt_final && seg_src && seg_tgt && seg_src_host && seg_tgt_host && consts && n_seg > 0 && iters >= 0 && ws &&
                       matches0 && matches1 && mscores0 && mscores1, "roreg_sinkhorn_batch: bad arguments");
-    int max_m = 0, max_n = 0;
+    int max_m = 0, max_n = 0, min_n = 0x7fffffff;
     for (int p = 0; p < n_seg; ++p) {
         const int m = seg_src_host[p + 1] - seg_src_host[p], n = seg_tgt_host[p + 1] - seg_tgt_host[p];
         ROREG_REQUIRE(m > 0 && n > 0, "roreg_sinkhorn_batch: pair %d is empty", p);
         if (m > max_m) max_m = m;
         if (n > max_n) max_n = n;
+        if (n < min_n) min_n = n;
     }
     const long long tm = seg_src_host[n_seg], tn = seg_tgt_host[n_seg];
     const size_t base_floats = roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, tm, tn);
@@ -1097,7 +1098,7 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
         // the iterations never touch Z0 / Z0T: every pass recomputes the scores on the matrix cores (csrc/ot_flash.hip); the two matrices
         // above only serve the read-out below
         roreg::ProfScope prof(roreg::PROF_SINKHORN, s);
-        if (roreg::ot_flash_iterations(src_final, tgt_final, seg_src, seg_tgt, consts, n_seg, max_m, max_n, alpha, iters, u, v, slab,
+        if (roreg::ot_flash_iterations(src_final, tgt_final, seg_src, seg_tgt, consts, n_seg, max_m, max_n, min_n, alpha, iters, u, v, slab,
                                        ws + base_floats, s) != 0) return 1;
     } else {
         for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent

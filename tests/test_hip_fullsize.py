@@ -3,6 +3,7 @@
 tests/golden/full_*.npz are written by tools/gen_golden_full.py, which imports /root/reference in the build container and runs it on
 CPU; the inputs of every case are rebuilt here from the stored seed (roreg_amd/synth.py, portable arithmetic only), so the fixtures
 hold just the reference's small outputs.  GPU only (-m gpu), through the C-ABI."""
+import json
 import os
 
 import shutil
@@ -148,8 +149,11 @@ def rm_net():
     return net.eval()
 
 
-def test_full_match_ot_keynum_2500(rm_net):
-    z = load_golden('full_match_ot')
+@pytest.mark.parametrize('tag', ['full_match_ot', 'full_match_ot_5000'])
+def test_full_match_ot_keynum_2500(rm_net, tag):
+    """`Match_ot.forward()` against the reference's own forward (shipped RM weights) at yoho_mat's default keynum 2500 and at m = n = 5000,
+    what `Test.py --RM --keynum 5000` hands it (test/evaluator.py:20,46 -> test/matcher.py:152-185)."""
+    z = load_golden(tag)
     f0, f1, k0, k1 = _match_ot_inputs(z)
     batch = {'feats0': torch.from_numpy(f1[None].copy()), 'feats1': torch.from_numpy(f0[None].copy()),
              'keys0': torch.from_numpy(k1[None].copy()), 'keys1': torch.from_numpy(k0[None].copy())}
@@ -169,10 +173,12 @@ def test_full_match_ot_keynum_2500(rm_net):
     assert np.abs(out['target_final'][0, :, ::25, 0].cpu().numpy() - z['target_final_sample']).max() < 1e-4
 
 
-def test_full_match_ot_stacked_path(rm_net):
-    """The engine's path (match_stacked: several pairs per pass, one-pass Sinkhorn) on the same full-size pair."""
+@pytest.mark.parametrize('tag', ['full_match_ot', 'full_match_ot_5000'])
+def test_full_match_ot_stacked_path(rm_net, tag):
+    """The engine's path (match_stacked: several pairs per pass, Sinkhorn on recomputed scores -- one workgroup per strip at 2500 target
+    points, two cooperating ones at 5000) on the same full-size pairs."""
     from roreg_amd import hip
-    z = load_golden('full_match_ot')
+    z = load_golden(tag)
     f0, f1, k0, k1 = _match_ot_inputs(z)
     n = int(z['n'])
     seg = hip.Segments([n, n])
@@ -239,7 +245,13 @@ def test_full_pipeline_vs_reference(tmp_path, mode, monkeypatch):
 
 
 # ---- BASELINE config 4's chain at full size against the reference's own end-to-end run ------------------------------------------------
-@pytest.mark.parametrize('tag', ['full_pipeline_rd_rm', 'full_pipeline_rd_rm_o60'])
+RD_RM_TAGS = ['full_pipeline_rd_rm', 'full_pipeline_rd_rm_o60', 'full_pipeline_rd_rm_o60_s1', 'full_pipeline_rd_rm_o60_s2', 'full_pipeline_rd_rm_o60_s3',
+              'full_pipeline_rd_rm_k5000']
+# pairs the reference itself registers (RRE < 1 degree in its own run): there the end-to-end chain must land on the reference's transform
+RD_RM_REGISTERS = {'full_pipeline_rd_rm_o60', 'full_pipeline_rd_rm_o60_s2'}
+
+
+@pytest.mark.parametrize('tag', RD_RM_TAGS)
 def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     """GF -> detector (shipped RD weights) -> rank scores -> NMS sampling of 2500 -> yoho_mat (shipped RM weights) -> one-shot RANSAC on the
     best-scored half (test/detector.py:26-47, test/matcher.py:11-42,152-210, test/estimator.py:405-443) on a 5000-keypoint pair at 20 % overlap
@@ -247,13 +259,18 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     The detector's saliency is a ~3e-3 standard deviation of 60 correlations of magnitude ~60, so float32 noise moves a few ranks (<= 30
     places of 5000, test_full_detector_on_a_whole_cloud) -- which is why the chain is ALSO checked stage by stage on the reference's own
     intermediate outputs, where every index list must be identical: NMS sample from the reference's ranks; matches from the reference's
-    samples; Des2R index, recalltime and transform from the reference's matches."""
+    samples; Des2R index, recalltime and transform from the reference's matches.
+    `_o60_s1..3`: three more 60 % pairs (s1 and s3 are registrations the reference itself fails: a wrong group element wins); `_k5000`: the
+    chain at `--keynum 5000` (SURVEY 3.1's hot path): NMS_sample returns a permutation of all 5000 keypoints and Match_ot runs at
+    m = n = 5000 (two cooperating workgroups per Sinkhorn strip, csrc/ot_flash.hip).  Every run appends what it measured for the two GEMM
+    kernels to gpurun_out/r05/rd_rm_e2e.jsonl (DESIGN.md section 2's table)."""
     from roreg_amd import hip
     from roreg_amd.test import name2extractor, name2detector, name2matcher, name2estimator, _cache
     from roreg_amd.test.matcher import NMS_sample
     z = load_golden(tag)
     root = str(tmp_path)
-    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=2500,
+    kn = int(z['keynum']) if 'keynum' in z.files else 2500
+    cfg = default_config(output_cache_fn=f'{root}/cache', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kn,
                          bs_GF=1250, bs_ET=1000, ET='yohoo', RD=True, RM=True, match_n=0.5)
     _write_ckpts(root, cfg)
     for d in ['RD', 'RM']:
@@ -262,7 +279,7 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     ds = synth.make_scene(int(z['scene_seed']), n_clouds=2, n_kpts=5000, overlap=float(z['overlap']), coord_noise=0.005, name='synth/scene0', portable=True)
     ds.write_inputs(cfg.output_cache_fn)
     base = f'{cfg.output_cache_fn}/{ds.name}'
-    md = f'{base}/match_2500'
+    md = f'{base}/match_{kn}'
     from roreg_amd import hip as _hip
     # The chain is run once per LDS-DMA GEMM kernel (hip.MFMA16): the two sum the same products in different orders, and the detector's
     # non-maximum suppression has near-ties at float32 noise -- the 32x32x16 kernel happens to land on the reference's side of all of them.
@@ -270,7 +287,7 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
         _hip.MFMA16, mfma16_was = mfma16, _hip.MFMA16
         try:
             _cache.clear()
-            for d in ('YOHO_Output_Group_feature', 'det_score', 'match_2500'):      # (the stages skip outputs that exist)
+            for d in ('YOHO_Output_Group_feature', 'det_score', f'match_{kn}'):      # (the stages skip outputs that exist)
                 shutil.rmtree(f'{base}/{d}', ignore_errors=True)
             # ---- end to end from the input features ----
             name2extractor['yoho_des'](cfg).run(ds)
@@ -281,20 +298,29 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
             for pc in ds.pc_ids:
                 det = np.load(f'{base}/det_score/{pc}.npy')
                 moved.append(np.abs(np.rint(det * 5000) - z[f'det_rank_{pc}']).max())
-                mine = NMS_sample(2500, 5).sample(ds.get_kps(pc), det)
+                mine = NMS_sample(kn, 5).sample(ds.get_kps(pc), det)
                 same_nms.append(len(set(mine.tolist()) & set(z[f'nms_{pc}'].astype(np.int64).tolist())))
             np.random.seed(1234)
-            name2matcher['yoho_mat'](cfg).run(ds, 2500)
+            name2matcher['yoho_mat'](cfg).run(ds, kn)
             np.random.seed(4321)
-            name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
+            name2estimator['yohoo'](cfg).run(ds, kn, 1000)
             m = np.load(f'{md}/0-1.npy'); want_m = z['match_0_1'].astype(np.int64)
             r = np.load(f'{md}/yohoo/1000iters/0-1.npz')
             rows_same = len({tuple(x) for x in m} & {tuple(x) for x in want_m})
             e2e_identical = np.array_equal(m, want_m) and int(r['recalltime']) == int(z['recall_0_1'])
-            print(f'[{tag}] end to end: detector ranks moved <= {max(moved):.0f} places; NMS samples shared {same_nms} of 2500; match rows shared {rows_same} of '
-                  f'{len(want_m)} (mine {len(m)}); recalltime {int(r["recalltime"])} vs {int(z["recall_0_1"])}; |dT| {np.abs(r["trans"] - z["trans_0_1"]).max():.2e}')
-            assert max(moved) <= 30 and min(same_nms) >= 2495             # measured: <= 15 places; at most ONE of the 2500 sampled keypoints differs
-            if tag.endswith('_o60'):
+            dT = float(np.abs(r['trans'] - z['trans_0_1']).max())
+            print(f'[{tag}] {"16x16x32" if mfma16 else "32x32x16"} end to end: detector ranks moved <= {max(moved):.0f} places; NMS samples shared {same_nms} of {kn}; match rows shared {rows_same} of '
+                  f'{len(want_m)} (mine {len(m)}); recalltime {int(r["recalltime"])} vs {int(z["recall_0_1"])}; |dT| {dT:.2e}')
+            try:
+                os.makedirs('gpurun_out/r05', exist_ok=True)
+                with open('gpurun_out/r05/rd_rm_e2e.jsonl', 'a') as fh:
+                    fh.write(json.dumps({'tag': tag, 'kernel': '16x16x32' if mfma16 else '32x32x16', 'ranks_moved': float(max(moved)), 'nms_shared': same_nms, 'keynum': kn,
+                                         'rows_shared': rows_same, 'rows_ref': int(len(want_m)), 'rows_mine': int(len(m)), 'recalltime': int(r['recalltime']),
+                                         'recalltime_ref': int(z['recall_0_1']), 'dT': dT}) + '\n')
+            except OSError:
+                pass
+            assert max(moved) <= 30 and min(same_nms) >= kn - 5             # measured: <= 15 places; at most ONE of the sampled keypoints differs
+            if tag == 'full_pipeline_rd_rm_o60':
                 # the pair that registers (60 % overlap): the whole chain stays on the reference's track from the input features -- both NMS samples,
                 # every one of the 212 match rows, the recalltime and the transform
                 same_rows = sorted(map(tuple, m.tolist())) == sorted(map(tuple, want_m.tolist()))
@@ -306,6 +332,12 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
                     # [2499, 2500] shared, 207 of the 212 rows, 211 matches) -- and the registration is the same to 6.5e-5
                     assert min(same_nms) >= 2499 and rows_same >= 200 and abs(len(m) - len(want_m)) <= 5, (same_nms, rows_same, len(m))
                 assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
+            elif tag in RD_RM_REGISTERS:
+                assert rows_same >= 0.9 * len(want_m) and abs(len(m) - len(want_m)) <= 10, (rows_same, len(m), len(want_m))
+                assert dT < 1e-4, dT
+            elif tag != 'full_pipeline_rd_rm':
+                # registrations the reference fails (a one-or-few-inlier winner among near-tied hypotheses): the matches must stay on its track
+                assert rows_same >= 0.8 * len(want_m) and abs(len(m) - len(want_m)) <= 20, (rows_same, len(m), len(want_m))
             else:
                 # the 20 % pair is a FAILED registration in the reference too (175 matches, a one-inlier winner); one keypoint of 2500 flips at the NMS
                 # boundary on float32 detector noise and the matcher's context is global: measured 150 of the reference's 175 rows shared.  The floor
@@ -319,15 +351,15 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     for pc in ds.pc_ids:
         ranks = z[f'det_rank_{pc}'].astype(np.float64) / 5000.0
         np.save(f'{base}/det_score/{pc}.npy', ranks.astype(np.float32))
-        assert np.array_equal(NMS_sample(2500, 5).sample(ds.get_kps(pc), ranks.astype(np.float32)), z[f'nms_{pc}'].astype(np.int64)), pc
+        assert np.array_equal(NMS_sample(kn, 5).sample(ds.get_kps(pc), ranks.astype(np.float32)), z[f'nms_{pc}'].astype(np.int64)), pc
     np.random.seed(1234)
-    name2matcher['yoho_mat'](cfg).run(ds, 2500)
+    name2matcher['yoho_mat'](cfg).run(ds, kn)
     m = np.load(f'{md}/0-1.npy'); sc = np.load(f'{md}/scores/0-1.npy')
     assert np.array_equal(m, want_m)
     assert sc.dtype == np.float32 and np.abs(sc - z['mscore_0_1']).max() < 1e-4
     np.save(f'{md}/scores/0-1.npy', z['mscore_0_1'])                       # the estimator's top-`match_n` selection: the reference's own scores
     np.random.seed(4321)
-    name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
+    name2estimator['yohoo'](cfg).run(ds, kn, 1000)
     assert np.array_equal(np.load(f'{md}/DR_index/0-1.npy'), z['dr_0_1'].astype(np.int64))
     tp = np.load(f'{md}/Trans_pre/0-1.npy')[::16]; tw = z['transpre_sample_0_1']
     # local transforms: the rotation (ET quaternion -> R, float32 in the reference) to 1e-4; the translation t = key0 - key1 R^T (estimator.py:362)

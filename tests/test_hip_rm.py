@@ -283,14 +283,16 @@ def test_sinkhorn_recomputed_on_the_matrix_cores_equals_the_materialised_iterati
 
 
 def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
-    """of_iter_kernel (one recomputation per iteration, csrc/ot_flash.hip) over its template range: 1 ... 10 column tiles per wave, ragged
-    pairs in one call (tiles a pair does not have read the pad tile).  (a) A pair's matches AND scores are bitwise the same stacked and
+    """of_iter_kernel / of_iter_coop_kernel (one recomputation per iteration, csrc/ot_flash.hip) over their template ranges: 1 ... 10 column
+    tiles per wave, one workgroup per strip (target clouds up to 2559 points) and two cooperating ones (2560 ... 5119), source clouds on
+    both sides of 2559 points (more than 80 strip sums per column), ragged pairs in one call (tiles a pair does not have read the pad
+    tile; each of the two kernels skips the other's pairs).  (a) A pair's matches AND scores are bitwise the same stacked and
     alone -- alone the kernel is another instantiation (tiles per wave follow the call's longest target cloud), so this is the
-    association-independence the kernel promises; (b) against the materialised iteration: matches identical where the arg-max is decided,
-    scores to 5e-5; (c) a call with a target cloud above 2559 points takes the two-pass form and meets the same bar."""
+    association-independence the kernels promise; (b) against the materialised iteration: matches identical where the arg-max is decided,
+    scores to 5e-5; (c) a call with a target cloud above 5119 points takes the two-pass form and meets the same bar."""
     from roreg_amd import hip
     rng = np.random.default_rng(41)
-    sizes = [(2500, 2500), (700, 1200), (1200, 700), (20, 300), (2500, 90)]
+    sizes = [(2500, 2500), (700, 1200), (1200, 700), (20, 300), (2500, 90), (3000, 1000), (5000, 2400), (1000, 3000), (2600, 5000), (300, 2600), (64, 5119)]
     S, T = [], []
     for m, n in sizes:
         s = rng.standard_normal((m, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((n, 32)).astype(np.float32) * 0.5
@@ -313,10 +315,10 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
         same = a0[o0:o0 + m] == b0[o0:o0 + m]
         assert same.mean() > 0.995 and (a0[o0:o0 + m] >= 0).sum() >= min(m, n) // 2 - 5, (q, same.mean())          # (near-ties may fall either way between two arithmetics)
         assert np.abs(as0[o0:o0 + m][same] - bs0[o0:o0 + m][same]).max() < 5e-5, q
-    # (c) one target cloud of 2600 points: the whole call runs of_pass_kernel twice per iteration
-    s = rng.standard_normal((300, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((2600, 32)).astype(np.float32) * 0.5
+    # (c) one target cloud of 5200 points: the whole call runs of_pass_kernel twice per iteration
+    s = rng.standard_normal((300, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((5200, 32)).astype(np.float32) * 0.5
     t[:150] = s[:150] * 3
-    seg_s = hip.Segments([300, sizes[1][0]]); seg_t = hip.Segments([2600, sizes[1][1]])
+    seg_s = hip.Segments([300, sizes[1][0]]); seg_t = hip.Segments([5200, sizes[1][1]])
     cs, ct = cu(np.concatenate([s, S[1]])), cu(np.concatenate([t, T[1]]))
     d = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=True)]
     e = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=False)]
@@ -327,14 +329,16 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
     assert (d[0][300:] == a0[hs[1]:hs[1] + m]).mean() > 0.995 and np.abs(d[2][300:] - as0[hs[1]:hs[1] + m])[d[0][300:] == a0[hs[1]:hs[1] + m]].max() < 2e-5
 
 
-def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path):
+@pytest.mark.parametrize('fvar,m,n', [(6, 2500, 2500), (6, 2500, 5000), (7, 3000, 4000), (7, 5000, 5000)])
+def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path, fvar, m, n):
     """of_iter_kernel redoes a strip with the row maxima as stabilisers when a row's sum leaves (1e-35, 1e35) -- which finite, sanely scaled
     input never provokes.  ROREG_OT_FVAR=6 (read once per process: a child process) sends EVERY strip through that path: same matches,
-    scores to 2e-5 against the normal path."""
+    scores to 2e-5 against the normal path (also with two cooperating workgroups per strip: n = 5000, three exchanges per iteration).
+    ROREG_OT_FVAR=7: the two halves of a strip never see each other's words, i.e. every workgroup takes the bounded wait's fall-back
+    (the partner's sums recomputed locally, then its own strip again) -- BITWISE the normal path's matches and scores."""
     import subprocess, sys
     from roreg_amd import hip
     rng = np.random.default_rng(43)
-    m = n = 2500                                                   # (10 column tiles per wave: the instantiation the switch covers)
     s = rng.standard_normal((m, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((n, 32)).astype(np.float32) * 0.5
     t[:1000] = s[:1000] * 3 + rng.standard_normal((1000, 32)).astype(np.float32) * 0.05
     np.savez(tmp_path / 'in.npz', s=s, t=t)
@@ -344,12 +348,14 @@ def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path):
             "seg_s = hip.Segments([s.shape[0]]); seg_t = hip.Segments([t.shape[0]])\n"
             "a0, a1, as0, as1 = hip.sinkhorn_batch(s, t, seg_s, seg_t, 1.5, 100, recompute=True)\n"
             "np.savez(sys.argv[2], a0=a0.cpu().numpy(), a1=a1.cpu().numpy(), as0=as0.cpu().numpy(), as1=as1.cpu().numpy())\n")
-    env = dict(os.environ, ROREG_OT_FVAR='6', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ROREG_OT_FVAR=str(fvar), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(tmp_path / 'out.npz')
     seg = hip.Segments([m])
     a0, a1, as0, as1 = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(s), cu(t), seg, hip.Segments([n]), 1.5, 100, recompute=True)]
+    if fvar == 7:
+        assert np.array_equal(z['a0'], a0) and np.array_equal(z['a1'], a1) and np.array_equal(z['as0'], as0) and np.array_equal(z['as1'], as1)
     same = z['a0'] == a0
     assert same.mean() > 0.998 and (a0 >= 0).sum() >= 990, same.mean()
     assert np.abs(z['as0'][same] - as0[same]).max() < 2e-5 and np.abs(z['as1'][z['a1'] == a1] - as1[z['a1'] == a1]).max() < 2e-5

@@ -4,7 +4,7 @@ Same rules as tools/gen_golden.py (build container only; the reference is import
 vectors are written).  The INPUTS of every case are rebuilt from a seed by roreg_amd/synth.py (portable arithmetic only), so the
 fixtures hold just the reference's small outputs: index lists, packed inlier masks, transforms and strided samples of the big tensors.
 
-    python tools/gen_golden_full.py [stages] [ransac] [ransac_ties] [match_ot] [pipeline] [pipeline_rd_rm] [yohoc] [rd]        (no argument = all; ~10 minutes on 8 cores)
+    python tools/gen_golden_full.py [stages] [ransac] [ransac_ties] [match_ot] [pipeline] [pipeline_rd_rm] [pipeline_rd_rm_o60] [pipeline_rd_rm_o60_s1..3] [pipeline_rd_rm_k5000] [match_ot_5000] [yohoc] [rd]        (no argument = all; ~10 minutes on 8 cores)
 """
 import os
 import shutil
@@ -93,13 +93,14 @@ def gen_ransac_ties():
          best_of_float64_accumulation=np.int64(best64), refine1=r1, refine2=r2)
 
 
-def gen_match_ot():
+def gen_match_ot(n=2500, tag='full_match_ot', seed=OT_SEED):
+    """`Match_ot.forward` of the reference with the shipped RM weights (network/rot_coh_match.py:339-390).  n = 2500 is yoho_mat's default
+    keynum; n = 5000 (`full_match_ot_5000`) is what `Test.py --RM --keynum 5000` hands it (test/evaluator.py:20,46 -> test/matcher.py:152-185)."""
     cfg = gg.make_cfg(tempfile.mkdtemp(prefix='golden_full_cfg_'))
     net = name2network['RM_test'](cfg)
     ck = torch.load(f'{REF}/checkpoints/FCGF/RM/model_best.pth')
     net.load_state_dict(ck['network_state_dict'], strict=True); net.eval()
-    n = 2500
-    ds = synth.make_scene(OT_SEED, n_clouds=2, n_kpts=n, overlap=0.6, coord_noise=0.005, portable=True)
+    ds = synth.make_scene(seed, n_clouds=2, n_kpts=n, overlap=0.6, coord_noise=0.005, portable=True)
     f0 = ds.feats[0]; f1 = ds.feats[1]
     f0 = f0 / np.sqrt((f0 * f0).sum(1, keepdims=True)); f1 = f1 / np.sqrt((f1 * f1).sum(1, keepdims=True))
     k0 = ds.get_kps('0').astype(np.float32); k1 = ds.get_kps('1').astype(np.float32)
@@ -110,7 +111,7 @@ def gen_match_ot():
     m0 = r['matches0'][0].numpy(); m1 = r['matches1'][0].numpy()
     print('   valid matches', int((m0 >= 0).sum()))
     Z = r['scores'][0].numpy()
-    save('full_match_ot', scene_seed=np.int64(OT_SEED), n=np.int64(n), matches0=_i16(m0), matches1=_i16(m1),
+    save(tag, scene_seed=np.int64(seed), n=np.int64(n), matches0=_i16(m0), matches1=_i16(m1),
          matching_scores0=r['matching_scores0'][0].numpy(), matching_scores1=r['matching_scores1'][0].numpy(),
          scores_sample=Z[::40, ::40].copy(), scores_lastrow=Z[-1, ::10].copy(), scores_lastcol=Z[::10, -1].copy(),
          source_final_sample=r['source_final'][0, :, ::25, 0].numpy(), target_final_sample=r['target_final'][0, :, ::25, 0].numpy())
@@ -150,15 +151,18 @@ def gen_pipeline():
         shutil.rmtree(root, ignore_errors=True)
 
 
-def gen_pipeline_rd_rm(tag='full_pipeline_rd_rm', overlap=0.2, seed=PIPE_SEED + 7):
+def gen_pipeline_rd_rm(tag='full_pipeline_rd_rm', overlap=0.2, seed=PIPE_SEED + 7, keynum=2500):
     """BASELINE config 4's chain in the reference, end to end at full size on a LOW-OVERLAP pair (20 % shared keypoints; a second fixture
     `_o60` at 60 %, where the trained matcher finds enough correct correspondences on synthetic descriptors to register the pair): GF (seeded
     weights) -> detector (shipped RD weights) -> rank scores -> NMS sampling of 2500 keypoints -> yoho_mat (shipped RM weights) -> one-shot
     RANSAC on the top-`match_n` = 0.5 matches (test/detector.py:26-47, test/matcher.py:11-42,152-210, test/estimator.py:405-443).
-    Stored: the detector's rank order, both NMS samples, matches + scores, DR_index, a strided sample of Trans_pre, the result."""
+    Stored: the detector's rank order, both NMS samples, matches + scores, DR_index, a strided sample of Trans_pre, the result.
+    `_o60_s1..3`: three more 60 % pairs (other seeds) for the comparison of the two GEMM kernels; `_k5000`: the same chain at
+    `--keynum 5000`, SURVEY 3.1's hot path (NMS_sample at num == n still runs its k-NN branch and returns a permutation; Match_ot sees
+    m = n = 5000)."""
     root = tempfile.mkdtemp(prefix='golden_full_')
     try:
-        cfg = gg.make_cfg(root, RD=True, RM=True, keynum=2500, match_n=0.5)
+        cfg = gg.make_cfg(root, RD=True, RM=True, keynum=keynum, match_n=0.5)
         cfg.bs_GF = 250; cfg.bs_ET = 500
         ds = synth.make_scene(seed, n_clouds=2, n_kpts=5000, overlap=overlap, coord_noise=0.005, name='synth/scene0', portable=True)
         ds.write_inputs(cfg.output_cache_fn)
@@ -166,19 +170,19 @@ def gen_pipeline_rd_rm(tag='full_pipeline_rd_rm', overlap=0.2, seed=PIPE_SEED + 
         gg.name2detector['yoho_det'](cfg).run(ds)
         np.random.seed(1234)
         mat = name2matcher['yoho_mat'](cfg)
-        mat.run(ds, 2500)
+        mat.run(ds, keynum)
         np.random.seed(4321)
-        name2estimator['yohoo'](cfg).run(ds, 2500, 1000)
+        name2estimator['yohoo'](cfg).run(ds, keynum, 1000)
         base = f'{cfg.output_cache_fn}/{ds.name}'
-        out = {'scene_seed': np.int64(seed), 'overlap': np.float64(overlap)}
+        out = {'scene_seed': np.int64(seed), 'overlap': np.float64(overlap), 'keynum': np.int64(keynum)}
         RefNMS = gg.ref_mat.NMS_sample                                # the reference's sampler, to store the two samples it drew
         for pc in ds.pc_ids:
             det = np.load(f'{base}/det_score/{pc}.npy')
             out[f'det_rank_{pc}'] = _i16(np.rint(det * det.shape[0]))
-            out[f'nms_{pc}'] = _i16(RefNMS(2500, 5).sample(ds.get_kps(pc), det))
+            out[f'nms_{pc}'] = _i16(RefNMS(keynum, 5).sample(ds.get_kps(pc), det))
             y = np.load(f'{base}/YOHO_Output_Group_feature/{pc}.npy')
             out[f'yoho_sample_{pc}'] = y[::250].copy()
-        md = f'{base}/match_2500'
+        md = f'{base}/match_{keynum}'
         for a, b in ds.pair_ids:
             out[f'match_{a}_{b}'] = _i16(np.load(f'{md}/{a}-{b}.npy'))
             out[f'mscore_{a}_{b}'] = np.load(f'{md}/scores/{a}-{b}.npy')
@@ -232,7 +236,12 @@ def gen_rd():
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'pipeline_rd_rm', 'pipeline_rd_rm_o60', 'yohoc', 'rd']
+    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'pipeline_rd_rm', 'pipeline_rd_rm_o60', 'pipeline_rd_rm_o60_s1', 'pipeline_rd_rm_o60_s2', 'pipeline_rd_rm_o60_s3', 'pipeline_rd_rm_k5000', 'match_ot_5000', 'yohoc', 'rd']
     for name in todo:
         print(name)
-        {'stages': gen_stages, 'ransac': gen_ransac, 'ransac_ties': gen_ransac_ties, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'pipeline_rd_rm': gen_pipeline_rd_rm, 'pipeline_rd_rm_o60': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60', 0.6, PIPE_SEED + 8), 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
+        {'stages': gen_stages, 'ransac': gen_ransac, 'ransac_ties': gen_ransac_ties, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'pipeline_rd_rm': gen_pipeline_rd_rm, 'pipeline_rd_rm_o60': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60', 0.6, PIPE_SEED + 8),
+         'pipeline_rd_rm_o60_s1': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60_s1', 0.6, PIPE_SEED + 21),
+         'pipeline_rd_rm_o60_s2': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60_s2', 0.6, PIPE_SEED + 22),
+         'pipeline_rd_rm_o60_s3': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60_s3', 0.6, PIPE_SEED + 23),
+         'pipeline_rd_rm_k5000': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_k5000', 0.6, PIPE_SEED + 9, keynum=5000),
+         'match_ot_5000': lambda: gen_match_ot(5000, 'full_match_ot_5000', OT_SEED + 1), 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
