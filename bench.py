@@ -462,11 +462,15 @@ def main():
 
     # ---- the strictly 24-bit matrix-core mode on the SAME full workload (the default f16x2 is 22 bits under a per-keypoint bound) ----
     bf16x3_value = None
+    bf16x3_all_value = None
     if not args.no_secondary and hip is not None and args.gemm == 'f16x2' and args.bf16x3_steps > 0:
         eng.set_gemm_mode('bf16x3')
         step()
         d_b, _, _ = bracket(args.bf16x3_steps)
         bf16x3_value = totals['pairs'] * args.bf16x3_steps / d_b
+        step(all_local_transforms=True)
+        d_ba, _, _ = bracket(args.bf16x3_steps, all_local_transforms=True)
+        bf16x3_all_value = totals['pairs'] * args.bf16x3_steps / d_ba
         eng.set_gemm_mode(args.gemm)
 
     # ---- secondary figures (outside the headline's timed region; kitchen scene only, so the default run stays short) ----
@@ -508,7 +512,13 @@ def main():
             sec['rd_rm_leg'] = rd_rm_leg(args, cfg, gf, et)
             sec['rd_rm_leg_pairs_per_s'] = sec['rd_rm_leg'].get('fp32', {}).get('pairs_per_s')
             sec['rd_rm_leg_pairs_per_s_bf16'] = sec['rd_rm_leg'].get('bf16', {}).get('pairs_per_s')
+            sec['rd_rm_leg_pairs_per_s_matrix_core_layers'] = sec['rd_rm_leg'].get('fp32_matrix_core_layers', {}).get('pairs_per_s')
             sec['rd_rm_leg_sinkhorn_ms_per_pair'] = (sec['rd_rm_leg'].get('fp32', {}).get('roofline_sinkhorn') or {}).get('ms_per_pair')
+            # the same chain at `--keynum 5000` (SURVEY 3.1's hot path: Match_ot at m = n = 5000)
+            sec['rd_rm_leg_k5000'] = rd_rm_leg(args, cfg, gf, et, keynum=5000, n_pairs=52, variants=('fp32', 'fp32_matrix_core_layers'))
+            sec['rd_rm_leg_k5000_pairs_per_s'] = sec['rd_rm_leg_k5000'].get('fp32', {}).get('pairs_per_s')
+            sec['rd_rm_leg_k5000_pairs_per_s_matrix_core_layers'] = sec['rd_rm_leg_k5000'].get('fp32_matrix_core_layers', {}).get('pairs_per_s')
+            sec['rd_rm_leg_k5000_sinkhorn_ms_per_pair'] = (sec['rd_rm_leg_k5000'].get('fp32', {}).get('roofline_sinkhorn') or {}).get('ms_per_pair')
 
     # ---- roofline of the dominant kernel: the irrep-domain GEMMs of the two big GF layers (256->512, 512->256) ----
     if hip is not None:
@@ -532,6 +542,11 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': totals['scaling'],
             'vs_baseline': None, 'dtype': ('stub' if STUB else DTYPE_OF[args.gemm] + ('' if args.dtype == 'fp32' else '; group features stored as bfloat16')),
             'data': 'stub engine (host-side test of the launcher and the multi-rank control flow; no kernels ran)' if STUB else 'synthetic',
+            # the like-for-like figures next to `value` (which evaluates only the <= 1000 local transforms one-shot RANSAC draws; identical results):
+            # the reference's per-pair work and inter-stage file contract -- the local transform of EVERY correspondence -- in the default
+            # matrix-core mode and in the strictly 24-bit one
+            'value_contract_complete': all_value,
+            'value_contract_complete_bf16x3': bf16x3_all_value,
             'value_all_local_transforms': all_value,
             'accuracy': metrics,
             'value_bf16x3': bf16x3_value,
@@ -540,6 +555,7 @@ def main():
                        # scalars repeated here because a record that keeps only the contract's keys keeps `config`'s scalars:
                        'value_all_local_transforms': all_value,            # the reference's per-pair work (every correspondence's local transform)
                        'value_bf16x3': bf16x3_value,                        # same workload, strictly 24-bit operands (3 x bf16) in the matrix cores
+                       'value_contract_complete': all_value, 'value_contract_complete_bf16x3': bf16x3_all_value,
                        'fmr': None if metrics is None else metrics['feature_matching_recall'],
                        'ir': None if metrics is None else metrics['inlier_ratio'],
                        'rr': None if metrics is None else metrics['registration_recall_pointdsc'],
@@ -626,17 +642,18 @@ def headroom_bits(eng, feats):
     return rep
 
 
-def rd_rm_leg(args, cfg0, gf, et):
-    """BASELINE configs[3] / [4] path on one low-overlap scene chunk: detector (RD) -> NMS sampling -> rotation-coherence matcher (RM) at keynum
-    2500 -> one-shot estimator on the top-`match_n` matches; float32 and bfloat16 descriptor storage.  Rooflines of the two kernels that dominate
+def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'bf16', 'fp32_matrix_core_layers')):
+    """BASELINE configs[3] / [4] path on one low-overlap scene chunk: detector (RD) -> NMS sampling -> rotation-coherence matcher (RM) at `keynum`
+    (2500 = yoho_mat's default; 5000 = `Test.py --keynum 5000`) -> one-shot estimator on the top-`match_n` matches; float32 and bfloat16
+    descriptor storage, and the matcher's opt-in matrix-core layers (ROREG_LINEAR_MFMA=1: another rounding, see Match_ot.match_stacked).  Rooflines of the two kernels that dominate
     Match_ot measured with the library's HIP-event brackets: the Sinkhorn iterations (HBM: one pass over every pair's (m+1) x (n+1) float32
     coupling matrix per iteration) and roreg_topk_dot (f32 vector FMA: 2 x 32 x m x n per searched direction)."""
     from roreg_amd import hip, synth
     from roreg_amd.engine import RegistrationEngine
     from roreg_amd.network import name2network
     from roreg_amd.parses.parses_test import default_config
-    n_clouds, n_pairs, overlap = 24, 100, 0.2
-    cfg = default_config(keynum=2500, max_iter=1000, ET='yohoo', RD=True, RM=True)
+    n_clouds, overlap = 24, 0.2
+    cfg = default_config(keynum=keynum, max_iter=1000, ET='yohoo', RD=True, RM=True)
     rd = name2network['RD_test'](cfg); rm = name2network['RM_test'](cfg)
     weights = 'random-init'
     gdir = os.path.join(ROOT, 'tests', 'golden')
@@ -649,9 +666,11 @@ def rd_rm_leg(args, cfg0, gf, et):
     feats, keys, poses = synth.make_scene_device(1400, n_clouds, args.kpts, overlap)
     pairs = [(str(a), str(b)) for a, b in synth.scene_pair_list(n_clouds, n_pairs, 4343, locality=8.0)]
     seeds = [(11 + zlib.crc32(f'lo:{a}:{b}'.encode())) % (2 ** 32) for a, b in pairs]
-    out = {'workload': f'{n_clouds} clouds x {args.kpts} kpts, {n_pairs} pairs, overlap {overlap} (3DLoMatch-like), --RD --RM --ET yohoo --keynum 2500 --match_n {cfg.match_n}',
+    out = {'workload': f'{n_clouds} clouds x {args.kpts} kpts, {n_pairs} pairs, overlap {overlap} (3DLoMatch-like), --RD --RM --ET yohoo --keynum {keynum} --match_n {cfg.match_n}',
            'weights': weights}
-    for dtype in ('fp32', 'bf16'):
+    for variant in variants:
+        dtype = variant.split('_')[0]
+        rm.matrix_core_layers = variant.endswith('matrix_core_layers')
         eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
         eng.set_gemm_mode(args.gemm); eng.set_descriptor_dtype(dtype)
         for _ in range(2):
@@ -679,7 +698,7 @@ def rd_rm_leg(args, cfg0, gf, et):
             # No coupling matrix is read; what the fused kernel moves instead is 5 bytes of L2-resident fragments per element and iteration,
             # and that traffic is what bounds it (measured: fetching every fragment twice costs +50-67 %).
             cells = work.get('sinkhorn_cells', 0.0)
-            fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and cfg.keynum <= 2559
+            fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and (cfg.keynum <= 2559 or os.environ.get('ROREG_OT_COOP') == '1')
             per_cell = 224.0 if fused else 448.0
             tf = cells * per_cell / (sk_ms * 1e-3) / 1e12
             ex = cells * (1.0 if fused else 2.0) / (sk_ms * 1e-3)
@@ -710,8 +729,9 @@ def rd_rm_leg(args, cfg0, gf, et):
                                                   'replaces score_mat + full argsort, network/rot_coh_match.py:8-12,34-45)', 'bound': 'valu-f32', 'unit': 'TFLOP/s', 'launches': tk_n,
                                         'avg_ms': tk_ms / tk_n, 'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'frac': tf / PEAK_F32_MFMA_TFLOPS,
                                         'note': '2 x 32 x m x n flop per search on the f32 vector pipe (157.3 TFLOP/s FMA peak); the sorted k-list insertions are extra VALU work'}
-        out[dtype] = leg
+        out[variant] = leg
         del eng
+    rm.matrix_core_layers = None
     return out
 
 

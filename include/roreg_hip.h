@@ -28,7 +28,7 @@ extern "C" {
  * roreg_irrep_gemm_f16x2 take the plane-layout flags; 4: round 4 -- additions only (roreg_nn_search_ex / roreg_knn_search_ex / roreg_pdist and the entries marked "v4"),
  * bumped so that a binding can rely on them).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
-#define ROREG_ABI_VERSION 4
+#define ROREG_ABI_VERSION 5
 int roreg_abi_version(void);
 const char *roreg_last_error(void);
 
@@ -358,8 +358,11 @@ int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t 
                    float *ws, size_t ws_floats, const int32_t *segA, const int32_t *segB, int n_seg, int max_m, int max_n, void *stream);
 
 /* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
- * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119): one float32 fmaf chain per (row, output), inputs ascending, starting from the bias. */
+ * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119): one float32 fmaf chain per (row, output), inputs ascending, starting from the bias.
+ * v5: that chain runs on the matrix cores (v_mfma_f32_32x32x2_f32 is a float32 fmaf chain over k on gfx950, bit for bit: csrc/linear_chain.hip);
+ * roreg_linear_path(1) selects the vector-pipe kernels instead (same bits; returns the previous setting, 0 = matrix cores). */
 int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
+int roreg_linear_path(int path);
 /* v4: the same layer on the matrix cores for Cin >= 32 (other shapes: roreg_linear): fp16 hi + lo operands under exact per-row / per-tensor
  * power-of-two scales, all four cross products, f32 accumulate (<= 6e-7 of sum |w||x| per element: the level of the fmaf chain, other
  * rounding); one kernel for every L, a row's result depends on that row alone.  csrc/linear_mfma.hip; used by the stacked matcher. */
@@ -416,13 +419,23 @@ int roreg_sinkhorn_batch(const float *src_final, const float *tgt_final, const i
  * materialised and read once per iteration: 4 (m+1)(n+1) bytes per pair and iteration from HBM).  recompute = 1: the iterations never read
  * a matrix -- every pass recomputes the scores <s_i, t_j> on the matrix cores from the L2-resident descriptors (fp16 hi + lo operands, f32
  * accumulate; potentials, dustbins and padding ride in one more MFMA) and only exponentiates and adds (csrc/ot_flash.hip); same read-outs
- * (indices identical on the tests, scores to 1e-6).  The matrix is still built once per pair for the read-out.
+ * (indices identical on the tests, scores to 1e-6).  The matrix is still built once per pair for the read-out.  A pair whose TARGET cloud
+ * has at most 2559 points (yoho_mat's default keynum 2500, test/matcher.py:152) recomputes the scores ONCE per iteration (a 32-row strip's
+ * exponentials stay in registers between the row and the column sums); a longer one (`Test.py --keynum 5000`, test/evaluator.py:20,46)
+ * twice (rows, then columns) -- or, recompute = 2, once, with two cooperating workgroups per strip up to 5119 points.  The form is chosen
+ * per pair, so a pair's result does not depend on what is stacked beside it.
  * ws: roreg_sinkhorn_batch2_workspace_size floats. */
 size_t roreg_sinkhorn_batch2_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n);
 int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
                           const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                           int recompute, void *stream);
+/* v5: the same, and (Z_out non-null, n_seg == 1) the pair's log-coupling matrix Z [(m+1) x (n+1)] row-major = ((Z0 + u) + v) - norm, the
+ * `scores` of Match_ot.forward (network/rot_coh_match.py:313,366) -- so that forward() and the stacked path run ONE set of Sinkhorn kernels. */
+int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                          const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                          int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                          int recompute, float *Z_out, void *stream);
 
 /* ---- group-Fourier evaluation of the group convolution (csrc/fourier.hip, roreg_amd/fourier.py) ---------------
  * In the basis of the five real irreps (d = 1,3,3,4,5) the 13-stencil group conv is one dense GEMM per irrep,

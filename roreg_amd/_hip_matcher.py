@@ -9,7 +9,7 @@ import torch
 from . import hip as _core
 from .hip import HipError, _check, _ptr, _stream, ensure_des2r, ensure_tables, lib, upload
 
-__all__ = ['OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'topk_dot', 'value_input']
+__all__ = ['OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'topk_dot', 'value_input', 'vector_pipe_layers']
 
 
 def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpose=False, want_idx=False, perm_coefs=None, bcast_coefs=None):
@@ -90,6 +90,18 @@ class matrix_core_layers:
     def __exit__(self, *exc):
         global MATRIX_CORE_LAYERS
         MATRIX_CORE_LAYERS = self.prev
+        return False
+
+
+class vector_pipe_layers:
+    """`with hip.vector_pipe_layers():` -- linear() / mlp_instnorm() evaluate their fmaf chains on the vector pipe instead of the matrix cores
+    (roreg_linear_path; same bits -- tests and A/B measurements)."""
+
+    def __enter__(self):
+        self.prev = lib().roreg_linear_path(1)
+
+    def __exit__(self, *exc):
+        lib().roreg_linear_path(self.prev)
         return False
 
 
@@ -190,12 +202,19 @@ def sinkhorn(src_final, tgt_final, alpha, iters):
 # Sinkhorn iterations of the stacked matcher path: 1 = recompute the scores on the matrix cores in every pass (csrc/ot_flash.hip, default);
 # ROREG_OT_RECOMPUTE=0 = read the materialised coupling matrix once per iteration (rounds 1-3; A/B switch)
 OT_RECOMPUTE = os.environ.get('ROREG_OT_RECOMPUTE', '1') == '1'
+# target clouds of 2560 ... 5119 points (keynum 5000): 0 = two recomputations per iteration (default: measured faster), 1 = one, two cooperating
+# workgroups per strip (csrc/ot_flash.hip)
+OT_COOP = os.environ.get('ROREG_OT_COOP', '0') == '1'
 
 
-def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters, recompute=None):
+def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters, recompute=None, want_Z=False):
     """Sinkhorn + mutual read-out of several pairs (descriptors concatenated by seg_src / seg_tgt) ->
-    (matches0 [sum m] local indices or -1, matches1 [sum n], mscores0, mscores1).  recompute: None = OT_RECOMPUTE."""
-    recompute = OT_RECOMPUTE if recompute is None else bool(recompute)
+    (matches0 [sum m] local indices or -1, matches1 [sum n], mscores0, mscores1).  recompute: None = OT_RECOMPUTE (and OT_COOP);
+    False = the materialised matrix; True = scores recomputed on the matrix cores; 'coop' = the same with cooperating workgroups for target
+    clouds of 2560 ... 5119 points.  want_Z (one pair only): the log-coupling matrix [(m+1),(n+1)] is returned in front."""
+    if recompute is None:
+        recompute = ('coop' if OT_COOP else True) if OT_RECOMPUTE else False
+    mode = 2 if recompute == 'coop' else (1 if recompute else 0)
     dev = src_final.device
     tm, tn = seg_src.total, seg_tgt.total
     m0 = torch.empty(tm, dtype=torch.int64, device=dev); m1 = torch.empty(tn, dtype=torch.int64, device=dev)
@@ -205,14 +224,16 @@ def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters, recompu
     cdev = upload(consts)
     wsn = lib().roreg_sinkhorn_batch2_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
     ws = torch.empty(wsn, dtype=torch.float32, device=dev)
-    _check(lib().roreg_sinkhorn_batch2(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
+    Z = torch.empty((seg_src.max + 1, seg_tgt.max + 1), dtype=torch.float32, device=dev) if want_Z else None
+    _check(lib().roreg_sinkhorn_batch3(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),
                                        _ptr(seg_tgt.dev, torch.int32), seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, _ptr(cdev), seg_src.n,
-                                       float(alpha), int(iters), _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, 1 if recompute else 0, _stream()),
-           'roreg_sinkhorn_batch2')
+                                       float(alpha), int(iters), _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), wsn, mode,
+                                       _ptr(Z) if want_Z else None, _stream()),
+           'roreg_sinkhorn_batch3')
     if _core.WORK is not None:
         cells = float(np.sum((np.diff(seg_src.host).astype(np.float64) + 1) * (np.diff(seg_tgt.host) + 1)))
         _core.WORK['sinkhorn_bytes'] = _core.WORK.get('sinkhorn_bytes', 0.0) + 4.0 * cells * int(iters)
         _core.WORK['sinkhorn_cells'] = _core.WORK.get('sinkhorn_cells', 0.0) + cells * int(iters)
         _core.WORK['sinkhorn_pairs'] = _core.WORK.get('sinkhorn_pairs', 0) + seg_src.n
         _core.WORK['sinkhorn_recompute'] = bool(recompute)
-    return m0, m1, s0, s1
+    return (Z, m0, m1, s0, s1) if want_Z else (m0, m1, s0, s1)

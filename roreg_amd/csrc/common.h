@@ -59,8 +59,12 @@ struct ProfScope {
 // Sinkhorn iterations without a materialised coupling matrix (csrc/ot_flash.hip): potentials (natural log) of every pair to u_out / v_out
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n);
 int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
-                        int max_m, int max_n, int min_n, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s);
+                        int max_m, int max_n, int min_n, bool coop_wanted, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s);
 
+// the matcher's 1x1 layers as float32 fmaf chains on the matrix cores (csrc/linear_chain.hip; bitwise the vector-pipe kernels): true = shape served
+bool linear_chain(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);
+bool linear_tail_chain(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,
+                       int mult, hipStream_t s);
 // the matcher's 1x1 layers on the matrix cores (csrc/linear_mfma.hip): true = shape served, launch issued
 bool linear_mfma(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);
 bool linear_tail_mfma(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,

@@ -717,6 +717,16 @@ __global__ __launch_bounds__(256) void ot_final_kernel(const float *__restrict__
     Z[i] = Z0[(size_t)r * ld + c] + u[r] + v[c] - normc;
 }
 
+// the same with the normalisation constant read from the device (the stacked call's constants array; one pair)
+__global__ __launch_bounds__(256) void ot_final_batch1_kernel(const float *__restrict__ Z0, int ld, int m, int n, const float *__restrict__ u,
+                                                              const float *__restrict__ v, const float *__restrict__ consts, float *__restrict__ Z) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)(m + 1) * (n + 1);
+    if (i >= tot) return;
+    const int r = (int)(i / (n + 1)), c = (int)(i - (size_t)r * (n + 1));
+    Z[i] = Z0[(size_t)r * ld + c] + u[r] + v[c] - consts[0];
+}
+
 // arg-max over the first C-1 columns of rows 0..R-2 of (Z0[i,j] + vec[j]) (+ rowc[i] - normc for the value)
 template <bool ROWC_FIRST>
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ Z, int R, int C, int ld, const float *__restrict__ vec,
@@ -853,9 +863,22 @@ extern "C" int roreg_mlp_tail_mfma(const float *h, int L, int Cmid, const float 
     return roreg_mlp_tail(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, stream);
 }
 
+// 0 (default): the fmaf chains of roreg_linear / roreg_mlp_tail run on the matrix cores (csrc/linear_chain.hip: v_mfma_f32_32x32x2_f32 is a
+// float32 fmaf chain over k, bit for bit); 1: on the vector pipe (the kernels above).  Returns the previous setting.  Same results either way.
+static int g_linear_path = 0;
+extern "C" int roreg_linear_path(int path) {
+    const int prev = g_linear_path;
+    if (path == 0 || path == 1) g_linear_path = path;
+    return prev;
+}
+
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
+    if (g_linear_path == 0 && roreg::linear_chain(x, L, Cin, W, b, Cout, y, s)) {
+        ROREG_CHECK_LAUNCH("roreg_linear");
+        return 0;
+    }
     const int oc = linear_ochunk(L, Cout);
     const dim3 g((L + 255) / 256, (Cout + oc - 1) / oc), t(256);
 #define RM_LIN_T(CI, CO)                                                                                                         \
@@ -901,6 +924,10 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
     if (!seg_off) { n_seg = 1; mult = 1; }
     hipStream_t s = roreg::as_stream(stream);
+    if (g_linear_path == 0 && roreg::linear_tail_chain(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s)) {
+        ROREG_CHECK_LAUNCH("roreg_mlp_tail");
+        return 0;
+    }
     const int oc = linear_ochunk(L, 32);
     const dim3 g((L + 255) / 256, (32 + oc - 1) / oc), t(256);
     if (oc == 32 && Cmid == 64) hipLaunchKernelGGL((linear_tiled_kernel<64, 32, true, true>), dim3((L + 255) / 256), t, 0, s, h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult);
@@ -1062,9 +1089,10 @@ extern "C" size_t roreg_sinkhorn_batch2_workspace_size(int n_seg, int max_m, int
 static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
                                const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                                int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
-                               int recompute, void *stream) {
+                               int recompute, float *Z_out, void *stream) {
     ROREG_REQUIRE(src_final && tgt_final && seg_src && seg_tgt && seg_src_host && seg_tgt_host && consts && n_seg > 0 && iters >= 0 && ws &&
                       matches0 && matches1 && mscores0 && mscores1, "roreg_sinkhorn_batch: bad arguments");
+    ROREG_REQUIRE(!Z_out || n_seg == 1, "roreg_sinkhorn_batch3: the log-couplings are returned for a call of ONE pair (got %d)", n_seg);
     int max_m = 0, max_n = 0, min_n = 0x7fffffff;
     for (int p = 0; p < n_seg; ++p) {
         const int m = seg_src_host[p + 1] - seg_src_host[p], n = seg_tgt_host[p + 1] - seg_tgt_host[p];
@@ -1098,7 +1126,7 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
         // the iterations never touch Z0 / Z0T: every pass recomputes the scores on the matrix cores (csrc/ot_flash.hip); the two matrices
         // above only serve the read-out below
         roreg::ProfScope prof(roreg::PROF_SINKHORN, s);
-        if (roreg::ot_flash_iterations(src_final, tgt_final, seg_src, seg_tgt, consts, n_seg, max_m, max_n, min_n, alpha, iters, u, v, slab,
+        if (roreg::ot_flash_iterations(src_final, tgt_final, seg_src, seg_tgt, consts, n_seg, max_m, max_n, min_n, recompute == 2, alpha, iters, u, v, slab,
                                        ws + base_floats, s) != 0) return 1;
     } else {
         for (int p = 0; p < n_seg; ++p) (void)hipMemsetAsync(u + p * slab, 0, sizeof(float) * (ldt + ldz), s);       // u and v are adjacent
@@ -1122,6 +1150,10 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
         }
         }
     }
+    if (Z_out) {                                             // Z = ((Z0 + u) + v) - norm (network/rot_coh_match.py:313): the one pair's (m+1) x (n+1) log-couplings
+        const size_t tot = (size_t)(max_m + 1) * (max_n + 1);
+        hipLaunchKernelGGL(ot_final_batch1_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Z0, ldz, max_m, max_n, u, v, consts, Z_out);
+    }
     hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
     hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);
     const int mx = max_m > max_n ? max_m : max_n;
@@ -1136,7 +1168,7 @@ extern "C" int roreg_sinkhorn_batch(const float *src_final, const float *tgt_fin
                                     int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                                     void *stream) {
     return sinkhorn_batch_impl(src_final, tgt_final, seg_src, seg_tgt, seg_src_host, seg_tgt_host, consts, n_seg, alpha, iters, matches0, matches1,
-                               mscores0, mscores1, ws, ws_floats, 0, stream);
+                               mscores0, mscores1, ws, ws_floats, 0, nullptr, stream);
 }
 
 extern "C" int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
@@ -1144,5 +1176,13 @@ extern "C" int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_fi
                                      int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                                      int recompute, void *stream) {
     return sinkhorn_batch_impl(src_final, tgt_final, seg_src, seg_tgt, seg_src_host, seg_tgt_host, consts, n_seg, alpha, iters, matches0, matches1,
-                               mscores0, mscores1, ws, ws_floats, recompute, stream);
+                               mscores0, mscores1, ws, ws_floats, recompute, nullptr, stream);
+}
+
+extern "C" int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
+                                     const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
+                                     int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
+                                     int recompute, float *Z_out, void *stream) {
+    return sinkhorn_batch_impl(src_final, tgt_final, seg_src, seg_tgt, seg_src_host, seg_tgt_host, consts, n_seg, alpha, iters, matches0, matches1,
+                               mscores0, mscores1, ws, ws_floats, recompute, Z_out, stream);
 }

@@ -18,6 +18,11 @@ import torch.nn as nn
 from .. import hip
 from .ops import _version_key
 
+# ROREG_LINEAR_MFMA=1: the stacked path's 1x1 layers / R_indicator on the matrix cores (another rounding; see Match_ot.match_stacked)
+MATRIX_CORE_LAYERS_DEFAULT = os.environ.get('ROREG_LINEAR_MFMA', '0') != '0'
+# ROREG_OT_LITERAL=1: forward() iterates on the materialised coupling matrix with the literal two-pass log-domain kernel (hip.sinkhorn)
+OT_LITERAL = os.environ.get('ROREG_OT_LITERAL', '0') == '1'
+
 
 def _wb(conv):
     """[Cout,Cin] weight and bias of a 1x1 Conv2d as contiguous device float32 (cached per parameter version)."""
@@ -181,6 +186,7 @@ class Match_ot(nn.Module):
         self.Graph = Graph_enhance_net()
         self.final_mlp = mlp_2layer(64, 64, 32)
         self.ot_layer = sinkhorn_ot(0.2, 100)
+        object.__setattr__(self, 'matrix_core_layers', None)       # None = MATRIX_CORE_LAYERS_DEFAULT; True / False: this instance's stacked path
 
     def _alpha_value(self):
         bs = self.ot_layer.bin_score
@@ -199,16 +205,19 @@ class Match_ot(nn.Module):
     def match_stacked(self, source_eqv, target_eqv, source_keys, target_keys, seg_s, seg_t):
         """match_many on already stacked tensors: the pairs' points are concatenated (hip.Segments seg_s / seg_t give the row ranges);
         every per-pair operation of the graph (neighbour search, InstanceNorm statistics, the context maximum, Sinkhorn) is
-        segmented.  This is the throughput path: the 1x1 layers run on the matrix cores (hip.matrix_core_layers: float32-accurate, another
-        rounding than forward()'s fmaf chains; ROREG_LINEAR_MFMA=0 keeps forward()'s kernels) and the Sinkhorn iterations recompute the scores
-        instead of reading a coupling matrix (hip.sinkhorn_batch).  A pair's result does not depend on which pairs are stacked beside it.
-        Against forward() pair by pair: matches identical on the tests (incl. the reference's keynum-2500 golden), scores to 2e-5."""
+        segmented.  This is the throughput path (the engine, yoho_mat.run).  It runs forward()'s kernels -- the float32 fmaf chains in the
+        reference's summation order and the Sinkhorn iterations on recomputed scores (hip.sinkhorn_batch) -- so ONE arithmetic stands
+        behind the reference's API and the engine, and the reference goldens of forward() (matches bit-exact at 112, 2500 and 5000 points)
+        certify this path too.  A pair's result does not depend on which pairs are stacked beside it.
+        ROREG_LINEAR_MFMA=1 moves the 1x1 layers and R_indicator to the matrix cores (hip.matrix_core_layers: equally accurate, ANOTHER
+        rounding): +10-15 % pairs/s on BASELINE configs[3], and on the reference's 5000-point golden one spurious mutual match of 136 (a
+        top-k neighbour falls on the other side of a float32 near-tie) -- opt-in, measured beside the default in bench.py."""
         source_eqv = source_eqv.contiguous(); target_eqv = target_eqv.contiguous()
         source_coor = (source_keys / self.coor_norm_step).contiguous()
         target_coor = (target_keys / self.coor_norm_step).contiguous()
         source_inv = hip.mean_over_group(source_eqv)
         target_inv = hip.mean_over_group(target_eqv)
-        with hip.matrix_core_layers(os.environ.get('ROREG_LINEAR_MFMA', '1') != '0'):
+        with hip.matrix_core_layers(MATRIX_CORE_LAYERS_DEFAULT if self.matrix_core_layers is None else self.matrix_core_layers):
             sources, targets = self.Graph(source_eqv, target_eqv, source_coor, target_coor, source_inv, target_inv, seg_s, seg_t)
             source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]), seg=seg_s)
             target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]), seg=seg_t)
@@ -228,7 +237,11 @@ class Match_ot(nn.Module):
         source_final = self.final_mlp(hip.concat_rows(source_inv, sources[-1]))
         target_final = self.final_mlp(hip.concat_rows(target_inv, targets[-1]))
         alpha = self._alpha_value()
-        Z, m0, m1, s0, s1 = hip.sinkhorn(source_final, target_final, alpha, self.ot_layer.iters)
+        if OT_LITERAL:      # the literal two-pass log-domain iteration on the materialised matrix (rounds 1-4's forward(); A/B switch)
+            Z, m0, m1, s0, s1 = hip.sinkhorn(source_final, target_final, alpha, self.ot_layer.iters)
+        else:               # the stacked path's Sinkhorn on one pair, plus the log-couplings
+            Z, m0, m1, s0, s1 = hip.sinkhorn_batch(source_final, target_final, hip.Segments([source_final.shape[0]]), hip.Segments([target_final.shape[0]]),
+                                                   alpha, self.ot_layer.iters, want_Z=True)
         out = _MatchResult({
             'scores': Z[None], 'matches0': m0[None], 'matches1': m1[None], 'matching_scores0': s0[None], 'matching_scores1': s1[None],
             'source_final': source_final.t().contiguous()[None, :, :, None], 'target_final': target_final.t().contiguous()[None, :, :, None]})

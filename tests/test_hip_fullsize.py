@@ -164,20 +164,44 @@ def test_full_match_ot_keynum_2500(rm_net, tag):
     assert np.abs(out['matching_scores0'][0].cpu().numpy() - z['matching_scores0']).max() < 1e-4
     assert np.abs(out['matching_scores1'][0].cpu().numpy() - z['matching_scores1']).max() < 1e-4
     Z = out['scores'][0].cpu().numpy()
-    # 1e-4 on every floating-point output, also at 2501 x 2501 after 100 Sinkhorn iterations (measured 2.3e-5 on the
-    # log-couplings, 4.5e-6 on the final descriptors; the reference's own float32-vs-float64 noise on this case is 3.2e-5 / 4.9e-6,
-    # tools/match_ot_noise.py -> tests/golden/match_ot_noise.json)
-    assert np.abs(Z[::40, ::40] - z['scores_sample']).max() < 1e-4
-    assert np.abs(Z[-1, ::10] - z['scores_lastrow']).max() < 1e-4 and np.abs(Z[::10, -1] - z['scores_lastcol']).max() < 1e-4
-    assert np.abs(out['source_final'][0, :, ::25, 0].cpu().numpy() - z['source_final_sample']).max() < 1e-4
-    assert np.abs(out['target_final'][0, :, ::25, 0].cpu().numpy() - z['target_final_sample']).max() < 1e-4
+    dZ = np.abs(Z[::40, ::40] - z['scores_sample'])
+    dS = np.abs(out['source_final'][0, :, ::25, 0].cpu().numpy() - z['source_final_sample']).max()
+    dT = np.abs(out['target_final'][0, :, ::25, 0].cpu().numpy() - z['target_final_sample']).max()
+    noise = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'match_ot_noise.json')))
+    print(f'[{tag}] |dZ| on the sample: max {dZ.max():.2e} median {np.median(dZ):.2e} p99 {np.quantile(dZ, 0.99):.2e}; final descriptors {dS:.2e} / {dT:.2e}')
+    if tag == 'full_match_ot':
+        # 1e-4 on every floating-point output, also at 2501 x 2501 after 100 Sinkhorn iterations (measured 2.3e-5 on the
+        # log-couplings, 4.5e-6 on the final descriptors; the reference's own float32-vs-float64 noise on this case is 3.2e-5 / 4.9e-6,
+        # tools/match_ot_noise.py -> tests/golden/match_ot_noise.json)
+        assert dZ.max() < 1e-4
+        assert np.abs(Z[-1, ::10] - z['scores_lastrow']).max() < 1e-4 and np.abs(Z[::10, -1] - z['scores_lastcol']).max() < 1e-4
+        assert dS < 1e-4 and dT < 1e-4
+    else:
+        # At 5000 x 5000 the reference is not within 1e-4 of ITSELF: its float32 forward against its own float64 forward (tools/match_ot_noise.py)
+        # differs by 4.1 on the log-couplings (median 3.2e-4, 86 % of the entries above 1e-4) and by 0.34 / 0.50 on the final descriptors --
+        # among 5000 candidates some point's k-th and (k+1)-th dot-product neighbours are closer than float32 resolves, another neighbour
+        # enters its attention, its descriptor moves, and with it a row and a column of Z and, through the normalisation, everything a
+        # little.  What that noise does NOT touch is what the pipeline consumes: matches0/1 (identical above) and the matching scores (1.4e-6;
+        # 1e-4 asserted above).  The continuous outputs are held to the reference's own float32 noise level: median and 99th percentile of
+        # |dZ| no larger than twice the reference's f32-vs-f64 figures, the descriptors no further than its own f32-vs-f64 distance.
+        nz = noise['full_5000x5000']
+        assert np.median(dZ) < 2 * nz['scores_median'] and np.quantile(dZ, 0.99) < 2 * nz['scores_p99'], (np.median(dZ), np.quantile(dZ, 0.99))
+        assert dZ.max() < 2 * nz['scores'] and dS < 2 * nz['source_final'] and dT < 2 * nz['target_final']
 
 
+@pytest.mark.parametrize('coop,mfma_layers', [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize('tag', ['full_match_ot', 'full_match_ot_5000'])
-def test_full_match_ot_stacked_path(rm_net, tag):
-    """The engine's path (match_stacked: several pairs per pass, Sinkhorn on recomputed scores -- one workgroup per strip at 2500 target
-    points, two cooperating ones at 5000) on the same full-size pairs."""
-    from roreg_amd import hip
+def test_full_match_ot_stacked_path(rm_net, tag, coop, mfma_layers, monkeypatch):
+    """The engine's path (match_stacked: several pairs per pass; forward()'s kernels, segmented) on the same full-size pairs against the
+    reference's forward: matches bit-exact, matching scores to 1e-4 -- at 2500 target points (one Sinkhorn recomputation per iteration) and
+    at 5000 (two passes per iteration; coop: two cooperating workgroups per strip).  mfma_layers = the opt-in ROREG_LINEAR_MFMA=1 (1x1
+    layers and R_indicator on the matrix cores, another rounding): identical at 2500; at 5000 ONE spurious mutual match of 136 (score 5e-4:
+    a top-k neighbour on the other side of a float32 near-tie) -- which is why it is not the default."""
+    from roreg_amd import hip, _hip_matcher
+    if coop and tag == 'full_match_ot':
+        pytest.skip('2500 target points: one workgroup per strip either way')
+    monkeypatch.setattr(_hip_matcher, 'OT_COOP', coop)
+    monkeypatch.setattr(rm_net, 'matrix_core_layers', mfma_layers, raising=False)
     z = load_golden(tag)
     f0, f1, k0, k1 = _match_ot_inputs(z)
     n = int(z['n'])
@@ -186,9 +210,16 @@ def test_full_match_ot_stacked_path(rm_net, tag):
     sk = cu(np.concatenate([k1, k1])); tk = cu(np.concatenate([k0, k0]))
     with torch.no_grad():
         res = rm_net.match_stacked(se, te, sk, tk, seg, seg)
+    want = z['matches0'].astype(np.int64)
     for m0, s0 in res:
-        assert np.array_equal(m0.cpu().numpy(), z['matches0'].astype(np.int64))
-        assert np.abs(s0.cpu().numpy() - z['matching_scores0']).max() < 1e-4
+        m0 = m0.cpu().numpy(); s0 = s0.cpu().numpy()
+        if mfma_layers and tag == 'full_match_ot_5000':
+            bad = np.nonzero(m0 != want)[0]
+            print(f'[{tag}] matrix-core layers: {len(bad)} of {int((want >= 0).sum())} matches differ, scores of the differing ones {s0[bad].tolist()}')
+            assert len(bad) <= 2 and (s0[bad] < 1e-2).all() and np.abs(s0 - z['matching_scores0'])[m0 == want].max() < 1e-4
+            continue
+        assert np.array_equal(m0, want)
+        assert np.abs(s0 - z['matching_scores0']).max() < 1e-4
 
 
 # ---- the whole path on three 5000-keypoint clouds against the reference's own end-to-end run -------------------------------------------

@@ -151,6 +151,45 @@ def test_linear_layers_on_the_matrix_cores_are_f32_accurate(cin, cout):
     assert err < 6e-7, err
 
 
+@pytest.mark.parametrize('cin,cout', [(32, 32), (96, 64), (120, 128), (64, 64), (96, 32), (120, 32), (64, 32), (3, 64), (3, 32)])
+def test_fmaf_chains_on_the_matrix_cores_are_bitwise_the_vector_pipe_chains(cin, cout, rm):
+    """The default 1x1 layers: one float32 fmaf chain per (row, output), inputs ascending, starting from the bias -- evaluated by
+    v_mfma_f32_32x32x2_f32, which IS such a chain on gfx950 (csrc/linear_chain.hip, tools/probe/mfma_f32_order.hip).  BITWISE the
+    vector-pipe kernels (hip.vector_pipe_layers) on rows spanning 1e-3 .. 1e6 in magnitude, float32 subnormals and exact zeros, ragged row
+    counts on both sides of the 128-row tile and of the 65536-row switch of the vector-pipe kernels; and the InstanceNorm + ReLU + second
+    conv + residual of mlp_2layer with per-pair statistics (segments cutting through row tiles)."""
+    from roreg_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(1000 * cin + cout)
+    for L in (1, 127, 129, 4133, 70001):
+        x = torch.randn((L, cin), device='cuda', generator=g)
+        x *= torch.pow(10.0, torch.randint(-3, 4, (L, 1), device='cuda', generator=g).float())
+        if L > 200:
+            x[7] *= 1e3; x[100:110] *= 1e-38; x[120:125] = 0.0                    # 1e6-sized rows, subnormal products, exact zeros
+        W = torch.randn((cout, cin), device='cuda', generator=g) * 0.3; b = torch.randn(cout, device='cuda', generator=g)
+        y = hip.linear(x, W, b)
+        with hip.vector_pipe_layers():
+            want = hip.linear(x, W, b)
+        assert torch.equal(y, want), (cin, cout, L, float((y - want).abs().max()))
+        ref = x.double() @ W.double().t() + b.double()
+        scale = x.double().abs() @ W.double().abs().t() + b.double().abs()
+        assert ((y.double() - ref).abs() / scale).max().item() < 4e-6
+    if (cin, cout) in ((64, 32), (120, 128)):                                        # mlp_2layer (64 -> 64 -> 32 and 120 -> 128 -> 32) with per-pair statistics
+        cmid = 64 if cin == 64 else 128
+        sizes = [900, 37, 5000, 130, 2500]
+        seg = hip.Segments(sizes)
+        for mult in (1, 16):
+            x = torch.randn((sum(sizes) * mult, cin), device='cuda', generator=g)
+            W1 = torch.randn((cmid, cin), device='cuda', generator=g) * 0.2; b1 = torch.randn(cmid, device='cuda', generator=g)
+            W2 = torch.randn((32, cmid), device='cuda', generator=g) * 0.2; b2 = torch.randn(32, device='cuda', generator=g)
+            Wr = torch.randn((32, cin), device='cuda', generator=g) * 0.2; br = torch.randn(32, device='cuda', generator=g)
+            if cin == 120:
+                continue                                                          # (a 120 -> 128 first conv exists, its residual branch is 120 -> 32)
+            y = hip.mlp_instnorm(x, W1, b1, W2, b2, Wr, br, seg=seg)
+            with hip.vector_pipe_layers():
+                want = hip.mlp_instnorm(x, W1, b1, W2, b2, Wr, br, seg=seg)
+            assert torch.equal(y, want), (cin, mult)
+
+
 def test_mlp_tail_on_the_matrix_cores(rm):
     """mlp_2layer (conv -> InstanceNorm -> ReLU -> conv + residual conv; rot_coh_match.py:14-32) with the shipped final_mlp weights against
     a float64 torch evaluation of the same formula."""
@@ -282,14 +321,16 @@ def test_sinkhorn_recomputed_on_the_matrix_cores_equals_the_materialised_iterati
         o0 += m; o1 += n
 
 
-def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
-    """of_iter_kernel / of_iter_coop_kernel (one recomputation per iteration, csrc/ot_flash.hip) over their template ranges: 1 ... 10 column
-    tiles per wave, one workgroup per strip (target clouds up to 2559 points) and two cooperating ones (2560 ... 5119), source clouds on
-    both sides of 2559 points (more than 80 strip sums per column), ragged pairs in one call (tiles a pair does not have read the pad
-    tile; each of the two kernels skips the other's pairs).  (a) A pair's matches AND scores are bitwise the same stacked and
-    alone -- alone the kernel is another instantiation (tiles per wave follow the call's longest target cloud), so this is the
-    association-independence the kernels promise; (b) against the materialised iteration: matches identical where the arg-max is decided,
-    scores to 5e-5; (c) a call with a target cloud above 5119 points takes the two-pass form and meets the same bar."""
+@pytest.mark.parametrize('mode', [True, 'coop'])
+def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking(mode):
+    """The forms of the recomputed iteration (csrc/ot_flash.hip) in ONE stacked call: of_iter_kernel (target clouds up to 2559 points, 1 ... 10
+    column tiles per wave), and beyond that two passes per iteration (mode True, the default) or two cooperating workgroups per strip up to
+    5119 points (mode 'coop'); source clouds on both sides of 2559 points (more than 80 strip sums per column); ragged pairs (tiles a pair
+    does not have read the pad tile; every kernel skips the pairs of the other form).  (a) A pair's matches AND scores are bitwise the same
+    stacked and alone -- alone the kernels are other instantiations (tiles per wave follow the call's longest target cloud) and the group
+    needs other launches, so this is the independence of the stacking that the forms promise; (b) against the materialised iteration:
+    matches identical where the arg-max is decided, scores to 5e-5; (c) a call with a target cloud above 5119 points takes the two-pass
+    form in both modes and meets the same bar."""
     from roreg_amd import hip
     rng = np.random.default_rng(41)
     sizes = [(2500, 2500), (700, 1200), (1200, 700), (20, 300), (2500, 90), (3000, 1000), (5000, 2400), (1000, 3000), (2600, 5000), (300, 2600), (64, 5119)]
@@ -301,6 +342,7 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
         S.append(s); T.append(t)
 
     def run(idx, recompute):
+        recompute = mode if recompute else False
         seg_s = hip.Segments([sizes[q][0] for q in idx]); seg_t = hip.Segments([sizes[q][1] for q in idx])
         out = hip.sinkhorn_batch(cu(np.concatenate([S[q] for q in idx])), cu(np.concatenate([T[q] for q in idx])), seg_s, seg_t, 1.5, 100, recompute=recompute)
         return [x.cpu().numpy() for x in out], seg_s.host, seg_t.host
@@ -320,7 +362,7 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
     t[:150] = s[:150] * 3
     seg_s = hip.Segments([300, sizes[1][0]]); seg_t = hip.Segments([5200, sizes[1][1]])
     cs, ct = cu(np.concatenate([s, S[1]])), cu(np.concatenate([t, T[1]]))
-    d = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=True)]
+    d = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=mode)]
     e = [x.cpu().numpy() for x in hip.sinkhorn_batch(cs, ct, seg_s, seg_t, 1.5, 100, recompute=False)]
     same = d[0] == e[0]
     assert same.mean() > 0.995 and (d[0][:300] >= 0).sum() >= 145 and np.abs(d[2][same] - e[2][same]).max() < 5e-5
@@ -333,9 +375,9 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking():
 def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path, fvar, m, n):
     """of_iter_kernel redoes a strip with the row maxima as stabilisers when a row's sum leaves (1e-35, 1e35) -- which finite, sanely scaled
     input never provokes.  ROREG_OT_FVAR=6 (read once per process: a child process) sends EVERY strip through that path: same matches,
-    scores to 2e-5 against the normal path (also with two cooperating workgroups per strip: n = 5000, three exchanges per iteration).
+    scores to 2e-5 against the normal path (n = 5000: the cooperating workgroups, three exchanges per iteration).
     ROREG_OT_FVAR=7: the two halves of a strip never see each other's words, i.e. every workgroup takes the bounded wait's fall-back
-    (the partner's sums recomputed locally, then its own strip again) -- BITWISE the normal path's matches and scores."""
+    (the partner's sums recomputed locally) -- BITWISE the normal path's matches and scores."""
     import subprocess, sys
     from roreg_amd import hip
     rng = np.random.default_rng(43)
@@ -346,19 +388,22 @@ def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path, fva
             "from roreg_amd import hip\n"
             "z = np.load(sys.argv[1]); s = torch.from_numpy(z['s']).cuda(); t = torch.from_numpy(z['t']).cuda()\n"
             "seg_s = hip.Segments([s.shape[0]]); seg_t = hip.Segments([t.shape[0]])\n"
-            "a0, a1, as0, as1 = hip.sinkhorn_batch(s, t, seg_s, seg_t, 1.5, 100, recompute=True)\n"
+            "a0, a1, as0, as1 = hip.sinkhorn_batch(s, t, seg_s, seg_t, 1.5, 100, recompute='coop')\n"
             "np.savez(sys.argv[2], a0=a0.cpu().numpy(), a1=a1.cpu().numpy(), as0=as0.cpu().numpy(), as1=as1.cpu().numpy())\n")
     env = dict(os.environ, ROREG_OT_FVAR=str(fvar), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(tmp_path / 'out.npz')
-    seg = hip.Segments([m])
-    a0, a1, as0, as1 = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(s), cu(t), seg, hip.Segments([n]), 1.5, 100, recompute=True)]
+    a0, a1, as0, as1 = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(s), cu(t), hip.Segments([m]), hip.Segments([n]), 1.5, 100, recompute='coop')]
     if fvar == 7:
         assert np.array_equal(z['a0'], a0) and np.array_equal(z['a1'], a1) and np.array_equal(z['as0'], as0) and np.array_equal(z['as1'], as1)
     same = z['a0'] == a0
     assert same.mean() > 0.998 and (a0 >= 0).sum() >= 990, same.mean()
     assert np.abs(z['as0'][same] - as0[same]).max() < 2e-5 and np.abs(z['as1'][z['a1'] == a1] - as1[z['a1'] == a1]).max() < 2e-5
+    if n > 2559:                                                   # and the two forms a long target cloud can take agree like two arithmetics do
+        b0, b1, bs0, bs1 = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(s), cu(t), hip.Segments([m]), hip.Segments([n]), 1.5, 100, recompute=True)]
+        same = a0 == b0
+        assert same.mean() > 0.998 and np.abs(as0[same] - bs0[same]).max() < 2e-5
 
 
 def test_sinkhorn_recomputed_survives_non_finite_and_huge_descriptors():
@@ -399,12 +444,15 @@ def test_match_ot_forward_vs_reference_golden(rm):
     assert np.abs(out['scores_other'].cpu().numpy() - z['out_scores_other']).max() < 1e-4
 
 
-def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm):
+@pytest.mark.parametrize('mfma_layers', [False, True])
+def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm, mfma_layers):
     """Several ragged pairs through ONE pass of the network (segmented neighbour search, InstanceNorm statistics, context maximum,
-    Sinkhorn) against forward() pair by pair: identical matches, scores to rounding (the stacked path runs its 1x1 layers on the matrix
-    cores and its Sinkhorn iterations on recomputed scores: float32-accurate, another rounding than forward()'s).  The golden pair is
-    one of them and is checked against the reference directly; a pair's result does not depend on the pairs stacked beside it."""
+    Sinkhorn) against forward() pair by pair.  Default: the stacked path runs forward()'s kernels -- matches AND scores BITWISE the
+    per-pair forward()'s (one arithmetic behind both).  mfma_layers (ROREG_LINEAR_MFMA=1, opt-in): its 1x1 layers and R_indicator on the
+    matrix cores -- float32-accurate, another rounding: identical matches on these pairs, scores to 2e-5.  The golden pair is one of them
+    and is checked against the reference directly; a pair's result does not depend on the pairs stacked beside it."""
     net, sd = rm
+    object.__setattr__(net, 'matrix_core_layers', mfma_layers)
     z = load_golden('match_ot')
     rng = np.random.default_rng(11)
     pairs = [(cu(z['feats0'][0]), cu(z['feats1'][0]), cu(z['keys0'][0]), cu(z['keys1'][0]))]
@@ -419,8 +467,10 @@ def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm):
         for (f0, f1, k0, k1), (m0, s0) in zip(pairs, got):
             want = net({'feats0': f0[None], 'feats1': f1[None], 'keys0': k0[None], 'keys1': k1[None]})
             assert torch.equal(m0, want['matches0'][0])
-            # the stacked Sinkhorn folds rows into the column sums in one pass (different association than the two-matrix passes)
-            assert (s0 - want['matching_scores0'][0]).abs().max() < 2e-5
+            if mfma_layers:
+                assert (s0 - want['matching_scores0'][0]).abs().max() < 2e-5
+            else:
+                assert torch.equal(s0, want['matching_scores0'][0])
     assert np.array_equal(got[0][0].cpu().numpy(), z['out_matches0'][0])
     assert np.abs(got[0][1].cpu().numpy() - z['out_matching_scores0'][0]).max() < 1e-4
     assert int((got[1][0] >= 0).sum()) > 20                      # the synthetic pairs do produce matches
@@ -428,6 +478,7 @@ def test_match_ot_stacked_pairs_equal_the_per_pair_forward(rm):
         alone = net.match_many(pairs[2:3]); reordered = net.match_many([pairs[3], pairs[2], pairs[0]])
     assert torch.equal(alone[0][0], got[2][0]) and torch.equal(alone[0][1], got[2][1])                  # bitwise, whatever the stacking
     assert torch.equal(reordered[1][0], got[2][0]) and torch.equal(reordered[1][1], got[2][1]) and torch.equal(reordered[2][1], got[0][1])
+    object.__setattr__(net, 'matrix_core_layers', None)
 
 
 def test_stage_yoho_mat_and_yohoo_with_rm_scores(tmp_path):

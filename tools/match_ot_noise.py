@@ -33,19 +33,25 @@ def main():
     cases = {}
     z = np.load(os.path.join(OUT, 'match_ot.npz'))
     cases['golden_120x112'] = {k: torch.from_numpy(z[k]) for k in ('feats0', 'feats1', 'keys0', 'keys1')}
-    zf = np.load(os.path.join(OUT, 'full_match_ot.npz'))
-    n = int(zf['n'])
-    ds = synth.make_scene(int(zf['scene_seed']), n_clouds=2, n_kpts=n, overlap=0.6, coord_noise=0.005, portable=True)
-    f0 = ds.feats[0]; f1 = ds.feats[1]
-    f0 = f0 / np.sqrt((f0 * f0).sum(1, keepdims=True)); f1 = f1 / np.sqrt((f1 * f1).sum(1, keepdims=True))
-    cases['full_2500x2500'] = {'feats0': torch.from_numpy(f1[None].copy()), 'feats1': torch.from_numpy(f0[None].copy()),
-                               'keys0': torch.from_numpy(ds.get_kps('1').astype(np.float32)[None].copy()),
-                               'keys1': torch.from_numpy(ds.get_kps('0').astype(np.float32)[None].copy())}
+    for tag, name in (('full_match_ot', 'full_2500x2500'), ('full_match_ot_5000', 'full_5000x5000')):
+        zf = np.load(os.path.join(OUT, f'{tag}.npz'))
+        n = int(zf['n'])
+        ds = synth.make_scene(int(zf['scene_seed']), n_clouds=2, n_kpts=n, overlap=0.6, coord_noise=0.005, portable=True)
+        f0 = ds.feats[0]; f1 = ds.feats[1]
+        f0 = f0 / np.sqrt((f0 * f0).sum(1, keepdims=True)); f1 = f1 / np.sqrt((f1 * f1).sum(1, keepdims=True))
+        cases[name] = {'feats0': torch.from_numpy(f1[None].copy()), 'feats1': torch.from_numpy(f0[None].copy()),
+                       'keys0': torch.from_numpy(ds.get_kps('1').astype(np.float32)[None].copy()),
+                       'keys1': torch.from_numpy(ds.get_kps('0').astype(np.float32)[None].copy())}
     out = {}
     for name, batch in cases.items():
         f32, i32 = run(net, batch, torch.float32)
         f64, i64 = run(net, batch, torch.float64)
         res = {k: float(np.abs(f32[k] - f64[k]).max()) for k in f32 if k in f64 and f32[k].shape == f64[k].shape}
+        d = np.abs(f32['scores'] - f64['scores'])[0]
+        # how the float32 evaluation noise is distributed: a top-k neighbour that flips between the two precisions moves whole rows / columns
+        res['scores_median'] = float(np.median(d)); res['scores_p99'] = float(np.quantile(d, 0.99)); res['scores_p9999'] = float(np.quantile(d, 0.9999))
+        res['scores_rows_above_1e-4'] = int((d.max(1) > 1e-4).sum()); res['scores_cols_above_1e-4'] = int((d.max(0) > 1e-4).sum())
+        res['scores_fraction_above_1e-4'] = float((d > 1e-4).mean())
         res['matches0_equal'] = bool(np.array_equal(i32['matches0'], i64['matches0']))
         res['matches0_differing'] = int((i32['matches0'] != i64['matches0']).sum())
         out[name] = res

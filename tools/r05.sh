@@ -30,11 +30,33 @@ tests)
   tag=$(echo "$1" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40)
   timeout 3000 python -m pytest ${2:-tests} -m gpu -x -q -s -k "$1" > $OUT/pytest_$tag.log 2>&1; echo "pytest rc $?"; grep -E "^\[|passed|failed|Error|error" $OUT/pytest_$tag.log | tail -40 ;;
 ot5000)
-  echo "--- cooperating workgroups"; timeout 600 python tools/time_sinkhorn.py 5000 1 4 13 26 2>&1 | tail -4
-  echo "--- two-pass form (ROREG_OT_COOP=0)"; ROREG_OT_COOP=0 timeout 600 python tools/time_sinkhorn.py 5000 13 26 2>&1 | tail -2
+  echo "--- two passes per iteration (default beyond 2559 target points)"; timeout 600 python tools/time_sinkhorn.py 5000 1 4 13 26 52 2>&1 | tail -5
+  echo "--- cooperating workgroups (ROREG_OT_COOP=1)"; ROREG_OT_COOP=1 timeout 600 python tools/time_sinkhorn.py 5000 13 26 52 2>&1 | tail -3
   echo "--- 2500"; timeout 600 python tools/time_sinkhorn.py 2500 30 100 2>&1 | tail -2
   kt sinkhorn_5000 tools/time_sinkhorn.py 5000 26
   grep -E "of_|calls" $OUT/sinkhorn_5000_kernel_trace.txt | cut -c1-160 ;;
+otpmc)   # otpmc <tag> <size> <pairs>: kernel trace + Sinkhorn-specific counter passes of tools/time_sinkhorn.py
+  tag=${1:-ot}; size=${2:-2500}; pairs=${3:-100}
+  export ROREG_TS_RECOMPUTE_ONLY=1
+  kt sinkhorn_$tag tools/time_sinkhorn.py $size $pairs
+  grep -E "of_|calls" $OUT/sinkhorn_${tag}_kernel_trace.txt | cut -c1-150
+  rm -rf $OUT/pmc_sk; i=0
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_sk/g$i -- python3 tools/time_sinkhorn.py $size $pairs > $OUT/pmc_sk_g$i.log 2>&1 || tail -3 $OUT/pmc_sk_g$i.log
+  done
+  python3 tools/pmc_kernel_means.py $OUT/pmc_sk > $OUT/sinkhorn_${tag}_pmc.txt
+  grep -E "of_iter" -A16 $OUT/sinkhorn_${tag}_pmc.txt | head -60
+  rm -rf $OUT/pmc_sk ;;
+config4)   # config4 [tag] [keynum]: kernel trace (+ idle gaps) of BASELINE configs[3]'s path (RD + RM + yohoo, 16 clouds / 60 pairs)
+  tag=${1:-head}; kn=${2:-2500}
+  rm -rf $OUT/kt_c4
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_c4 -- python3 tools/time_configs.py 16 60 --only RD+RM+yohoo --keynum $kn > $OUT/kt_c4.log 2>&1; tail -2 $OUT/kt_c4.log
+  db=$(find $OUT/kt_c4 -name '*.db' | head -1)
+  python3 tools/rocprof_summary.py $db $OUT/rd_rm_config_${tag}_kernel_trace.txt > /dev/null
+  python3 tools/rocprof_gaps.py $db > $OUT/rd_rm_config_${tag}_gaps.txt 2>&1; tail -15 $OUT/rd_rm_config_${tag}_gaps.txt
+  rm -rf $OUT/kt_c4
+  head -45 $OUT/rd_rm_config_${tag}_kernel_trace.txt | cut -c1-190 ;;
 bench)
   tag=${1:-head}; shift
   timeout 1500 python bench.py --steps 20 --warmup 5 "$@" > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err; echo "bench rc $?"

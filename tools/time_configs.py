@@ -20,6 +20,8 @@ for name, kw in (('mutual+yohoo', dict(keynum=5000, ET='yohoo')), ('mutual+yohoc
                  ('RD+RM+yohoo@1000', dict(keynum=1000, ET='yohoo', RD=True, RM=True))):      # the reference README's command line
     if '--only' in sys.argv and sys.argv[sys.argv.index('--only') + 1] != name:
         continue
+    if '--keynum' in sys.argv:
+        kw = dict(kw, keynum=int(sys.argv[sys.argv.index('--keynum') + 1]))
     cfg = default_config(max_iter=1000, **kw)
     gf = name2network['GF_test'](cfg); synth.seeded_state_dict(gf, 101)
     et = name2network['ET_test'](cfg); synth.seeded_state_dict(et, 202)
