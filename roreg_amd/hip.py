@@ -6,6 +6,7 @@ fails, an exception is raised (the product path must never silently run on the C
 """
 import ctypes
 import os
+import threading
 from ctypes import c_int, c_void_p, c_size_t, c_double, c_float, c_char_p
 
 import numpy as np
@@ -123,15 +124,15 @@ class _StagingRing:
         return dev
 
 
-_staging = None
+_staging = threading.local()          # one ring per host thread (a thread drives one stream)
 
 
 def upload(array):
     """numpy array -> device tensor (same shape and dtype) through the staging ring: does not wait for the kernels queued on the stream."""
-    global _staging
-    if _staging is None:
-        _staging = _StagingRing()
-    return _staging.upload(array)
+    ring = getattr(_staging, 'ring', None)
+    if ring is None:
+        ring = _staging.ring = _StagingRing()
+    return ring.upload(array)
 
 
 def _ptr(t, dtype=None):
