@@ -276,12 +276,14 @@ class RegistrationEngine:
                 raw.append(self.rd({'feats': x})['scores'])
                 i = j
         flat = torch.cat(raw).cpu().numpy()
-        o = 0
-        for c in todo:
-            n = c.eqv.shape[0]
-            s = flat[o:o + n].copy(); o += n
+        offs = np.cumsum([0] + [c.eqv.shape[0] for c in todo])
+
+        def rank(q):                                                  # (numpy's sort releases the GIL: the clouds' rank transforms run side by side)
+            s = flat[offs[q]:offs[q + 1]].copy()
             a = np.argsort(s)
             s[a] = np.arange(s.shape[0]) / s.shape[0]
+            return s
+        for c, s in zip(todo, _host_pool().map(rank, range(len(todo)))):
             c.det = s
 
     def nms_many(self, clouds, keynum):
@@ -301,8 +303,9 @@ class RegistrationEngine:
             seg = hip.Segments([c.keys.shape[0] for c in need])
             pts = torch.cat([c.keys.float() for c in need]).contiguous()
             flat = hip.knn_search_seg(pts, seg, 5).cpu().numpy()          # every cloud's 5-NN lists (self included) in two launches
-            for c, a, b in zip(need, seg.host[:-1], seg.host[1:]):
-                c.nms[keynum] = sampler.sample_from_neighbours(c.det, flat[a:b])
+            picks = _host_pool().map(lambda q: sampler.sample_from_neighbours(need[q].det, flat[seg.host[q]:seg.host[q + 1]]), range(len(need)))
+            for c, pick in zip(need, picks):
+                c.nms[keynum] = pick
 
     # ---- per pair ------------------------------------------------------------------------------------------
     def sample(self, c0, c1, keynum, seed=None):

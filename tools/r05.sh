@@ -54,7 +54,7 @@ config4)   # config4 [tag] [keynum]: kernel trace (+ idle gaps) of BASELINE conf
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_c4 -- python3 tools/time_configs.py 16 60 --only RD+RM+yohoo --keynum $kn > $OUT/kt_c4.log 2>&1; tail -2 $OUT/kt_c4.log
   db=$(find $OUT/kt_c4 -name '*.db' | head -1)
   python3 tools/rocprof_summary.py $db $OUT/rd_rm_config_${tag}_kernel_trace.txt > /dev/null
-  python3 tools/rocprof_gaps.py $db > $OUT/rd_rm_config_${tag}_gaps.txt 2>&1; tail -15 $OUT/rd_rm_config_${tag}_gaps.txt
+  python3 tools/rocprof_gaps.py $db 0.5 > $OUT/rd_rm_config_${tag}_gaps.txt 2>&1; tail -15 $OUT/rd_rm_config_${tag}_gaps.txt
   rm -rf $OUT/kt_c4
   head -45 $OUT/rd_rm_config_${tag}_kernel_trace.txt | cut -c1-190 ;;
 bench)
