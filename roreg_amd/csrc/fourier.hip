@@ -971,6 +971,9 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
     //     column blocks 4-7 the ACTIVATIONS of step S + 2 into the activation stages of step S - 1;
     //   * the one barrier of the step sits in front of column block 7, behind s_waitcnt vmcnt(3): in issue order only the three activation
     //     pieces of blocks 4-6 may be in flight, so this step's weight pieces and everything older (the activations of step S + 1) have landed;
+    //     the same wait covers lgkmcnt(0): block 7's own fragments and `an`'s last one (requested in block 6) have been READ out of the
+    //     stages the next DMA pieces overwrite before any wave passes the barrier (round 4 relied on DMA latency >> LDS latency there;
+    //     the wait is free: block 7 waits for the same fragments immediately behind the barrier);
     //   * behind it column block 7 reads step S + 1's first column block, and step S + 1 reads its weight fragments; in front of it lie all
     //     reads of this step's activation stages (the last: block 7's fragments, requested in block 6) and of step S + 1's weight stages
     //     (the eight fragments of `an`, column blocks 0-6) -- the stages the next step's DMA overwrites.
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
             constexpr int cb = decltype(cb_c)::value;
             frag (&bc)[2] = (cb & 1) ? b1 : b0;
             frag (&bn)[2] = (cb & 1) ? b0 : b1;
-            if constexpr (cb == 7) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+            if constexpr (cb == 7) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ROREG_PIN_B("s_waitcnt lgkmcnt(0)", bc);                                  // this column block's fragments (requested one block ago)
             auto mm = [&](int i) {                                                     // product i of the four row blocks: 0 = lo.hi, 1 = hi.lo, 2 = hi.hi
                 const frag bb = bc[i == 1 ? 1 : 0];

@@ -178,7 +178,10 @@ class watchdog:
     process ends with status 1 (faulthandler's own C thread: it needs neither the GIL nor a live Python main thread, so it also fires
     while the host is stuck inside a collective or a stream synchronisation behind one).  A hung rank then fails the whole job
     (torch.distributed.run tears the other ranks down) instead of holding the node.  Nothing is re-executed and nothing forks.
-    Blocks may nest: leaving the inner one re-arms the outer one with the time it has left.  seconds <= 0 disables."""
+    Blocks may nest: leaving the inner one re-arms the outer one with the time it has left.  seconds <= 0 disables.
+    The watchdog OWNS faulthandler's one process-global timer while a block is open (another user of dump_traceback_later -- e.g. pytest's
+    faulthandler_timeout -- would cancel it and be cancelled by it).  Arming writes one line `what` + the deadline to stderr, so the stacks
+    a timeout dumps can be attributed to the collective section that hung."""
     _stack = []
 
     def __init__(self, seconds, what=''):
@@ -186,8 +189,10 @@ class watchdog:
 
     @staticmethod
     def _arm(deadline, what):
-        import faulthandler, sys, time
+        import faulthandler, os, sys, time
         left = max(deadline - time.monotonic(), 0.05)
+        if what and os.environ.get('ROREG_WATCHDOG_QUIET', '0') in ('', '0'):
+            sys.stderr.write(f'[roreg watchdog] {what}: stacks + exit(1) if not finished in {left:.0f} s\n')
         sys.stderr.flush()
         faulthandler.dump_traceback_later(left, exit=True)
 

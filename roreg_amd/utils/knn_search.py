@@ -10,7 +10,11 @@ and the class's other public methods with the reference's signatures, shapes and
 find_knn_gpu (:68-103), find_corr (:105-136).  dist_type 'L2' = sqrt(sum (a-b)^2 + 1e-7), 'SquareL2' = sum (a-b)^2; anything else raises
 NotImplementedError('Not implemented') like the reference.  `nn_max_n` (the reference's chunk length against its N x M temporary) is
 accepted and ignored: the kernels never materialise the matrix.  The distance formula / tie-break contract is the kernels'
-(roreg_nn_search_ex, roreg_knn_search_ex, roreg_pdist): first minimum wins, k lists in increasing distance."""
+(roreg_nn_search_ex, roreg_knn_search_ex, roreg_pdist): first minimum wins, k lists in increasing distance.
+
+Restriction (the reference accepts any width and any k): the search kernels are built for the two feature widths the pipeline uses -- 3
+(keypoint coordinates) and 32 (FCGF / invariant descriptors) -- and for k <= 8; anything else raises NotImplementedError here, before
+a kernel is launched (only `pdist` is general).  A one-row input keeps its row axis (the reference's `.squeeze()` would drop it)."""
 import numpy as np
 import torch
 
@@ -25,12 +29,25 @@ def _squared(dist_type):
     raise NotImplementedError('Not implemented')
 
 
-def _rows(F):
-    """the reference's `.squeeze()`d [rows, f] matrix, on the device in float32"""
+SUPPORTED_WIDTHS, MAX_K = (3, 32), 8
+
+
+def _check_shape(f, k=1):
+    if f not in SUPPORTED_WIDTHS:
+        raise NotImplementedError(f'knn_module: feature width {f} is not supported by the HIP search kernels (built for widths {SUPPORTED_WIDTHS}); '
+                                  'use pdist() for other widths')
+    if k > MAX_K:
+        raise NotImplementedError(f'knn_module: k = {k} is not supported by the HIP search kernels (k <= {MAX_K})')
+
+
+def _rows(F, k=1):
+    """the reference's `.squeeze()`d [rows, f] matrix, on the device in float32 (a single row keeps its row axis)"""
     F = F if torch.is_tensor(F) else torch.as_tensor(np.asarray(F))
-    F = F.squeeze()
+    if F.dim() > 2:
+        F = F.reshape(-1, F.shape[-1]) if F.numel() == F.shape[-2] * F.shape[-1] else F.squeeze()
     if F.dim() == 1:
         F = F[None]
+    _check_shape(int(F.shape[-1]), k)
     return F.to('cuda', torch.float32).contiguous()
 
 
@@ -55,7 +72,7 @@ class modified_knn_matcher():
     def find_knn_gpu(self, source_F, target_F, nn_max_n=1000, return_distance=True, dist_type='SquareL2'):
         """-> (dists [m,1,k] f32, inds [m,k] i64) CPU tensors, or inds alone (utils/knn_search.py:68-103)."""
         sq = _squared(dist_type)
-        idx, d = hip.knn_search(_rows(source_F), _rows(target_F), self.k, want_dist=True, squared=sq)
+        idx, d = hip.knn_search(_rows(source_F, self.k), _rows(target_F, self.k), self.k, want_dist=True, squared=sq)
         dists, inds = d.cpu()[:, None, :], idx.cpu()
         return (dists, inds) if return_distance else inds
 
@@ -81,6 +98,7 @@ class modified_knn_matcher():
 
     def __call__(self, target_F, source_F, nn_max_n=500, dist_type='L2'):
         sq = _squared(dist_type)
+        _check_shape(int(target_F.shape[-2]), self.k)
         tgt = target_F.reshape(target_F.shape[-2], target_F.shape[-1]).t().to('cuda', torch.float32).contiguous()   # [n,f]
         src = source_F.reshape(source_F.shape[-2], source_F.shape[-1]).t().to('cuda', torch.float32).contiguous()   # [m,f]
         if self.k < 2:
