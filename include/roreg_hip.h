@@ -93,6 +93,13 @@ int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w_exp, const
 int roreg_dense_f16x2(const float *x, const void *wsplit2, int w_exp, const float *bias, const float *scale, const float *shift,
                       float act_smax, float act_tmax, const float *in_rowmax_dev, const float *residual, int residual_stride, float *out,
                       float *out_rowmax_dev, int B, int K, int O, void *stream);
+/* v5: the ET trunk's 256 -> 512 convolution (network/eqv_trans.py:101-117, network/ops.py:46-57) fed by roreg_ft_nonlin_packed: x_words [B,Cin,Lin] holds
+ * fp16 hi | fp16 lo << 16 of ReLU(BN(x[b])) * 2^e_b with e_b derived from in_bound_dev[b] (the bound the producer scaled with) -- BatchNorm, ReLU and
+ * the operand split happened in the producer, the kernel's staging only regroups the halves.  Same outputs as roreg_group_conv_f16x2 up to the
+ * block scale (a propagated bound instead of the tracked row maximum: ~3 of the 22 bits). */
+int roreg_group_conv_f16x2_packed(const uint32_t *x_words, const void *wsplit2, int w_exp, const float *bias, const float *in_bound_dev,
+                                  float *out, float *out_rowmax_dev, const int32_t *gather, const int32_t *lds_order, int lds_stride,
+                                  int B, int Cin, int Cout, int Lin, int Lout, int KS, void *stream);
 
 /* eqv_raw [B,32,60] -> eqv = eqv_raw / max(||.||_2 over 32 ch, 1e-4) per (b,g);
  * inv = mean_g(eqv_raw) / max(||.||, 1e-4)  (inv may be NULL).  network/group_feat.py:38-43. */
@@ -502,6 +509,13 @@ int roreg_ft_nonlin(const float *Xin /* flat [60*C*B] */, const float *x_spatial
                     int spatial_bf16 /* x_spatial / resid_spatial point to bfloat16 tensors (BASELINE config 5: group features stored as bf16) */,
                     int out_planes /* split = 2 with Xout: write Xout in the HALF-BLOCK layout roreg_irrep_gemm_f16x2(x_planes = 1) consumes */,
                     void *stream);
+/* v5: the inverse transform + bias + BatchNorm + ReLU of roreg_ft_nonlin with the group-domain result [B,C,Lout] written as WORDS fp16 hi | fp16 lo << 16
+ * of value * 2^e_b, e_b = the block exponent of out_bound[b] (a bound on |ReLU(BN(.))| of row b that exists before the tensor does: the producing
+ * GEMM's propagated bound with u_o = sqrt(60) |scale_o|, v_o = |scale_o| |bias_o| + |shift_o|) -- the operand of roreg_group_conv_f16x2_packed.
+ * raw_col (nullable, [B,C] float32): the value BEFORE BatchNorm / ReLU at group element raw_g (ET's identity short cut, eqv_trans.py:112-117). */
+int roreg_ft_nonlin_packed(const float *Xin, const float *bias, const float *bn_scale, const float *bn_shift, uint32_t *out_words,
+                           const int32_t *g_map, int Lout, int Lvalid, int B, int C, const float *out_bound, float *raw_col, int raw_g,
+                           void *stream);
 
 /* Optional kernel timing for bench.py's measured rooflines (no reference counterpart: the reference has no profiler hooks).
  * While enabled, the library brackets selected launches with HIP events recorded ON THE LAUNCH STREAM; roreg_profile_read synchronises

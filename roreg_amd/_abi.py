@@ -19,6 +19,7 @@ PROTOTYPES = {
     'roreg_group_conv': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     'roreg_group_conv_split': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'roreg_group_conv_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'roreg_group_conv_f16x2_packed': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'roreg_dense_f16x2': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, c_float, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     'roreg_dense_split': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     'roreg_gf_finalize': (c_int, [_P, _P, c_int, _P, c_int, _P]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     'roreg_irrep_gemm_f16x2': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     'roreg_row_bound': (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P]),
     'roreg_ft_nonlin': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
+    'roreg_ft_nonlin_packed': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
 }
 
 

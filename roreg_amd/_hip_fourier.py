@@ -10,7 +10,7 @@ import torch
 from . import hip as _core
 from .hip import HipError, _check, _feat, _ptr, _stream, lib
 
-__all__ = ['DenseSplitLayer', 'IRREP_DIMS', 'IRREP_OFFSETS', '_bf16_split3', '_keypoint_of_columns', '_ptr_array', '_res_ptr', '_tile_cache', 'bf16_split3_pack', 'bound_exp', 'coef_pitch', 'coef_size', 'coef_views', 'dense_split', 'ensure_fourier', 'f16_scale_exp', 'f16_split2_pack', 'ft_nonlin', 'group_conv_split_pack', 'irrep_gemm', 'next_bound', 'pack_coefs_f16x2', 'row_bound', 'unpack_coefs_f16x2', 'words_to_planes']
+__all__ = ['DenseSplitLayer', 'IRREP_DIMS', 'IRREP_OFFSETS', '_bf16_split3', '_keypoint_of_columns', '_ptr_array', '_res_ptr', '_tile_cache', 'bf16_split3_pack', 'bound_exp', 'coef_pitch', 'coef_size', 'coef_views', 'dense_split', 'ensure_fourier', 'f16_scale_exp', 'f16_split2_pack', 'ft_nonlin', 'ft_nonlin_packed', 'group_conv_split_pack', 'irrep_gemm', 'next_bound', 'next_bound_spatial', 'pack_coefs_f16x2', 'row_bound', 'unpack_coefs_f16x2', 'words_to_planes']
 
 
 _fourier_ready = False
@@ -168,6 +168,35 @@ def unpack_coefs_f16x2(X_words, bound, C, B):
         lo = (w >> 16).to(torch.int16).view(torch.float16).float()
         o.copy_(torch.ldexp(hi + lo, -e[kp][None, :]))
     return out
+
+
+def next_bound_spatial(bn, bias):
+    """(u, v) device float32 [O] for a GEMM epilogue whose output goes back to the GROUP domain through ReLU(scale_o (IFT(T)_o + bias_o) + shift_o)
+    (roreg_ft_nonlin_packed): |IFT(T)(g)| <= sqrt(60) max_q |T_q|, so |value| <= max_{o,q} (sqrt(60) |scale_o| |T_oq| + |scale_o| |bias_o| + |shift_o|);
+    the 2^-9 margin covers the float32 rounding of the transform."""
+    scale, shift = bn
+    sc = scale.detach().double().abs().cpu(); sh = shift.detach().double().abs().cpu()
+    b = bias.detach().double().cpu()
+    k = 1.0 + 2.0 ** -9
+    u = (np.sqrt(60.0) * k) * sc
+    v = k * (sc * b.abs() + sh) + 1e-30
+    return u.float().cuda().contiguous(), v.float().cuda().contiguous()
+
+
+def ft_nonlin_packed(B, C, coef_in, bias, bn, out_bound, g_map=None, Lout=60, Lvalid=60, raw_g=None):
+    """IFT + bias + BatchNorm + ReLU -> (words int32 [B,C,Lout] = fp16 hi | lo << 16 under the block scale of out_bound, raw [B,C] float32 = the
+    pre-activation value of group element raw_g or None): the operand of hip.group_conv_packed."""
+    ensure_fourier()
+    dev = coef_in.device
+    if coef_in.numel() != coef_size(C, B) or out_bound.numel() != coef_pitch(B):
+        raise HipError('ft_nonlin_packed: coef_in / out_bound sizes')
+    words = torch.empty((B, C, Lout if g_map is not None else 60), dtype=torch.int32, device=dev)
+    raw = torch.empty((B, C), dtype=torch.float32, device=dev) if raw_g is not None else None
+    scale, shift = bn if bn is not None else (None, None)
+    _check(lib().roreg_ft_nonlin_packed(_ptr(coef_in, torch.float32), _ptr(bias), _ptr(scale), _ptr(shift), _ptr(words), _ptr(g_map, torch.int32),
+                                        int(Lout), int(Lvalid), B, C, _ptr(out_bound, torch.float32), _ptr(raw), int(raw_g or 0), _stream()),
+           'roreg_ft_nonlin_packed')
+    return words, raw
 
 
 def next_bound(bn, bias, bias2=None):

@@ -1193,6 +1193,10 @@ struct NonlinParams {
     int x_bf16;                  // the group-domain input / residual tensors are bfloat16 instead of float32
     int out_planes;              // SPLIT = 2 coefficient output in HALF-BLOCK layout (see irrep_gemm_xdma_kernel): every 32-column block of a row holds
                                  // its 32 fp16 hi values (order 0, 16, 1, 17, ...), then its 32 lo values, instead of 32 words hi | lo << 16
+    int sp_pack;                 // SPLIT = 2, group-domain output: the values leave as WORDS fp16 hi | fp16 lo << 16 of value * 2^bound_exp(out_bound[b]) (the operand of
+                                 // roreg_group_conv_f16x2_packed: its staging then only unpacks -- no BatchNorm, no conversion); out_bound [Bp] is required
+    float *raw_col;              // with sp_pack, optional [B][C]: the value BEFORE BatchNorm / ReLU of group element raw_g (ET's identity short cut reads column g = 0)
+    int raw_g;
     int B, Bp, C, tiles_per_c, Lout, Lvalid;     // B valid keypoints; Bp = B rounded up to 32 = the column pitch unit of the coefficient buffers
 };
 
@@ -1344,6 +1348,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         const int c = (IN_SPATIAL || OUT_SPATIAL) ? tile % C : tile / p.tiles_per_c;      // group-domain tensors are [b][c][.]: channel-fastest tiles
         const int tb = (IN_SPATIAL || OUT_SPATIAL) ? tile / C : tile - c * p.tiles_per_c;         // make the waves of a workgroup touch adjacent rows
         if constexpr (PACK_OUT) dst[NCV] = p.out_bound[tb * 32 + jn];
+        if constexpr (OUT_SPATIAL && SPLIT == 2) { if (p.sp_pack) dst[NCV] = p.out_bound[tb * 32 + jn]; }
         if constexpr (IN_SPATIAL) {
             // group-domain input [b][c][60]: ONE keypoint's contiguous 240-byte row per load instruction (lane = group element), slot i = the
             // tile's keypoint i; process() transposes through the wave's LDS buffer.  (Lane = keypoint reads -- 64 addresses 30 KB apart per
@@ -1495,6 +1500,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
         const bool rs_late = has_rs && !bn && !p.g_map && !p.out_rowmax;
         const size_t rs = ((size_t)bb * C + c) * ROREG_G;
         float *tb = (OUT_SPATIAL || OUT_ROWS) ? sT + (threadIdx.x >> 6) * (32 * 65) : nullptr;      // this wave's [32 keypoints][65] transpose buffer
+        const bool sp_pack = OUT_SPATIAL && SPLIT == 2 && p.sp_pack;
+        const float pk_scale = sp_pack ? ldexpf(1.f, bound_exp(cv[NCV])) : 1.f;      // the keypoint's block scale (the consumer derives the same exponent from the same bound)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1502,12 +1509,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void ft_nonlin_kernel(NonlinParams p
                 const int g = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float x = v[t][r] + bsum;
                 if (OUT_SPATIAL && has_rs && !rs_late && g < ROREG_G) x += ld_sp(p.r_spatial, rs + g);
+                if (sp_pack && p.raw_col && g == p.raw_g && valid) p.raw_col[(size_t)bb * C + c] = x;
                 if (bn) x = fmaxf(fmaf(x, sc, sh), 0.f);
                 if (g >= ROREG_G || !valid) x = 0.f;          // pad keypoints carry zeros through the forward transform: their coefficients are exact 0
                 v[t][r] = x;
                 if (OUT_SPATIAL && g < ROREG_G) {
                     const int go = sGmap[g];
-                    if (go >= 0) { tb[jn * 65 + go] = x; wmax = fmaxf(wmax, fabsf(x)); }      // (pad keypoints were zeroed above)
+                    if (go >= 0) {
+                        if (sp_pack) {                            // word = fp16(x 2^e) | fp16(x 2^e - hi) << 16
+                            const float xs = x * pk_scale;
+                            const _Float16 h1 = (_Float16)xs;
+                            const _Float16 l1 = (_Float16)(xs - (float)h1);
+                            tb[jn * 65 + go] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16));
+                        } else {
+                            tb[jn * 65 + go] = x; wmax = fmaxf(wmax, fabsf(x));      // (pad keypoints were zeroed above)
+                        }
+                    }
                 }
             }
         if (OUT_SPATIAL) {
@@ -2059,6 +2076,32 @@ extern "C" int roreg_ft_nonlin(const float *Xin, const float *x_spatial, const f
         else launch_ft<ft_nonlin_kernel<false, true, 0, 4, 1>>(p, n_tiles, s);
     }
     ROREG_CHECK_LAUNCH("roreg_ft_nonlin");
+    return 0;
+}
+
+// Inverse transform + bias + BatchNorm + ReLU with the group-domain result written as fp16 hi / lo WORDS under a per-row block scale taken from
+// a bound that exists before the tensor does (the producing GEMM's propagated bound): the operand of roreg_group_conv_f16x2_packed.
+extern "C" int roreg_ft_nonlin_packed(const float *Xin, const float *bias, const float *bn_scale, const float *bn_shift, uint32_t *out_words,
+                                      const int32_t *g_map, int Lout, int Lvalid, int B, int C, const float *out_bound, float *raw_col, int raw_g,
+                                      void *stream) {
+    ROREG_REQUIRE(g_A1 && g_A2, "roreg_ft_nonlin_packed: roreg_set_fourier_tables has not been called");
+    ROREG_REQUIRE(Xin && out_words && out_bound && B > 0 && C > 0 && C <= 512 && (bn_scale == nullptr) == (bn_shift == nullptr), "roreg_ft_nonlin_packed: bad arguments");
+    ROREG_REQUIRE(!g_map || (Lout >= Lvalid && Lvalid > 0 && Lout <= 64), "roreg_ft_nonlin_packed: bad Lout/Lvalid");
+    ROREG_REQUIRE(!raw_col || (raw_g >= 0 && raw_g < ROREG_G), "roreg_ft_nonlin_packed: raw_g out of range");
+    NonlinParams p;
+    memset(&p, 0, sizeof(p));
+    p.Xin = Xin; p.out_spatial = reinterpret_cast<float *>(out_words);
+    p.g_map = g_map; p.Lout = g_map ? Lout : ROREG_G; p.Lvalid = g_map ? Lvalid : ROREG_G;
+    p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.A1 = g_A1; p.A2 = g_A2;
+    p.A1s = reinterpret_cast<const bf16x8 *>(g_A1s); p.A2s = reinterpret_cast<const bf16x8 *>(g_A2s);
+    p.A1h = reinterpret_cast<const f16x8 *>(g_A1h); p.A2h = reinterpret_cast<const f16x8 *>(g_A2h); p.f_exp = g_f_exp;
+    p.out_bound = out_bound; p.sp_pack = 1; p.raw_col = raw_col; p.raw_g = raw_g;
+    p.B = B; p.Bp = (B + 31) / 32 * 32; p.C = C; p.tiles_per_c = (B + 31) / 32;
+    ROREG_REQUIRE((unsigned long long)C * p.Bp * 20ull < (1ull << 32), "roreg_ft_nonlin_packed: C * round_up(B, 32) must stay below 2^32 / 20 (32-bit lane offsets)");
+    hipStream_t s = roreg::as_stream(stream);
+    roreg::ProfScope prof(roreg::PROF_FT_NONLIN, s);
+    launch_ft<ft_nonlin_kernel<false, true, 2, 4, 1>>(p, (long long)C * p.tiles_per_c, s);
+    ROREG_CHECK_LAUNCH("roreg_ft_nonlin_packed");
     return 0;
 }
 

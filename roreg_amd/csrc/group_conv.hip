@@ -263,6 +263,10 @@ struct GCSplitParams {
     // with 1.97.  Pure data movement: results are bitwise unchanged.
     const int32_t *order;
     int S;
+    // NP = 2 only: x holds WORDS fp16 hi | fp16 lo << 16 of act(x[b]) * 2^row_scale_exp(b) (roreg_ft_nonlin_packed wrote them: BatchNorm, ReLU and the
+    // split happened in the producer); the staging then only regroups halves -- bn_scale / bn_shift must be null, sc.act_smax = 1, act_tmax = 0
+    // and sc.in_rowmax = the bound the producer scaled with.
+    int packed;
 };
 
 __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
@@ -276,8 +280,9 @@ __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x
     }
 }
 
-template <int KS, int NP>
+template <int KS, int NP, bool PACKED = false>
 __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams p) {
+    static_assert(!PACKED || NP == 2, "packed input words are fp16 hi / lo pairs");
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *gt = reinterpret_cast<int *>(smem);                             // [Lout * KS] slot of every gathered column, then [Lin] slot of every input column
@@ -355,33 +360,66 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
             }
         }
     };
-    auto convert = [&](int c0) {
+    // The staging items of a thread are the same for every chunk: (source offset in the raw chunk, destination fragment) are worked out once
+    // (two integer divisions per item and chunk before: the conversion was 4.4 vector instructions per MFMA of the whole kernel,
+    // profiles/r05_et_conv_pmc.txt).
+    constexpr int CV_ITEMS = 5;                                                      // ceil(nkp_max * 2 * Lin / 256) for Lout = 13, Lin <= 48
+    int cv_src[CV_ITEMS], cv_dst[CV_ITEMS];
+    {
         const int items = nkp * 2 * Lin;
-        for (int i = tid; i < items; i += 256) {
-            const int col = i % Lin, r = i / Lin;
-            const int ho = r & 1, kp = r >> 1;
-            const int sl = slot_of[col];
-            if (sl < 0) continue;                                                    // a column no output gathers (padding)
-            const float *src = raw + (kp * 16 + 8 * ho) * Lin + col;
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = src[e * Lin];
-            if (has_bn) {
-                const float4 *sc4 = reinterpret_cast<const float4 *>(bn_s + c0 + 8 * ho), *sh4 = reinterpret_cast<const float4 *>(bn_h + c0 + 8 * ho);
-                const float4 s0 = sc4[0], s1 = sc4[1], h0 = sh4[0], h1 = sh4[1];
-                const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+        for (int q = 0; q < CV_ITEMS; ++q) {
+            const int i = tid + q * 256;
+            cv_src[q] = -1; cv_dst[q] = 0;
+            if (i < items) {
+                const int col = i % Lin, r = i / Lin;
+                const int ho = r & 1, kp = r >> 1;
+                const int sl = p.order ? p.order[col] : col;
+                if (sl >= 0) { cv_src[q] = (kp * 16 + 8 * ho) * Lin + col; cv_dst[q] = ho * h_stride + kp * S + sl; }      // (kp_scale index = cv_src / (16 Lin))
             }
-            frag *dst = slab + ho * h_stride + kp * S + sl;
-            if constexpr (NP == 3) {
-                bf16x8 b1, b2, b3;
-                gc_split3(v, b1, b2, b3);
-                dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
+        }
+    }
+    auto convert = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < CV_ITEMS; ++q) {
+            if (cv_src[q] < 0) continue;                                             // beyond the tile, or a column no output gathers (padding)
+            const float *src = raw + cv_src[q];
+            frag *dst = slab + cv_dst[q];
+            if constexpr (PACKED) {
+                // words hi | lo << 16 of eight channels -> the hi octet and the lo octet (v_perm_b32: two per output dword)
+                unsigned wv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wv[e] = __float_as_uint(src[e * Lin]);
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x05040100u);      // low halves of (w0, w1): w0.lo | w1.lo << 16
+                    lw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x07060302u);      // high halves
+                }
+                struct Q4 { unsigned a, b, c, d; };
+                dst[0] = __builtin_bit_cast(f16x8, Q4{hw[0], hw[1], hw[2], hw[3]});
+                dst[plane_stride] = __builtin_bit_cast(f16x8, Q4{lw[0], lw[1], lw[2], lw[3]});
             } else {
-                f16x8 hi, lo;
-                gc_split2(v, kp_scale[kp], hi, lo);
-                dst[0] = hi; dst[plane_stride] = lo;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = src[e * Lin];
+                const int ho8 = ((cv_src[q] / Lin) & 15);                                // 0 or 8: the chunk's channel octet
+                if (has_bn) {
+                    const float4 *sc4 = reinterpret_cast<const float4 *>(bn_s + c0 + ho8), *sh4 = reinterpret_cast<const float4 *>(bn_h + c0 + ho8);
+                    const float4 s0 = sc4[0], s1 = sc4[1], h0 = sh4[0], h1 = sh4[1];
+                    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+                }
+                if constexpr (NP == 3) {
+                    bf16x8 b1, b2, b3;
+                    gc_split3(v, b1, b2, b3);
+                    dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
+                } else {
+                    f16x8 hi, lo;
+                    gc_split2(v, kp_scale[cv_src[q] / (16 * Lin)], hi, lo);
+                    dst[0] = hi; dst[plane_stride] = lo;
+                }
             }
         }
     };
@@ -880,7 +918,9 @@ static int launch_conv_split(GCSplitParams p, hipStream_t s) {
     const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4        // slot tables, fragment slab, raw chunk,
                        + (size_t)(2 * p.Cin + p.nkp_max) * 4;                                                                // BatchNorm parameters, keypoint scales
     ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
-    auto kern = group_conv_split_kernel<13, NP>;
+    ROREG_REQUIRE((size_t)p.nkp_max * 2 * p.Lin <= 5 * 256, "roreg_group_conv_split: %d keypoints x %d columns per tile exceed the staging plan", p.nkp_max, p.Lin);
+    void (*kern)(GCSplitParams) = group_conv_split_kernel<13, NP>;
+    if constexpr (NP == 2) { if (p.packed) kern = group_conv_split_kernel<13, 2, true>; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
     const int grid = ((p.ncols + 127) / 128) * (p.Cout / 256);
@@ -891,9 +931,10 @@ static int launch_conv_split(GCSplitParams p, hipStream_t s) {
 
 static int conv_split_common(int np, const float *x, const void *wsplit, const float *bias, const float *bn_scale, const float *bn_shift,
                              float *out, const int32_t *gather, const int32_t *lds_order, int lds_stride, int B, int Cin, int Cout, int Lin, int Lout,
-                             int KS, SplitScale sc, void *stream) {
+                             int KS, SplitScale sc, void *stream, int packed = 0) {
     if (B == 0) return 0;
     ROREG_REQUIRE(x && wsplit && bias && out && gather && B > 0, "roreg_group_conv_split: bad arguments");
+    ROREG_REQUIRE(!packed || (np == 2 && !bn_scale), "roreg_group_conv_split: packed input words go with the fp16 x 2 kernel and carry their activation");
     ROREG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "roreg_group_conv_split: bn_scale/bn_shift must come together");
     ROREG_REQUIRE(KS == 13 && Cin % 16 == 0 && Cout % 256 == 0 && Lin > 0 && Lin <= 64 && Lout > 0 && Lout <= 64,
                   "roreg_group_conv_split: unsupported shape (KS=%d Cin=%d Cout=%d Lin=%d Lout=%d)", KS, Cin, Cout, Lin, Lout);
@@ -906,7 +947,7 @@ static int conv_split_common(int np, const float *x, const void *wsplit, const f
     p.gt_bytes = round_up((Lout * KS + Lin) * 4, 16);
     p.nkp_max = (128 - 1) / Lout + 2;
     if (p.nkp_max > B) p.nkp_max = B;
-    p.sc = sc;
+    p.sc = sc; p.packed = packed;
     return np == 3 ? launch_conv_split<3>(p, roreg::as_stream(stream)) : launch_conv_split<2>(p, roreg::as_stream(stream));
 }
 
@@ -924,6 +965,17 @@ extern "C" int roreg_group_conv_f16x2(const float *x, const void *wsplit2, int w
     ROREG_REQUIRE(in_rowmax_dev, "roreg_group_conv_f16x2: in_rowmax_dev is required");
     SplitScale sc = {in_rowmax_dev, act_smax, act_tmax, w_exp, out_rowmax_dev};
     return conv_split_common(2, x, wsplit2, bias, bn_scale, bn_shift, out, gather, lds_order, lds_stride, B, Cin, Cout, Lin, Lout, KS, sc, stream);
+}
+
+// x = the WORDS roreg_ft_nonlin_packed wrote (fp16 hi | lo << 16 of act(x[b]) 2^e_b, e_b from in_bound_dev[b]): the same convolution with a staging
+// that only regroups halves (no BatchNorm, no conversion, no multiplication: 40 instead of ~250 vector instructions per 16-byte fragment pair)
+extern "C" int roreg_group_conv_f16x2_packed(const uint32_t *x_words, const void *wsplit2, int w_exp, const float *bias, const float *in_bound_dev,
+                                             float *out, float *out_rowmax_dev, const int32_t *gather, const int32_t *lds_order, int lds_stride, int B,
+                                             int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
+    ROREG_REQUIRE(in_bound_dev, "roreg_group_conv_f16x2_packed: in_bound_dev is required");
+    SplitScale sc = {in_bound_dev, 1.f, 0.f, w_exp, out_rowmax_dev};
+    return conv_split_common(2, reinterpret_cast<const float *>(x_words), wsplit2, bias, nullptr, nullptr, out, gather, lds_order, lds_stride, B, Cin, Cout, Lin,
+                             Lout, KS, sc, stream, 1);
 }
 
 template <int NP>

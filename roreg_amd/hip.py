@@ -324,6 +324,30 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
     return out
 
 
+def group_conv_packed(x_words, layer, in_bound, gather, want_rowmax=False, lds_order=None):
+    """The fp16 x 2 stencil convolution on PACKED input words (ft_nonlin_packed: BatchNorm, ReLU and the hi / lo split already applied under the
+    block scale of in_bound [>= B]): x_words int32 [B,Cin,Lin] -> out f32 [B,Cout,Lout] (+ tracked max |out[b]|).  layer: a ConvLayer; only its
+    weights and bias are used (its BatchNorm belongs to the producer)."""
+    ensure_tables()
+    B, Cin, Lin = x_words.shape
+    assert Cin == layer.Cin and x_words.dtype == torch.int32, (Cin, layer.Cin, x_words.dtype)
+    Lout = int(gather.shape[0])
+    if not (layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0):
+        raise HipError('group_conv_packed: the fp16 x 2 kernel does not support this shape')
+    if in_bound.numel() < B:
+        raise HipError(f'group_conv_packed: in_bound must hold one value per row ({B}), got {in_bound.numel()}')
+    order_t, order_s = (None, 0) if lds_order is None else lds_order
+    if order_t is not None:
+        _check_lds_order(order_t, order_s, gather, Lin)
+    w2, w_exp, _, _ = _conv_wsplit2(layer)
+    out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x_words.device)
+    amax = torch.zeros(B, dtype=torch.float32, device=x_words.device) if want_rowmax else None
+    _check(lib().roreg_group_conv_f16x2_packed(_ptr(x_words, torch.int32), _ptr(w2), w_exp, _ptr(layer.bias), _ptr(in_bound, torch.float32), _ptr(out),
+                                               _ptr(amax), _ptr(gather, torch.int32), _ptr(order_t, torch.int32), order_s, B, Cin, layer.Cout, Lin, Lout,
+                                               layer.KS, _stream()), 'roreg_group_conv_f16x2_packed')
+    return (out, amax) if want_rowmax else out
+
+
 def gf_finalize(eqv_raw, want_inv=True, out_dtype=torch.float32):
     """out_dtype=torch.bfloat16: the descriptors are stored in bfloat16 (BASELINE config 5); `inv` is computed from the float32 values."""
     B = eqv_raw.shape[0]

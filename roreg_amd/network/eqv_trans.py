@@ -7,6 +7,8 @@ The reference evaluates its 1x1 head at all 60 group columns and keeps column g=
 only the group columns that can reach g=0 through the 13-stencil are live: 45 columns of Conv_init's output,
 13 of comb_layer_in's, 1 of comb_layer_out's.  The pruned path computes exactly those (5.6x fewer MACs, same
 values); `pruned=False` evaluates every column like the reference, for the equality test."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -31,6 +33,7 @@ class ET_test(nn.Module):
         self.pruned = True
         self.fourier_init = True
         self.gemm = hip.GEMM_MODE           # 'f16x2' | 'bf16x3' | 'f32' (hip.GEMM_MODE)
+        self.packed_trunk = os.environ.get('ROREG_ET_PACKED', '1') != '0'      # f16x2 mode: the trunk convolution reads packed words (see trunk_and_head)
 
     # ---- kernel plans -------------------------------------------------------------------------------------
     def _head_plans(self):
@@ -117,6 +120,17 @@ class ET_test(nn.Module):
             self._finit_key = key
         return self._finit
 
+    def _trunk_bn(self):
+        """((scale, shift) of the trunk convolution's folded BatchNorm, the (u, v) tables of the bound Conv_init's GEMM propagates to it)."""
+        from .gf_fourier import _fold_bn
+        res = self.PartII_SO3_Conv_layers[0]
+        key = _version_key(res.comb_layer_in[0], self.Conv_init)
+        if getattr(self, '_tbn_key', None) != key:
+            bn = _fold_bn(res.comb_layer_in[0])
+            self._tbn = (bn, hip.next_bound_spatial(bn, self._fourier_init()[0].bias))
+            self._tbn_key = key
+        return self._tbn
+
     def assemble(self, data):
         """x [B,128,60] = cat(before0[P[pre]], before1, after0[P[pre]], after1)  (eqv_trans.py:126-129)."""
         dev = 'cuda'
@@ -151,15 +165,29 @@ class ET_test(nn.Module):
                     # so a correspondence's quaternion does not depend on which other correspondences share the batch
                     b0 = x_bound if x_bound is not None else hip.row_bound(x, bn=bn)
                     X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn, split='f16x2', out_bound=b0, planes=hip.use_planes(256))      # half-block layout: LDS-DMA GEMM
-                    T0 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0, x_planes=hip.use_planes(256))
-                    del X0
-                    h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split='f16x2',
-                                          want_rowmax=True)                                                          # [B,256,48]
-                    del T0
-                    m, am = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True, lds_order=self._trunk_lds_order())   # [B,512,13]
                     d_out, d0, d1, d2 = self._dense_plans()
-                    # identity short cut = column g = 0 of h, read in place (element (b, o) at stride LIVE_PAD from h[0, 0, p0])
-                    t, at = hip.dense_split(m.view(B, -1), d_out, residual=h[:, :, p0:], residual_stride=self.LIVE_PAD, in_rowmax=am, want_rowmax=True)   # [B,256]
+                    if self.packed_trunk:
+                        # The trunk convolution's operand leaves the inverse transform READY: ReLU(BN(h)) as fp16 hi / lo words under the row's block
+                        # scale -- from a bound the GEMM's epilogue propagates (sqrt(60) |scale| |T| + |scale| |bias| + |shift| >= |ReLU(BN(IFT(T) + bias))|),
+                        # so it exists before h does -- and the convolution's staging only regroups halves (it spent 4.4 vector instructions per MFMA
+                        # on BatchNorm + conversion + split of the float tensor, profiles/r05_et_conv_pmc.txt).  The identity short cut's column g = 0
+                        # of h (before BatchNorm) comes out beside the words.
+                        bn_t, nb_t = self._trunk_bn()
+                        T0, b1 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0, next_bound=nb_t, x_planes=hip.use_planes(256))
+                        del X0
+                        hw, h0 = hip.ft_nonlin_packed(B, 256, T0, layer.bias, bn_t, b1, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, raw_g=0)   # [B,256,48] words, [B,256]
+                        del T0
+                        m, am = hip.group_conv_packed(hw, res._b_in.plan(), b1, gb, want_rowmax=True, lds_order=self._trunk_lds_order())       # [B,512,13]
+                        t, at = hip.dense_split(m.view(B, -1), d_out, residual=h0, in_rowmax=am, want_rowmax=True)                             # [B,256]
+                    else:
+                        T0 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0, x_planes=hip.use_planes(256))
+                        del X0
+                        h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=self.LIVE_PAD, Lvalid=45, split='f16x2',
+                                              want_rowmax=True)                                                          # [B,256,48]
+                        del T0
+                        m, am = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True, lds_order=self._trunk_lds_order())   # [B,512,13]
+                        # identity short cut = column g = 0 of h, read in place (element (b, o) at stride LIVE_PAD from h[0, 0, p0])
+                        t, at = hip.dense_split(m.view(B, -1), d_out, residual=h[:, :, p0:], residual_stride=self.LIVE_PAD, in_rowmax=am, want_rowmax=True)   # [B,256]
                     z, az = hip.dense_split(t, d0, in_rowmax=at, want_rowmax=True)
                     z, az = hip.dense_split(z, d1, in_rowmax=az, want_rowmax=True)
                     return hip.dense_split(z, d2, in_rowmax=az)                                                      # [B,4]

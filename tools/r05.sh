@@ -67,5 +67,14 @@ print('value', j['value'], 'ms/step', j['ms_per_step'], 'contract', j.get('value
       'ft ms', (j.get('transforms') or {}).get('ms_per_step'), 'rd_rm', c.get('rd_rm_leg_pairs_per_s'), c.get('rd_rm_leg_pairs_per_s_bf16'), 'k5000', c.get('rd_rm_leg_k5000_pairs_per_s'), c.get('rd_rm_leg_k5000_sinkhorn_ms_per_pair'), 'rr', c.get('rr'))
 PY
   ;;
+profile)   # profile [tag]: kernel trace (+ idle gaps) of the driver's bench command, short
+  tag=${1:-head}
+  rm -rf $OUT/kt_b
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_line_under_kernel_trace_$tag.json 2> $OUT/kt_b.err
+  db=$(find $OUT/kt_b -name '*.db' | head -1)
+  python3 tools/rocprof_summary.py $db $OUT/bench_kernel_trace_$tag.txt > /dev/null
+  python3 tools/rocprof_gaps.py $db 3.0 > $OUT/bench_gpu_idle_$tag.txt 2>&1; head -6 $OUT/bench_gpu_idle_$tag.txt
+  rm -rf $OUT/kt_b
+  head -16 $OUT/bench_kernel_trace_$tag.txt | cut -c1-170 ;;
 *) echo "unknown command $cmd"; exit 2 ;;
 esac
