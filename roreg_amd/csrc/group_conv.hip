@@ -280,8 +280,13 @@ __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x
     }
 }
 
-template <int KS, int NP, bool PACKED = false>
-__global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams p) {
+// PK: 0 = float32 input (BatchNorm, ReLU and the split happen while staging); 1 = packed words, staged between two barriers like the floats;
+// 2 = packed words with DOUBLE-BUFFERED raw chunks and fragment slabs: chunk c + 1 is regrouped from its raw copy into the other slab in the
+// shadow of chunk c's MFMAs (a few LDS reads and writes per stencil position), the raw copy of chunk c + 2 is in flight meanwhile -- one
+// barrier per chunk and no staging phase; 134 KB of LDS, i.e. one workgroup per CU.
+template <int KS, int NP, int PK = 0>
+__global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(GCSplitParams p) {
+    constexpr bool PACKED = PK != 0;
     static_assert(!PACKED || NP == 2, "packed input words are fp16 hi / lo pairs");
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -340,23 +345,25 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
     // stencil loop every thread converts its k-octets from the raw LDS copy (BatchNorm, ReLU, split) into the fragment slab.  (The earlier
     // form loaded each k-octet with eight dependent global loads, one item after the other: 12-16 us of exposed latency per chunk against
     // 4 us of MFMAs -- the kernel ran at 42 % matrix-pipe duty, independent of the operands, i.e. stall-bound, not power-bound.)
-    float *raw = reinterpret_cast<float *>(slab + (size_t)NP * plane_stride);       // [nkp_max][16][Lin]
+    const int slab_frags = PK == 2 ? NP * plane_stride : 0;                          // PK = 2: a second slab behind the first
+    float *raw = reinterpret_cast<float *>(slab + (size_t)NP * plane_stride + slab_frags);       // [nkp_max][16][Lin] (PK = 2: two of them)
+    const int raw_floats = p.nkp_max * 16 * Lin;
     // BatchNorm parameters of all input channels and the block scale of this tile's keypoints, staged ONCE: convert() runs between two
     // barriers of every chunk, and with these as global loads every one of its 4-5 iterations per thread exposed two L2 round trips
     // (the ISA showed s_waitcnt vmcnt(0) twice per iteration) -- more time per chunk than the chunk's MFMAs.
-    float *bn_s = raw + (size_t)p.nkp_max * 16 * Lin, *bn_h = bn_s + p.Cin, *kp_scale = bn_h + p.Cin;       // [Cin], [Cin], [nkp_max]
+    float *bn_s = raw + (size_t)(PK == 2 ? 2 : 1) * raw_floats, *bn_h = bn_s + p.Cin, *kp_scale = bn_h + p.Cin;       // [Cin], [Cin], [nkp_max]
     for (int i = tid; i < p.Cin; i += 256) { bn_s[i] = has_bn ? p.bn_scale[i] : 1.f; bn_h[i] = has_bn ? p.bn_shift[i] : 0.f; }
     if constexpr (NP == 2)
         for (int i = tid; i < nkp; i += 256) kp_scale[i] = ldexpf(1.f, row_scale_exp(p.sc, b_first + i));
     const int pieces = nkp * 4 * Lin;                                                // 16-byte pieces of a chunk
-    auto issue_raw = [&](int c0) {
+    auto issue_raw = [&](int c0, int buf = 0) {
         for (int base = w * 64; base < pieces; base += 256) {                        // (wave-uniform trip count)
             const int pc = base + lane;
             if (pc < pieces) {
                 const int kp = pc / (4 * Lin), r = pc - kp * (4 * Lin);
                 const float *src = p.x + ((size_t)(b_first + kp) * p.Cin + c0) * Lin + 4 * r;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(raw + (size_t)base * 4), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(raw + (size_t)buf * raw_floats + (size_t)base * 4), 16, 0, 0);
             }
         }
     };
@@ -379,49 +386,67 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
             }
         }
     }
-    auto convert = [&](int c0) {
+    // PK = 2: one item's eight words out of raw buffer `rb` (requested at one stencil position) ...
+    auto cv_load = [&](int q, int rb, unsigned (&wv)[8]) {
+        if (cv_src[q] < 0) return;
+        const float *src = raw + (size_t)rb * raw_floats + cv_src[q];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = __float_as_uint(src[e * Lin]);
+    };
+    // ... and, regrouped into the hi octet and the lo octet, into slab `sb` (at the next position)
+    auto cv_store = [&](int q, int sb, const unsigned (&wv)[8]) {
+        if (cv_src[q] < 0) return;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x05040100u);
+            lw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x07060302u);
+        }
+        struct Q4 { unsigned a, b, c, d; };
+        frag *dst = slab + (size_t)sb * slab_frags + cv_dst[q];
+        dst[0] = __builtin_bit_cast(frag, Q4{hw[0], hw[1], hw[2], hw[3]});
+        dst[plane_stride] = __builtin_bit_cast(frag, Q4{lw[0], lw[1], lw[2], lw[3]});
+    };
+    auto convert_packed = [&]() {                                                 // PK = 1 / the first chunk of PK = 2: all items between two barriers
 #pragma unroll
         for (int q = 0; q < CV_ITEMS; ++q) {
-            if (cv_src[q] < 0) continue;                                             // beyond the tile, or a column no output gathers (padding)
-            const float *src = raw + cv_src[q];
-            frag *dst = slab + cv_dst[q];
-            if constexpr (PACKED) {
-                // words hi | lo << 16 of eight channels -> the hi octet and the lo octet (v_perm_b32: two per output dword)
-                unsigned wv[8];
+            unsigned wv[8];
+            cv_load(q, 0, wv);
+            cv_store(q, 0, wv);
+        }
+    };
+    auto convert_float = [&](int c0) {
+        const int items = nkp * 2 * Lin;
+        for (int i = tid; i < items; i += 256) {
+            const int col = i % Lin, r = i / Lin;
+            const int ho = r & 1, kp = r >> 1;
+            const int sl = slot_of[col];
+            if (sl < 0) continue;                                                    // a column no output gathers (padding)
+            const float *src = raw + (kp * 16 + 8 * ho) * Lin + col;
+            float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) wv[e] = __float_as_uint(src[e * Lin]);
-                unsigned hw[4], lw[4];
+            for (int e = 0; e < 8; ++e) v[e] = src[e * Lin];
+            if (has_bn) {
+                const float4 *sc4 = reinterpret_cast<const float4 *>(bn_s + c0 + 8 * ho), *sh4 = reinterpret_cast<const float4 *>(bn_h + c0 + 8 * ho);
+                const float4 s0 = sc4[0], s1 = sc4[1], h0 = sh4[0], h1 = sh4[1];
+                const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x05040100u);      // low halves of (w0, w1): w0.lo | w1.lo << 16
-                    lw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x07060302u);      // high halves
-                }
-                struct Q4 { unsigned a, b, c, d; };
-                dst[0] = __builtin_bit_cast(f16x8, Q4{hw[0], hw[1], hw[2], hw[3]});
-                dst[plane_stride] = __builtin_bit_cast(f16x8, Q4{lw[0], lw[1], lw[2], lw[3]});
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+            }
+            frag *dst = slab + ho * h_stride + kp * S + sl;
+            if constexpr (NP == 3) {
+                bf16x8 b1, b2, b3;
+                gc_split3(v, b1, b2, b3);
+                dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
             } else {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = src[e * Lin];
-                const int ho8 = ((cv_src[q] / Lin) & 15);                                // 0 or 8: the chunk's channel octet
-                if (has_bn) {
-                    const float4 *sc4 = reinterpret_cast<const float4 *>(bn_s + c0 + ho8), *sh4 = reinterpret_cast<const float4 *>(bn_h + c0 + ho8);
-                    const float4 s0 = sc4[0], s1 = sc4[1], h0 = sh4[0], h1 = sh4[1];
-                    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
-                }
-                if constexpr (NP == 3) {
-                    bf16x8 b1, b2, b3;
-                    gc_split3(v, b1, b2, b3);
-                    dst[0] = b1; dst[plane_stride] = b2; dst[2 * plane_stride] = b3;
-                } else {
-                    f16x8 hi, lo;
-                    gc_split2(v, kp_scale[cv_src[q] / (16 * Lin)], hi, lo);
-                    dst[0] = hi; dst[plane_stride] = lo;
-                }
+                f16x8 hi, lo;
+                gc_split2(v, kp_scale[kp], hi, lo);
+                dst[0] = hi; dst[plane_stride] = lo;
             }
         }
+    };
+    auto convert = [&](int c0) {
+        if constexpr (PACKED) convert_packed(); else convert_float(c0);
     };
     issue_raw(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,9 +456,14 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
     for (int t = 0; t < 4; ++t) gix0[t] = gt[gi[t] * KS];
 
+    if constexpr (PK == 2) { if (p.Cin > 16) issue_raw(16, 1); }                     // chunk 1's raw copy travels under the first barrier
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
-        __syncthreads();                                                             // the slab of this chunk is complete, the raw buffer is free
         const bool more = c0 + 16 < p.Cin;
+        const int cur = PK == 2 ? (c0 >> 4) & 1 : 0;                                 // slab / raw buffer of this chunk
+        if constexpr (PK == 2) { if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // this wave's pieces of the next chunk's raw copy have landed
+        __syncthreads();                                                             // the slab of this chunk is complete, the raw buffer is free
+        const frag *slab_cur = slab + (size_t)cur * slab_frags;
+        unsigned cvw[8];                                                             // (PK = 2) the staging item in flight
 
         // ---- MFMA over the stencil; the weight fragments of position k+1 are in flight during position k ----------------
         // (the stencil loop is fully unrolled with two named fragment sets: a rolled loop with a register copy made the compiler wait for
@@ -455,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
 #pragma unroll
         for (int t = 0; t < 4; ++t) gix[0][t] = gix0[t];
         auto read_frags = [&](int slot, int t, int set) {
-            const frag *bp = slab + rowbase[t] + slot;
+            const frag *bp = slab_cur + rowbase[t] + slot;
 #pragma unroll
             for (int sp = 0; sp < NP; ++sp) fb[set][sp] = bp[sp * plane_stride];
         };
@@ -464,7 +494,15 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
         for (int k = 0; k < KS; ++k) {
             const frag (&a_cur)[2][NP] = aw[k & 1];
             if (k + 1 < KS) load_a(k + 1, aw[(k + 1) & 1]);
-            if (k == 0 && more) issue_raw(c0 + 16);                 // (after the weight loads of k = 1: their wait does not cover the DMA)
+            if constexpr (PK != 2) {
+                if (k == 0 && more) issue_raw(c0 + 16);             // (after the weight loads of k = 1: their wait does not cover the DMA)
+            } else {
+                if (k == 0 && c0 + 32 < p.Cin) issue_raw(c0 + 32, cur);      // this chunk's raw buffer was regrouped during the previous chunk: free
+                if (more) {                                         // the next chunk, item by item, into the other slab
+                    if (k >= 1 && (k & 1) && (k >> 1) < CV_ITEMS) cv_load(k >> 1, cur ^ 1, cvw);
+                    if (k >= 2 && !(k & 1) && (k >> 1) - 1 < CV_ITEMS) cv_store((k >> 1) - 1, cur ^ 1, cvw);
+                }
+            }
             if (k + 1 < KS) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) gix[(k + 1) & 1][t] = gt[gi[t] * KS + k + 1];
@@ -505,10 +543,12 @@ __global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's DMA pieces have landed ...
-            __syncthreads();                                                         // ... everyone's have, and nobody reads the slab any more
-            convert(c0 + 16);
+        if constexpr (PK != 2) {
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's DMA pieces have landed ...
+                __syncthreads();                                                     // ... everyone's have, and nobody reads the slab any more
+                convert(c0 + 16);
+            }
         }
     }
 
@@ -915,12 +955,13 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
 
 template <int NP>
 static int launch_conv_split(GCSplitParams p, hipStream_t s) {
-    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4        // slot tables, fragment slab, raw chunk,
+    const int nbuf = (NP == 2 && p.packed == 2) ? 2 : 1;
+    const size_t lds = (size_t)p.gt_bytes + (size_t)nbuf * ((size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4)        // slot tables, fragment slab(s), raw chunk(s),
                        + (size_t)(2 * p.Cin + p.nkp_max) * 4;                                                                // BatchNorm parameters, keypoint scales
     ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
     ROREG_REQUIRE((size_t)p.nkp_max * 2 * p.Lin <= 5 * 256, "roreg_group_conv_split: %d keypoints x %d columns per tile exceed the staging plan", p.nkp_max, p.Lin);
     void (*kern)(GCSplitParams) = group_conv_split_kernel<13, NP>;
-    if constexpr (NP == 2) { if (p.packed) kern = group_conv_split_kernel<13, 2, true>; }
+    if constexpr (NP == 2) { if (p.packed) kern = p.packed == 2 ? group_conv_split_kernel<13, 2, 2> : group_conv_split_kernel<13, 2, 1>; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
     const int grid = ((p.ncols + 127) / 128) * (p.Cout / 256);
@@ -974,8 +1015,12 @@ extern "C" int roreg_group_conv_f16x2_packed(const uint32_t *x_words, const void
                                              int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
     ROREG_REQUIRE(in_bound_dev, "roreg_group_conv_f16x2_packed: in_bound_dev is required");
     SplitScale sc = {in_bound_dev, 1.f, 0.f, w_exp, out_rowmax_dev};
+    // ROREG_ET_OVERLAP=1: the double-buffered form (regrouping of chunk c + 1 under chunk c's MFMAs, one barrier per chunk, one workgroup per CU).
+    // Measured SLOWER than staging between two barriers with two workgroups per CU (bench: 1061 / 671 against 1079 / 693 pairs/s headline /
+    // contract-complete): the second resident workgroup hides more than the staging phase costs.  Kept for measurements.
+    static const int overlapped = getenv("ROREG_ET_OVERLAP") && atoi(getenv("ROREG_ET_OVERLAP")) == 1;
     return conv_split_common(2, reinterpret_cast<const float *>(x_words), wsplit2, bias, nullptr, nullptr, out, gather, lds_order, lds_stride, B, Cin, Cout, Lin,
-                             Lout, KS, sc, stream, 1);
+                             Lout, KS, sc, stream, overlapped ? 2 : 1);
 }
 
 template <int NP>
