@@ -356,14 +356,28 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
     if constexpr (NP == 2)
         for (int i = tid; i < nkp; i += 256) kp_scale[i] = ldexpf(1.f, row_scale_exp(p.sc, b_first + i));
     const int pieces = nkp * 4 * Lin;                                                // 16-byte pieces of a chunk
+    // A lane's DMA pieces are the same for every chunk (only the channel offset moves): their source offsets are worked out once -- the per-piece
+    // integer division by 4 Lin was ~400 vector instructions per wavefront and chunk, more than the chunk's 312 MFMAs have issue slots to spare.
+    constexpr int RAW_ITERS = 9;                                                     // ceil(nkp_max * 4 * Lin / 256) for Lout = 13, Lin <= 48
+    int raw_off[RAW_ITERS];                                                          // float offset of the piece in x at c0 = 0 (-1: none)
+#pragma unroll
+    for (int q = 0; q < RAW_ITERS; ++q) {
+        const int pc = w * 64 + q * 256 + lane;
+        raw_off[q] = -1;
+        if (pc < pieces) {
+            const int kp = pc / (4 * Lin), r = pc - kp * (4 * Lin);
+            raw_off[q] = ((b_first + kp) * p.Cin) * Lin + 4 * r;                     // (B * Cin * Lin < 2^31: checked by the launcher)
+        }
+    }
     auto issue_raw = [&](int c0, int buf = 0) {
-        for (int base = w * 64; base < pieces; base += 256) {                        // (wave-uniform trip count)
-            const int pc = base + lane;
-            if (pc < pieces) {
-                const int kp = pc / (4 * Lin), r = pc - kp * (4 * Lin);
-                const float *src = p.x + ((size_t)(b_first + kp) * p.Cin + c0) * Lin + 4 * r;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(raw + (size_t)buf * raw_floats + (size_t)base * 4), 16, 0, 0);
+        const float *xc = p.x + (size_t)c0 * Lin;
+        float *dst0 = raw + (size_t)buf * raw_floats + (size_t)(w * 64) * 4;
+#pragma unroll
+        for (int q = 0; q < RAW_ITERS; ++q) {
+            if (w * 64 + q * 256 < pieces) {                                         // (wave-uniform)
+                if (raw_off[q] >= 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xc + raw_off[q]),
+                                                     (__attribute__((address_space(3))) void *)(dst0 + (size_t)q * 1024), 16, 0, 0);
             }
         }
     };
@@ -959,7 +973,8 @@ static int launch_conv_split(GCSplitParams p, hipStream_t s) {
     const size_t lds = (size_t)p.gt_bytes + (size_t)nbuf * ((size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4)        // slot tables, fragment slab(s), raw chunk(s),
                        + (size_t)(2 * p.Cin + p.nkp_max) * 4;                                                                // BatchNorm parameters, keypoint scales
     ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
-    ROREG_REQUIRE((size_t)p.nkp_max * 2 * p.Lin <= 5 * 256, "roreg_group_conv_split: %d keypoints x %d columns per tile exceed the staging plan", p.nkp_max, p.Lin);
+    ROREG_REQUIRE((size_t)p.nkp_max * 2 * p.Lin <= 5 * 256 && (size_t)p.nkp_max * 4 * p.Lin <= 9 * 256, "roreg_group_conv_split: %d keypoints x %d columns per tile exceed the staging plan", p.nkp_max, p.Lin);
+    ROREG_REQUIRE((long long)p.B * p.Cin * p.Lin < (1ll << 31), "roreg_group_conv_split: input tensor beyond 2^31 elements");
     void (*kern)(GCSplitParams) = group_conv_split_kernel<13, NP>;
     if constexpr (NP == 2) { if (p.packed) kern = p.packed == 2 ? group_conv_split_kernel<13, 2, 2> : group_conv_split_kernel<13, 2, 1>; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
