@@ -402,3 +402,54 @@ def test_et_both_gemm_modes_vs_golden(group):
         q[split] = net(batch)['quaternion_pre'].cpu().numpy()
         assert np.abs(q[split] - z['quaternion']).max() < 1e-4, split
     assert np.abs(q['f32'] - q['bf16x3']).max() < 2e-5 and np.abs(q['f32'] - q['f16x2']).max() < 2e-5
+
+
+@pytest.mark.parametrize('B', [37, 3000])
+def test_packed_trunk_operand_equals_the_float_path(group, B):
+    """The ET trunk convolution's packed operand (roreg_ft_nonlin_packed -> roreg_group_conv_f16x2_packed, round 5) against the float path it
+    replaces, stage by stage on the same coefficients: (a) the words decode to ReLU(BN(h)) of the float inverse transform within 2^-19 of the
+    row's bound (fp16 hi + lo resolve 22 bits below the block scale; the propagated bound sits <= 3 bits above the row maximum here);
+    (b) the raw short-cut column is BITWISE column g = 0 of h; (c) the propagated bound really bounds every row; (d) the convolution on the
+    words equals the float-input convolution to 2e-5 of the output scale; (e) a row's result does not depend on the other rows."""
+    from roreg_amd import hip
+    from roreg_amd.network import name2network
+    net = name2network['ET_test'](default_config())
+    synth.seeded_state_dict(net, 202)
+    net.gemm = 'f16x2'
+    res = net.PartII_SO3_Conv_layers[0]
+    layer, bn0 = net._fourier_init()
+    bn_t, nb_t = net._trunk_bn()
+    ga, gb, gc, p0, gmap = net._pruned_gathers()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn((B, 128, 60), device='cuda', generator=g)
+    x = x / x.norm(dim=1, keepdim=True)
+    x[3] *= 50.0; x[5] *= 1e-3                                            # rows of very different magnitude: the block scale is per row
+    b0 = hip.row_bound(x, bn=bn0)
+    X0 = hip.ft_nonlin(B, 128, x_spatial=x, bn=bn0, split='f16x2', out_bound=b0, planes=hip.use_planes(256))
+    T0, b1 = hip.irrep_gemm(X0, None, 128, 256, B, f16x2=layer.wsplit2, x_bound=b0, next_bound=nb_t, x_planes=hip.use_planes(256))
+    h, ah = hip.ft_nonlin(B, 256, coef_in=T0, bias=layer.bias, spatial_out=True, g_map=gmap, Lout=net.LIVE_PAD, Lvalid=45, split='f16x2', want_rowmax=True)
+    hw, h0 = hip.ft_nonlin_packed(B, 256, T0, layer.bias, bn_t, b1, g_map=gmap, Lout=net.LIVE_PAD, Lvalid=45, raw_g=0)
+    assert torch.equal(h0, h[:, :, p0])                                                             # (b)
+    act = torch.relu(h * bn_t[0][None, :, None] + bn_t[1][None, :, None]); act[:, :, 45:] = 0
+    assert bool((act.abs().amax(dim=(1, 2)) <= b1[:B]).all())                                       # (c)
+    e = hip.bound_exp(b1[:B]).double()
+    w = hw.to(torch.int64) & 0xffffffff
+    hi = (w & 0xffff).to(torch.int16).view(torch.float16).double(); lo = ((w >> 16) & 0xffff).to(torch.int16).view(torch.float16).double()
+    dec = (hi + lo) * torch.pow(2.0, -e)[:, None, None]
+    err = (dec - act.double()).abs().amax(dim=(1, 2)) / b1[:B].double()
+    assert float(err.max()) < 2.0 ** -19, float(err.max())                                           # (a)
+    headroom = torch.log2(b1[:B].double() / act.abs().amax(dim=(1, 2)).double().clamp_min(1e-300))
+    print(f'bound headroom over the row maximum: {float(headroom.min()):.2f} .. {float(headroom.max()):.2f} bits')
+    m_ref, _ = res._b_in(h, gather=gb, in_rowmax=ah, want_rowmax=True, lds_order=net._trunk_lds_order())
+    m_pk, am = hip.group_conv_packed(hw, res._b_in.plan(), b1, gb, want_rowmax=True, lds_order=net._trunk_lds_order())
+    scale = m_ref.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    assert float(((m_pk - m_ref).abs().amax(dim=(1, 2)) / scale).max()) < 2e-5                      # (d)
+    assert torch.allclose(am, m_pk.abs().amax(dim=(1, 2)))
+    sub = slice(2, 9)                                                                                # (e) seven rows alone: bitwise the same
+    xs = x[sub].contiguous(); nb = xs.shape[0]
+    b0s = hip.row_bound(xs, bn=bn0)
+    X0s = hip.ft_nonlin(nb, 128, x_spatial=xs, bn=bn0, split='f16x2', out_bound=b0s, planes=hip.use_planes(256))
+    T0s, b1s = hip.irrep_gemm(X0s, None, 128, 256, nb, f16x2=layer.wsplit2, x_bound=b0s, next_bound=nb_t, x_planes=hip.use_planes(256))
+    hws, _ = hip.ft_nonlin_packed(nb, 256, T0s, layer.bias, bn_t, b1s, g_map=gmap, Lout=net.LIVE_PAD, Lvalid=45, raw_g=0)
+    assert torch.equal(hws, hw[sub]) and torch.equal(b1s[:nb], b1[sub])
+    assert torch.equal(hip.group_conv_packed(hws, res._b_in.plan(), b1s, gb, lds_order=net._trunk_lds_order()), m_pk[sub])
