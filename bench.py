@@ -673,13 +673,15 @@ def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'b
         rm.matrix_core_layers = variant.endswith('matrix_core_layers')
         eng = RegistrationEngine(cfg, gf, et, rd_net=rd, rm_net=rm)
         eng.set_gemm_mode(args.gemm); eng.set_descriptor_dtype(dtype)
-        for _ in range(2):
-            res = eng.run_scene(feats, keys, pairs, pair_seeds=seeds)
+        # the chunk several times through engine.run_scenes, the way the full benchmark runs its scenes: software-pipelined across the scene's host
+        # synchronisations (detector scores, NMS neighbour lists, matcher read-outs, match counts, result table), so that the host's rank
+        # transforms / NMS selection / task tables of one pass run under the kernels of the next
+        job = (feats, keys, pairs, dict(pair_seeds=seeds))
+        n_rep = 6
+        eng.run_scenes([job] * n_rep)                                    # (warm-up at the timed depth: the caching allocator sees the same live set)
         hip.profile_enable(True); hip.WORK = {}
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        n_rep = 3
-        for _ in range(n_rep):
-            res = eng.run_scene(feats, keys, pairs, pair_seeds=seeds)
+        res = eng.run_scenes([job] * n_rep)[-1]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         sk_ms, sk_n = hip.profile_read('sinkhorn'); tk_ms, tk_n = hip.profile_read('topk_dot')
         work = hip.WORK; hip.WORK = None; hip.profile_enable(False)

@@ -260,9 +260,24 @@ class RegistrationEngine:
         self.detect_many([cloud])
         return cloud.det
 
+    @staticmethod
+    def _drive(gen):
+        """Run a stage generator synchronously: every tensor list it yields is downloaded with a blocking copy and sent back as numpy arrays."""
+        try:
+            req = next(gen)
+            while True:
+                req = gen.send([t.cpu().numpy() for t in req])
+        except StopIteration as fin:
+            return fin.value
+
     def detect_many(self, clouds):
         """Detector scores of several clouds: every cloud's network pass is enqueued, ONE download, then the rank transform of
         test/detector.py:45-46 per cloud on the host."""
+        return self._drive(self._detect_steps(clouds))
+
+    def _detect_steps(self, clouds):
+        """detect_many as a generator (yields the device tensor it needs on the host, is sent its numpy copy): inside run_scenes the download
+        is asynchronous and the rank transforms run under the kernels of the other scenes in flight."""
         todo = [c for c in clouds if c.det is None]
         if not todo:
             return
@@ -275,7 +290,7 @@ class RegistrationEngine:
                 x = todo[i].eqv if j - i == 1 else torch.cat([c.eqv for c in todo[i:j]])
                 raw.append(self.rd({'feats': x})['scores'])
                 i = j
-        flat = torch.cat(raw).cpu().numpy()
+        flat = (yield [torch.cat(raw)])[0]
         offs = np.cumsum([0] + [c.eqv.shape[0] for c in todo])
 
         def rank(q):                                                  # (numpy's sort releases the GIL: the clouds' rank transforms run side by side)
@@ -290,6 +305,10 @@ class RegistrationEngine:
         """NMS sampling (test/matcher.py:11-42) of several clouds: it is a pure function of the cloud (keypoints, detector scores,
         keynum; no RNG), so it is computed once per cloud -- the reference recomputes it for both clouds of every pair
         (matcher.py:77-82) -- with the 5-NN search of all clouds in one segmented launch and ONE download of the neighbour lists."""
+        return self._drive(self._nms_steps(clouds, keynum))
+
+    def _nms_steps(self, clouds, keynum):
+        """nms_many as a generator (see _detect_steps)."""
         from .test.matcher import NMS_sample
         sampler = NMS_sample(keynum, 5)
         todo = [c for c in clouds if keynum not in c.nms]
@@ -302,7 +321,7 @@ class RegistrationEngine:
         if need:
             seg = hip.Segments([c.keys.shape[0] for c in need])
             pts = torch.cat([c.keys.float() for c in need]).contiguous()
-            flat = hip.knn_search_seg(pts, seg, 5).cpu().numpy()          # every cloud's 5-NN lists (self included) in two launches
+            flat = (yield [hip.knn_search_seg(pts, seg, 5)])[0]           # every cloud's 5-NN lists (self included) in two launches
             picks = _host_pool().map(lambda q: sampler.sample_from_neighbours(need[q].det, flat[seg.host[q]:seg.host[q + 1]]), range(len(need)))
             for c, pick in zip(need, picks):
                 c.nms[keynum] = pick
@@ -340,6 +359,10 @@ class RegistrationEngine:
         many pairs are stacked and the network runs ONCE per group of pairs with segmented per-pair operations (Match_ot.match_stacked;
         bitwise the per-pair forward()); one synchronisation, one download of the read-outs and one upload of the match lists per call.
         The batch carries cloud 1 as the source (feats0/keys0) and cloud 0 as the target (test/matcher.py:192-197)."""
+        return self._drive(self._match_rm_steps(jobs, max_points))
+
+    def _match_rm_steps(self, jobs, max_points=None):
+        """match_rm_many as a generator (see _detect_steps): the read-outs of all groups come to the host in one (asynchronous) download."""
         if not jobs:
             return []
         max_points = self.rm_max_points if max_points is None else max_points
@@ -368,8 +391,7 @@ class RegistrationEngine:
             hip.gather_rows_batch(gf); hip.gather_rows_batch(gk)
             with torch.no_grad():
                 issued += self.rm.match_stacked(se.float(), te.float(), sk.float(), tk.float(), seg_s, seg_t)   # (bf16 rows: lossless up-cast)
-        m0_all = torch.cat([m for m, _ in issued]).cpu().numpy()            # the one sync of the matcher stage
-        sc_all = torch.cat([s for _, s in issued]).cpu().numpy()
+        m0_all, sc_all = yield [torch.cat([m for m, _ in issued]), torch.cat([s for _, s in issued])]      # the one sync of the matcher stage
         out, o = [], 0
         for (c0, c1, s0, s1), (m, _) in zip(jobs, issued):
             n = int(m.shape[0])
@@ -544,7 +566,8 @@ class RegistrationEngine:
         a job may also be a callable returning that tuple, evaluated when the pipeline reaches it (distributed.run_plan: the jobs that
         first have to wait for received clouds).
         A scene synchronises with the host twice -- for the match counts (the hypothesis order needs every pair's M) and for the result
-        table -- and between a download and the next launch the host shuffles, builds task tables and uploads: ~5 ms per scene with the GPU
+        table (with --RD / --RM three more times: detector scores, NMS neighbour lists, the matcher's read-outs) -- and between a download and
+        the next launch the host shuffles, builds task tables and uploads: ~5 ms per scene with the GPU
         idle when the scenes run one after the other (3 % of a step, profiles/r02_bench_gpu_idle.txt).  Here scene i + 1's extraction and
         matcher are enqueued BEFORE the host waits for scene i's counts, and scene i's estimator before it waits for scene i - 1's results;
         every download goes through a side stream ordered by an event behind its producer, so it does not wait for the kernels queued
@@ -634,8 +657,8 @@ class RegistrationEngine:
             ready.update(fresh)
         t0 = self._mark('extract', t0)
         if self.cfg.RD:
-            self.detect_many([clouds[i] for i in used])
-            self.nms_many([clouds[i] for i in used], keynum)
+            yield from self._detect_steps([clouds[i] for i in used])
+            yield from self._nms_steps([clouds[i] for i in used], keynum)
         # stage 3: all pairs
         full, all_scores = [], []
         if self.cfg.RM:
@@ -643,7 +666,7 @@ class RegistrationEngine:
             for q, (a, b) in enumerate(pair_ids):
                 c0, c1 = clouds[int(a)], clouds[int(b)]
                 jobs.append((c0, c1) + tuple(self.sample(c0, c1, keynum, None if pair_seeds is None else pair_seeds[q])))
-            for (c0, c1, _, _), (m, sc) in zip(jobs, self.match_rm_many(jobs)):
+            for (c0, c1, _, _), (m, sc) in zip(jobs, (yield from self._match_rm_steps(jobs))):
                 full.append((c0, c1, m)); all_scores.append(sc)
             counts = np.array([m.shape[0] for _, _, m in full])
         else:
