@@ -26,7 +26,7 @@ def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpo
                                             _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(cor), _stream()), 'roreg_group_corr_irrep')
         return cor
     cor = torch.empty((M, 60), dtype=torch.float32, device=perm_feats.device)
-    if MATRIX_CORE_LAYERS and not want_idx:             # (inside matrix_core_layers(): the stacked matcher) one 60 x 32 x 60 product per point + coset sums
+    if (MATRIX_CORE_LAYERS or CORR_MFMA) and not want_idx:      # one 60 x 32 x 60 float32 MFMA product per point + coset sums (csrc/corr_mfma.hip)
         _check(lib().roreg_group_corr_mfma(_ptr(perm_feats, torch.float32), _ptr(perm_rows, torch.int64), _ptr(bcast_feats, torch.float32),
                                            _ptr(bcast_rows, torch.int64), M, 1 if transpose else 0, _ptr(cor), _stream()), 'roreg_group_corr_mfma')
         return cor
@@ -73,6 +73,8 @@ def topk_dot(A, B, k, want_val=False, segA=None, segB=None):
 # equally accurate, flips a top-k neighbour on that fixture); True = fp16 hi + lo MFMAs (csrc/linear_mfma.hip) and one float32 MFMA product per
 # point (csrc/corr_mfma.hip): the stacked matcher, which returns matches and scores only.  Set by matrix_core_layers().
 MATRIX_CORE_LAYERS = False
+# ROREG_CORR_MFMA=1: R_indicator alone through csrc/corr_mfma.hip (in forward() and the stacked path alike); measurement switch, see NOTES.md round 5
+CORR_MFMA = os.environ.get('ROREG_CORR_MFMA', '0') == '1'
 
 
 class matrix_core_layers:
