@@ -438,7 +438,11 @@ int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_final, const 
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                           int recompute, void *stream);
 /* v5: the same, and (Z_out non-null, n_seg == 1) the pair's log-coupling matrix Z [(m+1) x (n+1)] row-major = ((Z0 + u) + v) - norm, the
- * `scores` of Match_ot.forward (network/rot_coh_match.py:313,366) -- so that forward() and the stacked path run ONE set of Sinkhorn kernels. */
+ * `scores` of Match_ot.forward (network/rot_coh_match.py:313,366) -- so that forward() and the stacked path run ONE set of Sinkhorn kernels.
+ * With recompute != 0 and Z_out == NULL nothing materialises a matrix: the mutual arg-max read-out (rot_coh_match.py:369-379) is taken from float32
+ * MFMA chains over the descriptors (bitwise the fmaf chains the matrix held) with the potentials added in the reference's association, and the
+ * workspace (roreg_sinkhorn_batch3_workspace_size) shrinks from 2 (m+1)(n+1) floats per pair to ~4 (m+n). */
+size_t roreg_sinkhorn_batch3_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n, int recompute, int want_Z);
 int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
                           const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,

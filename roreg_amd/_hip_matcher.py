@@ -224,7 +224,7 @@ def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters, recompu
     consts = np.empty(4 * seg_src.n, np.float32)
     _check(lib().roreg_sinkhorn_batch_consts(seg_src.host.ctypes.data, seg_tgt.host.ctypes.data, seg_src.n, consts.ctypes.data), 'roreg_sinkhorn_batch_consts')
     cdev = upload(consts)
-    wsn = lib().roreg_sinkhorn_batch2_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn)
+    wsn = lib().roreg_sinkhorn_batch3_workspace_size(seg_src.n, seg_src.max, seg_tgt.max, tm, tn, mode, 1 if want_Z else 0)
     ws = torch.empty(wsn, dtype=torch.float32, device=dev)
     Z = torch.empty((seg_src.max + 1, seg_tgt.max + 1), dtype=torch.float32, device=dev) if want_Z else None
     _check(lib().roreg_sinkhorn_batch3(_ptr(src_final, torch.float32), _ptr(tgt_final, torch.float32), _ptr(seg_src.dev, torch.int32),

@@ -765,6 +765,106 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict
     if (threadIdx.x == 0) { idx[i] = si[0]; val[i] = sv[0]; }
 }
 
+// ---- the read-out without a matrix ---------------------------------------------------------------------------------------------------
+// Row and column arg-max of x_ij = ((Z0_ij + u_i) + v_j) - norm over the points (network/rot_coh_match.py:369-371) straight from the descriptors:
+// Z0_ij = the float32 fmaf chain over the 32 channels that ot_build_kernel evaluates -- and that v_mfma_f32_32x32x2_f32 evaluates bit for bit
+// (csrc/linear_chain.hip) -- so a workgroup takes a 32-row strip of sources, its four wavefronts walk the 32-column tiles of targets (16 chained
+// MFMAs each), form x in the reference's association and keep, per accumulator element, packed keys (orderable float bits << 32 | ~index): a
+// 64-bit maximum is "larger value, then lower index" -- the first maximum, as torch.max returns it.  Rows: reduced over the lanes and the four
+// wavefronts at the end of the strip.  Columns: the strip's best row per column goes to a global 64-bit atomic maximum (order-independent).
+// The two (m+1) x (n+1) matrices per pair that served only this read-out (2 x 100 MB at 5000 points) are neither built nor read.
+typedef float f32x16_rd __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned long long rd_key(float x, unsigned idx) {
+    const unsigned b = __float_as_uint(x);
+    const unsigned o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);         // order-preserving map of finite floats and infinities
+    return ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+__device__ __forceinline__ float rd_val(unsigned long long k) {
+    const unsigned o = (unsigned)(k >> 32);
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__global__ __launch_bounds__(256) void ot_argmax_mfma_kernel(const float *__restrict__ S, const float *__restrict__ T, const int *__restrict__ segS,
+                                                             const int *__restrict__ segT, const float *__restrict__ u, const float *__restrict__ v,
+                                                             size_t uv_stride, const float *__restrict__ consts, unsigned long long *__restrict__ colbest,
+                                                             int64_t *__restrict__ i0, float *__restrict__ val0) {
+    const int pair = blockIdx.y, strip = blockIdx.x;
+    const int s0 = segS[pair], m = segS[pair + 1] - s0, t0 = segT[pair], n = segT[pair + 1] - t0;
+    if (strip * 32 >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+    const float normc = consts[pair * 2];
+    const float *up = u + pair * uv_stride, *vp = v + pair * uv_stride;
+    float a[16];                                                          // A fragments of the strip: row strip * 32 + j, channels 2 k + h
+    {
+        const float4 *sr = reinterpret_cast<const float4 *>(S + (size_t)(s0 + min(strip * 32 + j, m - 1)) * RM_F);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 x4 = sr[q]; a[2 * q] = h ? x4.y : x4.x; a[2 * q + 1] = h ? x4.w : x4.z; }
+    }
+    float ur[16];
+    bool rok[16];
+    unsigned long long bk[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = strip * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        rok[r] = row < m;
+        ur[r] = up[min(row, m - 1)];
+        bk[r] = 0ull;
+    }
+    const int ntile = (n + 31) / 32;
+    for (int jt = w; jt < ntile; jt += 4) {
+        const int col = jt * 32 + j;
+        const bool cok = col < n;
+        float bq[16];
+        {
+            const float4 *tr = reinterpret_cast<const float4 *>(T + (size_t)(t0 + min(col, n - 1)) * RM_F);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float4 x4 = tr[q]; bq[2 * q] = h ? x4.y : x4.x; bq[2 * q + 1] = h ? x4.w : x4.z; }
+        }
+        const float vj = vp[min(col, n - 1)];
+        f32x16_rd acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bq[kk], acc, 0, 0, 0);      // = fmaf chain over channels 0..31 from 0
+        unsigned long long ck = 0ull;                                     // this lane's best row for column `col`
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = (((acc[r] + ur[r]) + vj) - normc) + 0.f;      // (+ 0: -0 becomes +0, so that equal floats have equal keys)
+            if (cok && rok[r] && x == x) {                                // (NaN never wins: the sentinel stays)
+                const unsigned long long kr = rd_key(x, (unsigned)col);
+                if (kr > bk[r]) bk[r] = kr;
+                const unsigned long long kc = rd_key(x, (unsigned)(strip * 32 + 8 * (r >> 2) + 4 * h + (r & 3)));
+                if (kc > ck) ck = kc;
+            }
+        }
+        const unsigned long long other = __shfl_xor(ck, 32);
+        if (other > ck) ck = other;
+        if (h == 0 && cok && ck) atomicMax(colbest + t0 + col, ck);
+    }
+    // rows: over the 32 lanes of each half-wave, then over the four wavefronts
+    __shared__ unsigned long long srow[4][32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long k = bk[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(k, o); if (x > k) k = x; }
+        if (j == 0) srow[w][8 * (r >> 2) + 4 * h + (r & 3)] = k;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int row = strip * 32 + tid;
+        if (row < m) {
+            unsigned long long k = srow[0][tid];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if (srow[q][tid] > k) k = srow[q][tid];
+            i0[s0 + row] = k ? (int64_t)(0xffffffffu - (unsigned)k) : (int64_t)0x7fffffff;
+            val0[s0 + row] = k ? rd_val(k) : -__builtin_inff();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ot_colbest_decode_kernel(const unsigned long long *__restrict__ colbest, long long total, int64_t *__restrict__ i1) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < total) { const unsigned long long k = colbest[t]; i1[t] = k ? (int64_t)(0xffffffffu - (unsigned)k) : (int64_t)0x7fffffff; }
+}
+
 // batched: blockIdx.y = pair; i0/v0/m0/s0 are concatenated by seg0, i1/m1/s1 by seg1; indices stay LOCAL to the pair
 __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restrict__ i0, const float *__restrict__ v0, int m,
                                                          const int64_t *__restrict__ i1, int n, int64_t *__restrict__ m0,
@@ -1086,6 +1186,22 @@ extern "C" size_t roreg_sinkhorn_batch2_workspace_size(int n_seg, int max_m, int
     return roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, total_m, total_n) + ot_flash_floats(n_seg, max_m, max_n);
 }
 
+// recomputed iterations + read-out from the descriptors (no log-couplings asked for): per pair only the two potential vectors
+static bool ot_no_matrix(int recompute, bool want_Z) {
+    static const bool rd_mfma = !(getenv("ROREG_OT_READOUT_MFMA") && atoi(getenv("ROREG_OT_READOUT_MFMA")) == 0);
+    return recompute && !want_Z && rd_mfma;
+}
+static size_t ot_base_floats(int n_seg, int max_m, int max_n, long long tm, long long tn, bool no_matrix) {
+    if (!no_matrix) return roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, tm, tn);
+    const size_t ldz = (max_n + 4) & ~3, ldt = (max_m + 4) & ~3;
+    return (size_t)n_seg * (ldt + ldz) + 2 * (size_t)tn + 3 * (size_t)(tm + tn) + 64;       // potentials, column keys, read-out values + indices
+}
+// v5: the workspace of roreg_sinkhorn_batch3 for THIS mode -- with recompute != 0 and no log-couplings the two (m+1) x (n+1) matrices per pair
+// are not needed (0.25 GB per pair at 5000 points): ~4 (m + n) floats per pair + the fragment workspace of the iterations
+extern "C" size_t roreg_sinkhorn_batch3_workspace_size(int n_seg, int max_m, int max_n, long long total_m, long long total_n, int recompute, int want_Z) {
+    return ot_base_floats(n_seg, max_m, max_n, total_m, total_n, ot_no_matrix(recompute, want_Z != 0)) + (recompute ? ot_flash_floats(n_seg, max_m, max_n) : 0);
+}
+
 static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
                                const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                                int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
@@ -1102,26 +1218,36 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
         if (n < min_n) min_n = n;
     }
     const long long tm = seg_src_host[n_seg], tn = seg_tgt_host[n_seg];
-    const size_t base_floats = roreg_sinkhorn_batch_workspace_size(n_seg, max_m, max_n, tm, tn);
+    const bool no_matrix = ot_no_matrix(recompute, Z_out != nullptr);
+    const size_t base_floats = ot_base_floats(n_seg, max_m, max_n, tm, tn, no_matrix);
     ROREG_REQUIRE(ws_floats >= base_floats + (recompute ? ot_flash_floats(n_seg, max_m, max_n) : 0), "roreg_sinkhorn_batch: workspace too small");
     hipStream_t s = roreg::as_stream(stream);
     const int ldz = (max_n + 4) & ~3, ldt = (max_m + 4) & ~3;
-    const size_t slab = ot_slab(max_m, max_n);
-    float *Z0 = ws, *Z0T = Z0 + (size_t)(max_m + 1) * ldz, *u = Z0T + (size_t)(max_n + 1) * ldt, *v = u + ldt;
-    const size_t pstride = ot_part_stride(max_m, max_n);
+    // recomputed iterations and no log-couplings asked for: nothing needs the two matrices -- the read-out comes from the descriptors too, and a
+    // pair's slab shrinks to its two potential vectors
+    const size_t slab = no_matrix ? (size_t)(ldt + ldz) : ot_slab(max_m, max_n);
+    float *Z0 = ws, *Z0T = Z0 + (size_t)(max_m + 1) * ldz, *u = no_matrix ? ws : Z0T + (size_t)(max_n + 1) * ldt, *v = u + ldt;
+    const size_t pstride = no_matrix ? (size_t)0 : ot_part_stride(max_m, max_n);
     float *part = ws + (size_t)n_seg * slab;
+    unsigned long long *colbest = nullptr;                               // (no_matrix) packed (value, ~row) keys of the columns' best rows, [sum n]
     float *tail = part + (size_t)n_seg * pstride;
+    if (no_matrix) {
+        colbest = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(part) + 15) & ~(uintptr_t)15);
+        tail = reinterpret_cast<float *>(colbest + tn);
+    }
     float *val0 = tail, *val1 = val0 + tm;
     const size_t off = ((reinterpret_cast<uintptr_t>(val1 + tn) + 7) & ~(uintptr_t)7) - reinterpret_cast<uintptr_t>(ws);
     int64_t *i0 = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + off);
     int64_t *i1 = i0 + tm;
-    ROREG_REQUIRE(reinterpret_cast<char *>(i1 + tn) <= reinterpret_cast<char *>(ws + ws_floats), "roreg_sinkhorn_batch: workspace too small");
+    ROREG_REQUIRE(reinterpret_cast<char *>(i1 + tn) <= reinterpret_cast<char *>(ws + base_floats), "roreg_sinkhorn_batch: workspace too small");
     const OtBatch rows = {seg_src, seg_tgt, slab, consts}, cols = {seg_tgt, seg_src, slab, consts + 2 * n_seg};
     const int rpb = 32;
-    hipLaunchKernelGGL(ot_build_kernel, dim3((max_n + 1 + 255) / 256, (max_m + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, src_final, 0,
-                       tgt_final, 0, alpha, rpb, Z0, ldz, seg_src, seg_tgt, slab);
-    hipLaunchKernelGGL(ot_build_kernel, dim3((max_m + 1 + 255) / 256, (max_n + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, tgt_final, 0,
-                       src_final, 0, alpha, rpb, Z0T, ldt, seg_tgt, seg_src, slab);
+    if (!no_matrix) {
+        hipLaunchKernelGGL(ot_build_kernel, dim3((max_n + 1 + 255) / 256, (max_m + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, src_final, 0,
+                           tgt_final, 0, alpha, rpb, Z0, ldz, seg_src, seg_tgt, slab);
+        hipLaunchKernelGGL(ot_build_kernel, dim3((max_m + 1 + 255) / 256, (max_n + 1 + rpb - 1) / rpb, n_seg), dim3(256), 0, s, tgt_final, 0,
+                           src_final, 0, alpha, rpb, Z0T, ldt, seg_tgt, seg_src, slab);
+    }
     if (recompute) {
         // the iterations never touch Z0 / Z0T: every pass recomputes the scores on the matrix cores (csrc/ot_flash.hip); the two matrices
         // above only serve the read-out below
@@ -1154,8 +1280,15 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
         const size_t tot = (size_t)(max_m + 1) * (max_n + 1);
         hipLaunchKernelGGL(ot_final_batch1_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Z0, ldz, max_m, max_n, u, v, consts, Z_out);
     }
-    hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
-    hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);
+    if (no_matrix) {
+        (void)hipMemsetAsync(colbest, 0, (size_t)tn * sizeof(unsigned long long), s);
+        hipLaunchKernelGGL(ot_argmax_mfma_kernel, dim3((max_m + 31) / 32, n_seg), dim3(256), 0, s, src_final, tgt_final, seg_src, seg_tgt, u, v, slab, consts,
+                           colbest, i0, val0);
+        hipLaunchKernelGGL(ot_colbest_decode_kernel, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, s, colbest, tn, i1);
+    } else {
+        hipLaunchKernelGGL(row_argmax_kernel<true>, dim3(max_m, n_seg), dim3(256), 0, s, Z0, 0, 0, ldz, v, u, 0.f, i0, val0, rows);
+        hipLaunchKernelGGL(row_argmax_kernel<false>, dim3(max_n, n_seg), dim3(256), 0, s, Z0T, 0, 0, ldt, u, v, 0.f, i1, val1, cols);
+    }
     const int mx = max_m > max_n ? max_m : max_n;
     hipLaunchKernelGGL(ot_readout_kernel, dim3((mx + 255) / 256, n_seg), dim3(256), 0, s, i0, val0, 0, i1, 0, matches0, matches1, mscores0,
                        mscores1, seg_src, seg_tgt);

@@ -366,10 +366,10 @@ class RegistrationEngine:
         if not jobs:
             return []
         max_points = self.rm_max_points if max_points is None else max_points
-        # ... capped by what fits a quarter of the free device memory: per pair the two read-out matrices and the Sinkhorn workspace
-        # (roreg_sinkhorn_batch2_workspace_size) plus ~60 KB of neighbourhood activations per point (k = 16 neighbours x <= 120 channels, a few tensors)
+        # ... capped by what fits a quarter of the free device memory: per pair the Sinkhorn workspace (roreg_sinkhorn_batch3_workspace_size: no
+        # coupling matrices in the default mode) plus ~60 KB of neighbourhood activations per point (k = 16 neighbours x <= 120 channels, a few tensors)
         longest = max(max(len(s0), len(s1)) for _, _, s0, s1 in jobs)
-        per_pair = 4 * hip.lib().roreg_sinkhorn_batch2_workspace_size(1, longest, longest, longest, longest) + 60_000 * 2 * longest
+        per_pair = 4 * hip.lib().roreg_sinkhorn_batch3_workspace_size(1, longest, longest, longest, longest, 1, 0) + 60_000 * 2 * longest
         max_points = max(longest, min(max_points, int(0.25 * torch.cuda.mem_get_info()[0] / per_pair) * longest))
         flat = np.concatenate([np.ascontiguousarray(x, np.int64) for _, _, s0, s1 in jobs for x in (s0, s1)])
         flat_dev = hip.upload(flat)                                         # ONE upload of all sample lists

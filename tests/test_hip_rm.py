@@ -406,6 +406,39 @@ def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path, fva
         assert same.mean() > 0.998 and np.abs(as0[same] - bs0[same]).max() < 2e-5
 
 
+def test_sinkhorn_readout_without_the_matrix_is_bitwise_the_matrix_readout(tmp_path):
+    """The read-out of the recomputed path comes straight from the descriptors (ot_argmax_mfma_kernel: Z0 as float32 MFMA chains = ot_build_kernel's
+    fmaf chains, packed (value, ~index) keys).  Against the same call with the two (m+1) x (n+1) matrices built and scanned
+    (ROREG_OT_READOUT_MFMA=0, a child process): matches0 / matches1 / both score vectors BITWISE, on ragged stacked pairs with DUPLICATED
+    descriptors on both sides (exact ties: the first index must win in rows and in columns) and a pair with fewer points than a tile."""
+    import subprocess, sys
+    from roreg_amd import hip
+    rng = np.random.default_rng(77)
+    sizes = [(700, 650), (33, 5000), (5000, 97), (20, 20), (2500, 2500)]
+    S, T = [], []
+    for m, n in sizes:
+        s = rng.standard_normal((m, 32)).astype(np.float32) * 0.5; t = rng.standard_normal((n, 32)).astype(np.float32) * 0.5
+        k = min(m, n) // 2
+        t[:k] = s[:k] * 3
+        if m > 40 and n > 40:
+            t[n - 10:] = t[:10]; s[m - 7:] = s[3:10]                  # duplicated targets and sources: exactly tied scores
+        S.append(s); T.append(t)
+    np.savez(tmp_path / 'in.npz', s=np.concatenate(S), t=np.concatenate(T), m=np.array([a for a, _ in sizes]), n=np.array([b for _, b in sizes]))
+    code = ("import numpy as np, torch, sys\n"
+            "from roreg_amd import hip\n"
+            "z = np.load(sys.argv[1]); s = torch.from_numpy(z['s']).cuda(); t = torch.from_numpy(z['t']).cuda()\n"
+            "out = hip.sinkhorn_batch(s, t, hip.Segments(z['m']), hip.Segments(z['n']), 1.5, 100, recompute=True)\n"
+            "np.savez(sys.argv[2], *[x.cpu().numpy() for x in out])\n")
+    env = dict(os.environ, ROREG_OT_READOUT_MFMA='0', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / 'out.npz')
+    got = hip.sinkhorn_batch(cu(np.concatenate(S)), cu(np.concatenate(T)), hip.Segments([a for a, _ in sizes]), hip.Segments([b for _, b in sizes]), 1.5, 100, recompute=True)
+    for q, g in enumerate(got):
+        assert np.array_equal(g.cpu().numpy(), z[f'arr_{q}']), q
+    assert int((got[0] >= 0).sum()) > 1000
+
+
 def test_sinkhorn_recomputed_survives_non_finite_and_huge_descriptors():
     """No fault and no hang on NaN / inf / 1e6-sized descriptors (the fp16 operands overflow: those pairs' results are meaningless, as the
     reference's would be); a healthy pair stacked beside them is unaffected."""

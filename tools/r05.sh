@@ -76,5 +76,30 @@ profile)   # profile [tag]: kernel trace (+ idle gaps) of the driver's bench com
   python3 tools/rocprof_gaps.py $db 3.0 > $OUT/bench_gpu_idle_$tag.txt 2>&1; head -6 $OUT/bench_gpu_idle_$tag.txt
   rm -rf $OUT/kt_b
   head -16 $OUT/bench_kernel_trace_$tag.txt | cut -c1-170 ;;
+pmcbench)   # pmcbench <tag>: four PMC passes of one bench step -> $OUT/bench_pmc_<tag>.txt, $OUT/irrep_gemm_pmc_<tag>.json (roofline.traffic / mfma_busy_fraction)
+  tag=${1:-head}
+  ARGS="--no-cpu-baseline --no-secondary"
+  i=0; rm -rf $OUT/pmc_bench_$tag
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_bench_$tag/g$i -- python3 bench.py --steps 1 --warmup 0 $ARGS > $OUT/pmc_bench_${tag}_g$i.log 2>&1
+  done
+  ROREG_GIT_COMMIT=$tag python3 tools/pmc_summary.py $OUT/bench_pmc_$tag.txt $OUT/irrep_gemm_pmc_$tag.json 3dmatch-full:f16x2=$OUT/pmc_bench_$tag | tail -5
+  rm -rf $OUT/pmc_bench_$tag ;;
+final)      # final: build, smoke, full gpu suite, the driver's bench command, forced-collectives bench, 3 ranks on one GPU
+  python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_final.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest_gpu_final.log
+  timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2> $OUT/bench_final.err; echo "bench rc $? lines $(wc -l < $OUT/bench_final.json)"
+  timeout 900 python bench.py --force-collectives --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_forced_final.json 2> $OUT/bench_forced_final.err; echo "forced rc $? lines $(wc -l < $OUT/bench_forced_final.json)"
+  ROREG_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 3 --backend gloo --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_shared3_final.json 2> $OUT/bench_shared3_final.err; echo "shared3 rc $? lines $(wc -l < $OUT/bench_shared3_final.json)"
+  python3 - <<'PY'
+import json
+j=json.load(open('gpurun_out/r05/bench_final.json')); f=json.load(open('gpurun_out/r05/bench_forced_final.json')); k=json.load(open('gpurun_out/r05/bench_shared3_final.json'))
+c=j['config']
+print('final', j['value'], j['ms_per_step'], j['value_contract_complete'], j.get('value_contract_complete_bf16x3'), j.get('value_bf16x3'), j['roofline']['frac'], j['roofline']['traffic'], c.get('rd_rm_leg_pairs_per_s'), c.get('rd_rm_leg_k5000_pairs_per_s'), c.get('rd_rm_leg_k5000_sinkhorn_ms_per_pair'), c.get('rr'))
+print('forced', f['value'], f['config']['forced_collectives'], f['config']['eqv_bytes_moved_per_step'], f['config'].get('backend'))
+print('shared3', k['n_gpus'], k['value'], k['config']['eqv_transfers_per_step'], k['config']['cloud_extractions_per_rank'], k['accuracy'] == j['accuracy'])
+PY
+  ;;
 *) echo "unknown command $cmd"; exit 2 ;;
 esac
