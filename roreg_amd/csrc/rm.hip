@@ -62,6 +62,75 @@ __global__ __launch_bounds__(256) void topk_dot_kernel(const float *__restrict__
     }
 }
 
+// The same search with the dot products on the matrix cores: acc = fmaf(a[f], b[f], acc) over the 32 channels from 0 is exactly what a chain of
+// sixteen v_mfma_f32_32x32x2_f32 computes (a float32 fma chain over k, csrc/linear_chain.hip), so the scores -- and with them every list -- are
+// BITWISE those of topk_dot_kernel at half its vector work.  A wavefront owns 32 source rows as the tile's COLUMNS (lane l: source l % 32) and
+// walks its slice of the targets in 32-row tiles: a lane then holds 16 scores of ITS source per tile (target rows 8 (r / 4) + 4 (l / 32) + r % 4,
+// ascending in r), which go through the same sorted insertion, in index order; the two lanes of a source (l, l + 32: disjoint target subsets)
+// merge their lists at the end under (value descending, index ascending).
+typedef float f32x16_tk __attribute__((ext_vector_type(16)));
+template <int K>
+__device__ __forceinline__ void topk_insert_idx(float (&bv)[K], int (&bi)[K], float v, int j) {      // full order: an equal value with a LOWER index goes first
+    if (!(v > bv[K - 1] || (v == bv[K - 1] && j < bi[K - 1]))) return;
+#pragma unroll
+    for (int q = K - 1; q >= 0; --q) {
+        const bool up = q > 0 && (v > bv[q - 1] || (v == bv[q - 1] && j < bi[q - 1]));
+        if (q > 0 && up) { bv[q] = bv[q - 1]; bi[q] = bi[q - 1]; }
+        else { bv[q] = v; bi[q] = j; break; }
+    }
+}
+template <int K>
+__global__ __launch_bounds__(256) void topk_dot_mfma_kernel(const float *__restrict__ A, int m, const float *__restrict__ B, int n,
+                                                            const int *__restrict__ segA, const int *__restrict__ segB, int slices,
+                                                            float *__restrict__ pv, int *__restrict__ pi) {
+    const int a0 = segA ? segA[blockIdx.z] : 0, mp = segA ? segA[blockIdx.z + 1] - a0 : m;
+    const int b0 = segA ? segB[blockIdx.z] : 0, np_ = segA ? segB[blockIdx.z + 1] - b0 : n;
+    if ((int)(blockIdx.x * 128) >= mp || np_ <= 0) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int i = blockIdx.x * 128 + w * 32 + j;                           // this lane's source row (of the pair)
+    float sq[16];                                                          // B operand: source row i, channels 2 k + h
+    {
+        const float4 *sr = reinterpret_cast<const float4 *>(A + (size_t)(a0 + min(i, mp - 1)) * RM_F);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 x4 = sr[q]; sq[2 * q] = h ? x4.y : x4.x; sq[2 * q + 1] = h ? x4.w : x4.z; }
+    }
+    float bv[K];
+    int bi[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { bv[q] = -__builtin_inff(); bi[q] = 0x7fffffff; }
+    const int slice = (np_ + slices - 1) / slices;
+    const int j0 = blockIdx.y * slice, j1 = min(j0 + slice, np_);          // (local to the pair)
+    for (int t0 = j0; t0 < j1; t0 += 32) {
+        float tq[16];                                                      // A operand: target row t0 + j, channels 2 k + h
+        {
+            const float4 *tr = reinterpret_cast<const float4 *>(B + (size_t)(b0 + min(t0 + j, np_ - 1)) * RM_F);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float4 x4 = tr[q]; tq[2 * q] = h ? x4.y : x4.x; tq[2 * q + 1] = h ? x4.w : x4.z; }
+        }
+        f32x16_tk acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq[kk], sq[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (t < j1) topk_insert<K>(bv, bi, acc[r], b0 + t);
+        }
+    }
+    // the other half-wave's list of the same source
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const float ov = __shfl_xor(bv[q], 32);
+        const int oi = __shfl_xor(bi[q], 32);
+        if (h == 0 && oi != 0x7fffffff) topk_insert_idx<K>(bv, bi, ov, oi);
+    }
+    if (h == 0 && i < mp) {
+        float *ov = pv + ((size_t)blockIdx.y * m + a0 + i) * K;
+        int *oi = pi + ((size_t)blockIdx.y * m + a0 + i) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) { ov[q] = bv[q]; oi[q] = bi[q]; }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ pv, const int *__restrict__ pi, int m, int slices,
                                                          int64_t *__restrict__ idx, float *__restrict__ val) {
@@ -917,8 +986,10 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     if (!segA) { n_seg = 1; max_m = m; max_n = n; }
     ROREG_REQUIRE(n_seg > 0 && max_m > 0 && max_n > 0 && max_m <= m && max_n <= n, "roreg_topk_dot: bad segment description");
     ROREG_REQUIRE(segA || k <= n, "roreg_topk_dot: k > n");      // with segments the caller guarantees k <= every pair's target count
-    const int gx = (max_m + 255) / 256;
-    int slices = topk_slices(gx * n_seg, max_n, segA != nullptr);
+    // ROREG_TOPK_VALU=1: the vector-pipe kernel (one thread per source row); default: the dot products as float32 MFMA chains, bitwise the same lists
+    static const bool valu = getenv("ROREG_TOPK_VALU") && atoi(getenv("ROREG_TOPK_VALU")) == 1;
+    const int gx = valu ? (max_m + 255) / 256 : (max_m + 127) / 128;
+    int slices = topk_slices((max_m + 255) / 256 * n_seg, max_n, segA != nullptr);
     if (!segA) {                                 // one pair: the slice width the kernel derives must cover n with this many slices
         const int slice = (n + slices - 1) / slices;
         slices = (n + slice - 1) / slice;
@@ -930,7 +1001,8 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     const int gm = (m + 255) / 256;
     roreg::ProfScope prof(roreg::PROF_TOPK, s);
 #define RM_TOPK(KK)                                                                                                                  \
-    hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
+    if (valu) hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
+    else hipLaunchKernelGGL(topk_dot_mfma_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
     hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
     if (k == 16) { RM_TOPK(16) } else if (k == 8) { RM_TOPK(8) } else { RM_TOPK(1) }
 #undef RM_TOPK

@@ -47,6 +47,43 @@ def test_topk_dot(m, n, k):
         assert list(idx[i]).index(1) < list(idx[i]).index(n // 2)
 
 
+def test_topk_on_the_matrix_cores_is_bitwise_the_vector_pipe_search(tmp_path):
+    """roreg_topk_dot's default kernel forms the dot products as float32 MFMA chains (= the fmaf chains of the vector-pipe kernel, bit for bit) and
+    selects per lane; against ROREG_TOPK_VALU=1 (a child process): indices AND values bitwise, k = 16 / 8 / 1, stacked ragged pairs (segments),
+    exact ties (duplicated targets: lower index first) within and across the two half-wave lists and across slices, sizes on both sides of the
+    32-row tile and the 128-source workgroup."""
+    import subprocess, sys
+    from roreg_amd import hip
+    rng = np.random.default_rng(91)
+    sizes = [(300, 257), (64, 190), (513, 2500), (2500, 33), (129, 5000), (17, 40)]
+    A = [rng.standard_normal((m, 32)).astype(np.float32) for m, _ in sizes]
+    B = [rng.standard_normal((n, 32)).astype(np.float32) for _, n in sizes]
+    for b in B:
+        n = b.shape[0]
+        b[n // 2] = b[1]; b[n - 1] = b[0]; b[min(n - 1, 36)] = b[4]        # exact ties: same tile / other half-wave / far apart
+    np.savez(tmp_path / 'in.npz', A=np.concatenate(A), B=np.concatenate(B), m=np.array([a for a, _ in sizes]), n=np.array([b for _, b in sizes]))
+    code = ("import numpy as np, torch, sys\n"
+            "from roreg_amd import hip\n"
+            "z = np.load(sys.argv[1]); A = torch.from_numpy(z['A']).cuda(); B = torch.from_numpy(z['B']).cuda()\n"
+            "out = {}\n"
+            "for k in (16, 8, 1):\n"
+            "    i, v = hip.topk_dot(A, B, k, want_val=True, segA=hip.Segments(z['m']), segB=hip.Segments(z['n']))\n"
+            "    out[f'i{k}'] = i.cpu().numpy(); out[f'v{k}'] = v.cpu().numpy()\n"
+            "    i, v = hip.topk_dot(A[:300].contiguous(), B[:257].contiguous(), k, want_val=True)\n"
+            "    out[f'si{k}'] = i.cpu().numpy(); out[f'sv{k}'] = v.cpu().numpy()\n"
+            "np.savez(sys.argv[2], **out)\n")
+    env = dict(os.environ, ROREG_TOPK_VALU='1', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / 'out.npz')
+    cA, cB = cu(np.concatenate(A)), cu(np.concatenate(B))
+    for k in (16, 8, 1):
+        i, v = hip.topk_dot(cA, cB, k, want_val=True, segA=hip.Segments([a for a, _ in sizes]), segB=hip.Segments([b for _, b in sizes]))
+        assert np.array_equal(i.cpu().numpy(), z[f'i{k}']) and np.array_equal(v.cpu().numpy(), z[f'v{k}']), k
+        i, v = hip.topk_dot(cA[:300].contiguous(), cB[:257].contiguous(), k, want_val=True)
+        assert np.array_equal(i.cpu().numpy(), z[f'si{k}']) and np.array_equal(v.cpu().numpy(), z[f'sv{k}']), k
+
+
 def test_group_corr_transposed_is_r_indicator(group):
     from roreg_amd import hip
     rng = np.random.default_rng(5)
