@@ -26,7 +26,8 @@ extern "C" {
  * roreg_lt_prepare_batch, roreg_group_conv_f16x2, roreg_lt_task 80 -> 96 bytes; 3: round 3 -- roreg_ransac_score / roreg_refine /
  * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order; roreg_ft_nonlin /
  * roreg_irrep_gemm_f16x2 take the plane-layout flags; 4: round 4 -- additions only (roreg_nn_search_ex / roreg_knn_search_ex / roreg_pdist and the entries marked "v4"),
- * bumped so that a binding can rely on them).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * bumped so that a binding can rely on them; 5: round 5 -- additions only, the entries marked "v5": roreg_sinkhorn_batch3 (+ its workspace size),
+ * roreg_linear_path, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
 #define ROREG_ABI_VERSION 5
 int roreg_abi_version(void);
