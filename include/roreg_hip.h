@@ -27,7 +27,7 @@ extern "C" {
  * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order; roreg_ft_nonlin /
  * roreg_irrep_gemm_f16x2 take the plane-layout flags; 4: round 4 -- additions only (roreg_nn_search_ex / roreg_knn_search_ex / roreg_pdist and the entries marked "v4"),
  * bumped so that a binding can rely on them; 5: round 5 -- additions only, the entries marked "v5": roreg_sinkhorn_batch3 (+ its workspace size),
- * roreg_linear_path, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * roreg_linear_path, roreg_gemm_persistent, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
 #define ROREG_ABI_VERSION 5
 int roreg_abi_version(void);
@@ -497,6 +497,11 @@ int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float
                            activations then reach LDS by LDS-DMA and the matrix cores through transposing LDS reads, no register staging
                            (needs tile_m = 256); x_planes = 1: 32x32x16 MFMAs, results bitwise those of the word layout; x_planes = 2 (round 4): the same
                            operands and LDS images under v_mfma_f32_16x16x32_f16 (K = 32 per step: ~4 % faster, the same error bound, last bits differ) */, void *stream);
+/* v5: how the x_planes = 2 kernel is launched.  0: one workgroup per 256 x 256 tile (round 4).  1: PERSISTENT workgroups, one per CU, that claim
+ * tiles from the list's per-XCD streams and request the next tile's first operand stages before they store the finished one
+ * (irrep_gemm_xdma16p_kernel, csrc/fourier.hip); the same MFMA sequence per output element: bitwise the same results.  -1: query.
+ * Returns the previous setting; the initial one is the environment's ROREG_GEMM_PERSIST (unset = DEFAULT). */
+int roreg_gemm_persistent(int on);
 /* bound_out[b] (b < round_up(B,32); 0 for pad keypoints) = sqrt(60) max_{c,g} |act(x[b,c,g])| >= every coefficient of FT(act(x[b])), act =
  * ReLU(bn_scale_c x + bn_shift_c) or the identity (bn NULL): the x_bound of a layer whose input is a group-domain tensor [B,C,60]. */
 int roreg_row_bound(const void *x_spatial, int x_bf16 /* x is bfloat16 instead of float32 */, const float *bn_scale, const float *bn_shift,

@@ -10,7 +10,7 @@ import torch
 from . import hip as _core
 from .hip import HipError, _check, _feat, _ptr, _stream, lib
 
-__all__ = ['DenseSplitLayer', 'IRREP_DIMS', 'IRREP_OFFSETS', '_bf16_split3', '_keypoint_of_columns', '_ptr_array', '_res_ptr', '_tile_cache', 'bf16_split3_pack', 'bound_exp', 'coef_pitch', 'coef_size', 'coef_views', 'dense_split', 'ensure_fourier', 'f16_scale_exp', 'f16_split2_pack', 'ft_nonlin', 'ft_nonlin_packed', 'group_conv_split_pack', 'irrep_gemm', 'next_bound', 'next_bound_spatial', 'pack_coefs_f16x2', 'row_bound', 'unpack_coefs_f16x2', 'words_to_planes']
+__all__ = ['DenseSplitLayer', 'IRREP_DIMS', 'IRREP_OFFSETS', '_bf16_split3', '_keypoint_of_columns', '_ptr_array', '_res_ptr', '_tile_cache', 'bf16_split3_pack', 'bound_exp', 'coef_pitch', 'coef_size', 'coef_views', 'dense_split', 'ensure_fourier', 'f16_scale_exp', 'f16_split2_pack', 'ft_nonlin', 'ft_nonlin_packed', 'gemm_persistent', 'group_conv_split_pack', 'irrep_gemm', 'next_bound', 'next_bound_spatial', 'pack_coefs_f16x2', 'row_bound', 'unpack_coefs_f16x2', 'words_to_planes']
 
 
 _fourier_ready = False
@@ -99,6 +99,21 @@ def irrep_gemm(X_buf, Wpacks, C, O, B, split=None, add=None, f16x2=None, x_bound
     if _core.PROFILE is not None:
         e1.record(); _core.PROFILE.append((('irrep_gemm_f16x2' if f16x2 is not None else 'irrep_gemm_split' if split is not None else 'irrep_gemm', Bp, C, O), e0, e1))
     return (out, bound_out) if next_bound is not None else out
+
+
+class gemm_persistent:
+    """`with hip.gemm_persistent(True | False):` -- how the 16x16x32 LDS-DMA GEMM is launched inside the block (roreg_gemm_persistent): persistent
+    workgroups that claim tiles, or one workgroup per tile.  Same bits either way -- tests and A/B measurements."""
+
+    def __init__(self, on=True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = lib().roreg_gemm_persistent(self.on)
+
+    def __exit__(self, *exc):
+        lib().roreg_gemm_persistent(self.prev)
+        return False
 
 
 def row_bound(x, bn=None):

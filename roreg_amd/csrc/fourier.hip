@@ -15,6 +15,7 @@
 //                       layout of the first, so no transpose is needed).
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -787,7 +788,35 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f);    
 // residual (16-byte loads), 16-byte stores (1 KB per instruction: two rows x 512 contiguous bytes), optional bound of the next
 // transform (max over the rows of u_o |T| + v_o per column, merged per keypoint with atomic max: order-independent).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int wb, f32x4_t (&acc)[4][8], char *smem) {
+// What the epilogue needs from memory besides the residual, fetched at the START of the workgroup's life (round 5) -- the first DMA pieces'
+// trip from HBM covers these loads, the values ride through the loop in six registers, and the epilogue begins without a memory round trip
+// (it used to open with one: the column scales' bounds, then the rows' (u, v) of the next bound behind a barrier):
+struct Epi16Pre {
+    float osc[4];                 // 2^-(e(keypoint) + w_exp) of this lane's four adjacent columns (1 beyond N); until gemm_split_epilogue16_scales: the keypoints' bounds
+    float u, v;                   // thread t < 256: (nb_u, nb_v) of tile row t (0 beyond M, or without bound propagation)
+};
+__device__ __forceinline__ Epi16Pre gemm_split_epilogue16_request(const GemmSplitDescs &p, int irr, int mt, int n0, int wb) {
+    constexpr int OT = 256;
+    const int tid = threadIdx.x, rl = tid & 31;
+    const int N = p.N[irr], M = p.M[irr], dirr = kIrrDim[irr];
+    const int ncol = n0 + wb * 128 + 4 * rl;                     // (N % 32 == 0: the four columns are inside or outside together; four adjacent
+    Epi16Pre e;                                                  //  columns of a 32-column block = four adjacent keypoints: one 16-byte load)
+    const f32x4_t xb = ncol < N ? *reinterpret_cast<const f32x4_t *>(p.xbound + column_keypoint(ncol, dirr)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.osc[i] = xb[i];
+    e.u = 0.f; e.v = 0.f;
+    if (p.out_bound != nullptr && tid < OT) {
+        const int m = mt * OT + tid;
+        if (m < M) { e.u = p.nb_u[m % p.O]; e.v = p.nb_v[m % p.O]; }
+    }
+    return e;
+}
+__device__ __forceinline__ void gemm_split_epilogue16_scales(const GemmSplitDescs &p, Epi16Pre &e, bool col_ok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.osc[i] = col_ok ? ldexpf(1.f, -(bound_exp(e.osc[i]) + p.w_exp)) : 1.f;
+}
+__device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int wb, f32x4_t (&acc)[4][8], char *smem,
+                                                      const Epi16Pre &pre) {
     constexpr int NCOL = 256, OT = 256, NT = 512, P = 192;      // P: row pitch of a wave's LDS tile in floats (a multiple of the 64 banks: the row's bank shift is rowpad alone)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -809,43 +838,58 @@ __device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, i
     // group they cover the 64 banks exactly once
     const int rowpad_w = 8 * (q & 1) + 32 * (q >> 1);
     const int rl = lane & 31, rr = lane >> 5;                    // read side: columns 4 rl .. 4 rl + 3, row parity rr
-    const int ncol = n0 + wb * 128 + 4 * rl;                     // (N % 32 == 0: the four columns are inside or outside together)
+    const int ncol = n0 + wb * 128 + 4 * rl;
     const bool col_ok = ncol < N;
-    float osc[4], bm[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        osc[e] = col_ok ? ldexpf(1.f, -(bound_exp(p.xbound[column_keypoint(ncol + e, dirr)]) + p.w_exp)) : 1.f;
-        bm[e] = 0.f;
-    }
+    const int ncl = col_ok ? ncol : N - 4;                       // (clamped: the residual is always read from a valid address)
+    float bm[4] = {0.f, 0.f, 0.f, 0.f};
     if (want_bound) {                                            // (the LDS rings are dead: the loop ended with a barrier)
-        for (int i = tid; i < OT; i += NT) {
-            const int m = mt * OT + i;
-            su[i] = m < M ? p.nb_u[m % p.O] : 0.f; sv[i] = m < M ? p.nb_v[m % p.O] : 0.f;
-        }
+        if (tid < OT) { su[tid] = pre.u; sv[tid] = pre.v; }
         for (int i = tid; i < NCOL; i += NT) cm[i] = 0u;
         __syncthreads();
     }
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
+        // the row block's eight residual pieces are requested first and arrive under the LDS round trip (round 5; they used to be
+        // 8 x (load, wait, add, store) per row block: the compiler drains vmcnt in front of a load's first use while stores are pending)
+        size_t off[8];
+        bool ok[8];
+        f32x4_t ad[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = mt * OT + wo * 64 + rb * 16 + 2 * it + rr;
+            ok[it] = m < M && col_ok;
+            off[it] = (size_t)(m < M ? m : M - 1) * N + ncl;
+        }
+        if (Add) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) ad[it] = *reinterpret_cast<const f32x4_t *>(Add + off[it]);
+        }
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf[(4 * q + r) * P + rowpad_w + cw[cb]] = acc[rb][cb][r];
+        f32x4_t o[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row_l = 2 * it + rr;
-            const int row = wo * 64 + rb * 16 + row_l;
-            const int m = mt * OT + row;
             const f32x4_t v = *reinterpret_cast<const f32x4_t *>(buf + row_l * P + 8 * ((row_l >> 2) & 1) + 32 * ((row_l >> 3) & 1) + 4 * rl);
-            if (m < M && col_ok) {
-                f32x4_t o = {v[0] * osc[0], v[1] * osc[1], v[2] * osc[2], v[3] * osc[3]};
-                const size_t off = (size_t)m * N + ncol;
-                if (Add) { const f32x4_t ad = *reinterpret_cast<const f32x4_t *>(Add + off); o = o + ad; }
-                *reinterpret_cast<f32x4_t *>(Out + off) = o;
-                if (want_bound) {
-                    const float ur = su[row], vr = sv[row];
+            o[it] = f32x4_t{v[0] * pre.osc[0], v[1] * pre.osc[1], v[2] * pre.osc[2], v[3] * pre.osc[3]};
+        }
+        if (Add) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bm[e] = fmaxf(bm[e], fmaf(ur, fabsf(o[e]), vr));
+            for (int it = 0; it < 8; ++it) o[it] = o[it] + ad[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            if (ok[it]) *reinterpret_cast<f32x4_t *>(Out + off[it]) = o[it];
+        if (want_bound) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = wo * 64 + rb * 16 + 2 * it + rr;
+                const float ur = su[row], vr = sv[row];
+                if (ok[it]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bm[e] = fmaxf(bm[e], fmaf(ur, fabsf(o[it][e]), vr));
                 }
             }
         }
@@ -1010,8 +1054,13 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
     };
     // ---- prologue: steps 0 and 1 (K16 stages 0-3) requested, landed; the weight fragments of step 0 and the first column block into registers ----
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { dma_x(0, ks); dma_x(1, ks); dma_w(0, ks); dma_w(1, ks); }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int ks = 0; ks < 4; ++ks) { dma_w(0, ks); dma_w(1, ks); }
+    for (int ks = 0; ks < 2; ++ks) { dma_x(0, ks); dma_x(1, ks); }
+    Epi16Pre pre = gemm_split_epilogue16_request(p, irr, mt, n0, wb);      // (what the epilogue would otherwise open with: in flight together with the first stages)
+    for (int ks = 2; ks < 4; ++ks) { dma_x(0, ks); dma_x(1, ks); }
+    // in issue order the four pieces of activation stages 2, 3 are the newest: step 0's operands and step 1's weights have landed (those stages
+    // are first read behind step 0's barrier, whose vmcnt(3) covers them)
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     static_for<8>([&](auto c) { read_a(0, integral_constant<int, decltype(c)::value / 2>{}, integral_constant<int, decltype(c)::value % 2>{}, aA); });
     read_b(0u, integral_constant<int, 0>{}, b0);
     // (the first step's DMA pieces target stages 4, 5 of the activations -- never used -- and stages 0, 1 of the weights, whose fragments
@@ -1023,7 +1072,296 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the clamped look-ahead pieces still target LDS the epilogue reuses
 #undef ROREG_PIN_B
-    gemm_split_epilogue16(p, irr, mt, n0, wo, wb, acc, smem);
+    gemm_split_epilogue16_scales(p, pre, n0 + wb * 128 + 4 * (lane & 31) < N);
+    gemm_split_epilogue16(p, irr, mt, n0, wo, wb, acc, smem, pre);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// irrep_gemm_xdma16_kernel as PERSISTENT workgroups (round 5).  That kernel's workgroup owns a CU (all 160 KB of LDS), so nothing runs under
+// the ends of its life: the dispatch of its successor, the tile decode, the first DMA pieces' trip from HBM (the loop cannot start before
+// two K32 steps of both operands have landed) and the epilogue are exposed once per 256 x 256 tile.  Here gridDim.x = 8 c workgroups (c per
+// XCD, one per CU) walk the work list: workgroup b takes positions b / 8, b / 8 + c, ... of stream b % 8 (the list is eight interleaved
+// per-XCD streams, roreg_irrep_gemm_tiles_m; which CU runs a workgroup decides nothing but speed), and requests the next tile's first operand
+// stages BEFORE it has stored the finished one:
+//     loop end (rings dead) | next entry (scalar loads, under the epilogue's own first loads) | epilogue passes 0 .. RA-1 | DMA: weights K16
+//     stages 0-3 + activations 0-2 -> ring slots the epilogue does not touch | passes RA .. 7 | barrier | DMA: activation stage 3 | next loop
+// The main loop (steps, waits, barrier) is the other kernel's, instruction for instruction, and so is every accumulator's MFMA sequence:
+// results are bitwise the same.  The epilogue works in 48 KB .. 88 KB of the LDS (activation stages 3-5): a wave passes 16 rows x 64 columns
+// at a time through a 16 x 72 float buffer (8 passes per tile instead of 4 of 128 columns: 4.5 KB per wave instead of 12); the write side's
+// four 16-lane groups are shifted by 0, 32, 8, 40 banks (row pitch 72 = 8 mod 64, four rows = 32, + 8 floats for the rows of q >= 2), the
+// read side's 16-lane groups read 256 contiguous bytes: no bank conflicts on either side.
+template <int BIG, int RA>
+__global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16p_kernel(GemmSplitDescs p, const int *__restrict__ tiles, int longest) {
+    using frag = f16x8;
+    using f32x4 = f32x4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCOL = 256, OT = 256, NT = 512;
+    constexpr int XIMG = 16 * NCOL * 2, XSTAGE = 2 * XIMG;
+    constexpr int ABUF = 2 * 2 * OT;
+    constexpr int NXS = 6, NWS = 4;
+    constexpr int EP = 72;                                       // row pitch (floats) of a wave's epilogue buffer
+    constexpr int EPI0 = 3 * XSTAGE, EPI_BYTES = 4096 + 8 * 16 * EP * 4;      // 48 KB .. 88 KB
+    static_assert(EPI0 + EPI_BYTES <= NXS * XSTAGE, "the epilogue stays inside activation stages 3-5");
+    char *xs = smem;
+    frag *as = reinterpret_cast<frag *>(smem + NXS * XSTAGE);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int wo = w % 4, wb = w / 4;
+    const int stream_k = blockIdx.x & 7, pos_step = gridDim.x >> 3;
+    int pos = blockIdx.x >> 3;
+    if (pos >= longest) return;
+    int irr = tiles[(size_t)(pos * 8 + stream_k) * 3], mt = tiles[(size_t)(pos * 8 + stream_k) * 3 + 1], nt = tiles[(size_t)(pos * 8 + stream_k) * 3 + 2];
+    if (irr < 0) return;                                         // (padding: the stream is shorter than the longest one)
+
+    // ---- DMA of the tile (irr, mt, nt): exactly the other kernel's pieces ----
+    const int x_plane = w >> 2;
+    const char *xsrc[2];
+    int xdst[2];
+    const frag *wsrc = nullptr;
+    size_t xstep = 0, split_stride = 0;
+    int nsteps = 0, nss = 0, Mpad = 0;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) { xsrc[i2] = nullptr; xdst[i2] = x_plane * XIMG + ((2 * w + i2) & 7) * 1024; }
+    auto setup = [&]() {
+        const int K = p.K[irr], N = p.N[irr];
+        Mpad = p.Mpad[irr];
+        nsteps = K / 16; nss = K / 32;
+        split_stride = (size_t)(K / 16) * 2 * Mpad;
+        xstep = (size_t)16 * N * 4;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int mm = (2 * w + i2) & 7;
+            const int pi = mm * 64 + lane;
+            const int beta = pi >> 3, r = (pi & 7) >> 1, half = pi & 1;
+            const int k = 4 * (beta >> 4) + r;
+            int col = nt * NCOL + 16 * ((beta & 15) ^ ((beta >> 5) & 1)) + 8 * half;
+            if (col > N - 8) col = N - 8;
+            xsrc[i2] = reinterpret_cast<const char *>(p.X[irr]) + (size_t)k * N * 4 + (col >> 5) * 128 + x_plane * 64 + (col & 31) * 2;
+        }
+        wsrc = reinterpret_cast<const frag *>(p.W[irr]) + (size_t)(tid / OT) * Mpad + mt * OT + ((tid % OT) ^ (8 * (tid / OT)));
+    };
+    auto dma_x = [&](int i2, int kstep) {
+        const char *src = xsrc[i2] + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * xstep;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(xs + (kstep % NXS) * XSTAGE + xdst[i2]), 16, 0, 0);
+    };
+    auto dma_w = [&](int sp, int kstep) {
+        const frag *src = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + sp * split_stride),
+                                         (__attribute__((address_space(3))) void *)(as + (kstep % NWS) * ABUF + sp * (2 * OT) + w * 64), 16, 0, 0);
+    };
+    auto request_a = [&]() {                                     // everything of the first two K32 steps that lands outside 48 KB .. 96 KB
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { dma_w(0, ks); dma_w(1, ks); }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { dma_x(0, ks); dma_x(1, ks); }
+    };
+    auto request_b = [&]() { dma_x(0, 3); dma_x(1, 3); };
+
+    // ---- fragment addresses (tile independent) ----
+    const int a_lane = (q >> 1) * ABUF + (q & 1) * OT + wo * 64 + (j ^ (8 * (q & 1)));
+    const unsigned x_lane = (unsigned)(uintptr_t)xs + (unsigned)((q >> 1) * XSTAGE + ((2 * (q & 1)) * 16 + wb * 8) * 128 + j * 8);
+    const unsigned x_swap = (q & 1) ? 128u : 0u;
+    frag aA[4][2], aB[4][2];
+    frag b0[2], b1[2];
+    f32x4 acc[4][8];
+    auto read_a = [&](int S, auto rb_c, auto pl_c, frag (&a)[4][2]) {
+        constexpr int rb = decltype(rb_c)::value, pl = decltype(pl_c)::value;
+        a[rb][pl] = as[(S & 1) * 2 * ABUF + a_lane + pl * (2 * OT) + rb * 16];
+    };
+    auto read_b = [&](unsigned xoff, auto cb_c, frag (&b)[2]) {
+        constexpr int cb = decltype(cb_c)::value;
+        const unsigned a = (cb & 1) ? x_lane + xoff - x_swap : x_lane + xoff + x_swap;
+        unsigned long long u[4];
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[0]) : "v"(a), "n"(cb * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[1]) : "v"(a), "n"(cb * 128 + 2048));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[2]) : "v"(a), "n"(XIMG + cb * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[3]) : "v"(a), "n"(XIMG + cb * 128 + 2048));
+        struct Pair { unsigned long long lo, hi; };
+        b[0] = __builtin_bit_cast(frag, Pair{u[0], u[1]});
+        b[1] = __builtin_bit_cast(frag, Pair{u[2], u[3]});
+    };
+#define ROREG_PIN_B(waits, B) asm volatile(waits : "+v"(B[0]), "+v"(B[1]) :: "memory")
+    using std::integral_constant;
+    auto step = [&](int S, const frag (&a)[4][2], frag (&an)[4][2]) {      // (irrep_gemm_xdma16_kernel's step: see there for who may touch what, and when)
+        const unsigned xoff = (unsigned)((S % 3) * 2 * XSTAGE), xoff_next = (unsigned)(((S + 1) % 3) * 2 * XSTAGE);
+        static_for<8>([&](auto cb_c) {
+            constexpr int cb = decltype(cb_c)::value;
+            frag (&bc)[2] = (cb & 1) ? b1 : b0;
+            frag (&bn)[2] = (cb & 1) ? b0 : b1;
+            if constexpr (cb == 7) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            ROREG_PIN_B("s_waitcnt lgkmcnt(0)", bc);
+            auto mm = [&](int i) {
+                const frag bb = bc[i == 1 ? 1 : 0];
+                const int ai = i == 0 ? 1 : 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rb][ai], bb, acc[rb][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (cb < 7) read_b(xoff, integral_constant<int, cb + 1>{}, bn);
+            else read_b(xoff_next, integral_constant<int, 0>{}, bn);
+            if constexpr (cb == 0) { read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 0>{}, an); read_a(S + 1, integral_constant<int, 0>{}, integral_constant<int, 1>{}, an); }
+            else if constexpr (cb < 7) read_a(S + 1, integral_constant<int, (cb + 1) / 2>{}, integral_constant<int, (cb + 1) % 2>{}, an);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0);
+            if constexpr (cb < 4) dma_w(cb & 1, 2 * (S + 2) + (cb >> 1));
+            else dma_x(cb & 1, 2 * (S + 2) + ((cb - 4) >> 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1);
+            mm(2);
+        });
+    };
+
+    // ---- epilogue state (of the tile that has just been multiplied) ----
+    float *su = reinterpret_cast<float *>(smem + EPI0), *sv = su + OT;
+    unsigned *cm = reinterpret_cast<unsigned *>(sv + OT);
+    float *ebuf = reinterpret_cast<float *>(smem + EPI0 + 4096) + w * (16 * EP);
+    int cwl[4];                                                  // write side: the column (inside the pass's 64) of block cbl in this lane
+#pragma unroll
+    for (int cbl = 0; cbl < 4; ++cbl) {
+        const int pp = (cbl & 1) * 16 + j;
+        cwl[cbl] = (cbl >> 1) * 32 + (pp >> 1) + 16 * (pp & 1);
+    }
+    const int wr_off = 4 * q * EP + 8 * (q >> 1);                // + r * EP + cwl
+    const int rl = lane & 15, rrow = lane >> 4;                  // read side: columns 4 rl .. 4 rl + 3 of the 64, row rrow of every four
+    int e_mt = 0, e_M = 0, e_N = 0, e_dirr = 1;
+    float *__restrict__ e_Out = nullptr;
+    const float *__restrict__ e_Add = nullptr;
+    const bool want_bound = p.out_bound != nullptr;
+    int e_ncol[2];
+    float osc[2][4], bm[2][4];
+    auto epi_begin = [&]() {                                     // (the rings are dead: the loop ended with a barrier)
+        e_mt = mt; e_M = p.M[irr]; e_N = p.N[irr]; e_dirr = kIrrDim[irr];
+        e_Out = p.Out[irr]; e_Add = p.Add[irr];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            e_ncol[hf] = nt * NCOL + wb * 128 + hf * 64 + 4 * rl;      // (N % 32 == 0: the four columns are inside or outside together)
+            // (four adjacent columns of a 32-column block = four adjacent keypoints: one 16-byte load)
+            const f32x4 xb = e_ncol[hf] < e_N ? *reinterpret_cast<const f32x4 *>(p.xbound + column_keypoint(e_ncol[hf], e_dirr)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                osc[hf][e] = e_ncol[hf] < e_N ? ldexpf(1.f, -(bound_exp(xb[e]) + p.w_exp)) : 1.f;
+                bm[hf][e] = 0.f;
+            }
+        }
+        if (want_bound) {
+            for (int i = tid; i < OT; i += NT) {
+                const int m = e_mt * OT + i;
+                su[i] = m < e_M ? p.nb_u[m % p.O] : 0.f; sv[i] = m < e_M ? p.nb_v[m % p.O] : 0.f;
+            }
+            for (int i = tid; i < NCOL; i += NT) cm[i] = 0u;
+            __syncthreads();
+        }
+    };
+    auto epi_pass = [&](auto rb_c, auto hf_c) {
+        constexpr int rb = decltype(rb_c)::value, hf = decltype(hf_c)::value;
+        // the pass's four residual rows are requested first (from clamped, always valid addresses) and arrive under the LDS round trip: the
+        // compiler drains vmcnt completely in front of the first use of a load while stores are pending, so loads and stores are kept in
+        // two groups per pass instead of 4 x (load, wait, store)
+        const bool col_ok = e_ncol[hf] < e_N;
+        const int ncl = col_ok ? e_ncol[hf] : e_N - 4;
+        size_t off[4];
+        bool ok[4];
+        f32x4 ad[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = e_mt * OT + wo * 64 + rb * 16 + 4 * it + rrow;
+            ok[it] = m < e_M && col_ok;
+            off[it] = (size_t)(m < e_M ? m : e_M - 1) * e_N + ncl;
+        }
+        if (e_Add) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ad[it] = *reinterpret_cast<const f32x4 *>(e_Add + off[it]);
+        }
+#pragma unroll
+        for (int cbl = 0; cbl < 4; ++cbl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ebuf[wr_off + r * EP + cwl[cbl]] = acc[rb][4 * hf + cbl][r];
+        f32x4 o[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(ebuf + (4 * it + rrow) * EP + 8 * (it >> 1) + 4 * rl);
+            o[it] = f32x4{v[0] * osc[hf][0], v[1] * osc[hf][1], v[2] * osc[hf][2], v[3] * osc[hf][3]};
+        }
+        if (e_Add) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) o[it] = o[it] + ad[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (ok[it]) *reinterpret_cast<f32x4 *>(e_Out + off[it]) = o[it];
+        if (want_bound) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = wo * 64 + rb * 16 + 4 * it + rrow;
+                const float ur = su[row], vr = sv[row];
+                if (ok[it]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bm[hf][e] = fmaxf(bm[hf][e], fmaf(ur, fabsf(o[it][e]), vr));
+                }
+            }
+        }
+    };
+    auto epi_end = [&]() {
+        if (want_bound) {
+            const int e_n0 = e_ncol[0] - (wb * 128 + 4 * rl);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = fmaxf(bm[hf][e], __shfl_xor(bm[hf][e], 16));
+                    x = fmaxf(x, __shfl_xor(x, 32));
+                    if (rrow == 0) atomicMax(cm + wb * 128 + hf * 64 + 4 * rl + e, __float_as_uint(x));      // non-negative floats order like their bit patterns
+                }
+            __syncthreads();
+            for (int i = tid; i < NCOL; i += NT) {
+                const int n = e_n0 + i;
+                if (n < e_N) atomicMax(reinterpret_cast<unsigned *>(p.out_bound) + column_keypoint(n, e_dirr), cm[i]);
+            }
+        }
+    };
+
+    // ---- first tile ----
+    setup(); request_a(); request_b();
+    for (;;) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // in issue order the two pieces of activation stage 3 are the newest: everything of steps 0 and 1 but that stage has landed (the
+        // stage is first read behind step 0's barrier, whose vmcnt(3) covers it)
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        static_for<8>([&](auto c) { read_a(0, integral_constant<int, decltype(c)::value / 2>{}, integral_constant<int, decltype(c)::value % 2>{}, aA); });
+        read_b(0u, integral_constant<int, 0>{}, b0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int S = 0; S < nss; S += 2) {
+            step(S, aA, aB);
+            if (S + 1 < nss) step(S + 1, aB, aA);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the clamped look-ahead pieces have landed: the rings are dead
+        // the next entry of this workgroup's walk: scalar loads, in flight together with the epilogue's first loads
+        pos += pos_step;
+        int n_irr = -1, n_mt = 0, n_nt = 0;
+        if (pos < longest) {
+            const int *t = tiles + (size_t)(pos * 8 + stream_k) * 3;
+            n_irr = t[0]; n_mt = t[1]; n_nt = t[2];
+        }
+        epi_begin();
+        const bool more = n_irr >= 0;
+        static_for<8>([&](auto ps) {
+            constexpr int P = decltype(ps)::value;
+            if constexpr (P == RA) {
+                if (more) { irr = n_irr; mt = n_mt; nt = n_nt; setup(); request_a(); }
+            }
+            epi_pass(integral_constant<int, P / 2>{}, integral_constant<int, P % 2>{});
+        });
+        epi_end();
+        __syncthreads();                                         // every wave is done with 48 KB .. 88 KB: activation stage 3 may be overwritten
+        if (!more) break;
+        request_b();
+    }
+#undef ROREG_PIN_B
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1899,6 +2237,31 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
     return 0;
 }
 
+// ---- the persistent GEMM's host side: switch, CU count ----
+#define ROREG_GEMM_PERSIST_DEFAULT 0
+static std::atomic<int> g_gemm_persist{-1};                  // -1: not decided yet (environment at first use)
+static bool gemm_persistent() {
+    int v = g_gemm_persist.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("ROREG_GEMM_PERSIST");
+        v = e ? (e[0] == '1') : ROREG_GEMM_PERSIST_DEFAULT;
+        g_gemm_persist.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+extern "C" int roreg_gemm_persistent(int on) {
+    const int prev = gemm_persistent() ? 1 : 0;
+    if (on == 0 || on == 1) g_gemm_persist.store(on, std::memory_order_relaxed);
+    return prev;
+}
+static int gemm_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
 template <int NP, int WO>
 static int launch_gemm_split(const char *what, const float *const *X, float *const *Out, const float *const *Add, const void *const *Wsplit,
                              const float *xbound, int w_exp, const float *nb_u, const float *nb_v, float *out_bound, int C, int O, int B,
@@ -1924,7 +2287,19 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
                              : ((long long)C * O == 256ll * 512 ? irrep_gemm_xdma_kernel<1> : irrep_gemm_xdma_kernel<0>);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
             if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
-            hipLaunchKernelGGL(kx, dim3(n_tiles), dim3(512), lds_use, roreg::as_stream(stream), p, tiles_dev);
+            if (mfma16 && gemm_persistent()) {
+                const bool big = (long long)C * O == 256ll * 512;
+                static const int ra = [] { const char *v = getenv("ROREG_GEMM_PERSIST_RA"); return v ? atoi(v) : 2; }();
+                auto kp = ra == 0 ? (big ? irrep_gemm_xdma16p_kernel<1, 0> : irrep_gemm_xdma16p_kernel<0, 0>)
+                        : ra == 4 ? (big ? irrep_gemm_xdma16p_kernel<1, 4> : irrep_gemm_xdma16p_kernel<0, 4>)
+                                  : (big ? irrep_gemm_xdma16p_kernel<1, 2> : irrep_gemm_xdma16p_kernel<0, 2>);
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
+                if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
+                const int wgs = std::min(n_tiles, gemm_cu_count() / 8 * 8);      // one workgroup per CU (each needs the whole LDS); n_tiles is a multiple of 8
+                hipLaunchKernelGGL(kp, dim3(wgs), dim3(512), lds_use, roreg::as_stream(stream), p, tiles_dev, n_tiles / 8);
+            } else {
+                hipLaunchKernelGGL(kx, dim3(n_tiles), dim3(512), lds_use, roreg::as_stream(stream), p, tiles_dev);
+            }
             hipError_t e2 = hipGetLastError();
             if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
             return 0;

@@ -311,6 +311,33 @@ def test_plane_layout_gemm_is_bitwise_the_word_layout_gemm(group, C, Oc, B):    
         assert float((T16 - Tw).abs().max()) <= 2e-6 * float(Tw.abs().max()), float((T16 - Tw).abs().max()) / float(Tw.abs().max())
         assert float(((b16 - bw).abs() / bw.abs().clamp_min(1e-30)).max()) <= 1e-5
         assert torch.equal(T16.view(torch.int32), hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=True, **kw)[0].view(torch.int32)) == hip.MFMA16
+        # ... launched as persistent workgroups that walk the tile list (roreg_gemm_persistent): the same MFMA sequence per element
+        with hip.gemm_persistent(True):
+            Tq, bq = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=yb, next_bound=nb, x_planes=2, **kw)
+        assert torch.equal(T16.view(torch.int32), Tq.view(torch.int32)) and torch.equal(b16.view(torch.int32), bq.view(torch.int32))
+
+
+@pytest.mark.parametrize('C,Oc,B,resid', [(256, 512, 20000, False), (512, 256, 19993, True), (32, 256, 9000, False)])
+def test_persistent_gemm_launch_is_bitwise_the_per_tile_launch(group, C, Oc, B, resid):
+    """hip.gemm_persistent(True): one workgroup per CU walks its share of the tile list (several tiles each at these sizes, tiles of all five
+    irreps, ragged last column tiles) and requests the next tile's operands while it stores the finished one -- coefficients and the
+    propagated bound bit for bit those of the launch with one workgroup per tile, with and without the residual; twice, so that a launch
+    also starts from whatever the previous one left in LDS."""
+    from roreg_amd import hip
+    from roreg_amd.network.gf_fourier import _Layer
+    torch.manual_seed(B)
+    L = _Layer(torch.nn.Conv2d(C, Oc, (1, 13)))
+    x = torch.randn(hip.coef_size(C, B), device='cuda') * torch.exp(torch.randn(hip.coef_size(C, B), device='cuda'))
+    Xp, xb = hip.pack_coefs_f16x2(x, C, B)
+    Xp = hip.words_to_planes(Xp, C, B)
+    add = torch.randn(hip.coef_size(Oc, B), device='cuda') if resid else None
+    nb = (torch.rand(Oc, device='cuda') + 0.5, torch.rand(Oc, device='cuda'))
+    with hip.gemm_persistent(False):
+        T0, b0 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb, next_bound=nb, x_planes=2, add=add)
+    for _ in range(2):
+        with hip.gemm_persistent(True):
+            T1, b1 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb, next_bound=nb, x_planes=2, add=add)
+        assert torch.equal(T0.view(torch.int32), T1.view(torch.int32)) and torch.equal(b0.view(torch.int32), b1.view(torch.int32))
 
 
 def test_gemm_bound_propagation(group):
