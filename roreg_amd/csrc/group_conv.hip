@@ -567,7 +567,17 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
     }
 
     // ---- epilogue: bias, masked store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    // The lane's 32 biases are fetched first, all in flight together (round 5: read inside the store loop, every one of the 128 stores was
+    // load, s_waitcnt vmcnt(0), add, store -- the wait also drains the store before it: 128 serialised round trips per wavefront).
     float wmax[4] = {0.f, 0.f, 0.f, 0.f};
+    float bv[2][16];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            bv[ot][r] = o < p.Cout ? p.bias[o] : 0.f;
+        }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
 #pragma unroll
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int o = o_wave + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (o < p.Cout) {
-                    const float v = (NP == 2 ? acc[ot][t][r] * oscale[t] : acc[ot][t][r]) + p.bias[o];
+                    const float v = (NP == 2 ? acc[ot][t][r] * oscale[t] : acc[ot][t][r]) + bv[ot][r];
                     p.out[((size_t)bcol[t] * p.Cout + o) * Lout + gi[t]] = v;
                     wmax[t] = fmaxf(wmax[t], fabsf(v));
                 }

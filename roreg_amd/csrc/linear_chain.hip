@@ -97,16 +97,23 @@ __global__ __launch_bounds__(256) void linear_chain_kernel(const float *__restri
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[(nt * KS + j) * 64 + lane], acc[nt], 0, 0, 0);
         }
         // accumulator register r of lane l: row 8 (r / 4) + 4 (l / 32) + r % 4, output l % 32: 128-byte runs per row
+        // (ACCUM: the sixteen old values are fetched together -- read inside the store loop each was load, s_waitcnt vmcnt(0), add, store)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            float prev[16];
+            if (ACCUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = min(p0 + w * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), L - 1);
+                    prev[r] = y[(size_t)p * COUT + nt * 32 + (lane & 31)];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = p0 + w * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                if (p < L) {
-                    float *yo = y + (size_t)p * COUT + nt * 32 + (lane & 31);
-                    *yo = ACCUM ? *yo + acc[nt][r] : acc[nt][r];
-                }
+                if (p < L) y[(size_t)p * COUT + nt * 32 + (lane & 31)] = ACCUM ? prev[r] + acc[nt][r] : acc[nt][r];
             }
+        }
     }
 }
 

@@ -131,14 +131,16 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
             // accumulator register r of lane l: row 8 (r / 4) + 4 (l / 32) + r % 4 of the tile, output nt * 32 + l % 32
             const int o = nt * 32 + (lane & 31);
             const float bias = b[o];
+            float prev[16];                                                 // (ACCUM: fetched together, not load / wait / add / store per row)
+            if (ACCUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prev[r] = y[(size_t)min(row0 + 8 * (r >> 2) + 4 * kg + (r & 3), L - 1) * COUT + o];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = 8 * (r >> 2) + 4 * kg + (r & 3);
                 const float val = acc[r] * upr[r] + bias;                   // exact power-of-two rescale, then the bias
-                if (row0 + rr < L) {
-                    float *yo = y + (size_t)(row0 + rr) * COUT + o;
-                    *yo = ACCUM ? *yo + val : val;
-                }
+                if (row0 + rr < L) y[(size_t)(row0 + rr) * COUT + o] = ACCUM ? prev[r] + val : val;
             }
         }
     }
