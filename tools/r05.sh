@@ -91,7 +91,7 @@ final)      # final: build, smoke, full gpu suite, the driver's bench command, f
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_final.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest_gpu_final.log
   timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2> $OUT/bench_final.err; echo "bench rc $? lines $(wc -l < $OUT/bench_final.json)"
   timeout 900 python bench.py --force-collectives --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_forced_final.json 2> $OUT/bench_forced_final.err; echo "forced rc $? lines $(wc -l < $OUT/bench_forced_final.json)"
-  ROREG_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 3 --backend gloo --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_shared3_final.json 2> $OUT/bench_shared3_final.err; echo "shared3 rc $? lines $(wc -l < $OUT/bench_shared3_final.json)"
+  ROREG_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 3 --backend gloo --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_shared3_final.json 2> $OUT/bench_shared3_final.err; echo "shared3 rc $? lines $(wc -l < $OUT/bench_shared3_final.json)"
   python3 - <<'PY'
 import json
 j=json.load(open('gpurun_out/r05/bench_final.json')); f=json.load(open('gpurun_out/r05/bench_forced_final.json')); k=json.load(open('gpurun_out/r05/bench_shared3_final.json'))
