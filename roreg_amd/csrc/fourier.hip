@@ -206,7 +206,7 @@ __device__ __forceinline__ void split2(const float (&v)[8], float scale, f16x8 &
 //   cycles per 256 x 256 tile, 5.4 % of the kernel).  The B-fragment LDS slot of column n makes both sides conflict-free: block t's 32
 //   columns sit in 32 consecutive slots rotated by 4 t (16-lane ds_read_b128 groups read 16 consecutive slots; the 8-lane ds_write_b128
 //   groups of the staging -- 8 consecutive columns = 4 blocks x 2 lanes -- hit bank quads q, q+4, q+8, q+12, q+1, ...: all distinct).
-//   BLOCKED (rounds 1-2; the opt-in ping-pong kernel): t * 32 + j, slot n ^ ((n >> 3) & 1).
+//   BLOCKED (rounds 1-2): t * 32 + j, slot n ^ ((n >> 3) & 1).
 //   PAIRED (the LDS-DMA kernel): t * 32 + j / 2 + 16 (j % 2) -- the order in which ft_nonlin's half-block layout holds a 32-column block
 //   (16-bit position e = column e / 2 + 16 (e % 2): its 32-bit words pair columns w and w + 16, see ft_nonlin_kernel's store).
 // The arithmetic per output element is the same either way (same K order, same MFMA sequence): results are bitwise identical.
@@ -1365,153 +1365,6 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16p_kernel(GemmSplitDes
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// fp16 x 2 GEMM, 256 x 256 tile, 8 waves, "ping-pong" schedule.  The two waves that share a SIMD (w and w + 4: the two column halves of
-// the tile) alternate roles inside every K16 step instead of both interleaving matrix and memory work: after the step's barrier group 0
-// issues its 24 MFMAs back to back from fragment REGISTERS while group 1 does its LDS/VMEM work (fragment reads, staging of a later
-// step), then group 1's MFMAs run while group 0 reads its next fragments and stages -- the matrix pipe of the SIMD sees one unbroken
-// MFMA stream, and no MFMA ever waits on an LDS read issued after a barrier.  That needs the operands deeper in flight: a ring of FOUR
-// LDS stages (128 KB, one workgroup per CU; details at the loop).  Same MFMA sequence per accumulator as
-// irrep_gemm_split_kernel<.., 2, 4>: results are bitwise identical.  Measured slower than that kernel: opt-in experiment.
-template <int BIG>
-__global__ __launch_bounds__(512, 2) void irrep_gemm_pp_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NCOL = 256, OT = 256;
-    constexpr int XBUF = 2 * 2 * NCOL, ABUF = 2 * 2 * OT, STAGE = XBUF + ABUF;       // 16-byte fragments per stage (32 KB)
-    f16x8 *ring = reinterpret_cast<f16x8 *>(smem);                                   // [3][X planes | W planes]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int irr = tiles[blockIdx.x * 3], mt = tiles[blockIdx.x * 3 + 1], nt = tiles[blockIdx.x * 3 + 2];
-    if (irr < 0) return;
-    const float *__restrict__ X = p.X[irr];
-    const f16x8 *__restrict__ W = reinterpret_cast<const f16x8 *>(p.W[irr]);
-    const int K = p.K[irr], Mpad = p.Mpad[irr], N = p.N[irr];
-    const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;
-    const int wo = w & 3;
-    const int grp = __builtin_amdgcn_readfirstlane(w >> 2);                          // wave-uniform role: 0 computes first, 1 loads first
-    const int n0 = nt * NCOL, ncol_wave = grp * 128;
-    const int nsteps = K / 16;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
-
-    // staging patch of this thread: column n0 + pp (clamped), k-octet po of a step: 8 words fp16 hi | lo << 16
-    const int pp = tid & 255, po = tid >> 8;
-    int ncol = n0 + pp;
-    if (ncol > N - 1) ncol = N - 1;
-    const float *xcol = X + ncol + (size_t)(8 * po) * N;
-    auto load_x = [&](int kstep, float (&xr)[8]) {
-        const float *q = xcol + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 16 * N;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xr[e] = q[(size_t)e * N];
-    };
-    const int slot = po * NCOL + (pp ^ ((pp >> 3) & 1));
-    auto store_x = [&](int stage, const float (&xr)[8]) {
-        u32x4 H, L;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned a = __float_as_uint(xr[2 * i]), b = __float_as_uint(xr[2 * i + 1]);
-            H[i] = __builtin_amdgcn_perm(b, a, 0x05040100u);
-            L[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);
-        }
-        f16x8 *dst = ring + stage * STAGE;
-        dst[slot] = __builtin_bit_cast(f16x8, H); dst[2 * NCOL + slot] = __builtin_bit_cast(f16x8, L);
-    };
-    const f16x8 *wsrc = W + (size_t)(tid >> 8) * Mpad + mt * OT + (tid & 255);
-    // The weight DMA is issued through inline assembly so that the compiler's wait-count pass does not see a pending LDS write it would
-    // have to drain (vmcnt(0)) before every later LDS access; the explicit vmcnt(10) below orders it.  (Hidden VMEM operations only make the
-    // compiler's own counted waits for the patch loads stricter, never laxer: VMEM retires in order.)
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-    auto issue_a = [&](int kstep, int stage) {
-        const f16x8 *q = wsrc + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((stage * STAGE + XBUF + sp * (2 * OT) + w * 64) * 16));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(q + sp * split_stride), "s"(dst) : "memory");
-        }
-    };
-    int xslot[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { const int n = ncol_wave + t * 32 + j; xslot[t] = h * NCOL + (n ^ ((n >> 3) & 1)); }
-    const int aslot = XBUF + h * OT + wo * 64 + j;
-
-    f16x8 fa[2][2], fb[4][2];                                   // this wave's fragments of one step: [row block][plane], [column block][plane]
-    auto read_frags = [&](int stage) {
-        const f16x8 *st = ring + stage * STAGE;
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) fa[ot][sp] = st[aslot + sp * (2 * OT) + ot * 32];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { fb[t][0] = st[xslot[t]]; fb[t][1] = st[2 * NCOL + xslot[t]]; }
-    };
-    auto mfma_phase = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        // lo.hi, hi.lo, hi.hi -- the same three-term sequence per accumulator as the interleaved kernel, products outermost (8 MFMAs between
-        // two uses of one accumulator)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][1], fb[t][0], acc[ot][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][0], fb[t][1], acc[ot][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) acc[ot][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ot][0], fb[t][0], acc[ot][t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // Operands are two steps deep in flight: a ring of FOUR LDS stages; at step k the weight DMA of stage k+3 and the patch loads of step
-    // k+4 are issued, the patch of step k+2 (loaded two steps ago) is staged, and the step ends waiting only for what was issued BEFORE
-    // this step (vmcnt(10): VMEM operations retire in order; this step's 8 loads + 2 DMA pieces stay in flight across the barrier).
-    // The barrier is a RAW s_barrier behind lgkmcnt(0): __syncthreads() would fence with vmcnt(0) (an LDS-DMA is a pending LDS write on
-    // the VM counter) and drain exactly the loads that are meant to stay in flight.
-    float R0[8], R1[8], R2[8];                                  // the patch of step j lives in R[j % 3]: no register copies, so no load is waited for early
-    load_x(0, R0); load_x(1, R1);
-    issue_a(0, 0); issue_a(1, 1); issue_a(2, 2);
-    store_x(0, R0); store_x(1, R1);
-    load_x(2, R2); load_x(3, R0);                               // staged during steps 0 and 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (grp == 0) read_frags(0);
-    int sk = 0;
-    auto step = [&](int k, const float (&r_store)[8], float (&r_load)[8]) {
-        const int s1 = (sk + 1) & 3, s2 = (sk + 2) & 3, s3 = (sk + 3) & 3;
-        load_x(k + 4, r_load);
-        issue_a(k + 3, s3);
-        if (grp != 0) {                                         // group 1: memory work first, under group 0's MFMAs
-            read_frags(sk);
-            store_x(s2, r_store);
-        }
-        mfma_phase();                                           // (group 0: the fragments of step k are already in registers)
-        if (grp == 0) {                                         // group 0: memory work second, under group 1's MFMAs
-            read_frags(s1);                                     // step k + 1 (stage complete since the barrier that opened this step)
-            store_x(s2, r_store);
-        }
-        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everything issued before this step has landed
-        sk = s1;
-    };
-    int k = 0;
-#pragma unroll 1
-    for (; k + 3 <= nsteps; k += 3) {                           // whole triples: a fixed number of VMEM operations per trip, so the
-        step(k, R2, R1);                                        // compiler's own wait-count bookkeeping stays exact across the back edge
-        step(k + 1, R0, R2);
-        step(k + 2, R1, R0);
-    }
-    if (k < nsteps) step(k, R2, R1);
-    if (k + 1 < nsteps) step(k + 1, R0, R2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    gemm_split_epilogue<2, 4, COLS_BLOCKED>(p, irr, mt, n0, wo, ncol_wave, acc, smem);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 struct NonlinParams {
     const float *Xin;            // flat coefficient buffer [60*C*B] (nullptr when the input is spatial)
     float *Xout;                 // flat coefficient buffer out (nullptr when the output is spatial)
@@ -2306,21 +2159,6 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
         } else {
             roreg::set_error("%s: the half-block layout needs the fp16 x 2 kernel with tile_m = 256", what);
             return 2;
-        }
-    }
-    if constexpr (NP == 2 && WO == 4) {
-        // opt-in (ROREG_GEMM_PP=1): measured 13.4 vs 12.7 ms per launch against the interleaved kernel on the same box (round 2) -- neither
-        // the unbroken MFMA stream nor operands two steps deep in flight pay: the kernel is limited by the power the chip may draw
-        static const bool pingpong = [] { const char *e = getenv("ROREG_GEMM_PP"); return e && e[0] == '1'; }();
-        if (pingpong) {
-            const size_t lds_pp = 4 * (2 * 2 * 256 + 2 * 2 * 256) * 16;      // four stages of (activation planes + weight fragments)
-            auto kpp = (long long)C * O == 256ll * 512 ? irrep_gemm_pp_kernel<1> : irrep_gemm_pp_kernel<0>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kpp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp);
-            if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
-            hipLaunchKernelGGL(kpp, dim3(n_tiles), dim3(512), lds_pp, roreg::as_stream(stream), p, tiles_dev);
-            hipError_t e2 = hipGetLastError();
-            if (e2 != hipSuccess) { roreg::set_error("%s: launch failed: %s", what, hipGetErrorString(e2)); return 1; }
-            return 0;
         }
     }
     // ROREG_GEMM_PIPE=0 selects the loop without fragment pipelining (kept for A/B runs: results are bitwise the same)

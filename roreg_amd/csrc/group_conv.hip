@@ -280,12 +280,12 @@ __device__ __forceinline__ void gc_split3(const float (&v)[8], bf16x8 &b1, bf16x
     }
 }
 
-// PK: 0 = float32 input (BatchNorm, ReLU and the split happen while staging); 1 = packed words, staged between two barriers like the floats;
-// 2 = packed words with DOUBLE-BUFFERED raw chunks and fragment slabs: chunk c + 1 is regrouped from its raw copy into the other slab in the
-// shadow of chunk c's MFMAs (a few LDS reads and writes per stencil position), the raw copy of chunk c + 2 is in flight meanwhile -- one
-// barrier per chunk and no staging phase; 134 KB of LDS, i.e. one workgroup per CU.
+// PK: 0 = float32 input (BatchNorm, ReLU and the split happen while staging); 1 = packed words (fp16 hi | lo << 16 under the row's block scale),
+// staged between the same two barriers: the staging only regroups halves.  (A double-buffered form -- chunk c + 1 regrouped into a second slab
+// under chunk c's MFMAs, one barrier per chunk, 134 KB of LDS = one workgroup per CU -- measured slower, 671 vs 693 pairs/s contract-complete:
+// the second resident workgroup hides more than the staging phase costs.  Removed; NOTES.md round 5.)
 template <int KS, int NP, int PK = 0>
-__global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(GCSplitParams p) {
+__global__ __launch_bounds__(256, 2) void group_conv_split_kernel(GCSplitParams p) {
     constexpr bool PACKED = PK != 0;
     static_assert(!PACKED || NP == 2, "packed input words are fp16 hi / lo pairs");
     using frag = typename std::conditional<NP == 3, bf16x8, f16x8>::type;
@@ -345,13 +345,12 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
     // stencil loop every thread converts its k-octets from the raw LDS copy (BatchNorm, ReLU, split) into the fragment slab.  (The earlier
     // form loaded each k-octet with eight dependent global loads, one item after the other: 12-16 us of exposed latency per chunk against
     // 4 us of MFMAs -- the kernel ran at 42 % matrix-pipe duty, independent of the operands, i.e. stall-bound, not power-bound.)
-    const int slab_frags = PK == 2 ? NP * plane_stride : 0;                          // PK = 2: a second slab behind the first
-    float *raw = reinterpret_cast<float *>(slab + (size_t)NP * plane_stride + slab_frags);       // [nkp_max][16][Lin] (PK = 2: two of them)
+    float *raw = reinterpret_cast<float *>(slab + (size_t)NP * plane_stride);       // [nkp_max][16][Lin]
     const int raw_floats = p.nkp_max * 16 * Lin;
     // BatchNorm parameters of all input channels and the block scale of this tile's keypoints, staged ONCE: convert() runs between two
     // barriers of every chunk, and with these as global loads every one of its 4-5 iterations per thread exposed two L2 round trips
     // (the ISA showed s_waitcnt vmcnt(0) twice per iteration) -- more time per chunk than the chunk's MFMAs.
-    float *bn_s = raw + (size_t)(PK == 2 ? 2 : 1) * raw_floats, *bn_h = bn_s + p.Cin, *kp_scale = bn_h + p.Cin;       // [Cin], [Cin], [nkp_max]
+    float *bn_s = raw + raw_floats, *bn_h = bn_s + p.Cin, *kp_scale = bn_h + p.Cin;       // [Cin], [Cin], [nkp_max]
     for (int i = tid; i < p.Cin; i += 256) { bn_s[i] = has_bn ? p.bn_scale[i] : 1.f; bn_h[i] = has_bn ? p.bn_shift[i] : 0.f; }
     if constexpr (NP == 2)
         for (int i = tid; i < nkp; i += 256) kp_scale[i] = ldexpf(1.f, row_scale_exp(p.sc, b_first + i));
@@ -369,9 +368,9 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
             raw_off[q] = ((b_first + kp) * p.Cin) * Lin + 4 * r;                     // (B * Cin * Lin < 2^31: checked by the launcher)
         }
     }
-    auto issue_raw = [&](int c0, int buf = 0) {
+    auto issue_raw = [&](int c0) {
         const float *xc = p.x + (size_t)c0 * Lin;
-        float *dst0 = raw + (size_t)buf * raw_floats + (size_t)(w * 64) * 4;
+        float *dst0 = raw + (size_t)(w * 64) * 4;
 #pragma unroll
         for (int q = 0; q < RAW_ITERS; ++q) {
             if (w * 64 + q * 256 < pieces) {                                         // (wave-uniform)
@@ -400,15 +399,15 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
             }
         }
     }
-    // PK = 2: one item's eight words out of raw buffer `rb` (requested at one stencil position) ...
-    auto cv_load = [&](int q, int rb, unsigned (&wv)[8]) {
+    // one item's eight words out of the raw chunk ...
+    auto cv_load = [&](int q, unsigned (&wv)[8]) {
         if (cv_src[q] < 0) return;
-        const float *src = raw + (size_t)rb * raw_floats + cv_src[q];
+        const float *src = raw + cv_src[q];
 #pragma unroll
         for (int e = 0; e < 8; ++e) wv[e] = __float_as_uint(src[e * Lin]);
     };
-    // ... and, regrouped into the hi octet and the lo octet, into slab `sb` (at the next position)
-    auto cv_store = [&](int q, int sb, const unsigned (&wv)[8]) {
+    // ... and, regrouped into the hi octet and the lo octet, into the slab
+    auto cv_store = [&](int q, const unsigned (&wv)[8]) {
         if (cv_src[q] < 0) return;
         unsigned hw[4], lw[4];
 #pragma unroll
@@ -417,16 +416,16 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
             lw[e] = __builtin_amdgcn_perm(wv[2 * e + 1], wv[2 * e], 0x07060302u);
         }
         struct Q4 { unsigned a, b, c, d; };
-        frag *dst = slab + (size_t)sb * slab_frags + cv_dst[q];
+        frag *dst = slab + cv_dst[q];
         dst[0] = __builtin_bit_cast(frag, Q4{hw[0], hw[1], hw[2], hw[3]});
         dst[plane_stride] = __builtin_bit_cast(frag, Q4{lw[0], lw[1], lw[2], lw[3]});
     };
-    auto convert_packed = [&]() {                                                 // PK = 1 / the first chunk of PK = 2: all items between two barriers
+    auto convert_packed = [&]() {                                                 // all items between the chunk's two barriers
 #pragma unroll
         for (int q = 0; q < CV_ITEMS; ++q) {
             unsigned wv[8];
-            cv_load(q, 0, wv);
-            cv_store(q, 0, wv);
+            cv_load(q, wv);
+            cv_store(q, wv);
         }
     };
     auto convert_float = [&](int c0) {
@@ -470,14 +469,10 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) gix0[t] = gt[gi[t] * KS];
 
-    if constexpr (PK == 2) { if (p.Cin > 16) issue_raw(16, 1); }                     // chunk 1's raw copy travels under the first barrier
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
         const bool more = c0 + 16 < p.Cin;
-        const int cur = PK == 2 ? (c0 >> 4) & 1 : 0;                                 // slab / raw buffer of this chunk
-        if constexpr (PK == 2) { if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // this wave's pieces of the next chunk's raw copy have landed
         __syncthreads();                                                             // the slab of this chunk is complete, the raw buffer is free
-        const frag *slab_cur = slab + (size_t)cur * slab_frags;
-        unsigned cvw[8];                                                             // (PK = 2) the staging item in flight
+        const frag *slab_cur = slab;
 
         // ---- MFMA over the stencil; the weight fragments of position k+1 are in flight during position k ----------------
         // (the stencil loop is fully unrolled with two named fragment sets: a rolled loop with a register copy made the compiler wait for
@@ -508,15 +503,7 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
         for (int k = 0; k < KS; ++k) {
             const frag (&a_cur)[2][NP] = aw[k & 1];
             if (k + 1 < KS) load_a(k + 1, aw[(k + 1) & 1]);
-            if constexpr (PK != 2) {
-                if (k == 0 && more) issue_raw(c0 + 16);             // (after the weight loads of k = 1: their wait does not cover the DMA)
-            } else {
-                if (k == 0 && c0 + 32 < p.Cin) issue_raw(c0 + 32, cur);      // this chunk's raw buffer was regrouped during the previous chunk: free
-                if (more) {                                         // the next chunk, item by item, into the other slab
-                    if (k >= 1 && (k & 1) && (k >> 1) < CV_ITEMS) cv_load(k >> 1, cur ^ 1, cvw);
-                    if (k >= 2 && !(k & 1) && (k >> 1) - 1 < CV_ITEMS) cv_store((k >> 1) - 1, cur ^ 1, cvw);
-                }
-            }
+            if (k == 0 && more) issue_raw(c0 + 16);                 // (after the weight loads of k = 1: their wait does not cover the DMA)
             if (k + 1 < KS) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) gix[(k + 1) & 1][t] = gt[gi[t] * KS + k + 1];
@@ -557,12 +544,10 @@ __global__ __launch_bounds__(256, PK == 2 ? 1 : 2) void group_conv_split_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (PK != 2) {
-            if (more) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's DMA pieces have landed ...
-                __syncthreads();                                                     // ... everyone's have, and nobody reads the slab any more
-                convert(c0 + 16);
-            }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's DMA pieces have landed ...
+            __syncthreads();                                                         // ... everyone's have, and nobody reads the slab any more
+            convert(c0 + 16);
         }
     }
 
@@ -979,14 +964,13 @@ static int dispatch(GCParams p, int Lin, int KS, hipStream_t s, float *ws, size_
 
 template <int NP>
 static int launch_conv_split(GCSplitParams p, hipStream_t s) {
-    const int nbuf = (NP == 2 && p.packed == 2) ? 2 : 1;
-    const size_t lds = (size_t)p.gt_bytes + (size_t)nbuf * ((size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4)        // slot tables, fragment slab(s), raw chunk(s),
+    const size_t lds = (size_t)p.gt_bytes + (size_t)NP * 2 * p.nkp_max * p.S * 16 + (size_t)p.nkp_max * 16 * p.Lin * 4        // slot tables, fragment slab, raw chunk,
                        + (size_t)(2 * p.Cin + p.nkp_max) * 4;                                                                // BatchNorm parameters, keypoint scales
     ROREG_REQUIRE(lds <= 160 * 1024, "roreg_group_conv_split: tile needs %zu B of LDS", lds);
     ROREG_REQUIRE((size_t)p.nkp_max * 2 * p.Lin <= 5 * 256 && (size_t)p.nkp_max * 4 * p.Lin <= 9 * 256, "roreg_group_conv_split: %d keypoints x %d columns per tile exceed the staging plan", p.nkp_max, p.Lin);
     ROREG_REQUIRE((long long)p.B * p.Cin * p.Lin < (1ll << 31), "roreg_group_conv_split: input tensor beyond 2^31 elements");
     void (*kern)(GCSplitParams) = group_conv_split_kernel<13, NP>;
-    if constexpr (NP == 2) { if (p.packed) kern = p.packed == 2 ? group_conv_split_kernel<13, 2, 2> : group_conv_split_kernel<13, 2, 1>; }
+    if constexpr (NP == 2) { if (p.packed) kern = group_conv_split_kernel<13, 2, 1>; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { roreg::set_error("roreg_group_conv_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e)); return 1; }
     const int grid = ((p.ncols + 127) / 128) * (p.Cout / 256);
@@ -1040,12 +1024,8 @@ extern "C" int roreg_group_conv_f16x2_packed(const uint32_t *x_words, const void
                                              int Cin, int Cout, int Lin, int Lout, int KS, void *stream) {
     ROREG_REQUIRE(in_bound_dev, "roreg_group_conv_f16x2_packed: in_bound_dev is required");
     SplitScale sc = {in_bound_dev, 1.f, 0.f, w_exp, out_rowmax_dev};
-    // ROREG_ET_OVERLAP=1: the double-buffered form (regrouping of chunk c + 1 under chunk c's MFMAs, one barrier per chunk, one workgroup per CU).
-    // Measured SLOWER than staging between two barriers with two workgroups per CU (bench: 1061 / 671 against 1079 / 693 pairs/s headline /
-    // contract-complete): the second resident workgroup hides more than the staging phase costs.  Kept for measurements.
-    static const int overlapped = getenv("ROREG_ET_OVERLAP") && atoi(getenv("ROREG_ET_OVERLAP")) == 1;
     return conv_split_common(2, reinterpret_cast<const float *>(x_words), wsplit2, bias, nullptr, nullptr, out, gather, lds_order, lds_stride, B, Cin, Cout, Lin,
-                             Lout, KS, sc, stream, overlapped ? 2 : 1);
+                             Lout, KS, sc, stream, 1);
 }
 
 template <int NP>
