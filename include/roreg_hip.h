@@ -27,7 +27,7 @@ extern "C" {
  * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order; roreg_ft_nonlin /
  * roreg_irrep_gemm_f16x2 take the plane-layout flags; 4: round 4 -- additions only (roreg_nn_search_ex / roreg_knn_search_ex / roreg_pdist and the entries marked "v4"),
  * bumped so that a binding can rely on them; 5: round 5 -- additions only, the entries marked "v5": roreg_sinkhorn_batch3 (+ its workspace size),
- * roreg_linear_path, roreg_gemm_persistent, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * roreg_linear_path, roreg_linear_cat3, roreg_gemm_persistent, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
 #define ROREG_ABI_VERSION 5
 int roreg_abi_version(void);
@@ -371,6 +371,11 @@ int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t 
  * roreg_linear_path(1) selects the vector-pipe kernels instead (same bits; returns the previous setting, 0 = matrix cores). */
 int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
 int roreg_linear_path(int path);
+/* v5: y [m * k, Cout] (Cout = 64 | 32) = W [pos[r] (32) | table[idx[r]] (32) | conf[r / k] (32)] + b -- roreg_linear on the value MLP's input
+ * (rot_coh_match.py:95-119) without materialising its [m * k, 96] rows: the kernel's row staging reads the three sources.  The same chains on the same
+ * values: bitwise roreg_linear on the concatenated rows.  Matrix-core path only (with roreg_linear_path(1) build the rows and call roreg_linear). */
+int roreg_linear_cat3(const float *pos /* [m*k,32] */, const float *table /* [n,32] */, const int64_t *idx /* [m*k] rows of table */,
+                      const float *conf /* [m,32] */, int m, int k, const float *W /* [Cout,96] */, const float *b, int Cout, float *y, void *stream);
 /* v4: the same layer on the matrix cores for Cin >= 32 (other shapes: roreg_linear): fp16 hi + lo operands under exact per-row / per-tensor
  * power-of-two scales, all four cross products, f32 accumulate (<= 6e-7 of sum |w||x| per element: the level of the fmaf chain, other
  * rounding); one kernel for every L, a row's result depends on that row alone.  csrc/linear_mfma.hip; used by the stacked matcher. */

@@ -69,6 +69,7 @@ PROTOTYPES = {
     'roreg_linear': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_linear_mfma': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_linear_path': (c_int, [c_int]),
+    'roreg_linear_cat3': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_gemm_persistent': (c_int, [c_int]),
     'roreg_instnorm_stats': (c_int, [_P, c_int, c_int, c_float, _P, _P, _P, c_int, c_int, _P]),
     'roreg_mlp_tail': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),

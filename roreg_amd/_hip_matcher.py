@@ -9,7 +9,7 @@ import torch
 from . import hip as _core
 from .hip import HipError, _check, _ptr, _stream, ensure_des2r, ensure_tables, lib, upload
 
-__all__ = ['OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'topk_dot', 'value_input', 'vector_pipe_layers']
+__all__ = ['Cat3Rows', 'OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'topk_dot', 'value_input', 'vector_pipe_layers']
 
 
 def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpose=False, want_idx=False, perm_coefs=None, bcast_coefs=None):
@@ -107,8 +107,36 @@ class vector_pipe_layers:
         return False
 
 
+class Cat3Rows:
+    """The value MLP's input rows [m * k, 96] = [pos[r] | table[idx[r]] | conf[r // k]] WITHOUT the tensor (value_input): linear() hands the three
+    sources to roreg_linear_cat3, whose row staging assembles them (same chains on the same values: bitwise linear(materialise(), ...));
+    on the other kernel paths (vector pipe, fp16 hi/lo layers) the rows are built once and kept."""
+
+    def __init__(self, pos, table, conf, idx):
+        self.pos, self.table, self.conf, self.idx = pos, table, conf, idx
+        self.m, self.k = idx.shape
+        self.shape = (self.m * self.k, 96)
+        self.device = pos.device
+        self._rows = None
+
+    def materialise(self):
+        if self._rows is None:
+            self._rows = _rm_op(5, self.pos, torch.empty((self.m * self.k, 96), dtype=torch.float32, device=self.device), b=self.table, c=self.conf,
+                                idx=self.idx, L=self.m, k=self.k)
+        return self._rows
+
+
 def linear(x, W, b):
     """x [L,Cin] -> [L,Cout]; W [Cout,Cin], b [Cout] device float32."""
+    if isinstance(x, Cat3Rows):
+        Cout = W.shape[0]
+        if MATRIX_CORE_LAYERS or Cout not in (64, 32) or lib().roreg_linear_path(-1) != 0:
+            x = x.materialise()
+        else:
+            y = torch.empty((x.shape[0], Cout), dtype=torch.float32, device=x.device)
+            _check(lib().roreg_linear_cat3(_ptr(x.pos, torch.float32), _ptr(x.table, torch.float32), _ptr(x.idx, torch.int64), _ptr(x.conf, torch.float32),
+                                           x.m, x.k, _ptr(W, torch.float32), _ptr(b, torch.float32), Cout, _ptr(y), _stream()), 'roreg_linear_cat3')
+            return y
     L, Cin = x.shape
     Cout = W.shape[0]
     y = torch.empty((L, Cout), dtype=torch.float32, device=x.device)
@@ -172,9 +200,10 @@ def knn_coor(coor, idx):
     return _rm_op(3, coor, torch.empty((m * k, 3), dtype=torch.float32, device=coor.device), idx=idx, L=m, k=k)
 
 
-def value_input(pos_n, fea_n_table, conf_n, idx):
-    m, k = idx.shape
-    return _rm_op(5, pos_n, torch.empty((m * k, 96), dtype=torch.float32, device=pos_n.device), b=fea_n_table, c=conf_n, idx=idx, L=m, k=k)
+def value_input(pos_n, fea_n_table, conf_n, idx, materialise=False):
+    """-> the [m * k, 96] rows as a Cat3Rows (consumed by linear() / mlp_instnorm() without being built), or the tensor itself."""
+    rows = Cat3Rows(pos_n, fea_n_table, conf_n, idx)
+    return rows.materialise() if materialise else rows
 
 
 def concat_rows(a, b, c=None):

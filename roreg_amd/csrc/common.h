@@ -63,6 +63,8 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
 
 // the matcher's 1x1 layers as float32 fmaf chains on the matrix cores (csrc/linear_chain.hip; bitwise the vector-pipe kernels): true = shape served
 bool linear_chain(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);
+bool linear_chain_cat3(const float *x, const float *table, const int64_t *idx, const float *conf, int m, int k, const float *W, const float *b, int Cout,
+                       float *y, hipStream_t s);
 bool linear_tail_chain(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,
                        int mult, hipStream_t s);
 // the matcher's 1x1 layers on the matrix cores (csrc/linear_mfma.hip): true = shape served, launch issued

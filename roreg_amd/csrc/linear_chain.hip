@@ -29,11 +29,17 @@ __device__ __forceinline__ int lc_seg_of(const int *__restrict__ off, int n_seg,
 
 constexpr int LC_ROWS = 128;               // rows per workgroup tile: 4 wavefronts x 32
 
+// CAT3: the input row is never materialised -- row r = [x[r] (32) | table[idx[r]] (32) | conf[r / k] (32)], the value MLP's input of the attention
+// blocks (rot_coh_match.py:95-119: positional encoding, normalised neighbour feature, the point's own confidence): the staging reads the three
+// sources; the chains see the same 96 values in the same order
+struct Cat3 { const float *table; const int64_t *idx; const float *conf; int k; };
+
 // LDS: weights [COUT / 32][KP / 2][64 lanes] floats (lane l of step j: W[32 nt + l % 32][2 j + l / 32]) + rows [128][KP + 1] floats
-template <int CIN, int COUT, bool NORM, bool ACCUM>
+template <int CIN, int COUT, bool NORM, bool ACCUM, bool CAT3 = false>
 __global__ __launch_bounds__(256) void linear_chain_kernel(const float *__restrict__ x, int L, const float *__restrict__ W, const float *__restrict__ b,
                                                            const float *__restrict__ mean_rstd, float *__restrict__ y, const int *__restrict__ seg_off,
-                                                           int n_seg, int mult, int tiles) {
+                                                           int n_seg, int mult, int tiles, Cat3 cat) {
+    static_assert(!CAT3 || (CIN == 96 && !NORM), "CAT3: three 32-wide sources");
     static_assert(COUT % 32 == 0, "linear_chain_kernel: outputs in tiles of 32");
     constexpr int KP = (CIN + 1) & ~1, KS = KP / 2, NT = COUT / 32, PITCH = KP + 1;
     extern __shared__ __attribute__((aligned(16))) char lc_smem[];
@@ -60,7 +66,14 @@ __global__ __launch_bounds__(256) void linear_chain_kernel(const float *__restri
             for (int f = tid; f < LC_ROWS * C4; f += 256) {
                 const int row = f / C4, c4 = f - row * C4;
                 const int pr = min(p0 + row, L - 1);
-                float4 v = *reinterpret_cast<const float4 *>(x + (size_t)pr * CIN + c4 * 4);
+                float4 v;
+                if constexpr (CAT3) {
+                    const int c = c4 * 4;
+                    const float *src = c < 32 ? x + (size_t)pr * 32 + c : c < 64 ? cat.table + (size_t)cat.idx[pr] * 32 + (c - 32) : cat.conf + (size_t)(pr / cat.k) * 32 + (c - 64);
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    v = *reinterpret_cast<const float4 *>(x + (size_t)pr * CIN + c4 * 4);
+                }
                 if (NORM) {
                     const float *mr = mean_rstd + (seg_off ? (size_t)s_seg[row] * 2 * CIN : 0);
                     const int c = c4 * 4;
@@ -117,19 +130,19 @@ __global__ __launch_bounds__(256) void linear_chain_kernel(const float *__restri
     }
 }
 
-template <int CIN, int COUT, bool NORM, bool ACCUM>
+template <int CIN, int COUT, bool NORM, bool ACCUM, bool CAT3 = false>
 void launch_chain(const float *x, int L, const float *W, const float *b, const float *mean_rstd, float *y, const int *seg_off, int n_seg, int mult,
-                  hipStream_t s) {
+                  hipStream_t s, Cat3 cat = Cat3{nullptr, nullptr, nullptr, 1}) {
     constexpr int KP = (CIN + 1) & ~1;
     constexpr size_t smem = ((size_t)(COUT / 32) * (KP / 2) * 64 + (size_t)LC_ROWS * (KP + 1)) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(linear_chain_kernel<CIN, COUT, NORM, ACCUM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(linear_chain_kernel<CIN, COUT, NORM, ACCUM, CAT3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = true;
     }
     const int tiles = (L + LC_ROWS - 1) / LC_ROWS;
     const int grid = tiles < 1024 ? tiles : 1024;                       // (a workgroup stages the weights once and walks its tiles)
-    hipLaunchKernelGGL((linear_chain_kernel<CIN, COUT, NORM, ACCUM>), dim3(grid), dim3(256), smem, s, x, L, W, b, mean_rstd, y, seg_off, n_seg, mult, tiles);
+    hipLaunchKernelGGL((linear_chain_kernel<CIN, COUT, NORM, ACCUM, CAT3>), dim3(grid), dim3(256), smem, s, x, L, W, b, mean_rstd, y, seg_off, n_seg, mult, tiles, cat);
 }
 
 }  // namespace
@@ -141,6 +154,15 @@ bool linear_chain(const float *x, int L, int Cin, const float *W, const float *b
 #define LC(CI, CO) if (Cin == CI && Cout == CO) { launch_chain<CI, CO, false, false>(x, L, W, b, nullptr, y, nullptr, 1, 1, s); return true; }
     LC(32, 32) LC(96, 64) LC(120, 128) LC(64, 64) LC(96, 32) LC(120, 32) LC(64, 32) LC(3, 64) LC(3, 32)
 #undef LC
+    return false;
+}
+
+// y [m * k, Cout] = W [x[r] | table[idx[r]] | conf[r / k]] + b, Cout = 64 | 32
+bool linear_chain_cat3(const float *x, const float *table, const int64_t *idx, const float *conf, int m, int k, const float *W, const float *b, int Cout,
+                       float *y, hipStream_t s) {
+    const Cat3 cat = {table, idx, conf, k};
+    if (Cout == 64) { launch_chain<96, 64, false, false, true>(x, m * k, W, b, nullptr, y, nullptr, 1, 1, s, cat); return true; }
+    if (Cout == 32) { launch_chain<96, 32, false, false, true>(x, m * k, W, b, nullptr, y, nullptr, 1, 1, s, cat); return true; }
     return false;
 }
 

@@ -1044,6 +1044,21 @@ extern "C" int roreg_linear_path(int path) {
     return prev;
 }
 
+// The value MLP's first layers without their materialised input: row r of [m * k, 96] = [pos[r] | table[idx[r]] | conf[r / k]] is assembled while
+// the kernel stages its rows (value_input_kernel + two reads of its 96-float rows leave the matcher's trace).  Matrix-core path only.
+extern "C" int roreg_linear_cat3(const float *pos, const float *table, const int64_t *idx, const float *conf, int m, int k, const float *W, const float *b,
+                                 int Cout, float *y, void *stream) {
+    ROREG_REQUIRE(pos && table && idx && conf && W && b && y && m > 0 && k > 0, "roreg_linear_cat3: bad arguments");
+    ROREG_REQUIRE((long long)m * k < (1ll << 31), "roreg_linear_cat3: %d x %d rows", m, k);
+    ROREG_REQUIRE(g_linear_path == 0, "roreg_linear_cat3: the vector-pipe path has no fused form (materialise the rows and call roreg_linear)");
+    if (!roreg::linear_chain_cat3(pos, table, idx, conf, m, k, W, b, Cout, y, roreg::as_stream(stream))) {
+        roreg::set_error("roreg_linear_cat3: Cout = %d not served (64 | 32)", Cout);
+        return 2;
+    }
+    ROREG_CHECK_LAUNCH("roreg_linear_cat3");
+    return 0;
+}
+
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);

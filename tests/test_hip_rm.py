@@ -227,6 +227,33 @@ def test_fmaf_chains_on_the_matrix_cores_are_bitwise_the_vector_pipe_chains(cin,
             assert torch.equal(y, want), (cin, mult)
 
 
+@pytest.mark.parametrize('m,k', [(1, 16), (777, 16), (5000, 8), (40001, 16)])
+def test_value_rows_assembled_in_the_layer_are_bitwise_the_materialised_rows(m, k, rm):
+    """hip.value_input() no longer builds the attention blocks' [m k, 96] value-MLP input (rot_coh_match.py:95-119): linear() gets the three sources
+    and roreg_linear_cat3 assembles a row while it stages it.  Both first layers (96 -> 64, 96 -> 32) and the whole mlp_2layer BITWISE those on
+    the materialised rows -- ragged row counts, neighbour indices with repeats -- and the vector-pipe path (which materialises) agrees too."""
+    from roreg_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(7 * m + k)
+    n = max(m, 3)
+    pos = torch.randn((m * k, 32), device='cuda', generator=g); table = torch.randn((n, 32), device='cuda', generator=g)
+    conf = torch.randn((m, 32), device='cuda', generator=g)
+    idx = torch.randint(0, n, (m, k), device='cuda', generator=g)
+    rows = hip.value_input(pos, table, conf, idx)
+    full = hip.value_input(pos, table, conf, idx, materialise=True)
+    want = torch.cat([pos, table[idx.reshape(-1)], conf.repeat_interleave(k, 0)], 1)
+    assert torch.equal(full, want)
+    for cout in (64, 32):
+        W = torch.randn((cout, 96), device='cuda', generator=g) * 0.3; b = torch.randn(cout, device='cuda', generator=g)
+        assert torch.equal(hip.linear(rows, W, b), hip.linear(full, W, b))
+    W1 = torch.randn((64, 96), device='cuda', generator=g) * 0.2; b1 = torch.randn(64, device='cuda', generator=g)
+    W2 = torch.randn((32, 64), device='cuda', generator=g) * 0.2; b2 = torch.randn(32, device='cuda', generator=g)
+    Wr = torch.randn((32, 96), device='cuda', generator=g) * 0.2; br = torch.randn(32, device='cuda', generator=g)
+    y = hip.mlp_instnorm(hip.value_input(pos, table, conf, idx), W1, b1, W2, b2, Wr, br)
+    assert torch.equal(y, hip.mlp_instnorm(full, W1, b1, W2, b2, Wr, br))
+    with hip.vector_pipe_layers():
+        assert torch.equal(y, hip.mlp_instnorm(hip.value_input(pos, table, conf, idx), W1, b1, W2, b2, Wr, br))
+
+
 def test_mlp_tail_on_the_matrix_cores(rm):
     """mlp_2layer (conv -> InstanceNorm -> ReLU -> conv + residual conv; rot_coh_match.py:14-32) with the shipped final_mlp weights against
     a float64 torch evaluation of the same formula."""
