@@ -1,5 +1,10 @@
 """Timeline of a workgroup's life in the big GEMM launch (debug stamps, wall clock 100 MHz): per tile the phases
-prologue / loop / epilogue / tail, and per CU the gap between one workgroup's end and the next one's start."""
+prologue / loop / epilogue / tail, and per CU the gap between one workgroup's end and the next one's start.
+NEEDS AN INSTRUMENTED BUILD (not in the tree): GemmSplitDescs gets `unsigned long long *trace` (set through a debug entry
+roreg_gemm_trace_dbg(void *)), and thread 0 of a workgroup writes wall_clock64() into trace[slot * 8 + i] -- slot = blockIdx.x (per-tile launch)
+or blockIdx.x * 160 + tile (persistent launch); i = 0 kernel / tile start, 1 loop start, 2 loop end, 3 epilogue end, 4 after s_waitcnt vmcnt(0)
+(per-tile launch), 5 / 6 begin / end of the epilogue passes (persistent), 7 = nss << 48 | HW_REG_XCC_ID << 32 | HW_REG_HW_ID.  The output of the
+round-5 run is profiles/r05_gemm_tile_timeline.txt."""
 import os, sys, ctypes
 sys.path.insert(0, '.')
 import numpy as np, torch

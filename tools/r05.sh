@@ -3,6 +3,7 @@
 #   tests "<pytest -k expr>" [file]   -> gpurun_out/r05/pytest_<tag>.log
 #   ot5000                            -> Sinkhorn at 5000 x 5000: cooperating workgroups vs the two-pass form (timing + kernel trace)
 #   bench [tag] [extra args]          -> the driver's bench command
+#   gemmab                            -> the big GEMM launched per tile vs as persistent workgroups (bitwise? ms per launch), store-rate probe
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/r05; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -101,5 +102,9 @@ print('forced', f['value'], f['config']['forced_collectives'], f['config']['eqv_
 print('shared3', k['n_gpus'], k['value'], k['config']['eqv_transfers_per_step'], k['config']['cloud_extractions_per_rank'], k['accuracy'] == j['accuracy'])
 PY
   ;;
+gemmab)
+  timeout 600 python tools/gemm_persist_ab.py 3 2>&1 | grep -v amdgpu.ids
+  echo "--- zero operands"; ROREG_AB_ZEROS=1 timeout 600 python tools/gemm_persist_ab.py 2 2>&1 | grep "B=61440"
+  hipcc --offload-arch=gfx950 -O3 tools/probe/store_rate.hip -o /tmp/store_rate 2>/dev/null && timeout 120 /tmp/store_rate ;;
 *) echo "unknown command $cmd"; exit 2 ;;
 esac
