@@ -2148,7 +2148,7 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
                                   : (big ? irrep_gemm_xdma16p_kernel<1, 2> : irrep_gemm_xdma16p_kernel<0, 2>);
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
                 if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
-                const int wgs = std::min(n_tiles, gemm_cu_count() / 8 * 8);      // one workgroup per CU (each needs the whole LDS); n_tiles is a multiple of 8
+                const int wgs = std::min(n_tiles, std::max(8, gemm_cu_count() / 8 * 8));      // one workgroup per CU (each needs the whole LDS), a multiple of 8 like n_tiles
                 hipLaunchKernelGGL(kp, dim3(wgs), dim3(512), lds_use, roreg::as_stream(stream), p, tiles_dev, n_tiles / 8);
             } else {
                 hipLaunchKernelGGL(kx, dim3(n_tiles), dim3(512), lds_use, roreg::as_stream(stream), p, tiles_dev);
