@@ -53,6 +53,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         hip.lib()
 
 
+def test_round5_entry_points_validate_before_they_touch_the_gpu():
+    """The v5 additions refuse bad arguments with a message (no HIP call has happened: this runs on a CPU-only box), and the two run-time
+    switches report and restore their setting."""
+    from roreg_amd import hip
+    L = hip.lib()
+    assert L.roreg_linear_cat3(None, None, None, None, 10, 16, None, None, 64, None, None) != 0
+    assert b'roreg_linear_cat3' in L.roreg_last_error()
+    assert L.roreg_ft_nonlin_packed(None, None, None, None, None, None, 60, 60, 0, 32, None, None, 0, None) != 0
+    assert b'roreg_ft_nonlin_packed' in L.roreg_last_error()
+    for switch in (L.roreg_gemm_persistent, L.roreg_linear_path):
+        was = switch(-1)
+        assert was in (0, 1) and switch(1 - was) == was and switch(-1) == 1 - was
+        assert switch(was) == 1 - was and switch(-1) == was
+        assert switch(7) == was and switch(-1) == was                          # anything but 0 / 1 is a query
+
+
 def test_host_tensor_is_rejected_not_computed_on_cpu():
     import torch
     from roreg_amd import hip
