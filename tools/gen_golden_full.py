@@ -4,7 +4,7 @@ Same rules as tools/gen_golden.py (build container only; the reference is import
 vectors are written).  The INPUTS of every case are rebuilt from a seed by roreg_amd/synth.py (portable arithmetic only), so the
 fixtures hold just the reference's small outputs: index lists, packed inlier masks, transforms and strided samples of the big tensors.
 
-    python tools/gen_golden_full.py [stages] [ransac] [ransac_ties] [match_ot] [pipeline] [pipeline_rd_rm] [pipeline_rd_rm_o60] [pipeline_rd_rm_o60_s1..3] [pipeline_rd_rm_k5000] [match_ot_5000] [yohoc] [rd]        (no argument = all; ~10 minutes on 8 cores)
+    python tools/gen_golden_full.py [stages] [ransac] [ransac_ties] [match_ot] [pipeline] [pipeline_rd_rm] [pipeline_rd_rm_o60] [pipeline_rd_rm_o60_s1..3] [pipeline_rd_rm_k5000] [match_ot_5000] [match_ot_3000x1000] [match_ot_1200x4000] [yohoc] [rd]        (no argument = all; ~10 minutes on 8 cores)
 """
 import os
 import shutil
@@ -93,7 +93,7 @@ def gen_ransac_ties():
          best_of_float64_accumulation=np.int64(best64), refine1=r1, refine2=r2)
 
 
-def gen_match_ot(n=2500, tag='full_match_ot', seed=OT_SEED):
+def gen_match_ot(n=2500, tag='full_match_ot', seed=OT_SEED, m_src=None, n_tgt=None):
     """`Match_ot.forward` of the reference with the shipped RM weights (network/rot_coh_match.py:339-390).  n = 2500 is yoho_mat's default
     keynum; n = 5000 (`full_match_ot_5000`) is what `Test.py --RM --keynum 5000` hands it (test/evaluator.py:20,46 -> test/matcher.py:152-185)."""
     cfg = gg.make_cfg(tempfile.mkdtemp(prefix='golden_full_cfg_'))
@@ -104,6 +104,8 @@ def gen_match_ot(n=2500, tag='full_match_ot', seed=OT_SEED):
     f0 = ds.feats[0]; f1 = ds.feats[1]
     f0 = f0 / np.sqrt((f0 * f0).sum(1, keepdims=True)); f1 = f1 / np.sqrt((f1 * f1).sum(1, keepdims=True))
     k0 = ds.get_kps('0').astype(np.float32); k1 = ds.get_kps('1').astype(np.float32)
+    if m_src is not None:             # a ragged pair: the first m_src points of the source side against the first n_tgt of the target side
+        f1, k1, f0, k0 = f1[:m_src], k1[:m_src], f0[:n_tgt], k0[:n_tgt]
     batch = {'feats0': torch.from_numpy(f1[None].copy()), 'feats1': torch.from_numpy(f0[None].copy()),
              'keys0': torch.from_numpy(k1[None].copy()), 'keys1': torch.from_numpy(k0[None].copy())}
     with torch.no_grad():
@@ -111,7 +113,7 @@ def gen_match_ot(n=2500, tag='full_match_ot', seed=OT_SEED):
     m0 = r['matches0'][0].numpy(); m1 = r['matches1'][0].numpy()
     print('   valid matches', int((m0 >= 0).sum()))
     Z = r['scores'][0].numpy()
-    save(tag, scene_seed=np.int64(seed), n=np.int64(n), matches0=_i16(m0), matches1=_i16(m1),
+    save(tag, scene_seed=np.int64(seed), n=np.int64(n), m_src=np.int64(f1.shape[0]), n_tgt=np.int64(f0.shape[0]), matches0=_i16(m0), matches1=_i16(m1),
          matching_scores0=r['matching_scores0'][0].numpy(), matching_scores1=r['matching_scores1'][0].numpy(),
          scores_sample=Z[::40, ::40].copy(), scores_lastrow=Z[-1, ::10].copy(), scores_lastcol=Z[::10, -1].copy(),
          source_final_sample=r['source_final'][0, :, ::25, 0].numpy(), target_final_sample=r['target_final'][0, :, ::25, 0].numpy())
@@ -236,7 +238,7 @@ def gen_rd():
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'pipeline_rd_rm', 'pipeline_rd_rm_o60', 'pipeline_rd_rm_o60_s1', 'pipeline_rd_rm_o60_s2', 'pipeline_rd_rm_o60_s3', 'pipeline_rd_rm_k5000', 'match_ot_5000', 'yohoc', 'rd']
+    todo = sys.argv[1:] or ['ransac', 'ransac_ties', 'stages', 'match_ot', 'pipeline', 'pipeline_rd_rm', 'pipeline_rd_rm_o60', 'pipeline_rd_rm_o60_s1', 'pipeline_rd_rm_o60_s2', 'pipeline_rd_rm_o60_s3', 'pipeline_rd_rm_k5000', 'match_ot_5000', 'match_ot_3000x1000', 'match_ot_1200x4000', 'yohoc', 'rd']
     for name in todo:
         print(name)
         {'stages': gen_stages, 'ransac': gen_ransac, 'ransac_ties': gen_ransac_ties, 'match_ot': gen_match_ot, 'pipeline': gen_pipeline, 'pipeline_rd_rm': gen_pipeline_rd_rm, 'pipeline_rd_rm_o60': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60', 0.6, PIPE_SEED + 8),
@@ -244,4 +246,6 @@ if __name__ == '__main__':
          'pipeline_rd_rm_o60_s2': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60_s2', 0.6, PIPE_SEED + 22),
          'pipeline_rd_rm_o60_s3': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_o60_s3', 0.6, PIPE_SEED + 23),
          'pipeline_rd_rm_k5000': lambda: gen_pipeline_rd_rm('full_pipeline_rd_rm_k5000', 0.6, PIPE_SEED + 9, keynum=5000),
-         'match_ot_5000': lambda: gen_match_ot(5000, 'full_match_ot_5000', OT_SEED + 1), 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
+         'match_ot_5000': lambda: gen_match_ot(5000, 'full_match_ot_5000', OT_SEED + 1),
+         'match_ot_3000x1000': lambda: gen_match_ot(3000, 'full_match_ot_3000x1000', OT_SEED + 2, 3000, 1000),
+         'match_ot_1200x4000': lambda: gen_match_ot(4000, 'full_match_ot_1200x4000', OT_SEED + 3, 1200, 4000), 'yohoc': gen_yohoc, 'rd': gen_rd}[name]()
