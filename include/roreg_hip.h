@@ -502,10 +502,11 @@ int roreg_irrep_gemm_f16x2(const float *const *X, float *const *Out, const float
                            activations then reach LDS by LDS-DMA and the matrix cores through transposing LDS reads, no register staging
                            (needs tile_m = 256); x_planes = 1: 32x32x16 MFMAs, results bitwise those of the word layout; x_planes = 2 (round 4): the same
                            operands and LDS images under v_mfma_f32_16x16x32_f16 (K = 32 per step: ~4 % faster, the same error bound, last bits differ) */, void *stream);
-/* v5: how the x_planes = 2 kernel is launched.  0: one workgroup per 256 x 256 tile (round 4).  1: PERSISTENT workgroups, one per CU, that claim
- * tiles from the list's per-XCD streams and request the next tile's first operand stages before they store the finished one
- * (irrep_gemm_xdma16p_kernel, csrc/fourier.hip); the same MFMA sequence per output element: bitwise the same results.  -1: query.
- * Returns the previous setting; the initial one is the environment's ROREG_GEMM_PERSIST (unset = DEFAULT). */
+/* v5: how the x_planes = 2 kernel is launched.  0: one 8-wave workgroup per 256 x 256 tile (round 4).  1: PERSISTENT workgroups, one per CU, that walk
+ * the list's per-XCD streams and request the next tile's first operand stages before they store the finished one (irrep_gemm_xdma16p_kernel,
+ * csrc/fourier.hip).  2: 4-wave workgroups on 256 x 128 HALF tiles in 80 KB of LDS, two per CU, so that one's prologue and epilogue run under the
+ * other's loop (irrep_gemm_xdma16h_kernel).  The same MFMA sequence per output element in all three: bitwise the same results.  Other values:
+ * query.  Returns the previous setting; the initial one is the environment's ROREG_GEMM_PERSIST (unset = the default). */
 int roreg_gemm_persistent(int on);
 /* bound_out[b] (b < round_up(B,32); 0 for pad keypoints) = sqrt(60) max_{c,g} |act(x[b,c,g])| >= every coefficient of FT(act(x[b])), act =
  * ReLU(bn_scale_c x + bn_shift_c) or the identity (bn NULL): the x_bound of a layer whose input is a group-domain tensor [B,C,60]. */

@@ -106,7 +106,7 @@ class gemm_persistent:
     workgroups that claim tiles, or one workgroup per tile.  Same bits either way -- tests and A/B measurements."""
 
     def __init__(self, on=True):
-        self.on = 1 if on else 0
+        self.on = int(on)                                     # 0 / False: one workgroup per tile; 1 / True: persistent; 2: half tiles, two workgroups per CU
 
     def __enter__(self):
         self.prev = lib().roreg_gemm_persistent(self.on)

@@ -815,9 +815,10 @@ __device__ __forceinline__ void gemm_split_epilogue16_scales(const GemmSplitDesc
 #pragma unroll
     for (int i = 0; i < 4; ++i) e.osc[i] = col_ok ? ldexpf(1.f, -(bound_exp(e.osc[i]) + p.w_exp)) : 1.f;
 }
+template <int NT = 512, int NCOL = 256>      // threads per workgroup, columns of its tile (256 x 256 with eight waves; 256 x 128 with four: wb = 0)
 __device__ __forceinline__ void gemm_split_epilogue16(const GemmSplitDescs &p, int irr, int mt, int n0, int wo, int wb, f32x4_t (&acc)[4][8], char *smem,
                                                       const Epi16Pre &pre) {
-    constexpr int NCOL = 256, OT = 256, NT = 512, P = 192;      // P: row pitch of a wave's LDS tile in floats (a multiple of the 64 banks: the row's bank shift is rowpad alone)
+    constexpr int OT = 256, P = 192;                            // P: row pitch of a wave's LDS tile in floats (a multiple of the 64 banks: the row's bank shift is rowpad alone)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int M = p.M[irr], N = p.N[irr];
@@ -1074,6 +1075,163 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
 #undef ROREG_PIN_B
     gemm_split_epilogue16_scales(p, pre, n0 + wb * 128 + 4 * (lane & 31) < N);
     gemm_split_epilogue16(p, irr, mt, n0, wo, wb, acc, smem, pre);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// irrep_gemm_xdma16_kernel on HALF tiles, two workgroups per CU (round 5).  The timeline of that kernel (profiles/r05_gemm_tile_timeline.txt)
+// shows 12 us of a ~100 us tile -- dispatch, the first stages' trip from HBM, the epilogue's stores -- with the matrix pipes idle, because its one
+// workgroup owns the CU.  Here a workgroup is FOUR waves (one per SIMD) on a 256 x 128 tile in 80 KB of LDS, so two of them share a CU and one's
+// ends run under the other's loop.  Per wave nothing changes: 64 rows x 128 columns, the same fragments, the same 96 MFMAs per K32 step in the
+// same order -- results bitwise those of the 256 x 256 kernel.  What changes:
+//   * activations: a K16 stage is 128 columns (8 KB), six stages as before (48 KB);
+//   * weights: ONE K32 buffer (two K16 stages, 32 KB) instead of a ring of two: step S + 1's weights are requested at the start of step S into the
+//     buffer whose fragments (step S) every wave read at the end of step S - 1, land under step S (they come from L2), and are read into registers
+//     under the last column block; that takes a second barrier per step (at its start: everyone's fragment reads of the previous step's end are
+//     done) -- of four waves instead of eight;
+//   * the 256-row weight slice is fetched by both halves of a 256 x 256 tile (L2 -> LDS traffic of the weights doubles); in exchange an XCD holds 64
+//     tiles = one whole 8 x 8 block of the work list at a time (16 operand streams for 64 tiles instead of 12 for 32);
+//   * workgroup b -> entry (b / 16) * 8 + b % 8 of the list, column half (b / 8) % 2: both halves on the XCD of the entry's stream.
+template <int BIG>
+__global__ __launch_bounds__(256, 2) void irrep_gemm_xdma16h_kernel(GemmSplitDescs p, const int *__restrict__ tiles) {
+    using frag = f16x8;
+    using f32x4 = f32x4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCOL = 128, OT = 256, NPAN = NCOL / 16;
+    constexpr int XIMG = 16 * NCOL * 2, XSTAGE = 2 * XIMG;       // bytes: one plane's K16 x 128 image (4 KB); both planes
+    constexpr int ABUF = 2 * 2 * OT;                             // weight fragments per K16 stage
+    constexpr int NXS = 6;
+    char *xs = smem;                                             // [6 stages][2 planes][XIMG]
+    frag *as = reinterpret_cast<frag *>(smem + NXS * XSTAGE);    // [2 K16 stages][2 planes][2 k-octets][256 m]: one K32 step
+    const int tid = threadIdx.x, lane = tid & 63, wo = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int entry = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), half_n = (blockIdx.x >> 3) & 1;
+    const int irr = tiles[entry * 3], mt = tiles[entry * 3 + 1], nt = tiles[entry * 3 + 2];
+    if (irr < 0) return;
+    const frag *__restrict__ W = reinterpret_cast<const frag *>(p.W[irr]);
+    const int K = p.K[irr], Mpad = p.Mpad[irr], N = p.N[irr];
+    const int n0 = nt * 256 + half_n * NCOL;
+    if (n0 >= N) return;                                         // (the right half of a ragged last column tile may be empty)
+    const size_t split_stride = (size_t)(K / 16) * 2 * Mpad;     // in 16-byte fragments
+    const int nsteps = K / 16, nss = K / 32;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- activation DMA: per K16 stage and plane 256 pieces of 16 bytes; wave wo issues pieces (2 wo + i2) % 4 * 64 + lane of plane wo / 2 ----
+    const int x_plane = wo >> 1;
+    const char *xsrc[2];
+    int xdst[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int mm = (2 * wo + i2) & 3;
+        const int pi = mm * 64 + lane;                           // piece inside the plane's image: 128-byte block beta = pi / 8 = k quad * 8 + panel
+        const int beta = pi >> 3, r = (pi & 7) >> 1, half = pi & 1;
+        const int k = 4 * (beta >> 3) + r;
+        // (k quads 2 and 3 hold panel P at block position P ^ 1, as in the 256-column image: the 16-lane groups q and q + 1 of a fragment read
+        //  touch k quads 0 and 2 of the same panel, 2 KB apart = the same banks)
+        int col = n0 + 16 * ((beta & 7) ^ ((beta >> 4) & 1)) + 8 * half;
+        if (col > N - 8) col = N - 8;
+        xsrc[i2] = reinterpret_cast<const char *>(p.X[irr]) + (size_t)k * N * 4 + (col >> 5) * 128 + x_plane * 64 + (col & 31) * 2;
+        xdst[i2] = x_plane * XIMG + mm * 1024;
+    }
+    const size_t xstep = (size_t)16 * N * 4;
+    auto dma_x = [&](int i2, int kstep) {
+        const char *src = xsrc[i2] + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * xstep;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(xs + (kstep % NXS) * XSTAGE + xdst[i2]), 16, 0, 0);
+    };
+    // ---- weight DMA: per K16 stage [2 planes][2 k-octets][256 m]; a thread fetches row m = tid of both octets of both planes ----
+    const frag *wsrc0 = W + mt * OT + tid, *wsrc1 = W + (size_t)Mpad + mt * OT + (tid ^ 8);      // (octet 1: row m at slot m ^ 8, as in the other kernel)
+    auto dma_w = [&](int sp, int oct, int kstep) {
+        const frag *src = (oct ? wsrc1 : wsrc0) + (size_t)(kstep < nsteps ? kstep : nsteps - 1) * 2 * Mpad;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + sp * split_stride),
+                                         (__attribute__((address_space(3))) void *)(as + (kstep & 1) * ABUF + sp * (2 * OT) + oct * OT + wo * 64), 16, 0, 0);
+    };
+    // ---- fragment addresses ----
+    const int a_lane = (q >> 1) * ABUF + (q & 1) * OT + wo * 64 + (j ^ (8 * (q & 1)));      // + plane * 2 * OT + rb * 16
+    const unsigned x_lane = (unsigned)(uintptr_t)xs + (unsigned)((q >> 1) * XSTAGE + ((2 * (q & 1)) * NPAN) * 128 + j * 8);      // + (S % 3) * 2 * XSTAGE + plane * XIMG + cb * 128 (+ NPAN * 128)
+    const unsigned x_swap = (q & 1) ? 128u : 0u;
+    frag aA[4][2], aB[4][2];
+    frag b0[2], b1[2];
+    auto read_a = [&](auto rb_c, auto pl_c, frag (&a)[4][2]) {
+        constexpr int rb = decltype(rb_c)::value, pl = decltype(pl_c)::value;
+        a[rb][pl] = as[a_lane + pl * (2 * OT) + rb * 16];
+    };
+    auto read_b = [&](unsigned xoff, auto cb_c, frag (&b)[2]) {
+        constexpr int cb = decltype(cb_c)::value;
+        const unsigned a = (cb & 1) ? x_lane + xoff - x_swap : x_lane + xoff + x_swap;
+        unsigned long long u[4];
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[0]) : "v"(a), "n"(cb * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[1]) : "v"(a), "n"(cb * 128 + NPAN * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[2]) : "v"(a), "n"(XIMG + cb * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u[3]) : "v"(a), "n"(XIMG + cb * 128 + NPAN * 128));
+        struct Pair { unsigned long long lo, hi; };
+        b[0] = __builtin_bit_cast(frag, Pair{u[0], u[1]});
+        b[1] = __builtin_bit_cast(frag, Pair{u[2], u[3]});
+    };
+#define ROREG_PIN_B(waits, B) asm volatile(waits : "+v"(B[0]), "+v"(B[1]) :: "memory")
+    using std::integral_constant;
+    // One K32 step S.  a = this step's weight fragments (registers); an receives step S + 1's.
+    //   * column block 0 opens with the step's FIRST barrier, behind lgkmcnt(0): every wave has read step S's weight fragments (requested under
+    //     the previous step's last block) and its own first activation fragments -- the weight buffer may be overwritten: column blocks 0-3
+    //     request step S + 1's weights (two pieces each), column blocks 4-7 the ACTIVATIONS of step S + 2 into the stages of step S - 1;
+    //   * the SECOND barrier sits in front of column block 7, behind s_waitcnt vmcnt(3) lgkmcnt(0): in issue order only the activation pieces
+    //     of blocks 4-6 may be in flight, so step S + 1's weights (and its activations, requested a step ago) have landed for everyone, and
+    //     every read of this step's activation stages is done;
+    //   * behind it block 7 reads step S + 1's eight weight fragments and its first column block's activation fragments.
+    auto step = [&](int S, const frag (&a)[4][2], frag (&an)[4][2]) {
+        const unsigned xoff = (unsigned)((S % 3) * 2 * XSTAGE), xoff_next = (unsigned)(((S + 1) % 3) * 2 * XSTAGE);
+        static_for<8>([&](auto cb_c) {
+            constexpr int cb = decltype(cb_c)::value;
+            frag (&bc)[2] = (cb & 1) ? b1 : b0;
+            frag (&bn)[2] = (cb & 1) ? b0 : b1;
+            if constexpr (cb == 7) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (cb == 0) ROREG_PIN_B("s_waitcnt lgkmcnt(0)\n\ts_barrier", bc);
+            else ROREG_PIN_B("s_waitcnt lgkmcnt(0)", bc);
+            auto mm = [&](int i) {                                                     // product i of the four row blocks: 0 = lo.hi, 1 = hi.lo, 2 = hi.hi
+                const frag bb = bc[i == 1 ? 1 : 0];
+                const int ai = i == 0 ? 1 : 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rb][ai], bb, acc[rb][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (cb < 7) read_b(xoff, integral_constant<int, cb + 1>{}, bn);
+            else {
+                read_b(xoff_next, integral_constant<int, 0>{}, bn);
+                static_for<8>([&](auto c) { read_a(integral_constant<int, decltype(c)::value / 2>{}, integral_constant<int, decltype(c)::value % 2>{}, an); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0);
+            if constexpr (cb < 4) { dma_w(cb >> 1, cb & 1, 2 * (S + 1)); dma_w(cb >> 1, cb & 1, 2 * (S + 1) + 1); }
+            else dma_x(cb & 1, 2 * (S + 2) + ((cb - 4) >> 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1);
+            mm(2);
+        });
+    };
+    // ---- prologue: activations of steps 0 and 1 (K16 stages 0-3), weights of step 0; the scale / bound operands of the epilogue beside them ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { dma_w(0, 0, ks); dma_w(0, 1, ks); dma_w(1, 0, ks); dma_w(1, 1, ks); }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { dma_x(0, ks); dma_x(1, ks); }
+    Epi16Pre pre = gemm_split_epilogue16_request(p, irr, mt, n0, 0);
+#pragma unroll
+    for (int ks = 2; ks < 4; ++ks) { dma_x(0, ks); dma_x(1, ks); }
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");              // (stages 2, 3 of the activations land under step 0: its second barrier covers them)
+    static_for<8>([&](auto c) { read_a(integral_constant<int, decltype(c)::value / 2>{}, integral_constant<int, decltype(c)::value % 2>{}, aA); });
+    read_b(0u, integral_constant<int, 0>{}, b0);
+    for (int S = 0; S < nss; S += 2) {
+        step(S, aA, aB);
+        if (S + 1 < nss) step(S + 1, aB, aA);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the clamped look-ahead pieces still target LDS the epilogue reuses
+#undef ROREG_PIN_B
+    gemm_split_epilogue16_scales(p, pre, n0 + 4 * (lane & 31) < N);
+    gemm_split_epilogue16<256, NCOL>(p, irr, mt, n0, wo, 0, acc, smem, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2092,19 +2250,19 @@ extern "C" int roreg_irrep_gemm(const float *const *X, float *const *Out, const 
 
 // ---- the persistent GEMM's host side: switch, CU count ----
 #define ROREG_GEMM_PERSIST_DEFAULT 0
-static std::atomic<int> g_gemm_persist{-1};                  // -1: not decided yet (environment at first use)
-static bool gemm_persistent() {
+static std::atomic<int> g_gemm_persist{-1};                  // -1: not decided yet (environment at first use); 0 per tile, 1 persistent, 2 half tiles
+static int gemm_launch_form() {
     int v = g_gemm_persist.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("ROREG_GEMM_PERSIST");
-        v = e ? (e[0] == '1') : ROREG_GEMM_PERSIST_DEFAULT;
+        v = e ? (e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0) : ROREG_GEMM_PERSIST_DEFAULT;
         g_gemm_persist.store(v, std::memory_order_relaxed);
     }
-    return v == 1;
+    return v;
 }
 extern "C" int roreg_gemm_persistent(int on) {
-    const int prev = gemm_persistent() ? 1 : 0;
-    if (on == 0 || on == 1) g_gemm_persist.store(on, std::memory_order_relaxed);
+    const int prev = gemm_launch_form();
+    if (on >= 0 && on <= 2) g_gemm_persist.store(on, std::memory_order_relaxed);
     return prev;
 }
 static int gemm_cu_count() {
@@ -2140,7 +2298,13 @@ static int launch_gemm_split(const char *what, const float *const *X, float *con
                              : ((long long)C * O == 256ll * 512 ? irrep_gemm_xdma_kernel<1> : irrep_gemm_xdma_kernel<0>);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
             if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
-            if (mfma16 && gemm_persistent()) {
+            if (mfma16 && gemm_launch_form() == 2) {
+                auto kh = (long long)C * O == 256ll * 512 ? irrep_gemm_xdma16h_kernel<1> : irrep_gemm_xdma16h_kernel<0>;
+                const size_t lds_h = (size_t)6 * 8192 + 2 * 16384;      // six 128-column activation stages + one K32 step of weights = 80 KB: two workgroups per CU
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+                if (e != hipSuccess) { roreg::set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return 1; }
+                hipLaunchKernelGGL(kh, dim3(2 * n_tiles), dim3(256), lds_h, roreg::as_stream(stream), p, tiles_dev);
+            } else if (mfma16 && gemm_launch_form() == 1) {
                 const bool big = (long long)C * O == 256ll * 512;
                 static const int ra = [] { const char *v = getenv("ROREG_GEMM_PERSIST_RA"); return v ? atoi(v) : 2; }();
                 auto kp = ra == 0 ? (big ? irrep_gemm_xdma16p_kernel<1, 0> : irrep_gemm_xdma16p_kernel<0, 0>)

@@ -319,10 +319,11 @@ def test_plane_layout_gemm_is_bitwise_the_word_layout_gemm(group, C, Oc, B):    
 
 @pytest.mark.parametrize('C,Oc,B,resid', [(256, 512, 20000, False), (512, 256, 19993, True), (32, 256, 9000, False)])
 def test_persistent_gemm_launch_is_bitwise_the_per_tile_launch(group, C, Oc, B, resid):
-    """hip.gemm_persistent(True): one workgroup per CU walks its share of the tile list (several tiles each at these sizes, tiles of all five
-    irreps, ragged last column tiles) and requests the next tile's operands while it stores the finished one -- coefficients and the
-    propagated bound bit for bit those of the launch with one workgroup per tile, with and without the residual; twice, so that a launch
-    also starts from whatever the previous one left in LDS."""
+    """The two other launch forms of the 16x16x32 GEMM -- hip.gemm_persistent(1): one workgroup per CU walks its share of the tile list (several
+    tiles each at these sizes, tiles of all five irreps, ragged last column tiles) and requests the next tile's operands while it stores the
+    finished one; (2): four-wave workgroups on 256 x 128 half tiles, two per CU, one K32 weight buffer and two barriers per step (a ragged last
+    column tile's right half may be empty) -- return coefficients and the propagated bound bit for bit those of the launch with one eight-wave
+    workgroup per tile, with and without the residual; twice each, so that a launch also starts from whatever the previous one left in LDS."""
     from roreg_amd import hip
     from roreg_amd.network.gf_fourier import _Layer
     torch.manual_seed(B)
@@ -334,10 +335,10 @@ def test_persistent_gemm_launch_is_bitwise_the_per_tile_launch(group, C, Oc, B, 
     nb = (torch.rand(Oc, device='cuda') + 0.5, torch.rand(Oc, device='cuda'))
     with hip.gemm_persistent(False):
         T0, b0 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb, next_bound=nb, x_planes=2, add=add)
-    for _ in range(2):
-        with hip.gemm_persistent(True):
+    for form in (1, 2, 1, 2):                                 # 1: persistent workgroups; 2: half tiles (256 x 128), two 4-wave workgroups per CU
+        with hip.gemm_persistent(form):
             T1, b1 = hip.irrep_gemm(Xp, None, C, Oc, B, f16x2=L.wsplit2, x_bound=xb, next_bound=nb, x_planes=2, add=add)
-        assert torch.equal(T0.view(torch.int32), T1.view(torch.int32)) and torch.equal(b0.view(torch.int32), b1.view(torch.int32))
+        assert torch.equal(T0.view(torch.int32), T1.view(torch.int32)) and torch.equal(b0.view(torch.int32), b1.view(torch.int32)), form
 
 
 def test_gemm_bound_propagation(group):

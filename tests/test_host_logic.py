@@ -66,7 +66,8 @@ def test_round5_entry_points_validate_before_they_touch_the_gpu():
         was = switch(-1)
         assert was in (0, 1) and switch(1 - was) == was and switch(-1) == 1 - was
         assert switch(was) == 1 - was and switch(-1) == was
-        assert switch(7) == was and switch(-1) == was                          # anything but 0 / 1 is a query
+        assert switch(7) == was and switch(-1) == was                          # anything else is a query
+    assert L.roreg_gemm_persistent(2) == 0 and L.roreg_gemm_persistent(0) == 2 and L.roreg_gemm_persistent(-1) == 0      # (the GEMM has a third form)
 
 
 def test_host_tensor_is_rejected_not_computed_on_cpu():

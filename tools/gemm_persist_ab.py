@@ -1,4 +1,5 @@
-"""The 16x16x32 LDS-DMA irrep GEMM launched as persistent workgroups vs one workgroup per tile (hip.gemm_persistent): results bitwise
+"""The 16x16x32 LDS-DMA irrep GEMM in its three launch forms (hip.gemm_persistent: 0 one workgroup per tile "t", 1 persistent "P", 2 half tiles with two
+workgroups per CU "H"; FORMS=0,2 selects): results bitwise
 equal?  ms per launch, alternating, on random operands -- the big layers of the extractor (256 -> 512 plain; 512 -> 256 with the residual
 and the bound of the next transform), a 61440-keypoint batch and two smaller ones (ragged last tiles).
 Usage: python tools/gemm_persist_ab.py [reps]"""
@@ -9,6 +10,7 @@ from roreg_amd import hip
 from roreg_amd.network.gf_fourier import _Layer
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+FORMS = [int(f) for f in os.environ.get('FORMS', '0,1,2').split(',')]
 torch.manual_seed(0)
 
 
@@ -29,25 +31,25 @@ def run(C, O, B, resid, bound, n=20):
         return hip.irrep_gemm(Xp, L.wpack, C, O, B, f16x2=L.wsplit2, x_bound=xb, x_planes=2, add=add, next_bound=nb)
 
     outs = {}
-    for on in (False, True):
+    for on in FORMS:
         with hip.gemm_persistent(on):
             outs[on] = once()
     torch.cuda.synchronize()
-    a, b = outs[False], outs[True]
-    same = (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) if bound else torch.equal(a, b)
+    a = outs[FORMS[0]]
+    same = all(((torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) if bound else torch.equal(a, b)) for b in outs.values())
     line = f'C={C} O={O} B={B} resid={int(resid)} bound={int(bound)}: bitwise {same}'
     t_end = time.perf_counter() + 1.0
     while time.perf_counter() < t_end:
         once(); torch.cuda.synchronize()
     for rep in range(reps):
-        for on in (False, True):
+        for on in FORMS:
             with hip.gemm_persistent(on):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 once(); e0.record()
                 for _ in range(n):
                     once()
                 e1.record(); torch.cuda.synchronize()
-                line += f'  {"P" if on else "t"} {e0.elapsed_time(e1) / n:.3f}'
+                line += f'  {"tPH"[on]} {e0.elapsed_time(e1) / n:.3f}'
     print(line + ' ms', flush=True)
     return same
 
