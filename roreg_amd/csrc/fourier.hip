@@ -1085,9 +1085,8 @@ __global__ __launch_bounds__(512, 2) void irrep_gemm_xdma16_kernel(GemmSplitDesc
 // same order -- results bitwise those of the 256 x 256 kernel.  What changes:
 //   * activations: a K16 stage is 128 columns (8 KB), six stages as before (48 KB);
 //   * weights: ONE K32 buffer (two K16 stages, 32 KB) instead of a ring of two: step S + 1's weights are requested at the start of step S into the
-//     buffer whose fragments (step S) every wave read at the end of step S - 1, land under step S (they come from L2), and are read into registers
-//     under the last column block; that takes a second barrier per step (at its start: everyone's fragment reads of the previous step's end are
-//     done) -- of four waves instead of eight;
+//     buffer whose fragments (step S) were read at the end of step S - 1, land under step S (they come from L2), and are read into registers
+//     under the last column block; a thread fetches both k octets of its row, so a wave reads only what it fetched itself: no barrier for them;
 //   * the 256-row weight slice is fetched by both halves of a 256 x 256 tile (L2 -> LDS traffic of the weights doubles); in exchange an XCD holds 64
 //     tiles = one whole 8 x 8 block of the work list at a time (16 operand streams for 64 tiles instead of 12 for 32);
 //   * workgroup b -> entry (b / 16) * 8 + b % 8 of the list, column half (b / 8) % 2: both halves on the XCD of the entry's stream.
@@ -1175,12 +1174,13 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_xdma16h_kernel(GemmSplitDes
 #define ROREG_PIN_B(waits, B) asm volatile(waits : "+v"(B[0]), "+v"(B[1]) :: "memory")
     using std::integral_constant;
     // One K32 step S.  a = this step's weight fragments (registers); an receives step S + 1's.
-    //   * column block 0 opens with the step's FIRST barrier, behind lgkmcnt(0): every wave has read step S's weight fragments (requested under
-    //     the previous step's last block) and its own first activation fragments -- the weight buffer may be overwritten: column blocks 0-3
-    //     request step S + 1's weights (two pieces each), column blocks 4-7 the ACTIVATIONS of step S + 2 into the stages of step S - 1;
-    //   * the SECOND barrier sits in front of column block 7, behind s_waitcnt vmcnt(3) lgkmcnt(0): in issue order only the activation pieces
-    //     of blocks 4-6 may be in flight, so step S + 1's weights (and its activations, requested a step ago) have landed for everyone, and
-    //     every read of this step's activation stages is done;
+    //   * the weight buffer needs NO barrier: a wave fetches exactly the 64 rows (both octets, both planes) whose fragments it reads itself, so its
+    //     lgkmcnt(0) at the top of column block 0 (the reads of step S's fragments, requested under the previous step's last block, are done) orders
+    //     them against its own requests of step S + 1's weights in column blocks 0-3 (two pieces each), and its vmcnt wait in front of block 7
+    //     orders those against its reads; column blocks 4-7 request the ACTIVATIONS of step S + 2 into the stages of step S - 1;
+    //   * the one barrier sits in front of column block 7, behind s_waitcnt vmcnt(3) lgkmcnt(0): in issue order only the activation pieces of
+    //     blocks 4-6 may be in flight, so step S + 1's activations (requested a step ago, by all four waves) have landed for everyone and every
+    //     read of this step's activation stages is done -- and this wave's weights of step S + 1 have landed;
     //   * behind it block 7 reads step S + 1's eight weight fragments and its first column block's activation fragments.
     auto step = [&](int S, const frag (&a)[4][2], frag (&an)[4][2]) {
         const unsigned xoff = (unsigned)((S % 3) * 2 * XSTAGE), xoff_next = (unsigned)(((S + 1) % 3) * 2 * XSTAGE);
@@ -1189,8 +1189,7 @@ __global__ __launch_bounds__(256, 2) void irrep_gemm_xdma16h_kernel(GemmSplitDes
             frag (&bc)[2] = (cb & 1) ? b1 : b0;
             frag (&bn)[2] = (cb & 1) ? b0 : b1;
             if constexpr (cb == 7) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if constexpr (cb == 0) ROREG_PIN_B("s_waitcnt lgkmcnt(0)\n\ts_barrier", bc);
-            else ROREG_PIN_B("s_waitcnt lgkmcnt(0)", bc);
+            ROREG_PIN_B("s_waitcnt lgkmcnt(0)", bc);          // (cb == 0: also this wave's reads of step S's weight fragments -- see below)
             auto mm = [&](int i) {                                                     // product i of the four row blocks: 0 = lo.hi, 1 = hi.lo, 2 = hi.hi
                 const frag bb = bc[i == 1 ? 1 : 0];
                 const int ai = i == 0 ? 1 : 0;

@@ -55,6 +55,12 @@ def run(C, O, B, resid, bound, n=20):
 
 
 ok = True
+if os.environ.get('SHAPES'):                                   # SHAPES="C,O,B,resid,bound;..."
+    for sh in os.environ['SHAPES'].split(';'):
+        C, O, B, resid, bound = [int(v) for v in sh.split(',')]
+        ok = run(C, O, B, bool(resid), bool(bound)) and ok
+    print('ALL BITWISE EQUAL' if ok else 'MISMATCH')
+    sys.exit(0 if ok else 1)
 for (C, O, B, resid, bound) in ((256, 512, 61440, False, True), (512, 256, 61440, True, True), (256, 512, 61440, False, False), (512, 256, 61440, True, False),
                                 (256, 512, 5000, False, True), (512, 256, 4967, True, True), (256, 256, 14464, True, True), (32, 256, 1000, False, True)):
     ok = run(C, O, B, resid, bound, n=20 if B > 20000 else 50) and ok
