@@ -81,6 +81,10 @@ def parse(argv=None):
     ap.add_argument('--force-collectives', action='store_true', help='N = 1: initialise the process group (nccl = RCCL, one rank) anyway, run the result '
                     'table\'s all_gather every step and ship the extractor outputs of 4 clouds from the rank to itself through the grouped send/recv: a '
                     'single GPU then executes the whole multi-GPU code path (ROREG_FORCE_COLLECTIVES=1 does the same)')
+    ap.add_argument('--pipeline', choices=['mutual', 'rd_rm'], default='mutual', help="which pipeline the headline region times: 'mutual' (mutual matcher + yohoo: "
+                    "the default) or 'rd_rm' (`Test.py --RD --RM --ET yohoo --keynum 5000`: detector + NMS + rotation-coherence matcher + yohoo; the default run "
+                    "reports it as value_rd_rm_k5000 -- this switch makes it the timed region itself, for profiling)")
+    ap.add_argument('--rd-rm-steps', type=int, default=2, help='timed steps of RoReg\'s own pipeline (--RD --RM --ET yohoo at --keynum = --kpts) on the full workload (0 = skip)')
     ap.add_argument('--bf16x3-steps', type=int, default=2, help='timed steps of the strictly 24-bit matrix-core mode on the full workload (0 = skip)')
     return ap.parse_args(argv)
 
@@ -334,6 +338,7 @@ def main():
     from roreg_amd import synth
     from roreg_amd.parses.parses_test import default_config
     cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
+    eng_rr = rr_weights = None
     if STUB:
         import importlib
         mod, fn = STUB.split(':')
@@ -349,6 +354,18 @@ def main():
         eng.set_gemm_mode(args.gemm)
         if args.dtype == 'bf16':
             eng.set_descriptor_dtype('bf16')
+        # RoReg's own pipeline (README.md:149,175: `Test.py --RD --RM --ET yohoo --keynum 5000`) on the same workload: a second engine over the same
+        # extractor / ET networks plus the detector and the rotation-coherence matcher
+        cfg_rr = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo', RD=True, RM=True)
+        eng_rr = None
+        if args.pipeline == 'rd_rm' or (args.rd_rm_steps > 0 and not args.no_secondary):
+            rd, rm, rr_weights = rd_rm_nets(cfg_rr)
+            eng_rr = RegistrationEngine(cfg_rr, gf, et, rd_net=rd, rm_net=rm)
+            eng_rr.set_gemm_mode(args.gemm)
+            if args.dtype == 'bf16':
+                eng_rr.set_descriptor_dtype('bf16')
+        if args.pipeline == 'rd_rm':
+            eng, cfg = eng_rr, cfg_rr
 
     scenes, my_plan, totals = build_workload(args, rank, world, device=device, exchange=not args.no_exchange)   # inputs resident in HBM before timing
     transfers = totals['transfers']
@@ -365,11 +382,11 @@ def main():
         feats, keys, _, pairs = scenes[s]
         return feats, keys, pairs, seeds[s]
 
-    def step(only=None, **kw):
+    def step(only=None, engine=None, **kw):
         """One pass of this rank's share + the step's single collective -> (this rank's rows [(scene, PairResult)], gathered table or None)."""
         pieces = [p for p in my_plan if only is None or p[0] == only]
         with D.watchdog(step_timeout if dist is not None else 0.0, 'one step (exchange, kernels, gather)'):
-            done = D.run_plan(eng, pieces, scene_inputs, transfers if only is None else [], rank, stats=moved, **kw)
+            done = D.run_plan(eng if engine is None else engine, pieces, scene_inputs, transfers if only is None else [], rank, stats=moved, **kw)
             rows = [(s, r) for s, _, _, res in done for r in res]
             table = None
             if only is None:                                                  # the single result-table collective (RCCL over xGMI)
@@ -473,6 +490,12 @@ def main():
         bf16x3_all_value = totals['pairs'] * args.bf16x3_steps / d_ba
         eng.set_gemm_mode(args.gemm)
 
+
+    # ---- RoReg's own pipeline -- `Test.py --RD --RM --ET yohoo --keynum 5000` (README.md:149,175; SURVEY 3.1: THE hot path) -- on the SAME full workload ----
+    rr_full = None
+    if hip is not None and eng_rr is not None and args.pipeline != 'rd_rm' and args.rd_rm_steps > 0:
+        rr_full = rd_rm_full(args, totals, eng_rr, step, bracket, scenes, rr_weights, dist, coll_dev)
+
     # ---- secondary figures (outside the headline's timed region; kitchen scene only, so the default run stays short) ----
     sec_scene = kitchen if kitchen in scenes else sorted(scenes)[0]
     if not args.no_secondary and kitchen_whole:                               # BASELINE configs[1]: the kitchen scene alone on this GPU
@@ -537,6 +560,8 @@ def main():
                               f"(mutual matcher + yohoo estimator, max_iter=1000, 60-rot group feats); pairs sharded over the ranks by scene",
               'kitchen': f"3DMatch-kitchen-like scene: {totals['clouds']} clouds x {args.kpts} kpts, {total_pairs} pairs (mutual + yohoo, max_iter=1000)",
               'chunk': f"scene chunk per GPU: 16 clouds x {args.kpts} kpts, 60 pairs (mutual + yohoo, max_iter=1000)"}[args.workload]
+        if args.pipeline == 'rd_rm':
+            wl = wl.replace('mutual matcher + yohoo estimator', 'detector + NMS + rotation-coherence matcher + yohoo estimator: --RD --RM').replace('mutual + yohoo', '--RD --RM + yohoo')
         out = {
             'metric': 'pair-registrations/sec', 'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': totals['scaling'],
@@ -550,12 +575,16 @@ def main():
             'value_all_local_transforms': all_value,
             'accuracy': metrics,
             'value_bf16x3': bf16x3_value,
+            **({k: v for k, v in rr_full.items() if k != 'rd_rm_k5000'} if rr_full else {}),
             'config': {'workload': wl, 'pairs_per_step': total_pairs, 'clouds_per_step': totals['clouds'], 'parallelism': f'pairs-sharded x{world}',
                        'descriptor_dtype': args.dtype,
                        # scalars repeated here because a record that keeps only the contract's keys keeps `config`'s scalars:
                        'value_all_local_transforms': all_value,            # the reference's per-pair work (every correspondence's local transform)
                        'value_bf16x3': bf16x3_value,                        # same workload, strictly 24-bit operands (3 x bf16) in the matrix cores
                        'value_contract_complete': all_value, 'value_contract_complete_bf16x3': bf16x3_all_value,
+                       'value_rd_rm_k5000': None if not rr_full else rr_full['value_rd_rm_k5000'],
+                       'value_rd_rm_k5000_contract_complete': None if not rr_full else rr_full['value_rd_rm_k5000_contract_complete'],
+                       'rd_rm_k5000': None if not rr_full else rr_full['rd_rm_k5000'],
                        'fmr': None if metrics is None else metrics['feature_matching_recall'],
                        'ir': None if metrics is None else metrics['inlier_ratio'],
                        'rr': None if metrics is None else metrics['registration_recall_pointdsc'],
@@ -642,6 +671,70 @@ def headroom_bits(eng, feats):
     return rep
 
 
+def sinkhorn_roofline(work, sk_ms, sk_n, fused):
+    """MFMA roofline of the recomputing Sinkhorn iterations (csrc/ot_flash.hip) from the library's HIP-event brackets: executed fp16 MFMA flop per
+    coupling-matrix element and iteration (seven K = 16 MFMAs per 32 x 32 tile = 224; twice that when the scores are recomputed in two passes)."""
+    cells = work.get('sinkhorn_cells', 0.0)
+    per_cell = 224.0 if fused else 448.0
+    tf = cells * per_cell / (sk_ms * 1e-3) / 1e12
+    return {'kernel': 'of_iter_kernel + of_update_cols_kernel (one recomputation per iteration)' if fused else 'of_pass_kernel x 2 + of_update kernels (two recomputing passes per iteration)',
+            'bound': 'mfma', 'unit': 'TFLOP/s', 'launch_groups': sk_n, 'avg_ms': sk_ms / max(sk_n, 1), 'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1),
+            'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'executed_mfma_flop_per_element_and_iteration': per_cell,
+            'traffic': None, 'hbm_bytes_not_read': work.get('sinkhorn_bytes', 0.0)}
+
+
+def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_dev):
+    """RoReg's own pipeline on the full benchmark shape: detector -> NMS -> rotation-coherence matcher (Match_ot at m = n = keynum) -> yohoo on the top
+    `match_n` matches, through the same run_plan / run_scenes path as the headline.  -> dict of top-level keys for the record."""
+    from roreg_amd import hip, synth
+    from roreg_amd.utils.r_eval import compute_R_diff
+    n = args.rd_rm_steps
+    step(engine=eng_rr)                                                          # warm-up at the timed depth
+    hip.profile_enable(True); hip.WORK = {}
+    d, rows, _ = bracket(n, engine=eng_rr)
+    sk_ms, sk_n = hip.profile_read('sinkhorn'); tk_ms, tk_n = hip.profile_read('topk_dot'); ft_ms, ft_n = hip.profile_read('ft_nonlin')
+    work = hip.WORK; hip.WORK = None; hip.profile_enable(False)
+    value = totals['pairs'] * n / d
+    step(engine=eng_rr, all_local_transforms=True)
+    d_all, rows_all, _ = bracket(1, engine=eng_rr, all_local_transforms=True)
+    same = all(np.array_equal(a.trans, b.trans, equal_nan=True) and a.recalltime == b.recalltime for (_, a), (_, b) in zip(rows, rows_all))
+    eng_rr.phase_ms = {}                                                          # one synchronised (un-pipelined) pass: where the time goes, by stage
+    step(engine=eng_rr)
+    phases = {k: round(v, 2) for k, v in eng_rr.phase_ms.items()}; eng_rr.phase_ms = None
+    ok = []
+    for s, r in rows:
+        gt = synth.pose_transform(scenes[s][2], r.id0, r.id1)
+        ok.append(bool(np.isfinite(r.trans).all() and compute_R_diff(r.trans[:3, :3], gt[:3, :3]) < 15 and np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))) < 0.3))
+    out = {'value_rd_rm_k5000': value, 'value_rd_rm_k5000_contract_complete': totals['pairs'] / d_all,
+           'rd_rm_k5000': {'workload': f"the headline's workload ({totals['clouds']} clouds x {args.kpts} kpts, {totals['pairs']} pairs) through --RD --RM --ET yohoo --keynum {eng_rr.cfg.keynum} "
+                                       f"--match_n {eng_rr.cfg.match_n}: detector, NMS sampling, Match_ot at m = n = {eng_rr.cfg.keynum}, one-shot estimator on the top matches",
+                           'weights': weights + '; seeded GF / ET weights', 'steps': n, 'ms_per_step': 1e3 * d / n, 'ms_per_step_contract_complete': 1e3 * d_all,
+                           'results_identical_to_all_local_transforms': bool(same), 'mean_matches_rank0': float(np.mean([r.n_match for _, r in rows])) if rows else None,
+                           'registration_recall_pointdsc_rank0': float(np.mean(ok)) if ok else None,
+                           'stage_ms_one_synchronised_pass_rank0': phases,
+                           'transforms_ms_per_step': ft_ms / n if ft_n else None,
+                           'topk_dot_ms_per_step': tk_ms / n if tk_n else None,
+                           'sinkhorn_ms_per_step': sk_ms / n if sk_n else None}}
+    if sk_n and work.get('sinkhorn_recompute'):
+        fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and (eng_rr.cfg.keynum <= 2559 or bool(getattr(hip, 'OT_COOP', False)))
+        out['roofline_rd_rm'] = sinkhorn_roofline(work, sk_ms, sk_n, fused)
+    return out
+
+
+def rd_rm_nets(cfg):
+    """(detector, rotation-coherence matcher, description of their weights): the reference's shipped RD / RM checkpoints when the fixtures hold them."""
+    from roreg_amd import synth
+    from roreg_amd.network import name2network
+    rd = name2network['RD_test'](cfg); rm = name2network['RM_test'](cfg)
+    gdir = os.path.join(ROOT, 'tests', 'golden')
+    if os.path.exists(f'{gdir}/weights_RD.npz') and os.path.exists(f'{gdir}/weights_RM.npz'):
+        rd.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(f'{gdir}/weights_RD.npz').items()})
+        rm.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(f'{gdir}/weights_RM.npz').items()})
+        return rd, rm, 'the reference\'s shipped RD / RM checkpoints (tests/golden/weights_R{D,M}.npz)'
+    synth.seeded_state_dict(rd, 303); synth.seeded_state_dict(rm, 404)
+    return rd, rm, 'random-init'
+
+
 def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'bf16', 'fp32_matrix_core_layers')):
     """BASELINE configs[3] / [4] path on one low-overlap scene chunk: detector (RD) -> NMS sampling -> rotation-coherence matcher (RM) at `keynum`
     (2500 = yoho_mat's default; 5000 = `Test.py --keynum 5000`) -> one-shot estimator on the top-`match_n` matches; float32 and bfloat16
@@ -654,15 +747,7 @@ def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'b
     from roreg_amd.parses.parses_test import default_config
     n_clouds, overlap = 24, 0.2
     cfg = default_config(keynum=keynum, max_iter=1000, ET='yohoo', RD=True, RM=True)
-    rd = name2network['RD_test'](cfg); rm = name2network['RM_test'](cfg)
-    weights = 'random-init'
-    gdir = os.path.join(ROOT, 'tests', 'golden')
-    if os.path.exists(f'{gdir}/weights_RD.npz') and os.path.exists(f'{gdir}/weights_RM.npz'):
-        rd.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(f'{gdir}/weights_RD.npz').items()})
-        rm.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(f'{gdir}/weights_RM.npz').items()})
-        weights = 'the reference\'s shipped RD / RM checkpoints (tests/golden/weights_R{D,M}.npz)'
-    else:
-        synth.seeded_state_dict(rd, 303); synth.seeded_state_dict(rm, 404)
+    rd, rm, weights = rd_rm_nets(cfg)
     feats, keys, poses = synth.make_scene_device(1400, n_clouds, args.kpts, overlap)
     pairs = [(str(a), str(b)) for a, b in synth.scene_pair_list(n_clouds, n_pairs, 4343, locality=8.0)]
     seeds = [(11 + zlib.crc32(f'lo:{a}:{b}'.encode())) % (2 ** 32) for a, b in pairs]

@@ -658,7 +658,9 @@ class RegistrationEngine:
         t0 = self._mark('extract', t0)
         if self.cfg.RD:
             yield from self._detect_steps([clouds[i] for i in used])
+            t0 = self._mark('detect', t0)
             yield from self._nms_steps([clouds[i] for i in used], keynum)
+            t0 = self._mark('nms', t0)
         # stage 3: all pairs
         full, all_scores = [], []
         if self.cfg.RM:
