@@ -85,6 +85,7 @@ def parse(argv=None):
                     "the default) or 'rd_rm' (`Test.py --RD --RM --ET yohoo --keynum 5000`: detector + NMS + rotation-coherence matcher + yohoo; the default run "
                     "reports it as value_rd_rm_k5000 -- this switch makes it the timed region itself, for profiling)")
     ap.add_argument('--rd-rm-steps', type=int, default=2, help='timed steps of RoReg\'s own pipeline (--RD --RM --ET yohoo at --keynum = --kpts) on the full workload (0 = skip)')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the drop-in leg (one scene through yoho_evaluator.process_scene on disk: ~7 GB of temporary files)')
     ap.add_argument('--bf16x3-steps', type=int, default=2, help='timed steps of the strictly 24-bit matrix-core mode on the full workload (0 = skip)')
     return ap.parse_args(argv)
 
@@ -531,6 +532,11 @@ def main():
         eng.phase_ms = None
         if args.gemm == 'f16x2':
             sec['f16x2_scale_headroom_bits'] = headroom_bits(eng, scenes[sec_scene][0][0])
+        if world == 1 and not args.no_dropin:
+            try:
+                sec['dropin_leg'] = dropin_leg(args, gf_sd, et_sd)
+            except OSError as e:                                              # (no room for the scene's files in the temporary directory)
+                sec['dropin_leg'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1:
             sec['rd_rm_leg'] = rd_rm_leg(args, cfg, gf, et)
             sec['rd_rm_leg_pairs_per_s'] = sec['rd_rm_leg'].get('fp32', {}).get('pairs_per_s')
@@ -584,6 +590,7 @@ def main():
                        'value_contract_complete': all_value, 'value_contract_complete_bf16x3': bf16x3_all_value,
                        'value_rd_rm_k5000': None if not rr_full else rr_full['value_rd_rm_k5000'],
                        'value_rd_rm_k5000_contract_complete': None if not rr_full else rr_full['value_rd_rm_k5000_contract_complete'],
+                       'value_rd_rm_k5000_all_sinkhorn_iterations': None if not rr_full else rr_full['value_rd_rm_k5000_all_sinkhorn_iterations'],
                        'rd_rm_k5000': None if not rr_full else rr_full['rd_rm_k5000'],
                        'fmr': None if metrics is None else metrics['feature_matching_recall'],
                        'ir': None if metrics is None else metrics['inlier_ratio'],
@@ -685,16 +692,29 @@ def sinkhorn_roofline(work, sk_ms, sk_n, fused):
 
 def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_dev):
     """RoReg's own pipeline on the full benchmark shape: detector -> NMS -> rotation-coherence matcher (Match_ot at m = n = keynum) -> yohoo on the top
-    `match_n` matches, through the same run_plan / run_scenes path as the headline.  -> dict of top-level keys for the record."""
+    `match_n` matches, through the same run_plan / run_scenes path as the headline.  -> dict of top-level keys for the record.
+    Timed twice: as the library runs it by default (a pair's Sinkhorn iterations stop at the float32 fixed point, include/roreg_hip.h v6), and with
+    every pair run through all 100 iterations like the reference's loop (network/rot_coh_match.py:289-292) -- the second also prices the Sinkhorn
+    kernel against the MFMA peak (executed flops are then known exactly)."""
     from roreg_amd import hip, synth
     from roreg_amd.utils.r_eval import compute_R_diff
     n = args.rd_rm_steps
     step(engine=eng_rr)                                                          # warm-up at the timed depth
-    hip.profile_enable(True); hip.WORK = {}
+    hip.profile_enable(True); hip.WORK = {}; hip.sinkhorn_iteration_stats()
     d, rows, _ = bracket(n, engine=eng_rr)
     sk_ms, sk_n = hip.profile_read('sinkhorn'); tk_ms, tk_n = hip.profile_read('topk_dot'); ft_ms, ft_n = hip.profile_read('ft_nonlin')
     work = hip.WORK; hip.WORK = None; hip.profile_enable(False)
+    it_run, it_pairs = hip.sinkhorn_iteration_stats()
     value = totals['pairs'] * n / d
+    # the same with every pair run through all the iterations
+    with hip.sinkhorn_early_exit(False):
+        step(engine=eng_rr)
+        hip.profile_enable(True); hip.WORK = {}
+        d_fix, rows_fix, _ = bracket(1, engine=eng_rr)
+        skf_ms, skf_n = hip.profile_read('sinkhorn')
+        work_fix = hip.WORK; hip.WORK = None; hip.profile_enable(False)
+    same_m = int(sum(1 for (_, a), (_, b) in zip(rows, rows_fix) if a.n_match == b.n_match))
+    dT = [float(np.abs(a.trans - b.trans).max()) for (_, a), (_, b) in zip(rows, rows_fix) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()]
     step(engine=eng_rr, all_local_transforms=True)
     d_all, rows_all, _ = bracket(1, engine=eng_rr, all_local_transforms=True)
     same = all(np.array_equal(a.trans, b.trans, equal_nan=True) and a.recalltime == b.recalltime for (_, a), (_, b) in zip(rows, rows_all))
@@ -706,19 +726,116 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
         gt = synth.pose_transform(scenes[s][2], r.id0, r.id1)
         ok.append(bool(np.isfinite(r.trans).all() and compute_R_diff(r.trans[:3, :3], gt[:3, :3]) < 15 and np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))) < 0.3))
     out = {'value_rd_rm_k5000': value, 'value_rd_rm_k5000_contract_complete': totals['pairs'] / d_all,
+           'value_rd_rm_k5000_all_sinkhorn_iterations': totals['pairs'] / d_fix,
            'rd_rm_k5000': {'workload': f"the headline's workload ({totals['clouds']} clouds x {args.kpts} kpts, {totals['pairs']} pairs) through --RD --RM --ET yohoo --keynum {eng_rr.cfg.keynum} "
                                        f"--match_n {eng_rr.cfg.match_n}: detector, NMS sampling, Match_ot at m = n = {eng_rr.cfg.keynum}, one-shot estimator on the top matches",
                            'weights': weights + '; seeded GF / ET weights', 'steps': n, 'ms_per_step': 1e3 * d / n, 'ms_per_step_contract_complete': 1e3 * d_all,
+                           'ms_per_step_all_sinkhorn_iterations': 1e3 * d_fix,
+                           'sinkhorn': {'iterations_asked': 100, 'iterations_run_mean': it_run / max(it_pairs, 1), 'pairs': it_pairs // max(n, 1),
+                                        'rule': 'a pair stops once an iteration moved none of its potentials by more than max(2^-22 |u|, 2^-20) in log2 units (2 .. 4 float32 ulps): '
+                                                'the fixed point of the float32 iteration; roreg_sinkhorn_early_exit(0) runs all of them',
+                                        'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1) if sk_n else None,
+                                        'ms_per_pair_all_iterations': skf_ms / max(work_fix.get('sinkhorn_pairs', 1), 1) if skf_n else None,
+                                        'pairs_with_the_same_match_count_as_all_iterations': same_m, 'pairs_compared': len(rows),
+                                        'max_abs_diff_of_transforms_vs_all_iterations': max(dT or [0.0])},
                            'results_identical_to_all_local_transforms': bool(same), 'mean_matches_rank0': float(np.mean([r.n_match for _, r in rows])) if rows else None,
                            'registration_recall_pointdsc_rank0': float(np.mean(ok)) if ok else None,
                            'stage_ms_one_synchronised_pass_rank0': phases,
                            'transforms_ms_per_step': ft_ms / n if ft_n else None,
                            'topk_dot_ms_per_step': tk_ms / n if tk_n else None,
                            'sinkhorn_ms_per_step': sk_ms / n if sk_n else None}}
-    if sk_n and work.get('sinkhorn_recompute'):
+    if skf_n and work_fix.get('sinkhorn_recompute'):
         fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and (eng_rr.cfg.keynum <= 2559 or bool(getattr(hip, 'OT_COOP', False)))
-        out['roofline_rd_rm'] = sinkhorn_roofline(work, sk_ms, sk_n, fused)
+        out['roofline_rd_rm'] = dict(sinkhorn_roofline(work_fix, skf_ms, skf_n, fused), measured_on='the pass with every pair run through all 100 iterations (executed flops known exactly)')
     return out
+
+
+def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
+    """The boundary north_star names -- `Test.py` unchanged, i.e. `yoho_evaluator(cfg).process_scene(dataset)` (Test.py:20-23, test/evaluator.py:39-48)
+    -- on ONE kitchen-shaped scene (60 clouds x 5000 kpts, 449 pairs, mutual matcher + yohoo) laid out on disk the way testset.py leaves it
+    ({cache}/{scene}/FCGF_Input_Group_feature/{pc}.npy, checkpoints under --model_fn), timed three ways:
+      stages  : the file-coupled chain of stage.run() calls (ROREG_EVALUATOR=stages: every stage reads its inputs from .npy and writes its outputs),
+      engine  : what process_scene does by default -- the device-resident engine + StageFileWriter: the same files, written asynchronously,
+      no_files: the engine alone on inputs already resident in HBM, every correspondence's local transform evaluated (the same per-pair work), no file.
+    Inputs are page-cached (just written); every output file of `engine` is compared with `stages` (.npy byte for byte, .npz by content)."""
+    import filecmp
+    import glob
+    import shutil
+    import tempfile
+    from roreg_amd import hip, synth
+    from roreg_amd.engine import RegistrationEngine
+    from roreg_amd.network import name2network
+    from roreg_amd.parses.parses_test import default_config
+    from roreg_amd.test import _cache
+    from roreg_amd.test.evaluator import yoho_evaluator
+    root = tempfile.mkdtemp(prefix='roreg_dropin_', dir=os.environ.get('ROREG_BENCH_TMP'))
+    try:
+        feats, keys, poses = synth.make_scene_device(777, n_clouds, args.kpts, OVERLAP)
+        pairs = synth.scene_pair_list(n_clouds, n_pairs, 901, locality=8.0)
+        ds = synth.SynthScene('synth/kitchen', [k.cpu().numpy() for k in keys], None, poses, pairs)
+        inputs = f'{root}/inputs/FCGF_Input_Group_feature'
+        os.makedirs(inputs)
+        for i, f in enumerate(feats):
+            np.save(f'{inputs}/{i}.npy', f.cpu().numpy())
+        for kind, sd in (('GF', gf_sd), ('ET', et_sd)):
+            os.makedirs(f'{root}/ckpt/{kind}')
+            torch.save({'best_para': 0, 'network_state_dict': sd}, f'{root}/ckpt/{kind}/model_best.pth')
+        out = {'workload': f'one scene on disk: {n_clouds} clouds x {args.kpts} kpts, {n_pairs} pairs, mutual matcher + yohoo (Test.py --ET yohoo --keynum {args.kpts}), '
+                           f'{n_clouds * args.kpts * 1920 * 4 / 1e9:.1f} GB of input features, page-cached', 'tmp': os.path.dirname(root)}
+        before = os.environ.get('ROREG_EVALUATOR')
+        for route in ('stages', 'engine'):
+            cache = f'{root}/cache_{route}'
+            os.makedirs(f'{cache}/{ds.name}')
+            os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
+            cfg = default_config(output_cache_fn=cache, model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, ET='yohoo')
+            os.environ['ROREG_EVALUATOR'] = route
+            _cache.clear()
+            ev = yoho_evaluator(cfg)
+            if route == 'engine':
+                ev._engine().set_gemm_mode(args.gemm)
+            else:
+                hip.GEMM_MODE = args.gemm
+            np.random.seed(5)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ev.process_scene(ds)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            out[route] = {'pairs_per_s': n_pairs / dt, 's_per_scene': dt}
+            del ev
+        if before is None:
+            os.environ.pop('ROREG_EVALUATOR', None)
+        else:
+            os.environ['ROREG_EVALUATOR'] = before
+        _cache.clear()
+        a, b = f'{root}/cache_stages/{ds.name}', f'{root}/cache_engine/{ds.name}'
+        rel = sorted(os.path.relpath(f, a) for f in glob.glob(f'{a}/**/*.npy', recursive=True) if 'Input_Group_feature' not in f)
+        rel_b = sorted(os.path.relpath(f, b) for f in glob.glob(f'{b}/**/*.npy', recursive=True) if 'Input_Group_feature' not in f)
+        differ = [r for r in rel if r not in rel_b or not filecmp.cmp(f'{a}/{r}', f'{b}/{r}', shallow=False)]
+        res = sorted(os.path.relpath(f, a) for f in glob.glob(f'{a}/**/*.npz', recursive=True))
+        res_differ = []
+        for r in res:
+            x, y = np.load(f'{a}/{r}'), np.load(f'{b}/{r}') if os.path.exists(f'{b}/{r}') else None
+            if y is None or sorted(x.files) != sorted(y.files) or not all(np.array_equal(x[k], y[k], equal_nan=True) for k in x.files):
+                res_differ.append(r)
+        out['files'] = {'npy_files_compared_byte_for_byte': len(rel), 'npy_files_that_differ': len(differ) + len(set(rel_b) - set(rel)), 'result_npz_compared': len(res),
+                        'result_npz_that_differ': len(res_differ), 'bytes_written_per_route': int(sum(os.path.getsize(f'{a}/{r}') for r in rel)),
+                        'examples_of_differing_files': (differ + res_differ)[:4]}
+        # the engine alone, inputs resident in HBM, the same per-pair work (every correspondence's local transform), no files
+        cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
+        gf = name2network['GF_test'](cfg); gf.load_state_dict(gf_sd)
+        et = name2network['ET_test'](cfg); et.load_state_dict(et_sd)
+        eng = RegistrationEngine(cfg, gf, et); eng.set_gemm_mode(args.gemm)
+        np.random.seed(5)
+        eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=True)
+        np.random.seed(5)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out['no_files'] = {'pairs_per_s': n_pairs / dt, 's_per_scene': dt}
+        out['engine_over_stages'] = out['engine']['pairs_per_s'] / out['stages']['pairs_per_s']
+        out['engine_over_no_files'] = out['engine']['pairs_per_s'] / out['no_files']['pairs_per_s']
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def rd_rm_nets(cfg):
@@ -764,10 +881,12 @@ def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'b
         job = (feats, keys, pairs, dict(pair_seeds=seeds))
         n_rep = 6
         eng.run_scenes([job] * n_rep)                                    # (warm-up at the timed depth: the caching allocator sees the same live set)
-        hip.profile_enable(True); hip.WORK = {}
+        hip.profile_enable(True); hip.WORK = {}; hip.sinkhorn_iteration_stats()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res = eng.run_scenes([job] * n_rep)[-1]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        it_run, it_pairs = hip.sinkhorn_iteration_stats()
+        it_frac = it_run / (100.0 * it_pairs) if it_pairs else 1.0           # share of the asked iterations that ran (pairs stop at their float32 fixed point)
         sk_ms, sk_n = hip.profile_read('sinkhorn'); tk_ms, tk_n = hip.profile_read('topk_dot')
         work = hip.WORK; hip.WORK = None; hip.profile_enable(False)
         from roreg_amd.utils.r_eval import compute_R_diff
@@ -784,8 +903,8 @@ def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'b
             # between the row sums and the column sums) unless ROREG_OT_FUSED=0 or a target cloud exceeds 2559 points (two passes: twice that).
             # No coupling matrix is read; what the fused kernel moves instead is 5 bytes of L2-resident fragments per element and iteration,
             # and that traffic is what bounds it (measured: fetching every fragment twice costs +50-67 %).
-            cells = work.get('sinkhorn_cells', 0.0)
-            fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and (cfg.keynum <= 2559 or os.environ.get('ROREG_OT_COOP') == '1')
+            cells = work.get('sinkhorn_cells', 0.0) * it_frac                # (element-iterations that were executed)
+            fused = os.environ.get('ROREG_OT_FUSED', '1') != '0' and (cfg.keynum <= 2559 or bool(hip.OT_COOP))
             per_cell = 224.0 if fused else 448.0
             tf = cells * per_cell / (sk_ms * 1e-3) / 1e12
             ex = cells * (1.0 if fused else 2.0) / (sk_ms * 1e-3)
@@ -793,6 +912,7 @@ def rd_rm_leg(args, cfg0, gf, et, keynum=2500, n_pairs=100, variants=('fp32', 'b
                                                   ': 100 iterations per stacked group of pairs; <s_i, t_j> + potentials + dustbins from seven fp16 MFMAs per 32 x 32 tile, then exponentiated; '
                                                   'the coupling matrix is never read', 'bound': 'l2-fragment-traffic' if fused else 'mfma', 'unit': 'TFLOP/s',
                                         'launch_groups': sk_n, 'avg_ms': sk_ms / sk_n, 'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1),
+                                        'iterations_run_mean': 100.0 * it_frac, 'iterations_asked': 100,
                                         'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': tf / PEAK_BF16_MFMA_TFLOPS,
                                         'executed_mfma_flop_per_element_and_iteration': per_cell,
                                         'exponentials_per_s': ex, 'exponential_peak_per_s': 256 * 4 * 16 / 2 * 2.4e9,

@@ -27,9 +27,9 @@ extern "C" {
  * roreg_ransac_batch take `w_f32`, the scores' storage type; roreg_group_conv_split / _f16x2 take an LDS slot order; roreg_ft_nonlin /
  * roreg_irrep_gemm_f16x2 take the plane-layout flags; 4: round 4 -- additions only (roreg_nn_search_ex / roreg_knn_search_ex / roreg_pdist and the entries marked "v4"),
  * bumped so that a binding can rely on them; 5: round 5 -- additions only, the entries marked "v5": roreg_sinkhorn_batch3 (+ its workspace size),
- * roreg_linear_path, roreg_linear_cat3, roreg_gemm_persistent, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2).  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
+ * roreg_linear_path, roreg_linear_cat3, roreg_gemm_persistent, roreg_ft_nonlin_packed, roreg_group_conv_f16x2_packed; roreg_sinkhorn_batch2's `recompute` also takes 2); 6: round 6 -- additions only, the entries marked "v6".  A binding must compare roreg_abi_version() with the ROREG_ABI_VERSION it was written against and
  * refuse to call a library that answers differently (roreg_amd/hip.py:lib() does). */
-#define ROREG_ABI_VERSION 5
+#define ROREG_ABI_VERSION 6
 int roreg_abi_version(void);
 const char *roreg_last_error(void);
 
@@ -453,6 +453,16 @@ int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const 
                           const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                           int recompute, float *Z_out, void *stream);
+/* v6: the recomputed iterations stop PER PAIR once an iteration has moved none of the pair's m + n + 2 potentials by more than 2 .. 4 units in
+ * the last place of its float32 value (|du| <= max(2^-22 |u|, 2^-20) in log2 units): the float32 fixed point of
+ * u <- log_mu - LSE(Z + v), v <- log_nu - LSE(Z + u) (network/rot_coh_match.py:285-292).  The reference always runs `iters` (= 100) iterations;
+ * past that point they only move last bits back and forth, so matches are unchanged and scores agree to float32 noise (tests/test_hip_rm.py,
+ * tests/test_hip_fullsize.py hold both settings to the reference's goldens).  A pair whose potentials keep moving runs all `iters`.
+ * roreg_sinkhorn_early_exit(on): 1 = stop converged pairs (default; ROREG_OT_EARLY_EXIT=0 in the environment starts with 0), 0 = always `iters`
+ * iterations, < 0 = query; returns the previous setting.  roreg_sinkhorn_iteration_stats: sum of the iterations run and number of pairs over
+ * the recomputed-iteration calls since the last reset (synchronises `stream`; host pointers). */
+int roreg_sinkhorn_early_exit(int on);
+int roreg_sinkhorn_iteration_stats(long long *iterations, long long *pairs, int reset, void *stream);
 
 /* ---- group-Fourier evaluation of the group convolution (csrc/fourier.hip, roreg_amd/fourier.py) ---------------
  * In the basis of the five real irreps (d = 1,3,3,4,5) the 13-stencil group conv is one dense GEMM per irrep,

@@ -6,7 +6,7 @@ from ctypes import c_int, c_void_p, c_size_t, c_double, c_float, c_char_p
 
 import numpy as np
 
-ABI_VERSION = 5          # == ROREG_ABI_VERSION of include/roreg_hip.h; hip.lib() refuses a library that reports another one
+ABI_VERSION = 6          # == ROREG_ABI_VERSION of include/roreg_hip.h; hip.lib() refuses a library that reports another one
 
 _P = c_void_p
 PROTOTYPES = {
@@ -66,6 +66,8 @@ PROTOTYPES = {
     'roreg_sinkhorn_batch2': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'roreg_sinkhorn_batch3_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int]),
     'roreg_sinkhorn_batch3': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P, _P]),
+    'roreg_sinkhorn_early_exit': (c_int, [c_int]),
+    'roreg_sinkhorn_iteration_stats': (c_int, [_P, _P, c_int, _P]),
     'roreg_linear': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_linear_mfma': (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'roreg_linear_path': (c_int, [c_int]),

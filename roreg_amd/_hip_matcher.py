@@ -1,6 +1,7 @@
 """ctypes bindings of the rotation-coherence matcher's kernels (csrc/rm.hip, ot_flash.hip, linear_mfma.hip, corr_mfma.hip): part of the
 `roreg_amd.hip` namespace (hip.py re-exports everything here; callers keep writing `hip.sinkhorn_batch(...)`).  Module state that callers
 set on `hip` (hip.WORK) is read through the module, never copied."""
+import ctypes
 import os
 
 import numpy as np
@@ -9,7 +10,7 @@ import torch
 from . import hip as _core
 from .hip import HipError, _check, _ptr, _stream, ensure_des2r, ensure_tables, lib, upload
 
-__all__ = ['Cat3Rows', 'OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'topk_dot', 'value_input', 'vector_pipe_layers']
+__all__ = ['Cat3Rows', 'OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'sinkhorn_early_exit', 'sinkhorn_iteration_stats', 'topk_dot', 'value_input', 'vector_pipe_layers']
 
 
 def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpose=False, want_idx=False, perm_coefs=None, bcast_coefs=None):
@@ -236,6 +237,30 @@ OT_RECOMPUTE = os.environ.get('ROREG_OT_RECOMPUTE', '1') == '1'
 # target clouds of 2560 ... 5119 points (keynum 5000): 0 = two recomputations per iteration (default: measured faster), 1 = one, two cooperating
 # workgroups per strip (csrc/ot_flash.hip)
 OT_COOP = os.environ.get('ROREG_OT_COOP', '0') == '1'
+
+
+class sinkhorn_early_exit:
+    """`with hip.sinkhorn_early_exit(False): ...` -- every pair runs all `iters` Sinkhorn iterations, like the reference's loop
+    (network/rot_coh_match.py:289-292); the default (True) stops a pair once an iteration moved none of its potentials by more than 2 .. 4
+    float32 units in the last place (include/roreg_hip.h, roreg_sinkhorn_early_exit).  The library-wide switch is restored on exit."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.before = lib().roreg_sinkhorn_early_exit(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        lib().roreg_sinkhorn_early_exit(self.before)
+        return False
+
+
+def sinkhorn_iteration_stats(reset=True):
+    """-> (iterations run, pairs) summed over the recomputed-iteration Sinkhorn calls since the last reset (synchronises the stream)."""
+    it = ctypes.c_longlong(0); pr = ctypes.c_longlong(0)
+    _check(lib().roreg_sinkhorn_iteration_stats(ctypes.byref(it), ctypes.byref(pr), 1 if reset else 0, _stream()), 'roreg_sinkhorn_iteration_stats')
+    return int(it.value), int(pr.value)
 
 
 def sinkhorn_batch(src_final, tgt_final, seg_src, seg_tgt, alpha, iters, recompute=None, want_Z=False):

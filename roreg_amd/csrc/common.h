@@ -58,6 +58,8 @@ struct ProfScope {
 
 // Sinkhorn iterations without a materialised coupling matrix (csrc/ot_flash.hip): potentials (natural log) of every pair to u_out / v_out
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n);
+int ot_flash_early_exit(int on);                       // 1 / 0 / < 0 = query -> previous setting
+int ot_flash_iteration_stats(long long *iters_sum, long long *pairs, int reset, hipStream_t s);
 int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_src, const int32_t *seg_tgt, const float *consts, int n_seg,
                         int max_m, int max_n, int min_n, bool coop_wanted, float alpha, int iters, float *u_out, float *v_out, size_t uv_stride, void *ws, hipStream_t s);
 

@@ -57,6 +57,31 @@ struct Side {                             // one side (source rows or target col
     const float *consts;                  // per pair (normc, log of the OTHER side's length): natural logs (roreg_sinkhorn_batch_consts)
 };
 
+// Per-pair convergence flags of the iterations (ot_flash_iterations): flag[pair][t] != 0 <=> iteration t ran and moved some potential of the
+// pair by more than OF_TOL_REL of its magnitude (2 .. 4 units in the last place of a float32).  Iteration t runs for a pair iff t == 0 or
+// flag[pair][t - 1] != 0: once an iteration has left every potential where it was (to float32 resolution) the pair has reached the fixed
+// point of the float32 iteration -- the reference's remaining iterations (network/rot_coh_match.py:289-292 always runs `iters` of them) only
+// move the last bits back and forth -- and every later launch returns at once for that pair.  The flags of an iteration that did not run
+// stay 0 (the array is cleared up front), which makes "done" sticky.  prev == nullptr: the pair's work always runs (early exit off,
+// iteration 0); cur == nullptr: nothing is recorded.  A pair's flags depend on its own data only.
+struct Conv {
+    const unsigned *prev;
+    unsigned *cur;
+    int stride;
+};
+constexpr float OF_TOL_REL = 0x1p-22f, OF_TOL_ABS = 0x1p-20f;
+__device__ __forceinline__ bool conv_done(const Conv &c, int pair) { return c.prev != nullptr && c.prev[(size_t)pair * c.stride] == 0u; }
+__device__ __forceinline__ void conv_note(const Conv &c, int pair, float np, float old) {
+    if (c.cur != nullptr && fabsf(np - old) > fmaxf(fabsf(np) * OF_TOL_REL, OF_TOL_ABS)) c.cur[(size_t)pair * c.stride] = 1u;
+}
+// iterations a pair has run: the first t >= 1 whose predecessor left the flag at 0, else all of them
+__device__ __forceinline__ int conv_executed(const unsigned *flags, int stride, int pair, int iters) {
+    if (flags == nullptr) return iters;
+    int t = iters > 0 ? 1 : 0;
+    while (t < iters && flags[(size_t)pair * stride + t - 1] != 0u) ++t;
+    return t;
+}
+
 __device__ __forceinline__ void split3(float x, _Float16 &h, _Float16 &m, _Float16 &l) {
     h = (_Float16)x;
     const float r = x - (float)h;
@@ -173,9 +198,10 @@ __device__ __forceinline__ float half_max(float x) {
 // so the vector pipe works in the matrix pipe's shadow; the fragments of tile t + 2 are in flight meanwhile.  The file is compiled with
 // -amdgpu-mfma-vgpr-form: accumulators in VGPRs, no v_accvgpr_read per element.
 template <bool MAXP, int R, int VAR = 0>     // VAR: ablations for measurements only (ROREG_OT_VARIANT): 1 = no exponentials, 2 = no MFMAs, 3 = no column loads in the loop
-__global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch, const int *__restrict__ tseg, int skip_le) {
+__global__ __launch_bounds__(256) void of_pass_kernel(Side a, Side b, int nch, const int *__restrict__ tseg, int skip_le, Conv cv) {
     const int pair = blockIdx.z, chunk = blockIdx.y;
     if ((tseg[pair + 1] - tseg[pair]) / 32 + 1 <= skip_le) return;          // (a pair whose TARGET cloud fits the whole-iteration kernel is left to it)
+    if (conv_done(cv, pair)) return;                                        // (the pair's potentials no longer move)
     const int lane = threadIdx.x & 63;
     const int lenA = a.seg[pair + 1] - a.seg[pair], lenB = b.seg[pair + 1] - b.seg[pair];
     const int tilesA = lenA / 32 + 1, tilesB = lenB / 32 + 1;              // (len + 1 rows: the dustbin)
@@ -316,9 +342,10 @@ __device__ __forceinline__ void store_pieces(const Side &a, int pair, int i, flo
 // log-domain evaluation of that row.  `cht` = tiles of the OTHER side per partial sum (OF_CHT for of_pass_kernel's chunks, 1 for the row
 // strips of of_iter_kernel), `nch` = partial sums allocated per row.
 template <bool MAXP>
-__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int cht, int slot0, float alpha, const int *__restrict__ tseg, int skip_le) {
+__global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch, int cht, int slot0, float alpha, const int *__restrict__ tseg, int skip_le, Conv cv) {
     const int pair = blockIdx.y;
     if ((tseg[pair + 1] - tseg[pair]) / 32 + 1 <= skip_le) return;
+    if (conv_done(cv, pair)) return;
     const int lenA = a.seg[pair + 1] - a.seg[pair];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i > lenA) return;
@@ -342,6 +369,7 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
         const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
         if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
         else np = exact_potential(a, b, pair, i, alpha, lmu);
+        conv_note(cv, pair, np, pot[i]);
     }
     pot[i] = np;
     store_pieces(a, pair, i, np, slot0);
@@ -352,10 +380,11 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
 // chip -- so here FOUR waves share a block of 64 columns, wave q adds the q-th quarter of the strips (in order, 20 loads in flight at a
 // time), and wave 0 adds the four quarter sums ((q0 + q1) + (q2 + q3)): four times the loads in flight, the association a function of
 // the pair's own strip count alone.
-__global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int nparts, float alpha, int fused_le) {
+__global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int nparts, float alpha, int fused_le, Conv cv) {
     const int pair = blockIdx.y;
     const int lenA = a.seg[pair + 1] - a.seg[pair];
     if (lenA / 32 + 1 > fused_le) return;                              // (a = the TARGET side here: pairs beyond the whole-iteration kernels take the two-pass form)
+    if (conv_done(cv, pair)) return;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     if (blockIdx.x * 64 > lenA) return;
@@ -382,6 +411,7 @@ __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int
     float np;
     if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
     else np = exact_potential(a, b, pair, i, alpha, lmu);
+    conv_note(cv, pair, np, pot[i]);
     pot[i] = np;
     store_pieces(a, pair, i, np, 3);
 }
@@ -421,7 +451,7 @@ struct Xchg {                              // (value, token) words of the cooper
 // VAR: measurements / tests only.  ROREG_OT_FVAR: 1 no exponentials, 2 no MFMAs, 4 every fragment fetched twice, 5 no row update;
 // 6 (tests) every strip through the stabilised redo; 7 (tests) the cooperating halves never see each other (always the bounded wait's fallback)
 template <int NT, int NT_OTHER, bool COOP, int VAR>
-__device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int nparts, int parity, int pair, int tA, int hb, unsigned long long *xw, int token0) {
+__device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int nparts, int parity, int pair, int tA, int hb, unsigned long long *xw, int token0, const Conv &cv) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (w in a scalar register: tile addresses are scalar)
     const int lenA = a.seg[pair + 1] - a.seg[pair], lenB = b.seg[pair + 1] - b.seg[pair];
     const int tilesB = lenB / 32 + 1;
@@ -626,7 +656,7 @@ __device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int n
         if (!redo && row_valid) {
             const float np = old + (lmu - __log2f(S));             // u + log2 mu - log2 sum_j 2^(Z' + u + v)
             frow = __builtin_amdgcn_exp2f(np - old);               // E f = 2^(Z' + u_new + v)
-            if (threadIdx.x < 32 && hb == 0) pot[i_row] = np;
+            if (threadIdx.x < 32 && hb == 0) { pot[i_row] = np; conv_note(cv, pair, np, old); }
         }
     }
     if (redo) {                                                    // rare: stabilised evaluation of the whole strip
@@ -642,7 +672,7 @@ __device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int n
             const float m = s_np[lane & 31];
             const float np = old + ((lmu - m) - __log2f(S));
             frow = __builtin_amdgcn_exp2f((np - old) + m);         // = mu_i / S_i: E f = 2^(Z' + u_new + v)
-            if (threadIdx.x < 32 && hb == 0) pot[i_row] = np;
+            if (threadIdx.x < 32 && hb == 0) { pot[i_row] = np; conv_note(cv, pair, np, old); }
         }
     }
     // ---- phase 2: the strip's part of the column sums ----
@@ -663,36 +693,43 @@ __device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int n
 
 // one workgroup per strip: pairs whose target cloud has at most OF_HALF column tiles (others are left to the cooperating kernel)
 template <int NT, int VAR = 0>
-__global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts, int parity) {
+__global__ __launch_bounds__(64 * OF_FW) void of_iter_kernel(Side a, Side b, int nparts, int t, Conv cv) {
     const int pair = blockIdx.y, tA = blockIdx.x;
     const int tilesA = (a.seg[pair + 1] - a.seg[pair]) / 32 + 1, tilesB = (b.seg[pair + 1] - b.seg[pair]) / 32 + 1;
-    if (tA >= tilesA || tilesB > OF_HALF) return;
-    of_iter_body<NT, 0, false, VAR>(a, b, nparts, parity, pair, tA, 0, nullptr, 0);
+    if (tA >= tilesA || tilesB > OF_HALF || conv_done(cv, pair)) return;
+    of_iter_body<NT, 0, false, VAR>(a, b, nparts, t & 1, pair, tA, 0, nullptr, 0, cv);
 }
 
 // two workgroups per strip: pairs with OF_HALF < column tiles <= 2 OF_HALF.  Linear workgroup id L -> XCD L % 8, position L / 8 in that
 // XCD's dispatch order; positions 2 s and 2 s + 1 are the two halves of unit 8 s + XCD (unit = pair * ta + strip).
 template <int NT1, int VAR = 0>
-__global__ __launch_bounds__(64 * OF_FW) void of_iter_coop_kernel(Side a, Side b, int nparts, int parity, int ta, int units, Xchg x) {
+__global__ __launch_bounds__(64 * OF_FW) void of_iter_coop_kernel(Side a, Side b, int nparts, int parity, int ta, int units, Xchg x, Conv cv) {
     const int L = blockIdx.x, pos = L >> 3;
     const int unit = (pos >> 1) * 8 + (L & 7), hb = pos & 1;
     if (unit >= units) return;
     const int pair = unit / ta, tA = unit - pair * ta;
     const int tilesA = (a.seg[pair + 1] - a.seg[pair]) / 32 + 1, tilesB = (b.seg[pair + 1] - b.seg[pair]) / 32 + 1;
-    if (tA >= tilesA || tilesB <= OF_HALF || tilesB > 2 * OF_HALF) return;
+    if (tA >= tilesA || tilesB <= OF_HALF || tilesB > 2 * OF_HALF || conv_done(cv, pair)) return;
     unsigned long long *xw = x.words + (size_t)unit * 64;
-    if (NT1 == OF_FT) of_iter_body<OF_FT, OF_FT, true, VAR>(a, b, nparts, parity, pair, tA, hb, xw, x.token0);      // (one body for both halves)
-    else if (hb == 0) of_iter_body<OF_FT, NT1, true, VAR>(a, b, nparts, parity, pair, tA, 0, xw, x.token0);
-    else of_iter_body<NT1, OF_FT, true, VAR>(a, b, nparts, parity, pair, tA, 1, xw, x.token0);
+    if (NT1 == OF_FT) of_iter_body<OF_FT, OF_FT, true, VAR>(a, b, nparts, parity, pair, tA, hb, xw, x.token0, cv);      // (one body for both halves)
+    else if (hb == 0) of_iter_body<OF_FT, NT1, true, VAR>(a, b, nparts, parity, pair, tA, 0, xw, x.token0, cv);
+    else of_iter_body<NT1, OF_FT, true, VAR>(a, b, nparts, parity, pair, tA, 1, xw, x.token0, cv);
 }
 
 // (tseg / fused_le / odd: the row potentials of a pair that took a whole-iteration kernel sit in the second buffer after an odd number of iterations)
-__global__ __launch_bounds__(256) void of_export_kernel(Side a, float *__restrict__ out, size_t out_stride, const int *__restrict__ tseg, int fused_le, int odd) {
+// (with early exit the number of iterations a pair has run is its own: conv_executed)
+__global__ __launch_bounds__(256) void of_export_kernel(Side a, float *__restrict__ out, size_t out_stride, const int *__restrict__ tseg, int fused_le, int iters,
+                                                        const unsigned *__restrict__ flags, int flag_stride, unsigned long long *__restrict__ ran) {
     const int pair = blockIdx.y;
     const int len = a.seg[pair + 1] - a.seg[pair];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool second = odd && a.pot2 && (tseg[pair + 1] - tseg[pair]) / 32 + 1 <= fused_le;
+    const int done = conv_executed(flags, flag_stride, pair, iters);
+    const bool second = (done & 1) && a.pot2 && (tseg[pair + 1] - tseg[pair]) / 32 + 1 <= fused_le;
     if (i <= len) out[pair * out_stride + i] = (second ? a.pot2 : a.pot)[pair * a.pot_stride + i] * LN2;
+    if (ran != nullptr && i == 0) {                                    // statistics: (iterations run, pairs) summed over the calls since the last reset
+        atomicAdd(reinterpret_cast<unsigned long long *>(ran), (unsigned long long)done);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ran) + 1, 1ull);
+    }
 }
 
 __host__ __device__ inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -720,6 +757,27 @@ static bool ot_flash_on() {
     return on;
 }
 
+// Early exit of converged pairs (struct Conv): on by default, ROREG_OT_EARLY_EXIT=0 or ot_flash_early_exit(0) runs every pair through all
+// `iters` iterations like the reference's loop.
+constexpr int OF_MAX_FLAG_ITERS = 256;                 // flags are kept for calls of up to this many iterations (longer ones run them all)
+static int g_early_exit = -1;
+static unsigned long long *g_iter_stats = nullptr;     // device: (iterations run, pairs) of every export since the last reset
+int ot_flash_early_exit(int on) {
+    if (g_early_exit < 0) g_early_exit = (getenv("ROREG_OT_EARLY_EXIT") && atoi(getenv("ROREG_OT_EARLY_EXIT")) == 0) ? 0 : 1;
+    const int before = g_early_exit;
+    if (on >= 0) g_early_exit = on ? 1 : 0;
+    return before;
+}
+int ot_flash_iteration_stats(long long *iters_sum, long long *pairs, int reset, hipStream_t s) {
+    unsigned long long h[2] = {0, 0};
+    if (g_iter_stats != nullptr) {
+        if (hipMemcpyAsync(h, g_iter_stats, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+        if (reset && hipMemsetAsync(g_iter_stats, 0, sizeof(h), s) != hipSuccess) return -1;
+    }
+    *iters_sum = (long long)h[0]; *pairs = (long long)h[1];
+    return 0;
+}
+
 // bytes of workspace of ot_flash_iterations (16-byte aligned pieces): per pair the two sides' fragments, potentials and chunk partials
 size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
     const size_t ta = max_m / 32 + 1, tb = max_n / 32 + 1;
@@ -728,7 +786,7 @@ size_t ot_flash_workspace_bytes(int n_seg, int max_m, int max_n) {
     const size_t nparts = fused && ta > nch ? ta : nch;                          // side B's partial sums: one per row strip in the fused iteration
     const size_t per_pair = (ta + tb + 2) * OF_TILE_HALFS * sizeof(_Float16) + (2 * ta + tb) * 32 * sizeof(float) + (ta * nch + tb * nparts) * 32 * sizeof(float)
                             + (fused && tb > (size_t)OF_HALF ? ta * 64 * sizeof(unsigned long long) : 0);     // + the cooperating halves' words
-    return (size_t)n_seg * per_pair + round_up((size_t)n_seg * 2 * sizeof(unsigned), 16) + 256;
+    return (size_t)n_seg * per_pair + round_up((size_t)n_seg * 2 * sizeof(unsigned), 16) + (size_t)n_seg * OF_MAX_FLAG_ITERS * sizeof(unsigned) + 256;
 }
 
 // `iters` Sinkhorn iterations for every pair; the potentials (natural log, u[0..m], v[0..n]) are written to u_out + pair * uv_stride and
@@ -760,8 +818,16 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     A.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * A.pot_stride * nch * sizeof(float);
     B.part = reinterpret_cast<float *>(p); p += (size_t)n_seg * B.pot_stride * nparts * sizeof(float);
     unsigned *amax = reinterpret_cast<unsigned *>(p); p += round_up((size_t)n_seg * 2 * sizeof(unsigned), 16);
+    unsigned *flags = reinterpret_cast<unsigned *>(p); p += (size_t)n_seg * OF_MAX_FLAG_ITERS * sizeof(unsigned);
     Xchg X = {reinterpret_cast<unsigned long long *>(p), 0};
     const int units = n_seg * (int)ta;
+    const bool early = ot_flash_early_exit(-1) != 0 && iters <= OF_MAX_FLAG_ITERS;
+    if (g_iter_stats == nullptr) {
+        if (hipMalloc(&g_iter_stats, 2 * sizeof(unsigned long long)) != hipSuccess) return -1;
+        (void)hipMemsetAsync(g_iter_stats, 0, 2 * sizeof(unsigned long long), s);
+    }
+    if (early) (void)hipMemsetAsync(flags, 0, (size_t)n_seg * OF_MAX_FLAG_ITERS * sizeof(unsigned), s);
+    auto conv_of = [&](int it) { return early ? Conv{it > 0 ? flags + (it - 1) : nullptr, flags + it, OF_MAX_FLAG_ITERS} : Conv{nullptr, nullptr, 0}; };
     (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
     if (coop) (void)hipMemsetAsync(X.words, 0, (size_t)units * 64 * sizeof(unsigned long long), s);       // token 0 = nothing published
     hipLaunchKernelGGL(of_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, amax);      // 8 workgroups per (pair, side): 32 atomics each
@@ -769,30 +835,31 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     const dim3 gA((unsigned)((ta + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg), gB((unsigned)((tb + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg);
     const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);
     if (iters > 0) {                                   // every pair's first stabiliser: minus the row maxima
-        hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0);
-        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha, seg_tgt, 0);
+        hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0, Conv{nullptr, nullptr, 0});
+        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha, seg_tgt, 0, Conv{nullptr, nullptr, 0});
     }
     for (int it = 0; it < iters; ++it) {
+        const Conv cv = conv_of(it);
         if (variant >= 1 && variant <= 4) {            // measurements: the passes without exponentials / MFMAs / fragment loads / update launches
-            using Pass = void (*)(Side, Side, int, const int *, int);
+            using Pass = void (*)(Side, Side, int, const int *, int, Conv);
             const Pass pk = variant == 1 ? of_pass_kernel<false, OF_R, 1> : variant == 2 ? of_pass_kernel<false, OF_R, 2> : variant == 3 ? of_pass_kernel<false, OF_R, 3> : of_pass_kernel<false, OF_R>;
-            hipLaunchKernelGGL(pk, gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0);
-            hipLaunchKernelGGL(pk, gB, dim3(256), 0, s, B, A, nparts, seg_tgt, 0);
+            hipLaunchKernelGGL(pk, gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0, Conv{nullptr, nullptr, 0});
+            hipLaunchKernelGGL(pk, gB, dim3(256), 0, s, B, A, nparts, seg_tgt, 0, Conv{nullptr, nullptr, 0});
             continue;
         }
         if (any_fused) {                               // the row update and the strips' column sums in one launch; then the column update
             static const int fvar = getenv("ROREG_OT_FVAR") ? atoi(getenv("ROREG_OT_FVAR")) : 0;
             if (single) {                              // pairs with <= OF_HALF column tiles
-                using Kern = void (*)(Side, Side, int, int);
+                using Kern = void (*)(Side, Side, int, int, Conv);
                 static const Kern by_nt[OF_FT] = {of_iter_kernel<1>, of_iter_kernel<2>, of_iter_kernel<3>, of_iter_kernel<4>, of_iter_kernel<5>,
                                                   of_iter_kernel<6>, of_iter_kernel<7>, of_iter_kernel<8>, of_iter_kernel<9>, of_iter_kernel<10>};
                 const int nt = (int)tb > OF_HALF ? OF_FT : (int)(tb + OF_FW - 1) / OF_FW;        // column tiles per wave
                 Kern kern = by_nt[nt - 1];
                 if (fvar && nt == OF_FT) kern = fvar == 1 ? of_iter_kernel<OF_FT, 1> : fvar == 2 ? of_iter_kernel<OF_FT, 2> : fvar == 4 ? of_iter_kernel<OF_FT, 4> : fvar == 6 ? of_iter_kernel<OF_FT, 6> : fvar == 5 ? of_iter_kernel<OF_FT, 5> : fvar == 8 ? of_iter_kernel<OF_FT, 8> : kern;
-                hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts, it & 1);
+                hipLaunchKernelGGL(kern, dim3((unsigned)ta, n_seg), dim3(64 * OF_FW), 0, s, A, B, nparts, it, cv);
             }
             if (coop) {                                // pairs with more (ROREG_OT_COOP=1): two workgroups per strip
-                using Kern = void (*)(Side, Side, int, int, int, int, Xchg);
+                using Kern = void (*)(Side, Side, int, int, int, int, Xchg, Conv);
                 static const Kern by_nt[OF_FT / 2] = {of_iter_coop_kernel<2>, of_iter_coop_kernel<4>, of_iter_coop_kernel<6>, of_iter_coop_kernel<8>, of_iter_coop_kernel<10>};
                 const int tbc = (int)tb < 2 * OF_HALF ? (int)tb : 2 * OF_HALF;
                 const int nt1 = (tbc - OF_HALF + OF_FW - 1) / OF_FW;                 // the second half's column tiles per wave (instantiated for even counts)
@@ -800,21 +867,22 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
                 if (fvar == 6) kern = of_iter_coop_kernel<OF_FT, 6>;              // (tests: a full-length second half)
                 if (fvar == 7) kern = of_iter_coop_kernel<OF_FT, 7>;
                 X.token0 = 4 * it + 1;
-                hipLaunchKernelGGL(kern, dim3(2 * (unsigned)round_up(units, 8)), dim3(64 * OF_FW), 0, s, A, B, nparts, it & 1, (int)ta, units, X);
+                hipLaunchKernelGGL(kern, dim3(2 * (unsigned)round_up(units, 8)), dim3(64 * OF_FW), 0, s, A, B, nparts, it & 1, (int)ta, units, X, cv);
             }
             Side Anew = A;                             // (the column update's exact fall-back reads the row potentials just written)
             Anew.pot = (it & 1) ? A.pot : A.pot2;
-            hipLaunchKernelGGL(of_update_cols_kernel, dim3((max_n + 64) / 64, n_seg), dim3(256), 0, s, B, Anew, nparts, alpha, fused_le);
+            hipLaunchKernelGGL(of_update_cols_kernel, dim3((max_n + 64) / 64, n_seg), dim3(256), 0, s, B, Anew, nparts, alpha, fused_le, cv);
         }
         if (any_two) {                                 // the other pairs: rows, then columns (potentials updated in place)
-            hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch, seg_tgt, fused_le);
-            hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha, seg_tgt, fused_le);
-            hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nparts, seg_tgt, fused_le);
-            hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, OF_CHT, 3, alpha, seg_tgt, fused_le);
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gA, dim3(256), 0, s, A, B, nch, seg_tgt, fused_le, cv);
+            hipLaunchKernelGGL(of_update_kernel<false>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha, seg_tgt, fused_le, cv);
+            hipLaunchKernelGGL((of_pass_kernel<false, OF_R>), gB, dim3(256), 0, s, B, A, nparts, seg_tgt, fused_le, cv);
+            hipLaunchKernelGGL(of_update_kernel<false>, uB, dim3(256), 0, s, B, A, nparts, OF_CHT, 3, alpha, seg_tgt, fused_le, cv);
         }
     }
-    hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride, seg_tgt, fused_le, iters & 1);
-    hipLaunchKernelGGL(of_export_kernel, uB, dim3(256), 0, s, B, v_out, uv_stride, seg_tgt, fused_le, 0);
+    const unsigned *fl = early ? flags : nullptr;
+    hipLaunchKernelGGL(of_export_kernel, uA, dim3(256), 0, s, A, u_out, uv_stride, seg_tgt, fused_le, iters, fl, OF_MAX_FLAG_ITERS, g_iter_stats);
+    hipLaunchKernelGGL(of_export_kernel, uB, dim3(256), 0, s, B, v_out, uv_stride, seg_tgt, fused_le, iters, fl, OF_MAX_FLAG_ITERS, (unsigned long long *)nullptr);
     return 0;
 }
 

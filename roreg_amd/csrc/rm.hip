@@ -1399,6 +1399,14 @@ extern "C" int roreg_sinkhorn_batch2(const float *src_final, const float *tgt_fi
                                mscores0, mscores1, ws, ws_floats, recompute, nullptr, stream);
 }
 
+extern "C" int roreg_sinkhorn_early_exit(int on) { return roreg::ot_flash_early_exit(on); }
+
+extern "C" int roreg_sinkhorn_iteration_stats(long long *iterations, long long *pairs, int reset, void *stream) {
+    ROREG_REQUIRE(iterations && pairs, "roreg_sinkhorn_iteration_stats: null output pointer");
+    ROREG_REQUIRE(roreg::ot_flash_iteration_stats(iterations, pairs, reset, (hipStream_t)stream) == 0, "roreg_sinkhorn_iteration_stats: device copy failed");
+    return 0;
+}
+
 extern "C" int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const int32_t *seg_src, const int32_t *seg_tgt,
                                      const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                                      int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,

@@ -63,20 +63,35 @@ class StageFileWriter:
 
     byte for byte what the file-coupled stage classes write.  Off the critical path: a device tensor is copied to pinned host memory on
     a side stream (ordered after its producing kernels by an event), and a worker thread waits for that copy and calls np.save; the
-    engine never synchronises for it.  close() joins the worker (call it before reading the files)."""
+    engine never synchronises for it.  close() joins the worker (call it before reading the files).
 
-    def __init__(self, cfg, dataset_name, keynum):
+    clouds_dir (optional; `{cache}/{feature scene}`): the per-cloud stage files are written too --
+
+        {clouds_dir}/YOHO_Output_Group_feature/{pc}.npy       [N,32,60] f32   test/extractor.py:57  (every cloud the engine extracts)
+        {clouds_dir}/det_score/{pc}.npy                       [N] f32         test/detector.py:45-47 (every cloud it scores)
+
+    which makes the engine a complete stand-in for the stage chain of test/evaluator.py:39-48 (roreg_amd/test/evaluator.py)."""
+
+    def __init__(self, cfg, dataset_name, keynum, clouds_dir=None):
         import queue
         import threading
         from .utils.utils import make_non_exists_dir
         self.dir = f'{cfg.output_cache_fn}/{dataset_name}/match_{keynum}'
         for d in ('', '/scores', '/DR_index', '/Trans_pre'):
             make_non_exists_dir(self.dir + d)
+        self.clouds_dir = clouds_dir
+        if clouds_dir is not None:
+            make_non_exists_dir(f'{clouds_dir}/YOHO_Output_Group_feature')
+            if getattr(cfg, 'RD', False):
+                make_non_exists_dir(f'{clouds_dir}/det_score')
         self.stream = torch.cuda.Stream()
         self.q = queue.Queue()
         self.error = None
-        self.thread = threading.Thread(target=self._work, daemon=True)
-        self.thread.start()
+        # a few workers: np.save of a contiguous array is one fwrite with the GIL released, so the 38.4 MB feature files of a scene go to
+        # the page cache side by side (one worker wrote 60 of them in ~2 s, longer than the scene's kernels take)
+        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, int(os.environ.get('ROREG_WRITER_THREADS', 4))))]
+        for t in self.threads:
+            t.start()
 
     def _work(self):
         while True:
@@ -93,7 +108,9 @@ class StageFileWriter:
 
     def save(self, rel, a):
         """rel: path below match_{keynum}/ without '.npy'; a: device tensor or host ndarray (dtype as it must appear on disk)."""
-        path = f'{self.dir}/{rel}.npy'
+        self.save_path(f'{self.dir}/{rel}.npy', a)
+
+    def save_path(self, path, a):
         if not torch.is_tensor(a):
             self.q.put((path, np.ascontiguousarray(a), None))
             return
@@ -107,8 +124,10 @@ class StageFileWriter:
         self.q.put((path, host, done))
 
     def close(self):
-        self.q.put(None)
-        self.thread.join()
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
         if self.error is not None:
             raise self.error
 
@@ -626,7 +645,7 @@ class RegistrationEngine:
         return out
 
     def _scene_steps(self, feats, keys, pair_ids, keynum=None, max_iter=None, keep_matches=False, all_local_transforms=False, pair_seeds=None,
-                     writer=None, ready=None):
+                     writer=None, ready=None, host_svd=False):
         """Generator behind run_scene / run_scenes: yields the device tensors it needs on the host at each of the scene's two synchronisation
         points and is sent their numpy copies; returns [PairResult].
         feats/keys: dict or list indexed by int(pc_id); pair_ids: list of (id0,id1) strings.
@@ -639,6 +658,9 @@ class RegistrationEngine:
         every correspondence's local transform, like the reference's).
         ready: optional {int cloud id: CloudState} of clouds that need no extraction (received from their owner rank, or extracted for
         an earlier pair range of the same scene); the clouds this call extracts are added to it.
+        host_svd: close BOTH refinements of every pair with the reference's own LAPACK call on the host (one more launch + download per scene),
+        like the file-coupled estimator classes do -- the result files are then theirs bit for bit; default: the device's 3x3 Jacobi SVD
+        (<= 1e-10 from LAPACK's), host LAPACK only for rank-deficient covariances.
         Returns [PairResult]."""
         if writer is not None:
             all_local_transforms = True
@@ -655,9 +677,16 @@ class RegistrationEngine:
         clouds = {i: (have[i] if i in have else fresh[i]) for i in used}
         if ready is not None:
             ready.update(fresh)
+        if writer is not None and writer.clouds_dir is not None:         # the extractor's file contract: float32 whatever the storage type
+            for i in todo:
+                writer.save_path(f'{writer.clouds_dir}/YOHO_Output_Group_feature/{i}.npy', fresh[i].eqv.float())
         t0 = self._mark('extract', t0)
         if self.cfg.RD:
+            unscored = [i for i in used if clouds[i].det is None]
             yield from self._detect_steps([clouds[i] for i in used])
+            if writer is not None and writer.clouds_dir is not None:
+                for i in unscored:
+                    writer.save_path(f'{writer.clouds_dir}/det_score/{i}.npy', clouds[i].det)
             t0 = self._mark('detect', t0)
             yield from self._nms_steps([clouds[i] for i in used], keynum)
             t0 = self._mark('nms', t0)
@@ -718,7 +747,7 @@ class RegistrationEngine:
         # exactly those pairs through the host-LAPACK path so engine == stages == reference in that case too.
         from .test.estimator import _kabsch_host, _dev64
         deficient = hip.stats_rank_deficient_many(st_host).any(axis=1) if len(full) else np.zeros(0, bool)       # [pairs, 2 refinements]
-        redo = [i for i in range(len(full)) if i not in skipped and deficient[i]]
+        redo = [i for i in range(len(full)) if i not in skipped and (deficient[i] or host_svd)]
         if redo:                                                            # their second refinements in ONE launch, one download
             T1s = np.stack([_kabsch_host(st_host[i, 0]) for i in redo])
             st_redo = hip.refine_batch(rctx, redo, T1s, ird)[1].cpu().numpy()

@@ -248,6 +248,51 @@ def test_engine_writer_files_equal_the_stage_classes_files(tmp_path, RD, RM, ET)
             assert np.abs(r.trans - want['trans']).max() < 1e-10
 
 
+@pytest.mark.parametrize('RD,RM,ET', [(False, False, 'yohoo'), (True, True, 'yohoo'), (False, False, 'yohoc'), (True, False, 'yohoo')])
+def test_evaluator_on_the_engine_writes_the_stage_chains_files(tmp_path, monkeypatch, RD, RM, ET):
+    """`yoho_evaluator.process_scene` (test/evaluator.py:39-48: what an unchanged Test.py calls) runs on the device-resident engine when its
+    stages are the built-in classes; every file of the contract -- extractor outputs, detector scores, matches, scores, DR_index, Trans_pre
+    byte for byte, the result .npz by content, pre.log as text -- equals what the chain of stage.run() calls (ROREG_EVALUATOR=stages) writes
+    from the same generator stream; a second call finds the per-cloud files and reuses them (the reference's skip rule)."""
+    import filecmp
+    import glob
+    from types import SimpleNamespace as NS
+    from roreg_amd.test import _cache
+    from roreg_amd.test.evaluator import yoho_evaluator
+    z = load_golden('pipeline_rd_rm_yohoo' if RM else 'pipeline_mutual_yohoo')
+    cfg, ds = _setup(tmp_path, z, ET=ET, RD=RD, RM=RM, max_iter=1000)
+    keynum = int(z['keynum'])
+    roots = {}
+    for route in ('stages', 'engine'):
+        c = NS(**{**vars(cfg), 'output_cache_fn': f'{tmp_path}/cache_{route}'})
+        ds.write_inputs(c.output_cache_fn)
+        monkeypatch.setenv('ROREG_EVALUATOR', route)
+        _cache.clear()
+        ev = yoho_evaluator(c)
+        assert ev._engine_route() == (route == 'engine')
+        np.random.seed(77)
+        ev.process_scene(ds)
+        roots[route] = f'{c.output_cache_fn}/{ds.name}'
+        if route == 'engine':
+            before = {f: os.stat(f).st_mtime_ns for f in glob.glob(f'{roots[route]}/YOHO_Output_Group_feature/*.npy') + glob.glob(f'{roots[route]}/det_score/*.npy')}
+            np.random.seed(77)
+            ev.process_scene(ds)                                          # per-cloud files exist now: reused, not rewritten
+            assert before and all(os.stat(f).st_mtime_ns == t for f, t in before.items())
+    a, b = roots['stages'], roots['engine']
+    rel = sorted(os.path.relpath(f, a) for f in glob.glob(f'{a}/**/*.npy', recursive=True) if 'Input_Group_feature' not in f)
+    assert rel == sorted(os.path.relpath(f, b) for f in glob.glob(f'{b}/**/*.npy', recursive=True) if 'Input_Group_feature' not in f)
+    assert any(r.startswith('YOHO_Output_Group_feature') for r in rel) and any('DR_index' in r for r in rel) and (not RD or any(r.startswith('det_score') for r in rel))
+    for r in rel:
+        assert filecmp.cmp(f'{a}/{r}', f'{b}/{r}', shallow=False), r
+    rdir = f'match_{keynum}/{ET}/1000iters'
+    for p0, p1 in ds.pair_ids:
+        x, y = np.load(f'{a}/{rdir}/{p0}-{p1}.npz'), np.load(f'{b}/{rdir}/{p0}-{p1}.npz')
+        assert sorted(x.files) == sorted(y.files)
+        for k in x.files:
+            assert x[k].dtype == y[k].dtype and np.array_equal(x[k], y[k], equal_nan=True), (p0, p1, k)
+    assert open(f'{a}/{rdir}/pre.log').read() == open(f'{b}/{rdir}/pre.log').read()
+
+
 @pytest.mark.parametrize('kind', ['mutual+yohoo', 'mutual+yohoc', 'rd+rm+yohoo'])
 def test_run_scenes_pipelined_equals_one_scene_at_a_time(kind):
     """engine.run_scenes (the next scene's extraction and matcher enqueued before the host waits for this scene's match counts; downloads on

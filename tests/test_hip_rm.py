@@ -435,6 +435,66 @@ def test_sinkhorn_whole_iteration_kernel_sizes_and_stacking(mode):
     assert (d[0][300:] == a0[hs[1]:hs[1] + m]).mean() > 0.995 and np.abs(d[2][300:] - as0[hs[1]:hs[1] + m])[d[0][300:] == a0[hs[1]:hs[1] + m]].max() < 2e-5
 
 
+@pytest.mark.parametrize('mode', [True, 'coop'])
+def test_sinkhorn_early_exit_of_converged_pairs_equals_all_iterations(mode):
+    """Round 6 (include/roreg_hip.h, roreg_sinkhorn_early_exit): a pair's iterations stop once one of them moved none of its potentials by more
+    than 2 .. 4 float32 units in the last place -- the float32 fixed point; the reference's loop (rot_coh_match.py:289-292) runs on to 100 and
+    only flips last bits.  Stacked ragged pairs through every form of the iteration (whole-iteration kernel up to 2559 target points, two
+    passes / cooperating workgroups beyond, odd and even stopping iterations for the double-buffered row potentials): matches identical to
+    the all-iterations run, scores to 2e-5; the statistics show the saving; a pair's result is bitwise the same stacked and alone (the
+    flags are per pair); with 1 or 0 iterations nothing changes; widely spread scores (slow movers) still agree."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(61)
+    sizes = [(2500, 2500), (700, 1200), (20, 300), (2500, 90), (3000, 1000), (1000, 3000), (2600, 5000), (64, 5119), (5000, 5000), (33, 64)]
+    S, T = [], []
+    for q, (m, n) in enumerate(sizes):
+        sc = 0.5 if q == 4 else (0.25 if q % 3 else 0.2)              # (scores up to ~10 settle in 7 .. 40 iterations -- the matcher's own final descriptors do, at
+                                                                      #  scores within [-18, 7] -- other scales stop elsewhere; pair 4, scores up to ~45, never settles)
+        s = rng.standard_normal((m, 32)).astype(np.float32) * sc; t = rng.standard_normal((n, 32)).astype(np.float32) * sc
+        k = min(m, n) // 2
+        t[:k] = s[:k] * 3 + rng.standard_normal((k, 32)).astype(np.float32) * 0.05
+        S.append(s); T.append(t)
+
+    def run(idx, on, iters=100, alpha=1.5):
+        seg_s = hip.Segments([sizes[q][0] for q in idx]); seg_t = hip.Segments([sizes[q][1] for q in idx])
+        hip.sinkhorn_iteration_stats()
+        with hip.sinkhorn_early_exit(on):
+            out = hip.sinkhorn_batch(cu(np.concatenate([S[q] for q in idx])), cu(np.concatenate([T[q] for q in idx])), seg_s, seg_t, alpha, iters, recompute=mode)
+        return [x.cpu().numpy() for x in out], seg_s.host, seg_t.host, hip.sinkhorn_iteration_stats()
+
+    full, hs, ht, st_full = run(range(len(sizes)), False)
+    early, _, _, st_early = run(range(len(sizes)), True)
+    assert st_full == (100 * len(sizes), len(sizes))
+    assert st_early[1] == len(sizes) and 100 + 2 * (len(sizes) - 1) <= st_early[0] < 100 + 50 * (len(sizes) - 1), st_early    # (pair 4 runs them all)
+    print(f'[early exit, mode {mode}] iterations run: {st_early[0]} of {st_full[0]}')
+    for k in range(2):
+        assert np.array_equal(full[k], early[k]), k
+    for k in (2, 3):
+        assert np.abs(full[k] - early[k]).max() < 2e-5, k
+    stops = set()
+    for q in (1, 3, 4, 6, 8):                                         # stacked == alone, bit for bit, with the flags on
+        one, _, _, st1 = run([q], True)
+        m, n = sizes[q]
+        assert np.array_equal(early[0][hs[q]:hs[q] + m], one[0]) and np.array_equal(early[1][ht[q]:ht[q] + n], one[1])
+        assert np.array_equal(early[2][hs[q]:hs[q] + m], one[2]) and np.array_equal(early[3][ht[q]:ht[q] + n], one[3])
+        assert (st1[0] == 100) if q == 4 else (2 <= st1[0] < 60), (q, st1)
+        stops.add(st1[0])
+    print(f'[early exit] iterations run by pairs 1, 3, 4, 6, 8 alone: {sorted(stops)}')
+    for iters in (0, 1, 2, 3):                                        # nothing can stop before iteration 1 has been looked at
+        a = run([1, 9], False, iters)[0]; b = run([1, 9], True, iters)[0]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), iters
+    # widely spread scores: columns that underflow, potentials of several hundred -- both settings agree to the usual bar
+    m, n = 300, 260
+    src = rng.standard_normal((m, 32)).astype(np.float32); tgt = rng.standard_normal((n, 32)).astype(np.float32)
+    src[:, 0] = np.abs(src[:, 0]) + 1.0; tgt[::7, 0] = -150.0; tgt[3::7] *= 6.0
+    seg_s = hip.Segments([m]); seg_t = hip.Segments([n])
+    with hip.sinkhorn_early_exit(False):
+        a = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(src), cu(tgt), seg_s, seg_t, 1.0, 100, recompute=mode)]
+    with hip.sinkhorn_early_exit(True):
+        b = [x.cpu().numpy() for x in hip.sinkhorn_batch(cu(src), cu(tgt), seg_s, seg_t, 1.0, 100, recompute=mode)]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.abs(a[2] - b[2]).max() < 1e-4 and np.abs(a[3] - b[3]).max() < 1e-4
+
+
 @pytest.mark.parametrize('fvar,m,n', [(6, 2500, 2500), (6, 2500, 5000), (7, 3000, 4000), (7, 5000, 5000)])
 def test_sinkhorn_stabilised_redo_of_a_strip_gives_the_same_result(tmp_path, fvar, m, n):
     """of_iter_kernel redoes a strip with the row maxima as stabilisers when a row's sum leaves (1e-35, 1e35) -- which finite, sanely scaled

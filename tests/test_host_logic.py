@@ -24,7 +24,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(L, name), f'{name} declared in roreg_hip.h but not exported'
         assert name in hip.PROTOTYPES, f'{name} has no ctypes prototype'
     assert sorted(hip.PROTOTYPES) == declared
-    assert L.roreg_abi_version() == hip.ABI_VERSION == 5
+    assert L.roreg_abi_version() == hip.ABI_VERSION == 6
     assert int(re.search(r'#define\s+ROREG_ABI_VERSION\s+(\d+)', header).group(1)) == hip.ABI_VERSION
     # pure host entry points work without a GPU
     assert L.roreg_group_conv_packed_size(256, 512, 13) == 13 * 256 * 512
