@@ -701,7 +701,7 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
     n = args.rd_rm_steps
     step(engine=eng_rr)                                                          # warm-up at the timed depth
     hip.profile_enable(True); hip.WORK = {}; hip.sinkhorn_iteration_stats()
-    d, rows, _ = bracket(n, engine=eng_rr)
+    d, rows, _ = bracket(n, engine=eng_rr, keep_matches=True)
     sk_ms, sk_n = hip.profile_read('sinkhorn'); tk_ms, tk_n = hip.profile_read('topk_dot'); ft_ms, ft_n = hip.profile_read('ft_nonlin')
     work = hip.WORK; hip.WORK = None; hip.profile_enable(False)
     it_run, it_pairs = hip.sinkhorn_iteration_stats()
@@ -710,11 +710,22 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
     with hip.sinkhorn_early_exit(False):
         step(engine=eng_rr)
         hip.profile_enable(True); hip.WORK = {}
-        d_fix, rows_fix, _ = bracket(1, engine=eng_rr)
+        d_fix, rows_fix, _ = bracket(1, engine=eng_rr, keep_matches=True)
         skf_ms, skf_n = hip.profile_read('sinkhorn')
         work_fix = hip.WORK; hip.WORK = None; hip.profile_enable(False)
-    same_m = int(sum(1 for (_, a), (_, b) in zip(rows, rows_fix) if a.n_match == b.n_match))
-    dT = [float(np.abs(a.trans - b.trans).max()) for (_, a), (_, b) in zip(rows, rows_fix) if np.isfinite(a.trans).all() and np.isfinite(b.trans).all()]
+    # what stopping at the fixed point changes: the match lists (the index outputs), the matching scores, and -- where the pair registers at all on
+    # this synthetic data (most do not under the shipped RM weights, and a failed registration is a function of the scores' last bits) -- the transform
+    same_m = 0; dsc = []; dT_ok = []; n_ok = 0
+    for (sc, a), (_, b) in zip(rows, rows_fix):
+        same = a.n_match == b.n_match and torch.equal(a.matches, b.matches)
+        same_m += int(same)
+        if same and a.scores is not None and len(a.scores):
+            dsc.append(float(np.abs(a.scores - b.scores).max()))
+        gt = synth.pose_transform(scenes[sc][2], a.id0, a.id1)
+        good = lambda r: bool(np.isfinite(r.trans).all() and compute_R_diff(r.trans[:3, :3], gt[:3, :3]) < 15 and np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))) < 0.3)
+        if good(a) or good(b):
+            n_ok += 1
+            dT_ok.append(float(np.abs(a.trans - b.trans).max()) if good(a) and good(b) else float('inf'))
     step(engine=eng_rr, all_local_transforms=True)
     d_all, rows_all, _ = bracket(1, engine=eng_rr, all_local_transforms=True)
     same = all(np.array_equal(a.trans, b.trans, equal_nan=True) and a.recalltime == b.recalltime for (_, a), (_, b) in zip(rows, rows_all))
@@ -732,12 +743,15 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
                            'weights': weights + '; seeded GF / ET weights', 'steps': n, 'ms_per_step': 1e3 * d / n, 'ms_per_step_contract_complete': 1e3 * d_all,
                            'ms_per_step_all_sinkhorn_iterations': 1e3 * d_fix,
                            'sinkhorn': {'iterations_asked': 100, 'iterations_run_mean': it_run / max(it_pairs, 1), 'pairs': it_pairs // max(n, 1),
-                                        'rule': 'a pair stops once an iteration moved none of its potentials by more than max(2^-22 |u|, 2^-20) in log2 units (2 .. 4 float32 ulps): '
-                                                'the fixed point of the float32 iteration; roreg_sinkhorn_early_exit(0) runs all of them',
+                                        'rule': 'a pair stops at the fixed point of the float32 iteration: once an iteration\'s largest step of a potential is <= max(2^-22 |u|, 2^-20) in log2 '
+                                                'units (2 .. 4 float32 ulps), or <= 8 such units and no longer shrinking (>= 0.95 of the previous iteration\'s): the noise floor '
+                                                'of the recomputed scores; roreg_sinkhorn_early_exit(0) runs all of them',
                                         'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1) if sk_n else None,
                                         'ms_per_pair_all_iterations': skf_ms / max(work_fix.get('sinkhorn_pairs', 1), 1) if skf_n else None,
-                                        'pairs_with_the_same_match_count_as_all_iterations': same_m, 'pairs_compared': len(rows),
-                                        'max_abs_diff_of_transforms_vs_all_iterations': max(dT or [0.0])},
+                                        'pairs_with_identical_match_lists_to_all_iterations': same_m, 'pairs_compared': len(rows),
+                                        'max_abs_diff_of_matching_scores_on_those': max(dsc or [0.0]),
+                                        'pairs_registered_in_either_run': n_ok, 'of_those_registered_in_both': int(sum(1 for x in dT_ok if np.isfinite(x))),
+                                        'max_abs_diff_of_transforms_on_those': max([x for x in dT_ok if np.isfinite(x)] or [0.0])},
                            'results_identical_to_all_local_transforms': bool(same), 'mean_matches_rank0': float(np.mean([r.n_match for _, r in rows])) if rows else None,
                            'registration_recall_pointdsc_rank0': float(np.mean(ok)) if ok else None,
                            'stage_ms_one_synchronised_pass_rank0': phases,
@@ -784,23 +798,27 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
                            f'{n_clouds * args.kpts * 1920 * 4 / 1e9:.1f} GB of input features, page-cached', 'tmp': os.path.dirname(root)}
         before = os.environ.get('ROREG_EVALUATOR')
         for route in ('stages', 'engine'):
-            cache = f'{root}/cache_{route}'
-            os.makedirs(f'{cache}/{ds.name}')
-            os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
-            cfg = default_config(output_cache_fn=cache, model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, ET='yohoo')
             os.environ['ROREG_EVALUATOR'] = route
-            _cache.clear()
-            ev = yoho_evaluator(cfg)
-            if route == 'engine':
-                ev._engine().set_gemm_mode(args.gemm)
-            else:
-                hip.GEMM_MODE = args.gemm
-            np.random.seed(5)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            ev.process_scene(ds)
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            out[route] = {'pairs_per_s': n_pairs / dt, 's_per_scene': dt}
-            del ev
+            runs = []
+            for rep in range(2):                                  # the scene twice, into two fresh cache directories: the SECOND run is reported (a benchmark is 8 scenes;
+                cache = f'{root}/cache_{route}' if rep == 1 else f'{root}/cache_{route}_first'      # the first one also pays for the allocators' first pinned blocks)
+                os.makedirs(f'{cache}/{ds.name}')
+                os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
+                cfg = default_config(output_cache_fn=cache, model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, ET='yohoo')
+                _cache.clear()
+                ev = yoho_evaluator(cfg)
+                if route == 'engine':
+                    ev._engine().set_gemm_mode(args.gemm)
+                else:
+                    hip.GEMM_MODE = args.gemm
+                np.random.seed(5)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ev.process_scene(ds)
+                torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
+                del ev
+                if rep == 0:
+                    shutil.rmtree(cache, ignore_errors=True)
+            out[route] = {'pairs_per_s': n_pairs / runs[1], 's_per_scene': runs[1], 's_first_scene': runs[0]}
         if before is None:
             os.environ.pop('ROREG_EVALUATOR', None)
         else:

@@ -57,28 +57,45 @@ struct Side {                             // one side (source rows or target col
     const float *consts;                  // per pair (normc, log of the OTHER side's length): natural logs (roreg_sinkhorn_batch_consts)
 };
 
-// Per-pair convergence flags of the iterations (ot_flash_iterations): flag[pair][t] != 0 <=> iteration t ran and moved some potential of the
-// pair by more than OF_TOL_REL of its magnitude (2 .. 4 units in the last place of a float32).  Iteration t runs for a pair iff t == 0 or
-// flag[pair][t - 1] != 0: once an iteration has left every potential where it was (to float32 resolution) the pair has reached the fixed
-// point of the float32 iteration -- the reference's remaining iterations (network/rot_coh_match.py:289-292 always runs `iters` of them) only
-// move the last bits back and forth -- and every later launch returns at once for that pair.  The flags of an iteration that did not run
-// stay 0 (the array is cleared up front), which makes "done" sticky.  prev == nullptr: the pair's work always runs (early exit off,
-// iteration 0); cur == nullptr: nothing is recorded.  A pair's flags depend on its own data only.
+// Per-pair convergence record of the iterations (ot_flash_iterations): move[pair][t] = the largest step any of the pair's m + n + 2 potentials
+// took in iteration t, in units of OF_TOL (max(2^-22 |u|, 2^-20) in log2 units: 2 .. 4 units in the last place of the float32 potential), as
+// float bits; 0 for an iteration that did not run (the array is cleared up front).  Iteration t >= 1 is SKIPPED for a pair when
+//   (a) move[t-1] <= 1: nothing moved beyond float32 resolution, or
+//   (b) move[t-1] <= OF_PLATEAU_MAX and move[t-1] >= OF_PLATEAU_RATIO move[t-2]: the steps are small and have stopped shrinking -- the
+//       iteration has reached the noise floor of its own arithmetic (the scores come out of fp16 hi/lo MFMAs accumulated in float32 at
+//       magnitudes |Z| + |u| + |v| ~ 40: a step of one ulp in u re-rounds them, and the potentials then jitter by 3 .. 4 ulps for ever).
+// Either way the pair sits at the fixed point of the float32 iteration; the reference's loop (network/rot_coh_match.py:289-292 always runs
+// `iters` = 100 of them) only moves last bits from there on.  A geometric sequence still contracting by less than OF_PLATEAU_RATIO per
+// iteration cannot come from a first step of ~20 to OF_PLATEAU_MAX units within 100 iterations, so (b) does not cut a slow convergence
+// short.  Skipping is sticky (a skipped iteration records 0, which is (a) for the next one) and a pair's record depends on its own data only.
+// hist == nullptr: everything runs and nothing is recorded (early exit off).
 struct Conv {
-    const unsigned *prev;
-    unsigned *cur;
-    int stride;
+    unsigned *hist;                            // move[pair 0][0]; pair p's record at hist + p * stride
+    int t, stride;
+    float tol_rel, tol_abs;
 };
-constexpr float OF_TOL_REL = 0x1p-22f, OF_TOL_ABS = 0x1p-20f;
-__device__ __forceinline__ bool conv_done(const Conv &c, int pair) { return c.prev != nullptr && c.prev[(size_t)pair * c.stride] == 0u; }
-__device__ __forceinline__ void conv_note(const Conv &c, int pair, float np, float old) {
-    if (c.cur != nullptr && fabsf(np - old) > fmaxf(fabsf(np) * OF_TOL_REL, OF_TOL_ABS)) c.cur[(size_t)pair * c.stride] = 1u;
+constexpr float OF_TOL_REL = 0x1p-22f, OF_TOL_ABS = 0x1p-20f, OF_PLATEAU_MAX = 8.0f, OF_PLATEAU_RATIO = 0.95f;
+__device__ __forceinline__ bool conv_stop(const unsigned *rec, int t) {
+    if (t < 1) return false;
+    const float r1 = __uint_as_float(rec[t - 1]);
+    if (r1 <= 1.0f) return true;
+    return t >= 2 && r1 <= OF_PLATEAU_MAX && r1 >= OF_PLATEAU_RATIO * __uint_as_float(rec[t - 2]);
 }
-// iterations a pair has run: the first t >= 1 whose predecessor left the flag at 0, else all of them
-__device__ __forceinline__ int conv_executed(const unsigned *flags, int stride, int pair, int iters) {
-    if (flags == nullptr) return iters;
+__device__ __forceinline__ bool conv_done(const Conv &c, int pair) { return c.hist != nullptr && conv_stop(c.hist + (size_t)pair * c.stride, c.t); }
+// every lane of the wave calls this (np = old for lanes without a potential); one atomic per wave
+__device__ __forceinline__ void conv_note(const Conv &c, int pair, float np, float old) {
+    if (c.hist == nullptr) return;
+    float r = fabsf(np - old) / fmaxf(fabsf(np) * c.tol_rel, c.tol_abs);
+    if (!(r >= 0.f)) r = 0.f;                                         // (non-finite potentials do not steer the record)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
+    if ((threadIdx.x & 63) == 0 && r > 0.f) atomicMax(c.hist + (size_t)pair * c.stride + c.t, __float_as_uint(r));
+}
+// iterations a pair has run: the first t >= 1 that was skipped, else all of them
+__device__ __forceinline__ int conv_executed(const unsigned *hist, int stride, int pair, int iters) {
+    if (hist == nullptr) return iters;
     int t = iters > 0 ? 1 : 0;
-    while (t < iters && flags[(size_t)pair * stride + t - 1] != 0u) ++t;
+    while (t < iters && !conv_stop(hist + (size_t)pair * stride, t)) ++t;
     return t;
 }
 
@@ -348,11 +365,13 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
     if (conv_done(cv, pair)) return;
     const int lenA = a.seg[pair + 1] - a.seg[pair];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i > lenA) return;
-    const float *part = a.part + pair * (a.pot_stride * nch) + i;
+    if (blockIdx.x * 256 > lenA) return;
+    const bool live = i <= lenA;                                      // (lanes beyond the dustbin stay for conv_note's wave-wide reduction)
+    const int il = live ? i : lenA;
+    const float *part = a.part + pair * (a.pot_stride * nch) + il;
     const int nch_pair = ((b.seg[pair + 1] - b.seg[pair]) / 32 + 1 + cht - 1) / cht;      // the partial sums this pair's other side really has
     float *pot = a.pot + pair * a.pot_stride;
-    float np;
+    float np, old = 0.f;
     if (MAXP) {
         float mx = -__builtin_inff();
         for (int c = 0; c < nch_pair; ++c) mx = fmaxf(mx, part[(size_t)c * a.pot_stride]);
@@ -366,11 +385,13 @@ __global__ __launch_bounds__(256) void of_update_kernel(Side a, Side b, int nch,
 #pragma unroll
             for (int q = 0; q < 40; ++q) if (c0 + q < nch_pair) S += v[q];
         }
-        const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
-        if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
-        else np = exact_potential(a, b, pair, i, alpha, lmu);
-        conv_note(cv, pair, np, pot[i]);
+        const float lmu = (il == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
+        old = pot[il];
+        if (S > 1e-35f && S < 1e35f) np = old + (lmu - __log2f(S));
+        else np = exact_potential(a, b, pair, il, alpha, lmu);
+        conv_note(cv, pair, live ? np : 0.f, live ? old : 0.f);
     }
+    if (!live) return;
     pot[i] = np;
     store_pieces(a, pair, i, np, slot0);
 }
@@ -404,14 +425,19 @@ __global__ __launch_bounds__(256) void of_update_cols_kernel(Side a, Side b, int
     }
     s_q[q][lane] = S;
     __syncthreads();
-    if (q != 0 || i > lenA) return;
+    if (q != 0) return;
+    const bool live = i <= lenA;                                       // (wave 0 stays whole for conv_note's reduction)
+    const int il = live ? i : lenA;
     S = (s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]);
     float *pot = a.pot + pair * a.pot_stride;
-    const float lmu = (i == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
+    const float lmu = (il == lenA ? a.consts[pair * 2] + a.consts[pair * 2 + 1] : a.consts[pair * 2]) * LOG2E;
+    const float old = pot[il];
     float np;
-    if (S > 1e-35f && S < 1e35f) np = pot[i] + (lmu - __log2f(S));
-    else np = exact_potential(a, b, pair, i, alpha, lmu);
-    conv_note(cv, pair, np, pot[i]);
+    if (!live) np = old;
+    else if (S > 1e-35f && S < 1e35f) np = old + (lmu - __log2f(S));
+    else np = exact_potential(a, b, pair, il, alpha, lmu);
+    conv_note(cv, pair, np, old);
+    if (!live) return;
     pot[i] = np;
     store_pieces(a, pair, i, np, 3);
 }
@@ -646,6 +672,7 @@ __device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int n
     phase1(integral_constant<int, 0>{});
     // ---- the strip's row update: every wave evaluates it for itself (same LDS data, same result: no second barrier); wave 0 stores it ----
     float frow = 0.f;                                              // f of row lane % 32
+    float cn_np = 0.f, cn_old = 0.f;                               // (the step of this lane's row, for the convergence record)
     bool redo = false;
     if (VAR == 5) {
         frow = row_valid ? 1.f : 0.f;
@@ -656,7 +683,7 @@ __device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int n
         if (!redo && row_valid) {
             const float np = old + (lmu - __log2f(S));             // u + log2 mu - log2 sum_j 2^(Z' + u + v)
             frow = __builtin_amdgcn_exp2f(np - old);               // E f = 2^(Z' + u_new + v)
-            if (threadIdx.x < 32 && hb == 0) { pot[i_row] = np; conv_note(cv, pair, np, old); }
+            if (threadIdx.x < 32 && hb == 0) { pot[i_row] = np; cn_np = np; cn_old = old; }
         }
     }
     if (redo) {                                                    // rare: stabilised evaluation of the whole strip
@@ -672,9 +699,10 @@ __device__ __forceinline__ void of_iter_body(const Side &a, const Side &b, int n
             const float m = s_np[lane & 31];
             const float np = old + ((lmu - m) - __log2f(S));
             frow = __builtin_amdgcn_exp2f((np - old) + m);         // = mu_i / S_i: E f = 2^(Z' + u_new + v)
-            if (threadIdx.x < 32 && hb == 0) { pot[i_row] = np; conv_note(cv, pair, np, old); }
+            if (threadIdx.x < 32 && hb == 0) { pot[i_row] = np; cn_np = np; cn_old = old; }
         }
     }
+    if (w == 0) conv_note(cv, pair, cn_np, cn_old);                // (wave 0 whole: lanes 0 .. 31 of half 0 carry the strip's 32 steps)
     // ---- phase 2: the strip's part of the column sums ----
     float f[16];
 #pragma unroll
@@ -827,7 +855,8 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
         (void)hipMemsetAsync(g_iter_stats, 0, 2 * sizeof(unsigned long long), s);
     }
     if (early) (void)hipMemsetAsync(flags, 0, (size_t)n_seg * OF_MAX_FLAG_ITERS * sizeof(unsigned), s);
-    auto conv_of = [&](int it) { return early ? Conv{it > 0 ? flags + (it - 1) : nullptr, flags + it, OF_MAX_FLAG_ITERS} : Conv{nullptr, nullptr, 0}; };
+    static const float tol_scale = getenv("ROREG_OT_EXIT_TOL") ? (float)atof(getenv("ROREG_OT_EXIT_TOL")) : 1.0f;      // (measurements: multiples of the default tolerance)
+    auto conv_of = [&](int it) { return early ? Conv{flags, it, OF_MAX_FLAG_ITERS, OF_TOL_REL * tol_scale, OF_TOL_ABS * tol_scale} : Conv{nullptr, 0, 0, 0.f, 0.f}; };
     (void)hipMemsetAsync(amax, 0, sizeof(unsigned) * 2 * n_seg, s);
     if (coop) (void)hipMemsetAsync(X.words, 0, (size_t)units * 64 * sizeof(unsigned long long), s);       // token 0 = nothing published
     hipLaunchKernelGGL(of_absmax_kernel, dim3(8, 2 * n_seg), dim3(256), 0, s, A, B, amax);      // 8 workgroups per (pair, side): 32 atomics each
@@ -835,16 +864,16 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
     const dim3 gA((unsigned)((ta + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg), gB((unsigned)((tb + 4 * OF_R - 1) / (4 * OF_R)), nch, n_seg);
     const dim3 uA((max_m + 256) / 256, n_seg), uB((max_n + 256) / 256, n_seg);
     if (iters > 0) {                                   // every pair's first stabiliser: minus the row maxima
-        hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0, Conv{nullptr, nullptr, 0});
-        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha, seg_tgt, 0, Conv{nullptr, nullptr, 0});
+        hipLaunchKernelGGL((of_pass_kernel<true, OF_R>), gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0, Conv{nullptr, 0, 0, 0.f, 0.f});
+        hipLaunchKernelGGL(of_update_kernel<true>, uA, dim3(256), 0, s, A, B, nch, OF_CHT, 0, alpha, seg_tgt, 0, Conv{nullptr, 0, 0, 0.f, 0.f});
     }
     for (int it = 0; it < iters; ++it) {
         const Conv cv = conv_of(it);
         if (variant >= 1 && variant <= 4) {            // measurements: the passes without exponentials / MFMAs / fragment loads / update launches
             using Pass = void (*)(Side, Side, int, const int *, int, Conv);
             const Pass pk = variant == 1 ? of_pass_kernel<false, OF_R, 1> : variant == 2 ? of_pass_kernel<false, OF_R, 2> : variant == 3 ? of_pass_kernel<false, OF_R, 3> : of_pass_kernel<false, OF_R>;
-            hipLaunchKernelGGL(pk, gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0, Conv{nullptr, nullptr, 0});
-            hipLaunchKernelGGL(pk, gB, dim3(256), 0, s, B, A, nparts, seg_tgt, 0, Conv{nullptr, nullptr, 0});
+            hipLaunchKernelGGL(pk, gA, dim3(256), 0, s, A, B, nch, seg_tgt, 0, Conv{nullptr, 0, 0, 0.f, 0.f});
+            hipLaunchKernelGGL(pk, gB, dim3(256), 0, s, B, A, nparts, seg_tgt, 0, Conv{nullptr, 0, 0, 0.f, 0.f});
             continue;
         }
         if (any_fused) {                               // the row update and the strips' column sums in one launch; then the column update

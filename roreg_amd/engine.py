@@ -132,6 +132,19 @@ class StageFileWriter:
             raise self.error
 
 
+class _LazySeq:
+    """[container[i] for i in ids] evaluated item by item, when asked (extract_many fetches a batch's clouds right before their launch)."""
+
+    def __init__(self, container, ids):
+        self.container, self.ids = container, ids
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, q):
+        return self.container[self.ids[q]]
+
+
 def even_groups(sizes, cap):
     """Consecutive groups [(i, j)] of `sizes` whose sums stay <= cap (a single item above the cap is a group of its own), EVEN in size:
     100 pairs of 2500 points under a cap of 80,000 are 4 x 25, not 32 + 32 + 32 + 4 -- a small last group leaves most of the chip idle, and
@@ -223,31 +236,39 @@ class RegistrationEngine:
         def on_device(f):                                        # (tensors that already sit on the device in the storage type pass untouched:
             if torch.is_tensor(f) and f.is_cuda and f.dtype == self.feat_dtype:      #  a no-op `.to()` still costs ~60 us of host time each)
                 return f
+            if torch.is_tensor(f) and not f.is_cuda and f.is_pinned():               # (a pinned host tensor -- the evaluator's prefetching loader -- goes up asynchronously)
+                return f.to('cuda', non_blocking=True).to(torch.float32).to(self.feat_dtype)
             return (f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, np.float32))).to('cuda', torch.float32).to(self.feat_dtype)
-        xs = [on_device(f) for f in feats_list]
         out = []
         i = 0
-        while i < len(xs):
+        n_all = len(keys_list)
+        fetched = {}                                             # (a lazy mapping -- files behind it -- is asked for each cloud once)
+        def get(q):
+            if q not in fetched:
+                fetched[q] = feats_list[q]
+            return fetched[q]
+        while i < n_all:
             j, rows = i, 0
-            while j < len(xs) and (j == i or rows + xs[j].shape[0] <= max_rows):
-                rows += xs[j].shape[0]; j += 1
+            while j < n_all and (j == i or rows + int(get(j).shape[0]) <= max_rows):
+                rows += int(get(j).shape[0]); j += 1
+            xs = [on_device(fetched.pop(q)) for q in range(i, j)]      # uploaded batch by batch: the next batch's host reads run under this batch's kernels
             # clouds that already sit back to back in one allocation (bench.py's device-generated scenes, a preloaded scene buffer) are
             # used in place; otherwise one concatenating copy
-            adjacent = all(xs[q].is_contiguous() and xs[q].dtype == xs[i].dtype and xs[q].untyped_storage().data_ptr() == xs[i].untyped_storage().data_ptr() and
-                           xs[q].data_ptr() == xs[q - 1].data_ptr() + xs[q - 1].numel() * xs[q - 1].element_size() for q in range(i + 1, j)) and xs[i].is_contiguous()
+            adjacent = all(xs[q].is_contiguous() and xs[q].dtype == xs[0].dtype and xs[q].untyped_storage().data_ptr() == xs[0].untyped_storage().data_ptr() and
+                           xs[q].data_ptr() == xs[q - 1].data_ptr() + xs[q - 1].numel() * xs[q - 1].element_size() for q in range(1, j - i)) and xs[0].is_contiguous()
             if j - i == 1:
-                xcat = xs[i].contiguous()
+                xcat = xs[0].contiguous()
             elif adjacent:
-                xcat = torch.as_strided(xs[i], (rows, 32, 60), (1920, 60, 1))
+                xcat = torch.as_strided(xs[0], (rows, 32, 60), (1920, 60, 1))
             else:
-                xcat = torch.cat(xs[i:j], 0)
+                xcat = torch.cat(xs, 0)
             with torch.no_grad():
                 eqv = self.gf.PartI_net(xcat, want_inv=False, out_dtype=self.feat_dtype)['eqv']
             inv = hip.inv_descriptor(eqv)
             eft = hip.feat_coefs(eqv)
             o = 0
             for q in range(i, j):
-                n = xs[q].shape[0]
+                n = xs[q - i].shape[0]
                 k = keys_list[q]
                 k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
                 if not (k.is_cuda and k.dtype == torch.float64 and k.is_contiguous()):
@@ -673,7 +694,7 @@ class RegistrationEngine:
         used = sorted({int(i) for p in pair_ids for i in p})
         have = {} if ready is None else ready
         todo = [i for i in used if i not in have]
-        fresh = dict(zip(todo, self.extract_many([feats[i] for i in todo], [keys[i] for i in todo])))
+        fresh = dict(zip(todo, self.extract_many(_LazySeq(feats, todo), [keys[i] for i in todo])))
         clouds = {i: (have[i] if i in have else fresh[i]) for i in used}
         if ready is not None:
             ready.update(fresh)

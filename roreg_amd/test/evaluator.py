@@ -92,10 +92,28 @@ class yoho_evaluator:
         used = sorted({int(i) for p in dataset.pair_ids for i in p})
         print(f'Registering {len(dataset.pair_ids)} pairs of {dataset.name} on the device-resident engine (stage files are written asynchronously)')
 
-        class Inputs:                                            # {cloud id: [N,32,60] float32}, read when the engine uploads the cloud
-            def __getitem__(_, i):
-                return np.load(files.input_feature(int(i)), mmap_mode='r')
-        feats = Inputs()
+        class Inputs:
+            """{cloud id: [N,32,60] float32 pinned host tensor}: a few threads copy the scene's input files (page cache -> pinned memory, the GIL
+            released) ahead of the engine, which uploads a cloud asynchronously right before the extractor launch that needs it"""
+
+            def __init__(self, ids):
+                import torch
+                from concurrent.futures import ThreadPoolExecutor
+                self.pool = ThreadPoolExecutor(max(1, int(os.environ.get('ROREG_LOADER_THREADS', 4))))
+
+                def read(i):
+                    src = np.load(files.input_feature(int(i)), mmap_mode='r')
+                    dst = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+                    np.copyto(dst.numpy(), src, casting='same_kind')
+                    return dst
+                self.jobs = {i: self.pool.submit(read, i) for i in ids}
+
+            def __getitem__(self, i):
+                return self.jobs[int(i)].result()
+
+            def close(self):
+                self.pool.shutdown(wait=True)
+        feats = Inputs(ids)
         keys = {i: dataset.get_kps(str(i)) for i in ids}
         writer = StageFileWriter(cfg, dataset.name, self.keynum, clouds_dir=files.clouds)
         files.make(files.result_dir(self.ET, self.max_iter))
@@ -119,6 +137,7 @@ class yoho_evaluator:
             res = eng.run_scene(feats, keys, dataset.pair_ids, keynum=self.keynum, max_iter=self.max_iter, writer=writer, ready=ready, host_svd=True)
         finally:
             writer.close()
+            feats.close()
         for r in res:
             extra_kw = {'center': np.ones([6, 3])} if (self.ET == 'yohoc' and r.recalltime == 50000) else {}
             np.savez(files.result(self.ET, self.max_iter, r.id0, r.id1), trans=r.trans, **extra_kw, recalltime=r.recalltime)
