@@ -800,8 +800,10 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
         for route in ('stages', 'engine'):
             os.environ['ROREG_EVALUATOR'] = route
             runs = []
-            for rep in range(2):                                  # the scene twice, into two fresh cache directories: the SECOND run is reported (a benchmark is 8 scenes;
-                cache = f'{root}/cache_{route}' if rep == 1 else f'{root}/cache_{route}_first'      # the first one also pays for the allocators' first pinned blocks)
+            phases = None
+            for rep in range(3 if route == 'engine' else 2):      # the scene twice, into two fresh cache directories: the SECOND run is reported (a benchmark is 8 scenes;
+                cache = f'{root}/cache_{route}' if rep == 1 else f'{root}/cache_{route}_{rep}'      # the first one also pays for the allocators' first pinned blocks);
+                                                                  # the engine route a third time with synchronised stage marks (diagnostics, not reported as a rate)
                 os.makedirs(f'{cache}/{ds.name}')
                 os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
                 cfg = default_config(output_cache_fn=cache, model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, ET='yohoo')
@@ -809,16 +811,26 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
                 ev = yoho_evaluator(cfg)
                 if route == 'engine':
                     ev._engine().set_gemm_mode(args.gemm)
+                    if rep == 2:
+                        ev._engine().phase_ms = {}
                 else:
                     hip.GEMM_MODE = args.gemm
                 np.random.seed(5)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 ev.process_scene(ds)
                 torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
+                if rep == 1:
+                    split = getattr(ev, 'last_scene_seconds', None)
+                if rep == 2:
+                    phases = {k: round(v, 1) for k, v in ev._engine().phase_ms.items()}
                 del ev
-                if rep == 0:
+                if rep != 1:
                     shutil.rmtree(cache, ignore_errors=True)
             out[route] = {'pairs_per_s': n_pairs / runs[1], 's_per_scene': runs[1], 's_first_scene': runs[0]}
+            if split:
+                out[route]['seconds'] = {k: round(v, 3) for k, v in split.items()}
+            if phases:
+                out[route]['stage_ms_one_synchronised_run'] = phases
         if before is None:
             os.environ.pop('ROREG_EVALUATOR', None)
         else:
@@ -837,6 +849,17 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
         out['files'] = {'npy_files_compared_byte_for_byte': len(rel), 'npy_files_that_differ': len(differ) + len(set(rel_b) - set(rel)), 'result_npz_compared': len(res),
                         'result_npz_that_differ': len(res_differ), 'bytes_written_per_route': int(sum(os.path.getsize(f'{a}/{r}') for r in rel)),
                         'examples_of_differing_files': (differ + res_differ)[:4]}
+        # what the temporary directory takes: the scene's extractor outputs (60 x 38.4 MB) through np.save on four threads, from memory
+        from concurrent.futures import ThreadPoolExecutor
+        blob = np.zeros((args.kpts, 32, 60), np.float32)
+        os.makedirs(f'{root}/io_probe')
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(4) as pool:
+            list(pool.map(lambda i: np.save(f'{root}/io_probe/{i}.npy', blob), range(n_clouds)))
+        dt_io = time.perf_counter() - t0
+        out['files']['np_save_of_the_extractor_outputs_alone_s'] = round(dt_io, 3)
+        out['files']['np_save_GB_per_s'] = round(n_clouds * blob.nbytes / dt_io / 1e9, 2)
+        shutil.rmtree(f'{root}/io_probe', ignore_errors=True)
         # the engine alone, inputs resident in HBM, the same per-pair work (every correspondence's local transform), no files
         cfg = default_config(keynum=args.kpts, max_iter=1000, ET='yohoo')
         gf = name2network['GF_test'](cfg); gf.load_state_dict(gf_sd)
@@ -849,6 +872,11 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
         eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=True)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         out['no_files'] = {'pairs_per_s': n_pairs / dt, 's_per_scene': dt}
+        eng.phase_ms = {}
+        np.random.seed(5)
+        eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=True)
+        out['no_files']['stage_ms_one_synchronised_run'] = {k: round(v, 1) for k, v in eng.phase_ms.items()}
+        eng.phase_ms = None
         out['engine_over_stages'] = out['engine']['pairs_per_s'] / out['stages']['pairs_per_s']
         out['engine_over_no_files'] = out['engine']['pairs_per_s'] / out['no_files']['pairs_per_s']
         return out

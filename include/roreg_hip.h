@@ -453,6 +453,18 @@ int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const 
                           const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                           int recompute, float *Z_out, void *stream);
+/* v6: mlp_2layer / Contextnorm (network/rot_coh_match.py:14-32, 63-81): the first convolution (Cin -> C1, output h [L, C1]) and the residual
+ * branch (Cin -> 32, output y [L, 32]) in ONE launch -- the float32 fmaf chains of roreg_linear on the matrix cores, bit for bit, the input tile
+ * staged once, the next tile's rows in flight under the chains -- plus the per-pair InstanceNorm statistics of h (mean_rstd [n_seg][2 C1], the
+ * operand of roreg_mlp_tail) from per-tile float64 channel sums added in a fixed per-pair order: roreg_instnorm_stats' numbers in another
+ * association (float64 sums rounded to float32: the same floats but for an ulp once in ~1e8 values).  x [L, Cin], or x == NULL and
+ * pos / table / idx / conf (m, k; L = m k; Cin = 96): the value MLP's rows as in roreg_linear_cat3.  Served: (Cin, C1) = (3, 64), (64, 64),
+ * (96, 64), (120, 128) on the matrix-core path; returns 3 and launches nothing otherwise (call roreg_linear x 2 + roreg_instnorm_stats).
+ * ws: roreg_mlp_head_workspace(L, n_seg, C1) doubles. */
+size_t roreg_mlp_head_workspace(int L, int n_seg, int C1);
+int roreg_mlp_head(const float *x, const float *pos, const float *table, const int64_t *idx, const float *conf, int m, int k, int L, int Cin,
+                   const float *W1, const float *b1, int C1, const float *Wr, const float *br, float *h, float *y, const int32_t *seg_off,
+                   int n_seg, int mult, float eps, float *mean_rstd, double *ws, void *stream);
 /* v6: the recomputed iterations stop PER PAIR at the fixed point of the float32 iteration u <- log_mu - LSE(Z + v), v <- log_nu - LSE(Z + u)
  * (network/rot_coh_match.py:285-292).  Every iteration records the largest step any of the pair's m + n + 2 potentials took, in units of
  * max(2^-22 |u|, 2^-20) (log2 units: 2 .. 4 units in the last place of the float32 potential); the pair's remaining iterations are skipped once

@@ -10,7 +10,7 @@ import torch
 from . import hip as _core
 from .hip import HipError, _check, _ptr, _stream, ensure_des2r, ensure_tables, lib, upload
 
-__all__ = ['Cat3Rows', 'OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'sinkhorn_early_exit', 'sinkhorn_iteration_stats', 'topk_dot', 'value_input', 'vector_pipe_layers']
+__all__ = ['Cat3Rows', 'OT_COOP', 'OT_RECOMPUTE', 'Segments', '_rm_op', 'concat_rows', 'context_with_colmax', 'group_corr', 'knn_attention', 'knn_coor', 'l2_normalize_rows', 'linear', 'matrix_core_layers', 'mean_over_group', 'round5_chain_layers', 'mlp_instnorm', 'sinkhorn', 'sinkhorn_batch', 'sinkhorn_early_exit', 'sinkhorn_iteration_stats', 'topk_dot', 'value_input', 'vector_pipe_layers']
 
 
 def group_corr(perm_feats, bcast_feats, perm_rows=None, bcast_rows=None, transpose=False, want_idx=False, perm_coefs=None, bcast_coefs=None):
@@ -108,6 +108,18 @@ class vector_pipe_layers:
         return False
 
 
+class round5_chain_layers:
+    """`with hip.round5_chain_layers():` -- the matrix-core fmaf chains through round 5's kernels (one launch per convolution, no software
+    pipeline, roreg_instnorm_stats for the statistics): roreg_linear_path(2); tests and A/B measurements."""
+
+    def __enter__(self):
+        self.prev = lib().roreg_linear_path(2)
+
+    def __exit__(self, *exc):
+        lib().roreg_linear_path(self.prev)
+        return False
+
+
 class Cat3Rows:
     """The value MLP's input rows [m * k, 96] = [pos[r] | table[idx[r]] | conf[r // k]] WITHOUT the tensor (value_input): linear() hands the three
     sources to roreg_linear_cat3, whose row staging assembles them (same chains on the same values: bitwise linear(materialise(), ...));
@@ -131,7 +143,7 @@ def linear(x, W, b):
     """x [L,Cin] -> [L,Cout]; W [Cout,Cin], b [Cout] device float32."""
     if isinstance(x, Cat3Rows):
         Cout = W.shape[0]
-        if MATRIX_CORE_LAYERS or Cout not in (64, 32) or lib().roreg_linear_path(-1) != 0:
+        if MATRIX_CORE_LAYERS or Cout not in (64, 32) or lib().roreg_linear_path(-1) == 1:
             x = x.materialise()
         else:
             y = torch.empty((x.shape[0], Cout), dtype=torch.float32, device=x.device)
@@ -148,19 +160,38 @@ def linear(x, W, b):
 
 def mlp_instnorm(x, W1, b1, W2, b2, Wr, br, eps=1e-5, seg=None):
     """mlp_2layer / Contextnorm: conv -> InstanceNorm -> ReLU -> conv, plus the residual conv.  x [L,Cin] -> [L,32].
-    seg (Segments of the points; L = mult * seg.total rows): the InstanceNorm statistics are per pair."""
+    seg (Segments of the points; L = mult * seg.total rows): the InstanceNorm statistics are per pair.
+    Default path: roreg_mlp_head (first conv + residual conv in one launch, the statistics of h from its tiles' channel sums) and
+    roreg_mlp_tail; other paths / shapes: the two convs, roreg_instnorm_stats, the tail."""
     L = x.shape[0]
-    h = linear(x, W1, b1)
-    C = h.shape[1]
+    C = W1.shape[0]
     n_seg = seg.n if seg is not None else 1
     mult = L // seg.total if seg is not None else 1
     if seg is not None and mult * seg.total != L:
         raise HipError('mlp_instnorm: rows are not a multiple of the segmented points')
     sg = (_ptr(seg.dev, torch.int32) if seg is not None else None, n_seg, mult)
-    stats = torch.empty(n_seg * 2 * C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(n_seg * 2 * C * 256, dtype=torch.float64, device=x.device)
-    _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), *sg, _stream()), 'roreg_instnorm_stats')
-    y = linear(x, Wr, br)
+    dev = x.device
+    stats = torch.empty(n_seg * 2 * C, dtype=torch.float32, device=dev)
+    h = y = None
+    if not MATRIX_CORE_LAYERS and Wr.shape[0] == 32:
+        cat = isinstance(x, Cat3Rows)
+        h = torch.empty((L, C), dtype=torch.float32, device=dev); y = torch.empty((L, 32), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib().roreg_mlp_head_workspace(L, n_seg, C), dtype=torch.float64, device=dev)
+        if cat:
+            args = (None, _ptr(x.pos, torch.float32), _ptr(x.table, torch.float32), _ptr(x.idx, torch.int64), _ptr(x.conf, torch.float32), x.m, x.k, L, 96)
+        else:
+            args = (_ptr(x, torch.float32), None, None, None, None, 0, 0, L, x.shape[1])
+        rc = lib().roreg_mlp_head(*args, _ptr(W1, torch.float32), _ptr(b1, torch.float32), C, _ptr(Wr, torch.float32), _ptr(br, torch.float32), _ptr(h), _ptr(y),
+                                  *sg, float(eps), _ptr(stats), _ptr(ws), _stream())
+        if rc == 3:                                             # a shape or path the fused head does not serve
+            h = y = None
+        else:
+            _check(rc, 'roreg_mlp_head')
+    if h is None:
+        h = linear(x, W1, b1)
+        ws = torch.empty(n_seg * 2 * C * 256, dtype=torch.float64, device=dev)
+        _check(lib().roreg_instnorm_stats(_ptr(h), L, C, float(eps), _ptr(stats), _ptr(ws), *sg, _stream()), 'roreg_instnorm_stats')
+        y = linear(x, Wr, br)
     tail = lib().roreg_mlp_tail_mfma if MATRIX_CORE_LAYERS else lib().roreg_mlp_tail
     _check(tail(_ptr(h), L, C, _ptr(stats), _ptr(W2, torch.float32), _ptr(b2, torch.float32), _ptr(y), *sg, _stream()), 'roreg_mlp_tail')
     return y

@@ -65,6 +65,16 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
 
 // the matcher's 1x1 layers as float32 fmaf chains on the matrix cores (csrc/linear_chain.hip; bitwise the vector-pipe kernels): true = shape served
 bool linear_chain(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);
+// round 6: the same chains software-pipelined (lc2_kernel); mlp_head_chain = first convolution + residual branch of mlp_2layer in one launch + the per-pair
+// InstanceNorm statistics of h from the tiles' float64 channel sums (cat3_* non-null: the value MLP's assembled [m k, 96] rows)
+bool linear_chain2_on();
+void linear_chain2_set(bool on);
+bool linear_chain2(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);
+bool linear_tail_chain2(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,
+                        int mult, hipStream_t s);
+bool mlp_head_chain(const float *x, const float *cat3_table, const int64_t *cat3_idx, const float *cat3_conf, int cat3_k, int L, int Cin, const float *W1,
+                    const float *b1, int C1, const float *Wr, const float *br, float *h, float *y, const int *seg_off, int n_seg, int mult, float eps,
+                    float *mean_rstd, double *part, hipStream_t s);
 bool linear_chain_cat3(const float *x, const float *table, const int64_t *idx, const float *conf, int m, int k, const float *W, const float *b, int Cout,
                        float *y, hipStream_t s);
 bool linear_tail_chain(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,

@@ -145,6 +145,226 @@ void launch_chain(const float *x, int L, const float *W, const float *b, const f
     hipLaunchKernelGGL((linear_chain_kernel<CIN, COUT, NORM, ACCUM, CAT3>), dim3(grid), dim3(256), smem, s, x, L, W, b, mean_rstd, y, seg_off, n_seg, mult, tiles, cat);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same chains, software-pipelined, with the two convolutions that read one input in ONE launch.
+//
+// mlp_2layer (rot_coh_match.py:14-32) applies two 1x1 convolutions to the same input -- the first layer (CIN -> C1, its output h goes through
+// InstanceNorm) and the residual branch (CIN -> C2 = 32) -- and then needs h's per-pair channel statistics.  lc2_kernel stages a 128-row tile
+// once and runs the chains of both weight sets on it (y1 = W1 x + b1, y2 = W2 x + b2: the same fmaf chains as before, bit for bit); with
+// STATS it also leaves the tile's float64 channel sums of y1, so no kernel reads h again for the statistics (in_stats_partial_kernel read
+// 61 MB per 5000-point pair and k = 16).  Tiles never straddle two pairs (a pair's statistics then associate the same way whatever is stacked
+// beside it): tile t of segment s covers rows [off[s] mult + 128 t, ...).  Per tile: the NEXT tile's rows are requested from global memory
+// into registers before the chains start and land under them (the round-5 kernel loaded, waited, staged, synchronised and only then
+// multiplied: 16-25 % of the float32 MFMA rate on the 96-wide layers); with ACCUM the sixteen old values per output tile are requested there too.
+struct LcSegs { const int *off; int n_seg, mult, L; };
+
+__device__ __forceinline__ int lc_seg_rows(const LcSegs &sg, int s) { return sg.off ? (sg.off[s + 1] - sg.off[s]) * sg.mult : sg.L; }
+__device__ __forceinline__ int lc_total_tiles(const LcSegs &sg) {
+    int n = 0;
+    for (int s = 0; s < sg.n_seg; ++s) n += (lc_seg_rows(sg, s) + LC_ROWS - 1) / LC_ROWS;
+    return n;
+}
+// tile t (>= the tile the cursor stands on) -> (first row, rows, segment); the cursor (segment, its first tile) only moves forward
+__device__ __forceinline__ void lc_locate(const LcSegs &sg, int t, int &cs, int &cbase, int &row0, int &nrows) {
+    for (;;) {
+        const int len = lc_seg_rows(sg, cs), nt = (len + LC_ROWS - 1) / LC_ROWS;
+        if (t < cbase + nt || cs + 1 >= sg.n_seg) {
+            const int r = (t - cbase) * LC_ROWS;
+            row0 = (sg.off ? sg.off[cs] * sg.mult : 0) + r;
+            nrows = min(LC_ROWS, len - r);
+            return;
+        }
+        cbase += nt; ++cs;
+    }
+}
+
+template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS>
+__global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+                                                  const float *__restrict__ b2, const float *__restrict__ mean_rstd, float *__restrict__ y1, float *__restrict__ y2,
+                                                  double *__restrict__ part, LcSegs sg, Cat3 cat) {
+    static_assert(!CAT3 || (CIN == 96 && !NORM), "CAT3: three 32-wide sources");
+    static_assert(C1 % 32 == 0 && C2 % 32 == 0 && (!ACCUM || C2 == 0), "lc2_kernel: outputs in tiles of 32");
+    constexpr int KP = (CIN + 1) & ~1, KS = KP / 2, NT1 = C1 / 32, NT = (C1 + C2) / 32, PITCH = KP + 1;
+    constexpr bool VEC = CIN % 4 == 0;
+    constexpr int C4 = VEC ? CIN / 4 : 1, NV = VEC ? (LC_ROWS * C4 + 255) / 256 : (LC_ROWS * KP + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char lc_smem[];
+    float *wf = reinterpret_cast<float *>(lc_smem);                      // [NT][KS][64]
+    float *xs = wf + NT * KS * 64;                                        // [LC_ROWS][PITCH]
+    __shared__ double s_st[STATS ? 4 : 1][STATS ? C1 : 1][2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int f = tid; f < NT * KS * 64; f += 256) {
+        const int l = f & 63, j = (f >> 6) % KS, nt = f / (64 * KS);
+        const int o = nt * 32 + (l & 31), c = 2 * j + (l >> 5);
+        wf[f] = c < CIN ? (o < C1 ? W1[o * CIN + c] : W2[(o - C1) * CIN + c]) : 0.f;
+    }
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = nt < NT1 ? b1[nt * 32 + (lane & 31)] : b2[(nt - NT1) * 32 + (lane & 31)];
+    const int total = lc_total_tiles(sg);
+    int cs = 0, cbase = 0;                                                // the tile cursor
+    // ---- the rows of a tile, 16 bytes per thread and trip, into registers ----
+    float4 pre[VEC ? NV : 1];
+    float pre1[VEC ? 1 : NV];
+    auto fetch = [&](int row0, int nrows) {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int f = tid + 256 * q;
+                const int row = f / C4, c4 = f - row * C4;
+                const int pr = row0 + min(row, nrows - 1);               // (rows past the tile's end repeat its last row: never stored)
+                if (LC_ROWS * C4 % 256 != 0 && f >= LC_ROWS * C4) { pre[q] = float4{0.f, 0.f, 0.f, 0.f}; continue; }
+                if constexpr (CAT3) {
+                    const int c = c4 * 4;
+                    const float *src = c < 32 ? x + (size_t)pr * 32 + c : c < 64 ? cat.table + (size_t)cat.idx[pr] * 32 + (c - 32) : cat.conf + (size_t)(pr / cat.k) * 32 + (c - 64);
+                    pre[q] = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    pre[q] = *reinterpret_cast<const float4 *>(x + (size_t)pr * CIN + c4 * 4);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int f = tid + 256 * q;
+                const int row = f / KP, c = f - row * KP;
+                const int pr = row0 + min(row, nrows - 1);
+                pre1[q] = (f < LC_ROWS * KP && c < CIN) ? x[(size_t)pr * CIN + c] : 0.f;
+            }
+        }
+    };
+    auto stage = [&](int seg) {                                          // registers -> LDS (normalised if asked)
+        const float *mr = NORM ? mean_rstd + (size_t)seg * 2 * CIN : nullptr;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int f = tid + 256 * q;
+                if (LC_ROWS * C4 % 256 != 0 && f >= LC_ROWS * C4) continue;
+                const int row = f / C4, c4 = f - row * C4;
+                float4 v = pre[q];
+                if (NORM) {
+                    const int c = c4 * 4;
+                    v.x = fmaxf((v.x - mr[c]) * mr[CIN + c], 0.f); v.y = fmaxf((v.y - mr[c + 1]) * mr[CIN + c + 1], 0.f);
+                    v.z = fmaxf((v.z - mr[c + 2]) * mr[CIN + c + 2], 0.f); v.w = fmaxf((v.w - mr[c + 3]) * mr[CIN + c + 3], 0.f);
+                }
+                float *d = xs + row * PITCH + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int f = tid + 256 * q;
+                if (f >= LC_ROWS * KP) continue;
+                const int row = f / KP, c = f - row * KP;
+                float v = pre1[q];
+                if (NORM && c < CIN) v = fmaxf((v - mr[c]) * mr[CIN + c], 0.f);
+                xs[row * PITCH + c] = v;
+            }
+        }
+    };
+    int t = blockIdx.x, row0 = 0, nrows = 0;
+    if (t < total) { lc_locate(sg, t, cs, cbase, row0, nrows); fetch(row0, nrows); }
+    for (; t < total; t += gridDim.x) {
+        const int seg = cs, p0 = row0, nr = nrows;
+        __syncthreads();                                                  // (the previous tile's fragments are read; the first trip: the weights are written)
+        stage(seg);
+        __syncthreads();
+        if (t + (int)gridDim.x < total) { lc_locate(sg, t + gridDim.x, cs, cbase, row0, nrows); fetch(row0, nrows); }   // in flight under the chains
+        float prev[ACCUM ? NT1 : 1][16];
+        if (ACCUM) {
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = p0 + min(w * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), nr - 1);
+                    prev[nt][r] = y1[(size_t)p * C1 + nt * 32 + (lane & 31)];
+                }
+        }
+        // ---- the wavefront's 32 rows x all outputs: D = bias, then CIN / 2 chained MFMAs per output tile (k ascending) ----
+        const float *xr = xs + (w * 32 + (lane & 31)) * PITCH + (lane >> 5);             // A fragment of step j: xr[2 j]
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = bias[nt];
+#pragma unroll 4
+        for (int j = 0; j < KS; ++j) {
+            const float a = xr[2 * j];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[(nt * KS + j) * 64 + lane], acc[nt], 0, 0, 0);
+        }
+        // accumulator register r of lane l: row 8 (r / 4) + 4 (l / 32) + r % 4, output l % 32: 128-byte runs per row
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float *y = nt < NT1 ? y1 : y2;
+            const int CO = nt < NT1 ? C1 : C2, o0 = (nt < NT1 ? nt : nt - NT1) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = w * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (rr < nr) y[(size_t)(p0 + rr) * CO + o0 + (lane & 31)] = (ACCUM && nt < NT1) ? prev[nt < NT1 ? nt : 0][r] + acc[nt][r] : acc[nt][r];
+            }
+        }
+        if (STATS) {                                                      // the tile's channel sums of y1 (float64): rows of this wave, the lane pair (l, l + 32), the four waves
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = w * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                    if (rr < nr) { const double v = (double)acc[nt][r]; s1 += v; s2 += v * v; }
+                }
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 32) { s_st[w][nt * 32 + lane][0] = s1; s_st[w][nt * 32 + lane][1] = s2; }
+            }
+            __syncthreads();
+            if (tid < C1) {
+                double *po = part + ((size_t)t * C1 + tid) * 2;
+                po[0] = (s_st[0][tid][0] + s_st[1][tid][0]) + (s_st[2][tid][0] + s_st[3][tid][0]);
+                po[1] = (s_st[0][tid][1] + s_st[1][tid][1]) + (s_st[2][tid][1] + s_st[3][tid][1]);
+            }
+        }
+    }
+}
+
+// mean / rstd of a pair from its tiles' channel sums: thread q adds tiles q, q + 256, ... in order, then a fixed tree; biased variance in float64
+__global__ __launch_bounds__(256) void lc_stats_final_kernel(const double *__restrict__ part, LcSegs sg, int C, float eps, float *__restrict__ mean_rstd) {
+    __shared__ double sa[256], sb[256];
+    const int c = blockIdx.x, seg = blockIdx.y;
+    int base = 0;
+    for (int s = 0; s < seg; ++s) base += (lc_seg_rows(sg, s) + LC_ROWS - 1) / LC_ROWS;
+    const int Lp = lc_seg_rows(sg, seg), nt = (Lp + LC_ROWS - 1) / LC_ROWS;
+    double a = 0, a2 = 0;
+    for (int q = threadIdx.x; q < nt; q += 256) { a += part[((size_t)(base + q) * C + c) * 2]; a2 += part[((size_t)(base + q) * C + c) * 2 + 1]; }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = a2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mu = sa[0] / Lp;
+        double var = sb[0] / Lp - mu * mu;
+        if (var < 0) var = 0;
+        mean_rstd[(size_t)seg * 2 * C + c] = (float)mu;
+        mean_rstd[(size_t)seg * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS>
+void launch_lc2(const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *mean_rstd, float *y1, float *y2, double *part,
+                const LcSegs &sg, hipStream_t s, Cat3 cat = Cat3{nullptr, nullptr, nullptr, 1}) {
+    constexpr int KP = (CIN + 1) & ~1;
+    constexpr size_t smem = ((size_t)((C1 + C2) / 32) * (KP / 2) * 64 + (size_t)LC_ROWS * (KP + 1)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lc2_kernel<CIN, C1, C2, NORM, ACCUM, CAT3, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    const int upper = sg.L / LC_ROWS + sg.n_seg;                          // >= the tile count (the kernel counts them itself)
+    const int per_cu = smem > 80 * 1024 ? 1 : smem > 52 * 1024 ? 2 : 3;  // resident workgroups per compute unit by their LDS
+    const int grid = upper < 256 * per_cu ? upper : 256 * per_cu;       // (a workgroup stages the weights once and walks its tiles)
+    hipLaunchKernelGGL((lc2_kernel<CIN, C1, C2, NORM, ACCUM, CAT3, STATS>), dim3(grid), dim3(256), smem, s, x, W1, b1, W2, b2, mean_rstd, y1, y2, part, sg, cat);
+}
+
 }  // namespace
 
 namespace roreg {
@@ -170,6 +390,51 @@ bool linear_tail_chain(const float *h, int L, int Cmid, const float *mean_rstd, 
                        int mult, hipStream_t s) {
     if (Cmid == 64) { launch_chain<64, 32, true, true>(h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult, s); return true; }
     if (Cmid == 128) { launch_chain<128, 32, true, true>(h, L, W2, b2, mean_rstd, y, seg_off, n_seg, mult, s); return true; }
+    return false;
+}
+
+
+// Round 6 entry points: the pipelined kernel (lc2_kernel) behind every shape the matcher uses.
+static bool g_lc2 = !(getenv("ROREG_LC2") && atoi(getenv("ROREG_LC2")) == 0);    // ROREG_LC2=0: round 5's kernels (A/B, tests)
+
+bool linear_chain2_on() { return g_lc2; }
+void linear_chain2_set(bool on) { g_lc2 = on; }
+
+// mlp_2layer's first convolution and residual branch in one launch (+ the per-pair statistics of h): h [L, C1], y [L, 32], mean_rstd [n_seg][2 C1];
+// part: >= (L / 128 + n_seg) * C1 * 2 doubles.  cat != nullptr: the value MLP's assembled rows (Cin = 96).  true = shape served.
+bool mlp_head_chain(const float *x, const float *cat3_table, const int64_t *cat3_idx, const float *cat3_conf, int cat3_k, int L, int Cin, const float *W1,
+                    const float *b1, int C1, const float *Wr, const float *br, float *h, float *y, const int *seg_off, int n_seg, int mult, float eps,
+                    float *mean_rstd, double *part, hipStream_t s) {
+    const LcSegs sg = {seg_off, seg_off ? n_seg : 1, seg_off ? mult : 1, L};
+    bool ok = true;
+    if (cat3_table) {
+        const Cat3 cat = {cat3_table, cat3_idx, cat3_conf, cat3_k};
+        if (Cin == 96 && C1 == 64) launch_lc2<96, 64, 32, false, false, true, true>(x, W1, b1, Wr, br, nullptr, h, y, part, sg, s, cat);
+        else ok = false;
+    }
+    else if (Cin == 96 && C1 == 64) launch_lc2<96, 64, 32, false, false, false, true>(x, W1, b1, Wr, br, nullptr, h, y, part, sg, s);
+    else if (Cin == 64 && C1 == 64) launch_lc2<64, 64, 32, false, false, false, true>(x, W1, b1, Wr, br, nullptr, h, y, part, sg, s);
+    else if (Cin == 120 && C1 == 128) launch_lc2<120, 128, 32, false, false, false, true>(x, W1, b1, Wr, br, nullptr, h, y, part, sg, s);
+    else if (Cin == 3 && C1 == 64) launch_lc2<3, 64, 32, false, false, false, true>(x, W1, b1, Wr, br, nullptr, h, y, part, sg, s);
+    else ok = false;
+    if (!ok) return false;
+    hipLaunchKernelGGL(lc_stats_final_kernel, dim3(C1, sg.n_seg), dim3(256), 0, s, part, sg, C1, eps, mean_rstd);
+    return true;
+}
+
+bool linear_tail_chain2(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,
+                        int mult, hipStream_t s) {
+    const LcSegs sg = {seg_off, seg_off ? n_seg : 1, seg_off ? mult : 1, L};
+    if (Cmid == 64) { launch_lc2<64, 32, 0, true, true, false, false>(h, W2, b2, nullptr, nullptr, mean_rstd, y, nullptr, nullptr, sg, s); return true; }
+    if (Cmid == 128) { launch_lc2<128, 32, 0, true, true, false, false>(h, W2, b2, nullptr, nullptr, mean_rstd, y, nullptr, nullptr, sg, s); return true; }
+    return false;
+}
+
+bool linear_chain2(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s) {
+    const LcSegs sg = {nullptr, 1, 1, L};
+#define LC(CI, CO) if (Cin == CI && Cout == CO) { launch_lc2<CI, CO, 0, false, false, false, false>(x, W, b, nullptr, nullptr, nullptr, y, nullptr, nullptr, sg, s); return true; }
+    LC(32, 32) LC(96, 64) LC(120, 128) LC(64, 64) LC(96, 32) LC(120, 32) LC(64, 32) LC(3, 64) LC(3, 32)
+#undef LC
     return false;
 }
 

@@ -1036,11 +1036,14 @@ extern "C" int roreg_mlp_tail_mfma(const float *h, int L, int Cmid, const float 
 }
 
 // 0 (default): the fmaf chains of roreg_linear / roreg_mlp_tail run on the matrix cores (csrc/linear_chain.hip: v_mfma_f32_32x32x2_f32 is a
-// float32 fmaf chain over k, bit for bit); 1: on the vector pipe (the kernels above).  Returns the previous setting.  Same results either way.
+// float32 fmaf chain over k, bit for bit; since round 6 software-pipelined, lc2_kernel); 1: on the vector pipe (the kernels above); 2: the matrix cores
+// through round 5's kernels.  Returns the previous setting.  Same results every way.
 static int g_linear_path = 0;
 extern "C" int roreg_linear_path(int path) {
-    const int prev = g_linear_path;
+    const int prev = g_linear_path != 0 ? g_linear_path : (roreg::linear_chain2_on() ? 0 : 2);
     if (path == 0 || path == 1) g_linear_path = path;
+    if (path == 2) g_linear_path = 0;                    // v6: 2 = the matrix cores through round 5's un-pipelined kernels (one launch per convolution; A/B, tests)
+    if (path == 0 || path == 2) roreg::linear_chain2_set(path == 0);
     return prev;
 }
 
@@ -1059,10 +1062,30 @@ extern "C" int roreg_linear_cat3(const float *pos, const float *table, const int
     return 0;
 }
 
+// v6: mlp_2layer's first convolution (Cin -> C1, output h) and residual branch (Cin -> 32, output y) in ONE launch -- the same fmaf chains on the
+// matrix cores, the input staged once -- plus the per-pair InstanceNorm statistics of h (mean_rstd [n_seg][2 C1]) from per-tile float64 channel sums
+// (no kernel reads h again).  pos / table / idx / conf (m, k): the value MLP's assembled rows as in roreg_linear_cat3 (x == NULL then, Cin = 96,
+// L = m k).  ws: roreg_mlp_head_workspace(L, n_seg, C1) doubles.  Returns 3 (and launches nothing) for a shape or path it does not serve.
+extern "C" size_t roreg_mlp_head_workspace(int L, int n_seg, int C1) { return ((size_t)L / 128 + (size_t)(n_seg > 0 ? n_seg : 1) + 1) * (size_t)C1 * 2; }
+extern "C" int roreg_mlp_head(const float *x, const float *pos, const float *table, const int64_t *idx, const float *conf, int m, int k, int L, int Cin,
+                              const float *W1, const float *b1, int C1, const float *Wr, const float *br, float *h, float *y, const int32_t *seg_off,
+                              int n_seg, int mult, float eps, float *mean_rstd, double *ws, void *stream) {
+    ROREG_REQUIRE((x || (pos && table && idx && conf && k > 0 && (long long)m * k == L)) && W1 && b1 && Wr && br && h && y && mean_rstd && ws && L > 0,
+                  "roreg_mlp_head: bad arguments");
+    if (!seg_off) { n_seg = 1; mult = 1; }
+    ROREG_REQUIRE(n_seg > 0 && mult > 0, "roreg_mlp_head: bad segment description");
+    if (g_linear_path != 0 || !roreg::linear_chain2_on()) return 3;
+    if (!roreg::mlp_head_chain(x ? x : pos, x ? nullptr : table, idx, conf, k, L, Cin, W1, b1, C1, Wr, br, h, y, seg_off, n_seg, mult, eps, mean_rstd, ws,
+                               roreg::as_stream(stream)))
+        return 3;
+    ROREG_CHECK_LAUNCH("roreg_mlp_head");
+    return 0;
+}
+
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
-    if (g_linear_path == 0 && roreg::linear_chain(x, L, Cin, W, b, Cout, y, s)) {
+    if (g_linear_path == 0 && ((roreg::linear_chain2_on() && roreg::linear_chain2(x, L, Cin, W, b, Cout, y, s)) || roreg::linear_chain(x, L, Cin, W, b, Cout, y, s))) {
         ROREG_CHECK_LAUNCH("roreg_linear");
         return 0;
     }
@@ -1111,7 +1134,8 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
     if (!seg_off) { n_seg = 1; mult = 1; }
     hipStream_t s = roreg::as_stream(stream);
-    if (g_linear_path == 0 && roreg::linear_tail_chain(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s)) {
+    if (g_linear_path == 0 && ((roreg::linear_chain2_on() && roreg::linear_tail_chain2(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s)) ||
+                               roreg::linear_tail_chain(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s))) {
         ROREG_CHECK_LAUNCH("roreg_mlp_tail");
         return 0;
     }

@@ -82,8 +82,10 @@ class yoho_evaluator:
         from ..engine import StageFileWriter
         from . import _cache
         from ._files import SceneFiles
-        from .estimator import R_pre_log
+        from .estimator import pre_log_entry
+        import time
         cfg = self.cfg
+        t_start = time.perf_counter()
         eng = self._engine()
         files = SceneFiles(cfg, dataset, self.keynum)
         ft = _cache.feat_dtype(cfg)
@@ -135,13 +137,20 @@ class yoho_evaluator:
                 for i in unscored:
                     writer.save_path(files.det_score(i), ready[i].det)
             res = eng.run_scene(feats, keys, dataset.pair_ids, keynum=self.keynum, max_iter=self.max_iter, writer=writer, ready=ready, host_svd=True)
+            t_run = time.perf_counter()
+            # the result files and pre.log (test/estimator.py:14-26, 436-441) while the writer's threads drain the stage files
+            rdir = files.result_dir(self.ET, self.max_iter)
+            with open(f'{rdir}/pre.log', 'w') as log:
+                for r in res:
+                    extra_kw = {'center': np.ones([6, 3])} if (self.ET == 'yohoc' and r.recalltime == 50000) else {}
+                    np.savez(files.result(self.ET, self.max_iter, r.id0, r.id1), trans=r.trans, **extra_kw, recalltime=r.recalltime)
+                    log.write(pre_log_entry(r.id0, r.id1, len(dataset.pc_ids), r.trans))
+            t_res = time.perf_counter()
         finally:
             writer.close()
             feats.close()
-        for r in res:
-            extra_kw = {'center': np.ones([6, 3])} if (self.ET == 'yohoc' and r.recalltime == 50000) else {}
-            np.savez(files.result(self.ET, self.max_iter, r.id0, r.id1), trans=r.trans, **extra_kw, recalltime=r.recalltime)
-        R_pre_log(dataset, files.result_dir(self.ET, self.max_iter))
+        t_end = time.perf_counter()
+        self.last_scene_seconds = {'engine_until_results_on_host': t_run - t_start, 'result_files': t_res - t_run, 'waiting_for_the_stage_file_writer': t_end - t_res}
 
     # ---- metrics --------------------------------------------------------------------------------------------
     def _match_dir(self, dataset):

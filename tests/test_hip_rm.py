@@ -227,6 +227,58 @@ def test_fmaf_chains_on_the_matrix_cores_are_bitwise_the_vector_pipe_chains(cin,
             assert torch.equal(y, want), (cin, mult)
 
 
+@pytest.mark.parametrize('cin,cmid', [(3, 64), (64, 64), (96, 64), (120, 128), ('cat3', 64)])
+def test_pipelined_chain_kernels_equal_round5s_kernels(cin, cmid):
+    """Round 6 (csrc/linear_chain.hip, lc2_kernel): the float32 fmaf chains software-pipelined, mlp_2layer's first convolution and residual branch
+    in one launch (roreg_mlp_head) with the InstanceNorm statistics of h taken from the tiles' float64 channel sums.  Against round 5's kernels
+    (hip.round5_chain_layers: one launch per convolution, roreg_instnorm_stats): every plain layer bit for bit; the whole mlp_2layer bit for
+    bit too on these inputs (the statistics are the same float64 sums in another association -- equal after rounding to float32 but for one
+    value in ~1e8) -- on ragged stacked pairs whose tiles end inside a 128-row tile, k-expanded rows (mult 16 / 8), one-row and empty-ish
+    pairs, rows spanning 1e-3 .. 1e3 with subnormals and zeros; a pair's result does not depend on what is stacked beside it."""
+    from roreg_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(7 + (0 if cin == 'cat3' else cin))
+    rnd = lambda *shape, s=1.0: torch.randn(shape, device='cuda', generator=g) * s
+    sizes = [900, 37, 5000, 1, 130, 2500, 129]
+    seg = hip.Segments(sizes)
+    for mult in ((16, 8) if cin in (3, 'cat3') else (1,)):
+        m = sum(sizes); L = m * mult
+        if cin == 'cat3':
+            pos = rnd(L, 32); table = rnd(m, 32); conf = rnd(m, 32)
+            idx = torch.randint(0, m, (m, mult), device='cuda', generator=g)
+            x = hip.Cat3Rows(pos, table, conf, idx); ci = 96
+            x_plain = x.materialise().clone()
+        else:
+            ci = cin
+            x = rnd(L, ci) * torch.pow(10.0, torch.randint(-3, 4, (L, 1), device='cuda', generator=g).float())
+            x[7] *= 1e3; x[100:110] *= 1e-38; x[120:125] = 0.0
+            x_plain = x
+        W1 = rnd(cmid, ci, s=0.2); b1 = rnd(cmid); W2 = rnd(32, cmid, s=0.2); b2 = rnd(32); Wr = rnd(32, ci, s=0.2); br = rnd(32)
+        y = hip.mlp_instnorm(x, W1, b1, W2, b2, Wr, br, seg=seg)
+        with hip.round5_chain_layers():
+            want = hip.mlp_instnorm(x_plain, W1, b1, W2, b2, Wr, br, seg=seg)
+            want_h = hip.linear(x_plain, W1, b1)
+        assert torch.equal(y, want), (cin, mult, float((y - want).abs().max()))
+        assert torch.equal(hip.linear(x_plain, W1, b1), want_h)
+        # one pair alone: the same rows, the same statistics
+        q = 2
+        o = int(seg.host[q]) * mult; n = sizes[q] * mult
+        if cin == 'cat3':
+            lo = int(seg.host[q])
+            xa = hip.Cat3Rows(pos[o:o + n].contiguous(), table[lo:lo + sizes[q]].contiguous(), conf[lo:lo + sizes[q]].contiguous(), (idx[lo:lo + sizes[q]] % sizes[q]).contiguous())
+            xs = hip.Cat3Rows(pos, table, conf, torch.cat([idx[:lo], idx[lo:lo + sizes[q]] % sizes[q] + lo, idx[lo + sizes[q]:]]).contiguous())
+            ys = hip.mlp_instnorm(xs, W1, b1, W2, b2, Wr, br, seg=seg)
+            ya = hip.mlp_instnorm(xa, W1, b1, W2, b2, Wr, br, seg=hip.Segments([sizes[q]]))
+            assert torch.equal(ys[o:o + n], ya)
+        else:
+            ya = hip.mlp_instnorm(x[o:o + n].contiguous(), W1, b1, W2, b2, Wr, br, seg=hip.Segments([sizes[q]]))
+            assert torch.equal(y[o:o + n], ya)
+        # no segments: one InstanceNorm over everything
+        y1 = hip.mlp_instnorm(x_plain[:4133].contiguous(), W1, b1, W2, b2, Wr, br)
+        with hip.round5_chain_layers():
+            w1 = hip.mlp_instnorm(x_plain[:4133].contiguous(), W1, b1, W2, b2, Wr, br)
+        assert torch.equal(y1, w1)
+
+
 @pytest.mark.parametrize('m,k', [(1, 16), (777, 16), (5000, 8), (40001, 16)])
 def test_value_rows_assembled_in_the_layer_are_bitwise_the_materialised_rows(m, k, rm):
     """hip.value_input() no longer builds the attention blocks' [m k, 96] value-MLP input (rot_coh_match.py:95-119): linear() gets the three sources
