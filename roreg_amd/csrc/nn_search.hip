@@ -120,6 +120,51 @@ __global__ __launch_bounds__(256) void knn_search_kernel(const float *__restrict
         }
 }
 
+
+// Any feature width, k <= 32 (round 6): the reference's modified_knn_matcher accepts every width and every k (utils/knn_search.py:13-162); the
+// tuned kernels above are built for the pipeline's widths 3 and 32 and k <= 8.  This one only has to be CORRECT: one thread per source row, the
+// same distance formula in the same order (explicit differences, channels ascending, separate multiply and add, correctly rounded root), the
+// same sorted-list insertion (first index wins a tie), row lists optional.  The source row is re-read per target (L1), the list lives in
+// registers / scratch.
+constexpr int KNN_GENERIC_MAX_K = 32;
+template <bool SQ>
+__global__ __launch_bounds__(256) void knn_generic_kernel(const float *__restrict__ src, const int64_t *__restrict__ src_rows, int m, const float *__restrict__ tgt,
+                                                          const int64_t *__restrict__ tgt_rows, int n, int F, int k, int64_t *__restrict__ idx_out,
+                                                          float *__restrict__ dist_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ii = i < m ? i : m - 1;
+    const float *srow = src + (src_rows ? (size_t)src_rows[ii] : (size_t)ii) * F;
+    float bd[KNN_GENERIC_MAX_K];
+    int bj[KNN_GENERIC_MAX_K];
+#pragma unroll
+    for (int q = 0; q < KNN_GENERIC_MAX_K; ++q) { bd[q] = __builtin_inff(); bj[q] = -1; }
+    for (int j = 0; j < n; ++j) {
+        const float *t = tgt + (tgt_rows ? (size_t)tgt_rows[j] : (size_t)j) * F;       // wave-uniform
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float d = __fsub_rn(srow[f], t[f]);
+            acc = __fadd_rn(acc, __fmul_rn(d, d));
+        }
+        float d = SQ ? acc : sqrtf(__fadd_rn(acc, 1e-7f));
+        int dj = j;
+        if (!(d < bd[k - 1])) continue;                  // (not better than the list's last entry: nothing moves; NaN never enters)
+        bool ins = false;
+#pragma unroll
+        for (int q = 0; q < KNN_GENERIC_MAX_K; ++q) {
+            if (q < k && (ins || d < bd[q])) {
+                const float td = bd[q]; const int tj = bj[q];
+                bd[q] = d; bj[q] = dj; d = td; dj = tj;
+                ins = true;
+            }
+        }
+    }
+    if (i < m)
+        for (int q = 0; q < k; ++q) {
+            idx_out[(size_t)i * k + q] = bj[q];
+            if (dist_out) dist_out[(size_t)i * k + q] = bd[q];
+        }
+}
+
 // the same scan over one slice of the targets (grid.y slices fill the chip: one thread per source alone is 20 workgroups at m = 5000);
 // per-slice sorted lists go to a workspace and are merged in slice order = index order, so ties still resolve to the first index
 // Segments (several clouds per launch, blockIdx.z = cloud): seg_src / seg_tgt [P+1] are row offsets into the stacked point lists, a
@@ -272,8 +317,14 @@ extern "C" int roreg_nn_search_ex(const float *src, const int64_t *src_rows, int
                                   int n, int F, int squared, int64_t *idx_out, float *dist_out, uint64_t *scratch, void *stream) {
     if (m == 0) return 0;
     ROREG_REQUIRE(src && tgt && idx_out && scratch && m > 0 && n > 0, "roreg_nn_search: bad arguments");
-    ROREG_REQUIRE(F == 32 || F == 3, "roreg_nn_search: F must be 32 or 3 (got %d)", F);
+    ROREG_REQUIRE(F >= 1, "roreg_nn_search: F must be positive (got %d)", F);
     hipStream_t s = roreg::as_stream(stream);
+    if (F != 32 && F != 3) {                           // v6: any other width through the generic kernel (k = 1: the first minimum)
+        if (squared) hipLaunchKernelGGL(knn_generic_kernel<true>, dim3((m + 255) / 256), dim3(256), 0, s, src, src_rows, m, tgt, tgt_rows, n, F, 1, idx_out, dist_out);
+        else hipLaunchKernelGGL(knn_generic_kernel<false>, dim3((m + 255) / 256), dim3(256), 0, s, src, src_rows, m, tgt, tgt_rows, n, F, 1, idx_out, dist_out);
+        ROREG_CHECK_LAUNCH("roreg_nn_search");
+        return 0;
+    }
     unsigned long long *g_packed = reinterpret_cast<unsigned long long *>(scratch);
     hipLaunchKernelGGL(fill_u64_kernel, dim3((m + 255) / 256), dim3(256), 0, s, g_packed, ~0ull, m);
     const int gx = (m + 255) / 256;
@@ -321,9 +372,16 @@ extern "C" int roreg_knn_search_ex(const float *src, int m, const float *tgt, in
                                    void *workspace, size_t workspace_bytes, void *stream) {
     if (m == 0) return 0;
     ROREG_REQUIRE(src && tgt && idx_out && m > 0 && n > 0, "roreg_knn_search: bad arguments");
-    ROREG_REQUIRE(k >= 1 && k <= 8 && k <= n, "roreg_knn_search: k must be in 1..min(8,n) (got %d)", k);
-    ROREG_REQUIRE(F == 3 || F == 32, "roreg_knn_search: F must be 3 or 32 (got %d)", F);
+    ROREG_REQUIRE(k >= 1 && k <= KNN_GENERIC_MAX_K && k <= n, "roreg_knn_search: k must be in 1..min(32,n) (got %d)", k);
+    ROREG_REQUIRE(F >= 1, "roreg_knn_search: F must be positive (got %d)", F);
     hipStream_t s = roreg::as_stream(stream);
+    if ((F != 3 && F != 32) || k > 8) {                // v6: other widths / longer lists through the generic kernel
+        const int64_t *no_rows = nullptr;
+        if (squared) hipLaunchKernelGGL(knn_generic_kernel<true>, dim3((m + 255) / 256), dim3(256), 0, s, src, no_rows, m, tgt, no_rows, n, F, k, idx_out, dist_out);
+        else hipLaunchKernelGGL(knn_generic_kernel<false>, dim3((m + 255) / 256), dim3(256), 0, s, src, no_rows, m, tgt, no_rows, n, F, k, idx_out, dist_out);
+        ROREG_CHECK_LAUNCH("roreg_knn_search");
+        return 0;
+    }
     const int slices = knn_slices(m, n);
     const size_t need = roreg_knn_search_workspace(m, n);
     const int *none = nullptr;

@@ -98,8 +98,16 @@ class StageFileWriter:
             item = self.q.get()
             if item is None:
                 return
-            path, host, done = item
             try:
+                if len(item) == 4:                                   # save_many: one pinned buffer, a file per slice
+                    paths, host, done, shapes = item
+                    done.synchronize()
+                    a, o = host.numpy(), 0
+                    for path, shape in zip(paths, shapes):
+                        n = int(np.prod(shape))
+                        np.save(path, a[o:o + n].reshape(shape)); o += n
+                    continue
+                path, host, done = item
                 if done is not None:
                     done.synchronize()
                 np.save(path, host.numpy() if torch.is_tensor(host) else host)
@@ -122,6 +130,23 @@ class StageFileWriter:
             done = torch.cuda.Event(); done.record(self.stream)
         a.record_stream(self.stream)                                # the allocator must not hand the block out before the copy ran
         self.q.put((path, host, done))
+
+    def save_many(self, rels, tensors):
+        """Many small device tensors of one dtype (a scene's per-pair match lists, DR_index, Trans_pre): ONE concatenation, ONE device -> pinned-host
+        copy and one queue entry; the worker writes each file from its slice (a copy per file cost ~0.3 ms of host time on the critical path:
+        ~1800 of them per 449-pair scene)."""
+        if not tensors:
+            return
+        shapes = [tuple(t.shape) for t in tensors]
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        ready = torch.cuda.Event(); ready.record()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+            host.copy_(flat, non_blocking=True)
+            done = torch.cuda.Event(); done.record(self.stream)
+        flat.record_stream(self.stream)
+        self.q.put(([f'{self.dir}/{r}.npy' for r in rels], host, done, shapes))
 
     def close(self):
         for _ in self.threads:
@@ -534,8 +559,8 @@ class RegistrationEngine:
         items = [(c0, c1, m, None if all_local_transforms else h) for (c0, c1, m), h in zip(full, hyp_dev)]
         lts = self.local_transforms_many(items)
         if writer is not None:                                             # (all_local_transforms is on: complete DR_index / Trans_pre files)
-            for (a, b), (dr, Trans) in zip(pair_ids, lts):
-                writer.save(f'DR_index/{a}-{b}', dr); writer.save(f'Trans_pre/{a}-{b}', Trans)
+            writer.save_many([f'DR_index/{a}-{b}' for a, b in pair_ids], [dr for dr, _ in lts])
+            writer.save_many([f'Trans_pre/{a}-{b}' for a, b in pair_ids], [T for _, T in lts])
         # the estimator tail of every pair in five launches (gather, score, first-best, refine x2)
         rt, w_all = [], []
         have = [sc is not None for sc in all_scores]
@@ -746,8 +771,8 @@ class RegistrationEngine:
             full = [(clouds[int(a)], clouds[int(b)], mbuf[q, :int(M)]) for q, ((a, b), M) in enumerate(zip(pair_ids, counts))]
             all_scores = [None] * len(full)
         if writer is not None:
+            writer.save_many([f'{a}-{b}' for a, b in pair_ids], [m for _, _, m in full])
             for (a, b), (_, _, m), sc in zip(pair_ids, full, all_scores):
-                writer.save(f'{a}-{b}', m)
                 writer.save(f'scores/{a}-{b}', np.ones(int(m.shape[0])) if sc is None else sc)
         t0 = self._mark('match', t0)
         # stage 4: all pairs

@@ -12,9 +12,10 @@ NotImplementedError('Not implemented') like the reference.  `nn_max_n` (the refe
 accepted and ignored: the kernels never materialise the matrix.  The distance formula / tie-break contract is the kernels'
 (roreg_nn_search_ex, roreg_knn_search_ex, roreg_pdist): first minimum wins, k lists in increasing distance.
 
-Restriction (the reference accepts any width and any k): the search kernels are built for the two feature widths the pipeline uses -- 3
-(keypoint coordinates) and 32 (FCGF / invariant descriptors) -- and for k <= 8; anything else raises NotImplementedError here, before
-a kernel is launched (only `pdist` is general).  A one-row input keeps its row axis (the reference's `.squeeze()` would drop it)."""
+Any feature width and k <= 32 are served (the reference accepts anything): the tuned kernels are built for the two widths the pipeline
+uses -- 3 (keypoint coordinates) and 32 (FCGF / invariant descriptors) -- with k <= 8; other widths and longer lists go through a plain
+one-thread-per-source kernel with the same distance formula and tie-break (csrc/nn_search.hip, knn_generic_kernel).  k > 32 raises
+NotImplementedError before a kernel is launched.  A one-row input keeps its row axis (the reference's `.squeeze()` would drop it)."""
 import numpy as np
 import torch
 
@@ -29,13 +30,12 @@ def _squared(dist_type):
     raise NotImplementedError('Not implemented')
 
 
-SUPPORTED_WIDTHS, MAX_K = (3, 32), 8
+TUNED_WIDTHS, MAX_K = (3, 32), 32
 
 
 def _check_shape(f, k=1):
-    if f not in SUPPORTED_WIDTHS:
-        raise NotImplementedError(f'knn_module: feature width {f} is not supported by the HIP search kernels (built for widths {SUPPORTED_WIDTHS}); '
-                                  'use pdist() for other widths')
+    if f < 1:
+        raise ValueError(f'knn_module: feature width {f}')
     if k > MAX_K:
         raise NotImplementedError(f'knn_module: k = {k} is not supported by the HIP search kernels (k <= {MAX_K})')
 

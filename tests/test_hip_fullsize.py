@@ -189,6 +189,11 @@ def test_full_match_ot_keynum_2500(rm_net, tag):
         # |dZ| no larger than twice the reference's f32-vs-f64 figures, the descriptors no further than its own f32-vs-f64 distance.
         nz = noise['full_5000x5000']
         assert np.median(dZ) < 2 * nz['scores_median'] and np.quantile(dZ, 0.99) < 2 * nz['scores_p99'], (np.median(dZ), np.quantile(dZ, 0.99))
+        # ... and a band on |dZ| must not hide a BIAS of the noise's size: the signed differences centre on zero -- their mean (dominated by the few
+        # rows / columns of points whose neighbourhood flipped) and their median (the bulk) both stay well inside the reference's own median noise
+        dZs = (Z[::40, ::40] - z['scores_sample']).astype(np.float64)
+        print(f'[{tag}] signed dZ: mean {dZs.mean():+.2e} median {np.median(dZs):+.2e} (the reference against itself: median |dZ| {nz["scores_median"]:.2e})')
+        assert abs(np.median(dZs)) < 0.25 * nz['scores_median'] and abs(dZs.mean()) < nz['scores_median'], (dZs.mean(), np.median(dZs))
         assert dZ.max() < 2 * nz['scores'] and dS < 2 * nz['source_final'] and dT < 2 * nz['target_final']
 
 
@@ -328,8 +333,6 @@ def test_full_pipeline_vs_reference(tmp_path, mode, monkeypatch):
 # ---- BASELINE config 4's chain at full size against the reference's own end-to-end run ------------------------------------------------
 RD_RM_TAGS = ['full_pipeline_rd_rm', 'full_pipeline_rd_rm_o60', 'full_pipeline_rd_rm_o60_s1', 'full_pipeline_rd_rm_o60_s2', 'full_pipeline_rd_rm_o60_s3',
               'full_pipeline_rd_rm_k5000']
-# pairs the reference itself registers (RRE < 1 degree in its own run): there the end-to-end chain must land on the reference's transform
-RD_RM_REGISTERS = {'full_pipeline_rd_rm_o60', 'full_pipeline_rd_rm_o60_s2'}
 
 
 @pytest.mark.parametrize('tag', RD_RM_TAGS)
@@ -400,32 +403,28 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
                                          'recalltime_ref': int(z['recall_0_1']), 'dT': dT}) + '\n')
             except OSError:
                 pass
-            assert max(moved) <= 30 and min(same_nms) >= kn - 5             # measured: <= 15 places; at most ONE of the sampled keypoints differs
+            # The bars are the reference's OWN noise (tests/golden/rd_chain_flip_study.json, tools/rd_chain_flip_study.py): the imported reference run on
+            # the same pair with its detector evaluated in float64 -- ranks move by 11 .. 15 places, one or two NMS samples change, and its match
+            # list shares 150 / 175, 206 / 212, 192 / 206, 198 / 201, 198 / 213, 257 / 257 rows with its float32 run.  This build must stay as close
+            # to the reference's float32 run as the reference's float64-detector run does, up to RD_SLACK_ROWS rows and RD_SLACK_RANKS rank places.
+            st = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rd_chain_flip_study.json')))[tag]
+            RD_SLACK_ROWS, RD_SLACK_RANKS = 8, 8
+            assert max(moved) <= st['rank_shift_max'] + RD_SLACK_RANKS, (max(moved), st['rank_shift_max'])
+            assert min(same_nms) >= min(st['nms_shared']) - 1, (same_nms, st['nms_shared'])
+            assert rows_same >= st['rows_shared'] - RD_SLACK_ROWS, (rows_same, st['rows_shared'])
+            assert abs(len(m) - len(want_m)) <= abs(st['rows_f64_detector'] - st['rows_f32']) + RD_SLACK_ROWS, (len(m), len(want_m), st)
             if tag == 'full_pipeline_rd_rm_o60':
-                # the pair that registers (60 % overlap): the whole chain stays on the reference's track from the input features -- both NMS samples,
-                # every one of the 212 match rows, the recalltime and the transform
+                # the pair that registers (60 % overlap): under the 32x32x16 GEMM kernel the whole chain stays on the reference's track from the input
+                # features -- both NMS samples, every one of the 212 match rows, the recalltime and the transform; under the default 16x16x32 kernel
+                # ONE of the 5000 sampled keypoints falls on the other side of an NMS near-tie (207 of 212 rows; the reference's float64-detector run: 206)
                 same_rows = sorted(map(tuple, m.tolist())) == sorted(map(tuple, want_m.tolist()))
                 if not mfma16:
                     assert same_nms == [2500, 2500] and same_rows and len(m) == len(want_m) == 212, (same_nms, same_rows, len(m), len(want_m), np.array_equal(m, want_m))
                     assert int(r['recalltime']) == int(z['recall_0_1'])
-                else:
-                    # 16x16x32 MFMAs (the default): ONE of the 5000 sampled keypoints falls on the other side of an NMS near-tie (measured:
-                    # [2499, 2500] shared, 207 of the 212 rows, 211 matches) -- and the registration is the same to 6.5e-5
-                    assert min(same_nms) >= 2499 and rows_same >= 200 and abs(len(m) - len(want_m)) <= 5, (same_nms, rows_same, len(m))
                 assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
-            elif tag in RD_RM_REGISTERS:
-                # (a few match rows differ through the detector's float32 near-ties, so the refinement sees a slightly different inlier set: the same
-                #  registration to 1e-3; on IDENTICAL inputs -- the stage-by-stage part below -- the bar is 1e-4)
-                assert rows_same >= 0.9 * len(want_m) and abs(len(m) - len(want_m)) <= 10, (rows_same, len(m), len(want_m))
-                assert dT < 1e-3, dT
-            elif tag != 'full_pipeline_rd_rm':
-                # registrations the reference fails (a one-or-few-inlier winner among near-tied hypotheses): the matches must stay on its track
-                assert rows_same >= 0.8 * len(want_m) and abs(len(m) - len(want_m)) <= 20, (rows_same, len(m), len(want_m))
-            else:
-                # the 20 % pair is a FAILED registration in the reference too (175 matches, a one-inlier winner); one keypoint of 2500 flips at the NMS
-                # boundary on float32 detector noise and the matcher's context is global: measured 150 of the reference's 175 rows shared.  The floor
-                # below is what "no worse than that" means; stage by stage (below) everything is identical.
-                assert rows_same >= 140 and abs(len(m) - len(want_m)) <= 15, (rows_same, len(m), len(want_m))
+            if st['registered_f32'] and st['registered_f64_detector']:
+                # a pair the reference registers either way: the same registration, as close as its two runs are to each other (4e-5 / 1.9e-4), x 5
+                assert dT < 5 * st['max_abs_diff_of_transforms'] + 1e-4, (dT, st['max_abs_diff_of_transforms'])
             if e2e_identical:
                 assert np.abs(r['trans'] - z['trans_0_1']).max() < 1e-4
         finally:

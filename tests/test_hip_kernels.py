@@ -209,6 +209,42 @@ def test_knn_matcher_public_methods_vs_reference_golden():
         M(B.T[None], A.T[None], dist_type='L1')
 
 
+def test_knn_matcher_other_widths_and_longer_lists_vs_reference_golden():
+    """The reference's modified_knn_matcher takes any feature width and any k (utils/knn_search.py:13-162); the tuned kernels serve the pipeline's
+    widths 3 / 32 with k <= 8 and everything else goes through the generic kernel (csrc/nn_search.hip, knn_generic_kernel; k <= 32).  F = 16
+    with k = 12 and F = 7 with k = 1 against the reference's own outputs (tools/gen_golden.py knn_wide), both distance types: indices bit for
+    bit (up to torch.topk's unspecified order among exactly tied duplicates), distances equal to the oracle's and within 1e-6 of the
+    reference's; the tuned and the generic kernel agree bit for bit where both apply (F = 32, k = 5 vs the same call padded to k = 9)."""
+    from roreg_amd import hip
+    from roreg_amd.utils.knn_search import knn_module
+    z = load_golden('knn_wide')
+    A, B = torch.from_numpy(z['A']), torch.from_numpy(z['B'])
+    M = knn_module.KNN(12)
+    for dt in ('L2', 'SquareL2'):
+        d, i = M.find_knn_gpu(A, B, nn_max_n=100, dist_type=dt)
+        od, oi = O.knn(z['B'], z['A'], 12, dist_type=dt)
+        assert d.shape == (257, 1, 12) and i.shape == (257, 12) and i.dtype == torch.int64
+        rd, ri = canon_knn(z[f'knn_d_{dt}'][:, 0, :], z[f'knn_i_{dt}'])
+        ok, n_dup = same_knn_up_to_duplicates(i.numpy(), ri, z['B'])
+        assert ok and n_dup <= 80 and np.array_equal(i.numpy(), oi) and np.array_equal(d.numpy()[:, 0], od), (dt, ok, n_dup)
+        assert (np.abs(d.numpy()[:, 0] - rd) / np.maximum(1.0, rd)).max() < 1e-6          # (squared distances ~20: one float32 ulp = 1.9e-6)
+        d2, i2 = M(B.T[None], A.T[None], dist_type=dt)
+        assert d2.shape == (1, 12, 1, 257) and np.array_equal(i2.numpy()[0].T, i.numpy())
+        d7, i7 = knn_module.KNN(1).find_nn_gpu(torch.from_numpy(z['A7']), torch.from_numpy(z['B7']), nn_max_n=64, dist_type=dt)
+        od7, oi7 = O.knn(z['B7'], z['A7'], 1, dist_type=dt)
+        assert np.array_equal(i7.numpy(), z[f'nn7_i_{dt}']) and np.array_equal(i7.numpy(), oi7) and np.array_equal(d7.numpy(), od7)
+        assert (np.abs(d7.numpy() - z[f'nn7_d_{dt}']) / np.maximum(1.0, d7.numpy())).max() < 1e-6
+    # the generic kernel against the tuned one on the pipeline's own width: the first five of a k = 9 list are the k = 5 list
+    g = load_golden('knn_api')
+    a, b = torch.from_numpy(g['A']).cuda(), torch.from_numpy(g['B']).cuda()
+    for sq in (False, True):
+        i5, d5 = hip.knn_search(a, b, 5, want_dist=True, squared=sq)
+        i9, d9 = hip.knn_search(a, b, 9, want_dist=True, squared=sq)
+        assert torch.equal(i9[:, :5], i5) and torch.equal(d9[:, :5], d5)
+    with pytest.raises(NotImplementedError):
+        knn_module.KNN(33).find_knn_gpu(A, B)
+
+
 def test_mutual_matches_bit_exact():
     from roreg_amd import hip
     rng = np.random.default_rng(4)

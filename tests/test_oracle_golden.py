@@ -71,6 +71,20 @@ def test_knn_matches_reference():
     assert np.array_equal(idx5, z['k5_idx'][0].T)
 
 
+def test_knn_other_widths_and_longer_lists_match_reference():
+    """The oracle's k-nearest lists at a width and a k the pipeline never uses (F = 16, k = 12; F = 7, k = 1) against the reference's
+    (tools/gen_golden.py knn_wide): the pin of the generic search kernel's checker."""
+    z = load_golden('knn_wide')
+    for dt in ('L2', 'SquareL2'):
+        d, i = O.knn(z['B'], z['A'], 12, dist_type=dt)
+        rd, ri = canon_knn(z[f'knn_d_{dt}'][:, 0, :], z[f'knn_i_{dt}'])
+        ok, n_dup = same_knn_up_to_duplicates(i, ri, z['B'])
+        assert ok and n_dup <= 80 and (np.abs(d - rd) / np.maximum(1.0, rd)).max() < 1e-6      # (unnormalised features: squared distances ~20, one float32 ulp = 1.9e-6)
+        assert np.array_equal(ri, canon_knn(z[f'call12_d_{dt}'][0, :, 0, :].T, z[f'call12_i_{dt}'][0].T)[1])
+        d7, i7 = O.knn(z['B7'], z['A7'], 1, dist_type=dt)
+        assert np.array_equal(i7, z[f'nn7_i_{dt}']) and (np.abs(d7 - z[f'nn7_d_{dt}']) / np.maximum(1.0, d7)).max() < 1e-6
+
+
 def test_knn_api_matches_reference():
     """pdist / find_nn_gpu / find_knn_gpu / find_corr in both distance types (utils/knn_search.py:17-136), incl. duplicated targets and
     near-duplicates whose roots may round together."""

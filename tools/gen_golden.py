@@ -187,6 +187,28 @@ def gen_knn_api():
     save('batch_create', f0_fcgf=f[0], f1_fcgf=f[1], f0_yomo=f[2], f1_yomo=f[3], index_pre=idx, **{k: v.numpy() for k, v in b.items()})
 
 
+def gen_knn_wide():
+    """modified_knn_matcher at a feature width and a k the pipeline never uses (utils/knn_search.py:13-162 accepts anything): F = 16 with k = 12, and
+    F = 7 with k = 1, both distance types; exact duplicates among the targets (first-index ties)."""
+    rng = np.random.default_rng(29)
+    out = {}
+    A = rng.standard_normal((257, 16)).astype(np.float32)
+    B = rng.standard_normal((400, 16)).astype(np.float32)
+    B[50:90] = A[:40]; B[150:190] = A[:40]
+    A7 = rng.standard_normal((130, 7)).astype(np.float32); B7 = rng.standard_normal((333, 7)).astype(np.float32); B7[10:40] = A7[:30]
+    out.update(A=A, B=B, A7=A7, B7=B7)
+    tA, tB = torch.from_numpy(A), torch.from_numpy(B)
+    M = knn_module.KNN(12)
+    for dt in ('L2', 'SquareL2'):
+        d, i = M.find_knn_gpu(tA, tB, nn_max_n=100, dist_type=dt)
+        out[f'knn_d_{dt}'] = d.numpy(); out[f'knn_i_{dt}'] = i.numpy()
+        d, i = M(tB.T[None], tA.T[None], dist_type=dt)
+        out[f'call12_d_{dt}'] = d.numpy(); out[f'call12_i_{dt}'] = i.numpy()
+        d, i = knn_module.KNN(1).find_nn_gpu(torch.from_numpy(A7), torch.from_numpy(B7), nn_max_n=64, dist_type=dt)
+        out[f'nn7_d_{dt}'] = d.numpy(); out[f'nn7_i_{dt}'] = i.numpy()
+    save('knn_wide', **out)
+
+
 def gen_nms():
     rng = np.random.default_rng(10)
     out = {}
