@@ -67,6 +67,8 @@ int ot_flash_iterations(const float *src, const float *tgt, const int32_t *seg_s
 bool linear_chain(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);
 // round 6: the same chains software-pipelined (lc2_kernel); mlp_head_chain = first convolution + residual branch of mlp_2layer in one launch + the per-pair
 // InstanceNorm statistics of h from the tiles' float64 channel sums (cat3_* non-null: the value MLP's assembled [m k, 96] rows)
+// one-time self-check (first use; synchronises `s` once per process): false + roreg_last_error() if the matrix cores do not evaluate the fmaf chain
+bool mfma_chain_verified(hipStream_t s);
 bool linear_chain2_on();
 void linear_chain2_set(bool on);
 bool linear_chain2(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s);

@@ -146,6 +146,47 @@ void launch_chain(const float *x, int L, const float *W, const float *b, const f
 }
 
 
+// One-time self-check behind every kernel that relies on it: v_mfma_f32_32x32x2_f32 must BE the float32 fmaf chain over k, each
+// step rounded (measured on gfx950, tools/probe/mfma_f32_order.hip).  One 32 x 32 tile with K = 32: operands spanning 1e-3 .. 1e3, exact zeros,
+// subnormal products, and columns built to cancel (a_k b_k + a_{k+1} b_{k+1} ~ 0: a fused pair or another association shows at once).
+__global__ __launch_bounds__(64) void mfma_chain_check_kernel(int *__restrict__ bad) {
+    const int lane = threadIdx.x, row = lane & 31, kh = lane >> 5;
+    auto gen = [](int i, int k, int side) {                             // deterministic operands
+        unsigned h = (unsigned)(i * 73856093u) ^ (unsigned)(k * 19349663u) ^ (unsigned)(side * 83492791u);
+        h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        float v = ((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f);
+        const int e = (int)((h >> 16) % 21) - 10;                       // 2^-10 .. 2^10
+        v = ldexpf(v, e);
+        if ((h >> 24) % 11 == 0) v = 0.f;
+        if ((h >> 24) % 13 == 1) v *= 1e-30f;                           // subnormal products
+        return v;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.25f;
+    for (int j = 0; j < 16; ++j) {                                      // A[row][k], B[k][col]: lane l carries k = 2 j + l / 32
+        const int k = 2 * j + kh;
+        float a = gen(row, k, 0), b = gen(row, k, 1);
+        if ((k & 1) && (row & 3) == 2) { a = gen(row, k - 1, 0); }      // A[row][k] = A[row][k-1]: with the B below the pair cancels for column == row
+        if ((k & 1) && (row & 3) == 2) { b = -gen(row, k - 1, 1); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    int wrong = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), c = lane & 31;     // D[i][c]
+        float want = 0.25f;
+        for (int k = 0; k < 32; ++k) {
+            float a = gen(i, k, 0), b = gen(c, k, 1);
+            if ((k & 1) && (i & 3) == 2) a = gen(i, k - 1, 0);
+            if ((k & 1) && (c & 3) == 2) b = -gen(c, k - 1, 1);
+            want = __fmaf_rn(a, b, want);
+        }
+        if (__float_as_uint(want) != __float_as_uint(acc[r])) ++wrong;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Round 6: the same chains, software-pipelined, with the two convolutions that read one input in ONE launch.
 //
@@ -393,6 +434,24 @@ bool linear_tail_chain(const float *h, int L, int Cmid, const float *mean_rstd, 
     return false;
 }
 
+
+// 0 = not checked yet, 1 = the matrix cores evaluate the fmaf chain (checked once per process), -1 = they do not
+static int g_chain_ok = 0;
+bool mfma_chain_verified(hipStream_t s) {
+    if (g_chain_ok == 0) {
+        int *bad = nullptr, host = -1;
+        if (hipMalloc(&bad, sizeof(int)) != hipSuccess) return false;
+        (void)hipMemsetAsync(bad, 0, sizeof(int), s);
+        hipLaunchKernelGGL(mfma_chain_check_kernel, dim3(1), dim3(64), 0, s, bad);
+        const bool copied = hipMemcpyAsync(&host, bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        (void)hipFree(bad);
+        g_chain_ok = copied && host == 0 ? 1 : -1;
+        if (g_chain_ok < 0)
+            set_error("v_mfma_f32_32x32x2_f32 does not evaluate the float32 fmaf chain on this device (%d of 1024 outputs differ): the matcher's pinned "
+                      "arithmetic would drift -- run with roreg_linear_path(1) (vector-pipe chains) and ROREG_TOPK_MFMA=0 / ROREG_OT_READOUT_MFMA=0", host);
+    }
+    return g_chain_ok > 0;
+}
 
 // Round 6 entry points: the pipelined kernel (lc2_kernel) behind every shape the matcher uses.
 static bool g_lc2 = !(getenv("ROREG_LC2") && atoi(getenv("ROREG_LC2")) == 0);    // ROREG_LC2=0: round 5's kernels (A/B, tests)

@@ -999,6 +999,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     int *pi = reinterpret_cast<int *>(ws + (size_t)slices * m * k);
     hipStream_t s = roreg::as_stream(stream);
     const int gm = (m + 255) / 256;
+    if (!valu && !roreg::mfma_chain_verified(s)) return 4;          // (one-time self-check of the fma-chain property; roreg_last_error() says what to switch)
     roreg::ProfScope prof(roreg::PROF_TOPK, s);
 #define RM_TOPK(KK)                                                                                                                  \
     if (valu) hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
@@ -1054,6 +1055,7 @@ extern "C" int roreg_linear_cat3(const float *pos, const float *table, const int
     ROREG_REQUIRE(pos && table && idx && conf && W && b && y && m > 0 && k > 0, "roreg_linear_cat3: bad arguments");
     ROREG_REQUIRE((long long)m * k < (1ll << 31), "roreg_linear_cat3: %d x %d rows", m, k);
     ROREG_REQUIRE(g_linear_path == 0, "roreg_linear_cat3: the vector-pipe path has no fused form (materialise the rows and call roreg_linear)");
+    if (!roreg::mfma_chain_verified(roreg::as_stream(stream))) return 4;
     if (!roreg::linear_chain_cat3(pos, table, idx, conf, m, k, W, b, Cout, y, roreg::as_stream(stream))) {
         roreg::set_error("roreg_linear_cat3: Cout = %d not served (64 | 32)", Cout);
         return 2;
@@ -1075,6 +1077,7 @@ extern "C" int roreg_mlp_head(const float *x, const float *pos, const float *tab
     if (!seg_off) { n_seg = 1; mult = 1; }
     ROREG_REQUIRE(n_seg > 0 && mult > 0, "roreg_mlp_head: bad segment description");
     if (g_linear_path != 0 || !roreg::linear_chain2_on()) return 3;
+    if (!roreg::mfma_chain_verified(roreg::as_stream(stream))) return 4;
     if (!roreg::mlp_head_chain(x ? x : pos, x ? nullptr : table, idx, conf, k, L, Cin, W1, b1, C1, Wr, br, h, y, seg_off, n_seg, mult, eps, mean_rstd, ws,
                                roreg::as_stream(stream)))
         return 3;
@@ -1085,6 +1088,7 @@ extern "C" int roreg_mlp_head(const float *x, const float *pos, const float *tab
 extern "C" int roreg_linear(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, void *stream) {
     ROREG_REQUIRE(x && W && b && y && L > 0, "roreg_linear: bad arguments");
     hipStream_t s = roreg::as_stream(stream);
+    if (g_linear_path == 0 && !roreg::mfma_chain_verified(s)) return 4;
     if (g_linear_path == 0 && ((roreg::linear_chain2_on() && roreg::linear_chain2(x, L, Cin, W, b, Cout, y, s)) || roreg::linear_chain(x, L, Cin, W, b, Cout, y, s))) {
         ROREG_CHECK_LAUNCH("roreg_linear");
         return 0;
@@ -1134,6 +1138,7 @@ extern "C" int roreg_mlp_tail(const float *h, int L, int Cmid, const float *mean
     ROREG_REQUIRE(h && mean_rstd && W2 && b2 && y && L > 0, "roreg_mlp_tail: bad arguments");
     if (!seg_off) { n_seg = 1; mult = 1; }
     hipStream_t s = roreg::as_stream(stream);
+    if (g_linear_path == 0 && !roreg::mfma_chain_verified(s)) return 4;
     if (g_linear_path == 0 && ((roreg::linear_chain2_on() && roreg::linear_tail_chain2(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s)) ||
                                roreg::linear_tail_chain(h, L, Cmid, mean_rstd, W2, b2, y, seg_off, n_seg, mult, s))) {
         ROREG_CHECK_LAUNCH("roreg_mlp_tail");
@@ -1392,6 +1397,7 @@ static int sinkhorn_batch_impl(const float *src_final, const float *tgt_final, c
         hipLaunchKernelGGL(ot_final_batch1_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Z0, ldz, max_m, max_n, u, v, consts, Z_out);
     }
     if (no_matrix) {
+        if (!roreg::mfma_chain_verified(s)) return 4;
         (void)hipMemsetAsync(colbest, 0, (size_t)tn * sizeof(unsigned long long), s);
         hipLaunchKernelGGL(ot_argmax_mfma_kernel, dim3((max_m + 31) / 32, n_seg), dim3(256), 0, s, src_final, tgt_final, seg_src, seg_tgt, u, v, slab, consts,
                            colbest, i0, val0);

@@ -99,6 +99,9 @@ class StageFileWriter:
             if item is None:
                 return
             try:
+                if callable(item):                                   # submit(): any host-side file work
+                    item()
+                    continue
                 if len(item) == 4:                                   # save_many: one pinned buffer, a file per slice
                     paths, host, done, shapes = item
                     done.synchronize()
@@ -130,6 +133,10 @@ class StageFileWriter:
             done = torch.cuda.Event(); done.record(self.stream)
         a.record_stream(self.stream)                                # the allocator must not hand the block out before the copy ran
         self.q.put((path, host, done))
+
+    def submit(self, fn):
+        """run fn() on a writer thread (result files, logs); close() waits for it"""
+        self.q.put(fn)
 
     def save_many(self, rels, tensors):
         """Many small device tensors of one dtype (a scene's per-pair match lists, DR_index, Trans_pre): ONE concatenation, ONE device -> pinned-host
@@ -434,7 +441,8 @@ class RegistrationEngine:
         # ... capped by what fits a quarter of the free device memory: per pair the Sinkhorn workspace (roreg_sinkhorn_batch3_workspace_size: no
         # coupling matrices in the default mode) plus ~60 KB of neighbourhood activations per point (k = 16 neighbours x <= 120 channels, a few tensors)
         longest = max(max(len(s0), len(s1)) for _, _, s0, s1 in jobs)
-        per_pair = 4 * hip.lib().roreg_sinkhorn_batch3_workspace_size(1, longest, longest, longest, longest, 1, 0) + 60_000 * 2 * longest
+        ot_mode = (2 if hip.OT_COOP else 1) if hip.OT_RECOMPUTE else 0      # (the workspace of the mode that will actually run: with ROREG_OT_RECOMPUTE=0 a pair
+        per_pair = 4 * hip.lib().roreg_sinkhorn_batch3_workspace_size(1, longest, longest, longest, longest, ot_mode, 0) + 60_000 * 2 * longest     #  keeps two coupling matrices)
         max_points = max(longest, min(max_points, int(0.25 * torch.cuda.mem_get_info()[0] / per_pair) * longest))
         flat = np.concatenate([np.ascontiguousarray(x, np.int64) for _, _, s0, s1 in jobs for x in (s0, s1)])
         flat_dev = hip.upload(flat)                                         # ONE upload of all sample lists
@@ -581,36 +589,59 @@ class RegistrationEngine:
         for the pairs the reference gives up on)."""
         from .test.estimator import yohoc_draws, three_point_transforms, _select_top
         batch = hip.LtBatch([(c0.eqv, c1.eqv, c0.eqv, c1.eqv, c0.keys, c1.keys, m, None, c0.eqv_ft, c1.eqv_ft) for c0, c1, m in full])
-        dr_all = batch.des2r().cpu().numpy()
+        sizes = [int(m.shape[0]) for _, _, m in full]
+        # (a generator like the other stages: the coarse rotations and the match lists come to the host through run_scenes' asynchronous download,
+        #  and the draws + the 3-point Kabsch stacks below -- host LAPACK, the reference's own call -- run under the other scenes' kernels)
+        need_keys = [c for c0, c1, _ in full for c in (c0, c1) if c.keys_host is None]
+        need_keys = list({id(c): c for c in need_keys}.values())
+        got = yield [batch.des2r(), torch.cat([m.reshape(-1) for _, _, m in full]) if full else torch.zeros(0, dtype=torch.int64, device='cuda')] + [c.keys for c in need_keys]
+        dr_all = np.asarray(got[0]); m_host = np.asarray(got[1]).reshape(-1, 2)
+        for c, k in zip(need_keys, got[2:]):
+            c.keys_host = np.array(k)
         if writer is not None:
             for (a, b), (off, n) in zip(pair_ids, batch.offsets):
                 writer.save(f'DR_index/{a}-{b}', dr_all[off:off + n].copy())
-        sizes = [int(m.shape[0]) for _, _, m in full]
-        m_host = torch.cat([m.reshape(-1) for _, _, m in full]).cpu().numpy().reshape(-1, 2) if full else np.zeros((0, 2), np.int64)
-        jobs, skipped, o = [], {}, 0
-        for i, ((c0, c1, _), sc, (off, n)) in enumerate(zip(full, all_scores, batch.offsets)):     # sequential: the global generator
-            pps = m_host[o:o + sizes[i]]; o += sizes[i]
-            # a pair's draws come from a stream of its own, RandomState(seed + 1) -- the same MT19937 stream np.random.seed(seed + 1) would
-            # start -- so the process-global generator is neither consumed nor left in a state that depends on the shard plan
-            rng = None if pair_seeds is None else np.random.RandomState((int(pair_seeds[i]) + 1) % (2 ** 32))
-            if c0.keys_host is None:
-                c0.keys_host = c0.keys.cpu().numpy()
-            if c1.keys_host is None:
-                c1.keys_host = c1.keys.cpu().numpy()
-            sel = _select_top(sc, self.cfg.match_n) if self.cfg.RM else np.arange(n)
+        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+        def draw(i, rng):
+            """pair i's hypothesis draws -> (keys0, keys1, rows0 [H,3], rows1 [H,3]) or the reference's give-up result (estimator.py:214-216)"""
+            c0, c1, _ = full[i]
+            off, n = batch.offsets[i]
+            pps = m_host[starts[i]:starts[i + 1]]
+            sel = _select_top(all_scores[i], self.cfg.match_n) if self.cfg.RM else np.arange(n)
             idxs = yohoc_draws(dr_all[off:off + n][sel], max_iter, rng=rng)
-            if idxs is None:                                               # no rotation bin with two correspondences (:214-216)
-                skipped[i] = ((np.random if rng is None else rng).rand(4, 4), 50000)
-                jobs.append(None)
-            else:
-                jobs.append((c0.keys_host, c1.keys_host, pps[sel, 0][idxs], pps[sel, 1][idxs]))
+            if idxs is None:                                               # no rotation bin with two correspondences
+                return None, ((np.random if rng is None else rng).rand(4, 4), 50000)
+            return (c0.keys_host, c1.keys_host, pps[sel, 0][idxs], pps[sel, 1][idxs]), None
         # the 3-point Kabsch stacks are pure functions of the draws: LAPACK releases the GIL, so the pairs run on a few host threads
         kabsch = lambda j: np.zeros((0, 3, 4)) if j is None else three_point_transforms(j[0][j[2]], j[1][j[3]])
-        hyps = list(_host_pool().map(kabsch, jobs))
-        flat = torch.from_numpy(np.concatenate(hyps) if hyps else np.zeros((0, 3, 4))).cuda()
-        rt, w_all, o = [], [], 0
+        skipped = {}
+        if pair_seeds is not None:
+            # a pair's draws come from a stream of its own, RandomState(seed + 1) -- the same MT19937 stream np.random.seed(seed + 1) would start --
+            # so the process-global generator is neither consumed nor left in a state that depends on the shard plan, and the pairs' draws
+            # are independent of each other: draws AND Kabsch stacks of all pairs on the host pool
+            def both(i):
+                job, gave_up = draw(i, np.random.RandomState((int(pair_seeds[i]) + 1) % (2 ** 32)))
+                return kabsch(job), gave_up
+            done = list(_host_pool().map(both, range(len(full))))
+            hyps = [h for h, _ in done]
+            skipped = {i: g for i, (_, g) in enumerate(done) if g is not None}
+        else:                                                              # the reference's single global stream: draws in pair order, then the stacks in parallel
+            jobs = []
+            for i in range(len(full)):
+                job, gave_up = draw(i, None)
+                jobs.append(job)
+                if gave_up is not None:
+                    skipped[i] = gave_up
+            hyps = list(_host_pool().map(kabsch, jobs))
+        flat = hip.upload(np.concatenate(hyps) if hyps else np.zeros((0, 3, 4)))       # ONE upload of all hypotheses (the staging ring: no stream sync)
+        have = [sc is not None for sc in all_scores]
+        w_flat = hip.upload(np.concatenate([sc.astype(np.float64) for sc in all_scores if sc is not None])) if any(have) else None
+        rt, w_all, o, ow = [], [], 0, 0
         for (c0, c1, matches), sc, T in zip(full, all_scores, hyps):
-            w = None if sc is None else torch.from_numpy(sc.astype(np.float64)).cuda()
+            w = None
+            if sc is not None:
+                w = w_flat[ow:ow + sc.shape[0]]; ow += sc.shape[0]
             rt.append((c0.keys, c1.keys, matches, w, flat[o:o + T.shape[0]], None)); w_all.append(w)
             o += T.shape[0]
         return rt, w_all, skipped
@@ -778,7 +809,7 @@ class RegistrationEngine:
         # stage 4: all pairs
         yohoc = getattr(self.cfg, 'ET', 'yohoo') == 'yohoc'
         if yohoc:
-            rt, w_all, skipped = self._yohoc_tasks(full, all_scores, max_iter, pair_seeds, writer, pair_ids)
+            rt, w_all, skipped = yield from self._yohoc_tasks(full, all_scores, max_iter, pair_seeds, writer, pair_ids)
         else:
             (rt, w_all), skipped = self._yohoo_tasks(full, all_scores, max_iter, all_local_transforms, pair_seeds, writer, pair_ids), {}
         t0 = self._mark('local_transforms', t0)

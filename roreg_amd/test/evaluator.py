@@ -156,11 +156,15 @@ class yoho_evaluator:
             t_run = time.perf_counter()
             # the result files and pre.log (test/estimator.py:14-26, 436-441) while the writer's threads drain the stage files
             rdir = files.result_dir(self.ET, self.max_iter)
-            with open(f'{rdir}/pre.log', 'w') as log:
-                for r in res:
+
+            def write_results(part):                              # (np.savez is a zip archive per pair: ~0.25 ms each, on the writer's threads)
+                for r in part:
                     extra_kw = {'center': np.ones([6, 3])} if (self.ET == 'yohoc' and r.recalltime == 50000) else {}
                     np.savez(files.result(self.ET, self.max_iter, r.id0, r.id1), trans=r.trans, **extra_kw, recalltime=r.recalltime)
-                    log.write(pre_log_entry(r.id0, r.id1, len(dataset.pc_ids), r.trans))
+            for q in range(0, len(res), 64):
+                writer.submit(lambda part=res[q:q + 64]: write_results(part))
+            with open(f'{rdir}/pre.log', 'w') as log:
+                log.write(''.join(pre_log_entry(r.id0, r.id1, len(dataset.pc_ids), r.trans) for r in res))
             t_res = time.perf_counter()
         finally:
             writer.close()

@@ -33,10 +33,11 @@ def test_empty_inputs_are_no_ops():
 
 def test_bad_arguments_raise_not_crash():
     from roreg_amd import hip
+    assert hip.nn_search(torch.randn(4, 7, device='cuda'), torch.randn(4, 7, device='cuda')).shape == (4,)   # (round 6: any width, the generic kernel)
     with pytest.raises(hip.HipError):
-        hip.nn_search(torch.randn(4, 7, device='cuda'), torch.randn(4, 7, device='cuda'))          # unsupported F
+        hip.knn_search(torch.randn(40, 3, device='cuda'), torch.randn(40, 3, device='cuda'), 33)   # k > 32
     with pytest.raises(hip.HipError):
-        hip.knn_search(torch.randn(4, 3, device='cuda'), torch.randn(4, 3, device='cuda'), 9)      # k > 8
+        hip.knn_search(torch.randn(4, 3, device='cuda'), torch.randn(4, 3, device='cuda'), 9)      # k > n
     with pytest.raises(hip.HipError):
         hip.group_conv(torch.randn(2, 32, 60), hip.ConvLayer(torch.randn(64, 32, 1, 13), torch.zeros(64), None))   # host tensor
     with pytest.raises(hip.HipError):

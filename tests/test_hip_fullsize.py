@@ -189,11 +189,15 @@ def test_full_match_ot_keynum_2500(rm_net, tag):
         # |dZ| no larger than twice the reference's f32-vs-f64 figures, the descriptors no further than its own f32-vs-f64 distance.
         nz = noise['full_5000x5000']
         assert np.median(dZ) < 2 * nz['scores_median'] and np.quantile(dZ, 0.99) < 2 * nz['scores_p99'], (np.median(dZ), np.quantile(dZ, 0.99))
-        # ... and a band on |dZ| must not hide a BIAS of the noise's size: the signed differences centre on zero -- their mean (dominated by the few
-        # rows / columns of points whose neighbourhood flipped) and their median (the bulk) both stay well inside the reference's own median noise
+        # ... and what the band on |dZ| could hide is looked at directly.  The noise here is NOT centred: when one point's neighbourhood flips, the
+        # iteration's mass balance moves every other log-coupling by a common offset -- the reference's float32 run sits 3.1e-4 (median, signed)
+        # below its own float64 run, with a spread of 1.9e-4 around that offset (tools/match_ot_noise.py: scores_signed_median,
+        # scores_spread_around_the_signed_median).  This build's offset against the reference's float32 run must be no larger than twice that
+        # (an exact evaluation would sit at +3.1e-4), and the spread around its own offset within three times the reference's.
         dZs = (Z[::40, ::40] - z['scores_sample']).astype(np.float64)
-        print(f'[{tag}] signed dZ: mean {dZs.mean():+.2e} median {np.median(dZs):+.2e} (the reference against itself: median |dZ| {nz["scores_median"]:.2e})')
-        assert abs(np.median(dZs)) < 0.25 * nz['scores_median'] and abs(dZs.mean()) < nz['scores_median'], (dZs.mean(), np.median(dZs))
+        off = float(np.median(dZs)); spread = float(np.median(np.abs(dZs - off)))
+        print(f'[{tag}] signed dZ: median {off:+.2e}, spread around it {spread:.2e} (the reference, f32 - f64: {nz["scores_signed_median"]:+.2e}, {nz["scores_spread_around_the_signed_median"]:.2e})')
+        assert abs(off) < 2 * abs(nz['scores_signed_median']) and spread < 3 * nz['scores_spread_around_the_signed_median'], (off, spread)
         assert dZ.max() < 2 * nz['scores'] and dS < 2 * nz['source_final'] and dT < 2 * nz['target_final']
 
 
@@ -346,7 +350,7 @@ def test_full_pipeline_rd_rm_vs_reference(tmp_path, tag):
     samples; Des2R index, recalltime and transform from the reference's matches.
     `_o60_s1..3`: three more 60 % pairs (s1 and s3 are registrations the reference itself fails: a wrong group element wins); `_k5000`: the
     chain at `--keynum 5000` (SURVEY 3.1's hot path): NMS_sample returns a permutation of all 5000 keypoints and Match_ot runs at
-    m = n = 5000 (two cooperating workgroups per Sinkhorn strip, csrc/ot_flash.hip).  Every run appends what it measured for the two GEMM
+    m = n = 5000 (two recomputing passes per Sinkhorn iteration, csrc/ot_flash.hip; the cooperating-workgroup form is opt-in).  Every run appends what it measured for the two GEMM
     kernels to gpurun_out/r05/rd_rm_e2e.jsonl (DESIGN.md section 2's table)."""
     from roreg_amd import hip
     from roreg_amd.test import name2extractor, name2detector, name2matcher, name2estimator, _cache

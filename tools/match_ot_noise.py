@@ -52,6 +52,11 @@ def main():
         res['scores_median'] = float(np.median(d)); res['scores_p99'] = float(np.quantile(d, 0.99)); res['scores_p9999'] = float(np.quantile(d, 0.9999))
         res['scores_rows_above_1e-4'] = int((d.max(1) > 1e-4).sum()); res['scores_cols_above_1e-4'] = int((d.max(0) > 1e-4).sum())
         res['scores_fraction_above_1e-4'] = float((d > 1e-4).mean())
+        # ... and how it is SIGNED: when one point's descriptor moves, the iteration's mass balance shifts every other log-coupling by a common
+        # offset -- at 5000 x 5000 the difference is mostly that offset (median of the signed difference ~ median of its magnitude)
+        sd = (f32['scores'] - f64['scores'])[0]
+        res['scores_signed_median'] = float(np.median(sd)); res['scores_signed_mean'] = float(sd.mean())
+        res['scores_spread_around_the_signed_median'] = float(np.median(np.abs(sd - np.median(sd))))
         res['matches0_equal'] = bool(np.array_equal(i32['matches0'], i64['matches0']))
         res['matches0_differing'] = int((i32['matches0'] != i64['matches0']).sum())
         out[name] = res
