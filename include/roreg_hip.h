@@ -453,6 +453,13 @@ int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const 
                           const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                           int recompute, float *Z_out, void *stream);
+/* v6 (host function): the YOHO-C hypothesis draws (test/estimator.py:119-137, 214-230) of n_pairs pairs, pair p from its own generator stream
+ * np.random.RandomState(seeds[p]): anchors = the pairs' coarse rotations (Des2R index of the correspondences hypotheses are drawn from),
+ * concatenated, pair p at [offsets[p], offsets[p+1]).  rows_out [n_pairs][max_iter][3]: the three correspondences (positions in the pair's list)
+ * of each hypothesis; n_hyp_out [n_pairs]: how many were drawn, or -1 when no rotation bin holds two correspondences -- the reference then
+ * answers np.random.rand(4, 4) (giveup_out [n_pairs][16], recalltime 50000).  Same words of the same streams as the Python loop, on n_threads. */
+int roreg_yohoc_draw_many(const uint32_t *seeds, int n_pairs, const int64_t *anchors, const int64_t *offsets, int max_iter, int max_tries,
+                          int64_t *rows_out, int32_t *n_hyp_out, double *giveup_out, int n_threads);
 /* v6: mlp_2layer / Contextnorm (network/rot_coh_match.py:14-32, 63-81): the first convolution (Cin -> C1, output h [L, C1]) and the residual
  * branch (Cin -> 32, output y [L, 32]) in ONE launch -- the float32 fmaf chains of roreg_linear on the matrix cores, bit for bit, the input tile
  * staged once, the next tile's rows in flight under the chains -- plus the per-pair InstanceNorm statistics of h (mean_rstd [n_seg][2 C1], the

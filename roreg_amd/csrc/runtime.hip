@@ -224,3 +224,90 @@ extern "C" int roreg_mt_shuffle_prefix(const uint32_t *seeds, int n_jobs, const 
     for (auto &t : th) t.join();
     return 0;
 }
+
+// v6: the YOHO-C draws of MANY pairs, each from a generator stream of its own -- per pair exactly what
+//     rng = np.random.RandomState(seed); yohoc_draws(anchors, max_iter, rng)          (roreg_amd/test/estimator.py; test/estimator.py:119-137,214-230)
+// does: the rotation-bin statistic (counts, num = counts / 100, prob = num (num - 0.01) (num - 0.02) for bins of two or more, normalised by numpy's
+// pairwise float64 sum), the sampling loop of roreg_yohoc_draw over the stream's raw words, and the rows of the pair's correspondence list
+// (members of a bin in increasing order).  A pair with no bin of two correspondences gives up like the reference (n_hyp = -1) and gets the 16
+// doubles of `rng.rand(4, 4)` from its untouched stream.  Host code, pairs spread over threads: the per-pair Python loop cost ~0.6 ms per pair
+// on the thread that feeds the GPU (270 ms per 449-pair scene).
+static double np_pairwise_sum60(const double *a) {                  // numpy's float64 add.reduce over 60 contiguous values (pairwise_sum, n < 128)
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < 56; i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < 60; ++i) res += a[i];
+    return res;
+}
+
+extern "C" int roreg_yohoc_draw_many(const uint32_t *seeds, int n_pairs, const int64_t *anchors, const int64_t *offsets, int max_iter, int max_tries,
+                                     int64_t *rows_out, int32_t *n_hyp_out, double *giveup_out, int n_threads) {
+    if (n_pairs == 0) return 0;
+    ROREG_REQUIRE(seeds && anchors && offsets && rows_out && n_hyp_out && giveup_out && n_pairs > 0 && max_iter >= 0, "roreg_yohoc_draw_many: bad arguments");
+    for (int p = 0; p < n_pairs; ++p) ROREG_REQUIRE(offsets[p + 1] >= offsets[p], "roreg_yohoc_draw_many: offsets must not decrease");
+    for (long long i = offsets[0]; i < offsets[n_pairs]; ++i) ROREG_REQUIRE(anchors[i] >= 0 && anchors[i] < 60, "roreg_yohoc_draw_many: anchor out of range");
+    auto work = [&](int p0, int p1) {
+        std::vector<int64_t> members;
+        for (int p = p0; p < p1; ++p) {
+            const int64_t *an = anchors + offsets[p];
+            const long long n = offsets[p + 1] - offsets[p];
+            Mt19937 g(seeds[p]);
+            auto next_double = [&]() { const uint32_t a = g.next() >> 5, b = g.next() >> 6; return (a * 67108864.0 + b) / 9007199254740992.0; };
+            long long counts[60] = {0}, starts[60];
+            for (long long i = 0; i < n; ++i) ++counts[an[i]];
+            double prob[60];
+            for (int r = 0; r < 60; ++r) {
+                const double num = (double)counts[r] / 100.0;
+                prob[r] = counts[r] < 2 ? 0.0 : num * (num - 0.01) * (num - 0.02);
+            }
+            const double total = np_pairwise_sum60(prob);
+            if (total == 0.0) for (int r = 0; r < 60; ++r) prob[r] = 0.0;
+            else for (int r = 0; r < 60; ++r) prob[r] = prob[r] / total;
+            if (np_pairwise_sum60(prob) < 1e-5) {                      // no rotation bin with two correspondences: the reference's random answer
+                n_hyp_out[p] = -1;
+                for (int q = 0; q < 16; ++q) giveup_out[(size_t)p * 16 + q] = next_double();
+                continue;
+            }
+            double cdf[60], run = 0.0;
+            for (int r = 0; r < 60; ++r) { run += prob[r]; cdf[r] = run; }
+            const double last = cdf[59];
+            for (int r = 0; r < 60; ++r) cdf[r] /= last;
+            long long acc = 0;
+            for (int r = 0; r < 60; ++r) { starts[r] = acc; acc += counts[r]; }
+            members.resize((size_t)n);
+            { long long fill[60]; for (int r = 0; r < 60; ++r) fill[r] = starts[r];
+              for (long long i = 0; i < n; ++i) members[(size_t)fill[an[i]]++] = i; }      // stable: increasing order inside a bin
+            int n_hyp = 0, tries = 0;
+            int64_t *rows = rows_out + (size_t)p * max_iter * 3;
+            while (n_hyp < max_iter) {
+                if (tries > max_tries) break;
+                ++tries;
+                const double u = next_double();
+                int lo = 0, hi = 60;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+                if (lo >= 60) lo = 59;                                 // (cdf[59] == 1 > u always; defensive)
+                const long long nb = counts[lo];
+                if (nb < 2) continue;
+                const uint32_t rng = (uint32_t)(nb - 1);
+                uint32_t mask = rng;
+                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                for (int t = 0; t < 3; ++t) {
+                    uint32_t v;
+                    do { v = g.next() & mask; } while (v > rng);
+                    rows[(size_t)n_hyp * 3 + t] = members[(size_t)(starts[lo] + v)];
+                }
+                ++n_hyp;
+            }
+            n_hyp_out[p] = n_hyp;
+        }
+    };
+    int nt = n_threads < 1 ? 1 : (n_threads > n_pairs ? n_pairs : n_threads);
+    if (nt == 1) { work(0, n_pairs); return 0; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((long long)n_pairs * t / nt), (int)((long long)n_pairs * (t + 1) / nt));
+    for (auto &t : th) t.join();
+    return 0;
+}

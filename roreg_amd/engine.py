@@ -620,12 +620,20 @@ class RegistrationEngine:
             # a pair's draws come from a stream of its own, RandomState(seed + 1) -- the same MT19937 stream np.random.seed(seed + 1) would start --
             # so the process-global generator is neither consumed nor left in a state that depends on the shard plan, and the pairs' draws
             # are independent of each other: draws AND Kabsch stacks of all pairs on the host pool
-            def both(i):
-                job, gave_up = draw(i, np.random.RandomState((int(pair_seeds[i]) + 1) % (2 ** 32)))
-                return kabsch(job), gave_up
-            done = list(_host_pool().map(both, range(len(full))))
-            hyps = [h for h, _ in done]
-            skipped = {i: g for i, (_, g) in enumerate(done) if g is not None}
+            sels = [_select_top(all_scores[i], self.cfg.match_n) if self.cfg.RM else None for i in range(len(full))]
+            anchors = [dr_all[off:off + n] if sel is None else dr_all[off:off + n][sel] for (off, n), sel in zip(batch.offsets, sels)]
+            drawn, giveup = hip.yohoc_draw_many(np.asarray(pair_seeds, np.int64) + 1, anchors, max_iter)     # one threaded host call (C: no interpreter lock)
+            jobs = []
+            for i, idxs in enumerate(drawn):
+                if idxs is None:
+                    skipped[i] = (giveup[i].copy(), 50000); jobs.append(None)
+                    continue
+                c0, c1, _ = full[i]
+                pps = m_host[starts[i]:starts[i + 1]]
+                if sels[i] is not None:
+                    pps = pps[sels[i]]
+                jobs.append((c0.keys_host, c1.keys_host, pps[:, 0][idxs], pps[:, 1][idxs]))
+            hyps = list(_host_pool().map(kabsch, jobs))
         else:                                                              # the reference's single global stream: draws in pair order, then the stacks in parallel
             jobs = []
             for i in range(len(full)):
@@ -706,15 +714,26 @@ class RegistrationEngine:
                 return None
             return [i, g, *download(req)]
 
-        for i in range(len(jobs)):
-            older = active
-            f, k, p, kw = materialise(jobs[i])                       # the next scene's first stage is enqueued ...
+        def start(i):
+            f, k, p, kw = materialise(jobs[i])
             g = self._scene_steps(f, k, p, **kw)
-            newest = []
             try:
-                newest = [[i, g, *download(next(g))]]
+                return [[i, g, *download(next(g))]]
             except StopIteration as fin:
                 out[i] = fin.value
+                return []
+
+        # The first round starts `prefill` extra scenes: a scene's first stage (extraction [+ detector]) is its second-longest piece of device work,
+        # and with one new scene per round the queue runs dry while the host prepares the first scenes' later stages (rank transforms, NMS
+        # selection, hypothesis draws: the gaps of profiles/r06_rd_rm_k5000_gaps_*.txt sit at the start and the end of a step).
+        prefill = int(os.environ.get('ROREG_PIPELINE_PREFILL', 1))
+        nxt = 0
+        while nxt < len(jobs):
+            older = active
+            newest = []
+            for _ in range(1 + (prefill if nxt == 0 else 0)):        # the next scene's first stage is enqueued ...
+                if nxt < len(jobs):
+                    newest += start(nxt); nxt += 1
             # ... before the host waits for anything of the scenes already in flight, each of which then moves one stage on (oldest first)
             active = [n for n in (advance(slot) for slot in older) if n is not None] + newest
         while active:

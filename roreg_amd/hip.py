@@ -564,6 +564,23 @@ def yohoc_draw(prob, bin_size, max_iter, max_tries=50000, rng=None):
 
 
 
+def yohoc_draw_many(seeds, anchors_list, max_iter, max_tries=50000, n_threads=None):
+    """yohoc_draws() of many pairs in one threaded host call, pair p from np.random.RandomState(seeds[p]) (roreg_yohoc_draw_many):
+    anchors_list[p] = the coarse rotations of the correspondences pair p draws from.  -> [rows int64 [H_p, 3] or None (the reference gives up),
+    give-up matrices f64 [n_pairs, 4, 4] (rng.rand(4, 4) of the pairs that gave up)]."""
+    n = len(anchors_list)
+    seeds = np.ascontiguousarray(np.asarray(seeds, np.int64) % (2 ** 32), np.uint32)
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum([len(a) for a in anchors_list])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(a, np.int64) for a in anchors_list]) if n else np.zeros(0, np.int64))
+    rows = np.empty((n, max(max_iter, 1), 3), np.int64); n_hyp = np.empty(n, np.int32); giveup = np.zeros((n, 4, 4), np.float64)
+    if n:
+        nt = n_threads if n_threads is not None else max(1, min(32, (os.cpu_count() or 2) // 2, n // 8 + 1))
+        _check(lib().roreg_yohoc_draw_many(c_void_p(seeds.ctypes.data), n, c_void_p(flat.ctypes.data), c_void_p(offs.ctypes.data), int(max_iter), int(max_tries),
+                                           c_void_p(rows.ctypes.data), c_void_p(n_hyp.ctypes.data), c_void_p(giveup.ctypes.data), int(nt)), 'roreg_yohoc_draw_many')
+    return [None if n_hyp[p] < 0 else rows[p, :n_hyp[p]] for p in range(n)], giveup
+
+
 def ransac_batch(tasks, ird, w_f32=False, keep=False):
     """tasks: [(keys0 [*,3] f64, keys1 [*,3] f64, matches [M,2] int64, w [M] f64 or None, Trans [*,3,4] f64, hyp_rows int64 [H] or None)]
     (device tensors).  One-shot RANSAC + the two refinements of every task in five launches ->

@@ -526,3 +526,38 @@ def test_even_groups_of_the_stacked_matcher():
         assert g[0][0] == 0 and g[-1][1] == len(sizes) and all(a[1] == b[0] for a, b in zip(g, g[1:])) and all(i < j for i, j in g)
         assert all(sum(sizes[i:j]) <= cap or j - i == 1 for i, j in g)
 
+
+def test_yohoc_draws_of_many_pairs_in_one_host_call_replay_the_per_pair_streams():
+    """roreg_yohoc_draw_many (round 6, host code): the rotation-bin statistic, the sampling loop and the give-up answer of
+    `yohoc_draws(anchors, max_iter, np.random.RandomState(seed))` for many pairs in one threaded C call -- the same words of the same MT19937
+    streams: rows identical, `rng.rand(4, 4)` of the pairs the reference gives up on identical (test/estimator.py:119-137, 214-230)."""
+    from roreg_amd import hip
+    from roreg_amd.test.estimator import yohoc_draws
+    rng = np.random.default_rng(3)
+    anchors, seeds = [], []
+    for q in range(40):
+        n = int(rng.integers(1, 3000))
+        kind = q % 5
+        if kind == 0:
+            a = rng.integers(0, 60, n)                                            # uniform bins
+        elif kind == 1:
+            a = np.where(rng.random(n) < 0.7, 17, rng.integers(0, 60, n))         # one dominant rotation
+        elif kind == 2:
+            a = rng.permutation(60)[:min(n, 60)]                                  # every bin at most one member: the reference gives up
+        elif kind == 3:
+            a = np.concatenate([np.full(2, 5), rng.permutation(60)[:10]])         # one bin of exactly two (+ maybe one more in bin 5)
+        else:
+            a = np.full(n, 59)                                                    # everything in the last bin
+        anchors.append(np.asarray(a, np.int64)); seeds.append(int(rng.integers(0, 2 ** 32)))
+    for max_iter in (1000, 7):
+        got, giveup = hip.yohoc_draw_many(seeds, anchors, max_iter, n_threads=3)
+        n_gave_up = 0
+        for q, (a, sd) in enumerate(zip(anchors, seeds)):
+            r = np.random.RandomState(sd)
+            want = yohoc_draws(a, max_iter, rng=r)
+            if want is None:
+                n_gave_up += 1
+                assert got[q] is None and np.array_equal(giveup[q], r.rand(4, 4)), q
+            else:
+                assert got[q] is not None and np.array_equal(got[q], want), q
+        assert n_gave_up >= 8
