@@ -198,43 +198,47 @@ __global__ __launch_bounds__(64) void mfma_chain_check_kernel(int *__restrict__ 
 // beside it): tile t of segment s covers rows [off[s] mult + 128 t, ...).  Per tile: the NEXT tile's rows are requested from global memory
 // into registers before the chains start and land under them (the round-5 kernel loaded, waited, staged, synchronised and only then
 // multiplied: 16-25 % of the float32 MFMA rate on the 96-wide layers); with ACCUM the sixteen old values per output tile are requested there too.
-struct LcSegs { const int *off; int n_seg, mult, L; };
+struct LcSegs { const int *off; int n_seg, mult, L, rows; };      // rows: rows per tile (32 per wavefront of the workgroup)
 
 __device__ __forceinline__ int lc_seg_rows(const LcSegs &sg, int s) { return sg.off ? (sg.off[s + 1] - sg.off[s]) * sg.mult : sg.L; }
 __device__ __forceinline__ int lc_total_tiles(const LcSegs &sg) {
     int n = 0;
-    for (int s = 0; s < sg.n_seg; ++s) n += (lc_seg_rows(sg, s) + LC_ROWS - 1) / LC_ROWS;
+    for (int s = 0; s < sg.n_seg; ++s) n += (lc_seg_rows(sg, s) + sg.rows - 1) / sg.rows;
     return n;
 }
-// tile t (>= the tile the cursor stands on) -> (first row, rows, segment); the cursor (segment, its first tile) only moves forward
-__device__ __forceinline__ void lc_locate(const LcSegs &sg, int t, int &cs, int &cbase, int &row0, int &nrows) {
+// tile t (>= the tile the cursor stands on) -> (first row, rows, segment, index of its first 128-row statistics unit); the cursor (segment, its first
+// tile, its first unit) only moves forward.  Statistics units are ALWAYS 128 rows (LC_ROWS) whatever the tile height, so the channel sums
+// associate the same way under 128- and 256-row tiles.
+__device__ __forceinline__ void lc_locate(const LcSegs &sg, int t, int &cs, int &cbase, int &ubase, int &row0, int &nrows, int &unit0) {
     for (;;) {
-        const int len = lc_seg_rows(sg, cs), nt = (len + LC_ROWS - 1) / LC_ROWS;
+        const int len = lc_seg_rows(sg, cs), nt = (len + sg.rows - 1) / sg.rows;
         if (t < cbase + nt || cs + 1 >= sg.n_seg) {
-            const int r = (t - cbase) * LC_ROWS;
+            const int r = (t - cbase) * sg.rows;
             row0 = (sg.off ? sg.off[cs] * sg.mult : 0) + r;
-            nrows = min(LC_ROWS, len - r);
+            nrows = min(sg.rows, len - r);
+            unit0 = ubase + r / LC_ROWS;
             return;
         }
-        cbase += nt; ++cs;
+        cbase += nt; ubase += (len + LC_ROWS - 1) / LC_ROWS; ++cs;
     }
 }
 
-template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS>
-__global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lc2_kernel(const float *__restrict__ x, const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                   const float *__restrict__ b2, const float *__restrict__ mean_rstd, float *__restrict__ y1, float *__restrict__ y2,
                                                   double *__restrict__ part, LcSegs sg, Cat3 cat) {
     static_assert(!CAT3 || (CIN == 96 && !NORM), "CAT3: three 32-wide sources");
     static_assert(C1 % 32 == 0 && C2 % 32 == 0 && (!ACCUM || C2 == 0), "lc2_kernel: outputs in tiles of 32");
     constexpr int KP = (CIN + 1) & ~1, KS = KP / 2, NT1 = C1 / 32, NT = (C1 + C2) / 32, PITCH = KP + 1;
     constexpr bool VEC = CIN % 4 == 0;
-    constexpr int C4 = VEC ? CIN / 4 : 1, NV = VEC ? (LC_ROWS * C4 + 255) / 256 : (LC_ROWS * KP + 255) / 256;
+    constexpr int ROWS = 32 * WAVES, NTH = 64 * WAVES;               // WAVES = 8: two wavefronts per SIMD share the staged weights and cover each other's LDS latency
+    constexpr int C4 = VEC ? CIN / 4 : 1, NV = VEC ? (ROWS * C4 + NTH - 1) / NTH : (ROWS * KP + NTH - 1) / NTH;
     extern __shared__ __attribute__((aligned(16))) char lc_smem[];
     float *wf = reinterpret_cast<float *>(lc_smem);                      // [NT][KS][64]
-    float *xs = wf + NT * KS * 64;                                        // [LC_ROWS][PITCH]
-    __shared__ double s_st[STATS ? 4 : 1][STATS ? C1 : 1][2];
+    float *xs = wf + NT * KS * 64;                                        // [ROWS][PITCH]
+    __shared__ double s_st[STATS ? WAVES : 1][STATS ? C1 : 1][2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int f = tid; f < NT * KS * 64; f += 256) {
+    for (int f = tid; f < NT * KS * 64; f += NTH) {
         const int l = f & 63, j = (f >> 6) % KS, nt = f / (64 * KS);
         const int o = nt * 32 + (l & 31), c = 2 * j + (l >> 5);
         wf[f] = c < CIN ? (o < C1 ? W1[o * CIN + c] : W2[(o - C1) * CIN + c]) : 0.f;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = nt < NT1 ? b1[nt * 32 + (lane & 31)] : b2[(nt - NT1) * 32 + (lane & 31)];
     const int total = lc_total_tiles(sg);
-    int cs = 0, cbase = 0;                                                // the tile cursor
+    int cs = 0, cbase = 0, ubase = 0;                                     // the tile cursor
     // ---- the rows of a tile, 16 bytes per thread and trip, into registers ----
     float4 pre[VEC ? NV : 1];
     float pre1[VEC ? 1 : NV];
@@ -251,10 +255,10 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                const int f = tid + 256 * q;
+                const int f = tid + NTH * q;
                 const int row = f / C4, c4 = f - row * C4;
                 const int pr = row0 + min(row, nrows - 1);               // (rows past the tile's end repeat its last row: never stored)
-                if (LC_ROWS * C4 % 256 != 0 && f >= LC_ROWS * C4) { pre[q] = float4{0.f, 0.f, 0.f, 0.f}; continue; }
+                if (ROWS * C4 % NTH != 0 && f >= ROWS * C4) { pre[q] = float4{0.f, 0.f, 0.f, 0.f}; continue; }
                 if constexpr (CAT3) {
                     const int c = c4 * 4;
                     const float *src = c < 32 ? x + (size_t)pr * 32 + c : c < 64 ? cat.table + (size_t)cat.idx[pr] * 32 + (c - 32) : cat.conf + (size_t)(pr / cat.k) * 32 + (c - 64);
@@ -266,10 +270,10 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
         } else {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                const int f = tid + 256 * q;
+                const int f = tid + NTH * q;
                 const int row = f / KP, c = f - row * KP;
                 const int pr = row0 + min(row, nrows - 1);
-                pre1[q] = (f < LC_ROWS * KP && c < CIN) ? x[(size_t)pr * CIN + c] : 0.f;
+                pre1[q] = (f < ROWS * KP && c < CIN) ? x[(size_t)pr * CIN + c] : 0.f;
             }
         }
     };
@@ -278,8 +282,8 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                const int f = tid + 256 * q;
-                if (LC_ROWS * C4 % 256 != 0 && f >= LC_ROWS * C4) continue;
+                const int f = tid + NTH * q;
+                if (ROWS * C4 % NTH != 0 && f >= ROWS * C4) continue;
                 const int row = f / C4, c4 = f - row * C4;
                 float4 v = pre[q];
                 if (NORM) {
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
         } else {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                const int f = tid + 256 * q;
-                if (f >= LC_ROWS * KP) continue;
+                const int f = tid + NTH * q;
+                if (f >= ROWS * KP) continue;
                 const int row = f / KP, c = f - row * KP;
                 float v = pre1[q];
                 if (NORM && c < CIN) v = fmaxf((v - mr[c]) * mr[CIN + c], 0.f);
@@ -302,14 +306,14 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
             }
         }
     };
-    int t = blockIdx.x, row0 = 0, nrows = 0;
-    if (t < total) { lc_locate(sg, t, cs, cbase, row0, nrows); fetch(row0, nrows); }
+    int t = blockIdx.x, row0 = 0, nrows = 0, unit0 = 0;
+    if (t < total) { lc_locate(sg, t, cs, cbase, ubase, row0, nrows, unit0); fetch(row0, nrows); }
     for (; t < total; t += gridDim.x) {
-        const int seg = cs, p0 = row0, nr = nrows;
+        const int seg = cs, p0 = row0, nr = nrows, u0 = unit0;
         __syncthreads();                                                  // (the previous tile's fragments are read; the first trip: the weights are written)
         stage(seg);
         __syncthreads();
-        if (t + (int)gridDim.x < total) { lc_locate(sg, t + gridDim.x, cs, cbase, row0, nrows); fetch(row0, nrows); }   // in flight under the chains
+        if (t + (int)gridDim.x < total) { lc_locate(sg, t + gridDim.x, cs, cbase, ubase, row0, nrows, unit0); fetch(row0, nrows); }   // in flight under the chains
         float prev[ACCUM ? NT1 : 1][16];
         if (ACCUM) {
 #pragma unroll
@@ -357,21 +361,24 @@ __global__ __launch_bounds__(256) void lc2_kernel(const float *__restrict__ x, c
                 if (lane < 32) { s_st[w][nt * 32 + lane][0] = s1; s_st[w][nt * 32 + lane][1] = s2; }
             }
             __syncthreads();
-            if (tid < C1) {
-                double *po = part + ((size_t)t * C1 + tid) * 2;
-                po[0] = (s_st[0][tid][0] + s_st[1][tid][0]) + (s_st[2][tid][0] + s_st[3][tid][0]);
-                po[1] = (s_st[0][tid][1] + s_st[1][tid][1]) + (s_st[2][tid][1] + s_st[3][tid][1]);
+            // one partial per 128-row unit: the four wavefronts of the unit in a fixed tree (a 256-row tile leaves two units; its second one only if it has rows)
+            for (int e = tid; e < (WAVES / 4) * C1; e += NTH) {
+                const int half = e / C1, c = e - half * C1;
+                if (half * LC_ROWS >= nr) continue;
+                double *po = part + ((size_t)(u0 + half) * C1 + c) * 2;
+                po[0] = (s_st[4 * half][c][0] + s_st[4 * half + 1][c][0]) + (s_st[4 * half + 2][c][0] + s_st[4 * half + 3][c][0]);
+                po[1] = (s_st[4 * half][c][1] + s_st[4 * half + 1][c][1]) + (s_st[4 * half + 2][c][1] + s_st[4 * half + 3][c][1]);
             }
         }
     }
 }
 
-// mean / rstd of a pair from its tiles' channel sums: thread q adds tiles q, q + 256, ... in order, then a fixed tree; biased variance in float64
+// mean / rstd of a pair from its 128-row units' channel sums: thread q adds units q, q + 256, ... in order, then a fixed tree; biased variance in float64
 __global__ __launch_bounds__(256) void lc_stats_final_kernel(const double *__restrict__ part, LcSegs sg, int C, float eps, float *__restrict__ mean_rstd) {
     __shared__ double sa[256], sb[256];
     const int c = blockIdx.x, seg = blockIdx.y;
     int base = 0;
-    for (int s = 0; s < seg; ++s) base += (lc_seg_rows(sg, s) + LC_ROWS - 1) / LC_ROWS;
+    for (int s = 0; s < seg; ++s) base += (lc_seg_rows(sg, s) + sg.rows - 1) / sg.rows;
     const int Lp = lc_seg_rows(sg, seg), nt = (Lp + LC_ROWS - 1) / LC_ROWS;
     double a = 0, a2 = 0;
     for (int q = threadIdx.x; q < nt; q += 256) { a += part[((size_t)(base + q) * C + c) * 2]; a2 += part[((size_t)(base + q) * C + c) * 2 + 1]; }
@@ -390,21 +397,40 @@ __global__ __launch_bounds__(256) void lc_stats_final_kernel(const double *__res
     }
 }
 
-template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS>
-void launch_lc2(const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *mean_rstd, float *y1, float *y2, double *part,
-                const LcSegs &sg, hipStream_t s, Cat3 cat = Cat3{nullptr, nullptr, nullptr, 1}) {
-    constexpr int KP = (CIN + 1) & ~1;
-    constexpr size_t smem = ((size_t)((C1 + C2) / 32) * (KP / 2) * 64 + (size_t)LC_ROWS * (KP + 1)) * sizeof(float);
+template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS, int WAVES>
+void launch_lc2w(const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *mean_rstd, float *y1, float *y2, double *part,
+                 LcSegs sg, hipStream_t s, Cat3 cat) {
+    constexpr int KP = (CIN + 1) & ~1, ROWS = 32 * WAVES;
+    constexpr size_t smem = ((size_t)((C1 + C2) / 32) * (KP / 2) * 64 + (size_t)ROWS * (KP + 1)) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lc2_kernel<CIN, C1, C2, NORM, ACCUM, CAT3, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lc2_kernel<CIN, C1, C2, NORM, ACCUM, CAT3, STATS, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = true;
     }
-    const int upper = sg.L / LC_ROWS + sg.n_seg;                          // >= the tile count (the kernel counts them itself)
+    sg.rows = ROWS;
+    const int upper = sg.L / ROWS + sg.n_seg;                             // >= the tile count (the kernel counts them itself)
     const int per_cu = smem > 80 * 1024 ? 1 : smem > 52 * 1024 ? 2 : 3;  // resident workgroups per compute unit by their LDS
     const int grid = upper < 256 * per_cu ? upper : 256 * per_cu;       // (a workgroup stages the weights once and walks its tiles)
-    hipLaunchKernelGGL((lc2_kernel<CIN, C1, C2, NORM, ACCUM, CAT3, STATS>), dim3(grid), dim3(256), smem, s, x, W1, b1, W2, b2, mean_rstd, y1, y2, part, sg, cat);
+    hipLaunchKernelGGL((lc2_kernel<CIN, C1, C2, NORM, ACCUM, CAT3, STATS, WAVES>), dim3(grid), dim3(64 * WAVES), smem, s, x, W1, b1, W2, b2, mean_rstd, y1, y2, part, sg, cat);
 }
+
+// rows per tile: 256 (eight wavefronts: two per SIMD) where the weights + a 256-row tile fit the LDS and there are tiles enough to fill the chip, else 128
+template <int CIN, int C1, int C2, bool NORM, bool ACCUM, bool CAT3, bool STATS>
+int launch_lc2(const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *mean_rstd, float *y1, float *y2, double *part,
+               const LcSegs &sg, hipStream_t s, Cat3 cat = Cat3{nullptr, nullptr, nullptr, 1}) {
+    constexpr int KP = (CIN + 1) & ~1;
+    constexpr size_t smem8 = ((size_t)((C1 + C2) / 32) * (KP / 2) * 64 + (size_t)256 * (KP + 1)) * sizeof(float);
+    static const int force = getenv("ROREG_LC2_WAVES") ? atoi(getenv("ROREG_LC2_WAVES")) : 0;          // (measurements: 4 or 8)
+    if constexpr (smem8 <= 160 * 1024) {
+        if (force != 4 && (force == 8 || sg.L >= 256 * 512)) {
+            launch_lc2w<CIN, C1, C2, NORM, ACCUM, CAT3, STATS, 8>(x, W1, b1, W2, b2, mean_rstd, y1, y2, part, sg, s, cat);
+            return 256;
+        }
+    }
+    launch_lc2w<CIN, C1, C2, NORM, ACCUM, CAT3, STATS, 4>(x, W1, b1, W2, b2, mean_rstd, y1, y2, part, sg, s, cat);
+    return 128;
+}
+
 
 }  // namespace
 
@@ -464,7 +490,7 @@ void linear_chain2_set(bool on) { g_lc2 = on; }
 bool mlp_head_chain(const float *x, const float *cat3_table, const int64_t *cat3_idx, const float *cat3_conf, int cat3_k, int L, int Cin, const float *W1,
                     const float *b1, int C1, const float *Wr, const float *br, float *h, float *y, const int *seg_off, int n_seg, int mult, float eps,
                     float *mean_rstd, double *part, hipStream_t s) {
-    const LcSegs sg = {seg_off, seg_off ? n_seg : 1, seg_off ? mult : 1, L};
+    LcSegs sg = {seg_off, seg_off ? n_seg : 1, seg_off ? mult : 1, L, LC_ROWS};
     bool ok = true;
     if (cat3_table) {
         const Cat3 cat = {cat3_table, cat3_idx, cat3_conf, cat3_k};
@@ -483,14 +509,14 @@ bool mlp_head_chain(const float *x, const float *cat3_table, const int64_t *cat3
 
 bool linear_tail_chain2(const float *h, int L, int Cmid, const float *mean_rstd, const float *W2, const float *b2, float *y, const int *seg_off, int n_seg,
                         int mult, hipStream_t s) {
-    const LcSegs sg = {seg_off, seg_off ? n_seg : 1, seg_off ? mult : 1, L};
+    LcSegs sg = {seg_off, seg_off ? n_seg : 1, seg_off ? mult : 1, L, LC_ROWS};
     if (Cmid == 64) { launch_lc2<64, 32, 0, true, true, false, false>(h, W2, b2, nullptr, nullptr, mean_rstd, y, nullptr, nullptr, sg, s); return true; }
     if (Cmid == 128) { launch_lc2<128, 32, 0, true, true, false, false>(h, W2, b2, nullptr, nullptr, mean_rstd, y, nullptr, nullptr, sg, s); return true; }
     return false;
 }
 
 bool linear_chain2(const float *x, int L, int Cin, const float *W, const float *b, int Cout, float *y, hipStream_t s) {
-    const LcSegs sg = {nullptr, 1, 1, L};
+    const LcSegs sg = {nullptr, 1, 1, L, LC_ROWS};
 #define LC(CI, CO) if (Cin == CI && Cout == CO) { launch_lc2<CI, CO, 0, false, false, false, false>(x, W, b, nullptr, nullptr, nullptr, y, nullptr, nullptr, sg, s); return true; }
     LC(32, 32) LC(96, 64) LC(120, 128) LC(64, 64) LC(96, 32) LC(120, 32) LC(64, 32) LC(3, 64) LC(3, 32)
 #undef LC

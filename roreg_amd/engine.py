@@ -723,10 +723,9 @@ class RegistrationEngine:
                 out[i] = fin.value
                 return []
 
-        # The first round starts `prefill` extra scenes: a scene's first stage (extraction [+ detector]) is its second-longest piece of device work,
-        # and with one new scene per round the queue runs dry while the host prepares the first scenes' later stages (rank transforms, NMS
-        # selection, hypothesis draws: the gaps of profiles/r06_rd_rm_k5000_gaps_*.txt sit at the start and the end of a step).
-        prefill = int(os.environ.get('ROREG_PIPELINE_PREFILL', 1))
+        # ROREG_PIPELINE_PREFILL = extra scenes started in the first round (measured, tools/probe/prefill_ab.sh: 0 / 1 / 2 give 471-479 / 478-480 /
+        # 473-478 pairs/s on the --RD --RM pipeline and 1093-1097 on the mutual one -- the queue does not run dry at the start of a step; default 0)
+        prefill = int(os.environ.get('ROREG_PIPELINE_PREFILL', 0))
         nxt = 0
         while nxt < len(jobs):
             older = active
