@@ -845,7 +845,7 @@ class RegistrationEngine:
         redo = [i for i in range(len(full)) if i not in skipped and (deficient[i] or host_svd)]
         if redo:                                                            # their second refinements in ONE launch, one download
             T1s = np.stack([_kabsch_host(st_host[i, 0]) for i in redo])
-            st_redo = hip.refine_batch(rctx, redo, T1s, ird)[1].cpu().numpy()
+            st_redo = (yield [hip.refine_batch(rctx, redo, T1s, ird)[1]])[0]   # (a yield point like the others: a blocking .cpu() here waited for every kernel queued behind the scene -- 60 ms per scene with --RM on pairs that fail to register)
             for i, st in zip(redo, st_redo):
                 T_host[i] = _kabsch_host(st)
         local = full

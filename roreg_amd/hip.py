@@ -99,7 +99,7 @@ class _StagingRing:
     a full synchronisation after which the host prepares the next launches with the GPU idle; `pin_memory()` per call costs more than
     that.)  A slot is reused only after its event has completed."""
 
-    def __init__(self, slots=8):
+    def __init__(self, slots=64):          # (a slot is reused only when its copy has run: with 8 the host stalled in upload() behind ~300 ms of queued kernels)
         self.bufs = [None] * slots
         self.events = [None] * slots
         self.next = 0

@@ -12,8 +12,8 @@ rm -rf $OUT/kt_rd_rm_$tag
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_rd_rm_$tag -- python3 bench.py $ARGS > $OUT/kt_rd_rm_$tag.log 2>&1
 db=$(find $OUT/kt_rd_rm_$tag -name '*.db' | head -1)
 python3 tools/rocprof_summary.py $db $OUT/rd_rm_k5000_${tag}_kernel_trace.txt > /dev/null
-python3 tools/rocprof_gaps.py $db 8 > $OUT/rd_rm_k5000_${tag}_gaps.txt
+python3 tools/rocprof_gaps.py $db 8 detail > $OUT/rd_rm_k5000_${tag}_gaps.txt
 find $OUT/kt_rd_rm_$tag -name '*.db' -delete
 tail -1 $OUT/kt_rd_rm_$tag.log | cut -c1-300
-head -40 $OUT/rd_rm_k5000_${tag}_kernel_trace.txt
+head -12 $OUT/rd_rm_k5000_${tag}_kernel_trace.txt
 cat $OUT/rd_rm_k5000_${tag}_gaps.txt

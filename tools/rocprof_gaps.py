@@ -1,5 +1,6 @@
 """GPU idle time inside a kernel trace (rocprofv3 rocpd database): gaps between the end of one kernel and the start of the next, by size class.
-usage: python tools/rocprof_gaps.py <results.db> [last_seconds]     (only the kernels of the last so many seconds of the trace)"""
+usage: python tools/rocprof_gaps.py <results.db> [last_seconds] [detail]     (only the kernels of the last so many seconds of the trace;
+`detail`: every gap >= 1 ms with its position in the window and the three kernels on either side)"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
@@ -28,3 +29,15 @@ for g, n in gaps:
 print('   gaps >= 200 us by (previous kernel -> next kernel):')
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
     print(f'      {c:4d} x, {t / 1e6:8.2f} ms  {n}')
+if len(sys.argv) > 3 and sys.argv[3] == 'detail':
+    print('   gaps >= 1 ms, in time order (offset from the window start; the kernels before | after):')
+    end = rows[0][1]; last_i = 0
+    t0 = rows[0][0]
+    for i in range(1, len(rows)):
+        s_, e_, n_ = rows[i]
+        if s_ > end and s_ - end >= 1e6:
+            before = ' < '.join(r[2].split('(')[0].split('::')[-1][:28] for r in rows[max(0, last_i - 2):last_i + 1])
+            after = ' > '.join(r[2].split('(')[0].split('::')[-1][:28] for r in rows[i:i + 3])
+            print(f'      at {(end - t0) / 1e6:9.1f} ms: {(s_ - end) / 1e6:6.2f} ms   {before}  |  {after}')
+        if e_ > end:
+            end = e_; last_i = i
