@@ -291,6 +291,11 @@ def group_conv(x, layer, gather=None, Lout=None, residual=None, out=None, split=
     if out is None:
         out = torch.empty((B, layer.Cout, Lout), dtype=torch.float32, device=x.device)
     split_ok = residual is None and layer.KS == 13 and Cin % 16 == 0 and layer.Cout % 256 == 0 and Lin <= 64 and Lout <= 64 and B > 0
+    # ... and the split kernels' precomputed staging plan (csrc/group_conv.hip, launch_conv_split: RAW_ITERS = 9, CV_ITEMS = 5 trips of 256
+    # threads over the tile's keypoints x columns) must cover the tile: e.g. Lin = 60 with Lout = 13 (11 keypoints per tile) does not fit and
+    # takes the f32 kernel below instead of an error
+    nkp = min((128 - 1) // max(Lout, 1) + 2, max(B, 1))
+    split_ok = split_ok and nkp * 2 * Lin <= 5 * 256 and nkp * 4 * Lin <= 9 * 256
     order_t, order_s = (None, 0) if lds_order is None else lds_order
     if order_t is not None:
         _check_lds_order(order_t, order_s, gather, Lin)
