@@ -368,7 +368,11 @@ int roreg_topk_dot(const float *A, int m, const float *B, int n, int k, int64_t 
 /* y [L,Cout] = x [L,Cin] W^T + b  (the 1x1 Conv2d layers: attention projections / merge, first and residual convs of
  * mlp_2layer and Contextnorm; rot_coh_match.py:14-32,63-81,95-119): one float32 fmaf chain per (row, output), inputs ascending, starting from the bias.
  * v5: that chain runs on the matrix cores (v_mfma_f32_32x32x2_f32 is a float32 fmaf chain over k on gfx950, bit for bit: csrc/linear_chain.hip);
- * roreg_linear_path(1) selects the vector-pipe kernels instead (same bits; returns the previous setting, 0 = matrix cores). */
+ * roreg_linear_path(1) selects the vector-pipe kernels instead (same bits; returns the previous setting, 0 = matrix cores).
+ * v6: the matrix-core kernels are software-pipelined (lc2_kernel); roreg_linear_path(2) = the matrix cores through round 5's kernels (A/B, tests).
+ * Every entry point that rests on the fma-chain property (roreg_linear / _cat3, roreg_mlp_tail, roreg_mlp_head, roreg_topk_dot's MFMA kernel, the
+ * matrix-free read-out of roreg_sinkhorn_batch3) verifies it ONCE per process on the device (1024 outputs: cancelling pairs, zeros, subnormal
+ * products) in front of its first launch and returns 4 with roreg_last_error() naming the vector-pipe switches if the hardware disagrees. */
 int roreg_linear(const float *x, int L, int Cin, const float *W /* [Cout,Cin] */, const float *b, int Cout, float *y, void *stream);
 int roreg_linear_path(int path);
 /* v5: y [m * k, Cout] (Cout = 64 | 32) = W [pos[r] (32) | table[idx[r]] (32) | conf[r / k] (32)] + b -- roreg_linear on the value MLP's input
