@@ -457,6 +457,11 @@ int roreg_sinkhorn_batch3(const float *src_final, const float *tgt_final, const 
                           const int32_t *seg_src_host, const int32_t *seg_tgt_host, const float *consts, int n_seg, float alpha, int iters,
                           int64_t *matches0, int64_t *matches1, float *mscores0, float *mscores1, float *ws, size_t ws_floats,
                           int recompute, float *Z_out, void *stream);
+/* v6 (host function): write n files -- file q = headers[q] (header_len[q] bytes, e.g. a .npy header) followed by data[q] (nbytes[q] bytes) -- on
+ * n_threads host threads: the device-resident engine's StageFileWriter leaves the reference's ~1800 small per-pair .npy files of a 449-pair scene
+ * (test/matcher.py:108-109, test/estimator.py:111,367) through it instead of one np.save each.  Returns 0, or 1 + the index of the first failure. */
+int roreg_write_files(const char *const *paths, const void *const *headers, const int32_t *header_len, const void *const *data,
+                      const int64_t *nbytes, int n, int n_threads);
 /* v6 (host function): the YOHO-C hypothesis draws (test/estimator.py:119-137, 214-230) of n_pairs pairs, pair p from its own generator stream
  * np.random.RandomState(seeds[p]): anchors = the pairs' coarse rotations (Des2R index of the correspondences hypotheses are drawn from),
  * concatenated, pair p at [offsets[p], offsets[p+1]).  rows_out [n_pairs][max_iter][3]: the three correspondences (positions in the pair's list)

@@ -66,6 +66,7 @@ PROTOTYPES = {
     'roreg_sinkhorn_batch2': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'roreg_sinkhorn_batch3_workspace_size': (c_size_t, [c_int, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int]),
     'roreg_sinkhorn_batch3': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, c_int, _P, _P]),
+    'roreg_write_files': (c_int, [_P, _P, _P, _P, _P, c_int, c_int]),
     'roreg_yohoc_draw_many': (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, _P, _P, c_int]),
     'roreg_mlp_head_workspace': (c_size_t, [c_int, c_int, c_int]),
     'roreg_mlp_head': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),

@@ -1,5 +1,6 @@
 // Library state: last-error text and the device copies of the icosahedral group tables.
 #include "common.h"
+#include <cstdio>
 #include <thread>
 #include <vector>
 #include <utility>
@@ -309,5 +310,35 @@ extern "C" int roreg_yohoc_draw_many(const uint32_t *seeds, int n_pairs, const i
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((long long)n_pairs * t / nt), (int)((long long)n_pairs * (t + 1) / nt));
     for (auto &t : th) t.join();
+    return 0;
+}
+
+// v6 (host function): write n files, file q = header[q] (header_len[q] bytes: the .npy header the caller formatted) followed by data[q]
+// (nbytes[q] bytes), on n_threads -- the engine's StageFileWriter leaves ~1800 small .npy files per 449-pair scene, and Python's np.save
+// spends ~80 us per file holding the interpreter lock the launching thread needs.  Returns 0, or 1 + the index of the first file that failed.
+extern "C" int roreg_write_files(const char *const *paths, const void *const *headers, const int32_t *header_len, const void *const *data,
+                                 const int64_t *nbytes, int n, int n_threads) {
+    if (n == 0) return 0;
+    ROREG_REQUIRE(paths && headers && header_len && data && nbytes && n > 0, "roreg_write_files: bad arguments");
+    std::vector<int> failed((size_t)(n_threads < 1 ? 1 : n_threads), -1);
+    auto work = [&](int t, int q0, int q1) {
+        for (int q = q0; q < q1; ++q) {
+            FILE *f = fopen(paths[q], "wb");
+            bool ok = f != nullptr;
+            if (ok && header_len[q] > 0) ok = fwrite(headers[q], 1, (size_t)header_len[q], f) == (size_t)header_len[q];
+            if (ok && nbytes[q] > 0) ok = fwrite(data[q], 1, (size_t)nbytes[q], f) == (size_t)nbytes[q];
+            if (f) ok = (fclose(f) == 0) && ok;
+            if (!ok && failed[t] < 0) failed[t] = q;
+        }
+    };
+    const int nt = n_threads < 1 ? 1 : (n_threads > n ? n : n_threads);
+    if (nt == 1) work(0, 0, n);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
+        for (auto &t : th) t.join();
+    }
+    for (int t = 0; t < nt; ++t)
+        if (failed[t] >= 0) { roreg::set_error("roreg_write_files: could not write %s", paths[failed[t]]); return 1 + failed[t]; }
     return 0;
 }

@@ -105,15 +105,16 @@ class StageFileWriter:
                 if len(item) == 4:                                   # save_many: one pinned buffer, a file per slice
                     paths, host, done, shapes = item
                     done.synchronize()
-                    a, o = host.numpy(), 0
-                    for path, shape in zip(paths, shapes):
+                    a, o, parts = host.numpy(), 0, []
+                    for shape in shapes:
                         n = int(np.prod(shape))
-                        np.save(path, a[o:o + n].reshape(shape)); o += n
+                        parts.append(a[o:o + n].reshape(shape)); o += n
+                    hip.write_npy_files(paths, parts, n_threads=2)   # (np.save's bytes without np.save's ~80 us of interpreter time per file)
                     continue
                 path, host, done = item
                 if done is not None:
                     done.synchronize()
-                np.save(path, host.numpy() if torch.is_tensor(host) else host)
+                hip.write_npy_files([path], [host.numpy() if torch.is_tensor(host) else host], n_threads=1)
             except Exception as e:                                  # surfaced by close()
                 self.error = e
 

@@ -569,6 +569,39 @@ def yohoc_draw(prob, bin_size, max_iter, max_tries=50000, rng=None):
 
 
 
+_NPY_HEADERS = {}
+
+
+def npy_header(dtype, shape):
+    """The bytes np.save puts in front of a C-ordered array of this dtype and shape (numpy's own header writer, version 1.0; cached)."""
+    key = (np.dtype(dtype).str, tuple(int(x) for x in shape))
+    h = _NPY_HEADERS.get(key)
+    if h is None:
+        import io
+        f = io.BytesIO()
+        np.lib.format.write_array_header_1_0(f, {'descr': np.lib.format.dtype_to_descr(np.dtype(dtype)), 'fortran_order': False, 'shape': key[1]})
+        h = f.getvalue()
+        if len(_NPY_HEADERS) < 65536:
+            _NPY_HEADERS[key] = h
+    return h
+
+
+def write_npy_files(paths, arrays, n_threads=4):
+    """np.save(path, a) for many C-contiguous host arrays in ONE call that releases the interpreter lock (roreg_write_files): byte for byte
+    np.save's files (the same header bytes, the same data)."""
+    n = len(paths)
+    if n == 0:
+        return
+    arrs = [np.ascontiguousarray(a) for a in arrays]
+    heads = [npy_header(a.dtype, a.shape) for a in arrs]
+    c_paths = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    c_heads = (ctypes.c_char_p * n)(*heads)
+    c_hlen = (ctypes.c_int32 * n)(*[len(h) for h in heads])
+    c_data = (ctypes.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+    c_len = (ctypes.c_int64 * n)(*[a.nbytes for a in arrs])
+    _check(lib().roreg_write_files(c_paths, c_heads, c_hlen, c_data, c_len, n, int(n_threads)), 'roreg_write_files')
+
+
 def yohoc_draw_many(seeds, anchors_list, max_iter, max_tries=50000, n_threads=None):
     """yohoc_draws() of many pairs in one threaded host call, pair p from np.random.RandomState(seeds[p]) (roreg_yohoc_draw_many):
     anchors_list[p] = the coarse rotations of the correspondences pair p draws from.  -> [rows int64 [H_p, 3] or None (the reference gives up),

@@ -561,3 +561,20 @@ def test_yohoc_draws_of_many_pairs_in_one_host_call_replay_the_per_pair_streams(
             else:
                 assert got[q] is not None and np.array_equal(got[q], want), q
         assert n_gave_up >= 8
+
+
+def test_write_npy_files_is_np_save_byte_for_byte(tmp_path):
+    """roreg_write_files behind hip.write_npy_files (round 6: the StageFileWriter's per-pair files without np.save's interpreter time): the same
+    header bytes numpy writes, the same data -- every dtype and shape of the stage-file contract, empty arrays included."""
+    import filecmp
+    from roreg_amd import hip
+    rng = np.random.default_rng(0)
+    arrs = [rng.integers(0, 5000, (137, 2)).astype(np.int64), np.ones(137), rng.random((0, 3, 4)), rng.random((449, 3, 4)), rng.random(5).astype(np.float32),
+            np.zeros((0, 2), np.int64), rng.random((50, 32, 60)).astype(np.float32), np.arange(7, dtype=np.int64), np.float32(rng.random(60))[::2]]
+    pa = [str(tmp_path / f'a{i}.npy') for i in range(len(arrs))]; pb = [str(tmp_path / f'b{i}.npy') for i in range(len(arrs))]
+    for p, a in zip(pa, arrs):
+        np.save(p, a)
+    hip.write_npy_files(pb, arrs, n_threads=3)
+    assert all(filecmp.cmp(x, y, shallow=False) for x, y in zip(pa, pb))
+    with pytest.raises(hip.HipError):
+        hip.write_npy_files([str(tmp_path / 'no_such_dir' / 'x.npy')], [np.zeros(3)])
