@@ -747,7 +747,7 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
                            'ms_per_step_all_sinkhorn_iterations': 1e3 * d_fix,
                            'sinkhorn': {'iterations_asked': 100, 'iterations_run_mean': it_run / max(it_pairs, 1), 'pairs': it_pairs // max(n, 1),
                                         'rule': 'a pair stops at the fixed point of the float32 iteration: once an iteration\'s largest step of a potential is <= max(2^-22 |u|, 2^-20) in log2 '
-                                                'units (2 .. 4 float32 ulps), or <= 8 such units and no longer shrinking (>= 0.95 of the previous iteration\'s): the noise floor '
+                                                'units (2 .. 4 float32 ulps), or <= 8 such units and not smaller than the previous iteration\'s: the noise floor '
                                                 'of the recomputed scores; roreg_sinkhorn_early_exit(0) runs all of them',
                                         'ms_per_pair': sk_ms / max(work.get('sinkhorn_pairs', 1), 1) if sk_n else None,
                                         'ms_per_pair_all_iterations': skf_ms / max(work_fix.get('sinkhorn_pairs', 1), 1) if skf_n else None,

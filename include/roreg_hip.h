@@ -484,12 +484,11 @@ int roreg_mlp_head(const float *x, const float *pos, const float *table, const i
 /* v6: the recomputed iterations stop PER PAIR at the fixed point of the float32 iteration u <- log_mu - LSE(Z + v), v <- log_nu - LSE(Z + u)
  * (network/rot_coh_match.py:285-292).  Every iteration records the largest step any of the pair's m + n + 2 potentials took, in units of
  * max(2^-22 |u|, 2^-20) (log2 units: 2 .. 4 units in the last place of the float32 potential); the pair's remaining iterations are skipped once
- * (a) an iteration's largest step is <= 1 unit, or (b) it is <= 8 units and no longer shrinking (>= 0.95 of the previous iteration's): the
+ * (a) an iteration's largest step is <= 1 unit, or (b) it is <= 8 units and not smaller than the previous iteration's: the
  * potentials then only jitter in their last bits (the recomputed scores are re-rounded whenever a potential moves by an ulp).  The reference
  * always runs `iters` (= 100) iterations; past that point they move nothing but those bits, so matches are unchanged and scores agree to
  * float32 noise (tests/test_hip_rm.py and tests/test_hip_fullsize.py hold both settings to the reference's goldens).  A pair whose potentials
- * keep moving runs all `iters`; a sequence still contracting slower than 0.95 per iteration cannot reach 8 units within 100 iterations, so (b)
- * never cuts a slow convergence short.  roreg_sinkhorn_early_exit(on): 1 = stop settled pairs (default; ROREG_OT_EARLY_EXIT=0 in the
+ * keep moving runs all `iters`; a sequence that still converges, however slowly, shrinks its steps monotonically and never satisfies (b).  roreg_sinkhorn_early_exit(on): 1 = stop settled pairs (default; ROREG_OT_EARLY_EXIT=0 in the
  * environment starts with 0), 0 = always `iters` iterations, < 0 = query; returns the previous setting.  roreg_sinkhorn_iteration_stats: sum
  * of the iterations run and number of pairs over the recomputed-iteration calls since the last reset (synchronises `stream`; host pointers). */
 int roreg_sinkhorn_early_exit(int on);

@@ -273,7 +273,7 @@ OT_COOP = os.environ.get('ROREG_OT_COOP', '0') == '1'
 class sinkhorn_early_exit:
     """`with hip.sinkhorn_early_exit(False): ...` -- every pair runs all `iters` Sinkhorn iterations, like the reference's loop
     (network/rot_coh_match.py:289-292); the default (True) stops a pair at the fixed point of the float32 iteration: once an iteration's largest
-    step is within 2 .. 4 float32 units in the last place, or within 8 such units and no longer shrinking (include/roreg_hip.h,
+    step is within 2 .. 4 float32 units in the last place, or within 8 such units and not smaller than the previous iteration's (include/roreg_hip.h,
     roreg_sinkhorn_early_exit).  The library-wide switch is restored on exit."""
 
     def __init__(self, on=True):

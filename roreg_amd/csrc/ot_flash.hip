@@ -61,20 +61,20 @@ struct Side {                             // one side (source rows or target col
 // took in iteration t, in units of OF_TOL (max(2^-22 |u|, 2^-20) in log2 units: 2 .. 4 units in the last place of the float32 potential), as
 // float bits; 0 for an iteration that did not run (the array is cleared up front).  Iteration t >= 1 is SKIPPED for a pair when
 //   (a) move[t-1] <= 1: nothing moved beyond float32 resolution, or
-//   (b) move[t-1] <= OF_PLATEAU_MAX and move[t-1] >= OF_PLATEAU_RATIO move[t-2]: the steps are small and have stopped shrinking -- the
+//   (b) move[t-1] <= OF_PLATEAU_MAX and move[t-1] >= move[t-2]: the steps are small and this one is NOT SMALLER than the last -- the
 //       iteration has reached the noise floor of its own arithmetic (the scores come out of fp16 hi/lo MFMAs accumulated in float32 at
 //       magnitudes |Z| + |u| + |v| ~ 40: a step of one ulp in u re-rounds them, and the potentials then jitter by 3 .. 4 ulps for ever).
 // Either way the pair sits at the fixed point of the float32 iteration; the reference's loop (network/rot_coh_match.py:289-292 always runs
-// `iters` = 100 of them) only moves last bits from there on.  A geometric sequence still contracting by less than OF_PLATEAU_RATIO per
-// iteration cannot come from a first step of ~20 to OF_PLATEAU_MAX units within 100 iterations, so (b) does not cut a slow convergence
-// short.  Skipping is sticky (a skipped iteration records 0, which is (a) for the next one) and a pair's record depends on its own data only.
+// `iters` = 100 of them) only moves last bits from there on.  A sequence that still converges -- however slowly: a slow mode shrinks its steps
+// monotonically -- never satisfies (b); at the noise floor the steps fluctuate (equal values are common: they are a few ulps), so (b) fires
+// within an iteration or two of reaching it.  Skipping is sticky (a skipped iteration records 0, which is (a) for the next one) and a pair's record depends on its own data only.
 // hist == nullptr: everything runs and nothing is recorded (early exit off).
 struct Conv {
     unsigned *hist;                            // move[pair 0][0]; pair p's record at hist + p * stride
     int t, stride;
     float tol_rel, tol_abs;
 };
-constexpr float OF_TOL_REL = 0x1p-22f, OF_TOL_ABS = 0x1p-20f, OF_PLATEAU_MAX = 8.0f, OF_PLATEAU_RATIO = 0.95f;
+constexpr float OF_TOL_REL = 0x1p-22f, OF_TOL_ABS = 0x1p-20f, OF_PLATEAU_MAX = 8.0f, OF_PLATEAU_RATIO = 1.0f;
 __device__ __forceinline__ bool conv_stop(const unsigned *rec, int t) {
     if (t < 1) return false;
     const float r1 = __uint_as_float(rec[t - 1]);
