@@ -718,7 +718,7 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
         work_fix = hip.WORK; hip.WORK = None; hip.profile_enable(False)
     # what stopping at the fixed point changes: the match lists (the index outputs), the matching scores, and -- where the pair registers at all on
     # this synthetic data (most do not under the shipped RM weights, and a failed registration is a function of the scores' last bits) -- the transform
-    same_m = 0; dsc = []; dT_ok = []; n_ok = 0
+    same_m = 0; dsc = []; dT_ok = []; n_ok = n_ok_a = n_ok_b = 0
     for (sc, a), (_, b) in zip(rows, rows_fix):
         same = a.n_match == b.n_match and torch.equal(a.matches, b.matches)
         same_m += int(same)
@@ -726,6 +726,7 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
             dsc.append(float(np.abs(a.scores - b.scores).max()))
         gt = synth.pose_transform(scenes[sc][2], a.id0, a.id1)
         good = lambda r: bool(np.isfinite(r.trans).all() and compute_R_diff(r.trans[:3, :3], gt[:3, :3]) < 15 and np.sqrt(np.sum(np.square(r.trans[:3, 3] - gt[:3, 3]))) < 0.3)
+        n_ok_a += int(good(a)); n_ok_b += int(good(b))
         if good(a) or good(b):
             n_ok += 1
             dT_ok.append(float(np.abs(a.trans - b.trans).max()) if good(a) and good(b) else float('inf'))
@@ -753,7 +754,7 @@ def rd_rm_full(args, totals, eng_rr, step, bracket, scenes, weights, dist, coll_
                                         'ms_per_pair_all_iterations': skf_ms / max(work_fix.get('sinkhorn_pairs', 1), 1) if skf_n else None,
                                         'pairs_with_identical_match_lists_to_all_iterations': same_m, 'pairs_compared': len(rows),
                                         'max_abs_diff_of_matching_scores_on_those': max(dsc or [0.0]),
-                                        'pairs_registered_in_either_run': n_ok, 'of_those_registered_in_both': int(sum(1 for x in dT_ok if np.isfinite(x))),
+                                        'pairs_registered': n_ok_a, 'pairs_registered_all_iterations': n_ok_b, 'pairs_registered_in_either_run': n_ok, 'of_those_registered_in_both': int(sum(1 for x in dT_ok if np.isfinite(x))),
                                         'max_abs_diff_of_transforms_on_those': max([x for x in dT_ok if np.isfinite(x)] or [0.0])},
                            'results_identical_to_all_local_transforms': bool(same), 'mean_matches_rank0': float(np.mean([r.n_match for _, r in rows])) if rows else None,
                            'registration_recall_pointdsc_rank0': float(np.mean(ok)) if ok else None,
