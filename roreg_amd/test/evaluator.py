@@ -106,6 +106,7 @@ class yoho_evaluator:
                 self.pool = ThreadPoolExecutor(max(1, int(os.environ.get('ROREG_LOADER_THREADS', 8))))
                 self.stream = torch.cuda.Stream()
                 self.keep = []                                   # (the pinned buffers live until the scene is done)
+                self.read_done = []
 
                 def read(i):
                     # a float32 C-ordered .npy (what testset.py writes) goes from the page cache into the pinned buffer with ONE readinto();
@@ -132,6 +133,7 @@ class yoho_evaluator:
                         dev = dst.to('cuda', non_blocking=True)
                         done = torch.cuda.Event(); done.record(self.stream)
                     self.keep.append(dst)
+                    self.read_done.append(time.perf_counter())
                     return dev, done
                 self.jobs = {i: self.pool.submit(read, i) for i in ids}
 
@@ -145,10 +147,13 @@ class yoho_evaluator:
             def close(self):
                 self.pool.shutdown(wait=True)
                 self.keep.clear()
+        marks = [('engine_ready', time.perf_counter() - t_start)]
         feats = Inputs(ids)
         keys = {i: dataset.get_kps(str(i)) for i in ids}
+        marks.append(('keypoints_loaded', time.perf_counter() - t_start))
         writer = StageFileWriter(cfg, dataset.name, self.keynum, clouds_dir=files.clouds)
         files.make(files.result_dir(self.ET, self.max_iter))
+        marks.append(('writer_ready', time.perf_counter() - t_start))
         ready = {}
         for i in ids:
             if os.path.exists(files.feature(i)):                 # extracted by an earlier run: the file is the contract
@@ -184,6 +189,9 @@ class yoho_evaluator:
             writer.close()
             feats.close()
         t_end = time.perf_counter()
+        marks += [('first_input_in_pinned_memory', min(feats.read_done, default=t_start) - t_start), ('last_input_in_pinned_memory', max(feats.read_done, default=t_start) - t_start),
+                  ('results_on_host', t_run - t_start), ('result_files_queued', t_res - t_start), ('writer_closed', t_end - t_start)]
+        self.last_scene_timeline = marks
         self.last_scene_seconds = {'engine_until_results_on_host': t_run - t_start, 'result_files': t_res - t_run, 'waiting_for_the_stage_file_writer': t_end - t_res}
 
     # ---- metrics --------------------------------------------------------------------------------------------

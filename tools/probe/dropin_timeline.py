@@ -1,0 +1,57 @@
+"""Workload for a GPU timeline of the evaluator's engine route (tools/probe/dropin_timeline.sh runs it under rocprofv3 --kernel-trace
+--memory-copy-trace): bench.py's dropin scene on disk, `process_scene` three times (the third is the one to read), then the engine alone on
+resident inputs twice -- 0.5 s of sleep between the runs so the report can cut the trace into windows."""
+import os, sys, time, tempfile, shutil
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from roreg_amd import synth
+from roreg_amd.engine import RegistrationEngine
+from roreg_amd.network import name2network
+from roreg_amd.parses.parses_test import default_config
+from roreg_amd.test import _cache
+from roreg_amd.test.evaluator import yoho_evaluator
+
+n_clouds, n_pairs, kpts = 60, 449, 5000
+torch.manual_seed(0)
+cfg0 = default_config(keynum=kpts, max_iter=1000, ET='yohoo')
+gf_sd = synth.seeded_state_dict(name2network['GF_test'](cfg0), 101)
+et_sd = synth.seeded_state_dict(name2network['ET_test'](cfg0), 202)
+root = tempfile.mkdtemp(prefix='roreg_dropin_tl_')
+try:
+    feats, keys, poses = synth.make_scene_device(777, n_clouds, kpts, 0.6)
+    pairs = synth.scene_pair_list(n_clouds, n_pairs, 901, locality=8.0)
+    ds = synth.SynthScene('synth/kitchen', [k.cpu().numpy() for k in keys], None, poses, pairs)
+    inputs = f'{root}/inputs/FCGF_Input_Group_feature'
+    os.makedirs(inputs)
+    for i, f in enumerate(feats):
+        np.save(f'{inputs}/{i}.npy', f.cpu().numpy())
+    for kind, sd in (('GF', gf_sd), ('ET', et_sd)):
+        os.makedirs(f'{root}/ckpt/{kind}')
+        torch.save({'best_para': 0, 'network_state_dict': sd}, f'{root}/ckpt/{kind}/model_best.pth')
+    cfg = default_config(output_cache_fn=f'{root}/cache_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kpts, max_iter=1000, ET='yohoo')
+    ev = yoho_evaluator(cfg)
+    for rep in range(3):
+        cache = f'{root}/cache_{rep}'
+        cfg.output_cache_fn = cache
+        os.makedirs(f'{cache}/{ds.name}')
+        os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
+        _cache.clear()
+        np.random.seed(5)
+        torch.cuda.synchronize(); time.sleep(0.5); t0 = time.perf_counter()
+        ev.process_scene(ds)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f'engine route, scene {rep}: {dt:.4f} s = {n_pairs / dt:.1f} pairs/s  {getattr(ev, "last_scene_seconds", None)}', flush=True)
+        tl = getattr(ev, 'last_scene_timeline', None)
+        if tl:
+            print('   host marks (ms from the start of process_scene): ' + ', '.join(f'{k} {1e3 * v:.1f}' for k, v in tl), flush=True)
+        shutil.rmtree(cache, ignore_errors=True)
+    eng = ev._engine()
+    for rep in range(3):
+        np.random.seed(5)
+        torch.cuda.synchronize(); time.sleep(0.5); t0 = time.perf_counter()
+        eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f'engine alone, resident inputs, run {rep}: {dt:.4f} s = {n_pairs / dt:.1f} pairs/s', flush=True)
+finally:
+    shutil.rmtree(root, ignore_errors=True)
