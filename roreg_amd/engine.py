@@ -11,6 +11,7 @@ the result table.
 from dataclasses import dataclass, field
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -84,14 +85,48 @@ class StageFileWriter:
             make_non_exists_dir(f'{clouds_dir}/YOHO_Output_Group_feature')
             if getattr(cfg, 'RD', False):
                 make_non_exists_dir(f'{clouds_dir}/det_score')
-        self.stream = torch.cuda.Stream()
+        # high priority: the copy kernels of the 38.4 MB feature downloads otherwise queue for compute units behind the estimator's launches
+        self.stream = torch.cuda.Stream(priority=-1)
         self.q = queue.Queue()
         self.error = None
+        self.log = []                                                # (directory, bytes, time the copy had landed, time the file was written)
         # a few workers: np.save of a contiguous array is one fwrite with the GIL released, so the 38.4 MB feature files of a scene go to
         # the page cache side by side (one worker wrote 60 of them in ~2 s, longer than the scene's kernels take)
         self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, int(os.environ.get('ROREG_WRITER_THREADS', 4))))]
         for t in self.threads:
             t.start()
+        self.also_precreate = []                                     # (a caller's own per-pair files, e.g. the evaluator's result archives: created after the engine's)
+        self._creator, self._cq = None, queue.Queue()
+
+    def precreate(self, paths):
+        """Create (empty) files that are ALWAYS rewritten -- match lists, scores, DR_index, Trans_pre, result archives; never the extractor /
+        detector outputs, whose existence means 'done' to the stage chain -- ahead of their data, on ONE thread of its own.  Creating a file
+        on the GPU box's overlay filesystem is a serialised ~0.16 ms (0.33 when several threads do it at once) against 0.01-0.03 ms for
+        writing into one that exists (tools/probe/small_files_probe.py): a 449-pair scene's ~2250 creations otherwise queue up behind the
+        scene's last kernel (0.13-0.35 s).  A file the writer got to first is left as it is (no truncation here)."""
+        import threading
+        if os.environ.get('ROREG_WRITER_PRECREATE', '1') == '0':     # (the switch is for A/B measurements)
+            return
+        if self._creator is None:
+            def create():
+                while True:
+                    batch = self._cq.get()
+                    if batch is None:
+                        return
+                    for p in batch:
+                        try:
+                            os.close(os.open(p, os.O_CREAT | os.O_WRONLY, 0o644))
+                        except OSError:
+                            pass                                     # (the write that follows reports what is wrong with the path)
+            self._creator = threading.Thread(target=create, daemon=True)
+            self._creator.start()
+        self._cq.put(list(paths))
+
+    def precreate_pairs(self, pair_ids, trans_pre):
+        """the engine's per-pair files of a scene, in the order they will be written, then the caller's (also_precreate)"""
+        names = [f'{a}-{b}.npy' for a, b in pair_ids]
+        self.precreate([f'{self.dir}/{sub}{n}' for sub in ('', 'scores/', 'DR_index/') + (('Trans_pre/',) if trans_pre else ()) for n in names] + list(self.also_precreate))
+        self.also_precreate = []
 
     def _work(self):
         while True:
@@ -105,16 +140,21 @@ class StageFileWriter:
                 if len(item) == 4:                                   # save_many: one pinned buffer, a file per slice
                     paths, host, done, shapes = item
                     done.synchronize()
+                    t_landed = time.perf_counter()
                     a, o, parts = host.numpy(), 0, []
                     for shape in shapes:
                         n = int(np.prod(shape))
                         parts.append(a[o:o + n].reshape(shape)); o += n
                     hip.write_npy_files(paths, parts, n_threads=2)   # (np.save's bytes without np.save's ~80 us of interpreter time per file)
+                    self.log.append((os.path.basename(os.path.dirname(paths[0])), a.nbytes, t_landed, time.perf_counter()))
                     continue
                 path, host, done = item
                 if done is not None:
                     done.synchronize()
-                hip.write_npy_files([path], [host.numpy() if torch.is_tensor(host) else host], n_threads=1)
+                t_landed = time.perf_counter()
+                a = host.numpy() if torch.is_tensor(host) else host
+                hip.write_npy_files([path], [a], n_threads=1)
+                self.log.append((os.path.basename(os.path.dirname(path)), a.nbytes, t_landed, time.perf_counter()))
             except Exception as e:                                  # surfaced by close()
                 self.error = e
 
@@ -139,6 +179,18 @@ class StageFileWriter:
         """run fn() on a writer thread (result files, logs); close() waits for it"""
         self.q.put(fn)
 
+    def save_many_host(self, rels, arrays):
+        """Many host arrays (a scene's per-pair score files), one queue entry, one threaded C call."""
+        if not len(rels):
+            return
+        paths = [f'{self.dir}/{r}.npy' for r in rels]
+
+        def write():
+            t0 = time.perf_counter()
+            hip.write_npy_files(paths, arrays, n_threads=2)
+            self.log.append((os.path.basename(os.path.dirname(paths[0])), sum(a.nbytes for a in arrays), t0, time.perf_counter()))
+        self.q.put(write)
+
     def save_many(self, rels, tensors):
         """Many small device tensors of one dtype (a scene's per-pair match lists, DR_index, Trans_pre): ONE concatenation, ONE device -> pinned-host
         copy and one queue entry; the worker writes each file from its slice (a copy per file cost ~0.3 ms of host time on the critical path:
@@ -157,6 +209,10 @@ class StageFileWriter:
         self.q.put(([f'{self.dir}/{r}.npy' for r in rels], host, done, shapes))
 
     def close(self):
+        if self._creator is not None:
+            self._cq.put(None)
+            self._creator.join()
+            self._creator = None
         for _ in self.threads:
             self.q.put(None)
         for t in self.threads:
@@ -262,7 +318,7 @@ class RegistrationEngine:
         k = keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys, np.float64))
         return CloudState(before=x, eqv=eqv, eqv_ft=hip.feat_coefs(eqv), inv=hip.inv_descriptor(eqv), keys=k.to('cuda', torch.float64).contiguous())
 
-    def extract_many(self, feats_list, keys_list, max_rows=None):
+    def extract_many(self, feats_list, keys_list, max_rows=None, on_batch=None):
         """Several clouds per group-conv launch: a 5000-keypoint cloud is 9.2 waves of workgroups on the 512 resident slots,
         so a lone cloud wastes ~8 % in the partial last wave; batching clouds makes that tail negligible."""
         max_rows = self.extract_rows if max_rows is None else max_rows
@@ -308,6 +364,8 @@ class RegistrationEngine:
                     k = k.to('cuda', torch.float64).contiguous()
                 out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], eqv_ft=eft[o:o + n], inv=inv[o:o + n], keys=k))
                 o += n
+            if on_batch is not None:                             # (the writer: a batch's downloads start behind ITS kernels, not behind the whole scene's)
+                on_batch(range(i, j), out[i:j])
             i = j
         return out
 
@@ -600,8 +658,7 @@ class RegistrationEngine:
         for c, k in zip(need_keys, got[2:]):
             c.keys_host = np.array(k)
         if writer is not None:
-            for (a, b), (off, n) in zip(pair_ids, batch.offsets):
-                writer.save(f'DR_index/{a}-{b}', dr_all[off:off + n].copy())
+            writer.save_many_host([f'DR_index/{a}-{b}' for a, b in pair_ids], [dr_all[off:off + n].copy() for off, n in batch.offsets])
         starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
 
         def draw(i, rng):
@@ -769,13 +826,17 @@ class RegistrationEngine:
         used = sorted({int(i) for p in pair_ids for i in p})
         have = {} if ready is None else ready
         todo = [i for i in used if i not in have]
-        fresh = dict(zip(todo, self.extract_many(_LazySeq(feats, todo), [keys[i] for i in todo])))
+        save_eqv = None
+        if writer is not None:
+            writer.precreate_pairs(pair_ids, trans_pre=getattr(self.cfg, 'ET', 'yohoo') != 'yohoc')
+        if writer is not None and writer.clouds_dir is not None:         # the extractor's file contract: float32 whatever the storage type
+            def save_eqv(qs, cs):
+                for q, c in zip(qs, cs):
+                    writer.save_path(f'{writer.clouds_dir}/YOHO_Output_Group_feature/{todo[q]}.npy', c.eqv.float())
+        fresh = dict(zip(todo, self.extract_many(_LazySeq(feats, todo), [keys[i] for i in todo], on_batch=save_eqv)))
         clouds = {i: (have[i] if i in have else fresh[i]) for i in used}
         if ready is not None:
             ready.update(fresh)
-        if writer is not None and writer.clouds_dir is not None:         # the extractor's file contract: float32 whatever the storage type
-            for i in todo:
-                writer.save_path(f'{writer.clouds_dir}/YOHO_Output_Group_feature/{i}.npy', fresh[i].eqv.float())
         t0 = self._mark('extract', t0)
         if self.cfg.RD:
             unscored = [i for i in used if clouds[i].det is None]
@@ -822,8 +883,7 @@ class RegistrationEngine:
             all_scores = [None] * len(full)
         if writer is not None:
             writer.save_many([f'{a}-{b}' for a, b in pair_ids], [m for _, _, m in full])
-            for (a, b), (_, _, m), sc in zip(pair_ids, full, all_scores):
-                writer.save(f'scores/{a}-{b}', np.ones(int(m.shape[0])) if sc is None else sc)
+            writer.save_many_host([f'scores/{a}-{b}' for a, b in pair_ids], [np.ones(int(m.shape[0])) if sc is None else sc for (_, _, m), sc in zip(full, all_scores)])
         t0 = self._mark('match', t0)
         # stage 4: all pairs
         yohoc = getattr(self.cfg, 'ET', 'yohoo') == 'yohoc'

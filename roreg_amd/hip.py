@@ -602,6 +602,21 @@ def write_npy_files(paths, arrays, n_threads=4):
     _check(lib().roreg_write_files(c_paths, c_heads, c_hlen, c_data, c_len, n, int(n_threads)), 'roreg_write_files')
 
 
+def write_files(paths, blobs, n_threads=4):
+    """file q = blobs[q] (bytes-like), many files in ONE call that releases the interpreter lock (roreg_write_files with empty headers)."""
+    n = len(paths)
+    if n == 0:
+        return
+    views = [np.frombuffer(b, np.uint8) for b in blobs]
+    empty = ctypes.c_char_p(b'')
+    c_paths = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    c_heads = (ctypes.c_char_p * n)(*([empty.value] * n))
+    c_hlen = (ctypes.c_int32 * n)(*([0] * n))
+    c_data = (ctypes.c_void_p * n)(*[v.ctypes.data if v.size else None for v in views])
+    c_len = (ctypes.c_int64 * n)(*[v.nbytes for v in views])
+    _check(lib().roreg_write_files(c_paths, c_heads, c_hlen, c_data, c_len, n, int(n_threads)), 'roreg_write_files')
+
+
 def yohoc_draw_many(seeds, anchors_list, max_iter, max_tries=50000, n_threads=None):
     """yohoc_draws() of many pairs in one threaded host call, pair p from np.random.RandomState(seeds[p]) (roreg_yohoc_draw_many):
     anchors_list[p] = the coarse rotations of the correspondences pair p draws from.  -> [rows int64 [H_p, 3] or None (the reference gives up),

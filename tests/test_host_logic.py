@@ -578,3 +578,32 @@ def test_write_npy_files_is_np_save_byte_for_byte(tmp_path):
     assert all(filecmp.cmp(x, y, shallow=False) for x, y in zip(pa, pb))
     with pytest.raises(hip.HipError):
         hip.write_npy_files([str(tmp_path / 'no_such_dir' / 'x.npy')], [np.zeros(3)])
+
+
+def test_result_archives_from_a_template_load_like_np_savez(tmp_path):
+    """The evaluator's engine route writes a scene's result archives (test/estimator.py:436-441: np.savez(trans=, [center=,] recalltime=)) from a
+    template of np.savez's own bytes with the data and CRCs replaced (_NpzTemplate) through hip.write_files: np.load gives the same members in the
+    same order, dtypes and shapes; the archive passes zipfile's CRC check; placeholder files created ahead (StageFileWriter.precreate) are
+    overwritten, never kept."""
+    import zipfile
+    from roreg_amd import hip
+    from roreg_amd.test.evaluator import _NpzTemplate
+    rng = np.random.default_rng(1)
+    for with_center in (False, True):
+        make = lambda: {'trans': rng.standard_normal((4, 4)), **({'center': np.ones([6, 3])} if with_center else {}), 'recalltime': int(rng.integers(0, 60000))}
+        tpl = _NpzTemplate(make())
+        sets = [make() for _ in range(9)]
+        assert all(_NpzTemplate.signature(a) == tpl.key for a in sets)
+        paths = [str(tmp_path / f'{int(with_center)}-{i}.npz') for i in range(len(sets))]
+        for p in paths[:4]:
+            open(p, 'wb').write(b'stale bytes of an earlier, longer file' * 100)
+        hip.write_files(paths, [tpl.fill(a) for a in sets], n_threads=3)
+        for p, a in zip(paths, sets):
+            ref = str(tmp_path / 'ref.npz')
+            np.savez(ref, **a)
+            x, y = np.load(p), np.load(ref)
+            assert x.files == y.files
+            assert all(np.array_equal(x[k], y[k]) and x[k].dtype == y[k].dtype and x[k].shape == y[k].shape for k in y.files)
+            assert zipfile.ZipFile(p).testzip() is None
+            assert os.path.getsize(p) == os.path.getsize(ref)
+    assert _NpzTemplate.signature({'trans': np.zeros((4, 4)), 'recalltime': np.int32(3)}) != _NpzTemplate.signature({'trans': np.zeros((4, 4)), 'recalltime': 3})

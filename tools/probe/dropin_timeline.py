@@ -38,9 +38,19 @@ try:
         os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
         _cache.clear()
         np.random.seed(5)
+        prof = None
+        if rep == 2 and '--cprofile' in sys.argv:
+            import cProfile
+            prof = cProfile.Profile()
         torch.cuda.synchronize(); time.sleep(0.5); t0 = time.perf_counter()
+        if prof: prof.enable()
         ev.process_scene(ds)
+        if prof: prof.disable()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if prof:
+            import io, pstats
+            for key in ('tottime', 'cumtime'):
+                st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats(key).print_stats(32); print(st.getvalue()[:7000])
         print(f'engine route, scene {rep}: {dt:.4f} s = {n_pairs / dt:.1f} pairs/s  {getattr(ev, "last_scene_seconds", None)}', flush=True)
         tl = getattr(ev, 'last_scene_timeline', None)
         if tl:
