@@ -86,7 +86,7 @@ class StageFileWriter:
             if getattr(cfg, 'RD', False):
                 make_non_exists_dir(f'{clouds_dir}/det_score')
         # high priority: the copy kernels of the 38.4 MB feature downloads otherwise queue for compute units behind the estimator's launches
-        self.stream = torch.cuda.Stream(priority=-1)
+        self.stream = hip.named_stream('stage_file_writer', priority=-1)
         self.q = queue.Queue()
         self.error = None
         self.log = []                                                # (directory, bytes, time the copy had landed, time the file was written)
@@ -137,8 +137,8 @@ class StageFileWriter:
                 if callable(item):                                   # submit(): any host-side file work
                     item()
                     continue
-                if len(item) == 4:                                   # save_many: one pinned buffer, a file per slice
-                    paths, host, done, shapes = item
+                if len(item) == 5:                                   # save_many: one pinned buffer, a file per slice
+                    paths, host, done, shapes, buf = item
                     done.synchronize()
                     t_landed = time.perf_counter()
                     a, o, parts = host.numpy(), 0, []
@@ -147,14 +147,19 @@ class StageFileWriter:
                         parts.append(a[o:o + n].reshape(shape)); o += n
                     hip.write_npy_files(paths, parts, n_threads=2)   # (np.save's bytes without np.save's ~80 us of interpreter time per file)
                     self.log.append((os.path.basename(os.path.dirname(paths[0])), a.nbytes, t_landed, time.perf_counter()))
+                    del a, parts, host
+                    hip.pinned_pool.release(buf)                     # (the copy has landed and the files are written)
                     continue
-                path, host, done = item
+                path, host, done, buf = item
                 if done is not None:
                     done.synchronize()
                 t_landed = time.perf_counter()
                 a = host.numpy() if torch.is_tensor(host) else host
                 hip.write_npy_files([path], [a], n_threads=1)
                 self.log.append((os.path.basename(os.path.dirname(path)), a.nbytes, t_landed, time.perf_counter()))
+                del a, host
+                if buf is not None:
+                    hip.pinned_pool.release(buf)
             except Exception as e:                                  # surfaced by close()
                 self.error = e
 
@@ -164,16 +169,23 @@ class StageFileWriter:
 
     def save_path(self, path, a):
         if not torch.is_tensor(a):
-            self.q.put((path, np.ascontiguousarray(a), None))
+            self.q.put((path, np.ascontiguousarray(a), None, None))
             return
         ready = torch.cuda.Event(); ready.record()                  # after the producing kernels on the current stream
+        host, buf = self._pinned(a)
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
-            host = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
             host.copy_(a, non_blocking=True)
             done = torch.cuda.Event(); done.record(self.stream)
         a.record_stream(self.stream)                                # the allocator must not hand the block out before the copy ran
-        self.q.put((path, host, done))
+        self.q.put((path, host, done, buf))
+
+    @staticmethod
+    def _pinned(a):
+        """a pinned host tensor of a's shape and dtype out of the process's pool (hip.PinnedPool: no pinned allocation in the steady state)"""
+        nbytes = a.numel() * a.element_size()
+        buf = hip.pinned_pool.acquire(nbytes)
+        return buf[:nbytes].view(a.dtype).reshape(a.shape), buf
 
     def submit(self, fn):
         """run fn() on a writer thread (result files, logs); close() waits for it"""
@@ -200,13 +212,13 @@ class StageFileWriter:
         shapes = [tuple(t.shape) for t in tensors]
         flat = torch.cat([t.reshape(-1) for t in tensors])
         ready = torch.cuda.Event(); ready.record()
+        host, buf = self._pinned(flat)
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
-            host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
             host.copy_(flat, non_blocking=True)
             done = torch.cuda.Event(); done.record(self.stream)
         flat.record_stream(self.stream)
-        self.q.put(([f'{self.dir}/{r}.npy' for r in rels], host, done, shapes))
+        self.q.put(([f'{self.dir}/{r}.npy' for r in rels], host, done, shapes, buf))
 
     def close(self):
         if self._creator is not None:
@@ -355,13 +367,21 @@ class RegistrationEngine:
                 eqv = self.gf.PartI_net(xcat, want_inv=False, out_dtype=self.feat_dtype)['eqv']
             inv = hip.inv_descriptor(eqv)
             eft = hip.feat_coefs(eqv)
+            # host keypoints (the evaluator's files): ONE upload per batch through the staging ring -- a pageable .to('cuda') per cloud waits for
+            # every kernel queued so far (the host then never runs ahead of the extractor), and a ring slot per cloud wraps the ring inside a scene
+            on_host = [q for q in range(i, j) if not (torch.is_tensor(keys_list[q]) and keys_list[q].is_cuda)]
+            k_dev = {}
+            if on_host:
+                hk = [np.ascontiguousarray(keys_list[q].numpy() if torch.is_tensor(keys_list[q]) else keys_list[q], np.float64).reshape(-1, 3) for q in on_host]
+                flat_k, ko = hip.upload(np.concatenate(hk)), 0
+                for q, h in zip(on_host, hk):
+                    k_dev[q] = flat_k[ko:ko + h.shape[0]]; ko += h.shape[0]
             o = 0
             for q in range(i, j):
                 n = xs[q - i].shape[0]
-                k = keys_list[q]
-                k = k if torch.is_tensor(k) else torch.from_numpy(np.ascontiguousarray(k, np.float64))
-                if not (k.is_cuda and k.dtype == torch.float64 and k.is_contiguous()):
-                    k = k.to('cuda', torch.float64).contiguous()
+                k = k_dev[q] if q in k_dev else keys_list[q]
+                if not (k.dtype == torch.float64 and k.is_contiguous()):
+                    k = k.to(torch.float64).contiguous()
                 out.append(CloudState(before=xcat[o:o + n], eqv=eqv[o:o + n], eqv_ft=eft[o:o + n], inv=inv[o:o + n], keys=k))
                 o += n
             if on_batch is not None:                             # (the writer: a batch's downloads start behind ITS kernels, not behind the whole scene's)

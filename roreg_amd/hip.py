@@ -93,6 +93,55 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class PinnedPool:
+    """Pinned host buffers kept across scenes.  A pinned allocation while kernels are in flight costs 5-90 ms on this stack (the launching thread
+    sat in `torch.empty(pin_memory=True)` / `.pin_memory()` for ~100 ms of a 600 ms scene, tools/probe/dropin_timeline.py --sample), so the
+    file loader, the stage-file writer and the staging ring take their buffers here and hand them back when the copy AND its consumer are done
+    (the caller's responsibility: release() only after the event behind the buffer's last copy has completed)."""
+
+    def __init__(self, max_bytes=None):
+        self.lock = threading.Lock()
+        self.free = {}                                           # size class -> [uint8 pinned tensors]
+        self.held = 0
+        self.max_bytes = int(os.environ.get('ROREG_PINNED_POOL_GB', 12)) << 30 if max_bytes is None else max_bytes
+
+    @staticmethod
+    def size_class(nbytes):
+        if nbytes <= 4096:
+            return 4096
+        step = 1 << max(int(nbytes - 1).bit_length() - 4, 0)     # eight classes per octave: <= 12.5 % unused, and sizes that drift from scene to
+        return -(-nbytes // step) * step                         # scene (match lists, hypothesis tables) land in a class the pool already holds
+
+    def acquire(self, nbytes):
+        c = self.size_class(max(int(nbytes), 1))
+        with self.lock:
+            got = self.free.get(c)
+            if got:
+                self.held -= c
+                return got.pop()
+        return torch.empty(c, dtype=torch.uint8, pin_memory=True)
+
+    def release(self, buf):
+        c = int(buf.shape[0])
+        with self.lock:
+            if self.held + c <= self.max_bytes:
+                self.free.setdefault(c, []).append(buf)
+                self.held += c
+
+
+pinned_pool = PinnedPool()
+_named_streams = {}
+
+
+def named_stream(name, priority=0):
+    """One persistent side stream per purpose ('loader', 'writer', ...).  torch's device allocator caches blocks per stream: a NEW stream per scene
+    for the loader's uploads would leave each scene's 2.3 GB of input blocks cached for a stream that never comes back."""
+    st = _named_streams.get(name)
+    if st is None:
+        st = _named_streams[name] = torch.cuda.Stream(priority=priority)
+    return st
+
+
 class _StagingRing:
     """Host -> device uploads that do not block the host: a ring of persistent pinned buffers, each guarded by an event recorded behind
     its last copy.  (A pageable `.cuda()` waits for everything queued on the stream before it copies -- in the middle of a scene that is
@@ -113,8 +162,12 @@ class _StagingRing:
         self.next = (k + 1) % len(self.bufs)
         if self.events[k] is not None:
             self.events[k].synchronize()
-        if self.bufs[k] is None or self.bufs[k].shape[0] < nbytes:
-            self.bufs[k] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        if self.bufs[k] is None or self.bufs[k].shape[0] < nbytes or self.bufs[k].shape[0] > 4 * PinnedPool.size_class(nbytes):
+            # the slot's buffer goes back to the pool and one of this upload's size class comes out of it: the scene's few large arrays (36 MB of
+            # sampled rows) and its many small ones rotate through the slots, and no slot pins a new buffer for a size the process has seen
+            if self.bufs[k] is not None:
+                pinned_pool.release(self.bufs[k])
+            self.bufs[k] = pinned_pool.acquire(nbytes)
         host = self.bufs[k][:nbytes]
         host.numpy()[:] = a.reshape(-1).view(np.uint8)
         dev = host.cuda(non_blocking=True).view(torch.from_numpy(a[:0].reshape(-1)).dtype).reshape(a.shape)

@@ -156,8 +156,8 @@ class yoho_evaluator:
                 from concurrent.futures import ThreadPoolExecutor
                 self.torch = torch
                 self.pool = ThreadPoolExecutor(max(1, int(os.environ.get('ROREG_LOADER_THREADS', 8))))
-                self.stream = torch.cuda.Stream()
-                self.keep = []                                   # (the pinned buffers live until the scene is done)
+                self.stream = hip.named_stream('input_loader')
+                self.keep = []                                   # (the pinned buffers go back to the pool when the scene is done)
                 self.read_done = []
 
                 def read(i):
@@ -169,7 +169,8 @@ class yoho_evaluator:
                         version = np.lib.format.read_magic(f)
                         shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
                         if dtype == np.float32 and not fortran:
-                            dst = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                            pooled = hip.pinned_pool.acquire(4 * int(np.prod(shape)))
+                            dst = pooled[:4 * int(np.prod(shape))].view(torch.float32).reshape(shape)
                             buf = memoryview(dst.numpy()).cast('B')
                             got = 0
                             while got < len(buf):
@@ -179,12 +180,13 @@ class yoho_evaluator:
                                 got += n
                     if dst is None:
                         src = np.load(path, mmap_mode='r')
-                        dst = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+                        pooled = hip.pinned_pool.acquire(4 * int(np.prod(src.shape)))
+                        dst = pooled[:4 * int(np.prod(src.shape))].view(torch.float32).reshape(src.shape)
                         np.copyto(dst.numpy(), src, casting='same_kind')
                     with torch.cuda.stream(self.stream):
                         dev = dst.to('cuda', non_blocking=True)
                         done = torch.cuda.Event(); done.record(self.stream)
-                    self.keep.append(dst)
+                    self.keep.append(pooled)
                     self.read_done.append(time.perf_counter())
                     return dev, done
                 self.jobs = {i: self.pool.submit(read, i) for i in ids}
@@ -198,6 +200,9 @@ class yoho_evaluator:
 
             def close(self):
                 self.pool.shutdown(wait=True)
+                self.stream.synchronize()                        # (every upload has run: the buffers may be overwritten)
+                for b in self.keep:
+                    hip.pinned_pool.release(b)
                 self.keep.clear()
         marks = [('engine_ready', time.perf_counter() - t_start)]
         feats = Inputs(ids)

@@ -31,7 +31,7 @@ try:
         torch.save({'best_para': 0, 'network_state_dict': sd}, f'{root}/ckpt/{kind}/model_best.pth')
     cfg = default_config(output_cache_fn=f'{root}/cache_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kpts, max_iter=1000, ET='yohoo')
     ev = yoho_evaluator(cfg)
-    for rep in range(3):
+    for rep in range(5):
         cache = f'{root}/cache_{rep}'
         cfg.output_cache_fn = cache
         os.makedirs(f'{cache}/{ds.name}')
@@ -39,7 +39,21 @@ try:
         _cache.clear()
         np.random.seed(5)
         prof = None
-        if rep == 2 and '--cprofile' in sys.argv:
+        samples, stop = [], None
+        if rep >= 1 and '--sample' in sys.argv:                  # where the launching thread sits, every 0.5 ms
+            import threading, traceback
+            main_id = threading.main_thread().ident
+            stop = threading.Event()
+            def sampler():
+                while not stop.is_set():
+                    fr = sys._current_frames().get(main_id)
+                    stack = []
+                    while fr is not None and len(stack) < 4:
+                        stack.append(f'{os.path.basename(fr.f_code.co_filename)}:{fr.f_lineno}({fr.f_code.co_name})'); fr = fr.f_back
+                    samples.append((time.perf_counter(), ' < '.join(stack)))
+                    time.sleep(0.0005)
+            threading.Thread(target=sampler, daemon=True).start()
+        if rep == 4 and '--cprofile' in sys.argv:
             import cProfile
             prof = cProfile.Profile()
         torch.cuda.synchronize(); time.sleep(0.5); t0 = time.perf_counter()
@@ -47,6 +61,18 @@ try:
         ev.process_scene(ds)
         if prof: prof.disable()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if stop is not None:
+            stop.set()
+            runs, cur = [], None
+            for t, w in samples:
+                if t < t0: continue
+                if cur is not None and cur[2] == w: cur[1] = t
+                else:
+                    cur = [t, t, w]; runs.append(cur)
+            print(f'   scene {rep}: where the launching thread stayed >= 4 ms (offset ms, duration ms, innermost frames):')
+            for a_, b_, w in runs:
+                if b_ - a_ >= 0.004:
+                    print(f'      {1e3 * (a_ - t0):7.1f} {1e3 * (b_ - a_):6.1f}  {w}')
         if prof:
             import io, pstats
             for key in ('tottime', 'cumtime'):
