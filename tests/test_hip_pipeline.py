@@ -620,3 +620,32 @@ def test_dropin_end_to_end_on_a_demo_layout(tmp_path, monkeypatch):
     T = np.load(f'{cache}/demo/kitchen/match_160/yohoo/1000iters/0-1.npz')['trans']
     assert np.abs(T[:3] - gt).max() < 1e-3
     assert os.path.exists(f'{base}/Keypoints_PC/cloud_bin_0Keypoints.npy')
+
+
+def test_pinned_pool_and_staging_ring_reuse_their_buffers():
+    """Steady state allocates no pinned memory (a pinned allocation with kernels in flight stalled the launching thread for 5-90 ms): a released
+    buffer comes back for the next request of its class, and the staging ring's uploads of alternating sizes settle on pooled buffers while the
+    uploaded values stay exact."""
+    from roreg_amd import hip
+    pool = hip.PinnedPool(max_bytes=1 << 26)
+    a = pool.acquire(100_000)
+    assert a.is_pinned() and a.shape[0] == hip.PinnedPool.size_class(100_000)
+    ptr = a.data_ptr()
+    pool.release(a); del a
+    b = pool.acquire(99_000)
+    assert b.data_ptr() == ptr                                   # (same class: the same buffer)
+    big = pool.acquire(1 << 27)                                  # beyond the cap: handed out, not kept
+    pool.release(big); pool.release(b)
+    assert pool.held == hip.PinnedPool.size_class(99_000)
+    rng = np.random.default_rng(0)
+    ring = hip._StagingRing(slots=4)
+    for rep in range(6):
+        for n in (37, 3_000_000, 11, 500_000, 2_000_001):
+            x = rng.integers(-9, 9, n).astype(np.int64)
+            d = ring.upload(x)
+            assert d.dtype == torch.int64 and torch.equal(d.cpu(), torch.from_numpy(x))
+    before = hip.pinned_pool.held
+    for n in (37, 3_000_000, 11, 500_000, 2_000_001) * 3:
+        ring.upload(np.zeros(n, np.int64))
+    torch.cuda.synchronize()
+    assert hip.pinned_pool.held <= before + 8 * 3_000_000 * 2    # (the pool does not keep growing)

@@ -607,3 +607,15 @@ def test_result_archives_from_a_template_load_like_np_savez(tmp_path):
             assert zipfile.ZipFile(p).testzip() is None
             assert os.path.getsize(p) == os.path.getsize(ref)
     assert _NpzTemplate.signature({'trans': np.zeros((4, 4)), 'recalltime': np.int32(3)}) != _NpzTemplate.signature({'trans': np.zeros((4, 4)), 'recalltime': 3})
+
+
+def test_pinned_pool_size_classes():
+    """hip.PinnedPool (the buffers of the file loader, the stage-file writer and the staging ring): a class is never smaller than the request,
+    wastes at most 12.5 %, and nearby sizes -- a scene's match lists vary by a few percent from scene to scene -- share one."""
+    from roreg_amd.hip import PinnedPool
+    for n in [1, 4095, 4096, 4097, 65537, 120000, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 38400000, 36 * 10 ** 6, (1 << 30) + 5]:
+        c = PinnedPool.size_class(n)
+        assert c >= n and (n <= 4096 or c <= n * 1.125 + 1)
+        assert PinnedPool.size_class(c) == c
+    assert PinnedPool.size_class(35_900_000) == PinnedPool.size_class(36_400_000)
+    assert len({PinnedPool.size_class(n) for n in range(1 << 20, 1 << 21, 4099)}) <= 9
