@@ -839,6 +839,27 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
                 out[route]['seconds'] = {k: round(v, 3) for k, v in split.items()}
             if phases:
                 out[route]['stage_ms_one_synchronised_run'] = phases
+        # the same route under the estimator an unflagged Test.py runs (parses/parses_test.py:42: --ET yohoc): draws from the process-global generator
+        # in pair order on the launching thread, 3-point Kabsch stacks on the host pool (files equal the stage chain's: tests/test_hip_pipeline.py)
+        os.environ['ROREG_EVALUATOR'] = 'engine'
+        cfg = default_config(output_cache_fn=f'{root}/cache_yohoc_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, ET='yohoc')
+        ev = yoho_evaluator(cfg)
+        ev._engine().set_gemm_mode(args.gemm)
+        runs = []
+        for rep in range(4):
+            cache = f'{root}/cache_yohoc_{rep}'
+            cfg.output_cache_fn = cache
+            os.makedirs(f'{cache}/{ds.name}')
+            os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
+            _cache.clear()
+            np.random.seed(5)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ev.process_scene(ds)
+            torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
+            shutil.rmtree(cache, ignore_errors=True)
+        del ev
+        out['engine_yohoc'] = {'pairs_per_s': n_pairs / float(np.mean(runs[1:])), 's_per_scene': float(np.mean(runs[1:])), 's_each_scene_after_the_first': [round(x, 4) for x in runs[1:]],
+                               's_first_scene': runs[0], 'what': 'Test.py without --ET (yohoc, parses_test.py:42), same scene, same file contract'}
         if before is None:
             os.environ.pop('ROREG_EVALUATOR', None)
         else:

@@ -712,14 +712,14 @@ class RegistrationEngine:
                     pps = pps[sels[i]]
                 jobs.append((c0.keys_host, c1.keys_host, pps[:, 0][idxs], pps[:, 1][idxs]))
             hyps = list(_host_pool().map(kabsch, jobs))
-        else:                                                              # the reference's single global stream: draws in pair order, then the stacks in parallel
-            jobs = []
+        else:                                                              # the reference's single global stream: draws in pair order on this thread,
+            futures = []                                                   # each pair's stack on the pool as soon as its draws exist
             for i in range(len(full)):
                 job, gave_up = draw(i, None)
-                jobs.append(job)
                 if gave_up is not None:
                     skipped[i] = gave_up
-            hyps = list(_host_pool().map(kabsch, jobs))
+                futures.append(_host_pool().submit(kabsch, job))
+            hyps = [f.result() for f in futures]
         flat = hip.upload(np.concatenate(hyps) if hyps else np.zeros((0, 3, 4)))       # ONE upload of all hypotheses (the staging ring: no stream sync)
         have = [sc is not None for sc in all_scores]
         w_flat = hip.upload(np.concatenate([sc.astype(np.float64) for sc in all_scores if sc is not None])) if any(have) else None

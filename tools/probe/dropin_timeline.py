@@ -14,7 +14,8 @@ from roreg_amd.test.evaluator import yoho_evaluator
 
 n_clouds, n_pairs, kpts = 60, 449, 5000
 torch.manual_seed(0)
-cfg0 = default_config(keynum=kpts, max_iter=1000, ET='yohoo')
+ET = 'yohoc' if '--yohoc' in sys.argv else 'yohoo'
+cfg0 = default_config(keynum=kpts, max_iter=1000, ET=ET)
 gf_sd = synth.seeded_state_dict(name2network['GF_test'](cfg0), 101)
 et_sd = synth.seeded_state_dict(name2network['ET_test'](cfg0), 202)
 root = tempfile.mkdtemp(prefix='roreg_dropin_tl_')
@@ -29,7 +30,7 @@ try:
     for kind, sd in (('GF', gf_sd), ('ET', et_sd)):
         os.makedirs(f'{root}/ckpt/{kind}')
         torch.save({'best_para': 0, 'network_state_dict': sd}, f'{root}/ckpt/{kind}/model_best.pth')
-    cfg = default_config(output_cache_fn=f'{root}/cache_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kpts, max_iter=1000, ET='yohoo')
+    cfg = default_config(output_cache_fn=f'{root}/cache_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kpts, max_iter=1000, ET=ET)
     ev = yoho_evaluator(cfg)
     for rep in range(5):
         cache = f'{root}/cache_{rep}'
@@ -86,7 +87,7 @@ try:
     for rep in range(3):
         np.random.seed(5)
         torch.cuda.synchronize(); time.sleep(0.5); t0 = time.perf_counter()
-        eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=True)
+        eng.run_scene(feats, keys, ds.pair_ids, all_local_transforms=(ET == 'yohoo'))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f'engine alone, resident inputs, run {rep}: {dt:.4f} s = {n_pairs / dt:.1f} pairs/s', flush=True)
 finally:
