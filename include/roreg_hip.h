@@ -327,6 +327,12 @@ int roreg_refine_batch(const roreg_ransac_task *tasks_dev, const int32_t *sel_de
  * its own; jobs are spread over n_threads host threads. */
 int roreg_mt_shuffle_prefix(const uint32_t *seeds, int n_jobs, const int32_t *sizes, int per_job, int take, int64_t *out, int n_threads);
 
+/* v6.  The same shuffles from ONE running stream, HOST function: the process-global generator an unseeded Test.py consumes (test/matcher.py:83-88,
+ * test/estimator.py:423-425).  key[624] / *pos: np.random.get_state()'s MT19937 key and position on entry, the stream's state after the last
+ * list on return (for np.random.set_state); `for n in sizes: idx = np.arange(n); np.random.shuffle(idx); idx[:take]`, list after list on one
+ * thread.  out int64 [n_lists][take] (-1 beyond a list's length). */
+int roreg_mt_stream_shuffle_prefix(uint32_t *key, int32_t *pos, const int32_t *sizes, int n_lists, int take, int64_t *out);
+
 /* YOHO-C hypothesis draws, HOST function (no device work): replays the generator calls of the reference's sampling loop
  * (test/estimator.py:220-230: np.random.choice(range(60), p=prob), then np.random.choice(bin_members, 3)) over a block of raw MT19937
  * words drawn by the caller from the global generator.  cdf f64 [60] = prob.cumsum()/prob.sum(); bin_size int32 [60] = members per

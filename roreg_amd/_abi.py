@@ -88,6 +88,7 @@ PROTOTYPES = {
     'roreg_profile_read': (c_int, [c_int, _P, _P]),
     'roreg_set_fourier_tables': (c_int, [_P]),
     'roreg_mt_shuffle_prefix': (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int]),
+    'roreg_mt_stream_shuffle_prefix': (c_int, [_P, _P, _P, c_int, c_int, _P]),
     'roreg_irrep_gemm_tiles': (c_size_t, [c_int, c_int, _P]),
     'roreg_irrep_gemm_tiles_m': (c_size_t, [c_int, c_int, c_int, _P]),
     'roreg_irrep_gemm': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),

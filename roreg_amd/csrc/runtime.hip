@@ -175,6 +175,7 @@ struct Mt19937 {
         for (int i = 0; i < 624; ++i) { key[i] = seed; seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u; }
         pos = 624;
     }
+    Mt19937(const uint32_t *state, int position) : pos(position) { for (int i = 0; i < 624; ++i) key[i] = state[i]; }
     void refill() {
         const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
         int i = 0;
@@ -223,6 +224,36 @@ extern "C" int roreg_mt_shuffle_prefix(const uint32_t *seeds, int n_jobs, const 
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((long long)n_jobs * t / nt), (int)((long long)n_jobs * (t + 1) / nt));
     for (auto &t : th) t.join();
+    return 0;
+}
+
+// v6: the same shuffles drawn from ONE running stream -- the process-global generator an unseeded Test.py consumes (test/matcher.py:83-88,
+// test/estimator.py:423-425).  key[624] / *pos are np.random.get_state()'s key and position on entry and the stream's state after the last list
+// on return (for np.random.set_state): `for n in sizes: idx = np.arange(n); np.random.shuffle(idx); idx[:take]`.  One thread: list i + 1 starts
+// where list i stopped.  449 pairs x 2 lists of 5000 cost ~40 ms in numpy on the launching thread, 13 ms of it with the GPU idle.
+extern "C" int roreg_mt_stream_shuffle_prefix(uint32_t *key, int32_t *pos, const int32_t *sizes, int n_lists, int take, int64_t *out) {
+    if (n_lists == 0) return 0;
+    ROREG_REQUIRE(key && pos && sizes && out && n_lists > 0 && take >= 0 && *pos >= 0 && *pos <= 624, "roreg_mt_stream_shuffle_prefix: bad arguments");
+    for (int i = 0; i < n_lists; ++i)
+        ROREG_REQUIRE(sizes[i] >= 0, "roreg_mt_stream_shuffle_prefix: negative list size");
+    Mt19937 g(key, *pos);
+    std::vector<int64_t> x;
+    for (int s = 0; s < n_lists; ++s) {
+        const int n = sizes[s];
+        x.resize((size_t)n);
+        for (int i = 0; i < n; ++i) x[i] = i;
+        for (int i = n - 1; i >= 1; --i) {
+            uint32_t mask = (uint32_t)i;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            uint32_t v;
+            do { v = g.next() & mask; } while (v > (uint32_t)i);
+            std::swap(x[i], x[v]);
+        }
+        int64_t *dst = out + (size_t)s * take;
+        for (int i = 0; i < take; ++i) dst[i] = i < n ? x[i] : -1;
+    }
+    for (int i = 0; i < 624; ++i) key[i] = g.key[i];
+    *pos = g.pos;
     return 0;
 }
 

@@ -635,9 +635,14 @@ class RegistrationEngine:
                 index = drawn[q, :min(max_iter, n)]                         # (a contiguous int64 row view: no per-pair copy)
                 hyps.append(index if rows is None else np.ascontiguousarray(rows[index], np.int64))
         else:
-            for rows, n in zip(rows_of, n_of):
+            drawn = hip.global_stream_shuffle_prefix(n_of, max_iter) if len(full) else None      # estimator.py:423-424 on the reference's single global stream, in C
+            for q, (rows, n) in enumerate(zip(rows_of, n_of)):
+                if drawn is not None:
+                    index = drawn[q, :min(max_iter, n)]
+                    hyps.append(index if rows is None else np.ascontiguousarray(rows[index], np.int64))
+                    continue
                 index = np.arange(n)
-                np.random.shuffle(index)                                    # estimator.py:423-424 (the reference's single global stream)
+                np.random.shuffle(index)
                 hyps.append(np.ascontiguousarray((index if rows is None else rows[index])[0:max_iter], np.int64))
         hyp_flat = hip.upload(np.concatenate(hyps) if hyps else np.zeros(0, np.int64))               # ONE upload of all hypothesis lists
         hyp_dev, o = [], 0
@@ -887,8 +892,18 @@ class RegistrationEngine:
                 drawn = hip.mt_shuffle_prefix(pair_seeds, sizes, keynum)
                 samples = [(drawn[q, 0, :min(keynum, int(sizes[q, 0]))], drawn[q, 1, :min(keynum, int(sizes[q, 1]))]) for q in range(len(pair_ids))]
             else:
-                samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
-                           for q, (a, b) in enumerate(pair_ids)]                                    # host; runs under the extractor's kernels
+                drawn = None
+                if pair_seeds is None and not self.cfg.RD and len(pair_ids):
+                    # the reference's single process-global stream, consumed in the reference's order (two shuffles per pair), replayed in C:
+                    # numpy's generator is left where np.random.shuffle would have left it (hip.global_stream_shuffle_prefix)
+                    sizes = np.array([[clouds[int(a)].before.shape[0], clouds[int(b)].before.shape[0]] for a, b in pair_ids], np.int32)
+                    drawn = hip.global_stream_shuffle_prefix(sizes.reshape(-1), keynum)
+                if drawn is not None:
+                    drawn = drawn.reshape(len(pair_ids), 2, -1)
+                    samples = [(drawn[q, 0, :min(keynum, int(sizes[q, 0]))], drawn[q, 1, :min(keynum, int(sizes[q, 1]))]) for q in range(len(pair_ids))]
+                else:
+                    samples = [self.sample(clouds[int(a)], clouds[int(b)], keynum, None if pair_seeds is None else pair_seeds[q])
+                               for q, (a, b) in enumerate(pair_ids)]                                # host; runs under the extractor's kernels
             flat = np.concatenate([np.ascontiguousarray(x, np.int64) for s in samples for x in s]) if samples else np.zeros(0, np.int64)
             flat_dev = hip.upload(flat)                   # does not wait for the extractor's kernels: the task table is built under them
             tasks, o = [], 0

@@ -956,6 +956,24 @@ def mt_shuffle_prefix(seeds, sizes, take, n_threads=None):
 
 
 
+def global_stream_shuffle_prefix(sizes, take):
+    """Host function: `for n in sizes: idx = np.arange(n); np.random.shuffle(idx); idx[:take]` on the PROCESS-GLOBAL numpy generator (the stream an
+    unseeded Test.py consumes), replayed in C (roreg_mt_stream_shuffle_prefix): the generator is left exactly where numpy would have left it.
+    sizes [L] -> int64 [L, take] with -1 beyond a list's length.  None when the global generator is not numpy's legacy MT19937."""
+    sizes = np.ascontiguousarray(sizes, np.int32).reshape(-1)
+    st = np.random.get_state()
+    if st[0] != 'MT19937':
+        return None
+    key = np.ascontiguousarray(st[1], np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    out = np.empty((sizes.shape[0], int(take)), np.int64)
+    if sizes.shape[0]:
+        _check(lib().roreg_mt_stream_shuffle_prefix(c_void_p(key.ctypes.data), ctypes.byref(pos), c_void_p(sizes.ctypes.data), sizes.shape[0], int(take),
+                                                    c_void_p(out.ctypes.data)), 'roreg_mt_stream_shuffle_prefix')
+        np.random.set_state(('MT19937', key, int(pos.value), st[3], st[4]))
+    return out
+
+
 def gather_rows_batch(tasks):
     """tasks [(src [*, ...] contiguous device tensor, rows int64 device [n], dst [n, ...] contiguous device tensor of src's dtype and row
     shape)]: dst[i] = src[rows[i]] for every task, ONE launch (all tasks must have the same row size in bytes, a multiple of 8)."""

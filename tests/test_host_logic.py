@@ -263,6 +263,31 @@ def test_mt_shuffle_prefix_replays_numpys_seeded_shuffles():
     assert np.array_equal(hip.mt_shuffle_prefix([77], [[300]], 300)[0, 0], a)
 
 
+def test_global_stream_shuffles_leave_numpys_generator_where_numpy_would():
+    """roreg_mt_stream_shuffle_prefix behind hip.global_stream_shuffle_prefix: the shuffles of an unseeded Test.py (test/matcher.py:83-88,
+    test/estimator.py:423-425) drawn from the process-global generator in C -- the same lists as np.random.shuffle, and the generator's state
+    afterwards is numpy's (whatever is drawn next agrees), from any position of the 624-word block, with a cached gaussian kept."""
+    from roreg_amd import hip
+    rng = np.random.default_rng(11)
+    for trial, (warm, take) in enumerate(((0, 500), (3, 1000), (623, 7), (624, 5000), (1251, 64))):
+        sizes = rng.integers(0, 5200, 23); sizes[:3] = (0, 1, 2)
+        np.random.seed(1000 + trial)
+        np.random.random_sample(warm)                               # (position inside the block)
+        if trial == 2:
+            np.random.standard_normal()                             # (leaves a cached gaussian in the legacy state)
+        start = np.random.get_state()
+        want = []
+        for n in sizes:
+            x = np.arange(int(n)); np.random.shuffle(x)
+            w = np.full(take, -1, np.int64); w[:min(take, x.shape[0])] = x[:take]; want.append(w)
+        after = (np.random.randint(0, 2 ** 31, 9), np.random.standard_normal(3), np.random.rand(2))
+        np.random.set_state(start)
+        got = hip.global_stream_shuffle_prefix(sizes, take)
+        assert np.array_equal(got, np.stack(want))
+        assert np.array_equal(np.random.randint(0, 2 ** 31, 9), after[0]) and np.array_equal(np.random.standard_normal(3), after[1]) and np.array_equal(np.random.rand(2), after[2])
+    assert hip.global_stream_shuffle_prefix([], 10).shape == (0, 10)
+
+
 def test_scene_pair_lists_touch_every_cloud_and_are_reproducible():
     """bench.py's synthetic pair lists (both kinds): the requested number of distinct pairs (i < j), sorted, every cloud touched (the chain
     (i, i+1) is always in), the same list for the same seed; with locality the pairs sit closer to the diagonal than uniformly drawn ones."""
