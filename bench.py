@@ -842,24 +842,35 @@ def dropin_leg(args, gf_sd, et_sd, n_clouds=60, n_pairs=449):
         # the same route under the estimator an unflagged Test.py runs (parses/parses_test.py:42: --ET yohoc): draws from the process-global generator
         # in pair order on the launching thread, 3-point Kabsch stacks on the host pool (files equal the stage chain's: tests/test_hip_pipeline.py)
         os.environ['ROREG_EVALUATOR'] = 'engine'
-        cfg = default_config(output_cache_fn=f'{root}/cache_yohoc_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, ET='yohoc')
-        ev = yoho_evaluator(cfg)
-        ev._engine().set_gemm_mode(args.gemm)
-        runs = []
-        for rep in range(4):
-            cache = f'{root}/cache_yohoc_{rep}'
-            cfg.output_cache_fn = cache
-            os.makedirs(f'{cache}/{ds.name}')
-            os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
-            _cache.clear()
-            np.random.seed(5)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            ev.process_scene(ds)
-            torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
-            shutil.rmtree(cache, ignore_errors=True)
-        del ev
-        out['engine_yohoc'] = {'pairs_per_s': n_pairs / float(np.mean(runs[1:])), 's_per_scene': float(np.mean(runs[1:])), 's_each_scene_after_the_first': [round(x, 4) for x in runs[1:]],
-                               's_first_scene': runs[0], 'what': 'Test.py without --ET (yohoc, parses_test.py:42), same scene, same file contract'}
+
+        def other_flags(tag, what, **flags):
+            cfg = default_config(output_cache_fn=f'{root}/cache_{tag}_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=args.kpts, max_iter=1000, **flags)
+            ev = yoho_evaluator(cfg)
+            ev._engine().set_gemm_mode(args.gemm)
+            runs = []
+            for rep in range(4):
+                cache = f'{root}/cache_{tag}_{rep}'
+                cfg.output_cache_fn = cache
+                os.makedirs(f'{cache}/{ds.name}')
+                os.symlink(inputs, f'{cache}/{ds.name}/FCGF_Input_Group_feature')
+                _cache.clear()
+                np.random.seed(5)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ev.process_scene(ds)
+                torch.cuda.synchronize(); runs.append(time.perf_counter() - t0)
+                shutil.rmtree(cache, ignore_errors=True)
+            del ev
+            return {'pairs_per_s': n_pairs / float(np.mean(runs[1:])), 's_per_scene': float(np.mean(runs[1:])), 's_each_scene_after_the_first': [round(x, 4) for x in runs[1:]],
+                    's_first_scene': runs[0], 'what': what}
+        out['engine_yohoc'] = other_flags('yohoc', 'Test.py without --ET (yohoc, parses_test.py:42), same scene, same file contract', ET='yohoc')
+        # ... and under the README's own command (README.md:149,175: --RD --RM --ET yohoo --keynum 5000; the shipped RD / RM checkpoints when the fixtures hold them)
+        rd, rm, rd_rm_weights = rd_rm_nets(default_config(keynum=args.kpts, max_iter=1000, ET='yohoo', RD=True, RM=True))
+        for kind, net in (('RD', rd), ('RM', rm)):
+            os.makedirs(f'{root}/ckpt/{kind}')
+            torch.save({'best_para': 0, 'network_state_dict': net.state_dict()}, f'{root}/ckpt/{kind}/model_best.pth')
+        del rd, rm
+        out['engine_rd_rm'] = other_flags('rd_rm', f'Test.py --RD --RM --ET yohoo --keynum {args.kpts} (README.md:149), same scene, the detector score files too; {rd_rm_weights}',
+                                          ET='yohoo', RD=True, RM=True)
         if before is None:
             os.environ.pop('ROREG_EVALUATOR', None)
         else:

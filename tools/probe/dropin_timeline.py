@@ -15,7 +15,8 @@ from roreg_amd.test.evaluator import yoho_evaluator
 n_clouds, n_pairs, kpts = 60, 449, 5000
 torch.manual_seed(0)
 ET = 'yohoc' if '--yohoc' in sys.argv else 'yohoo'
-cfg0 = default_config(keynum=kpts, max_iter=1000, ET=ET)
+RD = '--rd-rm' in sys.argv
+cfg0 = default_config(keynum=kpts, max_iter=1000, ET=ET, RD=RD, RM=RD)
 gf_sd = synth.seeded_state_dict(name2network['GF_test'](cfg0), 101)
 et_sd = synth.seeded_state_dict(name2network['ET_test'](cfg0), 202)
 root = tempfile.mkdtemp(prefix='roreg_dropin_tl_')
@@ -27,10 +28,15 @@ try:
     os.makedirs(inputs)
     for i, f in enumerate(feats):
         np.save(f'{inputs}/{i}.npy', f.cpu().numpy())
-    for kind, sd in (('GF', gf_sd), ('ET', et_sd)):
+    nets = [('GF', gf_sd), ('ET', et_sd)]
+    if RD:
+        import bench
+        rd, rm, _ = bench.rd_rm_nets(cfg0)
+        nets += [('RD', rd.state_dict()), ('RM', rm.state_dict())]
+    for kind, sd in nets:
         os.makedirs(f'{root}/ckpt/{kind}')
         torch.save({'best_para': 0, 'network_state_dict': sd}, f'{root}/ckpt/{kind}/model_best.pth')
-    cfg = default_config(output_cache_fn=f'{root}/cache_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kpts, max_iter=1000, ET=ET)
+    cfg = default_config(output_cache_fn=f'{root}/cache_0', model_fn=f'{root}/ckpt', base_dir=root, SO3_related_files=None, keynum=kpts, max_iter=1000, ET=ET, RD=RD, RM=RD)
     ev = yoho_evaluator(cfg)
     for rep in range(5):
         cache = f'{root}/cache_{rep}'

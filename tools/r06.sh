@@ -23,7 +23,7 @@ print('rd_rm_k5000', j.get('value_rd_rm_k5000'), 'contract', j.get('value_rd_rm_
 print('sinkhorn', json.dumps(c['rd_rm_k5000']['sinkhorn']))
 print('stages', c['rd_rm_k5000']['stage_ms_one_synchronised_pass_rank0'])
 d = c.get('dropin_leg') or {}
-print('dropin', {k: (round(v['pairs_per_s'], 1) if isinstance(v, dict) and 'pairs_per_s' in v else None) for k, v in d.items() if k in ('stages', 'engine', 'engine_yohoc', 'no_files')}, d.get('files'))
+print('dropin', {k: (round(v['pairs_per_s'], 1) if isinstance(v, dict) and 'pairs_per_s' in v else None) for k, v in d.items() if k in ('stages', 'engine', 'engine_yohoc', 'engine_rd_rm', 'no_files')}, d.get('files'))
 y = c.get('yohoc_leg') or {}
 print('yohoc', {k: round(v['pairs_per_s'], 1) for k, v in y.items() if isinstance(v, dict)})
 print('legs', c.get('rd_rm_leg_pairs_per_s'), c.get('rd_rm_leg_pairs_per_s_bf16'), c.get('rd_rm_leg_k5000_pairs_per_s'), c.get('rd_rm_leg_k5000_sinkhorn_ms_per_pair'), 'fmr/ir/rr', c.get('fmr'), c.get('ir'), c.get('rr'))
