@@ -20,11 +20,17 @@ struct GroupTablesDev {
     int32_t *Nei;    // [60*13]
     uint8_t *P8;     // [60*60]  same as P, one byte per entry (LDS friendly)
     uint8_t *P8t;    // [60*60]  transposed: P8t[h*60+g] = P[g*60+h]
+    uint8_t *split;  // [4096]   bank-split form of P8 for the gathered correlation (des2r.hip, SplitTab): per-lane rows in LDS-slot numbers,
+    uint8_t *split_t;//          lane -> group element, group element -> LDS slot; split_t: the same for P8t
     double *R;       // [60*9]   float64 rotations
     float *Rf;       // [60*9]   float32-rounded rotations (test/estimator.py:279 .astype(np.float32))
     bool ready;
 };
 const GroupTablesDev &group_tables();
+
+// Layout of GroupTablesDev::split (bytes): Q[64 lanes][60] at 0 (lane l's row of the table, entries already LDS slot numbers; a lane without a
+// group element repeats an active lane of its half), lane_elem[64] at 3840 (0xff = none), slot[60] at 3904.
+constexpr int SPLIT_Q = 0, SPLIT_LANE = 3840, SPLIT_SLOT = 3904, SPLIT_BYTES = 4096;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

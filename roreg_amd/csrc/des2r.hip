@@ -69,6 +69,192 @@ __device__ __forceinline__ void des2r_body(const float *__restrict__ feats1, siz
     if (lane == 0 && idx_out) idx_out[b] = bi;
 }
 
+// The same correlation, the same operation order (every s_f its own chain over g in order, products and sums rounded separately, then the
+// s_f in order), arranged for the LDS and the vector pipe (round 6; the matcher's R_indicator ran at 0.48 bank conflicts per LDS cycle with
+// the LDS index pipe 96 % and the vector pipe 83 % busy, profiles/r06_rd_rm_k5000_pmc.txt):
+//   * the permuted row sits in LDS in the bank-split order of runtime.hip's bank_split_table (pitch 64): whatever g is, the 30 lanes of a
+//     half-wave read 30 different banks;
+//   * lane l owns the group element lane_elem[l] (the two elements of a nu-orbit in different half-waves);
+//   * two channels per vector instruction: s_{2k}, s_{2k+1} advance together through v_pk_mul_f32 / v_pk_add_f32 (IEEE per element: the
+//     same roundings as the scalar form), their broadcast factors as an SGPR pair.
+typedef float des2r_f2 __attribute__((ext_vector_type(2)));
+constexpr int DES2R_SPITCH = 64;
+
+__device__ __forceinline__ void des2r_split_body(const float *__restrict__ feats1, size_t r1, const float *__restrict__ feats0, size_t r0,
+                                                 bool live, const uint8_t *__restrict__ split, size_t b, int64_t *__restrict__ idx_out,
+                                                 float *__restrict__ cor_out) {
+    __shared__ float d1s[4][ROREG_F * DES2R_SPITCH];
+    __shared__ uint8_t Ql[64 * ROREG_G];
+    __shared__ uint8_t slot_l[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 64 * ROREG_G / 4; i += 256)
+        reinterpret_cast<uint32_t *>(Ql)[i] = reinterpret_cast<const uint32_t *>(split + roreg::SPLIT_Q)[i];
+    if (tid < ROREG_G) slot_l[tid] = split[roreg::SPLIT_SLOT + tid];
+    const int elem = split[roreg::SPLIT_LANE + lane];              // the group element this lane accumulates (0xff: none)
+    const bool act = elem != 0xff;
+    float d2[ROREG_F];
+    {
+        const float *src = feats0 + r0 * (ROREG_F * ROREG_G);
+#pragma unroll
+        for (int f = 0; f < ROREG_F; ++f) d2[f] = lane < ROREG_G ? src[f * ROREG_G + lane] : 0.f;     // lane g holds column g of the broadcast side
+    }
+    __syncthreads();                                               // slot_l
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(feats1 + r1 * (ROREG_F * ROREG_G));
+        float *dst = d1s[w];
+        for (int i = lane; i < ROREG_F * ROREG_G / 4; i += 64) {
+            const float4 v = src[i];
+            const int f = (i * 4) / ROREG_G, j = (i * 4) % ROREG_G;           // (60 is a multiple of 4: a float4 never straddles two channels)
+            float *row = dst + f * DES2R_SPITCH;
+            row[slot_l[j]] = v.x; row[slot_l[j + 1]] = v.y; row[slot_l[j + 2]] = v.z; row[slot_l[j + 3]] = v.w;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    des2r_f2 s2[ROREG_F / 2];
+#pragma unroll
+    for (int k = 0; k < ROREG_F / 2; ++k) s2[k] = des2r_f2{0.f, 0.f};
+    const uint8_t *qrow = Ql + lane * ROREG_G;
+    const float *base = d1s[w];
+    for (int g = 0; g < ROREG_G; ++g) {
+        const float *col = base + qrow[g];
+#pragma unroll
+        for (int k = 0; k < ROREG_F / 2; ++k) {
+            des2r_f2 bc;
+            bc.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d2[2 * k]), g));
+            bc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d2[2 * k + 1]), g));
+            des2r_f2 a;
+            a.x = col[(2 * k) * DES2R_SPITCH];
+            a.y = col[(2 * k + 1) * DES2R_SPITCH];
+            const des2r_f2 prod = a * bc;                          // (contract off: a product, then a sum)
+            s2[k] = s2[k] + prod;
+        }
+    }
+    float cor = 0.f;
+#pragma unroll
+    for (int k = 0; k < ROREG_F / 2; ++k) { cor = __fadd_rn(cor, s2[k].x); cor = __fadd_rn(cor, s2[k].y); }
+    if (cor_out && act) cor_out[b * ROREG_G + elem] = cor;
+    // first argmax over the group elements: order by (value desc, element asc)
+    float bv = act ? cor : -__builtin_inff();
+    int bi = act ? elem : 0x7fffffff;
+    if (bv != bv) bv = -__builtin_inff();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0 && idx_out) idx_out[b] = bi;
+}
+
+// Third form: the broadcast factor comes through the DPP row_newbcast modifier of the multiply itself (lane C of every row of 16 lanes feeds
+// the whole row) instead of a v_readlane into an SGPR: measured, the vector pipe was the bound of the split form (SQ_ACTIVE_INST_VALU 96 % of the
+// kernel's cycles) and a v_readlane costs as much as a multiply.  Lane l keeps column 16 c + (l & 15) of the broadcast row in register
+// d2r[c][.] (c = 0 .. 3), so every row of 16 holds all 60 columns; DES2R_NCH (8 | 16) channels per pass: 76 / 120 registers.
+// Same chains, same roundings: s_f = (...((0 + p_0) + p_1)...) over g, then the s_f in order.
+template <int C>
+__device__ __forceinline__ float des2r_mul_row_bcast(float d1, float d2) {      // d1 * (d2 of lane C of this lane's row of 16), one instruction
+    float p;                                                                    // (written out: left to the compiler, one product in five became a
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"   //  v_mov_b32_dpp feeding a packed multiply -- three issue slots, not two)
+        : "=v"(p) : "v"(d2), "v"(d1), "n"(C));
+    return p;
+}
+
+                                    // channels per pass (16: the scheduler's hoisted LDS loads spill at 128 registers)
+
+template <int G0, int DES2R_NCH>
+__device__ __forceinline__ void des2r_dpp_steps(const float *__restrict__ base, const uint8_t *__restrict__ qrow, const float (&d2r)[4][DES2R_NCH],
+                                                float (&s)[DES2R_NCH]) {
+    if constexpr (G0 < ROREG_G) {
+        const float *col = base + qrow[G0];
+#pragma unroll
+        for (int k = 0; k < DES2R_NCH; ++k)
+            s[k] = __fadd_rn(s[k], des2r_mul_row_bcast<G0 % 16>(col[k * DES2R_SPITCH], d2r[G0 / 16][k]));
+        des2r_dpp_steps<G0 + 1, DES2R_NCH>(base, qrow, d2r, s);
+    }
+}
+
+template <int DES2R_NCH>
+__device__ __forceinline__ void des2r_dpp_body(const float *__restrict__ feats1, size_t r1, const float *__restrict__ feats0, size_t r0,
+                                               bool live, const uint8_t *__restrict__ split, size_t b, int64_t *__restrict__ idx_out,
+                                               float *__restrict__ cor_out) {
+    __shared__ float d1s[4][ROREG_F * DES2R_SPITCH];
+    __shared__ uint8_t Ql[64 * ROREG_G];
+    __shared__ uint8_t slot_l[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 64 * ROREG_G / 4; i += 256)
+        reinterpret_cast<uint32_t *>(Ql)[i] = reinterpret_cast<const uint32_t *>(split + roreg::SPLIT_Q)[i];
+    if (tid < ROREG_G) slot_l[tid] = split[roreg::SPLIT_SLOT + tid];
+    const int elem = split[roreg::SPLIT_LANE + lane];
+    const bool act = elem != 0xff;
+    __syncthreads();
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(feats1 + r1 * (ROREG_F * ROREG_G));
+        float *dst = d1s[w];
+        for (int i = lane; i < ROREG_F * ROREG_G / 4; i += 64) {
+            const float4 v = src[i];
+            const int f = (i * 4) / ROREG_G, j = (i * 4) % ROREG_G;
+            float *row = dst + f * DES2R_SPITCH;
+            row[slot_l[j]] = v.x; row[slot_l[j + 1]] = v.y; row[slot_l[j + 2]] = v.z; row[slot_l[j + 3]] = v.w;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint8_t *qrow = Ql + lane * ROREG_G;
+    const float *src0 = feats0 + r0 * (ROREG_F * ROREG_G);
+    const int c16 = lane & 15;
+    float cor = 0.f;
+    for (int fh = 0; fh < ROREG_F / DES2R_NCH; ++fh) {
+        float d2r[4][DES2R_NCH];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < DES2R_NCH; ++k)
+                d2r[c][k] = (16 * c + c16 < ROREG_G) ? src0[(fh * DES2R_NCH + k) * ROREG_G + 16 * c + c16] : 0.f;
+        float s[DES2R_NCH];
+#pragma unroll
+        for (int k = 0; k < DES2R_NCH; ++k) s[k] = 0.f;
+        des2r_dpp_steps<0, DES2R_NCH>(d1s[w] + fh * DES2R_NCH * DES2R_SPITCH, qrow, d2r, s);
+#pragma unroll
+        for (int k = 0; k < DES2R_NCH; ++k) cor = __fadd_rn(cor, s[k]);
+    }
+    if (cor_out && act) cor_out[b * ROREG_G + elem] = cor;
+    float bv = act ? cor : -__builtin_inff();
+    int bi = act ? elem : 0x7fffffff;
+    if (bv != bv) bv = -__builtin_inff();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0 && idx_out) idx_out[b] = bi;
+}
+
+template <int DES2R_NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void des2r_dpp_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,
+                                                        const float *__restrict__ feats0, const int64_t *__restrict__ rows0,
+                                                        const uint8_t *__restrict__ split, int M, int64_t *__restrict__ idx_out,
+                                                        float *__restrict__ cor_out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = b < M;
+    const size_t r1 = live ? (rows1 ? (size_t)rows1[b] : (size_t)b) : 0;
+    const size_t r0 = live ? (rows0 ? (size_t)rows0[b] : (size_t)b) : 0;
+    des2r_dpp_body<DES2R_NCH>(feats1, r1, feats0, r0, live, split, (size_t)b, idx_out, cor_out);
+}
+
+__global__ __launch_bounds__(256) void des2r_split_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,
+                                                          const float *__restrict__ feats0, const int64_t *__restrict__ rows0,
+                                                          const uint8_t *__restrict__ split, int M, int64_t *__restrict__ idx_out,
+                                                          float *__restrict__ cor_out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = b < M;
+    const size_t r1 = live ? (rows1 ? (size_t)rows1[b] : (size_t)b) : 0;
+    const size_t r0 = live ? (rows0 ? (size_t)rows0[b] : (size_t)b) : 0;
+    des2r_split_body(feats1, r1, feats0, r0, live, split, (size_t)b, idx_out, cor_out);
+}
+
 __global__ __launch_bounds__(256) void des2r_kernel(const float *__restrict__ feats1, const int64_t *__restrict__ rows1,
                                                     const float *__restrict__ feats0, const int64_t *__restrict__ rows0,
                                                     const uint8_t *__restrict__ P8, int M, int64_t *__restrict__ idx_out,
@@ -418,8 +604,20 @@ extern "C" int roreg_group_corr(const float *perm_feats, const int64_t *perm_row
     ROREG_REQUIRE(perm_feats && bcast_feats && (idx_out || cor_out) && M > 0, "roreg_group_corr: bad arguments");
     ROREG_REQUIRE(roreg::group_tables().ready, "roreg_group_corr: group tables not set");
     if (M == 0) return 0;
-    hipLaunchKernelGGL(des2r_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,
-                       bcast_rows, transpose_table ? roreg::group_tables().P8t : roreg::group_tables().P8, M, idx_out, cor_out);
+    static const int split = [] { const char *e = getenv("ROREG_DES2R_SPLIT"); return e ? atoi(e) : 2; }();      // (0: the round-2 kernel, 1: bank-split + packed, for A/B)
+    static const int nch = [] { const char *e = getenv("ROREG_DES2R_NCH"); return e ? atoi(e) : 16; }();       // channels per pass of the DPP form (8 | 16)
+    if (split == 2 && nch == 8)
+        hipLaunchKernelGGL(des2r_dpp_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,
+                           bcast_rows, transpose_table ? roreg::group_tables().split_t : roreg::group_tables().split, M, idx_out, cor_out);
+    else if (split == 2)
+        hipLaunchKernelGGL(des2r_dpp_kernel<16>, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,
+                           bcast_rows, transpose_table ? roreg::group_tables().split_t : roreg::group_tables().split, M, idx_out, cor_out);
+    else if (split)
+        hipLaunchKernelGGL(des2r_split_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,
+                           bcast_rows, transpose_table ? roreg::group_tables().split_t : roreg::group_tables().split, M, idx_out, cor_out);
+    else
+        hipLaunchKernelGGL(des2r_kernel, dim3((M + 3) / 4), dim3(256), 0, roreg::as_stream(stream), perm_feats, perm_rows, bcast_feats,
+                           bcast_rows, transpose_table ? roreg::group_tables().P8t : roreg::group_tables().P8, M, idx_out, cor_out);
     ROREG_CHECK_LAUNCH("roreg_group_corr");
     return 0;
 }

@@ -20,7 +20,7 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-static GroupTablesDev g_tables = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+static GroupTablesDev g_tables = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
 static std::mutex g_tables_mu;
 
 const GroupTablesDev &group_tables() { return g_tables; }
@@ -75,6 +75,55 @@ extern "C" int roreg_abi_version(void) { return ROREG_ABI_VERSION; }
 
 extern "C" const char *roreg_last_error(void) { return roreg::g_err; }
 
+// Bank-split form of a 60 x 60 table Pm (lane a of the gathered correlation reads element Pm[a][g] of a 60-float row, g = 0 .. 59).
+// A half-wave of 32 lanes reads 30 (or 32) DIFFERENT elements per step, and with the row stored as it comes two of them always share one of
+// the 32 LDS banks (elements j and j + 32): every access takes two passes (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.48 measured).
+// Pm is a translation table of the rotation group: x -> x[Pm[a][.]] commutes with the multiplications from the other side.  For an
+// involution t of the group (a 180-degree rotation; A5 has fifteen) let nu(a) = Pm[t][a]: then Pm[nu(a)][g] = mu(Pm[a][g]) for EVERY g with
+// one fixed-point-free involution mu of the row positions.  So: the two elements of a mu-orbit get LDS slots k and 32 + k (one bank), the
+// two group elements of a nu-orbit get lanes l and 32 + l (different half-waves) -- whatever g is, a half-wave reads exactly one element of
+// every mu-orbit: 30 different banks, no conflict.  A table without such a symmetry (any valid table is accepted) gets the plain
+// assignment; the result never depends on the assignment, only the conflict rate does.
+static void bank_split_table(const uint8_t *Pm, uint8_t *out) {
+    using namespace roreg;
+    uint8_t lane_elem[64], slot[60];
+    int nu[60], mu[60];
+    bool found = false;
+    for (int t = 0; t < 60 && !found; ++t) {
+        bool ok = true;
+        for (int a = 0; a < 60 && ok; ++a) { nu[a] = Pm[t * 60 + a]; }
+        for (int a = 0; a < 60 && ok; ++a) ok = nu[a] != a && nu[nu[a]] == a;
+        if (!ok) continue;
+        for (int j = 0; j < 60; ++j) mu[j] = -1;
+        for (int a = 0; a < 60; ++a) mu[Pm[a * 60]] = Pm[nu[a] * 60];
+        for (int j = 0; j < 60 && ok; ++j) ok = mu[j] >= 0 && mu[j] != j && mu[mu[j]] == j;
+        for (int g = 0; g < 60 && ok; ++g)
+            for (int a = 0; a < 60 && ok; ++a) ok = mu[Pm[a * 60 + g]] == Pm[nu[a] * 60 + g];
+        found = ok;
+    }
+    for (int l = 0; l < 64; ++l) lane_elem[l] = 0xff;
+    if (found) {
+        int l = 0, k = 0;
+        bool seen[60] = {false};
+        for (int a = 0; a < 60; ++a)
+            if (!seen[a]) { seen[a] = seen[nu[a]] = true; lane_elem[l] = (uint8_t)a; lane_elem[32 + l] = (uint8_t)nu[a]; ++l; }
+        bool placed[60] = {false};
+        for (int j = 0; j < 60; ++j)
+            if (!placed[j]) { placed[j] = placed[mu[j]] = true; slot[j] = (uint8_t)k; slot[mu[j]] = (uint8_t)(32 + k); ++k; }
+    } else {
+        for (int a = 0; a < 60; ++a) { lane_elem[a] = (uint8_t)a; slot[a] = (uint8_t)a; }
+    }
+    for (int l = 0; l < 64; ++l) {
+        int src = l;
+        if (lane_elem[src] == 0xff) src = l & 32;                 // (lanes 0 and 32 own an element under either assignment)
+        const int a = lane_elem[src];
+        for (int g = 0; g < 60; ++g) out[SPLIT_Q + l * 60 + g] = slot[Pm[a * 60 + g]];
+    }
+    for (int l = 0; l < 64; ++l) out[SPLIT_LANE + l] = lane_elem[l];
+    for (int j = 0; j < 60; ++j) out[SPLIT_SLOT + j] = slot[j];
+    for (int i = SPLIT_SLOT + 60; i < SPLIT_BYTES; ++i) out[i] = 0;
+}
+
 extern "C" int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_host, const double *R_host) {
     using namespace roreg;
     std::lock_guard<std::mutex> lk(g_tables_mu);
@@ -95,6 +144,8 @@ extern "C" int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_
         RT_CK(hipMalloc(&t.Nei, 780 * sizeof(int32_t)));
         RT_CK(hipMalloc(&t.P8, 3600));
         RT_CK(hipMalloc(&t.P8t, 3600));
+        RT_CK(hipMalloc(&t.split, SPLIT_BYTES));
+        RT_CK(hipMalloc(&t.split_t, SPLIT_BYTES));
         RT_CK(hipMalloc(&t.R, 540 * sizeof(double)));
         RT_CK(hipMalloc(&t.Rf, 540 * sizeof(float)));
     }
@@ -108,6 +159,11 @@ extern "C" int roreg_set_group_tables(const int32_t *P_host, const int32_t *Nei_
     RT_CK(hipMemcpy(t.Nei, Nei_host, 780 * sizeof(int32_t), hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.P8, p8, 3600, hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.P8t, p8t, 3600, hipMemcpyHostToDevice));
+    uint8_t sp[SPLIT_BYTES];
+    bank_split_table(p8, sp);
+    RT_CK(hipMemcpy(t.split, sp, SPLIT_BYTES, hipMemcpyHostToDevice));
+    bank_split_table(p8t, sp);
+    RT_CK(hipMemcpy(t.split_t, sp, SPLIT_BYTES, hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.R, R_host, 540 * sizeof(double), hipMemcpyHostToDevice));
     RT_CK(hipMemcpy(t.Rf, rf, 540 * sizeof(float), hipMemcpyHostToDevice));
 #undef RT_CK
