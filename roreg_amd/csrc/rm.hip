@@ -79,7 +79,30 @@ __device__ __forceinline__ void topk_insert_idx(float (&bv)[K], int (&bi)[K], fl
         else { bv[q] = v; bi[q] = j; break; }
     }
 }
+// The same insertion without a branch: new[q] = v > old[q - 1] ? old[q - 1] : (v > old[q] ? v : old[q]), from the bottom up (old[q - 1] is still the
+// old value when slot q is written).  A lane with nothing to insert passes v = -inf: every comparison is false and its list stays as it is.
 template <int K>
+__device__ __forceinline__ void topk_insert_flat(float (&bv)[K], int (&bi)[K], float v, int j) {
+    bool below = v > bv[K - 1];                 // c_q for q = K - 1
+#pragma unroll
+    for (int q = K - 1; q >= 1; --q) {
+        const bool above = v > bv[q - 1];       // c_{q-1}
+        bv[q] = above ? bv[q - 1] : (below ? v : bv[q]);
+        bi[q] = above ? bi[q - 1] : (below ? j : bi[q]);
+        below = above;
+    }
+    bv[0] = below ? v : bv[0];
+    bi[0] = below ? j : bi[0];
+}
+
+// List maintenance, packed (round 6).  A tile hands every lane 16 scores; the sorted insertion is a chain of K compare-and-shift steps that the
+// whole wavefront executes whenever ANY of its 64 lanes has to insert -- with the lists warm that is one or two lanes at a time, for a third
+// of all candidates: ~1550 chain executions per 2500 candidates (K = 16), the kernel's vector pipe several times busier than its matrix pipe.
+// PACKED: a lane first marks which of its 16 scores beat its list's last entry (one compare each), then the wavefront runs the chain
+// max-over-lanes(marked) times, every lane taking ITS next marked score (lowest target index first: the order of the plain form) -- ~375
+// executions for the same candidates.  A score that no longer beats the list when its turn comes is dropped by the insertion's own test, so
+// the lists are those of the plain form, entry for entry.
+template <bool PACKED, bool FLAT, int K>
 __global__ __launch_bounds__(256) void topk_dot_mfma_kernel(const float *__restrict__ A, int m, const float *__restrict__ B, int n,
                                                             const int *__restrict__ segA, const int *__restrict__ segB, int slices,
                                                             float *__restrict__ pv, int *__restrict__ pi) {
@@ -110,10 +133,44 @@ __global__ __launch_bounds__(256) void topk_dot_mfma_kernel(const float *__restr
         f32x16_tk acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq[kk], sq[kk], acc, 0, 0, 0);
+        if (!PACKED) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = t0 + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (t < j1) topk_insert<K>(bv, bi, acc[r], b0 + t);
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (t < j1) topk_insert<K>(bv, bi, acc[r], b0 + t);
+            }
+        } else {
+            const float last = bv[K - 1];
+            unsigned marked = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + 8 * (r >> 2) + 4 * h + (r & 3);
+                marked |= (t < j1 && acc[r] > last) ? (1u << r) : 0u;
+            }
+            while (__builtin_amdgcn_ballot_w64(marked != 0)) {
+                if (FLAT) {
+                    const int r = marked ? __builtin_ctz(marked) : 0;
+                    const bool r0 = r & 1, r1 = r & 2, r2 = r & 4, r3 = r & 8;
+                    const float a0_ = r0 ? acc[1] : acc[0], a1_ = r0 ? acc[3] : acc[2], a2_ = r0 ? acc[5] : acc[4], a3_ = r0 ? acc[7] : acc[6];
+                    const float a4_ = r0 ? acc[9] : acc[8], a5_ = r0 ? acc[11] : acc[10], a6_ = r0 ? acc[13] : acc[12], a7_ = r0 ? acc[15] : acc[14];
+                    const float c0_ = r1 ? a1_ : a0_, c1_ = r1 ? a3_ : a2_, c2_ = r1 ? a5_ : a4_, c3_ = r1 ? a7_ : a6_;
+                    const float e0_ = r2 ? c1_ : c0_, e1_ = r2 ? c3_ : c2_;
+                    const float v = marked ? (r3 ? e1_ : e0_) : -__builtin_inff();
+                    marked &= marked - 1;
+                    topk_insert_flat<K>(bv, bi, v, b0 + t0 + 8 * (r >> 2) + 4 * h + (r & 3));
+                } else if (marked) {
+                    const int r = __builtin_ctz(marked);
+                    marked &= marked - 1;
+                    // acc[r] for a per-lane r: a select tree over the bits of r (no indexed register file access)
+                    const bool r0 = r & 1, r1 = r & 2, r2 = r & 4, r3 = r & 8;
+                    const float a0_ = r0 ? acc[1] : acc[0], a1_ = r0 ? acc[3] : acc[2], a2_ = r0 ? acc[5] : acc[4], a3_ = r0 ? acc[7] : acc[6];
+                    const float a4_ = r0 ? acc[9] : acc[8], a5_ = r0 ? acc[11] : acc[10], a6_ = r0 ? acc[13] : acc[12], a7_ = r0 ? acc[15] : acc[14];
+                    const float c0_ = r1 ? a1_ : a0_, c1_ = r1 ? a3_ : a2_, c2_ = r1 ? a5_ : a4_, c3_ = r1 ? a7_ : a6_;
+                    const float e0_ = r2 ? c1_ : c0_, e1_ = r2 ? c3_ : c2_;
+                    const float v = r3 ? e1_ : e0_;
+                    topk_insert<K>(bv, bi, v, b0 + t0 + 8 * (r >> 2) + 4 * h + (r & 3));
+                }
+            }
         }
     }
     // the other half-wave's list of the same source
@@ -966,7 +1023,8 @@ __global__ __launch_bounds__(256) void ot_readout_kernel(const int64_t *__restri
 // target slices x row blocks: ~1 workgroup per CU is enough for one pair (more slices only lengthen the merge); stacked pairs are
 // bandwidth hungrier per launch and want ~4 per CU
 static int topk_slices(int gx_total, int max_n, bool stacked) {
-    const int target = stacked ? 1024 : 320;
+    static const int target_env = getenv("ROREG_TOPK_TARGET_WGS") ? atoi(getenv("ROREG_TOPK_TARGET_WGS")) : 0;      // (measurements)
+    const int target = target_env > 0 ? target_env : (stacked ? 1024 : 320);
     int slices = (target + gx_total - 1) / gx_total;
     if (slices > (max_n + 63) / 64) slices = (max_n + 63) / 64;
     return slices < 1 ? 1 : slices;
@@ -988,6 +1046,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     ROREG_REQUIRE(segA || k <= n, "roreg_topk_dot: k > n");      // with segments the caller guarantees k <= every pair's target count
     // ROREG_TOPK_VALU=1: the vector-pipe kernel (one thread per source row); default: the dot products as float32 MFMA chains, bitwise the same lists
     static const bool valu = getenv("ROREG_TOPK_VALU") && atoi(getenv("ROREG_TOPK_VALU")) == 1;
+    static const int packed = getenv("ROREG_TOPK_PACKED") ? atoi(getenv("ROREG_TOPK_PACKED")) : 1;      // (0: one insertion chain per candidate; 2: packed with the branch-free insertion; for A/B)
     const int gx = valu ? (max_m + 255) / 256 : (max_m + 127) / 128;
     int slices = topk_slices((max_m + 255) / 256 * n_seg, max_n, segA != nullptr);
     if (!segA) {                                 // one pair: the slice width the kernel derives must cover n with this many slices
@@ -1003,7 +1062,9 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     roreg::ProfScope prof(roreg::PROF_TOPK, s);
 #define RM_TOPK(KK)                                                                                                                  \
     if (valu) hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
-    else hipLaunchKernelGGL(topk_dot_mfma_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
+    else if (packed == 2) hipLaunchKernelGGL((topk_dot_mfma_kernel<true, true, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
+    else if (packed) hipLaunchKernelGGL((topk_dot_mfma_kernel<true, false, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
+    else hipLaunchKernelGGL((topk_dot_mfma_kernel<false, false, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
     hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
     if (k == 16) { RM_TOPK(16) } else if (k == 8) { RM_TOPK(8) } else { RM_TOPK(1) }
 #undef RM_TOPK
