@@ -79,30 +79,18 @@ __device__ __forceinline__ void topk_insert_idx(float (&bv)[K], int (&bi)[K], fl
         else { bv[q] = v; bi[q] = j; break; }
     }
 }
-// The same insertion without a branch: new[q] = v > old[q - 1] ? old[q - 1] : (v > old[q] ? v : old[q]), from the bottom up (old[q - 1] is still the
-// old value when slot q is written).  A lane with nothing to insert passes v = -inf: every comparison is false and its list stays as it is.
-template <int K>
-__device__ __forceinline__ void topk_insert_flat(float (&bv)[K], int (&bi)[K], float v, int j) {
-    bool below = v > bv[K - 1];                 // c_q for q = K - 1
-#pragma unroll
-    for (int q = K - 1; q >= 1; --q) {
-        const bool above = v > bv[q - 1];       // c_{q-1}
-        bv[q] = above ? bv[q - 1] : (below ? v : bv[q]);
-        bi[q] = above ? bi[q - 1] : (below ? j : bi[q]);
-        below = above;
-    }
-    bv[0] = below ? v : bv[0];
-    bi[0] = below ? j : bi[0];
-}
-
 // List maintenance, packed (round 6).  A tile hands every lane 16 scores; the sorted insertion is a chain of K compare-and-shift steps that the
 // whole wavefront executes whenever ANY of its 64 lanes has to insert -- with the lists warm that is one or two lanes at a time, for a third
 // of all candidates: ~1550 chain executions per 2500 candidates (K = 16), the kernel's vector pipe several times busier than its matrix pipe.
 // PACKED: a lane first marks which of its 16 scores beat its list's last entry (one compare each), then the wavefront runs the chain
 // max-over-lanes(marked) times, every lane taking ITS next marked score (lowest target index first: the order of the plain form) -- ~375
 // executions for the same candidates.  A score that no longer beats the list when its turn comes is dropped by the insertion's own test, so
-// the lists are those of the plain form, entry for entry.
-template <bool PACKED, bool FLAT, int K>
+// the lists are those of the plain form, entry for entry.  MEASURED (tools/probe/topk_ab.py, profiles/r06_topk_packed.txt): on random unit
+// descriptors the k = 16 search of 52 stacked 5000 x 5000 pairs goes 2.62 -> 1.93 ms (k = 8: 1.60 -> 1.52); inside the --RD --RM pipeline,
+// on the matcher's own features, 1443 -> 1495 us per launch at k = 16 and 1198 -> 1159 at k = 8: nothing.  Neither pipe is the bound there
+// (matrix pipe 27 - 36 % busy, vector pipe ~46 %): the kernel waits -- each wavefront's tile loads sit in front of its sixteen dependent
+// MFMAs, three wavefronts per SIMD.  Opt-in (ROREG_TOPK_PACKED=1).
+template <bool PACKED, int K>
 __global__ __launch_bounds__(256) void topk_dot_mfma_kernel(const float *__restrict__ A, int m, const float *__restrict__ B, int n,
                                                             const int *__restrict__ segA, const int *__restrict__ segB, int slices,
                                                             float *__restrict__ pv, int *__restrict__ pi) {
@@ -148,17 +136,7 @@ __global__ __launch_bounds__(256) void topk_dot_mfma_kernel(const float *__restr
                 marked |= (t < j1 && acc[r] > last) ? (1u << r) : 0u;
             }
             while (__builtin_amdgcn_ballot_w64(marked != 0)) {
-                if (FLAT) {
-                    const int r = marked ? __builtin_ctz(marked) : 0;
-                    const bool r0 = r & 1, r1 = r & 2, r2 = r & 4, r3 = r & 8;
-                    const float a0_ = r0 ? acc[1] : acc[0], a1_ = r0 ? acc[3] : acc[2], a2_ = r0 ? acc[5] : acc[4], a3_ = r0 ? acc[7] : acc[6];
-                    const float a4_ = r0 ? acc[9] : acc[8], a5_ = r0 ? acc[11] : acc[10], a6_ = r0 ? acc[13] : acc[12], a7_ = r0 ? acc[15] : acc[14];
-                    const float c0_ = r1 ? a1_ : a0_, c1_ = r1 ? a3_ : a2_, c2_ = r1 ? a5_ : a4_, c3_ = r1 ? a7_ : a6_;
-                    const float e0_ = r2 ? c1_ : c0_, e1_ = r2 ? c3_ : c2_;
-                    const float v = marked ? (r3 ? e1_ : e0_) : -__builtin_inff();
-                    marked &= marked - 1;
-                    topk_insert_flat<K>(bv, bi, v, b0 + t0 + 8 * (r >> 2) + 4 * h + (r & 3));
-                } else if (marked) {
+                if (marked) {
                     const int r = __builtin_ctz(marked);
                     marked &= marked - 1;
                     // acc[r] for a per-lane r: a select tree over the bits of r (no indexed register file access)
@@ -1046,7 +1024,8 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     ROREG_REQUIRE(segA || k <= n, "roreg_topk_dot: k > n");      // with segments the caller guarantees k <= every pair's target count
     // ROREG_TOPK_VALU=1: the vector-pipe kernel (one thread per source row); default: the dot products as float32 MFMA chains, bitwise the same lists
     static const bool valu = getenv("ROREG_TOPK_VALU") && atoi(getenv("ROREG_TOPK_VALU")) == 1;
-    static const int packed = getenv("ROREG_TOPK_PACKED") ? atoi(getenv("ROREG_TOPK_PACKED")) : 1;      // (0: one insertion chain per candidate; 2: packed with the branch-free insertion; for A/B)
+    // ROREG_TOPK_PACKED=1: the packed list maintenance (measured: 27 % faster at k = 16 on random descriptors, no gain inside the pipeline -- off by default)
+    static const bool packed = getenv("ROREG_TOPK_PACKED") && atoi(getenv("ROREG_TOPK_PACKED")) == 1;
     const int gx = valu ? (max_m + 255) / 256 : (max_m + 127) / 128;
     int slices = topk_slices((max_m + 255) / 256 * n_seg, max_n, segA != nullptr);
     if (!segA) {                                 // one pair: the slice width the kernel derives must cover n with this many slices
@@ -1062,9 +1041,8 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     roreg::ProfScope prof(roreg::PROF_TOPK, s);
 #define RM_TOPK(KK)                                                                                                                  \
     if (valu) hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
-    else if (packed == 2) hipLaunchKernelGGL((topk_dot_mfma_kernel<true, true, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
-    else if (packed) hipLaunchKernelGGL((topk_dot_mfma_kernel<true, false, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
-    else hipLaunchKernelGGL((topk_dot_mfma_kernel<false, false, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
+    else if (packed) hipLaunchKernelGGL((topk_dot_mfma_kernel<true, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
+    else hipLaunchKernelGGL((topk_dot_mfma_kernel<false, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
     hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
     if (k == 16) { RM_TOPK(16) } else if (k == 8) { RM_TOPK(8) } else { RM_TOPK(1) }
 #undef RM_TOPK

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r06; mkdir -p $OUT
-for split in 0 1; do
+for split in 0 1 2; do
   export ROREG_DES2R_SPLIT=$split
   rm -rf $OUT/pmc_des2r_$split
   i=0
@@ -13,5 +13,5 @@ for split in 0 1; do
   done
   python3 tools/pmc_kernel_means.py $OUT/pmc_des2r_$split > $OUT/des2r_pmc_$split.txt
   rm -rf $OUT/pmc_des2r_$split
-  grep -A26 "^des2r" $OUT/des2r_pmc_$split.txt | head -60
+  grep -A22 "^des2r" $OUT/des2r_pmc_$split.txt | head -24
 done
