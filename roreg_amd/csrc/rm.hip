@@ -166,6 +166,85 @@ __global__ __launch_bounds__(256) void topk_dot_mfma_kernel(const float *__restr
     }
 }
 
+// The same search with the target tile staged ONCE per workgroup (round 6).  The four wavefronts of a workgroup walk the same target tiles;
+// in the kernel above each of them fetches the whole 4 KB tile itself (a lane loads its target row's 128 bytes and uses half) and then waits
+// for it in front of its sixteen dependent MFMAs -- the counters have the matrix pipe 33-40 % and the vector pipe ~42 % busy, the rest is
+// waiting.  Here a lane loads 16 bytes of the NEXT tile while the current one is multiplied and inserted, the tile goes through LDS in the
+// operand order (element (row j, channel c) at ((c & 1) * 16 + (c >> 1)) * 32 + j: lane (j, h) reads channel 2 k + h at (h * 16 + k) * 32 + j,
+// consecutive lanes consecutive words), two buffers, one barrier per tile.  Scores, insertion order and lists are those of the kernel above.
+// In the --RD --RM pipeline: 1433 -> 1298 us per launch at k = 16, 1194 -> 1015 at k = 8 (profiles/r06_topk_packed.txt).  Also measured on top
+// of it: tile t + 1's MFMAs interleaved in program order with tile t's insertions (one candidate behind each MFMA) -- 1486 / 1305 us, slower
+// (156 registers, three wavefronts per SIMD, and the insertion's branches sit between the MFMAs): not kept.
+template <int K>
+__global__ __launch_bounds__(256) void topk_dot_mfma_lds_kernel(const float *__restrict__ A, int m, const float *__restrict__ B, int n,
+                                                                const int *__restrict__ segA, const int *__restrict__ segB, int slices,
+                                                                float *__restrict__ pv, int *__restrict__ pi) {
+    __shared__ float tile[2][RM_F * 32];
+    const int a0 = segA ? segA[blockIdx.z] : 0, mp = segA ? segA[blockIdx.z + 1] - a0 : m;
+    const int b0 = segA ? segB[blockIdx.z] : 0, np_ = segA ? segB[blockIdx.z + 1] - b0 : n;
+    if ((int)(blockIdx.x * 128) >= mp || np_ <= 0) return;                 // (uniform over the workgroup)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int i = blockIdx.x * 128 + w * 32 + j;
+    float sq[16];
+    {
+        const float4 *sr = reinterpret_cast<const float4 *>(A + (size_t)(a0 + min(i, mp - 1)) * RM_F);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 x4 = sr[q]; sq[2 * q] = h ? x4.y : x4.x; sq[2 * q + 1] = h ? x4.w : x4.z; }
+    }
+    float bv[K];
+    int bi[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { bv[q] = -__builtin_inff(); bi[q] = 0x7fffffff; }
+    const int slice = (np_ + slices - 1) / slices;
+    const int j0 = blockIdx.y * slice, j1 = min(j0 + slice, np_);
+    // this thread's share of a tile: row lr = tid / 8 (0 .. 31), channels 4 lc .. 4 lc + 3 (lc = tid % 8)
+    const int lr = threadIdx.x >> 3, lc = threadIdx.x & 7;
+    auto fetch = [&](int t0) -> float4 {
+        return *reinterpret_cast<const float4 *>(B + (size_t)(b0 + min(t0 + lr, np_ - 1)) * RM_F + 4 * lc);
+    };
+    auto stage = [&](float *buf, const float4 &x) {
+        // channels c = 4 lc + e: (c & 1) * 16 + (c >> 1) = (e & 1) * 16 + 2 lc + (e >> 1)
+        buf[(2 * lc) * 32 + lr] = x.x;
+        buf[(16 + 2 * lc) * 32 + lr] = x.y;
+        buf[(2 * lc + 1) * 32 + lr] = x.z;
+        buf[(16 + 2 * lc + 1) * 32 + lr] = x.w;
+    };
+    if (j0 < j1) stage(tile[0], fetch(j0));
+    __syncthreads();
+    int cur = 0;
+    for (int t0 = j0; t0 < j1; t0 += 32, cur ^= 1) {
+        const bool more = t0 + 32 < j1;
+        float4 nx = {0.f, 0.f, 0.f, 0.f};
+        if (more) nx = fetch(t0 + 32);                                     // in flight under this tile's MFMAs and list work
+        float tq[16];
+        const float *src = tile[cur] + h * 16 * 32 + j;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) tq[kk] = src[kk * 32];
+        f32x16_tk acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq[kk], sq[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (t < j1) topk_insert<K>(bv, bi, acc[r], b0 + t);
+        }
+        if (more) stage(tile[cur ^ 1], nx);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const float ov = __shfl_xor(bv[q], 32);
+        const int oi = __shfl_xor(bi[q], 32);
+        if (h == 0 && oi != 0x7fffffff) topk_insert_idx<K>(bv, bi, ov, oi);
+    }
+    if (h == 0 && i < mp) {
+        float *ov = pv + ((size_t)blockIdx.y * m + a0 + i) * K;
+        int *oi = pi + ((size_t)blockIdx.y * m + a0 + i) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) { ov[q] = bv[q]; oi[q] = bi[q]; }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ pv, const int *__restrict__ pi, int m, int slices,
                                                          int64_t *__restrict__ idx, float *__restrict__ val) {
@@ -1026,6 +1105,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     static const bool valu = getenv("ROREG_TOPK_VALU") && atoi(getenv("ROREG_TOPK_VALU")) == 1;
     // ROREG_TOPK_PACKED=1: the packed list maintenance (measured: 27 % faster at k = 16 on random descriptors, no gain inside the pipeline -- off by default)
     static const bool packed = getenv("ROREG_TOPK_PACKED") && atoi(getenv("ROREG_TOPK_PACKED")) == 1;
+    static const bool lds_tiles = !(getenv("ROREG_TOPK_LDS") && atoi(getenv("ROREG_TOPK_LDS")) == 0);       // (0: every wavefront fetches its own tiles, for A/B)
     const int gx = valu ? (max_m + 255) / 256 : (max_m + 127) / 128;
     int slices = topk_slices((max_m + 255) / 256 * n_seg, max_n, segA != nullptr);
     if (!segA) {                                 // one pair: the slice width the kernel derives must cover n with this many slices
@@ -1041,6 +1121,7 @@ extern "C" int roreg_topk_dot(const float *A, int m, const float *B, int n, int 
     roreg::ProfScope prof(roreg::PROF_TOPK, s);
 #define RM_TOPK(KK)                                                                                                                  \
     if (valu) hipLaunchKernelGGL(topk_dot_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
+    else if (lds_tiles) hipLaunchKernelGGL(topk_dot_mfma_lds_kernel<KK>, dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
     else if (packed) hipLaunchKernelGGL((topk_dot_mfma_kernel<true, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);  \
     else hipLaunchKernelGGL((topk_dot_mfma_kernel<false, KK>), dim3(gx, slices, n_seg), dim3(256), 0, s, A, m, B, n, segA, segB, slices, pv, pi);       \
     hipLaunchKernelGGL(topk_merge_kernel<KK>, dim3(gm), dim3(256), 0, s, pv, pi, m, slices, idx_out, val_out);
