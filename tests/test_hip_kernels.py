@@ -676,3 +676,30 @@ def test_gemm_pipelined_loop_is_bitwise_the_plain_loop():
         assert len(lines) == 4, lines                       # GF's big layer, its two thin ones (4-wave and 8-wave tiles), ET's Conv_init
         sums.append(lines)
     assert sums[0] == sums[1], sums
+
+
+def test_gathered_correlation_does_not_depend_on_the_tables_symmetry(group):
+    """The R_indicator / Des2R kernel lays its permuted row out by a symmetry it finds in the permutation table (runtime.hip bank_split_table:
+    an involution of the rotation group pairs lanes and LDS slots so that no two lanes of a half-wave share a bank).  Any table whose rows are
+    permutations is a valid input: one WITHOUT that symmetry gets the plain assignment and must give the same bit-exact correlations (only
+    the conflict rate depends on the assignment) -- here a table of random row permutations, checked against the oracle's literal order, both
+    table orientations; then the real tables are restored and give the golden's answer again."""
+    from roreg_amd import hip
+    hip.ensure_tables()
+    T = hip.tables()
+    rng = np.random.default_rng(12)
+    P_odd = np.stack([rng.permutation(60) for _ in range(60)]).astype(np.int32)
+    d1 = rng.standard_normal((137, 32, 60)).astype(np.float32); d2 = rng.standard_normal((137, 32, 60)).astype(np.float32)
+    nei, R = np.ascontiguousarray(T.Nei, np.int32), np.ascontiguousarray(T.R, np.float64)
+    try:
+        hip._check(hip.lib().roreg_set_group_tables(P_odd.ctypes.data, nei.ctypes.data, R.ctypes.data), 'roreg_set_group_tables')
+        idx, cor = hip.des2r(cu(d1), cu(d2), want_cor=True)
+        want = O.des2r_cor(d1, d2, P_odd)
+        assert np.array_equal(cor.cpu().numpy(), want) and np.array_equal(idx.cpu().numpy(), want.argmax(1))
+        got_t = hip.group_corr(cu(d1), cu(d2), perm_rows=None, bcast_rows=None, transpose=True).cpu().numpy()
+        assert np.array_equal(got_t, O.des2r_cor(d1, d2, np.ascontiguousarray(P_odd.T)))
+    finally:
+        P = np.ascontiguousarray(T.P, np.int32)
+        hip._check(hip.lib().roreg_set_group_tables(P.ctypes.data, nei.ctypes.data, R.ctypes.data), 'roreg_set_group_tables')
+    z = load_golden('des2r')
+    assert np.array_equal(hip.des2r(cu(z['d1']), cu(z['d2'])).cpu().numpy(), z['idx'])
