@@ -643,15 +643,24 @@ def test_knn_search_segmented_equals_per_cloud():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('env', [{'ROREG_MATCH_TILES': '1'}, {'ROREG_MATCH_BF16X3': '1'}, {'ROREG_GEMM_PIPE': '0'}],
-                         ids=['matcher per-tile form', 'matcher 3 x bf16 split', 'GEMM loop without fragment pipelining'])
+@pytest.mark.parametrize('env', [{'ROREG_MATCH_TILES': '1'}, {'ROREG_MATCH_BF16X3': '1'}, {'ROREG_GEMM_PIPE': '0'},
+                                 {'ROREG_DES2R_SPLIT': '0'}, {'ROREG_DES2R_SPLIT': '1'}, {'ROREG_DES2R_NCH': '8'},
+                                 {'ROREG_TOPK_LDS': '0'}, {'ROREG_TOPK_LDS': '0', 'ROREG_TOPK_PACKED': '1'}],
+                         ids=['matcher per-tile form', 'matcher 3 x bf16 split', 'GEMM loop without fragment pipelining',
+                              'gathered correlation: round-2 kernel', 'gathered correlation: bank-split + packed math', 'gathered correlation: 8 channels per pass',
+                              'top-k: a tile per wavefront', 'top-k: packed list maintenance'])
 def test_alternative_kernel_forms_stay_correct(env):
     """The kernel variants kept behind environment switches (the per-tile matcher passes, the matcher's 3 x bf16 operand split, the
-    irrep GEMM's plain loop) are chosen once per process, so each runs the relevant exactness tests in a process of its own."""
+    irrep GEMM's plain loop; round 6: the earlier forms of the gathered correlation and of the top-k search) are chosen once per process,
+    so each runs the relevant exactness tests in a process of its own."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if 'ROREG_GEMM_PIPE' in env:
         args = ['tests/test_hip_fourier.py', '-k', 'gemm or extractor or batch_invariant']
+    elif 'ROREG_DES2R_SPLIT' in env or 'ROREG_DES2R_NCH' in env:
+        args = ['tests/test_hip_kernels.py', 'tests/test_hip_rm.py', '-k', 'des2r or group_corr or symmetry']
+    elif 'ROREG_TOPK_LDS' in env:
+        args = ['tests/test_hip_rm.py', '-k', 'topk or match_ot or stacked']
     else:
         args = ['tests/test_hip_kernels.py', '-k', 'mutual or matcher']
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'] + args + ['--deselect',
