@@ -76,7 +76,8 @@ __device__ __forceinline__ void des2r_body(const float *__restrict__ feats1, siz
 //     half-wave read 30 different banks;
 //   * lane l owns the group element lane_elem[l] (the two elements of a nu-orbit in different half-waves);
 //   * two channels per vector instruction: s_{2k}, s_{2k+1} advance together through v_pk_mul_f32 / v_pk_add_f32 (IEEE per element: the
-//     same roundings as the scalar form), their broadcast factors as an SGPR pair.
+//     same roundings as the scalar form), their broadcast factors as an SGPR pair -- which bought nothing: a packed float32 instruction takes
+//     two issue slots on this part.  Kept for A/B (ROREG_DES2R_SPLIT=1); the default is the third form below.
 typedef float des2r_f2 __attribute__((ext_vector_type(2)));
 constexpr int DES2R_SPITCH = 64;
 
@@ -161,7 +162,6 @@ __device__ __forceinline__ float des2r_mul_row_bcast(float d1, float d2) {      
     return p;
 }
 
-                                    // channels per pass (16: the scheduler's hoisted LDS loads spill at 128 registers)
 
 template <int G0, int DES2R_NCH>
 __device__ __forceinline__ void des2r_dpp_steps(const float *__restrict__ base, const uint8_t *__restrict__ qrow, const float (&d2r)[4][DES2R_NCH],
